@@ -1,0 +1,260 @@
+#!/usr/bin/env python3
+"""bench.py -- HybVIO hot path on MI355X: VIO frames/s at 752x480 stereo, 200 KLT features.
+
+A "step" advances B independent VIO sequences (sessions) that live on one GPU by one stereo frame:
+    2B pyramid builds (left+right)  ->  B x 200 temporal LK tracks (prev-left -> cur-left)
+                                    ->  B x 200 stereo LK tracks   (cur-left  -> cur-right)
+    [workload c3 adds, per sequence: 10 EKF predicts + 20 chi2 gates + 5 visual updates + 1 augmentation]
+Frames are synthetic (hybvio_amd/synth.py), already resident in HBM when the timed region starts.
+B = 1 is the latency mode of a single sequence; the default B fills the chip (throughput mode) --
+both are reported. N GPUs run N independent replicas (a VIO sequence does not shard; no RCCL on
+the data path); the only collective is the timing barrier/max.
+
+Prints ONE JSON line (rank 0). See DESIGN.md section "Measurement" for the byte accounting.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+W, H, NPTS, LEVELS = 752, 480, 200, 4
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy ceiling)
+HBM_COPY_CEILING_GBS = 6290.0
+N_CYCLE = 8                    # frames of the closed camera path
+
+
+def level_sizes(w, h, levels=LEVELS, win=31):
+    out = []
+    for _ in range(levels):
+        out.append((w, h))
+        w, h = (w + 1) // 2, (h + 1) // 2
+        if w <= win or h <= win:
+            break
+    return out
+
+
+def algorithmic_bytes(w=W, h=H, npts=NPTS):
+    """per image / per LK call / per stereo frame, plus the per-kernel split."""
+    ls = level_sizes(w, h)
+    px = [a * b for a, b in ls]
+    pyr_image = px[0] + sum(px[1:]) + 4 * sum(px)                 # read L0 + write gray L1.. + write grads
+    pyr_l0 = px[0] + 4 * px[0] + (px[1] if len(px) > 1 else 0)    # the level-0 launch's share
+    klt_point_level = 32 * 32 * 1 + 32 * 32 * 4 + 32 * 32 * 1     # I + dI + J windows, first touch
+    klt_call = npts * len(ls) * klt_point_level
+    return dict(pyr_image=pyr_image, pyr_l0=pyr_l0, pyr_ln=pyr_image - pyr_l0, klt_call=klt_call,
+                stereo_frame=2 * pyr_image + 2 * klt_call)
+
+
+class TrackerBench:
+    """B sequences x (2 pyramid builds + 2 LK calls) per step, everything device resident."""
+
+    def __init__(self, B, device, seed=0):
+        import torch
+        from hybvio_amd import capi, synth
+        self.torch, self.B = torch, B
+        dev = torch.device("cuda", device)
+        self.ctx = capi.Context(width=W, height=H, levels=LEVELS, max_tracks=NPTS, pool_size=3 * B,
+                                max_pairs=B, device=device)
+        self.ctx.set_stream(torch.cuda.current_stream(dev).cuda_stream)
+        # one closed camera path rendered on a larger canvas; every sequence sees its own crop
+        M = 32
+        left, right, _ = synth.stereo_sequence(1000 + seed, W + 2 * M, H + 2 * M, N_CYCLE)
+        canvas = torch.from_numpy(np.stack([left, right], 1)).to(dev)          # [K, 2, H+2M, W+2M]
+        self.frames = torch.empty((N_CYCLE, 2, B, H, W), dtype=torch.uint8, device=dev)
+        rng = np.random.default_rng(seed)
+        offs = rng.integers(0, 2 * M + 1, (B, 2))
+        for s in range(B):
+            ox, oy = int(offs[s, 0]), int(offs[s, 1])
+            self.frames[:, :, s] = canvas[:, :, oy:oy + H, ox:ox + W]
+        del canvas
+        slots = np.array([self.ctx.acquire() for _ in range(3 * B)], np.int32).reshape(3, B)
+        i32 = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+        self.L = [i32(slots[0]), i32(slots[1])]
+        self.R = i32(slots[2])
+        self.build_slots = [i32(np.concatenate([slots[p], slots[2]])) for p in (0, 1)]
+        grid = synth.grid_points(W, H, NPTS, margin=40, seed=3)
+        self.grid = torch.from_numpy(np.tile(grid, (B, 1))).to(dev)            # [B*N, 2]
+        self.pts_left = self.grid.clone()
+        self.disp = torch.full((B * NPTS,), 20.0, dtype=torch.float32, device=dev)
+        self.cur_left = torch.empty_like(self.grid)
+        self.cur_right = torch.empty_like(self.grid)
+        self.st1 = torch.zeros(B * NPTS, dtype=torch.uint8, device=dev)
+        self.st2 = torch.zeros_like(self.st1)
+        self.err = torch.zeros(B * NPTS, dtype=torch.float32, device=dev)
+        self.k = 0
+        self.tracked = 0.0
+        self._build(0)                                                          # frame 0 primes "prev"
+        self.k = 1
+
+    def _build(self, k):
+        f = self.frames[k % N_CYCLE]
+        self.ctx.build_batch_dev(2 * self.B, self.build_slots[k % 2].data_ptr(), f.data_ptr(), W * H, W)
+
+    def step(self):
+        t, k, B = self.torch, self.k, self.B
+        self._build(k)
+        prev, cur = self.L[(k - 1) % 2], self.L[k % 2]
+        self.cur_left.copy_(self.pts_left)                                      # zero-flow prediction
+        self.ctx.klt_track_batch_dev(B, prev.data_ptr(), cur.data_ptr(), NPTS, self.pts_left.data_ptr(),
+                                     self.cur_left.data_ptr(), self.st1.data_ptr(), self.err.data_ptr(), True)
+        self.cur_right.copy_(self.cur_left)
+        self.cur_right[:, 0] -= self.disp                                       # predicted disparity
+        self.ctx.klt_track_batch_dev(B, cur.data_ptr(), self.R.data_ptr(), NPTS, self.cur_left.data_ptr(),
+                                     self.cur_right.data_ptr(), self.st2.data_ptr(), self.err.data_ptr(), True)
+        # stand-in for the host tracker's bookkeeping (tracker.cpp:441-478,604-670): merge stereo
+        # failures, drop out-of-image tracks, re-seed lost tracks so N stays constant
+        x, y = self.cur_left[:, 0], self.cur_left[:, 1]
+        ok = (self.st1 > 0) & (self.st2 > 0) & (x >= 16) & (x < W - 16) & (y >= 16) & (y < H - 16)
+        self.tracked = ok
+        self.pts_left = t.where(ok[:, None], self.cur_left, self.grid)
+        self.disp = t.where(ok, self.cur_left[:, 0] - self.cur_right[:, 0], t.full_like(self.disp, 20.0))
+        self.k += 1
+
+    def tracked_fraction(self):
+        return float(self.tracked.float().mean().item())
+
+
+def cpu_baseline(budget_s=12.0):
+    """The CPU oracle (a scalar restatement of the OpenCV path HybVIO calls; NOT SIMD OpenCV) timed
+    on this box on the same per-frame work: 2 pyramid builds + 2 LK calls x 200 points."""
+    from hybvio_amd import synth
+    from oracle import orc
+    left, right, _ = synth.stereo_sequence(1000, W, H, 3)
+    pts = synth.grid_points(W, H, NPTS, margin=40, seed=3)
+    prev = orc.Pyramid(left[0])
+    frames, t0 = 0, time.perf_counter()
+    while True:
+        k = 1 + frames % 2
+        cl, cr = orc.Pyramid(left[k]), orc.Pyramid(right[k])
+        xy, st, _ = orc.klt_track(prev, cl, pts, next_pts=pts)
+        guess = xy.copy()
+        guess[:, 0] -= 20.0
+        orc.klt_track(cl, cr, xy, next_pts=guess)
+        prev = cl
+        frames += 1
+        el = time.perf_counter() - t0
+        if el > budget_s:
+            break
+    return dict(value=frames / el, unit="frames/s", cores=1, kind="port",
+                sample=f"{frames} stereo frames 752x480 x 200 pts, oracle/pyrlk_oracle.c -O2, 1 thread, {el:.1f} s")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--sequences", type=int, default=256, help="independent VIO sequences per GPU (B)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-latency-mode", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    from hybvio_amd import capi
+    B = args.sequences
+    tb = TrackerBench(B, local_rank, seed=rank)
+    for _ in range(args.warmup):
+        tb.step()
+    tb.ctx.profile_enable(True)
+    tb.ctx.profile_reset()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        tb.step()
+    barrier()
+    el = time.perf_counter() - t0
+    prof = {name: tb.ctx.profile_read(kid) for name, kid in
+            (("pyr_l0", capi.K_PYR_L0), ("pyr_ln", capi.K_PYR_LN), ("klt", capi.K_KLT))}
+    tb.ctx.profile_enable(False)
+    tracked = tb.tracked_fraction()
+    if world > 1:
+        tt = torch.tensor([el], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        el = float(tt.item())
+
+    out = None
+    if rank == 0:
+        ab = algorithmic_bytes()
+        frames = world * B * args.steps
+        ms_step = el / args.steps * 1e3
+        # per-kernel achieved algorithmic GB/s from HIP-event durations on the context stream
+        per_launch_bytes = dict(pyr_l0=2 * B * ab["pyr_l0"], pyr_ln=2 * B * ab["pyr_ln"] / 3.0, klt=B * ab["klt_call"])
+        kern = {}
+        for name, (ms, n) in prof.items():
+            if n:
+                avg = ms / n
+                kern[name] = dict(avg_ms=avg, launches=n, total_ms=ms,
+                                  achieved_GBs=per_launch_bytes[name] / (avg * 1e-3) / 1e9)
+        stage_ms = sum(v["total_ms"] for v in kern.values()) / args.steps
+        stage_gbs = B * ab["stereo_frame"] / (stage_ms * 1e-3) / 1e9
+        dom = max(kern, key=lambda k: kern[k]["total_ms"])
+        out = {
+            "metric": "VIO frames/sec at 752x480 stereo, 200 KLT features; pyramid+KLT HBM GB/s",
+            "value": frames / el, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u8/int16 pixels, int32/int64 sums, f32 solve", "data": "synthetic",
+            "config": {"workload": "C2: 752x480 stereo, 200 pts, HIP pyramid+KLT tracker (2 builds + 2 LK calls per "
+                                   "frame), EKF not in the HIP path", "sequences_per_gpu": B,
+                       "frames_per_step": world * B, "parallelism": f"replicas x{world} (no collective)"},
+            "roofline": {"bound": "hbm", "kernel": dom, "achieved": kern[dom]["achieved_GBs"], "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": kern[dom]["achieved_GBs"] / HBM_PEAK_GBS, "traffic": None},
+            "kernels": kern,
+            "stage_pyramid_klt": {"ms_per_step": stage_ms, "achieved_GBs": stage_gbs,
+                                  "frac_of_8TBs": stage_gbs / HBM_PEAK_GBS,
+                                  "frac_of_measured_copy_ceiling": stage_gbs / HBM_COPY_CEILING_GBS,
+                                  "algorithmic_bytes_per_stereo_frame": ab["stereo_frame"]},
+            "tracked_fraction": tracked,
+        }
+    del tb
+
+    if rank == 0 and not args.no_latency_mode:
+        # latency mode: ONE sequence, one frame at a time (what a single `main` process sees)
+        t1 = TrackerBench(1, local_rank, seed=12345)
+        for _ in range(5):
+            t1.step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        n_lat = 200
+        for _ in range(n_lat):
+            t1.step()
+        torch.cuda.synchronize()
+        lat = (time.perf_counter() - t0) / n_lat
+        out["latency_mode"] = {"sequences": 1, "ms_per_frame": lat * 1e3, "frames_per_s": 1.0 / lat,
+                               "tracked_fraction": t1.tracked_fraction()}
+        del t1
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline()
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,41 @@
+"""In-tree build of libhybvio_hip.so (hipcc cross-compiles gfx950 without a GPU)."""
+from __future__ import annotations
+
+import glob
+import os
+import subprocess
+
+PKG = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(PKG, "csrc")
+LIBDIR = os.path.join(PKG, "lib")
+LIB = os.path.join(LIBDIR, "libhybvio_hip.so")
+
+# -ffp-contract=off: the LK float sequence must match the oracle bit for bit (no FMA fusion).
+HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", "-Wall"]
+
+
+def sources() -> list[str]:
+    return sorted(glob.glob(os.path.join(CSRC, "*.hip")))
+
+
+def _stale() -> bool:
+    if not os.path.exists(LIB):
+        return True
+    deps = sources() + glob.glob(os.path.join(CSRC, "*.hpp")) + [os.path.join(PKG, "..", "include", "hybvio_hip.h")]
+    return any(os.path.getmtime(d) > os.path.getmtime(LIB) for d in deps)
+
+
+def build_hip(force: bool = False, verbose: bool = False) -> str:
+    if not force and not _stale():
+        return LIB
+    os.makedirs(LIBDIR, exist_ok=True)
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    cmd = [hipcc] + HIPCC_FLAGS + ["-o", LIB] + sources()
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd, cwd=CSRC)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build_hip(force=True, verbose=True))

@@ -1,0 +1,209 @@
+"""ctypes binding of include/hybvio_hip.h (libhybvio_hip.so).
+
+Python is only the test / bench harness language here: the product is the C-ABI library and the
+C++ adapters under hybvio_amd/host/. There is no CPU fallback: if the library cannot be built or
+loaded, or no HIP device is present, calls raise.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import build as _build
+
+u8p = C.POINTER(C.c_uint8)
+i16p = C.POINTER(C.c_int16)
+i32p = C.POINTER(C.c_int32)
+f32p = C.POINTER(C.c_float)
+f64p = C.POINTER(C.c_double)
+
+HV_MAX_LEVELS = 6
+K_PYR_L0, K_PYR_LN, K_KLT, K_EKF_PREDICT, K_EKF_UPDATE, K_EKF_AUGMENT = range(6)
+
+# tracker::Feature::Status (src/tracker/track.hpp:9-21)
+ST_TRACKED, ST_NEW, ST_FAILED_FLOW, ST_RANSAC_OUTLIER, ST_FLOW_OUT_OF_RANGE = 0, 1, 2, 3, 4
+
+
+class Params(C.Structure):
+    _fields_ = [("device", C.c_int), ("width", C.c_int), ("height", C.c_int), ("levels", C.c_int),
+                ("win", C.c_int), ("max_iter", C.c_int), ("eps", C.c_double), ("min_eig", C.c_double),
+                ("max_tracks", C.c_int), ("pool_size", C.c_int), ("max_pairs", C.c_int)]
+
+
+class HvError(RuntimeError):
+    pass
+
+
+_LIB = None
+
+# name -> (restype, argtypes); also the list of symbols tests check against the header.
+PROTOTYPES = {
+    "hv_default_params": (None, [C.POINTER(Params)]),
+    "hv_abi_version": (C.c_int, []),
+    "hv_status_string": (C.c_char_p, [C.c_int]),
+    "hv_create": (C.c_int, [C.POINTER(Params), C.POINTER(C.c_void_p)]),
+    "hv_destroy": (None, [C.c_void_p]),
+    "hv_last_error": (C.c_char_p, [C.c_void_p]),
+    "hv_set_stream": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "hv_synchronize": (C.c_int, [C.c_void_p]),
+    "hv_pyramid_acquire": (C.c_int, [C.c_void_p, C.POINTER(C.c_int)]),
+    "hv_pyramid_release": (C.c_int, [C.c_void_p, C.c_int]),
+    "hv_pyramid_level_size": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "hv_pyramid_build": (C.c_int, [C.c_void_p, C.c_int, u8p, C.c_int]),
+    "hv_pyramid_build_batch_dev": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_longlong, C.c_int]),
+    "hv_pyramid_download": (C.c_int, [C.c_void_p, C.c_int, C.c_int, u8p, i16p]),
+    "hv_klt_track": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, f32p, f32p, u8p, f32p, C.c_int, C.c_int]),
+    "hv_optical_flow_compute": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, f32p, f32p, i32p, C.c_int, C.c_int]),
+    "hv_klt_track_batch_dev": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
+                                         C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int]),
+    "hv_profile_enable": (C.c_int, [C.c_void_p, C.c_int]),
+    "hv_profile_reset": (C.c_int, [C.c_void_p]),
+    "hv_profile_read": (C.c_int, [C.c_void_p, C.c_int, f64p, C.POINTER(C.c_longlong)]),
+}
+
+
+def lib():
+    """Load (building if needed) libhybvio_hip.so. Raises if it cannot be produced."""
+    global _LIB
+    if _LIB is None:
+        path = _build.build_hip()
+        if not os.path.exists(path):
+            raise HvError(f"{path} missing: the HIP extension is required, there is no fallback")
+        L = C.CDLL(path)
+        for name, (res, args) in PROTOTYPES.items():
+            fn = getattr(L, name)
+            fn.restype = res
+            fn.argtypes = args
+        _LIB = L
+    return _LIB
+
+
+def _p(a, t):
+    return a.ctypes.data_as(t) if a is not None else None
+
+
+class Context:
+    """One hv_ctx: a HIP stream, a pool of pyramid slots and the tracker parameters."""
+
+    def __init__(self, width=752, height=480, levels=4, win=31, max_iter=20, eps=0.03, min_eig=1e-3,
+                 max_tracks=200, pool_size=16, max_pairs=1, device=0):
+        L = lib()
+        p = Params()
+        L.hv_default_params(C.byref(p))
+        p.device, p.width, p.height, p.levels, p.win = device, width, height, levels, win
+        p.max_iter, p.eps, p.min_eig, p.max_tracks = max_iter, eps, min_eig, max_tracks
+        p.pool_size, p.max_pairs = pool_size, max_pairs
+        self.params = p
+        self._h = C.c_void_p()
+        rc = L.hv_create(C.byref(p), C.byref(self._h))
+        if rc != 0:
+            self._h = None
+            raise HvError(f"hv_create: {L.hv_status_string(rc).decode()}")
+        self.levels = 0
+        self.level_sizes = []
+        w, h = C.c_int(), C.c_int()
+        while self.levels < levels and L.hv_pyramid_level_size(self._h, self.levels, C.byref(w), C.byref(h)) == 0:
+            self.level_sizes.append((w.value, h.value))
+            self.levels += 1
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().hv_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        self.close()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def _chk(self, rc, what):
+        if rc != 0:
+            L = lib()
+            msg = L.hv_status_string(rc).decode()
+            if rc == -4:
+                msg += ": " + L.hv_last_error(self._h).decode()
+            raise HvError(f"{what}: {msg}")
+
+    # -- plumbing --
+    def set_stream(self, stream_ptr: int):
+        self._chk(lib().hv_set_stream(self._h, C.c_void_p(stream_ptr)), "hv_set_stream")
+
+    def synchronize(self):
+        self._chk(lib().hv_synchronize(self._h), "hv_synchronize")
+
+    # -- pyramid --
+    def acquire(self) -> int:
+        s = C.c_int()
+        self._chk(lib().hv_pyramid_acquire(self._h, C.byref(s)), "hv_pyramid_acquire")
+        return s.value
+
+    def release(self, slot: int):
+        self._chk(lib().hv_pyramid_release(self._h, slot), "hv_pyramid_release")
+
+    def build(self, slot: int, gray: np.ndarray):
+        gray = np.ascontiguousarray(gray, np.uint8)
+        assert gray.shape == (self.params.height, self.params.width), gray.shape
+        self._chk(lib().hv_pyramid_build(self._h, slot, _p(gray, u8p), gray.strides[0]), "hv_pyramid_build")
+        self.synchronize()   # the numpy temporary may die after return
+
+    def build_batch_dev(self, n: int, slots_dev: int, gray_dev: int, image_stride: int, row_stride: int):
+        self._chk(lib().hv_pyramid_build_batch_dev(self._h, n, C.c_void_p(slots_dev), C.c_void_p(gray_dev),
+                                                   image_stride, row_stride), "hv_pyramid_build_batch_dev")
+
+    def download(self, slot: int, level: int):
+        w, h = self.level_sizes[level]
+        g = np.empty((h, w), np.uint8)
+        d = np.empty((h, w, 2), np.int16)
+        self._chk(lib().hv_pyramid_download(self._h, slot, level, _p(g, u8p), _p(d, i16p)), "hv_pyramid_download")
+        return g, d
+
+    # -- Lucas-Kanade --
+    def klt_track(self, prev_slot, next_slot, prev_xy, next_xy=None, max_iter_override=-1):
+        prev_xy = np.ascontiguousarray(prev_xy, np.float32).reshape(-1, 2)
+        n = prev_xy.shape[0]
+        use_init = next_xy is not None
+        out = (np.ascontiguousarray(next_xy, np.float32).reshape(-1, 2).copy() if use_init
+               else np.zeros_like(prev_xy))
+        st = np.zeros(n, np.uint8)
+        err = np.zeros(n, np.float32)
+        self._chk(lib().hv_klt_track(self._h, prev_slot, next_slot, n, _p(prev_xy, f32p), _p(out, f32p),
+                                     _p(st, u8p), _p(err, f32p), int(use_init), max_iter_override), "hv_klt_track")
+        return out, st, err
+
+    def optical_flow_compute(self, prev_slot, cur_slot, prev_corners, corners=None, override_max_iterations=-1):
+        prev_corners = np.ascontiguousarray(prev_corners, np.float32).reshape(-1, 2)
+        n = prev_corners.shape[0]
+        use_init = corners is not None
+        out = (np.ascontiguousarray(corners, np.float32).reshape(-1, 2).copy() if use_init
+               else np.zeros_like(prev_corners))
+        st = np.full(n, ST_FAILED_FLOW, np.int32)
+        self._chk(lib().hv_optical_flow_compute(self._h, prev_slot, cur_slot, n, _p(prev_corners, f32p),
+                                                _p(out, f32p), _p(st, i32p), int(use_init),
+                                                override_max_iterations), "hv_optical_flow_compute")
+        return out, st
+
+    def klt_track_batch_dev(self, n_pairs, prev_slots_dev, next_slots_dev, pts_per_pair, prev_xy_dev,
+                            next_xy_dev, status_dev, err_dev, use_initial_flow=True, max_iter_override=-1):
+        self._chk(lib().hv_klt_track_batch_dev(self._h, n_pairs, C.c_void_p(prev_slots_dev),
+                                               C.c_void_p(next_slots_dev), pts_per_pair, C.c_void_p(prev_xy_dev),
+                                               C.c_void_p(next_xy_dev), C.c_void_p(status_dev),
+                                               C.c_void_p(err_dev), int(use_initial_flow), max_iter_override),
+                  "hv_klt_track_batch_dev")
+
+    # -- timers --
+    def profile_enable(self, on=True):
+        self._chk(lib().hv_profile_enable(self._h, int(on)), "hv_profile_enable")
+
+    def profile_reset(self):
+        self._chk(lib().hv_profile_reset(self._h), "hv_profile_reset")
+
+    def profile_read(self, kernel_id: int):
+        ms, n = C.c_double(), C.c_longlong()
+        self._chk(lib().hv_profile_read(self._h, kernel_id, C.byref(ms), C.byref(n)), "hv_profile_read")
+        return ms.value, n.value

@@ -1,0 +1,393 @@
+// extern "C" entry points of libhybvio_hip.so (see include/hybvio_hip.h): context, pyramid
+// pool, host-pointer convenience paths, per-kernel timers.
+#include <stdio.h>
+#include <string.h>
+
+#include <new>
+
+#include "hv_internal.hpp"
+
+namespace hv {
+
+int hip_fail(Ctx *c, hipError_t e, const char *what)
+{
+    if (c) {
+        char buf[512];
+        snprintf(buf, sizeof buf, "%s -> %s", what, hipGetErrorString(e));
+        c->last_error = buf;
+    }
+    return HV_ERR_HIP;
+}
+
+ScopedKernelTime::ScopedKernelTime(Ctx *c_, int id_) : c(c_), id(id_)
+{
+    if (!c->profiling) return;
+    KernelTimer &t = c->timers[id];
+    if (!t.free_list.empty()) { a = t.free_list.back().first; b = t.free_list.back().second; t.free_list.pop_back(); }
+    else { (void)hipEventCreate(&a); (void)hipEventCreate(&b); }
+    (void)hipEventRecord(a, c->stream);
+}
+
+ScopedKernelTime::~ScopedKernelTime()
+{
+    if (!a) return;
+    (void)hipEventRecord(b, c->stream);
+    c->timers[id].pending.emplace_back(a, b);
+}
+
+namespace {
+
+inline int align_up(int v, int a) { return (v + a - 1) / a * a; }
+inline long long align_up_ll(long long v, long long a) { return (v + a - 1) / a * a; }
+
+// A handful of ints travel to the device as kernel arguments (captured at launch, so the host
+// copy may be reused immediately and no pinned staging is needed).
+struct IntPack { int v[4]; };
+__global__ void set_ints_kernel(int *dst, IntPack p, int n)
+{
+    if ((int)threadIdx.x < n) dst[threadIdx.x] = p.v[threadIdx.x];
+}
+
+int compute_layout(const hv_params &p, PyrLayout &L)
+{
+    L = PyrLayout{};
+    L.win = p.win;
+    int w = p.width, h = p.height, n = 0;
+    // cv::buildOpticalFlowPyramid: a further level is built only while it stays larger than the window
+    for (int l = 0; l < p.levels; ++l) {
+        L.w[l] = w; L.h[l] = h; n = l + 1;
+        w = (w + 1) / 2; h = (h + 1) / 2;
+        if (w <= p.win || h <= p.win) break;
+    }
+    L.levels = n;
+    long long off = 0;
+    for (int l = 0; l < n; ++l) {
+        L.gstride[l] = align_up(L.w[l], 16);
+        L.goff[l] = off;
+        off = align_up_ll(off + (long long)L.gstride[l] * L.h[l], 256);
+    }
+    for (int l = 0; l < n; ++l) {
+        L.dstride[l] = align_up(L.w[l], 4);
+        L.doff[l] = off;
+        off = align_up_ll(off + (long long)L.dstride[l] * 4 * L.h[l], 256);
+    }
+    L.slot_bytes = off;
+    return HV_OK;
+}
+
+int ensure_point_staging(Ctx *c, int n)
+{
+    if (n <= c->stage_points) return HV_OK;
+    int cap = c->stage_points ? c->stage_points : 256;
+    while (cap < n) cap *= 2;
+    if (c->d_prev_xy) { (void)hipFree(c->d_prev_xy); (void)hipFree(c->d_next_xy); (void)hipFree(c->d_err); (void)hipFree(c->d_status); }
+    c->d_prev_xy = c->d_next_xy = c->d_err = nullptr; c->d_status = nullptr; c->stage_points = 0;
+    HV_HIP(c, hipMalloc(&c->d_prev_xy, sizeof(float) * 2 * cap));
+    HV_HIP(c, hipMalloc(&c->d_next_xy, sizeof(float) * 2 * cap));
+    HV_HIP(c, hipMalloc(&c->d_err, sizeof(float) * cap));
+    HV_HIP(c, hipMalloc(&c->d_status, cap));
+    c->stage_points = cap;
+    return HV_OK;
+}
+
+bool slot_ok(Ctx *c, int s) { return s >= 0 && s < c->p.pool_size && c->slot_used[s]; }
+
+}  // namespace
+}  // namespace hv
+
+using hv::Ctx;
+
+extern "C" {
+
+struct hv_ctx { Ctx c; };
+
+void hv_default_params(hv_params *p)
+{
+    if (!p) return;
+    memset(p, 0, sizeof *p);
+    p->device = 0; p->width = 752; p->height = 480;
+    p->levels = 4; p->win = 31; p->max_iter = 20; p->eps = 0.03; p->min_eig = 1e-3;
+    p->max_tracks = 200; p->pool_size = 16; p->max_pairs = 1;
+}
+
+int hv_abi_version(void) { return HV_ABI_VERSION; }
+
+const char *hv_status_string(int s)
+{
+    switch (s) {
+        case HV_OK: return "ok";
+        case HV_ERR_INVALID: return "invalid argument";
+        case HV_ERR_UNSUPPORTED: return "unsupported parameter";
+        case HV_ERR_NO_DEVICE: return "no HIP device";
+        case HV_ERR_HIP: return "HIP runtime error";
+        case HV_ERR_POOL: return "pyramid pool exhausted or bad slot";
+        case HV_ERR_NOMEM: return "out of memory";
+        default: return "unknown status";
+    }
+}
+
+int hv_create(const hv_params *params, hv_ctx **out)
+{
+    if (!params || !out) return HV_ERR_INVALID;
+    *out = nullptr;
+    const hv_params &p = *params;
+    if (p.width < 1 || p.height < 1 || p.levels < 1 || p.levels > HV_MAX_LEVELS || p.pool_size < 1 ||
+        p.max_iter < 0 || p.max_tracks < 1)
+        return HV_ERR_INVALID;
+    if (p.win != 31) return HV_ERR_UNSUPPORTED;   // lane layout of the LK kernel is built for 31x31
+    if (p.width <= p.win || p.height <= p.win) return HV_ERR_UNSUPPORTED;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || p.device < 0 || p.device >= ndev)
+        return HV_ERR_NO_DEVICE;
+    hv_ctx *h = new (std::nothrow) hv_ctx();
+    if (!h) return HV_ERR_NOMEM;
+    Ctx *c = &h->c;
+    c->p = p;
+    if (c->p.max_pairs < 1) c->p.max_pairs = 1;
+    hv::compute_layout(p, c->L);
+    int rc = HV_OK;
+    do {
+        if (hipSetDevice(p.device) != hipSuccess) { rc = HV_ERR_NO_DEVICE; break; }
+        if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { rc = HV_ERR_HIP; break; }
+        c->own_stream = true;
+        const size_t slab_bytes = (size_t)c->L.slot_bytes * p.pool_size;
+        if (hipMalloc(&c->slab, slab_bytes) != hipSuccess) { rc = HV_ERR_NOMEM; break; }
+        if (hipMalloc(&c->d_l0_ptr, sizeof(void *) * p.pool_size) != hipSuccess) { rc = HV_ERR_NOMEM; break; }
+        if (hipMalloc(&c->d_l0_stride, sizeof(int) * p.pool_size) != hipSuccess) { rc = HV_ERR_NOMEM; break; }
+        if (hipMalloc(&c->d_slots, sizeof(int) * 4) != hipSuccess) { rc = HV_ERR_NOMEM; break; }
+        if (hipMemsetAsync(c->d_l0_ptr, 0, sizeof(void *) * p.pool_size, c->stream) != hipSuccess) { rc = HV_ERR_HIP; break; }
+        c->slot_used.assign(p.pool_size, 0);
+        for (int s = p.pool_size - 1; s >= 0; --s) c->free_slots.push_back(s);
+        rc = hv::ensure_point_staging(c, p.max_tracks);
+    } while (0);
+    if (rc != HV_OK) { hv_destroy(h); return rc; }
+    *out = h;
+    return HV_OK;
+}
+
+void hv_destroy(hv_ctx *h)
+{
+    if (!h) return;
+    Ctx *c = &h->c;
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    for (auto &t : c->timers) {
+        for (auto &e : t.pending) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
+        for (auto &e : t.free_list) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
+    }
+    if (c->slab) (void)hipFree(c->slab);
+    if (c->d_l0_ptr) (void)hipFree(c->d_l0_ptr);
+    if (c->d_l0_stride) (void)hipFree(c->d_l0_stride);
+    if (c->d_slots) (void)hipFree(c->d_slots);
+    if (c->d_prev_xy) (void)hipFree(c->d_prev_xy);
+    if (c->d_next_xy) (void)hipFree(c->d_next_xy);
+    if (c->d_err) (void)hipFree(c->d_err);
+    if (c->d_status) (void)hipFree(c->d_status);
+    if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
+    delete h;
+}
+
+const char *hv_last_error(hv_ctx *h) { return h ? h->c.last_error.c_str() : "null context"; }
+
+int hv_set_stream(hv_ctx *h, void *hip_stream)
+{
+    if (!h) return HV_ERR_INVALID;
+    Ctx *c = &h->c;
+    HV_HIP(c, hipStreamSynchronize(c->stream));
+    if (c->own_stream) { (void)hipStreamDestroy(c->stream); c->own_stream = false; }
+    c->stream = reinterpret_cast<hipStream_t>(hip_stream);
+    return HV_OK;
+}
+
+int hv_synchronize(hv_ctx *h)
+{
+    if (!h) return HV_ERR_INVALID;
+    HV_HIP(&h->c, hipStreamSynchronize(h->c.stream));
+    return HV_OK;
+}
+
+/* ---- pyramid ---- */
+
+int hv_pyramid_acquire(hv_ctx *h, int *slot_out)
+{
+    if (!h || !slot_out) return HV_ERR_INVALID;
+    Ctx *c = &h->c;
+    if (c->free_slots.empty()) return HV_ERR_POOL;
+    const int s = c->free_slots.back();
+    c->free_slots.pop_back();
+    c->slot_used[s] = 1;
+    *slot_out = s;
+    return HV_OK;
+}
+
+int hv_pyramid_release(hv_ctx *h, int slot)
+{
+    if (!h) return HV_ERR_INVALID;
+    Ctx *c = &h->c;
+    if (!hv::slot_ok(c, slot)) return HV_ERR_POOL;
+    c->slot_used[slot] = 0;
+    c->free_slots.push_back(slot);
+    return HV_OK;
+}
+
+int hv_pyramid_level_size(hv_ctx *h, int level, int *width, int *height)
+{
+    if (!h || level < 0 || level >= h->c.L.levels) return HV_ERR_INVALID;
+    if (width) *width = h->c.L.w[level];
+    if (height) *height = h->c.L.h[level];
+    return HV_OK;
+}
+
+int hv_pyramid_build(hv_ctx *h, int slot, const uint8_t *gray_host, int stride_bytes)
+{
+    if (!h || !gray_host || stride_bytes < h->c.p.width) return HV_ERR_INVALID;
+    Ctx *c = &h->c;
+    if (!hv::slot_ok(c, slot)) return HV_ERR_POOL;
+    const hv::PyrLayout &L = c->L;
+    uint8_t *l0 = c->slab + (long long)slot * L.slot_bytes + L.goff[0];
+    HV_HIP(c, hipMemcpy2DAsync(l0, L.gstride[0], gray_host, stride_bytes, L.w[0], L.h[0],
+                               hipMemcpyHostToDevice, c->stream));
+    hv::IntPack pk{{slot, 0, 0, 0}};
+    hipLaunchKernelGGL(hv::set_ints_kernel, dim3(1), dim3(64), 0, c->stream, c->d_slots, pk, 1);
+    HV_HIP(c, hipGetLastError());
+    return hv::launch_pyramid_levels(c, 1, c->d_slots, c->slab + L.goff[0], L.slot_bytes, L.gstride[0], true);
+}
+
+int hv_pyramid_build_batch_dev(hv_ctx *h, int n, const int *slots_dev, const uint8_t *gray_dev,
+                               long long image_stride_bytes, int row_stride_bytes)
+{
+    if (!h || n < 0 || (n > 0 && (!slots_dev || !gray_dev)) || row_stride_bytes < h->c.p.width)
+        return HV_ERR_INVALID;
+    if (n == 0) return HV_OK;
+    return hv::launch_pyramid_levels(&h->c, n, slots_dev, gray_dev, image_stride_bytes, row_stride_bytes, false);
+}
+
+int hv_pyramid_download(hv_ctx *h, int slot, int level, uint8_t *gray, int16_t *grad)
+{
+    if (!h) return HV_ERR_INVALID;
+    Ctx *c = &h->c;
+    if (!hv::slot_ok(c, slot)) return HV_ERR_POOL;
+    const hv::PyrLayout &L = c->L;
+    if (level < 0 || level >= L.levels) return HV_ERR_INVALID;
+    HV_HIP(c, hipStreamSynchronize(c->stream));
+    const uint8_t *base = c->slab + (long long)slot * L.slot_bytes;
+    if (gray) {
+        const uint8_t *src = base + L.goff[level];
+        int stride = L.gstride[level];
+        if (level == 0) {   // level 0 may live in the caller's buffer
+            HV_HIP(c, hipMemcpy(&src, c->d_l0_ptr + slot, sizeof(void *), hipMemcpyDeviceToHost));
+            HV_HIP(c, hipMemcpy(&stride, c->d_l0_stride + slot, sizeof(int), hipMemcpyDeviceToHost));
+            if (!src) return HV_ERR_INVALID;
+        }
+        HV_HIP(c, hipMemcpy2D(gray, L.w[level], src, stride, L.w[level], L.h[level], hipMemcpyDeviceToHost));
+    }
+    if (grad) {
+        HV_HIP(c, hipMemcpy2D(grad, (size_t)L.w[level] * 4, base + L.doff[level], (size_t)L.dstride[level] * 4,
+                              (size_t)L.w[level] * 4, L.h[level], hipMemcpyDeviceToHost));
+    }
+    return HV_OK;
+}
+
+/* ---- Lucas-Kanade ---- */
+
+int hv_klt_track(hv_ctx *h, int prev_slot, int next_slot, int n, const float *prev_xy, float *next_xy,
+                 uint8_t *status, float *err, int use_initial_flow, int max_iter_override)
+{
+    if (!h || n < 0) return HV_ERR_INVALID;
+    if (n == 0) return HV_OK;
+    if (!prev_xy || !next_xy || !status) return HV_ERR_INVALID;
+    Ctx *c = &h->c;
+    if (!hv::slot_ok(c, prev_slot) || !hv::slot_ok(c, next_slot)) return HV_ERR_POOL;
+    int rc = hv::ensure_point_staging(c, n);
+    if (rc != HV_OK) return rc;
+    HV_HIP(c, hipMemcpyAsync(c->d_prev_xy, prev_xy, sizeof(float) * 2 * n, hipMemcpyHostToDevice, c->stream));
+    if (use_initial_flow)
+        HV_HIP(c, hipMemcpyAsync(c->d_next_xy, next_xy, sizeof(float) * 2 * n, hipMemcpyHostToDevice, c->stream));
+    hv::IntPack pk{{prev_slot, next_slot, 0, 0}};
+    hipLaunchKernelGGL(hv::set_ints_kernel, dim3(1), dim3(64), 0, c->stream, c->d_slots + 2, pk, 2);
+    HV_HIP(c, hipGetLastError());
+    const int iters = max_iter_override > 0 ? max_iter_override : c->p.max_iter;
+    rc = hv::launch_klt(c, 1, c->d_slots + 2, c->d_slots + 3, n, n, c->d_prev_xy, c->d_next_xy,
+                        c->d_status, c->d_err, use_initial_flow, iters);
+    if (rc != HV_OK) return rc;
+    HV_HIP(c, hipMemcpyAsync(next_xy, c->d_next_xy, sizeof(float) * 2 * n, hipMemcpyDeviceToHost, c->stream));
+    HV_HIP(c, hipMemcpyAsync(status, c->d_status, n, hipMemcpyDeviceToHost, c->stream));
+    if (err) HV_HIP(c, hipMemcpyAsync(err, c->d_err, sizeof(float) * n, hipMemcpyDeviceToHost, c->stream));
+    HV_HIP(c, hipStreamSynchronize(c->stream));
+    return HV_OK;
+}
+
+int hv_optical_flow_compute(hv_ctx *h, int prev_slot, int cur_slot, int n, const float *prev_corners,
+                            float *corners, int32_t *track_status, int use_initial_corners,
+                            int override_max_iterations)
+{
+    if (!h || n < 0) return HV_ERR_INVALID;
+    if (n == 0) return HV_OK;   // optical_flow.cpp:37-40
+    if (!prev_corners || !corners || !track_status) return HV_ERR_INVALID;
+    std::vector<uint8_t> st((size_t)n);
+    const int rc = hv_klt_track(h, prev_slot, cur_slot, n, prev_corners, corners, st.data(), nullptr,
+                                use_initial_corners, override_max_iterations);
+    if (rc != HV_OK) return rc;
+    const float width = (float)h->c.L.w[0], height = (float)h->c.L.h[0];
+    for (int i = 0; i < n; ++i) {   // optical_flow.cpp:52-58
+        const float x = corners[2 * i], y = corners[2 * i + 1];
+        track_status[i] = st[i] == 0 ? 2 /*FAILED_FLOW*/ : 0 /*TRACKED*/;
+        if (x < 0.0f || x >= width || y < 0.0f || y >= height) track_status[i] = 4 /*FLOW_OUT_OF_RANGE*/;
+    }
+    return HV_OK;
+}
+
+int hv_klt_track_batch_dev(hv_ctx *h, int n_pairs, const int *prev_slots_dev, const int *next_slots_dev,
+                           int pts_per_pair, const float *prev_xy_dev, float *next_xy_dev,
+                           uint8_t *status_dev, float *err_dev, int use_initial_flow, int max_iter_override)
+{
+    if (!h || n_pairs < 0 || pts_per_pair < 0) return HV_ERR_INVALID;
+    if (n_pairs == 0 || pts_per_pair == 0) return HV_OK;
+    if (!prev_slots_dev || !next_slots_dev || !prev_xy_dev || !next_xy_dev || !status_dev || !err_dev)
+        return HV_ERR_INVALID;
+    Ctx *c = &h->c;
+    const int iters = max_iter_override > 0 ? max_iter_override : c->p.max_iter;
+    return hv::launch_klt(c, n_pairs, prev_slots_dev, next_slots_dev, pts_per_pair, n_pairs * pts_per_pair,
+                          prev_xy_dev, next_xy_dev, status_dev, err_dev, use_initial_flow, iters);
+}
+
+/* ---- timers ---- */
+
+int hv_profile_enable(hv_ctx *h, int on)
+{
+    if (!h) return HV_ERR_INVALID;
+    h->c.profiling = on != 0;
+    return HV_OK;
+}
+
+static int drain_timers(Ctx *c)
+{
+    HV_HIP(c, hipStreamSynchronize(c->stream));
+    for (auto &t : c->timers) {
+        for (auto &e : t.pending) {
+            float ms = 0.f;
+            if (hipEventElapsedTime(&ms, e.first, e.second) == hipSuccess) { t.total_ms += ms; t.launches++; }
+            t.free_list.push_back(e);
+        }
+        t.pending.clear();
+    }
+    return HV_OK;
+}
+
+int hv_profile_reset(hv_ctx *h)
+{
+    if (!h) return HV_ERR_INVALID;
+    const int rc = drain_timers(&h->c);
+    for (auto &t : h->c.timers) { t.total_ms = 0.0; t.launches = 0; }
+    return rc;
+}
+
+int hv_profile_read(hv_ctx *h, int kernel_id, double *total_ms, long long *launches)
+{
+    if (!h || kernel_id < 0 || kernel_id >= HV_K_COUNT) return HV_ERR_INVALID;
+    const int rc = drain_timers(&h->c);
+    if (total_ms) *total_ms = h->c.timers[kernel_id].total_ms;
+    if (launches) *launches = h->c.timers[kernel_id].launches;
+    return rc;
+}
+
+}  // extern "C"

@@ -1,0 +1,100 @@
+// Internal declarations shared by the HIP translation units of libhybvio_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+#include <vector>
+
+#include "../../include/hybvio_hip.h"
+
+namespace hv {
+
+// Device layout of one pyramid slot (passed by value to kernels).
+//   gray level l >= 1 : u8, row stride gstride[l] bytes (multiple of 16), at goff[l]
+//   gray level 0      : either the slot's own copy at goff[0] (host build path) or the
+//                       caller's image used in place (batch_dev path); the per-slot pointer
+//                       table (l0_ptr / l0_stride) says which.
+//   gradient level l  : one dword per pixel = int16 dx | int16 dy << 16, row stride
+//                       dstride[l] dwords (multiple of 4), at doff[l]
+struct PyrLayout {
+    int levels;
+    int win;
+    int w[HV_MAX_LEVELS], h[HV_MAX_LEVELS];
+    int gstride[HV_MAX_LEVELS];
+    int dstride[HV_MAX_LEVELS];
+    long long goff[HV_MAX_LEVELS];
+    long long doff[HV_MAX_LEVELS];
+    long long slot_bytes;
+};
+
+struct KernelTimer {
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> free_list;
+    double total_ms = 0.0;
+    long long launches = 0;
+};
+
+struct Ctx {
+    hv_params p{};
+    PyrLayout L{};
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    uint8_t *slab = nullptr;              // pool_size * slot_bytes
+    const uint8_t **d_l0_ptr = nullptr;   // [pool_size]
+    int *d_l0_stride = nullptr;           // [pool_size]
+    std::vector<int> free_slots;
+    std::vector<uint8_t> slot_used;
+    // small staging buffers for the synchronous host-pointer entry points
+    int *d_slots = nullptr;               // [2 * max_pairs]
+    float *d_prev_xy = nullptr, *d_next_xy = nullptr, *d_err = nullptr;
+    uint8_t *d_status = nullptr;
+    int stage_points = 0;
+    std::string last_error;
+    bool profiling = false;
+    KernelTimer timers[HV_K_COUNT];
+};
+
+int hip_fail(Ctx *c, hipError_t e, const char *what);
+#define HV_HIP(c, call)                                                  \
+    do {                                                                 \
+        hipError_t e__ = (call);                                         \
+        if (e__ != hipSuccess) return hv::hip_fail((c), e__, #call);     \
+    } while (0)
+
+// RAII-ish per-launch timing helper (no-op unless profiling is on).
+struct ScopedKernelTime {
+    Ctx *c; int id; hipEvent_t a = nullptr, b = nullptr;
+    ScopedKernelTime(Ctx *c, int id);
+    ~ScopedKernelTime();
+};
+
+// pyramid.hip
+int launch_pyramid_levels(Ctx *c, int n, const int *slots_dev, const uint8_t *src_base,
+                          long long src_step, int src_stride, bool src_indexed_by_slot);
+// klt.hip
+int launch_klt(Ctx *c, int n_pairs, const int *prev_slots_dev, const int *next_slots_dev,
+               int pts_per_pair, int n_points, const float *prev_xy, float *next_xy,
+               uint8_t *status, float *err, int use_initial_flow, int max_iter);
+
+// XCD-aware block remap (MI355X: 8 XCDs, block b is dispatched to XCD b % 8): gives every XCD a
+// contiguous range of logical tiles so neighbouring tiles share that XCD's L2. Bijective for
+// any grid size (cdna_hip_programming.md T1).
+__device__ __forceinline__ unsigned xcd_remap(unsigned bid, unsigned nwg)
+{
+    const unsigned xcd = bid & 7u, idx = bid >> 3;
+    const unsigned q = nwg >> 3, r = nwg & 7u;
+    const unsigned base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + idx;
+}
+
+__device__ __forceinline__ int reflect101(int p, int len)
+{
+    // OpenCV borderInterpolate(BORDER_REFLECT_101). Exact for -len < p < 2*len-1, which covers
+    // the 31-px virtual border of every level (levels are > 31 px). The clamp only affects
+    // staging margins that no LK window can touch; it keeps those reads in bounds.
+    if (p < 0) p = -p;
+    if (p >= len) p = 2 * len - 2 - p;
+    return min(max(p, 0), len - 1);
+}
+
+}  // namespace hv

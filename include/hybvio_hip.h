@@ -1,0 +1,124 @@
+/*
+ * hybvio_hip.h -- C ABI of libhybvio_hip.so: the MI355X (gfx950) implementation of HybVIO's
+ * per-frame hot path (image pyramid + pyramidal Lucas-Kanade tracker + EKF covariance algebra).
+ *
+ * Plain pointers and sizes only; no C++/torch types cross this boundary. Every entry point
+ * returns HV_OK (0) or a negative hv_status; nothing throws. All device work of one hv_ctx is
+ * issued on one HIP stream (the reference runs Tracker::add and every EKF method on a single
+ * thread: src/api/api.cpp:82,425; src/util/bounded_processing_queue.hpp:18).
+ *
+ * Each group cites the reference interface (file:line under the HybVIO tree) that it replaces;
+ * INTEGRATION.md shows the C++ adapters a maintainer adds on the reference side.
+ *
+ * Names ending in _dev take DEVICE pointers and are asynchronous on the context stream
+ * (throughput / multi-session mode: many independent sequences per GPU in one launch).
+ * All other entry points take HOST pointers and are synchronous on return unless stated.
+ */
+#ifndef HYBVIO_HIP_H_
+#define HYBVIO_HIP_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HV_ABI_VERSION 1
+#define HV_MAX_LEVELS 6
+
+typedef enum hv_status {
+    HV_OK = 0,
+    HV_ERR_INVALID = -1,      /* bad argument                                  */
+    HV_ERR_UNSUPPORTED = -2,  /* parameter combination not implemented          */
+    HV_ERR_NO_DEVICE = -3,    /* no HIP device / HIP runtime failed to start    */
+    HV_ERR_HIP = -4,          /* a HIP call failed; see hv_last_error()         */
+    HV_ERR_POOL = -5,         /* pyramid pool exhausted / bad slot              */
+    HV_ERR_NOMEM = -6
+} hv_status;
+
+typedef struct hv_ctx hv_ctx;
+
+/* Mirror of the few odometry::ParametersTracker fields the path reads
+ * (codegen/parameter_definitions.c:262,336-344). */
+typedef struct hv_params {
+    int device;            /* HIP device ordinal                                         */
+    int width, height;     /* level-0 image size (all images of a context share it)      */
+    int levels;            /* pyrLKMaxLevel + 1                        (default 3 + 1)   */
+    int win;               /* pyrLKWindowSize                          (default 31)      */
+    int max_iter;          /* pyrLKMaxIter                             (default 20)      */
+    double eps;            /* pyrLKEpsilon                             (default 0.03)    */
+    double min_eig;        /* pyrLKMinEigThreshold                     (default 1e-3)    */
+    int max_tracks;        /* tracker.maxTracks: points per LK call    (default 200)     */
+    int pool_size;         /* pyramid slots kept on the device (util::Allocator analogue)*/
+    int max_pairs;         /* max (prev,next) pyramid pairs per batched LK launch        */
+} hv_params;
+
+void hv_default_params(hv_params *p);                 /* fills the defaults listed above */
+int hv_abi_version(void);
+const char *hv_status_string(int status);
+
+/* ---- context ---------------------------------------------------------------------------- */
+int hv_create(const hv_params *params, hv_ctx **out);
+void hv_destroy(hv_ctx *ctx);
+const char *hv_last_error(hv_ctx *ctx);               /* text of the last HV_ERR_HIP           */
+int hv_set_stream(hv_ctx *ctx, void *hip_stream);     /* run on a caller-owned hipStream_t     */
+int hv_synchronize(hv_ctx *ctx);
+
+/* ---- image pyramid ----------------------------------------------------------------------
+ * Replaces tracker::ImagePyramid::Factory::compute (src/tracker/image_pyramid.hpp:35-41,
+ * image_pyramid.cpp:40-48 -> cv::buildOpticalFlowPyramid(img, pyr, Size(win,win), maxLevel)).
+ * A slot is one image's pyramid: gray levels 1..L-1 (u8, 5x5 binomial, (s+128)>>8) and Scharr
+ * gradients 0..L-1 (int16 [dx,dy] interleaved, scale 1/32: image_pyramid.hpp:19-26).
+ * Device layout is compact (no 31-px border); borders are applied virtually by the tracker:
+ * BORDER_REFLECT_101 for gray, 0 for gradients, exactly as OpenCV pads.
+ * Slots are pooled like util::Allocator (src/util/allocator.hpp:55-67): acquire when an Image
+ * first needs its pyramid (image.cpp:209-214), release when the Image dies. */
+int hv_pyramid_acquire(hv_ctx *ctx, int *slot_out);
+int hv_pyramid_release(hv_ctx *ctx, int slot);
+int hv_pyramid_level_size(hv_ctx *ctx, int level, int *width, int *height);
+/* H2D copy of a host gray image (stride_bytes per row) + all level kernels; asynchronous. */
+int hv_pyramid_build(hv_ctx *ctx, int slot, const uint8_t *gray_host, int stride_bytes);
+/* n images already resident in HBM: image i starts at gray_dev + i*image_stride_bytes and
+ * is used in place as level 0 (it must stay valid until the slot is released/rebuilt).
+ * slots_dev: n slot indices in device memory. Asynchronous. */
+int hv_pyramid_build_batch_dev(hv_ctx *ctx, int n, const int *slots_dev, const uint8_t *gray_dev,
+                               long long image_stride_bytes, int row_stride_bytes);
+/* Test/debug read-back of one level (interior only): gray w*h u8 and/or grad w*h*2 int16;
+ * either pointer may be NULL. Synchronous. (ImagePyramid::getGrayLevel/getGradientLevel/getOpenCv) */
+int hv_pyramid_download(hv_ctx *ctx, int slot, int level, uint8_t *gray, int16_t *grad);
+
+/* ---- pyramidal Lucas-Kanade --------------------------------------------------------------
+ * hv_klt_track replaces cv::calcOpticalFlowPyrLK as called at src/tracker/optical_flow.cpp:46-49
+ * (window win x win, levels, TermCriteria(COUNT|EPS, max_iter, eps), minEigThreshold, err != NULL).
+ * next_xy is in/out: initial guess when use_initial_flow != 0 (OPTFLOW_USE_INITIAL_FLOW).
+ * status: 1 tracked / 0 lost. max_iter_override <= 0 keeps the context value. Synchronous. */
+int hv_klt_track(hv_ctx *ctx, int prev_slot, int next_slot, int n, const float *prev_xy,
+                 float *next_xy, uint8_t *status, float *err, int use_initial_flow,
+                 int max_iter_override);
+/* Replaces tracker::OpticalFlow::compute (src/tracker/optical_flow.hpp:31-38,
+ * optical_flow.cpp:10-59,78-102): runs LK, maps to Feature::Status (track.hpp:9-21:
+ * TRACKED=0, FAILED_FLOW=2) and overrides to FLOW_OUT_OF_RANGE=4 outside the level-0 image.
+ * corners is in/out (input when use_initial_corners). n == 0 is a no-op. Synchronous. */
+int hv_optical_flow_compute(hv_ctx *ctx, int prev_slot, int cur_slot, int n,
+                            const float *prev_corners, float *corners, int32_t *track_status,
+                            int use_initial_corners, int override_max_iterations);
+/* Batched: n_pairs independent (prev,next) pyramid pairs with pts_per_pair points each, one
+ * launch; point j of pair p is element p*pts_per_pair + j of every array. All arrays are in
+ * device memory; asynchronous. */
+int hv_klt_track_batch_dev(hv_ctx *ctx, int n_pairs, const int *prev_slots_dev,
+                           const int *next_slots_dev, int pts_per_pair, const float *prev_xy_dev,
+                           float *next_xy_dev, uint8_t *status_dev, float *err_dev,
+                           int use_initial_flow, int max_iter_override);
+
+/* ---- per-kernel timing (hipEvents on the context stream) ---------------------------------- */
+enum { HV_K_PYR_L0 = 0, HV_K_PYR_LN = 1, HV_K_KLT = 2, HV_K_EKF_PREDICT = 3, HV_K_EKF_UPDATE = 4,
+       HV_K_EKF_AUGMENT = 5, HV_K_COUNT = 6 };
+int hv_profile_enable(hv_ctx *ctx, int on);
+int hv_profile_reset(hv_ctx *ctx);
+/* Synchronizes, then returns accumulated device milliseconds and launch count of a kernel class. */
+int hv_profile_read(hv_ctx *ctx, int kernel_id, double *total_ms, long long *launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HYBVIO_HIP_H_ */

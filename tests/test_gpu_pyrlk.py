@@ -1,0 +1,228 @@
+"""GPU parity tests (run with -m gpu on an MI355X): HIP pyramid + LK through the C ABI vs the CPU
+oracle on the same seeded inputs. Bars (BASELINE.json north_star / SURVEY.md 8d):
+  pyramid gray + gradients ... bit-exact (integer)
+  LK status / Feature::Status . bit-exact
+  LK positions ............... |dxy| <= 1e-3 px (the integer-accumulator design makes them equal)
+"""
+import os
+
+import numpy as np
+import pytest
+
+from hybvio_amd import capi, synth
+
+pytestmark = pytest.mark.gpu
+POS_TOL = 1e-3
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden", "pyrlk_golden.npz")
+
+
+def _ctx(w, h, **kw):
+    return capi.Context(width=w, height=h, **kw)
+
+
+def _check_pyramid(ctx, oracle, img, slot):
+    ref = oracle.Pyramid(img)
+    assert ref.levels == ctx.levels
+    for l in range(ctx.levels):
+        g, d = ctx.download(slot, l)
+        np.testing.assert_array_equal(g, ref.gray(l), err_msg=f"gray level {l}")
+        np.testing.assert_array_equal(d, ref.deriv(l), err_msg=f"gradient level {l}")
+    return ref
+
+
+@pytest.mark.parametrize("shape", [(480, 752), (720, 1280), (479, 641), (70, 101), (33, 65), (97, 64), (256, 260)])
+def test_pyramid_bit_exact(oracle, shape):
+    rng = np.random.default_rng(shape[0] * 7 + shape[1])
+    img = rng.integers(0, 256, shape, dtype=np.uint8)
+    with _ctx(shape[1], shape[0]) as ctx:
+        s = ctx.acquire()
+        ctx.build(s, img)
+        _check_pyramid(ctx, oracle, img, s)
+        # strided host input (ROI of a wider buffer)
+        wide = np.zeros((shape[0], shape[1] + 13), np.uint8)
+        wide[:, :shape[1]] = img[::-1]
+        s2 = ctx.acquire()
+        rc = capi.lib().hv_pyramid_build(ctx._h, s2, wide.ctypes.data_as(capi.u8p), wide.strides[0])
+        assert rc == 0
+        ctx.synchronize()
+        _check_pyramid(ctx, oracle, np.ascontiguousarray(img[::-1]), s2)
+
+
+def test_pyramid_extreme_images(oracle):
+    for img in (np.zeros((480, 752), np.uint8), np.full((480, 752), 255, np.uint8),
+                (np.indices((480, 752)).sum(0) % 2 * 255).astype(np.uint8)):    # checkerboard: max |gradient|
+        with _ctx(752, 480) as ctx:
+            s = ctx.acquire()
+            ctx.build(s, img)
+            _check_pyramid(ctx, oracle, img, s)
+
+
+def test_pyramid_batch_dev_path_and_pool(oracle, seq752):
+    """Images resident in HBM, used in place as level 0; slots recycled like util::Allocator."""
+    import torch
+    left, right, _ = seq752
+    imgs = np.concatenate([left, right])                       # 6 images
+    with _ctx(752, 480, pool_size=8) as ctx:
+        ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+        slots = [ctx.acquire() for _ in range(8)]
+        with pytest.raises(capi.HvError, match="pool"):
+            ctx.acquire()
+        for s in slots[:2]:
+            ctx.release(s)
+        use = slots[2:]                                        # non-contiguous, non-zero-based
+        d_imgs = torch.from_numpy(imgs).cuda()
+        d_slots = torch.tensor(use, dtype=torch.int32, device="cuda")
+        ctx.build_batch_dev(len(use), d_slots.data_ptr(), d_imgs.data_ptr(), 752 * 480, 752)
+        ctx.synchronize()
+        for i, s in enumerate(use):
+            _check_pyramid(ctx, oracle, imgs[i], s)
+        # size-independent property at full size: pyramid of a flipped image = flipped pyramid (gray),
+        # and gradients negate along the flipped axis
+        flipped = torch.flip(d_imgs[:1], dims=[2]).contiguous()
+        s = ctx.acquire()
+        ctx.build_batch_dev(1, torch.tensor([s], dtype=torch.int32, device="cuda").data_ptr(),
+                            flipped.data_ptr(), 752 * 480, 752)
+        ctx.synchronize()
+        g0, d0 = ctx.download(use[0], 0)
+        g1, d1 = ctx.download(s, 0)
+        np.testing.assert_array_equal(g1, g0[:, ::-1])
+        np.testing.assert_array_equal(d1[..., 0], -d0[:, ::-1, 0])
+        np.testing.assert_array_equal(d1[..., 1], d0[:, ::-1, 1])
+
+
+def _compare_klt(ctx, oracle, refp, refn, sp, sn, pts, guess=None, **kw):
+    o_xy, o_st, o_err = oracle.klt_track(refp, refn, pts, next_pts=guess,
+                                         **({"max_count": kw["max_iter_override"]} if "max_iter_override" in kw else {}))
+    g_xy, g_st, g_err = ctx.klt_track(sp, sn, pts, next_xy=guess, **kw)
+    np.testing.assert_array_equal(g_st, o_st)
+    assert np.abs(g_xy - o_xy).max() <= POS_TOL, np.abs(g_xy - o_xy).max()
+    np.testing.assert_array_equal(g_xy, o_xy)          # stronger than required: identical floats
+    np.testing.assert_allclose(g_err, o_err, rtol=0, atol=0)
+    return g_xy, g_st
+
+
+def test_klt_parity_752_temporal_and_stereo(oracle, seq752):
+    left, right, warps = seq752
+    pts = synth.grid_points(752, 480, 200)
+    with _ctx(752, 480) as ctx:
+        s0, s1, sr = ctx.acquire(), ctx.acquire(), ctx.acquire()
+        ctx.build(s0, left[0]); ctx.build(s1, left[1]); ctx.build(sr, right[1])
+        r0, r1, rr = oracle.Pyramid(left[0]), oracle.Pyramid(left[1]), oracle.Pyramid(right[1])
+        xy, st = _compare_klt(ctx, oracle, r0, r1, s0, s1, pts)
+        gt = synth.true_flow(pts.astype(np.float64), warps[0], warps[1])
+        assert st.mean() > 0.98 and np.median(np.linalg.norm(xy - gt, axis=1)[st > 0]) < 0.05
+        _compare_klt(ctx, oracle, r1, rr, s1, sr, xy)                         # stereo: 20 px disparity, no guess
+        _compare_klt(ctx, oracle, r0, r1, s0, s1, pts, guess=gt.astype(np.float32))   # predicted flow
+        _compare_klt(ctx, oracle, r0, r1, s0, s1, pts, max_iter_override=1)
+        _compare_klt(ctx, oracle, r0, r1, s0, s1, pts, max_iter_override=3)
+
+
+def test_klt_parity_borders_failures_and_ragged_counts(oracle, seq752):
+    left, _, _ = seq752
+    rng = np.random.default_rng(11)
+    with _ctx(752, 480) as ctx:
+        s0, s2, sf = ctx.acquire(), ctx.acquire(), ctx.acquire()
+        flat = np.full((480, 752), 128, np.uint8)
+        ctx.build(s0, left[0]); ctx.build(s2, left[2]); ctx.build(sf, flat)
+        r0, r2, rf = oracle.Pyramid(left[0]), oracle.Pyramid(left[2]), oracle.Pyramid(flat)
+        # points on / beyond every border, with windows that leave the padded image
+        pts = rng.uniform([-45, -45], [800, 530], (300, 2)).astype(np.float32)
+        edge = np.array([[0, 0], [751, 479], [751.9, 0.1], [-15.5, 240], [766.4, 240], [376, -15.9],
+                         [376, 494.9], [15, 15], [736, 464], [-31, -31], [782, 510]], np.float32)
+        pts = np.concatenate([pts, edge])
+        xy, st = _compare_klt(ctx, oracle, r0, r2, s0, s2, pts)
+        assert 0 < st.sum() < len(pts)
+        guess = (pts + rng.normal(0, 6.0, pts.shape)).astype(np.float32)       # bad guesses: tile re-staging path
+        _compare_klt(ctx, oracle, r0, r2, s0, s2, pts, guess=guess)
+        _compare_klt(ctx, oracle, rf, rf, sf, sf, pts[:64])                     # no texture: all lost
+        _compare_klt(ctx, oracle, r0, rf, s0, sf, pts[:64])                     # texture -> flat
+        for n in (1, 2, 63, 64, 65, 257):                                       # ragged point counts
+            _compare_klt(ctx, oracle, r0, r2, s0, s2, pts[:n])
+        # Feature::Status mapping incl. FLOW_OUT_OF_RANGE and the empty call
+        o_xy, o_fs = oracle.optical_flow_compute(r0, r2, pts, corners=guess)
+        g_xy, g_fs = ctx.optical_flow_compute(s0, s2, pts, corners=guess)
+        np.testing.assert_array_equal(g_fs, o_fs)
+        np.testing.assert_array_equal(g_xy, o_xy)
+        assert {0, 2, 4} >= set(np.unique(g_fs)) and (g_fs == 4).any()
+        e_xy, e_fs = ctx.optical_flow_compute(s0, s2, np.zeros((0, 2), np.float32))
+        assert e_xy.shape == (0, 2) and e_fs.shape == (0,)
+
+
+@pytest.mark.parametrize("shape", [(720, 1280), (150, 200), (70, 101)])
+def test_klt_parity_other_sizes(oracle, shape):
+    h, w = shape
+    tex = synth.Texture.make(5)
+    a = synth.render(tex, w, h, synth.Warp.make(0, 0, 0, w / 2, h / 2))
+    b = synth.render(tex, w, h, synth.Warp.make(0.5, 2.2, -1.4, w / 2, h / 2), noise_seed=3, noise_sigma=2.0)
+    n = 400 if w == 1280 else 64
+    pts = synth.grid_points(w, h, n, margin=6, seed=2)
+    with _ctx(w, h, max_tracks=n) as ctx:
+        sa, sb = ctx.acquire(), ctx.acquire()
+        ctx.build(sa, a); ctx.build(sb, b)
+        _, st = _compare_klt(ctx, oracle, oracle.Pyramid(a), oracle.Pyramid(b), sa, sb, pts)
+        assert st.mean() > 0.8
+
+
+def test_klt_batch_dev_equals_single_calls(oracle, seq752):
+    """Throughput path: several (prev,next) pairs x 200 points in ONE launch, all arrays in HBM."""
+    import torch
+    left, right, _ = seq752
+    pts = synth.grid_points(752, 480, 200)
+    with _ctx(752, 480, pool_size=8) as ctx:
+        ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+        imgs = np.concatenate([left, right])
+        slots = [ctx.acquire() for _ in range(6)]
+        d_imgs = torch.from_numpy(imgs).cuda()
+        d_slots = torch.tensor(slots, dtype=torch.int32, device="cuda")
+        ctx.build_batch_dev(6, d_slots.data_ptr(), d_imgs.data_ptr(), 752 * 480, 752)
+        pairs = [(0, 1), (1, 2), (1, 4), (2, 5), (0, 2)]           # temporal and stereo pairs
+        prev = torch.tensor([slots[a] for a, _ in pairs], dtype=torch.int32, device="cuda")
+        nxt = torch.tensor([slots[b] for _, b in pairs], dtype=torch.int32, device="cuda")
+        P = torch.from_numpy(np.tile(pts, (len(pairs), 1))).cuda()
+        N = P.clone()
+        S = torch.zeros(len(pairs) * 200, dtype=torch.uint8, device="cuda")
+        E = torch.zeros(len(pairs) * 200, dtype=torch.float32, device="cuda")
+        ctx.klt_track_batch_dev(len(pairs), prev.data_ptr(), nxt.data_ptr(), 200, P.data_ptr(), N.data_ptr(),
+                                S.data_ptr(), E.data_ptr(), use_initial_flow=True)
+        torch.cuda.synchronize()
+        N, S, E = N.cpu().numpy().reshape(len(pairs), 200, 2), S.cpu().numpy().reshape(-1, 200), E.cpu().numpy().reshape(-1, 200)
+        refs = [oracle.Pyramid(im) for im in imgs]
+        for k, (a, b) in enumerate(pairs):
+            o_xy, o_st, o_err = oracle.klt_track(refs[a], refs[b], pts, next_pts=pts)
+            np.testing.assert_array_equal(S[k], o_st)
+            np.testing.assert_array_equal(N[k], o_xy)
+            np.testing.assert_array_equal(E[k], o_err)
+
+
+def test_golden_fixture_on_gpu():
+    """Committed fixture (tests/golden/pyrlk_golden.npz): needs no oracle build on the GPU box."""
+    g = np.load(GOLDEN)
+    h, w = g["img0"].shape
+    with _ctx(w, h) as ctx:
+        assert ctx.levels == int(g["levels"])
+        s0, s1 = ctx.acquire(), ctx.acquire()
+        ctx.build(s0, g["img0"]); ctx.build(s1, g["img1"])
+        for l in range(ctx.levels):
+            gg, dd = ctx.download(s0, l)
+            np.testing.assert_array_equal(gg, g[f"gray{l}"])
+            np.testing.assert_array_equal(dd, g[f"deriv{l}"])
+        xy, st, err = ctx.klt_track(s0, s1, g["pts"])
+        np.testing.assert_array_equal(st, g["status"])
+        assert np.abs(xy - g["next"]).max() <= POS_TOL
+        np.testing.assert_array_equal(err, g["err"])
+        fxy, fs = ctx.optical_flow_compute(s0, s1, g["pts"], corners=g["guess"])
+        np.testing.assert_array_equal(fs, g["flow_status"])
+        assert np.abs(fxy - g["flow_corners"]).max() <= POS_TOL
+
+
+def test_full_size_property_identity_tracking(oracle, seq752):
+    """Size-independent property: tracking an image onto itself returns the input points exactly
+    with status 1 and err 0 wherever the window has texture."""
+    left, _, _ = seq752
+    pts = synth.grid_points(752, 480, 200)
+    with _ctx(752, 480) as ctx:
+        s = ctx.acquire()
+        ctx.build(s, left[0])
+        xy, st, err = ctx.klt_track(s, s, pts)
+        assert st.all() and not err.any()
+        assert np.abs(xy - pts).max() < 1e-4
