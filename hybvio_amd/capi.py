@@ -11,6 +11,15 @@ import os
 
 import numpy as np
 
+# The torch wheel bundles its own libamdhip64/libhsa-runtime64. A process must initialise exactly
+# ONE HIP/HSA runtime, so when torch is installed it is imported BEFORE libhybvio_hip.so is loaded:
+# the dynamic linker then resolves our NEEDED libamdhip64.so.7 to the copy torch already mapped.
+# (A C++ host such as the reference `main` has no torch and simply uses /opt/rocm.)
+try:
+    import torch  # noqa: F401
+except ImportError:  # pragma: no cover
+    torch = None
+
 from . import build as _build
 
 u8p = C.POINTER(C.c_uint8)
