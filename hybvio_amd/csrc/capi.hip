@@ -283,6 +283,8 @@ int hv_pyramid_download(hv_ctx *h, int slot, int level, uint8_t *gray, int16_t *
     if (grad) {
         HV_HIP(c, hipMemcpy2D(grad, (size_t)L.w[level] * 4, base + L.doff[level], (size_t)L.dstride[level] * 4,
                               (size_t)L.w[level] * 4, L.h[level], hipMemcpyDeviceToHost));
+        const size_t n = (size_t)L.w[level] * L.h[level] * 2;      // device stores 4*d (exact): undo
+        for (size_t i = 0; i < n; ++i) grad[i] = (int16_t)(grad[i] >> hv::GRAD_SHIFT);
     }
     return HV_OK;
 }

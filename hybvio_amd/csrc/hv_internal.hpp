@@ -14,7 +14,7 @@ namespace hv {
 //   gray level 0      : either the slot's own copy at goff[0] (host build path) or the
 //                       caller's image used in place (batch_dev path); the per-slot pointer
 //                       table (l0_ptr / l0_stride) says which.
-//   gradient level l  : one dword per pixel = int16 dx | int16 dy << 16, row stride
+//   gradient level l  : one dword per pixel = int16 4*dx+2 | int16 (4*dy+2) << 16, row stride
 //                       dstride[l] dwords (multiple of 4), at doff[l]
 struct PyrLayout {
     int levels;
@@ -26,6 +26,9 @@ struct PyrLayout {
     long long doff[HV_MAX_LEVELS];
     long long slot_bytes;
 };
+
+// Gradients are stored as int16 ((d << GRAD_SHIFT) + 2) for dx and dy (see pyramid.hip / klt.hip).
+constexpr int GRAD_SHIFT = 2;
 
 struct KernelTimer {
     std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;

@@ -6,12 +6,18 @@
 //   * the level loop (coarse -> fine) stays inside the kernel, so one launch tracks every
 //     feature of every (prev,next) pair of the batch through all levels;
 //   * lane (half, cx) owns window column cx and rows half*16 .. half*16+15 of the 31x31 window;
-//     its 16 template samples (I, Ix, Iy; 5+ fractional bits, int16 range) live in VGPRs for the
+//     its 16 template samples (I, Ix, Iy; int16 range) live in VGPRs as packed pairs for the
 //     whole level, so an iteration reads only the J window;
-//   * the J window comes from a 48x48-byte tile of the next image staged in LDS with coalesced
-//     row loads; it is re-staged only when the window leaves the tile (8 px margin);
+//   * the J window comes from a 48x48 tile of the next image staged in LDS with coalesced row
+//     loads and re-staged only when the window leaves it (8 px margin). The tile is stored as one
+//     dword per pixel holding the packed pair (J[x], J[x+1]) << 7, so one ds_read_b32 per window
+//     row feeds v_dot2_i32_i16 directly and the rounding shift ">> 9" becomes "take the high
+//     half" (128*t + 32768 >> 16 == t + 256 >> 9). Gradients are stored x4 in the pyramid for
+//     the same reason (4*s + 32768 >> 16 == s + 8192 >> 14). The kernel is VALU-issue bound
+//     (rocprof: 90 % VALU busy), so the design minimises integer instructions per pixel;
 //   * the 2x2 normal equations are accumulated as exact integers per lane and reduced across the
-//     wavefront with DPP row operations + v_readlane (no LDS, no atomics). Integer sums are
+//     wavefront with DPP row operations + v_readlane (no LDS, no atomics): one 32-bit chain when
+//     a ballot proves the total fits, else an exact 2-chain 64-bit path. Integer sums are
 //     order independent, so status / positions are bit-reproducible against the CPU oracle;
 //   * image borders are virtual: BORDER_REFLECT_101 index math for gray, zero for gradients
 //     (OpenCV pads the pyramid by the window size instead).
@@ -27,8 +33,12 @@ namespace {
 
 constexpr int WIN = 31;
 constexpr int HALF_ROWS = 16;          // rows per half-wave
-constexpr int TS = 48;                 // staged J tile: TS x TS bytes
-constexpr int TSD = TS / 4;
+constexpr int TS = 48;                 // staged J tile: TS x TS pixels (one dword each)
+constexpr int GRAY_SHIFT = 7;          // gray samples are pre-scaled by 128 (<= 32640: fits int16)
+// The four bilinear weights always sum to 2^14, so adding 2 to every pre-scaled sample adds exactly
+// 2^15 to the weighted sum: the rounding constant of CV_DESCALE rides along in the data and every
+// dot2 chain starts from 0. Gradients are stored as 4*d + 2 for the same reason (pyramid.hip).
+constexpr uint32_t ROUND_PAIR = 0x00020002u;
 constexpr int MARGIN = 8;
 constexpr int W_BITS = 14;
 
@@ -54,8 +64,8 @@ typedef short short2v __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ gptr_u8 as_global(const uint8_t *p) { return (gptr_u8)(uintptr_t)p; }
 
-// v_dot2_i32_i16: a.lo*b.lo + a.hi*b.hi + c on packed int16 pairs (full-rate; a 32-bit
-// v_mul_lo_u32 is quarter-rate on CDNA and every operand here fits 16 bits).
+// v_dot2_i32_i16: a.lo*b.lo + a.hi*b.hi + c on packed int16 pairs (a 32-bit v_mul_lo_u32 is
+// quarter-rate on CDNA and every operand here fits 16 bits).
 __device__ __forceinline__ int dot2(uint32_t a, uint32_t b, int c)
 {
     return __builtin_amdgcn_sdot2(__builtin_bit_cast(short2v, a), __builtin_bit_cast(short2v, b), c, false);
@@ -66,6 +76,13 @@ __device__ __forceinline__ uint32_t hi16_pair(uint32_t a, uint32_t b) { return _
 __device__ __forceinline__ uint32_t pk_sub16(uint32_t a, uint32_t b)
 {
     return __builtin_bit_cast(uint32_t, __builtin_bit_cast(short2v, a) - __builtin_bit_cast(short2v, b));
+}
+// bytes (i, i+1) of the 8-byte string {lo, hi} as the pre-scaled pair (b_i << 7) | (b_i+1 << 23)
+template <int I>
+__device__ __forceinline__ uint32_t scaled_pair(uint32_t lo, uint32_t hi)
+{
+    constexpr uint32_t sel = 0x0C000C00u | (uint32_t)I | ((uint32_t)(I + 1) << 16);
+    return __builtin_amdgcn_perm(hi, lo, sel) * (1u << GRAY_SHIFT) + ROUND_PAIR;   // no carry between halves
 }
 
 // Wavefront sum of a small integer (|sum| < 2^31) entirely in DPP: 4 in-row steps, then
@@ -81,33 +98,42 @@ __device__ __forceinline__ int wave_sum_small(int v)
     return __builtin_amdgcn_readlane(v, 63);
 }
 
-// Exact wavefront sum of per-lane int32 partials, returned as the float nearest to it:
-// the low 16 bits and the signed high part are reduced separately (no overflow), recombined
-// exactly in f64 (< 2^53) and rounded once -- identical to (float)(int64 sum).
-__device__ __forceinline__ float wave_sum_to_float(int v)
+// Exact sum of per-lane int32 partials as the nearest float (== (float)(int64 sum)): the low 16
+// bits and the signed high part are reduced separately, recombined exactly in f64, rounded once.
+__device__ __forceinline__ float wave_sum_wide(int v)
 {
     const int lo = wave_sum_small(v & 0xFFFF);
     const int hi = wave_sum_small(v >> 16);
     return (float)((double)hi * 65536.0 + (double)lo);
 }
 
-__device__ __forceinline__ void bilinear_weights(float a, float b, int &iw00, int &iw01, int &iw10, int &iw11)
+// all |v| < 2^24 across the wavefront  =>  any 64-lane sum of them fits int32
+__device__ __forceinline__ bool all_small(int a, int b, int c)
 {
-    iw00 = __float2int_rn((1.f - a) * (1.f - b) * (float)(1 << W_BITS));
-    iw01 = __float2int_rn(a * (1.f - b) * (float)(1 << W_BITS));
-    iw10 = __float2int_rn((1.f - a) * b * (float)(1 << W_BITS));
-    iw11 = (1 << W_BITS) - iw00 - iw01 - iw10;
+    const unsigned C = 1u << 24;
+    const unsigned t = ((unsigned)a + C) | ((unsigned)b + C) | ((unsigned)c + C);
+    return __builtin_amdgcn_ballot_w64(t >= 2 * C) == 0;
+}
+
+__device__ __forceinline__ void bilinear_weights(float a, float b, uint32_t &wA, uint32_t &wB)
+{
+    const int iw00 = __float2int_rn((1.f - a) * (1.f - b) * (float)(1 << W_BITS));
+    const int iw01 = __float2int_rn(a * (1.f - b) * (float)(1 << W_BITS));
+    const int iw10 = __float2int_rn((1.f - a) * b * (float)(1 << W_BITS));
+    const int iw11 = (1 << W_BITS) - iw00 - iw01 - iw10;
+    wA = pack16(iw00, iw01);     // top row weights
+    wB = pack16(iw10, iw11);     // bottom row weights
 }
 
 __global__ __launch_bounds__(64) void klt_kernel(KltArgs a)
 {
-    __shared__ uint32_t jt[(TS + 1) * TSD];   // +1 row: the unused 17th row read of half 1
+    // one dword per pixel: (J[x] << 7) | (J[x+1] << 23); +1 row for the unused 17th row of half 1
+    __shared__ __attribute__((aligned(16))) uint32_t jt[(TS + 1) * TS];
 
     const int pt = (int)xcd_remap(blockIdx.x, gridDim.x);
     const int lane = threadIdx.x;
     const int half = lane >> 5, cx = lane & 31;
     const bool col_ok = cx < WIN;
-    const int nrows = half ? (WIN - HALF_ROWS) : HALF_ROWS;
     const PyrLayout &L = a.L;
 
     const int pair = pt / a.pts_per_pair;
@@ -121,6 +147,9 @@ __global__ __launch_bounds__(64) void klt_kernel(KltArgs a)
 
     const float half_win = (float)(WIN - 1) * 0.5f;
     const float FLT_SCALE = 1.f / (float)(1 << 20);
+    const float eps_lo = (float)(a.epsilon * (1.0 - 1e-5)), eps_hi = (float)(a.epsilon * (1.0 + 1e-5));
+    // pixel (cx, half*16 + k) exists for k < 16 (half 0) / k < 15 (half 1) and cx < 31
+    const uint32_t last_ok = (col_ok && !half) ? 1u : 0u;
     int st = 1;
     float errv = 0.f;
     float nx = 0.f, ny = 0.f;
@@ -155,18 +184,17 @@ __global__ __launch_bounds__(64) void klt_kernel(KltArgs a)
         const int Ids = L.dstride[level];
 
         // ---- template patch: bilinear samples of I and dI into registers, A = sum(dI dI^T) ----
-        int iw00, iw01, iw10, iw11;
-        bilinear_weights(px - (float)ipx, py - (float)ipy, iw00, iw01, iw10, iw11);
-
-        // packed int16 pairs (rows 2m, 2m+1): template value, x-gradient, y-gradient
+        // packed int16 pairs (window rows 2m, 2m+1 of this lane): value, x-gradient, y-gradient
         uint32_t Ivp[HALF_ROWS / 2], IXp[HALF_ROWS / 2], IYp[HALF_ROWS / 2];
         int sA11 = 0, sA12 = 0, sA22 = 0;
         {
-            const uint32_t wA = pack16(iw00, iw01), wB = pack16(iw10, iw11);
+            uint32_t wA, wB;
+            bilinear_weights(px - (float)ipx, py - (float)ipy, wA, wB);
+            if (!col_ok) { wA = 0; wB = 0; }          // zero weights => every sample of this lane is 0
             const int xa = ipx + cx;
             const int rbase = ipy + half * HALF_ROWS;
-            // Source rows rbase .. rbase+16 as packed pairs of columns (xa, xa+1). ALL loads of the
-            // 17 rows are issued before the first use (one memory round trip per level, not 17).
+            // Source rows rbase .. rbase+16 as pre-scaled packed pairs of columns (xa, xa+1). ALL
+            // loads of the 17 rows are issued before the first use (one round trip per level).
             uint32_t gp[HALF_ROWS + 1], dxp[HALF_ROWS + 1], dyp[HALF_ROWS + 1];
             const bool inside = ipx >= 0 && ipx + 32 <= w && ipy >= 0 && ipy + 32 <= h;   // wave-uniform
             if (inside) {
@@ -181,7 +209,7 @@ __global__ __launch_bounds__(64) void klt_kernel(KltArgs a)
                 }
 #pragma unroll
                 for (int r = 0; r <= HALF_ROWS; ++r) {
-                    gp[r] = ((uint32_t)graw[r] & 0xFFu) | (((uint32_t)graw[r] & 0xFF00u) << 8);
+                    gp[r] = scaled_pair<0>((uint32_t)graw[r], 0u);
                     dxp[r] = lo16_pair(draw[r].x, draw[r].y);
                     dyp[r] = hi16_pair(draw[r].x, draw[r].y);
                 }
@@ -204,32 +232,47 @@ __global__ __launch_bounds__(64) void klt_kernel(KltArgs a)
 #pragma unroll
                 for (int r = 0; r <= HALF_ROWS; ++r) {
                     const uint32_t mr = (unsigned)(rbase + r) < (unsigned)h ? 0xFFFFFFFFu : 0u;
-                    gp[r] = ga[r] | (gb[r] << 16);
-                    dxp[r] = lo16_pair(da[r] & ma & mr, db[r] & mb & mr);
-                    dyp[r] = hi16_pair(da[r] & ma & mr, db[r] & mb & mr);
+                    gp[r] = ((ga[r] << GRAY_SHIFT) | (gb[r] << (16 + GRAY_SHIFT))) + ROUND_PAIR;
+                    const uint32_t qa = (ma & mr) ? da[r] : ROUND_PAIR;     // border value 0 is stored as 4*0 + 2
+                    const uint32_t qb = (mb & mr) ? db[r] : ROUND_PAIR;
+                    dxp[r] = lo16_pair(qa, qb);
+                    dyp[r] = hi16_pair(qa, qb);
                 }
             }
-            int iv_prev = 0, ix_prev = 0, iy_prev = 0;
+            // DESCALE(s, 9) == (128 s + 32768) >> 16 and DESCALE(s, 14) == (4 s + 32768) >> 16: the
+            // inputs are pre-scaled by 128 / 4 and carry the +2 that sums to 32768, so each sample is
+            // the high half of one dot2 chain started from 0.
+            int vi_prev = 0, vx_prev = 0, vy_prev = 0;
 #pragma unroll
             for (int k = 0; k < HALF_ROWS; ++k) {
-                int ival = dot2(gp[k + 1], wB, dot2(gp[k], wA, 1 << (W_BITS - 5 - 1))) >> (W_BITS - 5);
-                int ixv = dot2(dxp[k + 1], wB, dot2(dxp[k], wA, 1 << (W_BITS - 1))) >> W_BITS;
-                int iyv = dot2(dyp[k + 1], wB, dot2(dyp[k], wA, 1 << (W_BITS - 1))) >> W_BITS;
-                if (!(col_ok && k < nrows)) { ival = 0; ixv = 0; iyv = 0; }
-                sA11 = __mul24(ixv, ixv) + sA11;
-                sA12 = __mul24(ixv, iyv) + sA12;
-                sA22 = __mul24(iyv, iyv) + sA22;
+                const uint32_t wAk = (k == HALF_ROWS - 1 && half) ? 0u : wA;   // row 31 does not exist
+                const uint32_t wBk = (k == HALF_ROWS - 1 && half) ? 0u : wB;
+                const int vi = dot2(gp[k + 1], wBk, dot2(gp[k], wAk, 0));
+                const int vx = dot2(dxp[k + 1], wBk, dot2(dxp[k], wAk, 0));
+                const int vy = dot2(dyp[k + 1], wBk, dot2(dyp[k], wAk, 0));
                 if (k & 1) {
-                    Ivp[k >> 1] = pack16(iv_prev, ival);
-                    IXp[k >> 1] = pack16(ix_prev, ixv);
-                    IYp[k >> 1] = pack16(iy_prev, iyv);
+                    const int m = k >> 1;
+                    Ivp[m] = hi16_pair((uint32_t)vi_prev, (uint32_t)vi);
+                    IXp[m] = hi16_pair((uint32_t)vx_prev, (uint32_t)vx);
+                    IYp[m] = hi16_pair((uint32_t)vy_prev, (uint32_t)vy);
+                    sA11 = dot2(IXp[m], IXp[m], sA11);
+                    sA12 = dot2(IXp[m], IYp[m], sA12);
+                    sA22 = dot2(IYp[m], IYp[m], sA22);
                 }
-                iv_prev = ival; ix_prev = ixv; iy_prev = iyv;
+                vi_prev = vi; vx_prev = vx; vy_prev = vy;
             }
         }
-        const float A11 = wave_sum_to_float(sA11) * FLT_SCALE;
-        const float A12 = wave_sum_to_float(sA12) * FLT_SCALE;
-        const float A22 = wave_sum_to_float(sA22) * FLT_SCALE;
+        float A11, A12, A22;
+        // per-lane sums of squares are < 2^29; when all are < 2^24 one int32 chain each is exact
+        if (all_small(sA11, sA12, sA22)) {
+            A11 = (float)wave_sum_small(sA11) * FLT_SCALE;
+            A12 = (float)wave_sum_small(sA12) * FLT_SCALE;
+            A22 = (float)wave_sum_small(sA22) * FLT_SCALE;
+        } else {
+            A11 = wave_sum_wide(sA11) * FLT_SCALE;
+            A12 = wave_sum_wide(sA12) * FLT_SCALE;
+            A22 = wave_sum_wide(sA22) * FLT_SCALE;
+        }
 
         float D = A11 * A22 - A12 * A12;
         const float min_eig = (A22 + A11 - sqrtf((A11 - A22) * (A11 - A22) + 4.f * A12 * A12)) /
@@ -245,25 +288,44 @@ __global__ __launch_bounds__(64) void klt_kernel(KltArgs a)
         int tox = -(1 << 28), toy = -(1 << 28);
         const bool j_aligned = ((reinterpret_cast<uintptr_t>(Jg) | (uintptr_t)Jgs) & 3u) == 0;
 
-        // Stage the J tile whose origin covers window origin (ix, iy) with an 8 px margin.
+        // Stage the J tile covering window origin (ix, iy) with an 8 px margin. A single wavefront
+        // issues its LDS accesses in order, so no workgroup barrier is needed.
         auto ensure_tile = [&](int ix, int iy) {
             if (ix >= tox && ix + 32 <= tox + TS && iy >= toy && iy + 32 <= toy + TS) return;
             tox = (ix - MARGIN) & ~3; toy = iy - MARGIN;
-            const bool fast = j_aligned && tox >= 0 && tox + TS <= w && toy >= 0 && toy + TS <= h;
+            // keep the (TS+4) x TS load footprint inside the image whenever the window allows it, so
+            // only windows that really cross the border take the reflecting path
+            const int cx0 = min(max(tox, 0), (w - TS - 4) & ~3), cy0 = min(max(toy, 0), h - TS);
+            if (w >= TS + 4 && h >= TS && ix >= cx0 && ix + 32 <= cx0 + TS && iy >= cy0 && iy + 32 <= cy0 + TS) {
+                tox = cx0; toy = cy0;
+            }
+            const bool fast = j_aligned && tox >= 0 && tox + TS + 4 <= w && toy >= 0 && toy + TS <= h;
             if (fast) {
+                uint2 raw[(TS * TS / 4) / 64];
 #pragma unroll
-                for (int i = 0; i < (TS * TSD) / 64; ++i) {
-                    const int e = lane + 64 * i, r = e / TSD, c = e - r * TSD;
-                    jt[e] = *(gptr_u32)(Jg + ((unsigned)(toy + r) * (unsigned)Jgs + (unsigned)(tox + 4 * c)));
+                for (int i = 0; i < (TS * TS / 4) / 64; ++i) {          // 48 rows x 12 groups of 4 pixels
+                    const int e = lane + 64 * i, r = e / (TS / 4), c = e - r * (TS / 4);
+                    __builtin_memcpy(&raw[i], (const void *)(uintptr_t)(Jg + ((unsigned)(toy + r) * (unsigned)Jgs +
+                                                                           (unsigned)(tox + 4 * c))), 8);
+                }
+#pragma unroll
+                for (int i = 0; i < (TS * TS / 4) / 64; ++i) {
+                    const int e = lane + 64 * i, r = e / (TS / 4), c = e - r * (TS / 4);
+                    *reinterpret_cast<uint4 *>(&jt[r * TS + 4 * c]) =
+                        make_uint4(scaled_pair<0>(raw[i].x, raw[i].y), scaled_pair<1>(raw[i].x, raw[i].y),
+                                   scaled_pair<2>(raw[i].x, raw[i].y), scaled_pair<3>(raw[i].x, raw[i].y));
                 }
             } else {
 #pragma unroll
-                for (int i = 0; i < (TS * TSD) / 64; ++i) {
-                    const int e = lane + 64 * i, r = e / TSD, c = e - r * TSD;
+                for (int i = 0; i < (TS * TS / 4) / 64; ++i) {
+                    const int e = lane + 64 * i, r = e / (TS / 4), c = e - r * (TS / 4);
                     const gptr_u8 row = Jg + (unsigned)reflect101(toy + r, h) * (unsigned)Jgs;
                     const int x = tox + 4 * c;
-                    jt[e] = (uint32_t)row[(unsigned)reflect101(x, w)] | ((uint32_t)row[(unsigned)reflect101(x + 1, w)] << 8) |
-                            ((uint32_t)row[(unsigned)reflect101(x + 2, w)] << 16) | ((uint32_t)row[(unsigned)reflect101(x + 3, w)] << 24);
+                    uint32_t b[5];
+#pragma unroll
+                    for (int q = 0; q < 5; ++q) b[q] = ((uint32_t)row[(unsigned)reflect101(x + q, w)] << GRAY_SHIFT) + 2u;
+                    *reinterpret_cast<uint4 *>(&jt[r * TS + 4 * c]) =
+                        make_uint4(b[0] | (b[1] << 16), b[1] | (b[2] << 16), b[2] | (b[3] << 16), b[3] | (b[4] << 16));
                 }
             }
         };
@@ -275,34 +337,46 @@ __global__ __launch_bounds__(64) void klt_kernel(KltArgs a)
                 break;
             }
             ensure_tile(inx, iny);
-            bilinear_weights(cxn - (float)inx, cyn - (float)iny, iw00, iw01, iw10, iw11);
+            uint32_t wA, wB;
+            bilinear_weights(cxn - (float)inx, cyn - (float)iny, wA, wB);
 
-            const uint8_t *jb = reinterpret_cast<const uint8_t *>(jt) +
-                                (iny - toy + half * HALF_ROWS) * TS + (inx - tox + cx);
-            const uint32_t wA = pack16(iw00, iw01), wB = pack16(iw10, iw11);
-            uint32_t jp = (uint32_t)jb[0] | ((uint32_t)jb[1] << 16);
+            const uint32_t *jrow = jt + (iny - toy + half * HALF_ROWS) * TS + (inx - tox + cx);
+            uint32_t jp = jrow[0];
             int sb1 = 0, sb2 = 0;
 #pragma unroll
             for (int m = 0; m < HALF_ROWS / 2; ++m) {
-                const uint32_t r1 = (uint32_t)jb[(2 * m + 1) * TS] | ((uint32_t)jb[(2 * m + 1) * TS + 1] << 16);
-                const uint32_t r2 = (uint32_t)jb[(2 * m + 2) * TS] | ((uint32_t)jb[(2 * m + 2) * TS + 1] << 16);
-                const int t0 = dot2(r1, wB, dot2(jp, wA, 1 << (W_BITS - 5 - 1))) >> (W_BITS - 5);
-                const int t1 = dot2(r2, wB, dot2(r1, wA, 1 << (W_BITS - 5 - 1))) >> (W_BITS - 5);
-                const uint32_t dp = pk_sub16(pack16(t0, t1), Ivp[m]);     // |diff| <= 8160: no int16 overflow
-                sb1 = dot2(dp, IXp[m], sb1);
+                const uint32_t r1 = jrow[(2 * m + 1) * TS], r2 = jrow[(2 * m + 2) * TS];
+                const int v0 = dot2(r1, wB, dot2(jp, wA, 0));
+                const int v1 = dot2(r2, wB, dot2(r1, wA, 0));
+                const uint32_t dp = pk_sub16(hi16_pair((uint32_t)v0, (uint32_t)v1), Ivp[m]);   // |diff| <= 8160
+                sb1 = dot2(dp, IXp[m], sb1);      // lanes / rows outside the window have IX = IY = 0
                 sb2 = dot2(dp, IYp[m], sb2);
                 jp = r2;
             }
-            const float b1 = wave_sum_to_float(sb1) * FLT_SCALE;
-            const float b2 = wave_sum_to_float(sb2) * FLT_SCALE;
+            float b1, b2;
+            if (all_small(sb1, sb2, 0)) {
+                b1 = (float)wave_sum_small(sb1) * FLT_SCALE;
+                b2 = (float)wave_sum_small(sb2) * FLT_SCALE;
+            } else {
+                b1 = wave_sum_wide(sb1) * FLT_SCALE;
+                b2 = wave_sum_wide(sb2) * FLT_SCALE;
+            }
             const float dx = (A12 * b2 - A22 * b1) * D;
             const float dy = (A12 * b1 - A11 * b2) * D;
 
             cxn += dx; cyn += dy;
             nx = cxn + half_win; ny = cyn + half_win;
 
-            if ((double)dx * (double)dx + (double)dy * (double)dy <= a.epsilon) break;
-            if (j > 0 && fabs((double)(dx + pdx)) < 0.01 && fabs((double)(dy + pdy)) < 0.01) {
+            // cv: delta.ddot(delta) <= epsilon, evaluated in double. The f32 value decides unless it
+            // falls within 1e-5 (relative) of the threshold -- f32 error is < 2e-7.
+            const float s2 = dx * dx + dy * dy;
+            bool converged;
+            if (s2 > eps_hi) converged = false;
+            else if (s2 < eps_lo) converged = true;
+            else converged = (double)dx * (double)dx + (double)dy * (double)dy <= a.epsilon;
+            if (converged) break;
+            // cv: |float sum| < 0.01 (double). 0.01f < 0.01, so for a float x: x < 0.01 <=> x <= 0.01f
+            if (j > 0 && fabsf(dx + pdx) <= 0.01f && fabsf(dy + pdy) <= 0.01f) {
                 nx -= dx * 0.5f; ny -= dy * 0.5f;
                 break;
             }
@@ -317,20 +391,22 @@ __global__ __launch_bounds__(64) void klt_kernel(KltArgs a)
                 st = 0;
             } else {
                 ensure_tile(inx, iny);
-                bilinear_weights(ex - (float)inx, ey - (float)iny, iw00, iw01, iw10, iw11);
-                const uint8_t *jb = reinterpret_cast<const uint8_t *>(jt) +
-                                    (iny - toy + half * HALF_ROWS) * TS + (inx - tox + cx);
-                int j0a = jb[0], j0b = jb[1];
+                uint32_t wA, wB;
+                bilinear_weights(ex - (float)inx, ey - (float)iny, wA, wB);
+                const uint32_t *jrow = jt + (iny - toy + half * HALF_ROWS) * TS + (inx - tox + cx);
+                uint32_t jp = jrow[0];
                 int sabs = 0;
+                const uint32_t ones = col_ok ? 0x00010001u : 0u;
 #pragma unroll
-                for (int k = 0; k < HALF_ROWS; ++k) {
-                    const int j1a = jb[(k + 1) * TS], j1b = jb[(k + 1) * TS + 1];
-                    const int tv = (__mul24(j0a, iw00) + __mul24(j0b, iw01) +
-                                    __mul24(j1a, iw10) + __mul24(j1b, iw11) +
-                                    (1 << (W_BITS - 5 - 1))) >> (W_BITS - 5);
-                    const int iv = (int)(short)((k & 1) ? (Ivp[k >> 1] >> 16) : (Ivp[k >> 1] & 0xFFFFu));
-                    sabs += (col_ok && k < nrows) ? abs(tv - iv) : 0;
-                    j0a = j1a; j0b = j1b;
+                for (int m = 0; m < HALF_ROWS / 2; ++m) {
+                    const uint32_t r1 = jrow[(2 * m + 1) * TS], r2 = jrow[(2 * m + 2) * TS];
+                    const int v0 = dot2(r1, wB, dot2(jp, wA, 0));
+                    const int v1 = dot2(r2, wB, dot2(r1, wA, 0));
+                    const short2v d = __builtin_bit_cast(short2v, pk_sub16(hi16_pair((uint32_t)v0, (uint32_t)v1), Ivp[m]));
+                    const uint32_t ad = __builtin_bit_cast(uint32_t, __builtin_elementwise_abs(d));
+                    const uint32_t msk = (m == HALF_ROWS / 2 - 1) ? ((ones & 0xFFFFu) | (last_ok << 16)) : ones;
+                    sabs = dot2(ad, msk, sabs);
+                    jp = r2;
                 }
                 // sum |diff| <= 961 * 8160 < 2^24: the oracle's float accumulation is exact too
                 errv = (float)wave_sum_small(sabs) * 1.f / (float)(32 * WIN * WIN);

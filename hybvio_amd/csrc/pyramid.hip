@@ -112,7 +112,10 @@ __global__ __launch_bounds__(256) void pyr_level_kernel(PyrLevelArgs a)
                 for (int i = 0; i < 4; ++i) {
                     const int dx = t0[i + 2] - t0[i];
                     const int dy = (t1[i] + t1[i + 2]) * 3 + t1[i + 1] * 10;
-                    o[i] = ((uint32_t)dx & 0xFFFFu) | ((uint32_t)dy << 16);
+                    // stored as 4*d + 2 (|.| <= 16322 fits int16): the LK kernel then takes the high
+                    // half of a v_dot2 chain instead of add-and-shift (klt.hip); hv_pyramid_download
+                    // undoes it with an arithmetic >> 2
+                    o[i] = ((uint32_t)((dx << GRAD_SHIFT) + 2) & 0xFFFFu) | ((uint32_t)((dy << GRAD_SHIFT) + 2) << 16);
                 }
                 uint32_t *d = dbase + (long long)y * a.dstride + x;
                 if (x + 3 < a.w) {
