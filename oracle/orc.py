@@ -127,3 +127,187 @@ def optical_flow_compute(prev: Pyramid, cur: Pyramid, prev_corners, corners=None
                                         _p(st, i32p), int(use_init), win, max_level, max_iter, eps, min_eig)
     assert rc == 0
     return out, st
+
+
+# ---------------------------------------------------------------------------------------------
+# EKF oracle (oracle/ekf_oracle.c)
+# ---------------------------------------------------------------------------------------------
+
+class EkfParams(C.Structure):
+    _fields_ = [("cameraTrailLength", C.c_int), ("hybridMapSize", C.c_int)] + [
+        (k, C.c_double) for k in (
+            "noiseScale", "gravity", "augmentR", "initZuptR", "rotationZuptR",
+            "noiseInitialPos", "noiseInitialOri", "noiseInitialVel", "noiseInitialPosTrail", "noiseInitialOriTrail",
+            "noiseInitialBGA", "noiseInitialBAA", "noiseInitialBAT", "noiseInitialSFT",
+            "noiseProcessAcc", "noiseProcessGyro", "noiseProcessBAA", "noiseProcessBGA",
+            "noiseProcessBAARev", "noiseProcessBGARev")]
+
+
+_EKF_READY = False
+
+
+def _ekf_lib():
+    global _EKF_READY
+    L = lib()
+    if not _EKF_READY:
+        vp, d, i = C.c_void_p, C.c_double, C.c_int
+        sig = {
+            "orc_ekf_default_params": (None, [C.POINTER(EkfParams)]),
+            "orc_ekf_create": (vp, [C.POINTER(EkfParams)]), "orc_ekf_clone": (vp, [vp]), "orc_ekf_free": (None, [vp]),
+            "orc_ekf_state_dim": (i, [vp]), "orc_ekf_state": (f64p, [vp]), "orc_ekf_cov": (f64p, [vp]),
+            "orc_ekf_process_noise": (f64p, [vp]), "orc_ekf_dydx": (f64p, [vp]),
+            "orc_ekf_platform_time": (d, [vp]), "orc_ekf_pose_count": (i, [vp]), "orc_ekf_was_stationary": (i, [vp]),
+            "orc_ekf_history_time": (d, [vp, i]), "orc_ekf_set_first_sample_time": (None, [vp, d]),
+            "orc_ekf_normalize_quaternions": (None, [vp, i]), "orc_ekf_maintain_psd": (None, [vp]),
+            "orc_ekf_initialize_orientation": (None, [vp, f64p]), "orc_ekf_predict": (None, [vp, d, f64p, f64p]),
+            "orc_ekf_update_zupt": (None, [vp, d]), "orc_ekf_update_zupt_initialization": (None, [vp]),
+            "orc_ekf_update_zrupt": (None, [vp, f64p]), "orc_ekf_update_pseudo_velocity": (None, [vp, d, d]),
+            "orc_ekf_update_position": (None, [vp, f64p, d]), "orc_ekf_update_zero_height": (None, [vp, d]),
+            "orc_ekf_update_orientation": (None, [vp, f64p, d]),
+            "orc_ekf_get_inertial_state": (None, [vp, f64p, f64p]), "orc_ekf_set_inertial_state": (None, [vp, f64p, f64p]),
+            "orc_ekf_translate_to": (None, [vp, f64p]), "orc_ekf_transform_to": (None, [vp, f64p, f64p, i]),
+            "orc_ekf_visual_track_outlier_check": (i, [vp, i, i, f64p, f64p, f64p, d, d, f64p]),
+            "orc_ekf_update_visual_track": (None, [vp, i, i, f64p, f64p, f64p, d]),
+            "orc_ekf_update_visual_pose_augmentation": (None, [vp, i]), "orc_ekf_update_undo_augmentation": (None, [vp]),
+            "orc_ekf_condition_on_last_pose": (None, [vp]), "orc_ekf_lock_biases": (None, [vp]),
+            "orc_ekf_map_point_state_index": (i, [vp, i]), "orc_ekf_insert_map_point": (None, [vp, i, f64p]),
+            "orc_ldlt_quadratic_form": (d, [i, f64p, f64p]),
+            "orc_quat2rmat": (None, [f64p, f64p]), "orc_quat2rmat_d": (None, [f64p, f64p, f64p]),
+        }
+        for name, (res, args) in sig.items():
+            fn = getattr(L, name)
+            fn.restype, fn.argtypes = res, args
+        _EKF_READY = True
+    return L
+
+
+def _d(a):
+    return np.ascontiguousarray(a, np.float64)
+
+
+def ekf_default_params(**over):
+    p = EkfParams()
+    _ekf_lib().orc_ekf_default_params(C.byref(p))
+    for k, v in over.items():
+        setattr(p, k, v)
+    return p
+
+
+def ldlt_quadratic_form(M, v):
+    M, v = np.asfortranarray(M, np.float64), _d(v)
+    return _ekf_lib().orc_ldlt_quadratic_form(len(v), M.ctypes.data_as(f64p), _p(v, f64p))
+
+
+def quat2rmat_d(q):
+    q = _d(q)
+    R, dR = np.zeros(9), np.zeros(36)
+    _ekf_lib().orc_quat2rmat_d(_p(q, f64p), _p(R, f64p), _p(dR, f64p))
+    return R.reshape(3, 3).T.copy(), [dR[9 * k:9 * k + 9].reshape(3, 3).T.copy() for k in range(4)]
+
+
+class _Owned(np.ndarray):
+    """ndarray view into C-owned storage that keeps its owner alive."""
+    _owner = None
+
+
+def _view(ptr, shape, owner):
+    a = np.ctypeslib.as_array(ptr, shape).view(_Owned)
+    a._owner = owner
+    return a
+
+
+class Ekf:
+    """odometry::EKF restatement (src/odometry/ekf.hpp:62-174). Matrices are numpy (row, col)."""
+    INLIER, NOT_COMPUTED, RMSE, CHI2 = 0, 1, 2, 3
+
+    def __init__(self, params=None, _handle=None):
+        L = _ekf_lib()
+        self.params = params if params is not None else ekf_default_params()
+        self._h = _handle if _handle is not None else L.orc_ekf_create(C.byref(self.params))
+        self.n = L.orc_ekf_state_dim(self._h)
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            _ekf_lib().orc_ekf_free(self._h)
+            self._h = None
+
+    def clone(self):
+        return Ekf(self.params, _ekf_lib().orc_ekf_clone(self._h))
+
+    # views into the C object's storage
+    @property
+    def m(self):
+        return _view(_ekf_lib().orc_ekf_state(self._h), (self.n,), self)
+
+    @property
+    def P(self):   # column-major storage exposed as an (n, n) array with P[i, j] semantics
+        return _view(_ekf_lib().orc_ekf_cov(self._h), (self.n, self.n), self).T
+
+    @property
+    def Q(self):
+        return _view(_ekf_lib().orc_ekf_process_noise(self._h), (12, 12), self).T
+
+    @property
+    def dydx(self):
+        return _view(_ekf_lib().orc_ekf_dydx(self._h), (20, 20), self).T
+
+    def set_state(self, m):
+        self.m[:] = m
+
+    def set_cov(self, P):
+        self.P[:, :] = P
+
+    def __getattr__(self, name):
+        # thin pass-through for the scalar-argument methods
+        simple = {"update_zupt", "update_zupt_initialization", "update_zero_height", "update_pseudo_velocity",
+                  "update_visual_pose_augmentation", "update_undo_augmentation", "condition_on_last_pose",
+                  "lock_biases", "maintain_psd", "normalize_quaternions", "set_first_sample_time",
+                  "platform_time", "pose_count", "was_stationary", "history_time", "map_point_state_index"}
+        if name in simple:
+            fn = getattr(_ekf_lib(), "orc_ekf_" + name)
+            return lambda *a: fn(self._h, *a)
+        raise AttributeError(name)
+
+    def initialize_orientation(self, xa):
+        _ekf_lib().orc_ekf_initialize_orientation(self._h, _p(_d(xa), f64p))
+
+    def predict(self, t, xg, xa):
+        _ekf_lib().orc_ekf_predict(self._h, t, _p(_d(xg), f64p), _p(_d(xa), f64p))
+
+    def update_zrupt(self, xg):
+        _ekf_lib().orc_ekf_update_zrupt(self._h, _p(_d(xg), f64p))
+
+    def update_position(self, pos, r):
+        _ekf_lib().orc_ekf_update_position(self._h, _p(_d(pos), f64p), r)
+
+    def update_orientation(self, q, r):
+        _ekf_lib().orc_ekf_update_orientation(self._h, _p(_d(q), f64p), r)
+
+    def get_inertial_state(self):
+        mean, cov = np.zeros(20), np.zeros(400)
+        _ekf_lib().orc_ekf_get_inertial_state(self._h, _p(mean, f64p), _p(cov, f64p))
+        return mean, cov.reshape(20, 20).T.copy()
+
+    def set_inertial_state(self, mean, cov):
+        _ekf_lib().orc_ekf_set_inertial_state(self._h, _p(_d(mean), f64p), np.asfortranarray(cov, np.float64).ctypes.data_as(f64p))
+
+    def translate_to(self, pos):
+        _ekf_lib().orc_ekf_translate_to(self._h, _p(_d(pos), f64p))
+
+    def transform_to(self, pos, q, i=-1):
+        _ekf_lib().orc_ekf_transform_to(self._h, _p(_d(pos), f64p), _p(_d(q), f64p), i)
+
+    def visual_track_outlier_check(self, H, f, y, r, rmse_threshold=-1.0):
+        Hf = np.asfortranarray(H, np.float64)
+        chi2 = C.c_double()
+        st = _ekf_lib().orc_ekf_visual_track_outlier_check(self._h, Hf.shape[0], Hf.shape[1], Hf.ctypes.data_as(f64p),
+                                                           _p(_d(f), f64p), _p(_d(y), f64p), r, rmse_threshold, C.byref(chi2))
+        return st, chi2.value
+
+    def update_visual_track(self, H, f, y, r):
+        Hf = np.asfortranarray(H, np.float64)
+        _ekf_lib().orc_ekf_update_visual_track(self._h, Hf.shape[0], Hf.shape[1], Hf.ctypes.data_as(f64p),
+                                               _p(_d(f), f64p), _p(_d(y), f64p), r)
+
+    def insert_map_point(self, idx, pf):
+        _ekf_lib().orc_ekf_insert_map_point(self._h, idx, _p(_d(pf), f64p))
