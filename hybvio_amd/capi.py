@@ -41,6 +41,16 @@ class Params(C.Structure):
                 ("max_tracks", C.c_int), ("pool_size", C.c_int), ("max_pairs", C.c_int)]
 
 
+class EkfParams(C.Structure):
+    _fields_ = [("cameraTrailLength", C.c_int), ("hybridMapSize", C.c_int)] + [
+        (k, C.c_double) for k in (
+            "noiseScale", "gravity", "augmentR", "initZuptR", "rotationZuptR",
+            "noiseInitialPos", "noiseInitialOri", "noiseInitialVel", "noiseInitialPosTrail", "noiseInitialOriTrail",
+            "noiseInitialBGA", "noiseInitialBAA", "noiseInitialBAT", "noiseInitialSFT",
+            "noiseProcessAcc", "noiseProcessGyro", "noiseProcessBAA", "noiseProcessBGA",
+            "noiseProcessBAARev", "noiseProcessBGARev")]
+
+
 class HvError(RuntimeError):
     pass
 
@@ -67,6 +77,29 @@ PROTOTYPES = {
     "hv_optical_flow_compute": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, f32p, f32p, i32p, C.c_int, C.c_int]),
     "hv_klt_track_batch_dev": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
                                          C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int]),
+    "hv_ekf_default_params": (None, [C.POINTER(EkfParams)]),
+    "hv_ekf_create": (C.c_int, [C.c_void_p, C.POINTER(EkfParams), C.c_int, C.POINTER(C.c_void_p)]),
+    "hv_ekf_destroy": (None, [C.c_void_p]),
+    "hv_ekf_state_dim": (C.c_int, [C.c_void_p]),
+    "hv_ekf_batch": (C.c_int, [C.c_void_p]),
+    "hv_ekf_set_state": (C.c_int, [C.c_void_p, C.c_int, f64p, f64p]),
+    "hv_ekf_get_state": (C.c_int, [C.c_void_p, C.c_int, f64p, f64p]),
+    "hv_ekf_get_means": (C.c_int, [C.c_void_p, f64p]),
+    "hv_ekf_set_process_noise": (C.c_int, [C.c_void_p, C.c_int, f64p]),
+    "hv_ekf_get_dydx": (C.c_int, [C.c_void_p, C.c_int, f64p]),
+    "hv_ekf_device_pointers": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]),
+    "hv_ekf_predict": (C.c_int, [C.c_void_p, f64p, f64p, f64p]),
+    "hv_ekf_predict_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "hv_ekf_update": (C.c_int, [C.c_void_p, C.c_int, C.c_int, f64p, f64p, f64p, u8p, C.c_int]),
+    "hv_ekf_visual_gate": (C.c_int, [C.c_void_p, C.c_int, C.c_int, f64p, f64p, C.c_double, f64p, i32p]),
+    "hv_ekf_visual_update": (C.c_int, [C.c_void_p, C.c_int, C.c_int, f64p, f64p, C.c_double, u8p]),
+    "hv_ekf_visual_dev": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_double, C.c_int,
+                                    C.c_void_p, C.c_void_p]),
+    "hv_ekf_augment": (C.c_int, [C.c_void_p, i32p, u8p]),
+    "hv_ekf_undo_augment": (C.c_int, [C.c_void_p, u8p]),
+    "hv_ekf_symmetrize": (C.c_int, [C.c_void_p]),
+    "hv_ekf_normalize_quaternions": (C.c_int, [C.c_void_p, C.c_int]),
+    "hv_ekf_transform": (C.c_int, [C.c_void_p, C.c_int, f64p, f64p, f64p]),
     "hv_profile_enable": (C.c_int, [C.c_void_p, C.c_int]),
     "hv_profile_reset": (C.c_int, [C.c_void_p]),
     "hv_profile_read": (C.c_int, [C.c_void_p, C.c_int, f64p, C.POINTER(C.c_longlong)]),
@@ -119,6 +152,8 @@ class Context:
 
     def close(self):
         if getattr(self, "_h", None):
+            for child in list(getattr(self, "_children", [])):   # hv_ekf objects must die before their hv_ctx
+                child.close()
             lib().hv_destroy(self._h)
             self._h = None
 
@@ -216,3 +251,143 @@ class Context:
         ms, n = C.c_double(), C.c_longlong()
         self._chk(lib().hv_profile_read(self._h, kernel_id, C.byref(ms), C.byref(n)), "hv_profile_read")
         return ms.value, n.value
+
+
+def ekf_default_params(**over) -> EkfParams:
+    p = EkfParams()
+    lib().hv_ekf_default_params(C.byref(p))
+    for k, v in over.items():
+        setattr(p, k, v)
+    return p
+
+
+def _f(a):
+    return np.ascontiguousarray(a, np.float64)
+
+
+class EkfBatch:
+    """hv_ekf: a batch of independent filters on one Context (batch = 1: the reference's EKF)."""
+
+    def __init__(self, ctx: Context, params: EkfParams | None = None, batch: int = 1):
+        self.ctx, self.batch = ctx, batch
+        self.params = params if params is not None else ekf_default_params()
+        self._h = C.c_void_p()
+        rc = lib().hv_ekf_create(ctx._h, C.byref(self.params), batch, C.byref(self._h))
+        if rc != 0:
+            self._h = None
+            raise HvError(f"hv_ekf_create: {lib().hv_status_string(rc).decode()}")
+        self.n = lib().hv_ekf_state_dim(self._h)
+        if not hasattr(ctx, "_children"):
+            ctx._children = []
+        ctx._children.append(self)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().hv_ekf_destroy(self._h)
+            self._h = None
+            if self in getattr(self.ctx, "_children", []):
+                self.ctx._children.remove(self)
+
+    def __del__(self):
+        self.close()
+
+    def _chk(self, rc, what):
+        self.ctx._chk(rc, what)
+
+    def set_state(self, b, m=None, P=None):
+        mm = _f(m) if m is not None else None
+        PP = np.asfortranarray(P, np.float64) if P is not None else None
+        self._chk(lib().hv_ekf_set_state(self._h, b, _p(mm, f64p), PP.ctypes.data_as(f64p) if PP is not None else None),
+                  "hv_ekf_set_state")
+
+    def get_state(self, b):
+        m, P = np.zeros(self.n), np.zeros((self.n, self.n))
+        self._chk(lib().hv_ekf_get_state(self._h, b, _p(m, f64p), _p(P, f64p)), "hv_ekf_get_state")
+        return m, P.T.copy()          # column-major buffer -> P[i, j]
+
+    def get_means(self):
+        m = np.zeros((self.batch, self.n))
+        self._chk(lib().hv_ekf_get_means(self._h, _p(m, f64p)), "hv_ekf_get_means")
+        return m
+
+    def set_process_noise(self, b, Q):
+        self._chk(lib().hv_ekf_set_process_noise(self._h, b, np.asfortranarray(Q, np.float64).ctypes.data_as(f64p)),
+                  "hv_ekf_set_process_noise")
+
+    def get_dydx(self, b):
+        F = np.zeros((20, 20))
+        self._chk(lib().hv_ekf_get_dydx(self._h, b, _p(F, f64p)), "hv_ekf_get_dydx")
+        return F.T.copy()
+
+    def device_pointers(self):
+        m, P = C.c_void_p(), C.c_void_p()
+        self._chk(lib().hv_ekf_device_pointers(self._h, C.byref(m), C.byref(P)), "hv_ekf_device_pointers")
+        return m.value, P.value
+
+    def predict(self, dt, gyro, acc):
+        dt, gyro, acc = _f(np.broadcast_to(dt, (self.batch,))), _f(np.broadcast_to(gyro, (self.batch, 3))), _f(np.broadcast_to(acc, (self.batch, 3)))
+        self._chk(lib().hv_ekf_predict(self._h, _p(dt, f64p), _p(gyro, f64p), _p(acc, f64p)), "hv_ekf_predict")
+        self.ctx.synchronize()
+
+    def predict_dev(self, dt_dev, gyro_dev, acc_dev):
+        self._chk(lib().hv_ekf_predict_dev(self._h, C.c_void_p(dt_dev), C.c_void_p(gyro_dev), C.c_void_p(acc_dev)),
+                  "hv_ekf_predict_dev")
+
+    @staticmethod
+    def _pack_H(H, batch):
+        H = np.asarray(H, np.float64)
+        if H.ndim == 2:
+            H = np.broadcast_to(H, (batch,) + H.shape)
+        nr, l = H.shape[1:]
+        return np.ascontiguousarray(np.transpose(H, (0, 2, 1))), nr, l     # [b][col][row] == column-major per filter
+
+    def update(self, H, y, r_diag, active=None, normalize_all=False):
+        Hc, nr, l = self._pack_H(H, self.batch)
+        y = _f(np.broadcast_to(y, (self.batch, nr)))
+        rd = _f(np.broadcast_to(r_diag, (self.batch,)))
+        act = np.ascontiguousarray(active, np.uint8) if active is not None else None
+        self._chk(lib().hv_ekf_update(self._h, nr, l, _p(Hc, f64p), _p(y, f64p), _p(rd, f64p), _p(act, u8p),
+                                      int(normalize_all)), "hv_ekf_update")
+        self.ctx.synchronize()
+
+    def visual_gate(self, H, v, r):
+        Hc, nr, l = self._pack_H(H, self.batch)
+        v = _f(np.broadcast_to(v, (self.batch, nr)))
+        chi2, st = np.zeros(self.batch), np.zeros(self.batch, np.int32)
+        self._chk(lib().hv_ekf_visual_gate(self._h, nr, l, _p(Hc, f64p), _p(v, f64p), r, _p(chi2, f64p), _p(st, i32p)),
+                  "hv_ekf_visual_gate")
+        return chi2, st
+
+    def visual_update(self, H, v, r, active=None):
+        Hc, nr, l = self._pack_H(H, self.batch)
+        v = _f(np.broadcast_to(v, (self.batch, nr)))
+        act = np.ascontiguousarray(active, np.uint8) if active is not None else None
+        self._chk(lib().hv_ekf_visual_update(self._h, nr, l, _p(Hc, f64p), _p(v, f64p), r, _p(act, u8p)),
+                  "hv_ekf_visual_update")
+        self.ctx.synchronize()
+
+    def visual_dev(self, nr, l, H_dev, v_dev, r, mode, chi2_dev=0, status_dev=0):
+        self._chk(lib().hv_ekf_visual_dev(self._h, nr, l, C.c_void_p(H_dev), C.c_void_p(v_dev), r, mode,
+                                          C.c_void_p(chi2_dev), C.c_void_p(status_dev)), "hv_ekf_visual_dev")
+
+    def augment(self, discarded=None, active=None):
+        d = np.ascontiguousarray(np.broadcast_to(discarded, (self.batch,)), np.int32) if discarded is not None else None
+        act = np.ascontiguousarray(active, np.uint8) if active is not None else None
+        self._chk(lib().hv_ekf_augment(self._h, _p(d, i32p), _p(act, u8p)), "hv_ekf_augment")
+        self.ctx.synchronize()
+
+    def undo_augment(self, active=None):
+        act = np.ascontiguousarray(active, np.uint8) if active is not None else None
+        self._chk(lib().hv_ekf_undo_augment(self._h, _p(act, u8p)), "hv_ekf_undo_augment")
+        self.ctx.synchronize()
+
+    def symmetrize(self):
+        self._chk(lib().hv_ekf_symmetrize(self._h), "hv_ekf_symmetrize")
+
+    def normalize_quaternions(self, only_current=False):
+        self._chk(lib().hv_ekf_normalize_quaternions(self._h, int(only_current)), "hv_ekf_normalize_quaternions")
+
+    def transform(self, b, pC, qC, tr):
+        self._chk(lib().hv_ekf_transform(self._h, b, _p(_f(pC), f64p), _p(_f(qC), f64p), _p(_f(tr), f64p)),
+                  "hv_ekf_transform")
+        self.ctx.synchronize()

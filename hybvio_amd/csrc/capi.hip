@@ -98,8 +98,11 @@ bool slot_ok(Ctx *c, int s) { return s >= 0 && s < c->p.pool_size && c->slot_use
 using hv::Ctx;
 
 extern "C" {
-
 struct hv_ctx { Ctx c; };
+}
+namespace hv { Ctx *ctx_of(hv_ctx *h) { return h ? &h->c : nullptr; } }
+
+extern "C" {
 
 void hv_default_params(hv_params *p)
 {

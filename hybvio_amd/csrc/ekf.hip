@@ -1,0 +1,902 @@
+// EKF covariance algebra for a batch of independent filters, one workgroup per filter.
+//
+// Replaces the dense parts of odometry::EKF (reference: src/odometry/ekf.cpp; oracle:
+// oracle/ekf_oracle.c). State m (n) and covariance P (n x n, f64, column-major as Eigen) live in
+// HBM / L2; the mean-side scalar bookkeeping (sample times, augment counters, rate limits) stays
+// in the host adapter. Design for CDNA4:
+//   * dense products (H*P, HP*H', P -= Y'Y) run on the f64 matrix cores
+//     (v_mfma_f64_16x16x4_f64): one wavefront owns a 16x16 output tile and streams its A/B
+//     operands straight from L2/LDS -- at n = 160 everything is cache resident, so no staging
+//     pipeline is needed and each MFMA retires 1024 MACs for two operand loads;
+//   * the innovation solve uses ONE right-looking Cholesky sweep over the tall matrix
+//     T = [S ; (HP)' ; v'] held in LDS: afterwards the lower rows are Y' = (L^-1 HP)' and
+//     z' = (L^-1 v)', so K is never formed: chi2 = ns z'z, m += Y'z, P -= Y'Y (symmetric by
+//     construction). The reference forms K = (S^-1 HP)' with a pivoted LDLT and P -= K*HP; the
+//     two are algebraically identical, parity is checked to 1e-5 relative (measured ~1e-13);
+//   * pose augmentation: the Joseph form (I-KH) P (I-KH)' + K R K' is expanded around the 7-row
+//     +-1 matrix visAugH into two rank-7 corrections, O(14 n^2) instead of two dense n^3 products,
+//     fused with the shift A P A' + Q (a gather) and the (P+P')/2 symmetrisation.
+#include <math.h>
+
+#include "chi2inv95.h"
+#include "hv_internal.hpp"
+
+namespace hv {
+
+namespace {
+
+enum { POS = 0, VEL = 3, ORI = 6, BGA = 10, BAA = 13, BAT = 16, SFT = 19, CAM = 20, INER = 20, POSE = 7, QD = 12 };
+enum { Q_ACC = 0, Q_GYRO = 3, Q_BGA_DRIFT = 6, Q_BAA_DRIFT = 9 };
+
+typedef double double4v __attribute__((ext_vector_type(4)));
+
+__device__ const double d_chi2inv95[HV_CHI2INV95_N] = { HV_CHI2INV95_VALUES };
+
+// One wavefront: acc(16x16) += A(16 x K) * B(K x 16); a_at(i, k) / b_at(k, j) return 0 outside
+// their matrices. f64 MFMA operand layout: lane l carries A[l & 15][l >> 4], B[l >> 4][l & 15];
+// result register q of lane l is C[(l >> 4) + 4 q][l & 15].
+template <class FA, class FB>
+__device__ __forceinline__ double4v mfma_tile(int K, FA a_at, FB b_at)
+{
+    const int lane = threadIdx.x & 63, r = lane & 15, q = lane >> 4;
+    double4v acc = {0.0, 0.0, 0.0, 0.0};
+    for (int k0 = 0; k0 < K; k0 += 4)
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a_at(r, k0 + q), b_at(k0 + q, r), acc, 0, 0, 0);
+    return acc;
+}
+
+__device__ __forceinline__ void normalize4(double *q)
+{
+    const double nn = sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+    if (nn > 0.0) { q[0] /= nn; q[1] /= nn; q[2] /= nn; q[3] /= nn; }
+}
+
+// ---------------------------------------------------------------------------------------------
+// predict (ekf.cpp:320-514)
+// ---------------------------------------------------------------------------------------------
+struct PredictArgs {
+    int n, batch;
+    double *m, *P, *Q, *dydx;            // per filter: n, n*n, 144, 400
+    const double *dt, *gyro, *acc;        // device arrays [batch], [batch*3], [batch*3] (or null -> immediates)
+    double dt0, g0[3], a0[3];
+    double noise_scale, gravity, baa, baa_rev, bga, bga_rev;
+};
+
+__device__ void quat2rmat_d(const double q[4], double R[9], double dR[36])   // util.cpp:10-47, column-major
+{
+    const double rows[4][9] = {
+        { 2*q[0], -2*q[3],  2*q[2],   2*q[3],  2*q[0], -2*q[1],  -2*q[2],  2*q[1],  2*q[0] },
+        { 2*q[1],  2*q[2],  2*q[3],   2*q[2], -2*q[1], -2*q[0],   2*q[3],  2*q[0], -2*q[1] },
+        {-2*q[2],  2*q[1],  2*q[0],   2*q[1],  2*q[2],  2*q[3],  -2*q[0],  2*q[3], -2*q[2] },
+        {-2*q[3], -2*q[0],  2*q[1],   2*q[0], -2*q[3],  2*q[2],   2*q[1],  2*q[2],  2*q[3] } };
+    for (int k = 0; k < 4; k++)
+        for (int i = 0; i < 3; i++)
+            for (int j = 0; j < 3; j++) dR[9 * k + 3 * j + i] = rows[k][3 * i + j];
+    const double Rr[9] = {
+        q[0]*q[0]+q[1]*q[1]-q[2]*q[2]-q[3]*q[3], 2*q[1]*q[2] - 2*q[0]*q[3], 2*q[1]*q[3] + 2*q[0]*q[2],
+        2*q[1]*q[2] + 2*q[0]*q[3], q[0]*q[0]-q[1]*q[1]+q[2]*q[2]-q[3]*q[3], 2*q[2]*q[3] - 2*q[0]*q[1],
+        2*q[1]*q[3] - 2*q[0]*q[2], 2*q[2]*q[3] + 2*q[0]*q[1], q[0]*q[0]-q[1]*q[1]-q[2]*q[2]+q[3]*q[3] };
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) R[3 * j + i] = Rr[3 * i + j];
+}
+
+#define F_(i, j) F[(j) * INER + (i)]
+#define L_(i, j) Lm[(j) * INER + (i)]
+
+__global__ __launch_bounds__(256) void ekf_predict_kernel(PredictArgs a)
+{
+    __shared__ double F[INER * INER], Lm[INER * QD], Qs[QD * QD], LQ[INER * QD], P00[INER * INER], FP[INER * INER];
+    const int b = blockIdx.x, t = threadIdx.x, n = a.n;
+    double *m = a.m + (size_t)b * n, *P = a.P + (size_t)b * n * n, *Q = a.Q + (size_t)b * QD * QD;
+    const double dt = a.dt ? a.dt[b] : a.dt0;
+    if (!(dt > 0.0)) return;                       // ekf.cpp:365-368 (the host adapter keeps the clock)
+
+    for (int i = t; i < INER * INER; i += 256) F[i] = (i % (INER + 1) == 0) ? 1.0 : 0.0;
+    for (int i = t; i < INER * QD; i += 256) Lm[i] = 0.0;
+    for (int i = t; i < QD * QD; i += 256) Qs[i] = Q[i];
+    __syncthreads();
+
+    if (t == 0) {
+        double xg[3], xa[3];
+        for (int i = 0; i < 3; i++) { xg[i] = a.gyro ? a.gyro[3 * b + i] : a.g0[i]; xa[i] = a.acc ? a.acc[3 * b + i] : a.a0[i]; }
+        if (a.baa > 0.0) {                          // ekf.cpp:397-404
+            double v = a.noise_scale * a.baa * a.baa;
+            if (a.baa_rev > 0.0) v *= (1 - exp(-2 * dt * a.baa_rev)) / (2 * a.baa_rev);
+            for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) Qs[(Q_BAA_DRIFT + j) * QD + Q_BAA_DRIFT + i] = (i == j) ? v : 0.0;
+        }
+        if (a.bga > 0.0) {                          // ekf.cpp:405-412
+            double v = a.noise_scale * a.bga * a.bga;
+            if (a.bga_rev > 0.0) v *= (1 - exp(-2 * dt * a.bga_rev)) / (2 * a.bga_rev);
+            for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) Qs[(Q_BGA_DRIFT + j) * QD + Q_BGA_DRIFT + i] = (i == j) ? v : 0.0;
+        }
+        // A = exp(-dt/2 Omega(w)) = cos(th) I + sin(th)/th S, th = |w| dt/2   (ekf.cpp:415-425)
+        const double w[3] = { xg[0] - m[BGA], xg[1] - m[BGA + 1], xg[2] - m[BGA + 2] };
+        const double Srow[16] = { 0, -w[0], -w[1], -w[2],  w[0], 0, -w[2], w[1],  w[1], w[2], 0, -w[0],  w[2], -w[1], w[0], 0 };
+        double A[16];                               // column-major 4x4
+        {
+            const double th = sqrt(w[0]*w[0] + w[1]*w[1] + w[2]*w[2]) * dt / 2;
+            const double c = cos(th), sc = th > 1e-8 ? sin(th) / th : 1.0 - th * th / 6.0;
+            for (int i = 0; i < 4; i++) for (int j = 0; j < 4; j++) A[4 * j + i] = sc * Srow[4 * i + j] * (-dt / 2) + (i == j ? c : 0.0);
+        }
+        double qn[4], R[9], dR[36], prevQ[4];
+        for (int i = 0; i < 4; i++) { double s = 0; for (int j = 0; j < 4; j++) s += A[4 * j + i] * m[ORI + j]; qn[i] = s; prevQ[i] = m[ORI + i]; }
+        quat2rmat_d(qn, R, dR);
+        double Txab[3];
+        for (int i = 0; i < 3; i++) Txab[i] = m[BAT + i] * xa[i] - m[BAA + i];
+        for (int i = 0; i < 3; i++) m[POS + i] += m[VEL + i] * dt;
+        const double grav[3] = { 0.0, 0.0, -a.gravity };
+        for (int i = 0; i < 3; i++) { double s = 0; for (int j = 0; j < 3; j++) s += R[3 * i + j] * Txab[j]; m[VEL + i] += (s + grav[i]) * dt; }
+        for (int i = 0; i < 4; i++) m[ORI + i] = qn[i];
+        if (a.baa > 0.0) { const double f = exp(-dt * a.baa_rev); for (int i = 0; i < 3; i++) m[BAA + i] *= f; }
+        if (a.bga > 0.0) { const double f = exp(-dt * a.bga_rev); for (int i = 0; i < 3; i++) m[BGA + i] *= f; }
+
+        for (int i = 0; i < 3; i++) F_(POS + i, VEL + i) = dt;
+        double T34[12];
+        for (int k = 0; k < 4; k++) for (int i = 0; i < 3; i++) { double s = 0; for (int j = 0; j < 3; j++) s += dR[9 * k + 3 * i + j] * Txab[j]; T34[3 * k + i] = s * dt; }
+        for (int i = 0; i < 3; i++) for (int j = 0; j < 4; j++) { double s = 0; for (int k = 0; k < 4; k++) s += T34[3 * k + i] * A[4 * j + k]; F_(VEL + i, ORI + j) = s; }
+        for (int i = 0; i < 4; i++) for (int j = 0; j < 4; j++) F_(ORI + i, ORI + j) = A[4 * j + i];
+        for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) L_(VEL + i, Q_ACC + j) = R[3 * i + j] * dt;
+        const double h = dt / 2;
+        const double dS[3][16] = {
+            { 0, h, 0, 0,  -h, 0, 0, 0,  0, 0, 0, h,  0, 0, -h, 0 },
+            { 0, 0, h, 0,  0, 0, 0, -h,  -h, 0, 0, 0,  0, h, 0, 0 },
+            { 0, 0, 0, h,  0, 0, h, 0,  0, -h, 0, 0,  -h, 0, 0, 0 } };
+        for (int g = 0; g < 3; g++) {
+            double t1[4];
+            for (int i = 0; i < 4; i++) { double s = 0; for (int j = 0; j < 4; j++) s += dS[g][4 * i + j] * prevQ[j]; t1[i] = s; }
+            for (int i = 0; i < 4; i++) { double s = 0; for (int j = 0; j < 4; j++) s += A[4 * j + i] * t1[j]; L_(ORI + i, Q_GYRO + g) = s; }
+        }
+        for (int i = 0; i < 3; i++) { L_(BGA + i, Q_BGA_DRIFT + i) = 1.0; L_(BAA + i, Q_BAA_DRIFT + i) = 1.0; }
+        for (int i = 0; i < 3; i++) for (int g = 0; g < 3; g++) { double s = 0; for (int k = 0; k < 4; k++) s += F_(VEL + i, ORI + k) * L_(ORI + k, Q_GYRO + g); L_(VEL + i, Q_GYRO + g) = s; }
+        for (int i = 0; i < 3; i++) for (int g = 0; g < 3; g++) F_(VEL + i, BGA + g) = -L_(VEL + i, Q_GYRO + g);
+        for (int i = 0; i < 4; i++) for (int g = 0; g < 3; g++) F_(ORI + i, BGA + g) = -L_(ORI + i, Q_GYRO + g);
+        for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) { F_(VEL + i, BAA + j) = -R[3 * i + j] * dt; F_(VEL + i, BAT + j) = R[3 * i + j] * xa[j] * dt; }
+    }
+    __syncthreads();
+
+    // P00 = F P00 F' + L Q L'; P10 = P10 F'; P01 = F P01 (ekf.cpp:504-508). Every output depends only
+    // on its own row / column of the old P, so the update is done in place.
+    for (int i = t; i < INER * INER; i += 256) { P00[i] = P[(size_t)(i / INER) * n + (i % INER)]; a.dydx[(size_t)b * INER * INER + i] = F[i]; }
+    for (int i = t; i < QD * QD; i += 256) Q[i] = Qs[i];
+    for (int e = t; e < INER * QD; e += 256) {
+        const int i = e % INER, j = e / INER;
+        double s = 0; for (int k = 0; k < QD; k++) s += L_(i, k) * Qs[j * QD + k];
+        LQ[e] = s;
+    }
+    __syncthreads();
+    for (int e = t; e < INER * INER; e += 256) {
+        const int i = e % INER, j = e / INER;
+        double s = 0; for (int k = 0; k < INER; k++) s += F_(i, k) * P00[j * INER + k];
+        FP[e] = s;
+    }
+    __syncthreads();
+    for (int e = t; e < INER * INER; e += 256) {
+        const int i = e % INER, j = e / INER;
+        double s = 0;
+        for (int k = 0; k < INER; k++) s += FP[k * INER + i] * F_(j, k);
+        for (int k = 0; k < QD; k++) s += LQ[k * INER + i] * L_(j, k);
+        P[(size_t)j * n + i] = s;
+    }
+    for (int i = INER + t; i < n; i += 256) {           // one thread per trailing row / column
+        double row[INER], col[INER];
+        for (int k = 0; k < INER; k++) { row[k] = P[(size_t)k * n + i]; col[k] = P[(size_t)i * n + k]; }
+        for (int c = 0; c < INER; c++) {
+            double s1 = 0, s2 = 0;
+            for (int k = 0; k < INER; k++) { s1 += row[k] * F_(c, k); s2 += F_(c, k) * col[k]; }
+            P[(size_t)c * n + i] = s1;                  // P10 F'
+            P[(size_t)i * n + c] = s2;                  // F P01
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// update / gate (ekf.cpp:57-82, 760-844)
+// ---------------------------------------------------------------------------------------------
+struct UpdateArgs {
+    int n, nr, l, R;                  // R = nr + n + 1 rows of the tall matrix
+    int mode;                         // 0 gate only, 1 update, 2 update only if the chi2 gate passes
+    int generic;                      // residual = y - H m[0:l] (ekf.cpp:76-79) instead of the given v
+    int normalize_all, use_lds;
+    double *m, *P;
+    const double *H, *v;              // per filter: nr*l column-major, nr
+    const double *rdiag;              // per filter diagonal of R (already scaled), or null -> rd0
+    double rd0, noise_scale;
+    double *ws;                       // per filter R*nr doubles (used when the tall matrix exceeds LDS)
+    double *chi2; int *status;        // optional outputs
+    const unsigned char *active;      // optional per-filter enable
+};
+
+constexpr int UPD_THREADS = 1024;
+
+__global__ __launch_bounds__(UPD_THREADS) void ekf_update_kernel(UpdateArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const int b = blockIdx.x;
+    if (a.active && !a.active[b]) return;
+    const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
+    constexpr int nwaves = UPD_THREADS / 64;
+    const int n = a.n, nr = a.nr, l = a.l, R = a.R;
+    double *m = a.m + (size_t)b * n, *P = a.P + (size_t)b * n * n;
+    const double *H = a.H + (size_t)b * nr * l;
+    const double rd = a.rdiag ? a.rdiag[b] : a.rd0;
+    // all LDS comes from the dynamic region (keeps the base 16-byte aligned): [T] colk[R] red[16] flag
+    double *T = a.use_lds ? smem : a.ws + (size_t)b * R * nr;       // T(r, c) = T[c * R + r]
+    double *colk = a.use_lds ? smem + (((size_t)R * nr + 1) & ~(size_t)1) : smem;   // current pivot column
+    double *red = colk + ((R + 1) & ~1);
+    int *s_stop = reinterpret_cast<int *>(red + nwaves);
+    const bool gate_only = a.mode == 0;
+
+    // ---- A: HP = H * P[0:l, :], stored transposed as rows nr .. nr+n-1 of T; residual row ----
+    {
+        const int tiles_i = (nr + 15) / 16, tiles_j = (n + 15) / 16;
+        for (int tile = wave; tile < tiles_i * tiles_j; tile += nwaves) {
+            const int i0 = (tile % tiles_i) * 16, j0 = (tile / tiles_i) * 16;
+            const double4v acc = mfma_tile(l,
+                [&](int i, int k) { return (i0 + i < nr && k < l) ? H[(size_t)k * nr + i0 + i] : 0.0; },
+                [&](int k, int j) { return (k < l && j0 + j < n) ? P[(size_t)(j0 + j) * n + k] : 0.0; });
+            const int j = j0 + (lane & 15);
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const int i = i0 + (lane >> 4) + 4 * q;
+                if (i < nr && j < n) T[(size_t)i * R + nr + j] = acc[q];
+            }
+        }
+    }
+    for (int i = t; i < nr; i += UPD_THREADS) {
+        double r = a.v[(size_t)b * nr + i];
+        if (a.generic) { double s = 0; for (int k = 0; k < l; k++) s += H[(size_t)k * nr + i] * m[k]; r -= s; }
+        T[(size_t)i * R + R - 1] = r;
+    }
+    __syncthreads();
+
+    // ---- B: S = HP[:, 0:l] * H' + R (lower triangle), rows 0 .. nr-1 of T ----
+    {
+        const int tb = (nr + 15) / 16;
+        for (int tile = wave; tile < tb * tb; tile += nwaves) {
+            const int ib = tile % tb, cb = tile / tb;
+            if (ib < cb) continue;
+            const int i0 = ib * 16, c0 = cb * 16;
+            const double4v acc = mfma_tile(l,
+                [&](int i, int k) { return (i0 + i < nr && k < l) ? T[(size_t)(i0 + i) * R + nr + k] : 0.0; },
+                [&](int k, int c) { return (k < l && c0 + c < nr) ? H[(size_t)k * nr + c0 + c] : 0.0; });
+            const int c = c0 + (lane & 15);
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const int i = i0 + (lane >> 4) + 4 * q;
+                if (i < nr && c < nr) T[(size_t)c * R + i] = acc[q] + (i == c ? rd : 0.0);
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- C: right-looking Cholesky over the tall matrix. Gate-only skips the (HP)' rows. ----
+    for (int k = 0; k < nr; k++) {
+        const double d = sqrt(T[(size_t)k * R + k]);
+        __syncthreads();                               // everyone has read the pivot
+        for (int r = k + t; r < R; r += UPD_THREADS) {
+            if (gate_only && r >= nr && r < R - 1) continue;
+            const double val = (r == k) ? d : T[(size_t)k * R + r] / d;
+            T[(size_t)k * R + r] = val;
+            colk[r] = val;
+        }
+        __syncthreads();
+        for (int c = k + 1 + wave; c < nr; c += nwaves) {
+            const double lc = colk[c];
+            for (int r = c + lane; r < R; r += 64) {
+                if (gate_only && r >= nr && r < R - 1) continue;
+                T[(size_t)c * R + r] -= colk[r] * lc;
+            }
+        }
+        __syncthreads();
+    }
+
+    // ---- D: chi2 = noise_scale * z'z ----
+    {
+        double s = 0;
+        for (int c = t; c < nr; c += UPD_THREADS) { const double z = T[(size_t)c * R + R - 1]; s += z * z; }
+        for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o);
+        if (lane == 0) red[wave] = s;
+        __syncthreads();
+        if (t == 0) {
+            double tot = 0; for (int w2 = 0; w2 < nwaves; w2++) tot += red[w2];
+            tot *= a.noise_scale;
+            const int outlier = (nr < HV_CHI2INV95_N) ? (tot > d_chi2inv95[nr]) : 0;
+            if (a.chi2) a.chi2[b] = tot;
+            if (a.status) a.status[b] = outlier ? 3 /*CHI2*/ : 0 /*INLIER*/;
+            *s_stop = (a.mode == 0) || (a.mode == 2 && outlier);
+        }
+        __syncthreads();
+        if (*s_stop) return;
+    }
+
+    // ---- E: m += Y' z ----
+    for (int j = t; j < n; j += UPD_THREADS) {
+        double s = 0;
+        for (int c = 0; c < nr; c++) s += T[(size_t)c * R + nr + j] * T[(size_t)c * R + R - 1];
+        m[j] += s;
+    }
+    // ---- F: P -= Y' Y ----
+    {
+        const int tb = (n + 15) / 16;
+        for (int tile = wave; tile < tb * tb; tile += nwaves) {
+            const int i0 = (tile % tb) * 16, j0 = (tile / tb) * 16;
+            const double4v acc = mfma_tile(nr,
+                [&](int i, int c) { return (i0 + i < n && c < nr) ? T[(size_t)c * R + nr + i0 + i] : 0.0; },
+                [&](int c, int j) { return (c < nr && j0 + j < n) ? T[(size_t)c * R + nr + j0 + j] : 0.0; });
+            const int j = j0 + (lane & 15);
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const int i = i0 + (lane >> 4) + 4 * q;
+                if (i < n && j < n) P[(size_t)j * n + i] -= acc[q];
+            }
+        }
+    }
+    __syncthreads();
+    // ---- G: quaternion normalisation (updateCommon ekf.cpp:29-31 / normalizeQuaternions 1024-1032) ----
+    const int nq = a.normalize_all ? 1 + (n - CAM) / POSE : 1;
+    if (t < nq) normalize4(m + (t == 0 ? ORI : CAM + POSE * (t - 1) + 3));
+}
+
+// ---------------------------------------------------------------------------------------------
+// pose augmentation / undo (ekf.cpp:848-903) and housekeeping
+// ---------------------------------------------------------------------------------------------
+struct AugmentArgs {
+    int n, cam_poses, map_dim;
+    double *m, *P, *P1, *m1;          // P1/m1: per-filter scratch (n*n, n)
+    const int *dropped;               // per filter (or null -> dropped0), -1 = last
+    int dropped0;
+    double q_pos, q_ori, rd;          // visAugQ diagonal (scaled), augmentR * noiseScale
+    const unsigned char *active;
+};
+
+__device__ __forceinline__ int aug_src(int i, int dropped, int n)   // visAugA[dropped] as a gather (ekf.cpp:230-248)
+{
+    if (i < CAM) return i;
+    if (i < CAM + POSE) return -1;                                    // slot 0 is re-created by the update
+    if (i < CAM + (dropped + 1) * POSE) return i - POSE;
+    return i;
+}
+__device__ __forceinline__ int augh_plus(int i) { return i < 3 ? POS + i : ORI + (i - 3); }   // visAugH (ekf.cpp:267-278)
+__device__ __forceinline__ int augh_minus(int i) { return CAM + i; }
+
+constexpr int AUG_THREADS = 1024;
+
+__global__ __launch_bounds__(AUG_THREADS) void ekf_augment_kernel(AugmentArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const int b = blockIdx.x, t = threadIdx.x, n = a.n;
+    if (a.active && !a.active[b]) return;
+    double *m = a.m + (size_t)b * n, *P = a.P + (size_t)b * n * n;
+    double *P1 = a.P1 + (size_t)b * n * n, *m1 = a.m1 + (size_t)b * n;
+    int dropped = a.dropped ? a.dropped[b] : a.dropped0;
+    if (dropped < 0) dropped = a.cam_poses - 1;
+    double *HP = smem, *K = HP + POSE * n, *G = K + POSE * n;       // 7 x n each, row-major [k * n + j]
+    double *S0 = G + POSE * n, *Lc = S0 + POSE * POSE, *vres = Lc + POSE * POSE;
+
+    // 1. m1 = A m ; P1 = A P A' + Q
+    for (int i = t; i < n; i += AUG_THREADS) { const int s = aug_src(i, dropped, n); m1[i] = s >= 0 ? m[s] : 0.0; }
+    for (int e = t; e < n * n; e += AUG_THREADS) {
+        const int i = e % n, j = e / n, si = aug_src(i, dropped, n), sj = aug_src(j, dropped, n);
+        double v = (si >= 0 && sj >= 0) ? P[(size_t)sj * n + si] : 0.0;
+        if (i == j && i >= CAM && i < CAM + POSE) v += (i < CAM + 3) ? a.q_pos : a.q_ori;
+        P1[e] = v;
+    }
+    __syncthreads();
+    // 2. HP = H P1 (7 x n), S0 = HP H'
+    for (int e = t; e < POSE * n; e += AUG_THREADS) {
+        const int k = e / n, j = e % n;
+        HP[e] = P1[(size_t)j * n + augh_plus(k)] - P1[(size_t)j * n + augh_minus(k)];
+    }
+    __syncthreads();
+    if (t < POSE * POSE) { const int i = t / POSE, c = t % POSE; S0[t] = HP[i * n + augh_plus(c)] - HP[i * n + augh_minus(c)]; }
+    if (t >= 64 && t < 64 + POSE) { const int i = t - 64; vres[i] = -(m1[augh_plus(i)] - m1[augh_minus(i)]); }
+    __syncthreads();
+    if (t == 0) {                                                   // Cholesky of S = S0 + rd I (7 x 7)
+        for (int i = 0; i < POSE; i++) for (int c = 0; c < POSE; c++) Lc[i * POSE + c] = 0.0;
+        for (int c = 0; c < POSE; c++) {
+            double d = S0[c * POSE + c] + a.rd;
+            for (int p = 0; p < c; p++) d -= Lc[c * POSE + p] * Lc[c * POSE + p];
+            d = sqrt(d);
+            Lc[c * POSE + c] = d;
+            for (int i = c + 1; i < POSE; i++) {
+                double s = 0.5 * (S0[i * POSE + c] + S0[c * POSE + i]);
+                for (int p = 0; p < c; p++) s -= Lc[i * POSE + p] * Lc[c * POSE + p];
+                Lc[i * POSE + c] = s / d;
+            }
+        }
+    }
+    __syncthreads();
+    // K(j, :) = S^-1 HP(:, j)   (K = (S^-1 HP)')
+    for (int j = t; j < n; j += AUG_THREADS) {
+        double x[POSE];
+        for (int i = 0; i < POSE; i++) { double s = HP[i * n + j]; for (int p = 0; p < i; p++) s -= Lc[i * POSE + p] * x[p]; x[i] = s / Lc[i * POSE + i]; }
+        for (int i = POSE - 1; i >= 0; i--) { double s = x[i]; for (int p = i + 1; p < POSE; p++) s -= Lc[p * POSE + i] * x[p]; x[i] = s / Lc[i * POSE + i]; }
+        double dm = 0;
+        for (int i = 0; i < POSE; i++) { K[i * n + j] = x[i]; dm += x[i] * vres[i]; }
+        m[j] = m1[j] + dm;                                          // m = A m + K (-H A m)
+    }
+    __syncthreads();
+    // 3. G = P1 H' - K S0 - rd K   (n x 7): then P = P1 - K HP - G K' reproduces the Joseph form
+    for (int e = t; e < POSE * n; e += AUG_THREADS) {
+        const int c = e / n, i = e % n;
+        double g = P1[(size_t)augh_plus(c) * n + i] - P1[(size_t)augh_minus(c) * n + i];
+        for (int k = 0; k < POSE; k++) g -= K[k * n + i] * S0[k * POSE + c];
+        G[e] = g - a.rd * K[c * n + i];
+    }
+    __syncthreads();
+    // 4. P = sym(P1 - K HP - G K')   (maintainPositiveSemiDefinite fused, ekf.cpp:872)
+    for (int e = t; e < n * n; e += AUG_THREADS) {
+        const int i = e % n, j = e / n;
+        if (i > j) continue;
+        double xij = P1[(size_t)j * n + i], xji = P1[(size_t)i * n + j];
+#pragma unroll
+        for (int k = 0; k < POSE; k++) {
+            xij -= K[k * n + i] * HP[k * n + j] + G[k * n + i] * K[k * n + j];
+            xji -= K[k * n + j] * HP[k * n + i] + G[k * n + j] * K[k * n + i];
+        }
+        const double s = 0.5 * (xij + xji);
+        P[(size_t)j * n + i] = s;
+        P[(size_t)i * n + j] = s;
+    }
+    __syncthreads();
+    const int nq = 1 + (n - a.map_dim - CAM) / POSE;
+    if (t < nq) normalize4(m + (t == 0 ? ORI : CAM + POSE * (t - 1) + 3));
+}
+
+struct ShiftArgs { int n, map_dim; double *m, *P, *P1, *m1; const unsigned char *active; };
+
+// updateUndoAugmentation (ekf.cpp:888-903): m = U m, P = U P U' with the shift visUnaugmentA (251-265)
+__device__ __forceinline__ int unaug_src(int i, int n, int map_dim)
+{
+    const int trail = n - map_dim;
+    if (i < CAM || i >= trail) return i;
+    return (i + POSE < trail) ? i + POSE : -1;
+}
+
+__global__ __launch_bounds__(1024) void ekf_unaugment_gather_kernel(ShiftArgs a)
+{
+    const int b = blockIdx.x, t = threadIdx.x, n = a.n;
+    if (a.active && !a.active[b]) return;
+    const double *m = a.m + (size_t)b * n, *P = a.P + (size_t)b * n * n;
+    double *P1 = a.P1 + (size_t)b * n * n, *m1 = a.m1 + (size_t)b * n;
+    for (int i = t; i < n; i += 1024) { const int s = unaug_src(i, n, a.map_dim); m1[i] = s >= 0 ? m[s] : 0.0; }
+    for (int e = t; e < n * n; e += 1024) {
+        const int si = unaug_src(e % n, n, a.map_dim), sj = unaug_src(e / n, n, a.map_dim);
+        P1[e] = (si >= 0 && sj >= 0) ? P[(size_t)sj * n + si] : 0.0;
+    }
+}
+
+__global__ __launch_bounds__(1024) void ekf_copy_back_kernel(ShiftArgs a)
+{
+    const int b = blockIdx.x, t = threadIdx.x, n = a.n;
+    if (a.active && !a.active[b]) return;
+    for (int i = t; i < n; i += 1024) a.m[(size_t)b * n + i] = a.m1[(size_t)b * n + i];
+    for (int e = t; e < n * n; e += 1024) a.P[(size_t)b * n * n + e] = a.P1[(size_t)b * n * n + e];
+}
+
+// maintainPositiveSemiDefinite (ekf.cpp:1059-1067): P = (P + P') / 2
+__global__ __launch_bounds__(1024) void ekf_symmetrize_kernel(int n, double *Pall)
+{
+    double *P = Pall + (size_t)blockIdx.x * n * n;
+    for (int e = threadIdx.x; e < n * n; e += 1024) {
+        const int i = e % n, j = e / n;
+        if (i >= j) continue;
+        const double s = 0.5 * (P[(size_t)j * n + i] + P[(size_t)i * n + j]);
+        P[(size_t)j * n + i] = s; P[(size_t)i * n + j] = s;
+    }
+}
+
+__global__ void ekf_normalize_kernel(int n, int map_dim, double *mall, int only_current)
+{
+    double *m = mall + (size_t)blockIdx.x * n;
+    const int nq = only_current ? 1 : 1 + (n - map_dim - CAM) / POSE;
+    const int t = threadIdx.x;
+    if (t < nq) normalize4(m + (t == 0 ? ORI : CAM + POSE * (t - 1) + 3));
+}
+
+// transformTo (ekf.cpp:704-758): m = A m (+ translation of every position), P = A P A' with the
+// block-diagonal A = diag(pC, pC, qC, I_10, {pC, qC} x poses [, I]); one thread per block pair.
+struct TransformArgs { int n, cam_poses; double *m, *P; double pC[9], qC[16], tr[3]; };   // row-major blocks
+
+__device__ __forceinline__ void blk_of(int idx, int cam_poses, int &start, int &size, int &kind)
+{
+    // kind 0: identity 1x1, 1: pC (3x3), 2: qC (4x4)
+    if (idx == 0) { start = POS; size = 3; kind = 1; return; }
+    if (idx == 1) { start = VEL; size = 3; kind = 1; return; }
+    if (idx == 2) { start = ORI; size = 4; kind = 2; return; }
+    if (idx < 13) { start = BGA + (idx - 3); size = 1; kind = 0; return; }
+    const int p = idx - 13;
+    if (p < 2 * cam_poses) { start = CAM + POSE * (p >> 1) + ((p & 1) ? 3 : 0); size = (p & 1) ? 4 : 3; kind = (p & 1) ? 2 : 1; return; }
+    start = CAM + POSE * cam_poses + (p - 2 * cam_poses); size = 1; kind = 0;
+}
+
+__global__ __launch_bounds__(256) void ekf_transform_kernel(TransformArgs a)
+{
+    const int n = a.n, nblk = 13 + 2 * a.cam_poses + (n - CAM - POSE * a.cam_poses);
+    double *P = a.P, *m = a.m;
+    for (int e = threadIdx.x + blockIdx.x * 256; e < nblk * nblk; e += 256 * gridDim.x) {
+        int si, ni, ki, sj, nj, kj;
+        blk_of(e % nblk, a.cam_poses, si, ni, ki);
+        blk_of(e / nblk, a.cam_poses, sj, nj, kj);
+        if (ki == 0 && kj == 0) continue;
+        double X[16], Y[16];
+        for (int i = 0; i < ni; i++) for (int j = 0; j < nj; j++) X[i * 4 + j] = P[(size_t)(sj + j) * n + si + i];
+        const double *Ai = ki == 1 ? a.pC : a.qC, *Aj = kj == 1 ? a.pC : a.qC;
+        for (int i = 0; i < ni; i++) for (int j = 0; j < nj; j++) {      // Y = Ai X
+            double s = 0;
+            if (ki == 0) s = X[i * 4 + j]; else for (int k = 0; k < ni; k++) s += Ai[i * ni + k] * X[k * 4 + j];
+            Y[i * 4 + j] = s;
+        }
+        for (int i = 0; i < ni; i++) for (int j = 0; j < nj; j++) {      // P = Y Aj'
+            double s = 0;
+            if (kj == 0) s = Y[i * 4 + j]; else for (int k = 0; k < nj; k++) s += Y[i * 4 + k] * Aj[j * nj + k];
+            P[(size_t)(sj + j) * n + si + i] = s;
+        }
+    }
+    if (blockIdx.x == 0 && threadIdx.x < nblk) {
+        int s, sz, kind;
+        blk_of(threadIdx.x, a.cam_poses, s, sz, kind);
+        if (kind) {
+            double x[4], y[4];
+            for (int i = 0; i < sz; i++) x[i] = m[s + i];
+            const double *A = kind == 1 ? a.pC : a.qC;
+            for (int i = 0; i < sz; i++) { double t2 = 0; for (int k = 0; k < sz; k++) t2 += A[i * sz + k] * x[k]; y[i] = t2; }
+            const bool is_pos = kind == 1 && s != VEL;
+            for (int i = 0; i < sz; i++) m[s + i] = y[i] + (is_pos ? a.tr[i] : 0.0);
+        }
+    }
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------
+struct Ekf {
+    Ctx *c = nullptr;
+    hv_ekf_params par{};
+    int batch = 0, n = 0, cam = 0, map_dim = 0;
+    double noise_scale = 0;
+    double *m = nullptr, *P = nullptr, *P1 = nullptr, *m1 = nullptr, *Q = nullptr, *dydx = nullptr, *ws = nullptr;
+    double *sH = nullptr, *sv = nullptr, *sr = nullptr, *schi2 = nullptr, *simu = nullptr;   // staging for host-pointer calls
+    int *sstatus = nullptr, *sdrop = nullptr;
+    unsigned char *sactive = nullptr;
+    size_t sH_cap = 0;
+    int max_rows = 0;
+};
+
+static int ekf_launch_update(Ekf *e, int nr, int l, const double *H_dev, const double *v_dev, const double *rdiag_dev,
+                             double rd0, int mode, int generic, int normalize_all, double *chi2_dev, int *status_dev,
+                             const unsigned char *active_dev)
+{
+    Ctx *c = e->c;
+    if (nr < 1 || nr > e->max_rows || l < 1 || l > e->n) return HV_ERR_INVALID;
+    UpdateArgs a{};
+    a.n = e->n; a.nr = nr; a.l = l; a.R = nr + e->n + 1;
+    a.mode = mode; a.generic = generic; a.normalize_all = normalize_all;
+    a.m = e->m; a.P = e->P; a.H = H_dev; a.v = v_dev; a.rdiag = rdiag_dev; a.rd0 = rd0; a.noise_scale = e->noise_scale;
+    a.ws = e->ws; a.chi2 = chi2_dev; a.status = status_dev; a.active = active_dev;
+    const size_t tall = (((size_t)a.R * nr + 1) & ~(size_t)1) * sizeof(double);
+    const size_t small = (size_t)(((a.R + 1) & ~1) + UPD_THREADS / 64 + 2) * sizeof(double);   // colk + red + flag
+    a.use_lds = tall + small <= 150 * 1024;
+    const size_t shmem = a.use_lds ? tall + small : small;
+    static bool attr_set = false;
+    if (!attr_set) {
+        HV_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void *>(ekf_update_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024));
+        attr_set = true;
+    }
+    ScopedKernelTime tm(c, HV_K_EKF_UPDATE);
+    hipLaunchKernelGGL(ekf_update_kernel, dim3(e->batch), dim3(UPD_THREADS), shmem, c->stream, a);
+    HV_HIP(c, hipGetLastError());
+    return HV_OK;
+}
+
+}  // namespace hv
+
+using hv::Ctx;
+using hv::Ekf;
+
+extern "C" {
+
+struct hv_ekf { Ekf e; };
+
+void hv_ekf_default_params(hv_ekf_params *p)
+{
+    if (!p) return;
+    p->cameraTrailLength = 20; p->hybridMapSize = 0;
+    p->noiseScale = 100; p->gravity = 9.819; p->augmentR = 1e-9; p->initZuptR = 1e-4; p->rotationZuptR = 1e-6;
+    p->noiseInitialPos = 1e-5; p->noiseInitialOri = 0.0316227766; p->noiseInitialVel = 0.1;
+    p->noiseInitialPosTrail = 100; p->noiseInitialOriTrail = 3.16227766;
+    p->noiseInitialBGA = 1e-3; p->noiseInitialBAA = 1e-6; p->noiseInitialBAT = 1e-5; p->noiseInitialSFT = 1e-5;
+    p->noiseProcessAcc = 0.003; p->noiseProcessGyro = 0.00017; p->noiseProcessBAA = 1e-4; p->noiseProcessBGA = 0;
+    p->noiseProcessBAARev = 0.1; p->noiseProcessBGARev = 0.1;
+}
+
+void hv_ekf_destroy(hv_ekf *h)
+{
+    if (!h) return;
+    Ekf *e = &h->e;
+    if (e->c && e->c->stream) (void)hipStreamSynchronize(e->c->stream);
+    void *ptrs[] = { e->m, e->P, e->P1, e->m1, e->Q, e->dydx, e->ws, e->sH, e->sv, e->sr, e->schi2, e->simu,
+                     e->sstatus, e->sdrop, e->sactive };
+    for (void *p : ptrs) if (p) (void)hipFree(p);
+    delete h;
+}
+
+int hv_ekf_create(hv_ctx *ctx, const hv_ekf_params *par, int batch, hv_ekf **out)
+{
+    if (!ctx || !par || !out || batch < 1 || par->cameraTrailLength < 1 || par->hybridMapSize < 0) return HV_ERR_INVALID;
+    *out = nullptr;
+    Ctx *c = hv::ctx_of(ctx);
+    hv_ekf *h = new (std::nothrow) hv_ekf();
+    if (!h) return HV_ERR_NOMEM;
+    Ekf *e = &h->e;
+    e->c = c; e->par = *par; e->batch = batch;
+    e->cam = par->cameraTrailLength; e->map_dim = 3 * par->hybridMapSize;
+    const int n = e->n = hv::INER + hv::POSE * e->cam + e->map_dim;
+    e->noise_scale = par->noiseScale * par->noiseScale;
+    e->max_rows = n;
+    const size_t nn = (size_t)n * n;
+    bool ok = true;
+    auto alloc = [&](auto &ptr, size_t bytes) { if (ok && hipMalloc(reinterpret_cast<void **>(&ptr), bytes) != hipSuccess) ok = false; };
+    alloc(e->m, sizeof(double) * n * batch); alloc(e->P, sizeof(double) * nn * batch);
+    alloc(e->P1, sizeof(double) * nn * batch); alloc(e->m1, sizeof(double) * n * batch);
+    alloc(e->Q, sizeof(double) * 144 * batch); alloc(e->dydx, sizeof(double) * 400 * batch);
+    alloc(e->ws, sizeof(double) * (size_t)(2 * n + 1) * n * batch);
+    e->sH_cap = nn * batch;
+    alloc(e->sH, sizeof(double) * e->sH_cap); alloc(e->sv, sizeof(double) * n * batch); alloc(e->sr, sizeof(double) * batch);
+    alloc(e->schi2, sizeof(double) * batch); alloc(e->simu, sizeof(double) * 7 * batch);
+    alloc(e->sstatus, sizeof(int) * batch); alloc(e->sdrop, sizeof(int) * batch); alloc(e->sactive, batch);
+    if (!ok) { hv_ekf_destroy(h); return HV_ERR_NOMEM; }
+
+    // initial state and covariance: EKFImplementation ctor, ekf.cpp:153-296
+    std::vector<double> m0(n, 0.0), P0(nn, 0.0), Q0(144, 0.0);
+    auto sq = [](double x) { return x * x; };
+    m0[hv::ORI] = 1.0; m0[hv::BAT] = m0[hv::BAT + 1] = m0[hv::BAT + 2] = 1.0;
+    for (int i = 0; i < 3; i++) {
+        P0[(size_t)(hv::POS + i) * n + hv::POS + i] = sq(par->noiseInitialPos);
+        P0[(size_t)(hv::VEL + i) * n + hv::VEL + i] = sq(par->noiseInitialVel);
+        P0[(size_t)(hv::BGA + i) * n + hv::BGA + i] = sq(par->noiseInitialBGA);
+        P0[(size_t)(hv::BAA + i) * n + hv::BAA + i] = sq(par->noiseInitialBAA);
+        P0[(size_t)(hv::BAT + i) * n + hv::BAT + i] = sq(par->noiseInitialBAT);
+    }
+    for (int i = 0; i < 4; i++) P0[(size_t)(hv::ORI + i) * n + hv::ORI + i] = 1.0;
+    P0[(size_t)hv::SFT * n + hv::SFT] = sq(par->noiseInitialSFT);
+    for (int cidx = 0; cidx < e->cam; cidx++) {
+        const int b0 = hv::CAM + cidx * hv::POSE;
+        for (int i = 0; i < 3; i++) P0[(size_t)(b0 + i) * n + b0 + i] = sq(par->noiseInitialPosTrail);
+        for (int i = 3; i < 7; i++) P0[(size_t)(b0 + i) * n + b0 + i] = sq(par->noiseInitialOriTrail);
+    }
+    for (int i = 0; i < 3; i++) { Q0[(hv::Q_ACC + i) * 13] = sq(par->noiseProcessAcc); Q0[(hv::Q_GYRO + i) * 13] = sq(par->noiseProcessGyro); }
+    for (auto &x : P0) x *= e->noise_scale;
+    for (auto &x : Q0) x *= e->noise_scale;
+    int rc = HV_OK;
+    for (int b = 0; b < batch && rc == HV_OK; b++) {
+        rc = hv_ekf_set_state(h, b, m0.data(), P0.data());
+        if (rc == HV_OK) rc = hv_ekf_set_process_noise(h, b, Q0.data());
+    }
+    if (rc != HV_OK) { hv_ekf_destroy(h); return rc; }
+    *out = h;
+    return HV_OK;
+}
+
+int hv_ekf_state_dim(const hv_ekf *h) { return h ? h->e.n : HV_ERR_INVALID; }
+int hv_ekf_batch(const hv_ekf *h) { return h ? h->e.batch : HV_ERR_INVALID; }
+
+int hv_ekf_set_state(hv_ekf *h, int b, const double *m, const double *P)
+{
+    if (!h || b < 0 || b >= h->e.batch) return HV_ERR_INVALID;
+    Ekf *e = &h->e; Ctx *c = e->c; const size_t n = e->n;
+    if (m) HV_HIP(c, hipMemcpyAsync(e->m + b * n, m, sizeof(double) * n, hipMemcpyHostToDevice, c->stream));
+    if (P) HV_HIP(c, hipMemcpyAsync(e->P + b * n * n, P, sizeof(double) * n * n, hipMemcpyHostToDevice, c->stream));
+    HV_HIP(c, hipStreamSynchronize(c->stream));
+    return HV_OK;
+}
+
+int hv_ekf_get_state(hv_ekf *h, int b, double *m, double *P)
+{
+    if (!h || b < 0 || b >= h->e.batch) return HV_ERR_INVALID;
+    Ekf *e = &h->e; Ctx *c = e->c; const size_t n = e->n;
+    if (m) HV_HIP(c, hipMemcpyAsync(m, e->m + b * n, sizeof(double) * n, hipMemcpyDeviceToHost, c->stream));
+    if (P) HV_HIP(c, hipMemcpyAsync(P, e->P + b * n * n, sizeof(double) * n * n, hipMemcpyDeviceToHost, c->stream));
+    HV_HIP(c, hipStreamSynchronize(c->stream));
+    return HV_OK;
+}
+
+int hv_ekf_get_means(hv_ekf *h, double *m_all)
+{
+    if (!h || !m_all) return HV_ERR_INVALID;
+    Ekf *e = &h->e; Ctx *c = e->c;
+    HV_HIP(c, hipMemcpyAsync(m_all, e->m, sizeof(double) * e->n * e->batch, hipMemcpyDeviceToHost, c->stream));
+    HV_HIP(c, hipStreamSynchronize(c->stream));
+    return HV_OK;
+}
+
+int hv_ekf_set_process_noise(hv_ekf *h, int b, const double *Q)
+{
+    if (!h || !Q || b < 0 || b >= h->e.batch) return HV_ERR_INVALID;
+    Ctx *c = h->e.c;
+    HV_HIP(c, hipMemcpyAsync(h->e.Q + (size_t)b * 144, Q, sizeof(double) * 144, hipMemcpyHostToDevice, c->stream));
+    HV_HIP(c, hipStreamSynchronize(c->stream));
+    return HV_OK;
+}
+
+int hv_ekf_get_dydx(hv_ekf *h, int b, double *F)
+{
+    if (!h || !F || b < 0 || b >= h->e.batch) return HV_ERR_INVALID;
+    Ctx *c = h->e.c;
+    HV_HIP(c, hipMemcpyAsync(F, h->e.dydx + (size_t)b * 400, sizeof(double) * 400, hipMemcpyDeviceToHost, c->stream));
+    HV_HIP(c, hipStreamSynchronize(c->stream));
+    return HV_OK;
+}
+
+int hv_ekf_device_pointers(hv_ekf *h, double **m_dev, double **P_dev)
+{
+    if (!h) return HV_ERR_INVALID;
+    if (m_dev) *m_dev = h->e.m;
+    if (P_dev) *P_dev = h->e.P;
+    return HV_OK;
+}
+
+static int predict_common(Ekf *e, const double *dt_dev, const double *gyro_dev, const double *acc_dev,
+                          double dt0, const double *g0, const double *a0)
+{
+    Ctx *c = e->c;
+    hv::PredictArgs a{};
+    a.n = e->n; a.batch = e->batch; a.m = e->m; a.P = e->P; a.Q = e->Q; a.dydx = e->dydx;
+    a.dt = dt_dev; a.gyro = gyro_dev; a.acc = acc_dev; a.dt0 = dt0;
+    for (int i = 0; i < 3; i++) { a.g0[i] = g0 ? g0[i] : 0.0; a.a0[i] = a0 ? a0[i] : 0.0; }
+    a.noise_scale = e->noise_scale; a.gravity = e->par.gravity;
+    a.baa = e->par.noiseProcessBAA; a.baa_rev = e->par.noiseProcessBAARev;
+    a.bga = e->par.noiseProcessBGA; a.bga_rev = e->par.noiseProcessBGARev;
+    hv::ScopedKernelTime tm(c, HV_K_EKF_PREDICT);
+    hipLaunchKernelGGL(hv::ekf_predict_kernel, dim3(e->batch), dim3(256), 0, c->stream, a);
+    HV_HIP(c, hipGetLastError());
+    return HV_OK;
+}
+
+int hv_ekf_predict(hv_ekf *h, const double *dt, const double *gyro, const double *acc)
+{
+    if (!h || !dt || !gyro || !acc) return HV_ERR_INVALID;
+    Ekf *e = &h->e; Ctx *c = e->c;
+    if (e->batch == 1) return predict_common(e, nullptr, nullptr, nullptr, dt[0], gyro, acc);   // immediates, no copy
+    const size_t B = e->batch;
+    HV_HIP(c, hipMemcpyAsync(e->simu, dt, sizeof(double) * B, hipMemcpyHostToDevice, c->stream));
+    HV_HIP(c, hipMemcpyAsync(e->simu + B, gyro, sizeof(double) * 3 * B, hipMemcpyHostToDevice, c->stream));
+    HV_HIP(c, hipMemcpyAsync(e->simu + 4 * B, acc, sizeof(double) * 3 * B, hipMemcpyHostToDevice, c->stream));
+    return predict_common(e, e->simu, e->simu + B, e->simu + 4 * B, 0.0, nullptr, nullptr);
+}
+
+int hv_ekf_predict_dev(hv_ekf *h, const double *dt_dev, const double *gyro_dev, const double *acc_dev)
+{
+    if (!h || !dt_dev || !gyro_dev || !acc_dev) return HV_ERR_INVALID;
+    return predict_common(&h->e, dt_dev, gyro_dev, acc_dev, 0.0, nullptr, nullptr);
+}
+
+static int stage_update_inputs(Ekf *e, int nr, int l, const double *H, const double *v, const double *rdiag,
+                               const unsigned char *active)
+{
+    Ctx *c = e->c; const size_t B = e->batch;
+    if ((size_t)nr * l * B > e->sH_cap) return HV_ERR_INVALID;
+    HV_HIP(c, hipMemcpyAsync(e->sH, H, sizeof(double) * nr * l * B, hipMemcpyHostToDevice, c->stream));
+    HV_HIP(c, hipMemcpyAsync(e->sv, v, sizeof(double) * nr * B, hipMemcpyHostToDevice, c->stream));
+    if (rdiag) HV_HIP(c, hipMemcpyAsync(e->sr, rdiag, sizeof(double) * B, hipMemcpyHostToDevice, c->stream));
+    if (active) HV_HIP(c, hipMemcpyAsync(e->sactive, active, B, hipMemcpyHostToDevice, c->stream));
+    return HV_OK;
+}
+
+int hv_ekf_update(hv_ekf *h, int nr, int l, const double *H, const double *y, const double *r_diag,
+                  const unsigned char *active, int normalize_all)
+{
+    if (!h || !H || !y || !r_diag) return HV_ERR_INVALID;
+    Ekf *e = &h->e;
+    if (nr < 1 || nr > e->max_rows || l < 1 || l > e->n) return HV_ERR_INVALID;
+    int rc = stage_update_inputs(e, nr, l, H, y, r_diag, active);
+    if (rc != HV_OK) return rc;
+    return hv::ekf_launch_update(e, nr, l, e->sH, e->sv, e->sr, 0.0, 1, 1, normalize_all, nullptr, nullptr,
+                                 active ? e->sactive : nullptr);
+}
+
+int hv_ekf_visual_gate(hv_ekf *h, int nr, int l, const double *H, const double *v, double r, double *chi2, int *status)
+{
+    if (!h || !H || !v) return HV_ERR_INVALID;
+    Ekf *e = &h->e; Ctx *c = e->c;
+    if (nr < 1 || nr > e->max_rows || l < 1 || l > e->n) return HV_ERR_INVALID;
+    int rc = stage_update_inputs(e, nr, l, H, v, nullptr, nullptr);
+    if (rc != HV_OK) return rc;
+    rc = hv::ekf_launch_update(e, nr, l, e->sH, e->sv, nullptr, r * r * e->noise_scale, 0, 0, 0, e->schi2, e->sstatus, nullptr);
+    if (rc != HV_OK) return rc;
+    if (chi2) HV_HIP(c, hipMemcpyAsync(chi2, e->schi2, sizeof(double) * e->batch, hipMemcpyDeviceToHost, c->stream));
+    if (status) HV_HIP(c, hipMemcpyAsync(status, e->sstatus, sizeof(int) * e->batch, hipMemcpyDeviceToHost, c->stream));
+    HV_HIP(c, hipStreamSynchronize(c->stream));
+    return HV_OK;
+}
+
+int hv_ekf_visual_update(hv_ekf *h, int nr, int l, const double *H, const double *v, double r, const unsigned char *active)
+{
+    if (!h || !H || !v) return HV_ERR_INVALID;
+    Ekf *e = &h->e;
+    if (nr < 1 || nr > e->max_rows || l < 1 || l > e->n) return HV_ERR_INVALID;
+    int rc = stage_update_inputs(e, nr, l, H, v, nullptr, active);
+    if (rc != HV_OK) return rc;
+    return hv::ekf_launch_update(e, nr, l, e->sH, e->sv, nullptr, r * r * e->noise_scale, 1, 0, 1, nullptr, nullptr,
+                                 active ? e->sactive : nullptr);
+}
+
+int hv_ekf_visual_dev(hv_ekf *h, int nr, int l, const double *H_dev, const double *v_dev, double r, int mode,
+                      double *chi2_dev, int *status_dev)
+{
+    if (!h || !H_dev || !v_dev || mode < 0 || mode > 2) return HV_ERR_INVALID;
+    Ekf *e = &h->e;
+    return hv::ekf_launch_update(e, nr, l, H_dev, v_dev, nullptr, r * r * e->noise_scale, mode, 0, 1, chi2_dev, status_dev, nullptr);
+}
+
+int hv_ekf_augment(hv_ekf *h, const int *discarded, const unsigned char *active)
+{
+    if (!h) return HV_ERR_INVALID;
+    Ekf *e = &h->e; Ctx *c = e->c;
+    hv::AugmentArgs a{};
+    a.n = e->n; a.cam_poses = e->cam; a.map_dim = e->map_dim;
+    a.m = e->m; a.P = e->P; a.P1 = e->P1; a.m1 = e->m1;
+    a.dropped0 = -1;
+    if (discarded) {
+        if (e->batch == 1) a.dropped0 = discarded[0];
+        else { HV_HIP(c, hipMemcpyAsync(e->sdrop, discarded, sizeof(int) * e->batch, hipMemcpyHostToDevice, c->stream)); a.dropped = e->sdrop; }
+    }
+    if (active) { HV_HIP(c, hipMemcpyAsync(e->sactive, active, e->batch, hipMemcpyHostToDevice, c->stream)); a.active = e->sactive; }
+    a.q_pos = e->par.noiseInitialPosTrail * e->par.noiseInitialPosTrail * e->noise_scale;
+    a.q_ori = e->par.noiseInitialOriTrail * e->par.noiseInitialOriTrail * e->noise_scale;
+    a.rd = e->par.augmentR * e->noise_scale;
+    const size_t shmem = sizeof(double) * (3 * hv::POSE * e->n + 2 * hv::POSE * hv::POSE + hv::POSE + 1);
+    hv::ScopedKernelTime tm(c, HV_K_EKF_AUGMENT);
+    hipLaunchKernelGGL(hv::ekf_augment_kernel, dim3(e->batch), dim3(hv::AUG_THREADS), shmem, c->stream, a);
+    HV_HIP(c, hipGetLastError());
+    return HV_OK;
+}
+
+int hv_ekf_undo_augment(hv_ekf *h, const unsigned char *active)
+{
+    if (!h) return HV_ERR_INVALID;
+    Ekf *e = &h->e; Ctx *c = e->c;
+    hv::ShiftArgs a{e->n, e->map_dim, e->m, e->P, e->P1, e->m1, nullptr};
+    if (active) { HV_HIP(c, hipMemcpyAsync(e->sactive, active, e->batch, hipMemcpyHostToDevice, c->stream)); a.active = e->sactive; }
+    hv::ScopedKernelTime tm(c, HV_K_EKF_AUGMENT);
+    hipLaunchKernelGGL(hv::ekf_unaugment_gather_kernel, dim3(e->batch), dim3(1024), 0, c->stream, a);
+    hipLaunchKernelGGL(hv::ekf_copy_back_kernel, dim3(e->batch), dim3(1024), 0, c->stream, a);
+    HV_HIP(c, hipGetLastError());
+    return HV_OK;
+}
+
+int hv_ekf_symmetrize(hv_ekf *h)
+{
+    if (!h) return HV_ERR_INVALID;
+    Ekf *e = &h->e; Ctx *c = e->c;
+    hipLaunchKernelGGL(hv::ekf_symmetrize_kernel, dim3(e->batch), dim3(1024), 0, c->stream, e->n, e->P);
+    HV_HIP(c, hipGetLastError());
+    return HV_OK;
+}
+
+int hv_ekf_normalize_quaternions(hv_ekf *h, int only_current)
+{
+    if (!h) return HV_ERR_INVALID;
+    Ekf *e = &h->e; Ctx *c = e->c;
+    hipLaunchKernelGGL(hv::ekf_normalize_kernel, dim3(e->batch), dim3(64), 0, c->stream, e->n, e->map_dim, e->m, only_current);
+    HV_HIP(c, hipGetLastError());
+    return HV_OK;
+}
+
+int hv_ekf_transform(hv_ekf *h, int b, const double *pC3x3, const double *qC4x4, const double *translation3)
+{
+    if (!h || !pC3x3 || !qC4x4 || !translation3 || b < 0 || b >= h->e.batch) return HV_ERR_INVALID;
+    Ekf *e = &h->e; Ctx *c = e->c;
+    hv::TransformArgs a{};
+    a.n = e->n; a.cam_poses = e->cam;
+    a.m = e->m + (size_t)b * e->n; a.P = e->P + (size_t)b * e->n * e->n;
+    for (int i = 0; i < 9; i++) a.pC[i] = pC3x3[i];
+    for (int i = 0; i < 16; i++) a.qC[i] = qC4x4[i];
+    for (int i = 0; i < 3; i++) a.tr[i] = translation3[i];
+    hipLaunchKernelGGL(hv::ekf_transform_kernel, dim3(8), dim3(256), 0, c->stream, a);
+    HV_HIP(c, hipGetLastError());
+    return HV_OK;
+}
+
+}  // extern "C"

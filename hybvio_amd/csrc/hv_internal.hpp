@@ -58,6 +58,7 @@ struct Ctx {
 };
 
 int hip_fail(Ctx *c, hipError_t e, const char *what);
+Ctx *ctx_of(hv_ctx *h);
 #define HV_HIP(c, call)                                                  \
     do {                                                                 \
         hipError_t e__ = (call);                                         \

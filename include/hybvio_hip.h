@@ -110,6 +110,72 @@ int hv_klt_track_batch_dev(hv_ctx *ctx, int n_pairs, const int *prev_slots_dev,
                            float *next_xy_dev, uint8_t *status_dev, float *err_dev,
                            int use_initial_flow, int max_iter_override);
 
+
+/* ---- EKF covariance algebra --------------------------------------------------------------
+ * Replaces the dense work of odometry::EKF (src/odometry/ekf.hpp:62-174, ekf.cpp) for a BATCH of
+ * independent filters that share one parameter set (batch = 1 is the reference's single session).
+ * State m (n = 20 + 7*cameraTrailLength + 3*hybridMapSize) and covariance P (n x n, f64,
+ * column-major like Eigen) stay on the device; the scalar bookkeeping of the reference class
+ * (sample clock, ZUPT rate limits, augmentTimes) lives in the host adapter (hybvio_amd/host).
+ * Per-filter inputs are arrays indexed [filter][...]. Calls are asynchronous on the context
+ * stream unless they return data to the host. */
+typedef struct hv_ekf hv_ekf;
+
+/* The odometry parameters EKFImplementation reads (codegen/parameter_definitions.c:68-160). */
+typedef struct hv_ekf_params {
+    int cameraTrailLength, hybridMapSize;
+    double noiseScale, gravity, augmentR, initZuptR, rotationZuptR;
+    double noiseInitialPos, noiseInitialOri, noiseInitialVel, noiseInitialPosTrail, noiseInitialOriTrail;
+    double noiseInitialBGA, noiseInitialBAA, noiseInitialBAT, noiseInitialSFT;
+    double noiseProcessAcc, noiseProcessGyro, noiseProcessBAA, noiseProcessBGA;
+    double noiseProcessBAARev, noiseProcessBGARev;
+} hv_ekf_params;
+
+void hv_ekf_default_params(hv_ekf_params *p);
+/* EKF::build (ekf.cpp:153-296, 1087-1092): initial m, P, Q as the reference constructor.
+ * An hv_ekf must be destroyed before the hv_ctx it was created on. */
+int hv_ekf_create(hv_ctx *ctx, const hv_ekf_params *params, int batch, hv_ekf **out);
+void hv_ekf_destroy(hv_ekf *ekf);
+int hv_ekf_state_dim(const hv_ekf *ekf);                         /* getStateDim            */
+int hv_ekf_batch(const hv_ekf *ekf);
+/* setState / setStateCovariance / getState / getStateCovariance (ekf.cpp:950-979); either
+ * pointer may be NULL. Synchronous. Also the route for the rare mean-side edits the adapter does
+ * on the host (lockBiases, conditionOnLastPose, insertMapPoint, setInertialState, translateTo). */
+int hv_ekf_set_state(hv_ekf *ekf, int filter, const double *m, const double *P_colmajor);
+int hv_ekf_get_state(hv_ekf *ekf, int filter, double *m, double *P_colmajor);
+int hv_ekf_get_means(hv_ekf *ekf, double *m_all /* batch * n */);
+int hv_ekf_set_process_noise(hv_ekf *ekf, int filter, const double *Q12x12);   /* setProcessNoise */
+int hv_ekf_get_dydx(hv_ekf *ekf, int filter, double *dydx20x20);               /* getDydx block   */
+int hv_ekf_device_pointers(hv_ekf *ekf, double **m_dev, double **P_dev);
+/* predict (ekf.cpp:320-514): mean, Jacobians and P <- F P F' + L Q L' on the device. dt[f] <= 0
+ * skips filter f. gyro/acc: [batch][3]. */
+int hv_ekf_predict(hv_ekf *ekf, const double *dt, const double *gyro, const double *acc);
+int hv_ekf_predict_dev(hv_ekf *ekf, const double *dt_dev, const double *gyro_dev, const double *acc_dev);
+/* update(m,P,y,H,R,...) (ekf.cpp:57-82) with truncated H (n_rows x l, column-major, per filter),
+ * R = r_diag[f] * I: used by ZUPT / ZRUPT / position / height / orientation updates. */
+int hv_ekf_update(hv_ekf *ekf, int n_rows, int l, const double *H, const double *y, const double *r_diag,
+                  const unsigned char *active /* optional [batch] */, int normalize_all_quaternions);
+/* visualTrackOutlierCheck (ekf.cpp:787-819) given v = y - f: chi2[f] = noiseScale * v' S^-1 v and
+ * status[f] = 0 (INLIER) / 3 (CHI2, chi2 > chi2inv95[n_rows]). Does not modify the filter. Synchronous. */
+int hv_ekf_visual_gate(hv_ekf *ekf, int n_rows, int l, const double *H, const double *v, double r,
+                       double *chi2, int *status);
+/* updateVisualTrack (ekf.cpp:829-844) given v = y - f; R = r^2 * noiseScale * I. */
+int hv_ekf_visual_update(hv_ekf *ekf, int n_rows, int l, const double *H, const double *v, double r,
+                         const unsigned char *active);
+/* Device-resident variant: mode 0 = gate only, 1 = update, 2 = update only where the gate passes. */
+int hv_ekf_visual_dev(hv_ekf *ekf, int n_rows, int l, const double *H_dev, const double *v_dev, double r,
+                      int mode, double *chi2_dev, int *status_dev);
+/* updateVisualPoseAugmentation(discarded[f]) (ekf.cpp:848-885; -1 = last pose) incl. the Joseph form,
+ * maintainPositiveSemiDefinite and normalizeQuaternions; updateUndoAugmentation (ekf.cpp:888-903). */
+int hv_ekf_augment(hv_ekf *ekf, const int *discarded /* [batch] or NULL */, const unsigned char *active);
+int hv_ekf_undo_augment(hv_ekf *ekf, const unsigned char *active);
+int hv_ekf_symmetrize(hv_ekf *ekf);                                 /* maintainPositiveSemiDefinite */
+int hv_ekf_normalize_quaternions(hv_ekf *ekf, int only_current);    /* ekf.cpp:1024-1032            */
+/* transformTo (ekf.cpp:704-758): the adapter computes pChangeMat (3x3), qChangeMat (4x4) (both
+ * row-major) and the translation from the host mirror; the device applies m = A m, P = A P A'. */
+int hv_ekf_transform(hv_ekf *ekf, int filter, const double *pChange3x3, const double *qChange4x4,
+                     const double *translation3);
+
 /* ---- per-kernel timing (hipEvents on the context stream) ---------------------------------- */
 enum { HV_K_PYR_L0 = 0, HV_K_PYR_LN = 1, HV_K_KLT = 2, HV_K_EKF_PREDICT = 3, HV_K_EKF_UPDATE = 4,
        HV_K_EKF_AUGMENT = 5, HV_K_COUNT = 6 };
