@@ -122,6 +122,96 @@ class TrackerBench:
         return float(self.tracked.float().mean().item())
 
 
+EKF_ROWS, EKF_COLS = 40, 160           # a 10-pose stereo track touching the whole trail
+EKF_PREDICTS, EKF_GATES, EKF_UPDATES = 10, 20, 5     # per camera frame: IMU 200 Hz / camera 20 Hz; backend.cpp:8,10
+HANOI = [19, 16, 17, 16, 18, 16, 17, 16]             # steady-state discard pattern (ekf_state_index.cpp:259-276)
+
+
+class EkfBench:
+    """Per step and per sequence: 10 predicts, 20 chi2 gates of which 5 pass and update, P=(P+P')/2,
+    1 pose augmentation (Joseph form) -- every call batched over the B filters, inputs in HBM."""
+
+    def __init__(self, ctx, B, device, seed=0):
+        import torch
+        from hybvio_amd import capi
+        self.torch, self.B, self.ctx = torch, B, ctx
+        dev = torch.device("cuda", device)
+        self.ekf = capi.EkfBatch(ctx, capi.ekf_default_params(), B)
+        rng = np.random.default_rng(100 + seed)
+        n_sets = 4
+        H = rng.normal(size=(n_sets, B, EKF_COLS, EKF_ROWS))               # [set][filter][col][row] = column-major
+        self.H = torch.from_numpy(H).to(dev)
+        self.v_in = torch.from_numpy(0.02 * rng.normal(size=(n_sets, B, EKF_ROWS))).to(dev)    # passes the gate
+        self.v_out = torch.from_numpy(2.0 * rng.normal(size=(n_sets, B, EKF_ROWS))).to(dev)    # rejected
+        self.dt = torch.full((B,), 0.005, dtype=torch.float64, device=dev)
+        self.gyro = torch.from_numpy(rng.normal(0, 0.05, (EKF_PREDICTS, B, 3))).to(dev)
+        self.acc = torch.from_numpy(rng.normal(0, 0.05, (EKF_PREDICTS, B, 3)) + [0.0, 0.0, 9.819]).to(dev)
+        self.chi2 = torch.zeros(B, dtype=torch.float64, device=dev)
+        self.status = torch.zeros(B, dtype=torch.int32, device=dev)
+        self.accepted = torch.zeros((), dtype=torch.int64, device=dev)
+        self.k = 0
+        for _ in range(24):                       # fill the pose trail before any visual update
+            self._predicts()
+            self.ekf._chk(capi.lib().hv_ekf_augment(self.ekf._h, None, None), "hv_ekf_augment")
+        torch.cuda.synchronize()
+
+    def _predicts(self):
+        for i in range(EKF_PREDICTS):
+            self.ekf.predict_dev(self.dt.data_ptr(), self.gyro[i].data_ptr(), self.acc[i].data_ptr())
+
+    def step(self):
+        from hybvio_amd import capi
+        s = self.k % self.H.shape[0]
+        self._predicts()
+        H = self.H[s].data_ptr()
+        for j in range(EKF_GATES):
+            passing = j % (EKF_GATES // EKF_UPDATES) == 0
+            v = (self.v_in if passing else self.v_out)[(s + j) % self.H.shape[0]]
+            self.ekf.visual_dev(EKF_ROWS, EKF_COLS, H, v.data_ptr(), 0.05, 2 if passing else 0,
+                                self.chi2.data_ptr(), self.status.data_ptr())
+            if passing:
+                self.accepted += (self.status == 0).sum()
+        self.ekf.symmetrize()
+        d = np.full(self.B, HANOI[self.k % len(HANOI)], np.int32)
+        self.ekf._chk(capi.lib().hv_ekf_augment(self.ekf._h, d.ctypes.data_as(capi.i32p), None), "hv_ekf_augment")
+        self.k += 1
+
+
+def cpu_baseline_ekf(budget_s=8.0):
+    """The same per-frame EKF call sequence on the CPU oracle (scalar C restatement of ekf.cpp with the
+    reference's dense Joseph form; NOT Eigen)."""
+    from oracle import orc
+    rng = np.random.default_rng(100)
+    e = orc.Ekf()
+    e.initialize_orientation(np.array([0.0, 0.0, 9.819]))
+    e.set_first_sample_time(0.0)
+    t = 0.0
+    for _ in range(24):
+        t += 0.05
+        e.predict(t, np.zeros(3), np.array([0.0, 0.0, 9.819]))
+        e.update_visual_pose_augmentation(-1)
+    H = rng.normal(size=(EKF_ROWS, EKF_COLS))
+    zeros = np.zeros(EKF_ROWS)
+    frames, t0 = 0, time.perf_counter()
+    while True:
+        for i in range(EKF_PREDICTS):
+            t += 0.005
+            e.predict(t, rng.normal(0, 0.05, 3), np.array([0.0, 0.0, 9.819]) + rng.normal(0, 0.05, 3))
+        for j in range(EKF_GATES):
+            passing = j % (EKF_GATES // EKF_UPDATES) == 0
+            v = rng.normal(size=EKF_ROWS) * (0.02 if passing else 2.0)
+            st, _ = e.visual_track_outlier_check(H, zeros, v, 0.05)
+            if st == 0:
+                e.update_visual_track(H, zeros, v, 0.05)
+        e.maintain_psd()
+        e.update_visual_pose_augmentation(HANOI[frames % len(HANOI)])
+        frames += 1
+        el = time.perf_counter() - t0
+        if el > budget_s:
+            break
+    return frames / el, f"{frames} frames of the EKF sequence, oracle/ekf_oracle.c -O2, 1 thread, {el:.1f} s"
+
+
 def cpu_baseline(budget_s=12.0):
     """The CPU oracle (a scalar restatement of the OpenCV path HybVIO calls; NOT SIMD OpenCV) timed
     on this box on the same per-frame work: 2 pyramid builds + 2 LK calls x 200 points."""
@@ -155,6 +245,7 @@ def main():
     ap.add_argument("--sequences", type=int, default=256, help="independent VIO sequences per GPU (B)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-latency-mode", action="store_true")
+    ap.add_argument("--no-ekf", action="store_true", help="skip the C3 (tracker + HIP EKF) leg")
     args = ap.parse_args()
 
     import torch
@@ -230,6 +321,37 @@ def main():
                                   "algorithmic_bytes_per_stereo_frame": ab["stereo_frame"]},
             "tracked_fraction": tracked,
         }
+    # ---- C3: the same tracker work + the HIP EKF (configs[2]) ----
+    if not args.no_ekf:
+        eb = EkfBench(tb.ctx, B, local_rank, seed=rank)
+        for _ in range(args.warmup):
+            tb.step(); eb.step()
+        tb.ctx.profile_enable(True)
+        tb.ctx.profile_reset()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            tb.step(); eb.step()
+        barrier()
+        el3 = time.perf_counter() - t0
+        prof3 = {name: tb.ctx.profile_read(kid) for name, kid in
+                 (("ekf_predict", capi.K_EKF_PREDICT), ("ekf_update_gate", capi.K_EKF_UPDATE), ("ekf_augment", capi.K_EKF_AUGMENT))}
+        tb.ctx.profile_enable(False)
+        accepted = int(eb.accepted.item())
+        if world > 1:
+            tt = torch.tensor([el3], dtype=torch.float64, device="cuda")
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            el3 = float(tt.item())
+        if rank == 0:
+            out["c3"] = {
+                "workload": "C3: C2 + HIP EKF per frame (10 predicts, 20 chi2 gates n=40 l=160 of which 5 update, "
+                            "symmetrise, 1 Joseph-form augmentation), state dim 160, f64",
+                "value": world * B * args.steps / el3, "unit": "frames/s", "ms_per_step": el3 / args.steps * 1e3,
+                "kernels": {k: {"avg_ms": ms / n, "launches": n, "total_ms": ms} for k, (ms, n) in prof3.items() if n},
+                "updates_accepted_fraction": accepted / float(B * args.steps * EKF_UPDATES * (1 + args.warmup / args.steps)),
+            }
+        eb.ekf.close()
+        del eb
     del tb
 
     if rank == 0 and not args.no_latency_mode:
@@ -249,6 +371,11 @@ def main():
         del t1
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline()
+        if "c3" in out:
+            fps_ekf, sample = cpu_baseline_ekf()
+            fps_trk = out["cpu_baseline"]["value"]
+            out["c3"]["cpu_baseline"] = {"value": 1.0 / (1.0 / fps_trk + 1.0 / fps_ekf), "unit": "frames/s", "cores": 1,
+                                         "kind": "port", "ekf_only_frames_per_s": fps_ekf, "sample": sample}
     if rank == 0:
         print(json.dumps(out))
     if world > 1:

@@ -40,8 +40,21 @@ __device__ __forceinline__ double4v mfma_tile(int K, FA a_at, FB b_at)
 {
     const int lane = threadIdx.x & 63, r = lane & 15, q = lane >> 4;
     double4v acc = {0.0, 0.0, 0.0, 0.0};
-    for (int k0 = 0; k0 < K; k0 += 4)
-        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a_at(r, k0 + q), b_at(k0 + q, r), acc, 0, 0, 0);
+    // operands come straight from L2/LDS: keep the next 4 k-steps (8 loads) in flight while the
+    // current 4 MFMAs issue, otherwise every MFMA waits a full memory round trip
+    constexpr int U = 4;
+    double a0[U], b0[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) { a0[u] = a_at(r, 4 * u + q); b0[u] = b_at(4 * u + q, r); }
+    for (int k0 = 0; k0 < K; k0 += 4 * U) {
+        double a1[U], b1[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) { a1[u] = a_at(r, k0 + 4 * (U + u) + q); b1[u] = b_at(k0 + 4 * (U + u) + q, r); }
+#pragma unroll
+        for (int u = 0; u < U; u++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[u], b0[u], acc, 0, 0, 0);
+#pragma unroll
+        for (int u = 0; u < U; u++) { a0[u] = a1[u]; b0[u] = b1[u]; }
+    }
     return acc;
 }
 
@@ -207,6 +220,7 @@ struct UpdateArgs {
 
 constexpr int UPD_THREADS = 1024;
 
+template <bool USE_LDS>
 __global__ __launch_bounds__(UPD_THREADS) void ekf_update_kernel(UpdateArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
@@ -218,10 +232,13 @@ __global__ __launch_bounds__(UPD_THREADS) void ekf_update_kernel(UpdateArgs a)
     double *m = a.m + (size_t)b * n, *P = a.P + (size_t)b * n * n;
     const double *H = a.H + (size_t)b * nr * l;
     const double rd = a.rdiag ? a.rdiag[b] : a.rd0;
-    // all LDS comes from the dynamic region (keeps the base 16-byte aligned): [T] colk[R] red[16] flag
-    double *T = a.use_lds ? smem : a.ws + (size_t)b * R * nr;       // T(r, c) = T[c * R + r]
-    double *colk = a.use_lds ? smem + (((size_t)R * nr + 1) & ~(size_t)1) : smem;   // current pivot column
-    double *red = colk + ((R + 1) & ~1);
+    // all LDS comes from the dynamic region (keeps the base 16-byte aligned): [T] colk[2][R] red[16] flag
+    // USE_LDS is a template parameter so that the common case compiles to ds_read/ds_write (a
+    // run-time select would turn every access into a flat load)
+    double *T = USE_LDS ? smem : a.ws + (size_t)b * R * nr;         // T(r, c) = T[c * R + r]
+    double *colk = USE_LDS ? smem + (((size_t)R * nr + 1) & ~(size_t)1) : smem;     // pivot column (2 buffers)
+    double *colk2 = colk + ((R + 1) & ~1);
+    double *red = colk2 + ((R + 1) & ~1);
     int *s_stop = reinterpret_cast<int *>(red + nwaves);
     const bool gate_only = a.mode == 0;
 
@@ -268,22 +285,33 @@ __global__ __launch_bounds__(UPD_THREADS) void ekf_update_kernel(UpdateArgs a)
     }
     __syncthreads();
 
-    // ---- C: right-looking Cholesky over the tall matrix. Gate-only skips the (HP)' rows. ----
-    for (int k = 0; k < nr; k++) {
-        const double d = sqrt(T[(size_t)k * R + k]);
-        __syncthreads();                               // everyone has read the pivot
-        for (int r = k + t; r < R; r += UPD_THREADS) {
+    // ---- C: right-looking Cholesky over the tall matrix, ONE barrier per column: the wavefront
+    // that owns column k+1 in the trailing update finishes it first and immediately scales it into
+    // the other pivot buffer (look-ahead), so the next step can start after a single barrier.
+    // Gate-only skips the (HP)' rows. ----
+    double *colbuf[2] = {colk, colk2};
+    auto scale_column = [&](int k, double *dst, int first, int stride) {
+        const double d = sqrt(T[(size_t)k * R + k]), inv = 1.0 / d;
+        for (int r = k + first; r < R; r += stride) {
             if (gate_only && r >= nr && r < R - 1) continue;
-            const double val = (r == k) ? d : T[(size_t)k * R + r] / d;
-            T[(size_t)k * R + r] = val;
-            colk[r] = val;
+            const double val = (r == k) ? d : T[(size_t)k * R + r] * inv;
+            if (r >= nr) T[(size_t)k * R + r] = val;      // only the Y' / z' rows are read again later
+            dst[r] = val;
         }
-        __syncthreads();
+    };
+    scale_column(0, colbuf[0], t, UPD_THREADS);
+    __syncthreads();
+    for (int k = 0; k < nr; k++) {
+        const double *ck = colbuf[k & 1];
         for (int c = k + 1 + wave; c < nr; c += nwaves) {
-            const double lc = colk[c];
+            const double lc = ck[c];
             for (int r = c + lane; r < R; r += 64) {
                 if (gate_only && r >= nr && r < R - 1) continue;
-                T[(size_t)c * R + r] -= colk[r] * lc;
+                T[(size_t)c * R + r] -= ck[r] * lc;
+            }
+            if (c == k + 1) {                              // this wavefront owns the next pivot column
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                scale_column(k + 1, colbuf[(k + 1) & 1], lane, 64);
             }
         }
         __syncthreads();
@@ -576,16 +604,17 @@ static int ekf_launch_update(Ekf *e, int nr, int l, const double *H_dev, const d
     a.m = e->m; a.P = e->P; a.H = H_dev; a.v = v_dev; a.rdiag = rdiag_dev; a.rd0 = rd0; a.noise_scale = e->noise_scale;
     a.ws = e->ws; a.chi2 = chi2_dev; a.status = status_dev; a.active = active_dev;
     const size_t tall = (((size_t)a.R * nr + 1) & ~(size_t)1) * sizeof(double);
-    const size_t small = (size_t)(((a.R + 1) & ~1) + UPD_THREADS / 64 + 2) * sizeof(double);   // colk + red + flag
+    const size_t small = (size_t)(2 * ((a.R + 1) & ~1) + UPD_THREADS / 64 + 2) * sizeof(double);   // 2 x colk + red + flag
     a.use_lds = tall + small <= 150 * 1024;
     const size_t shmem = a.use_lds ? tall + small : small;
     static bool attr_set = false;
     if (!attr_set) {
-        HV_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void *>(ekf_update_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024));
+        HV_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void *>(ekf_update_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024));
         attr_set = true;
     }
     ScopedKernelTime tm(c, HV_K_EKF_UPDATE);
-    hipLaunchKernelGGL(ekf_update_kernel, dim3(e->batch), dim3(UPD_THREADS), shmem, c->stream, a);
+    if (a.use_lds) hipLaunchKernelGGL(ekf_update_kernel<true>, dim3(e->batch), dim3(UPD_THREADS), shmem, c->stream, a);
+    else           hipLaunchKernelGGL(ekf_update_kernel<false>, dim3(e->batch), dim3(UPD_THREADS), shmem, c->stream, a);
     HV_HIP(c, hipGetLastError());
     return HV_OK;
 }
