@@ -37,5 +37,33 @@ def build_hip(force: bool = False, verbose: bool = False) -> str:
     return LIB
 
 
+HOST = os.path.join(PKG, "host")
+HOST_LIB = os.path.join(LIBDIR, "libhybvio_host.so")
+HOST_TEST = os.path.join(LIBDIR, "test_host_adapters")
+
+
+def build_host(force: bool = False, verbose: bool = False) -> tuple[str, str]:
+    """C++ adapters (pure C-ABI client: plain g++, no HIP headers) and their test executable."""
+    build_hip()
+    srcs = sorted(glob.glob(os.path.join(HOST, "*.cpp")))
+    test_src = os.path.join(PKG, "..", "tests", "cpp", "test_host_adapters.cpp")
+    deps = srcs + glob.glob(os.path.join(HOST, "*.hpp")) + [test_src, LIB]
+    fresh = all(os.path.exists(f) for f in (HOST_LIB, HOST_TEST)) and \
+        all(os.path.getmtime(d) <= min(os.path.getmtime(HOST_LIB), os.path.getmtime(HOST_TEST)) for d in deps)
+    if fresh and not force:
+        return HOST_LIB, HOST_TEST
+    cxx = os.environ.get("CXX", "g++")
+    common = ["-std=c++17", "-O2", "-Wall", "-Wextra", "-fPIC"]
+    link = ["-L" + LIBDIR, "-Wl,-rpath," + LIBDIR, "-Wl,-rpath,/opt/rocm/lib"]
+    cmds = [[cxx] + common + ["-shared", "-o", HOST_LIB] + srcs + link + ["-lhybvio_hip"],
+            [cxx] + common + ["-o", HOST_TEST, test_src] + link + ["-lhybvio_host", "-lhybvio_hip"]]
+    for cmd in cmds:
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+    return HOST_LIB, HOST_TEST
+
+
 if __name__ == "__main__":
     print(build_hip(force=True, verbose=True))
+    print(build_host(force=True, verbose=True))

@@ -86,6 +86,7 @@ PROTOTYPES = {
     "hv_ekf_get_state": (C.c_int, [C.c_void_p, C.c_int, f64p, f64p]),
     "hv_ekf_get_means": (C.c_int, [C.c_void_p, f64p]),
     "hv_ekf_set_process_noise": (C.c_int, [C.c_void_p, C.c_int, f64p]),
+    "hv_ekf_get_process_noise": (C.c_int, [C.c_void_p, C.c_int, f64p]),
     "hv_ekf_get_dydx": (C.c_int, [C.c_void_p, C.c_int, f64p]),
     "hv_ekf_device_pointers": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]),
     "hv_ekf_predict": (C.c_int, [C.c_void_p, f64p, f64p, f64p]),

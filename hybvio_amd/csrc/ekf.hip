@@ -749,6 +749,15 @@ int hv_ekf_set_process_noise(hv_ekf *h, int b, const double *Q)
     return HV_OK;
 }
 
+int hv_ekf_get_process_noise(hv_ekf *h, int b, double *Q)
+{
+    if (!h || !Q || b < 0 || b >= h->e.batch) return HV_ERR_INVALID;
+    Ctx *c = h->e.c;
+    HV_HIP(c, hipMemcpyAsync(Q, h->e.Q + (size_t)b * 144, sizeof(double) * 144, hipMemcpyDeviceToHost, c->stream));
+    HV_HIP(c, hipStreamSynchronize(c->stream));
+    return HV_OK;
+}
+
 int hv_ekf_get_dydx(hv_ekf *h, int b, double *F)
 {
     if (!h || !F || b < 0 || b >= h->e.batch) return HV_ERR_INVALID;

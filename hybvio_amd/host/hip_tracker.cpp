@@ -1,0 +1,114 @@
+// HIP-backed tracker::ImagePyramid::Factory and tracker::OpticalFlow (see hybvio_host.hpp).
+// Counterparts of CpuImagePyramidFactory (src/tracker/image_pyramid.cpp:27-49) and
+// OpenCvOpticalFlow (src/tracker/optical_flow.cpp:61-103).
+#include <cassert>
+#include <cstdio>
+#include <stdexcept>
+
+#include "hybvio_host.hpp"
+
+namespace hybvio {
+
+Session::Session(const hv_params &params) : params_(params)
+{
+    const int rc = hv_create(&params_, &ctx_);
+    if (rc != HV_OK) throw std::runtime_error(std::string("hv_create: ") + hv_status_string(rc));
+}
+
+Session::~Session() { hv_destroy(ctx_); }
+
+namespace tracker {
+
+ImagePyramid::~ImagePyramid() = default;
+ImagePyramid::Factory::~Factory() = default;
+OpticalFlow::~OpticalFlow() = default;
+
+namespace {
+
+// One pooled device slot. util::Allocator (src/util/allocator.hpp:55-67) recycles a pyramid when
+// only the pool still references it; here the shared_ptr's last owner returns the slot to the
+// device pool, which has the same effect: a pyramid lives exactly as long as an Image refers to it.
+struct HipImagePyramid : ImagePyramid {
+    hv_ctx *ctx;
+    int slot;
+    HipImagePyramid(hv_ctx *c, int s) : ctx(c), slot(s) {}
+    ~HipImagePyramid() override { hv_pyramid_release(ctx, slot); }
+    int deviceSlot() const final { return slot; }
+
+    std::vector<GrayType> getGrayLevel(std::size_t i, int &w, int &h) final {
+        const int rc0 = hv_pyramid_level_size(ctx, (int)i, &w, &h);
+        assert(rc0 == HV_OK); (void)rc0;
+        std::vector<GrayType> out((size_t)w * h);
+        const int rc = hv_pyramid_download(ctx, slot, (int)i, out.data(), nullptr);
+        assert(rc == HV_OK); (void)rc;
+        return out;
+    }
+    std::vector<GradientType> getGradientLevel(std::size_t i, int &w, int &h) final {
+        const int rc0 = hv_pyramid_level_size(ctx, (int)i, &w, &h);
+        assert(rc0 == HV_OK); (void)rc0;
+        std::vector<GradientType> out((size_t)w * h * GRADIENT_CHANNELS);
+        const int rc = hv_pyramid_download(ctx, slot, (int)i, nullptr, out.data());
+        assert(rc == HV_OK); (void)rc;
+        return out;
+    }
+};
+
+class HipImagePyramidFactory : public ImagePyramid::Factory {
+    Session &session;
+public:
+    explicit HipImagePyramidFactory(Session &s) : session(s) {}
+    std::shared_ptr<ImagePyramid> compute(const GrayImage &img) final {
+        assert(img.width == session.params().width && img.height == session.params().height);
+        int slot = -1;
+        int rc = hv_pyramid_acquire(session.ctx(), &slot);
+        assert(rc == HV_OK && "pyramid pool exhausted: raise hv_params.pool_size");
+        auto pyramid = std::make_shared<HipImagePyramid>(session.ctx(), slot);
+        rc = hv_pyramid_build(session.ctx(), slot, img.data, img.strideBytes);   // H2D + kernels, asynchronous
+        assert(rc == HV_OK); (void)rc;
+        // the caller's pixels were handed to an asynchronous copy: fence before they may be reused
+        hv_synchronize(session.ctx());
+        return pyramid;
+    }
+};
+
+class HipOpticalFlow : public OpticalFlow {
+    Session &session;
+    std::vector<std::int32_t> workStatus;
+public:
+    explicit HipOpticalFlow(Session &s) : session(s) {}
+    void compute(ImagePyramid &prevImagePyramid, ImagePyramid &imagePyramid,
+                 const std::vector<Feature::Point> &prevCorners, std::vector<Feature::Point> &corners,
+                 std::vector<Feature::Status> &trackStatus, bool useInitialCorners,
+                 int overrideMaxIterations) final {
+        // optical_flow.cpp:26-40: outputs are cleared and sized by the callee; empty input returns early
+        const size_t n = prevCorners.size();
+        trackStatus.clear();
+        trackStatus.resize(n, Feature::Status::FAILED_FLOW);
+        if (n == 0) { corners.clear(); return; }
+        if (!useInitialCorners) corners.assign(n, Feature::Point{0.f, 0.f});
+        assert(corners.size() == n);
+        workStatus.assign(n, 2);
+        static_assert(sizeof(Feature::Point) == 2 * sizeof(float), "Point must be two packed floats (optical_flow.cpp:21-22)");
+        const int rc = hv_optical_flow_compute(session.ctx(), prevImagePyramid.deviceSlot(), imagePyramid.deviceSlot(),
+                                               (int)n, reinterpret_cast<const float *>(prevCorners.data()),
+                                               reinterpret_cast<float *>(corners.data()), workStatus.data(),
+                                               useInitialCorners ? 1 : 0, overrideMaxIterations);
+        assert(rc == HV_OK); (void)rc;
+        for (size_t i = 0; i < n; ++i) trackStatus[i] = static_cast<Feature::Status>(workStatus[i]);
+    }
+};
+
+}  // namespace
+
+std::unique_ptr<ImagePyramid::Factory> ImagePyramid::Factory::buildHip(Session &s)
+{
+    return std::unique_ptr<ImagePyramid::Factory>(new HipImagePyramidFactory(s));
+}
+
+std::unique_ptr<OpticalFlow> OpticalFlow::buildHip(Session &s)
+{
+    return std::unique_ptr<OpticalFlow>(new HipOpticalFlow(s));
+}
+
+}  // namespace tracker
+}  // namespace hybvio

@@ -1,0 +1,188 @@
+// hybvio_host.hpp -- C++ host adapters that present libhybvio_hip.so (include/hybvio_hip.h) behind
+// HybVIO's own interfaces for the hot path:
+//
+//   tracker::ImagePyramid / ImagePyramid::Factory   src/tracker/image_pyramid.hpp:18-43
+//   tracker::OpticalFlow                            src/tracker/optical_flow.hpp:20-40
+//   tracker::Feature::{Point,Status}                src/tracker/track.hpp:8-32
+//   odometry::EKF                                   src/odometry/ekf.hpp:62-174
+//
+// Same class and method names, argument order and meaning, ownership (factories return unique_ptr,
+// pyramids are shared_ptr recycled from a pool) and error behaviour (contract violations assert;
+// algorithmic failure is data: Feature::Status / VuOutlierStatus) as the reference. The only
+// difference is vocabulary that the reference takes from libraries that are not vendored here:
+// accelerated::Image becomes GrayImage (pointer + size + stride) and Eigen vectors / matrices
+// become the plain aliases below (column-major storage, exactly what Eigen::Map wraps).
+// INTEGRATION.md shows the three-line glue that binds these to the reference's real types and the
+// two call sites (image.cpp:55-56, backend.cpp:187) where the HIP factories are selected.
+//
+// This layer is a pure client of the C ABI: it includes no HIP header and links only
+// libhybvio_hip.so.
+#pragma once
+#include <array>
+#include <cstdint>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "../../include/hybvio_hip.h"
+
+namespace hybvio {
+
+// ---- stand-ins for Eigen types (same memory layout as Eigen's defaults) ----
+using Vector3d = std::array<double, 3>;
+using Vector4d = std::array<double, 4>;
+using VectorXd = std::vector<double>;
+struct MatrixXd {                       // column-major, like Eigen::MatrixXd
+    int rows = 0, cols = 0;
+    std::vector<double> data;
+    MatrixXd() = default;
+    MatrixXd(int r, int c) : rows(r), cols(c), data((size_t)r * c, 0.0) {}
+    double &operator()(int i, int j) { return data[(size_t)j * rows + i]; }
+    double operator()(int i, int j) const { return data[(size_t)j * rows + i]; }
+};
+
+// One device session: the hv_ctx (stream + pyramid pool) shared by the tracker adapters and the EKF.
+class Session {
+public:
+    explicit Session(const hv_params &params);
+    ~Session();
+    Session(const Session &) = delete;
+    Session &operator=(const Session &) = delete;
+    hv_ctx *ctx() const { return ctx_; }
+    const hv_params &params() const { return params_; }
+private:
+    hv_ctx *ctx_ = nullptr;
+    hv_params params_{};
+};
+
+namespace tracker {
+
+struct Feature {   // src/tracker/track.hpp:8-32
+    enum class Status { TRACKED, NEW, FAILED_FLOW, RANSAC_OUTLIER, FLOW_OUT_OF_RANGE, OUT_OF_RANGE,
+                        FAILED_EPIPOLAR_CHECK, CULLED, BLACKLISTED };
+    struct Point { float x, y; };
+    int id = -1;
+    Status status = Status::NEW;
+    std::array<Point, 2> points = {{{-1, -1}, {-1, -1}}};
+    float depth = -1;
+};
+
+struct GrayImage {           // what accelerated::opencv::ref(cv::Mat) carries at image.cpp:211
+    const std::uint8_t *data;
+    int width, height, strideBytes;
+};
+
+struct ImagePyramid {        // src/tracker/image_pyramid.hpp:18-43
+    typedef std::uint8_t GrayType;
+    typedef std::int16_t GradientType;
+    static constexpr std::size_t GRADIENT_CHANNELS = 2;
+    static constexpr float GRADIENT_SCALE_0_255 = 1.0f / 32;
+    static constexpr float GRADIENT_SCALE_01 = GRADIENT_SCALE_0_255 / 255;
+
+    // The reference's getGrayLevel/getGradientLevel are `assert(false && "TODO")` GPU hooks
+    // (image_pyramid.cpp:17-25); here they read a level back from the device.
+    virtual std::vector<GrayType> getGrayLevel(std::size_t i, int &width, int &height) = 0;
+    virtual std::vector<GradientType> getGradientLevel(std::size_t i, int &width, int &height) = 0;
+    virtual int deviceSlot() const = 0;
+    virtual ~ImagePyramid();
+
+    struct Factory {
+        virtual std::shared_ptr<ImagePyramid> compute(const GrayImage &image) = 0;
+        virtual ~Factory();
+        static std::unique_ptr<Factory> buildHip(Session &session);   // sibling of buildOpenCv
+    };
+};
+
+struct OpticalFlow {         // src/tracker/optical_flow.hpp:20-40
+    static std::unique_ptr<OpticalFlow> buildHip(Session &session);   // sibling of buildOpenCv
+    virtual ~OpticalFlow();
+    virtual void compute(
+        ImagePyramid &prevImagePyramid,
+        ImagePyramid &imagePyramid,
+        const std::vector<Feature::Point> &prevCorners,
+        std::vector<Feature::Point> &corners,
+        std::vector<Feature::Status> &trackStatus,
+        bool useInitialCorners,
+        int overrideMaxIterations = -1) = 0;
+};
+
+}  // namespace tracker
+
+namespace odometry {
+
+// state layout: src/odometry/ekf.hpp:26-50
+constexpr int POS = 0, VEL = 3, ORI = 6, BGA = 10, BAA = 13, BAT = 16, SFT = 19, CAM = 20;
+constexpr int INER_DIM = CAM, POSE_DIM = 7, MAP_POINT_DIM = 3;
+constexpr int Q_ACC = 0, Q_GYRO = 3, Q_BGA_DRIFT = 6, Q_BAA_DRIFT = 9, Q_DIM = 12;
+
+enum class VuOutlierStatus { INLIER, NOT_COMPUTED, RMSE, CHI2 };
+
+using MatrixInertialCov = MatrixXd;     // INER_DIM x INER_DIM
+using VectorInertialMean = VectorXd;    // INER_DIM
+
+// Every pure virtual of odometry::EKF (ekf.hpp:62-174), same order.
+class EKF {
+public:
+    static std::unique_ptr<EKF> buildHip(Session &session, const hv_ekf_params &parameters);
+    virtual std::unique_ptr<EKF> clone() const = 0;
+    virtual ~EKF();
+
+    virtual void initializeOrientation(const Vector3d &xa) = 0;
+    virtual void predict(double t, const Vector3d &xg, const Vector3d &xa) = 0;
+    virtual Vector3d position() const = 0;
+    virtual Vector3d velocity() const = 0;
+    virtual Vector4d orientation() const = 0;
+    virtual Vector3d biasGyroscopeAdditive() const = 0;
+    virtual Vector3d biasAccelerometerAdditive() const = 0;
+    virtual Vector3d biasAccelerometerTransform() const = 0;
+    virtual int camTrailSize() const = 0;
+    virtual Vector3d historyPosition(int i) const = 0;
+    virtual Vector4d historyOrientation(int i) const = 0;
+    virtual double historyTime(int i) const = 0;
+    virtual double speed() const = 0;
+    virtual double horizontalSpeed() const = 0;
+    virtual void updateZupt(double r) = 0;
+    virtual void updateZuptInitialization() = 0;
+    virtual void updateZrupt(const Vector3d &xg) = 0;
+    virtual void updatePseudoVelocity(double defaultSpeed, double r) = 0;
+    virtual void updatePosition(const Vector3d &pos, double r) = 0;
+    virtual void updateZeroHeight(double r) = 0;
+    virtual void updateOrientation(const Vector4d &q, double r) = 0;
+    virtual void getInertialState(VectorInertialMean &mean, MatrixInertialCov &cov) const = 0;
+    virtual void setInertialState(const VectorInertialMean &mean, const MatrixInertialCov &cov) = 0;
+    virtual double getImuToCameraTimeShift() const = 0;
+    virtual void translateTo(const Vector3d &pos) = 0;
+    virtual void transformTo(const Vector3d &pos, const Vector4d &q, int i = -1) = 0;
+    virtual VuOutlierStatus visualTrackOutlierCheck(const MatrixXd &visH, const VectorXd &f, const VectorXd &y,
+                                                    double r, double trackRmseThreshold) = 0;
+    virtual void updateVisualTrack(const MatrixXd &visH, const VectorXd &f, const VectorXd &y, double r) = 0;
+    virtual void updateVisualPoseAugmentation(int discardedPoseIndex = -1) = 0;
+    virtual void updateUndoAugmentation() = 0;
+    virtual Vector3d getMapPoint(int idx) const = 0;
+    virtual void insertMapPoint(int idx, const Vector3d &pf) = 0;
+    virtual int getMapPointStateIndex(int idx) const = 0;
+    virtual void conditionOnLastPose() = 0;
+    virtual void lockBiases() = 0;
+    virtual void normalizeQuaternions(bool onlyCurrent) = 0;
+    virtual void setFirstSampleTime(double t) = 0;
+    virtual bool isPositiveSemiDefinite() = 0;
+    virtual void maintainPositiveSemiDefinite() = 0;
+    virtual void setState(const VectorXd &m) = 0;
+    virtual void setStateCovariance(const MatrixXd &P) = 0;
+    virtual void setProcessNoise(const MatrixXd &Q) = 0;
+    virtual double getPlatformTime() const = 0;
+    virtual int getPoseCount() const = 0;
+    virtual const VectorXd &getState() const = 0;
+    virtual MatrixXd getStateCovariance() const = 0;
+    virtual const MatrixXd &getStateCovarianceRef() const = 0;
+    virtual MatrixXd getVisAugH() const = 0;
+    virtual MatrixXd getVisAugA() const = 0;
+    virtual MatrixXd getVisAugQ() const = 0;
+    virtual MatrixXd getDydx() const = 0;
+    virtual std::string stateAsString() const = 0;
+    virtual int getStateDim() const = 0;
+    virtual bool getWasStationary() const = 0;
+};
+
+}  // namespace odometry
+}  // namespace hybvio

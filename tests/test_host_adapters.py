@@ -1,0 +1,66 @@
+"""C++ host adapters (hybvio_amd/host): tracker::ImagePyramid::Factory / OpticalFlow / odometry::EKF
+re-implemented on the C ABI with the reference's interfaces.
+
+CPU part: the adapter library and its test program compile and link with plain g++ against
+libhybvio_hip.so (no HIP headers: they are a pure C-ABI client).
+GPU part: tests/cpp/test_host_adapters.cpp runs the reference's EKF tests (test/ekf.cpp) through
+EKF::buildHip and drives the tracker adapters like image.cpp:87-106; its tracker output is compared
+with the CPU oracle here.
+"""
+import os
+import subprocess
+import tempfile
+
+import numpy as np
+import pytest
+
+from hybvio_amd import build, synth
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden", "ekf_reference_fixtures.npz")
+
+
+def test_host_library_and_test_program_build():
+    lib, exe = build.build_host()
+    assert os.path.exists(lib) and os.access(exe, os.X_OK)
+    syms = subprocess.check_output(["nm", "-D", "--defined-only", "-C", lib], text=True)
+    for name in ("hybvio::tracker::ImagePyramid::Factory::buildHip", "hybvio::tracker::OpticalFlow::buildHip",
+                 "hybvio::odometry::EKF::buildHip"):
+        assert name in syms, name
+    needed = subprocess.check_output(["readelf", "-d", lib], text=True)
+    assert "libhybvio_hip.so" in needed and "amdhip64" not in needed      # only the C ABI is linked
+
+
+@pytest.mark.gpu
+def test_reference_tests_through_the_cpp_adapters(oracle):
+    _, exe = build.build_host()
+    fx = np.load(GOLD)
+    w, h, n = 320, 240, 96
+    tex = synth.Texture.make(33)
+    img0 = synth.render(tex, w, h, synth.Warp.make(0, 0, 0, w / 2, h / 2))
+    img1 = synth.render(tex, w, h, synth.Warp.make(-0.4, 1.1, 2.3, w / 2, h / 2), noise_seed=5, noise_sigma=1.5)
+    rng = np.random.default_rng(6)
+    pts = np.concatenate([synth.grid_points(w, h, n - 16, margin=8, seed=9),
+                          rng.uniform([-20, -20], [w + 20, h + 20], (16, 2)).astype(np.float32)])
+    with tempfile.TemporaryDirectory() as d:
+        np.savetxt(os.path.join(d, "dims.txt"), [w, h])
+        for key, name in (("chi2_M", "chi2_M"), ("chi2_v", "chi2_v"), ("poses", "poses"), ("gyro", "gyro"),
+                          ("acc", "acc"), ("P55", "P55"), ("m55", "m55")):
+            np.savetxt(os.path.join(d, name + ".txt"), np.asarray(fx[key]).reshape(-1), fmt="%.17g")
+        img0.tofile(os.path.join(d, "img0.raw"))
+        img1.tofile(os.path.join(d, "img1.raw"))
+        np.savetxt(os.path.join(d, "pts.txt"), pts.reshape(-1), fmt="%.9g")
+        r = subprocess.run([exe, d], capture_output=True, text=True, timeout=300)
+        print(r.stdout, r.stderr)
+        assert r.returncode == 0, r.stdout + r.stderr
+        assert "all host adapter tests passed" in r.stdout
+        out = np.loadtxt(os.path.join(d, "flow_out.txt"))
+        out2 = np.loadtxt(os.path.join(d, "flow_out_init2.txt"))
+        g1 = np.fromfile(os.path.join(d, "gray1.raw"), np.uint8).reshape((h + 1) // 2, (w + 1) // 2)
+    p0, p1 = oracle.Pyramid(img0), oracle.Pyramid(img1)
+    o_xy, o_st = oracle.optical_flow_compute(p0, p1, pts)
+    np.testing.assert_array_equal(out[:, 2].astype(int), o_st)
+    assert np.abs(out[:, :2] - o_xy).max() <= 1e-3
+    o_xy2, o_st2 = oracle.optical_flow_compute(p0, p1, pts, corners=o_xy, max_iter=2)
+    np.testing.assert_array_equal(out2[:, 2].astype(int), o_st2)
+    assert np.abs(out2[:, :2] - o_xy2).max() <= 1e-3
+    np.testing.assert_array_equal(g1, p1.gray(1))
