@@ -237,6 +237,61 @@ def cpu_baseline(budget_s=12.0):
                 sample=f"{frames} stereo frames 752x480 x 200 pts, oracle/pyrlk_oracle.c -O2, 1 thread, {el:.1f} s")
 
 
+class DistEnv:
+    """One process per GPU (torch.distributed.run sets RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*).
+    The data path has no collective: replicas only. This class only provides the timing contract --
+    barrier + device sync on both sides of the timed region and MAX over ranks of the elapsed time.
+    backend "nccl" is RCCL on ROCm; "gloo" lets the same code run in the CPU tests."""
+
+    def __init__(self, backend="nccl"):
+        import torch
+        self.torch = torch
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        self.backend = backend
+        self.dist = None
+        if self.world > 1:
+            import torch.distributed as dist
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            kw = {"device_id": torch.device("cuda", self.local_rank)} if backend == "nccl" else {}
+            dist.init_process_group(backend, **kw)
+            self.dist = dist
+
+    def barrier(self):
+        if self.dist is not None:
+            self.dist.barrier()
+        if self.backend == "nccl":
+            self.torch.cuda.synchronize()
+
+    def max_over_ranks(self, seconds: float) -> float:
+        if self.dist is None:
+            return seconds
+        dev = "cuda" if self.backend == "nccl" else "cpu"
+        t = self.torch.tensor([seconds], dtype=self.torch.float64, device=dev)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def timed(self, fn, steps: int) -> float:
+        """barrier+sync, `steps` calls of fn, barrier+sync; returns the MAX over ranks of the wall time."""
+        self.barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            fn()
+        self.barrier()
+        return self.max_over_ranks(time.perf_counter() - t0)
+
+    def close(self):
+        if self.dist is not None:
+            self.dist.barrier()
+            self.dist.destroy_process_group()
+
+
+def aggregate_value(units_per_rank_step: int, world: int, steps: int, seconds: float) -> float:
+    """Whole-job throughput: units all ranks processed / max-over-ranks time (weak scaling)."""
+    return world * units_per_rank_step * steps / seconds
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -249,22 +304,12 @@ def main():
     args = ap.parse_args()
 
     import torch
-    import torch.distributed as dist
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-
-    def barrier():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
+    torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
+    env = DistEnv("nccl")
+    world, rank, local_rank = env.world, env.rank, env.local_rank
 
     from hybvio_amd import capi
     B = args.sequences
@@ -273,25 +318,15 @@ def main():
         tb.step()
     tb.ctx.profile_enable(True)
     tb.ctx.profile_reset()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        tb.step()
-    barrier()
-    el = time.perf_counter() - t0
+    el = env.timed(tb.step, args.steps)
     prof = {name: tb.ctx.profile_read(kid) for name, kid in
             (("pyr_l0", capi.K_PYR_L0), ("pyr_ln", capi.K_PYR_LN), ("klt", capi.K_KLT))}
     tb.ctx.profile_enable(False)
     tracked = tb.tracked_fraction()
-    if world > 1:
-        tt = torch.tensor([el], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        el = float(tt.item())
 
     out = None
     if rank == 0:
         ab = algorithmic_bytes()
-        frames = world * B * args.steps
         ms_step = el / args.steps * 1e3
         # per-kernel achieved algorithmic GB/s from HIP-event durations on the context stream
         per_launch_bytes = dict(pyr_l0=2 * B * ab["pyr_l0"], pyr_ln=2 * B * ab["pyr_ln"] / 3.0, klt=B * ab["klt_call"])
@@ -306,7 +341,7 @@ def main():
         dom = max(kern, key=lambda k: kern[k]["total_ms"])
         out = {
             "metric": "VIO frames/sec at 752x480 stereo, 200 KLT features; pyramid+KLT HBM GB/s",
-            "value": frames / el, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "value": aggregate_value(B, world, args.steps, el), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u8/int16 pixels, int32/int64 sums, f32 solve", "data": "synthetic",
             "config": {"workload": "C2: 752x480 stereo, 200 pts, HIP pyramid+KLT tracker (2 builds + 2 LK calls per "
@@ -328,25 +363,16 @@ def main():
             tb.step(); eb.step()
         tb.ctx.profile_enable(True)
         tb.ctx.profile_reset()
-        barrier()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            tb.step(); eb.step()
-        barrier()
-        el3 = time.perf_counter() - t0
+        el3 = env.timed(lambda: (tb.step(), eb.step()), args.steps)
         prof3 = {name: tb.ctx.profile_read(kid) for name, kid in
                  (("ekf_predict", capi.K_EKF_PREDICT), ("ekf_update_gate", capi.K_EKF_UPDATE), ("ekf_augment", capi.K_EKF_AUGMENT))}
         tb.ctx.profile_enable(False)
         accepted = int(eb.accepted.item())
-        if world > 1:
-            tt = torch.tensor([el3], dtype=torch.float64, device="cuda")
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            el3 = float(tt.item())
         if rank == 0:
             out["c3"] = {
                 "workload": "C3: C2 + HIP EKF per frame (10 predicts, 20 chi2 gates n=40 l=160 of which 5 update, "
                             "symmetrise, 1 Joseph-form augmentation), state dim 160, f64",
-                "value": world * B * args.steps / el3, "unit": "frames/s", "ms_per_step": el3 / args.steps * 1e3,
+                "value": aggregate_value(B, world, args.steps, el3), "unit": "frames/s", "ms_per_step": el3 / args.steps * 1e3,
                 "kernels": {k: {"avg_ms": ms / n, "launches": n, "total_ms": ms} for k, (ms, n) in prof3.items() if n},
                 "updates_accepted_fraction": accepted / float(B * args.steps * EKF_UPDATES * (1 + args.warmup / args.steps)),
             }
@@ -357,7 +383,7 @@ def main():
     if rank == 0 and not args.no_latency_mode:
         # latency mode: ONE sequence, one frame at a time (what a single `main` process sees)
         t1 = TrackerBench(1, local_rank, seed=12345)
-        for _ in range(5):
+        for _ in range(2 * N_CYCLE):
             t1.step()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -367,7 +393,36 @@ def main():
         torch.cuda.synchronize()
         lat = (time.perf_counter() - t0) / n_lat
         out["latency_mode"] = {"sequences": 1, "ms_per_frame": lat * 1e3, "frames_per_s": 1.0 / lat,
-                               "tracked_fraction": t1.tracked_fraction()}
+                               "tracked_fraction": t1.tracked_fraction(), "launch": "eager"}
+        # The eager number is host-launch bound (~16 launches per frame). A step is a fixed launch
+        # sequence with period N_CYCLE, so capture it in HIP graphs and replay: GPU-bound latency.
+        try:
+            side = torch.cuda.Stream()
+            t1.ctx.set_stream(side.cuda_stream)
+            graphs = []
+            with torch.cuda.stream(side):
+                for _ in range(N_CYCLE):
+                    t1.step()                                # warm up on the capture stream
+                side.synchronize()
+                for _ in range(N_CYCLE):
+                    g = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g, stream=side):
+                        t1.step()
+                    graphs.append(g)
+                side.synchronize()
+                for i in range(2 * N_CYCLE):
+                    graphs[i % N_CYCLE].replay()
+                side.synchronize()
+                t0 = time.perf_counter()
+                for i in range(n_lat):
+                    graphs[i % N_CYCLE].replay()
+                side.synchronize()
+            latg = (time.perf_counter() - t0) / n_lat
+            out["latency_mode_graph"] = {"sequences": 1, "ms_per_frame": latg * 1e3, "frames_per_s": 1.0 / latg,
+                                         "tracked_fraction": t1.tracked_fraction(), "launch": "hipGraph replay"}
+            del graphs
+        except Exception as ex:                               # pragma: no cover
+            out["latency_mode_graph"] = {"error": repr(ex)[:200]}
         del t1
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline()
@@ -378,9 +433,7 @@ def main():
                                          "kind": "port", "ekf_only_frames_per_s": fps_ekf, "sample": sample}
     if rank == 0:
         print(json.dumps(out))
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+    env.close()
 
 
 if __name__ == "__main__":

@@ -1,0 +1,45 @@
+"""The multi-GPU contract of bench.py without a GPU: world_size 2 over gloo (replicas
+only -- no data-path collective; the only collectives are the timing barrier and the MAX reduce)."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import bench
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def test_two_rank_timing_contract_over_gloo():
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.join(HERE, "_dist_worker.py")]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=180)
+    assert r.returncode == 0, r.stdout + r.stderr
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["world"] == 2 and d["calls"] == 5
+    assert d["seconds"] >= 5 * 0.03 * 0.9                      # rank 1 sleeps 30 ms per step: MAX over ranks
+    assert abs(d["value"] - 2 * 7 * 5 / d["seconds"]) < 1e-9   # whole-job aggregate: all ranks' units / max time
+
+
+def test_single_process_needs_no_rendezvous():
+    env = bench.DistEnv("gloo")
+    assert env.world == 1 and env.dist is None
+    assert env.max_over_ranks(1.5) == 1.5
+    assert bench.aggregate_value(256, 1, 10, 2.0) == 1280.0
+
+
+def test_algorithmic_byte_accounting():
+    ab = bench.algorithmic_bytes()
+    # SURVEY.md section 8(d)
+    assert ab["pyr_image"] == 2_397_000 and ab["klt_call"] == 4_915_200 and ab["stereo_frame"] == 14_624_400
+    assert ab["pyr_l0"] + ab["pyr_ln"] == ab["pyr_image"]
+    big = bench.algorithmic_bytes(1280, 720, 400)
+    assert big["pyr_image"] == 6_120_000 and big["stereo_frame"] == 31_900_800
