@@ -33,13 +33,14 @@ namespace {
 
 constexpr int WIN = 31;
 constexpr int HALF_ROWS = 16;          // rows per half-wave
-constexpr int TS = 48;                 // staged J tile: TS x TS pixels (one dword each)
+constexpr int TS = 44;                 // staged J tile: TS x TS pixels (one dword each): 10 KB of LDS per wave with `region`
+constexpr int RW = 48;                 // width of the in-image region used to build border tiles
 constexpr int GRAY_SHIFT = 7;          // gray samples are pre-scaled by 128 (<= 32640: fits int16)
 // The four bilinear weights always sum to 2^14, so adding 2 to every pre-scaled sample adds exactly
 // 2^15 to the weighted sum: the rounding constant of CV_DESCALE rides along in the data and every
 // dot2 chain starts from 0. Gradients are stored as 4*d + 2 for the same reason (pyramid.hip).
 constexpr uint32_t ROUND_PAIR = 0x00020002u;
-constexpr int MARGIN = 8;
+constexpr int MARGIN = 6;
 constexpr int W_BITS = 14;
 
 struct KltArgs {
@@ -65,10 +66,12 @@ typedef short short2v __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ gptr_u8 as_global(const uint8_t *p) { return (gptr_u8)(uintptr_t)p; }
 
 // v_dot2_i32_i16: a.lo*b.lo + a.hi*b.hi + c on packed int16 pairs (a 32-bit v_mul_lo_u32 is
-// quarter-rate on CDNA and every operand here fits 16 bits).
+// quarter-rate on CDNA and every operand here fits 16 bits). clamp=true selects the 3-operand
+// VOP3P encoding, which takes an inline 0 / a separate accumulator; without it hipcc emits the
+// tied-accumulator v_dot2c + a v_mov per chain. No sum here can reach the int32 clamp.
 __device__ __forceinline__ int dot2(uint32_t a, uint32_t b, int c)
 {
-    return __builtin_amdgcn_sdot2(__builtin_bit_cast(short2v, a), __builtin_bit_cast(short2v, b), c, false);
+    return __builtin_amdgcn_sdot2(__builtin_bit_cast(short2v, a), __builtin_bit_cast(short2v, b), c, true);
 }
 __device__ __forceinline__ uint32_t pack16(int lo, int hi) { return ((uint32_t)hi << 16) | ((uint32_t)lo & 0xFFFFu); }
 __device__ __forceinline__ uint32_t lo16_pair(uint32_t a, uint32_t b) { return __builtin_amdgcn_perm(b, a, 0x05040100u); }
@@ -125,10 +128,11 @@ __device__ __forceinline__ void bilinear_weights(float a, float b, uint32_t &wA,
     wB = pack16(iw10, iw11);     // bottom row weights
 }
 
-__global__ __launch_bounds__(64) void klt_kernel(KltArgs a)
+__global__ __launch_bounds__(64, 4) void klt_kernel(KltArgs a)
 {
     // one dword per pixel: (J[x] << 7) | (J[x+1] << 23); +1 row for the unused 17th row of half 1
     __shared__ __attribute__((aligned(16))) uint32_t jt[(TS + 1) * TS];
+    __shared__ __attribute__((aligned(16))) uint32_t region[TS * (RW / 4)];   // raw bytes, border tiles only
 
     const int pt = (int)xcd_remap(blockIdx.x, gridDim.x);
     const int lane = threadIdx.x;
@@ -164,7 +168,10 @@ __global__ __launch_bounds__(64) void klt_kernel(KltArgs a)
             nx = nx * 2.f; ny = ny * 2.f;
         }
         px -= half_win; py -= half_win;
-        const int ipx = (int)floorf(px), ipy = (int)floorf(py);
+        // wave-uniform by construction: v_readfirstlane moves them to SGPRs so that the address and
+        // border arithmetic derived from them runs on the scalar unit (the kernel is VALU-issue bound)
+        const int ipx = __builtin_amdgcn_readfirstlane((int)floorf(px));
+        const int ipy = __builtin_amdgcn_readfirstlane((int)floorf(py));
         const int w = L.w[level], h = L.h[level];
         if (ipx < -WIN || ipx >= w || ipy < -WIN || ipy >= h) {
             if (level == 0) { st = 0; errv = 0.f; }
@@ -192,74 +199,86 @@ __global__ __launch_bounds__(64) void klt_kernel(KltArgs a)
             bilinear_weights(px - (float)ipx, py - (float)ipy, wA, wB);
             if (!col_ok) { wA = 0; wB = 0; }          // zero weights => every sample of this lane is 0
             const int xa = ipx + cx;
-            const int rbase = ipy + half * HALF_ROWS;
-            // Source rows rbase .. rbase+16 as pre-scaled packed pairs of columns (xa, xa+1). ALL
-            // loads of the 17 rows are issued before the first use (one round trip per level).
-            uint32_t gp[HALF_ROWS + 1], dxp[HALF_ROWS + 1], dyp[HALF_ROWS + 1];
             const bool inside = ipx >= 0 && ipx + 32 <= w && ipy >= 0 && ipy + 32 <= h;   // wave-uniform
-            if (inside) {
-                const unsigned g0 = (unsigned)rbase * (unsigned)Igs + (unsigned)xa;
-                const unsigned d0 = (unsigned)rbase * (unsigned)Ids + (unsigned)xa;
-                uint16_t graw[HALF_ROWS + 1];
-                uint2 draw[HALF_ROWS + 1];
+            // per-lane part of every address; the per-row part is a scalar base (no VALU per load)
+            const unsigned vg = (unsigned)(half * HALF_ROWS) * (unsigned)Igs + (unsigned)xa;
+            const unsigned vd = (unsigned)(half * HALF_ROWS) * (unsigned)Ids + (unsigned)xa;
+            const unsigned gxa = (unsigned)reflect101(xa, w), gxb = (unsigned)reflect101(xa + 1, w);
+            const bool ina = (unsigned)xa < (unsigned)w, inb = (unsigned)(xa + 1) < (unsigned)w;
+
+            // The 17 source rows are processed in two batches of 9 (rows 0-8, 8-16): all loads of a
+            // batch are issued before the first use (one memory round trip each) while the in-flight
+            // registers stay below what 4 waves per SIMD allow.
+            constexpr int NB = HALF_ROWS / 2 + 1;
 #pragma unroll
-                for (int r = 0; r <= HALF_ROWS; ++r) {
-                    __builtin_memcpy(&graw[r], (const void *)(uintptr_t)(Ig + (g0 + (unsigned)r * (unsigned)Igs)), 2);
-                    __builtin_memcpy(&draw[r], (const void *)(uintptr_t)(Id + (d0 + (unsigned)r * (unsigned)Ids)), 8);
-                }
+            for (int batch = 0; batch < 2; ++batch) {
+                const int r0 = batch * (HALF_ROWS / 2);
+                uint32_t gp[NB], dxp[NB], dyp[NB];     // pre-scaled packed pairs of columns (xa, xa+1)
+                if (inside) {
+                    uint16_t graw[NB];
+                    uint2 draw[NB];
 #pragma unroll
-                for (int r = 0; r <= HALF_ROWS; ++r) {
-                    gp[r] = scaled_pair<0>((uint32_t)graw[r], 0u);
-                    dxp[r] = lo16_pair(draw[r].x, draw[r].y);
-                    dyp[r] = hi16_pair(draw[r].x, draw[r].y);
-                }
-            } else {
-                // virtual borders: BORDER_REFLECT_101 for gray, zero for the gradients; loads stay
-                // unconditional (clamped addresses) and are masked afterwards -- no divergent branches
-                const unsigned gxa = (unsigned)reflect101(xa, w), gxb = (unsigned)reflect101(xa + 1, w);
-                const uint32_t ma = (unsigned)xa < (unsigned)w ? 0xFFFFFFFFu : 0u;
-                const uint32_t mb = (unsigned)(xa + 1) < (unsigned)w ? 0xFFFFFFFFu : 0u;
-                uint32_t ga[HALF_ROWS + 1], gb[HALF_ROWS + 1], da[HALF_ROWS + 1], db[HALF_ROWS + 1];
+                    for (int r = 0; r < NB; ++r) {
+                        const gptr_u8 grow = Ig + (unsigned)(ipy + r0 + r) * (unsigned)Igs;      // scalar
+                        const gptr_u32 drow = Id + (unsigned)(ipy + r0 + r) * (unsigned)Ids;
+                        __builtin_memcpy(&graw[r], (const void *)(uintptr_t)(grow + vg), 2);
+                        __builtin_memcpy(&draw[r], (const void *)(uintptr_t)(drow + vd), 8);
+                    }
 #pragma unroll
-                for (int r = 0; r <= HALF_ROWS; ++r) {
-                    const int ry = rbase + r;
-                    const unsigned go = (unsigned)reflect101(ry, h) * (unsigned)Igs;
-                    const unsigned dof = (unsigned)min(max(ry, 0), h - 1) * (unsigned)Ids;
-                    ga[r] = Ig[go + gxa]; gb[r] = Ig[go + gxb];
-                    da[r] = Id[dof + gxa]; db[r] = Id[dof + gxb];
-                }
-                __builtin_amdgcn_sched_barrier(0);   // keep all 68 loads in flight before the first use
+                    for (int r = 0; r < NB; ++r) {
+                        gp[r] = scaled_pair<0>((uint32_t)graw[r], 0u);
+                        dxp[r] = lo16_pair(draw[r].x, draw[r].y);
+                        dyp[r] = hi16_pair(draw[r].x, draw[r].y);
+                    }
+                } else {
+                    // virtual borders: BORDER_REFLECT_101 for gray, zero for the gradients; loads stay
+                    // unconditional (clamped addresses) and are masked afterwards. Row offsets / masks
+                    // are computed for both half-waves on the scalar unit and selected per lane.
+                    uint32_t ga[NB], gb[NB], da[NB], db[NB];
 #pragma unroll
-                for (int r = 0; r <= HALF_ROWS; ++r) {
-                    const uint32_t mr = (unsigned)(rbase + r) < (unsigned)h ? 0xFFFFFFFFu : 0u;
-                    gp[r] = ((ga[r] << GRAY_SHIFT) | (gb[r] << (16 + GRAY_SHIFT))) + ROUND_PAIR;
-                    const uint32_t qa = (ma & mr) ? da[r] : ROUND_PAIR;     // border value 0 is stored as 4*0 + 2
-                    const uint32_t qb = (mb & mr) ? db[r] : ROUND_PAIR;
-                    dxp[r] = lo16_pair(qa, qb);
-                    dyp[r] = hi16_pair(qa, qb);
-                }
-            }
-            // DESCALE(s, 9) == (128 s + 32768) >> 16 and DESCALE(s, 14) == (4 s + 32768) >> 16: the
-            // inputs are pre-scaled by 128 / 4 and carry the +2 that sums to 32768, so each sample is
-            // the high half of one dot2 chain started from 0.
-            int vi_prev = 0, vx_prev = 0, vy_prev = 0;
+                    for (int r = 0; r < NB; ++r) {
+                        const int ry0 = ipy + r0 + r, ry1 = ry0 + HALF_ROWS;                              // uniform
+                        const unsigned go0 = (unsigned)reflect101(ry0, h) * (unsigned)Igs, go1 = (unsigned)reflect101(ry1, h) * (unsigned)Igs;
+                        const unsigned do0 = (unsigned)min(max(ry0, 0), h - 1) * (unsigned)Ids, do1 = (unsigned)min(max(ry1, 0), h - 1) * (unsigned)Ids;
+                        const unsigned go = half ? go1 : go0, dof = half ? do1 : do0;
+                        ga[r] = Ig[go + gxa]; gb[r] = Ig[go + gxb];
+                        da[r] = Id[dof + gxa]; db[r] = Id[dof + gxb];
+                    }
+                    __builtin_amdgcn_sched_barrier(0);   // keep the whole batch in flight before the first use
 #pragma unroll
-            for (int k = 0; k < HALF_ROWS; ++k) {
-                const uint32_t wAk = (k == HALF_ROWS - 1 && half) ? 0u : wA;   // row 31 does not exist
-                const uint32_t wBk = (k == HALF_ROWS - 1 && half) ? 0u : wB;
-                const int vi = dot2(gp[k + 1], wBk, dot2(gp[k], wAk, 0));
-                const int vx = dot2(dxp[k + 1], wBk, dot2(dxp[k], wAk, 0));
-                const int vy = dot2(dyp[k + 1], wBk, dot2(dyp[k], wAk, 0));
-                if (k & 1) {
-                    const int m = k >> 1;
-                    Ivp[m] = hi16_pair((uint32_t)vi_prev, (uint32_t)vi);
-                    IXp[m] = hi16_pair((uint32_t)vx_prev, (uint32_t)vx);
-                    IYp[m] = hi16_pair((uint32_t)vy_prev, (uint32_t)vy);
-                    sA11 = dot2(IXp[m], IXp[m], sA11);
-                    sA12 = dot2(IXp[m], IYp[m], sA12);
-                    sA22 = dot2(IYp[m], IYp[m], sA22);
+                    for (int r = 0; r < NB; ++r) {
+                        const bool rin0 = (unsigned)(ipy + r0 + r) < (unsigned)h, rin1 = (unsigned)(ipy + r0 + r + HALF_ROWS) < (unsigned)h;
+                        const bool rin = half ? rin1 : rin0;
+                        gp[r] = ((ga[r] << GRAY_SHIFT) | (gb[r] << (16 + GRAY_SHIFT))) + ROUND_PAIR;
+                        const uint32_t qa = (ina && rin) ? da[r] : ROUND_PAIR;     // border value 0 is stored as 4*0 + 2
+                        const uint32_t qb = (inb && rin) ? db[r] : ROUND_PAIR;
+                        dxp[r] = lo16_pair(qa, qb);
+                        dyp[r] = hi16_pair(qa, qb);
+                    }
                 }
-                vi_prev = vi; vx_prev = vx; vy_prev = vy;
+                // DESCALE(s, 9) == (128 s + 32768) >> 16 and DESCALE(s, 14) == (4 s + 32768) >> 16: the
+                // inputs are pre-scaled by 128 / 4 and carry the +2 that sums to 32768, so each sample is
+                // the high half of one dot2 chain started from 0.
+                int vi_prev = 0, vx_prev = 0, vy_prev = 0;
+#pragma unroll
+                for (int kk = 0; kk < HALF_ROWS / 2; ++kk) {
+                    const int k = r0 + kk;
+                    const uint32_t wAk = (k == HALF_ROWS - 1 && half) ? 0u : wA;   // row 31 does not exist
+                    const uint32_t wBk = (k == HALF_ROWS - 1 && half) ? 0u : wB;
+                    const int vi = dot2(gp[kk + 1], wBk, dot2(gp[kk], wAk, 0));
+                    const int vx = dot2(dxp[kk + 1], wBk, dot2(dxp[kk], wAk, 0));
+                    const int vy = dot2(dyp[kk + 1], wBk, dot2(dyp[kk], wAk, 0));
+                    if (k & 1) {
+                        const int m = k >> 1;
+                        Ivp[m] = hi16_pair((uint32_t)vi_prev, (uint32_t)vi);
+                        IXp[m] = hi16_pair((uint32_t)vx_prev, (uint32_t)vx);
+                        IYp[m] = hi16_pair((uint32_t)vy_prev, (uint32_t)vy);
+                        sA11 = dot2(IXp[m], IXp[m], sA11);
+                        sA12 = dot2(IXp[m], IYp[m], sA12);
+                        sA22 = dot2(IYp[m], IYp[m], sA22);
+                    }
+                    vi_prev = vi; vx_prev = vx; vy_prev = vy;
+                }
             }
         }
         float A11, A12, A22;
@@ -301,24 +320,74 @@ __global__ __launch_bounds__(64) void klt_kernel(KltArgs a)
             }
             const bool fast = j_aligned && tox >= 0 && tox + TS + 4 <= w && toy >= 0 && toy + TS <= h;
             if (fast) {
-                uint2 raw[(TS * TS / 4) / 64];
+                constexpr int NITEM = TS * TS / 4, NIT = (NITEM + 63) / 64, G = TS / 4;   // TS rows x G groups of 4 pixels
+                // item e = lane + 64 i -> (row, group). The 2-D index is stepped (64 = 5 G + 9) from an
+                // opaque copy of the lane id: otherwise hipcc hoists all 2 NIT divisions out of the level
+                // loop and keeps them in ~30 VGPRs for the whole kernel (costs a wave of occupancy).
+                int ln = lane;
+                asm volatile("" : "+v"(ln));
+                uint2 raw[NIT];
+                {
+                    int r = ln / G, c = ln - r * G;
 #pragma unroll
-                for (int i = 0; i < (TS * TS / 4) / 64; ++i) {          // 48 rows x 12 groups of 4 pixels
-                    const int e = lane + 64 * i, r = e / (TS / 4), c = e - r * (TS / 4);
-                    __builtin_memcpy(&raw[i], (const void *)(uintptr_t)(Jg + ((unsigned)(toy + r) * (unsigned)Jgs +
-                                                                           (unsigned)(tox + 4 * c))), 8);
+                    for (int i = 0; i < NIT; ++i) {
+                        const int rr = min(r, TS - 1);      // the clamped tail items re-read the last row: harmless
+                        __builtin_memcpy(&raw[i], (const void *)(uintptr_t)(Jg + ((unsigned)(toy + rr) * (unsigned)Jgs +
+                                                                               (unsigned)(tox + 4 * c))), 8);
+                        r += 64 / G; c += 64 % G;
+                        if (c >= G) { c -= G; r += 1; }
+                    }
                 }
+                {
+                    int r = ln / G, c = ln - r * G;
 #pragma unroll
-                for (int i = 0; i < (TS * TS / 4) / 64; ++i) {
-                    const int e = lane + 64 * i, r = e / (TS / 4), c = e - r * (TS / 4);
-                    *reinterpret_cast<uint4 *>(&jt[r * TS + 4 * c]) =
-                        make_uint4(scaled_pair<0>(raw[i].x, raw[i].y), scaled_pair<1>(raw[i].x, raw[i].y),
-                                   scaled_pair<2>(raw[i].x, raw[i].y), scaled_pair<3>(raw[i].x, raw[i].y));
+                    for (int i = 0; i < NIT; ++i) {
+                        const int rr = min(r, TS - 1);
+                        *reinterpret_cast<uint4 *>(&jt[rr * TS + 4 * c]) =
+                            make_uint4(scaled_pair<0>(raw[i].x, raw[i].y), scaled_pair<1>(raw[i].x, raw[i].y),
+                                       scaled_pair<2>(raw[i].x, raw[i].y), scaled_pair<3>(raw[i].x, raw[i].y));
+                        r += 64 / G; c += 64 % G;
+                        if (c >= G) { c -= G; r += 1; }
+                    }
+                }
+            } else if (w >= RW && h >= TS) {
+                // The window crosses the image border. Every pixel the virtual (reflected) tile needs
+                // lies in an RW x TS in-image region next to that border: copy the region with plain
+                // coalesced loads into LDS, then build the tile by reflected LDS byte reads (row index
+                // on the scalar unit, column index once per lane) -- ~3x fewer VALU than reflecting
+                // every global load.
+                const int rx0 = min(max(tox, 0), w - RW), ry0 = min(max(toy, 0), h - TS);
+                int ln = lane;
+                asm volatile("" : "+v"(ln));
+                {
+                    uint32_t raw[(TS * (RW / 4) + 63) / 64];
+#pragma unroll
+                    for (int i = 0; i < (TS * (RW / 4) + 63) / 64; ++i) {
+                        const int e = min(ln + 64 * i, TS * (RW / 4) - 1), r = e / (RW / 4), c = e - r * (RW / 4);
+                        __builtin_memcpy(&raw[i], (const void *)(uintptr_t)(Jg + ((unsigned)(ry0 + r) * (unsigned)Jgs +
+                                                                               (unsigned)(rx0 + 4 * c))), 4);
+                    }
+#pragma unroll
+                    for (int i = 0; i < (TS * (RW / 4) + 63) / 64; ++i) {
+                        const int e = min(ln + 64 * i, TS * (RW / 4) - 1);
+                        region[e] = raw[i];
+                    }
+                }
+                const int c = min(ln, TS - 1);                                     // lanes 0..TS-1: one tile column each
+                const uint8_t *rb = reinterpret_cast<const uint8_t *>(region);
+                const int sx0 = reflect101(tox + c, w) - rx0, sx1 = reflect101(tox + c + 1, w) - rx0;
+#pragma unroll 4
+                for (int r = 0; r < TS; ++r) {
+                    const int sr = (reflect101(toy + r, h) - ry0) * RW;              // uniform
+                    const uint32_t v = (((uint32_t)rb[sr + sx0] | ((uint32_t)rb[sr + sx1] << 16)) << GRAY_SHIFT) + ROUND_PAIR;
+                    if (lane < TS) jt[r * TS + c] = v;
                 }
             } else {
+                int ln = lane;
+                asm volatile("" : "+v"(ln));
 #pragma unroll
-                for (int i = 0; i < (TS * TS / 4) / 64; ++i) {
-                    const int e = lane + 64 * i, r = e / (TS / 4), c = e - r * (TS / 4);
+                for (int i = 0; i < (TS * TS / 4 + 63) / 64; ++i) {
+                    const int e = min(ln + 64 * i, TS * TS / 4 - 1), r = e / (TS / 4), c = e - r * (TS / 4);
                     const gptr_u8 row = Jg + (unsigned)reflect101(toy + r, h) * (unsigned)Jgs;
                     const int x = tox + 4 * c;
                     uint32_t b[5];
@@ -331,7 +400,8 @@ __global__ __launch_bounds__(64) void klt_kernel(KltArgs a)
         };
 
         for (int j = 0; j < a.max_count; ++j) {
-            const int inx = (int)floorf(cxn), iny = (int)floorf(cyn);
+            const int inx = __builtin_amdgcn_readfirstlane((int)floorf(cxn));
+            const int iny = __builtin_amdgcn_readfirstlane((int)floorf(cyn));
             if (inx < -WIN || inx >= w || iny < -WIN || iny >= h) {
                 if (level == 0) st = 0;
                 break;
@@ -386,7 +456,8 @@ __global__ __launch_bounds__(64) void klt_kernel(KltArgs a)
         // ---- level-0 epilogue (err requested, MIN_EIGENVALS flag unset): may clear status ----
         if (level == 0 && st) {
             const float ex = nx - half_win, ey = ny - half_win;
-            const int inx = (int)floorf(ex), iny = (int)floorf(ey);
+            const int inx = __builtin_amdgcn_readfirstlane((int)floorf(ex));
+            const int iny = __builtin_amdgcn_readfirstlane((int)floorf(ey));
             if (inx < -WIN || inx >= w || iny < -WIN || iny >= h) {
                 st = 0;
             } else {

@@ -37,7 +37,26 @@ struct PyrLevelArgs {
     int *l0_stride;
 };
 
-__device__ __forceinline__ int byte_of(uint32_t v, int i) { return (v >> (8 * i)) & 0xFF; }
+// ---- packed 16-bit helpers: every intermediate of both stencils fits 16 bits, so two pixels share
+// one VALU instruction (v_pk_add_u16 / v_pk_mad_u16 / v_pk_lshrrev_b16); bytes are widened to
+// 16-bit pairs with one v_perm_b32 each. Results are bit-identical to the scalar formulation. ----
+typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+
+// bytes I and J of the 8-byte string {lo, hi} as the 16-bit pair (b_I, b_J)
+template <int I, int J>
+__device__ __forceinline__ us2 bytes2(uint32_t lo, uint32_t hi)
+{
+    constexpr uint32_t sel = 0x0C000C00u | (uint32_t)I | ((uint32_t)J << 16);
+    return __builtin_bit_cast(us2, __builtin_amdgcn_perm(hi, lo, sel));
+}
+__device__ __forceinline__ us2 splat(unsigned v) { return us2{(unsigned short)v, (unsigned short)v}; }
+// (a.hi, b.lo)
+__device__ __forceinline__ us2 cross(us2 a, us2 b)
+{
+    return __builtin_bit_cast(us2, __builtin_amdgcn_alignbit(__builtin_bit_cast(uint32_t, b), __builtin_bit_cast(uint32_t, a), 16));
+}
+__device__ __forceinline__ uint32_t lo_pair(us2 a, us2 b) { return __builtin_amdgcn_perm(__builtin_bit_cast(uint32_t, b), __builtin_bit_cast(uint32_t, a), 0x05040100u); }
+__device__ __forceinline__ uint32_t hi_pair(us2 a, us2 b) { return __builtin_amdgcn_perm(__builtin_bit_cast(uint32_t, b), __builtin_bit_cast(uint32_t, a), 0x07060302u); }
 
 template <bool DOWN>
 __global__ __launch_bounds__(256) void pyr_level_kernel(PyrLevelArgs a)
@@ -60,70 +79,76 @@ __global__ __launch_bounds__(256) void pyr_level_kernel(PyrLevelArgs a)
     }
 
     // ---- stage the source tile + halo in LDS (coalesced 136-byte rows) ----
+    // BORDER_REFLECT_101 rows only change the row address; only the (at most two) dwords per row
+    // that straddle the left / right image edge need per-byte reflection, so the decision is made
+    // per dword, not per tile (42 % of the level-0 tiles touch an edge).
     const bool aligned = ((reinterpret_cast<uintptr_t>(src) | (uintptr_t)a.src_stride) & 3u) == 0;
-    const bool interior = aligned && x0 >= 4 && x0 + TW + 4 <= a.w && y0 >= 2 && y0 + TH + 2 <= a.h;
-    if (interior) {
+    {
+        int r = t / LWD, c = t - r * LWD;                    // 256 = 7 * 34 + 18: step the 2-D index
         for (int i = t; i < LH * LWD; i += 256) {
-            const int r = i / LWD, c = i - r * LWD;
-            tile[i] = *reinterpret_cast<const uint32_t *>(
-                src + (long long)(y0 - 2 + r) * a.src_stride + (x0 - 4 + 4 * c));
-        }
-    } else {
-        for (int i = t; i < LH * LWD; i += 256) {
-            const int r = i / LWD, c = i - r * LWD;
             const uint8_t *row = src + (long long)reflect101(y0 - 2 + r, a.h) * a.src_stride;
             const int x = x0 - 4 + 4 * c;
-            tile[i] = (uint32_t)row[reflect101(x, a.w)] | ((uint32_t)row[reflect101(x + 1, a.w)] << 8) |
-                      ((uint32_t)row[reflect101(x + 2, a.w)] << 16) |
-                      ((uint32_t)row[reflect101(x + 3, a.w)] << 24);
+            uint32_t v;
+            if (aligned && x >= 0 && x + 4 <= a.w) {
+                v = *reinterpret_cast<const uint32_t *>(row + x);
+            } else {
+                v = (uint32_t)row[reflect101(x, a.w)] | ((uint32_t)row[reflect101(x + 1, a.w)] << 8) |
+                    ((uint32_t)row[reflect101(x + 2, a.w)] << 16) | ((uint32_t)row[reflect101(x + 3, a.w)] << 24);
+            }
+            tile[i] = v;
+            r += 256 / LWD; c += 256 % LWD;
+            if (c >= LWD) { c -= LWD; r += 1; }
         }
     }
     __syncthreads();
 
     uint8_t *slot_base = a.slab + (long long)slot * a.slot_bytes;
 
-    // ---- Scharr gradients of the source level: lane = 4 consecutive pixels, 8 rows per pass ----
+    // ---- Scharr gradients: lane = 4 consecutive pixels x 4 consecutive rows ----
     {
         uint32_t *dbase = reinterpret_cast<uint32_t *>(slot_base + a.doff);
-        const int cg = t & 31, r0 = t >> 5;
+        const int cg = t & 31, rg = t >> 5;
+        const int x = x0 + 4 * cg, yb = y0 + 4 * rg;
+        if (x < a.w && yb < a.h) {
+            // source rows yb-1 .. yb+4 = LDS rows 4rg+1 .. 4rg+6; columns x-1 .. x+4 are bytes 3 .. 8 of the
+            // 12 staged bytes, widened to the pairs (x-1,x) (x+1,x+2) (x+3,x+4)
+            us2 R[6][3];
 #pragma unroll
-        for (int pass = 0; pass < TH / 8; ++pass) {
-            const int r = r0 + pass * 8;
-            const int y = y0 + r, x = x0 + 4 * cg;
-            if (y < a.h && x < a.w) {
-                const uint32_t *p = tile + (r + 1) * LWD + cg;   // LDS rows r+1..r+3 = source rows y-1..y+1
-                int t0[6], t1[6];
-                {
-                    const uint32_t a0 = p[0], a1 = p[1], a2 = p[2];
-                    const uint32_t b0 = p[LWD], b1 = p[LWD + 1], b2 = p[LWD + 2];
-                    const uint32_t c0 = p[2 * LWD], c1 = p[2 * LWD + 1], c2 = p[2 * LWD + 2];
-                    // columns x-1 .. x+4 are bytes 3 .. 8 of the 12 staged bytes
-                    const int top[6] = {byte_of(a0, 3), byte_of(a1, 0), byte_of(a1, 1), byte_of(a1, 2), byte_of(a1, 3), byte_of(a2, 0)};
-                    const int mid[6] = {byte_of(b0, 3), byte_of(b1, 0), byte_of(b1, 1), byte_of(b1, 2), byte_of(b1, 3), byte_of(b2, 0)};
-                    const int bot[6] = {byte_of(c0, 3), byte_of(c1, 0), byte_of(c1, 1), byte_of(c1, 2), byte_of(c1, 3), byte_of(c2, 0)};
+            for (int k = 0; k < 6; ++k) {
+                const uint32_t *p = tile + (4 * rg + 1 + k) * LWD + cg;
+                const uint32_t a0 = p[0], a1 = p[1], a2 = p[2];
+                R[k][0] = bytes2<3, 4>(a0, a1);
+                R[k][1] = bytes2<1, 2>(a1, a1);
+                R[k][2] = bytes2<3, 4>(a1, a2);
+            }
 #pragma unroll
-                    for (int j = 0; j < 6; ++j) {
-                        t0[j] = (top[j] + bot[j]) * 3 + mid[j] * 10;
-                        t1[j] = bot[j] - top[j];
+            for (int j = 0; j < 4; ++j) {
+                const int y = yb + j;
+                us2 T0[3], T1[3];
+#pragma unroll
+                for (int q = 0; q < 3; ++q) {
+                    T0[q] = (R[j][q] + R[j + 2][q]) * splat(3) + R[j + 1][q] * splat(10);   // 3*(top+bot) + 10*mid <= 4080
+                    T1[q] = R[j + 2][q] - R[j][q];                                            // bot - top (int16 wrap)
+                }
+                // dx = t0[x+1] - t0[x-1]; dy = 3*(t1[x-1] + t1[x+1]) + 10*t1[x]; stored as 4*d + 2 (klt.hip)
+                const us2 dxA = (T0[1] - T0[0]) * splat(4) + splat(2);
+                const us2 dxB = (T0[2] - T0[1]) * splat(4) + splat(2);
+                const us2 dyA = (T1[0] + T1[1]) * splat(12) + (cross(T1[0], T1[1]) * splat(40) + splat(2));
+                const us2 dyB = (T1[1] + T1[2]) * splat(12) + (cross(T1[1], T1[2]) * splat(40) + splat(2));
+                const uint32_t o0 = lo_pair(dxA, dyA), o1 = hi_pair(dxA, dyA), o2 = lo_pair(dxB, dyB), o3 = hi_pair(dxB, dyB);
+                if (y < a.h) {
+                    uint32_t *d = dbase + (long long)y * a.dstride + x;
+                    if (x + 3 < a.w) {
+                        // streamed once, consumed later by sparse LK windows: keep it out of the caches
+                        typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+                        const u32x4 pk = {o0, o1, o2, o3};
+                        __builtin_nontemporal_store(pk, reinterpret_cast<u32x4 *>(d));
+                    } else {
+                        const uint32_t o[4] = {o0, o1, o2, o3};
+#pragma unroll
+                        for (int i = 0; i < 4; ++i)
+                            if (x + i < a.w) d[i] = o[i];
                     }
-                }
-                uint32_t o[4];
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int dx = t0[i + 2] - t0[i];
-                    const int dy = (t1[i] + t1[i + 2]) * 3 + t1[i + 1] * 10;
-                    // stored as 4*d + 2 (|.| <= 16322 fits int16): the LK kernel then takes the high
-                    // half of a v_dot2 chain instead of add-and-shift (klt.hip); hv_pyramid_download
-                    // undoes it with an arithmetic >> 2
-                    o[i] = ((uint32_t)((dx << GRAD_SHIFT) + 2) & 0xFFFFu) | ((uint32_t)((dy << GRAD_SHIFT) + 2) << 16);
-                }
-                uint32_t *d = dbase + (long long)y * a.dstride + x;
-                if (x + 3 < a.w) {
-                    *reinterpret_cast<uint4 *>(d) = make_uint4(o[0], o[1], o[2], o[3]);
-                } else {
-#pragma unroll
-                    for (int i = 0; i < 4; ++i)
-                        if (x + i < a.w) d[i] = o[i];
                 }
             }
         }
@@ -134,23 +159,24 @@ __global__ __launch_bounds__(256) void pyr_level_kernel(PyrLevelArgs a)
         const int ocg = t & 15, orow = t >> 4;
         const int oy = (y0 >> 1) + orow, ox = (x0 >> 1) + 4 * ocg;
         if (oy < a.hn && ox < a.wn) {
-            int acc[4] = {0, 0, 0, 0};
+            // source columns 2*ox-2 .. 2*ox+8 are bytes 2 .. 12 of the 16 staged bytes (c_k = byte 2+k);
+            // horizontal [1 4 6 4 1] for outputs (0,1) and (2,3) as packed pairs, <= 4080
+            us2 H01[5], H23[5];
 #pragma unroll
             for (int j = 0; j < 5; ++j) {
-                const int kv = (j == 0 || j == 4) ? 1 : (j == 2 ? 6 : 4);
                 const uint32_t *p = tile + (2 * orow + j) * LWD + 2 * ocg;
-                const uint32_t q[4] = {p[0], p[1], p[2], p[3]};
-                int c[11];   // source columns 2*ox-2 .. 2*ox+8 are bytes 2 .. 12 of the 16 staged bytes
-#pragma unroll
-                for (int k = 0; k < 11; ++k) c[k] = byte_of(q[(k + 2) >> 2], (k + 2) & 3);
-#pragma unroll
-                for (int o = 0; o < 4; ++o)
-                    acc[o] += kv * (c[2 * o] + c[2 * o + 4] + 4 * (c[2 * o + 1] + c[2 * o + 3]) + 6 * c[2 * o + 2]);
+                const uint32_t q0 = p[0], q1 = p[1], q2 = p[2], q3 = p[3];
+                const us2 e24 = bytes2<2, 4>(q0, q1), e35 = bytes2<3, 5>(q0, q1), e46 = bytes2<0, 2>(q1, q1), e57 = bytes2<1, 3>(q1, q1);
+                const us2 e68 = bytes2<2, 4>(q1, q2), e79 = bytes2<3, 5>(q1, q2), e8a = bytes2<0, 2>(q2, q2), e9b = bytes2<1, 3>(q2, q2);
+                const us2 eac = bytes2<2, 4>(q2, q3);
+                H01[j] = (e24 + e68) + (e35 + e57) * splat(4) + e46 * splat(6);
+                H23[j] = (e68 + eac) + (e79 + e9b) * splat(4) + e8a * splat(6);
             }
+            // vertical [1 4 6 4 1] + 128, >> 8: sums <= 255*256 + 128 = 65408 still fit 16 bits
+            const us2 V01 = ((H01[0] + H01[4]) + (H01[1] + H01[3]) * splat(4) + (H01[2] * splat(6) + splat(128))) >> splat(8);
+            const us2 V23 = ((H23[0] + H23[4]) + (H23[1] + H23[3]) * splat(4) + (H23[2] * splat(6) + splat(128))) >> splat(8);
+            const uint32_t packed = __builtin_amdgcn_perm(__builtin_bit_cast(uint32_t, V23), __builtin_bit_cast(uint32_t, V01), 0x06040200u);
             uint8_t *g = slot_base + a.goff_next + (long long)oy * a.gstride_next + ox;
-            uint32_t packed = 0;
-#pragma unroll
-            for (int o = 0; o < 4; ++o) packed |= (uint32_t)((acc[o] + 128) >> 8) << (8 * o);
             if (ox + 3 < a.wn) {
                 *reinterpret_cast<uint32_t *>(g) = packed;
             } else {
