@@ -104,11 +104,11 @@ class TrackerBench:
         prev, cur = self.L[(k - 1) % 2], self.L[k % 2]
         self.cur_left.copy_(self.pts_left)                                      # zero-flow prediction
         self.ctx.klt_track_batch_dev(B, prev.data_ptr(), cur.data_ptr(), NPTS, self.pts_left.data_ptr(),
-                                     self.cur_left.data_ptr(), self.st1.data_ptr(), self.err.data_ptr(), True)
+                                     self.cur_left.data_ptr(), self.st1.data_ptr(), 0, True)   # err unused, as in HybVIO
         self.cur_right.copy_(self.cur_left)
         self.cur_right[:, 0] -= self.disp                                       # predicted disparity
         self.ctx.klt_track_batch_dev(B, cur.data_ptr(), self.R.data_ptr(), NPTS, self.cur_left.data_ptr(),
-                                     self.cur_right.data_ptr(), self.st2.data_ptr(), self.err.data_ptr(), True)
+                                     self.cur_right.data_ptr(), self.st2.data_ptr(), 0, True)
         # stand-in for the host tracker's bookkeeping (tracker.cpp:441-478,604-670): merge stereo
         # failures, drop out-of-image tracks, re-seed lost tracks so N stays constant
         x, y = self.cur_left[:, 0], self.cur_left[:, 1]

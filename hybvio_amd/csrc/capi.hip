@@ -312,7 +312,7 @@ int hv_klt_track(hv_ctx *h, int prev_slot, int next_slot, int n, const float *pr
     HV_HIP(c, hipGetLastError());
     const int iters = max_iter_override > 0 ? max_iter_override : c->p.max_iter;
     rc = hv::launch_klt(c, 1, c->d_slots + 2, c->d_slots + 3, n, n, c->d_prev_xy, c->d_next_xy,
-                        c->d_status, c->d_err, use_initial_flow, iters);
+                        c->d_status, err ? c->d_err : nullptr, use_initial_flow, iters);
     if (rc != HV_OK) return rc;
     HV_HIP(c, hipMemcpyAsync(next_xy, c->d_next_xy, sizeof(float) * 2 * n, hipMemcpyDeviceToHost, c->stream));
     HV_HIP(c, hipMemcpyAsync(status, c->d_status, n, hipMemcpyDeviceToHost, c->stream));
@@ -347,7 +347,7 @@ int hv_klt_track_batch_dev(hv_ctx *h, int n_pairs, const int *prev_slots_dev, co
 {
     if (!h || n_pairs < 0 || pts_per_pair < 0) return HV_ERR_INVALID;
     if (n_pairs == 0 || pts_per_pair == 0) return HV_OK;
-    if (!prev_slots_dev || !next_slots_dev || !prev_xy_dev || !next_xy_dev || !status_dev || !err_dev)
+    if (!prev_slots_dev || !next_slots_dev || !prev_xy_dev || !next_xy_dev || !status_dev)   /* err_dev may be NULL */
         return HV_ERR_INVALID;
     Ctx *c = &h->c;
     const int iters = max_iter_override > 0 ? max_iter_override : c->p.max_iter;

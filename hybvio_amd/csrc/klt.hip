@@ -460,7 +460,9 @@ __global__ __launch_bounds__(64, 4) void klt_kernel(KltArgs a)
             const int iny = __builtin_amdgcn_readfirstlane((int)floorf(ey));
             if (inx < -WIN || inx >= w || iny < -WIN || iny >= h) {
                 st = 0;
-            } else {
+            } else if (a.err != nullptr) {
+                // the reference discards err (optical_flow.cpp:26 "ignored"); only its side effect on
+                // status above is live, so the sum is skipped when the caller passes no err array
                 ensure_tile(inx, iny);
                 uint32_t wA, wB;
                 bilinear_weights(ex - (float)inx, ey - (float)iny, wA, wB);
@@ -488,7 +490,7 @@ __global__ __launch_bounds__(64, 4) void klt_kernel(KltArgs a)
     if (lane == 0) {
         a.next_xy[pt] = make_float2(nx, ny);
         a.status[pt] = (uint8_t)st;
-        a.err[pt] = errv;
+        if (a.err != nullptr) a.err[pt] = errv;
     }
 }
 

@@ -91,7 +91,9 @@ int hv_pyramid_download(hv_ctx *ctx, int slot, int level, uint8_t *gray, int16_t
  * hv_klt_track replaces cv::calcOpticalFlowPyrLK as called at src/tracker/optical_flow.cpp:46-49
  * (window win x win, levels, TermCriteria(COUNT|EPS, max_iter, eps), minEigThreshold, err != NULL).
  * next_xy is in/out: initial guess when use_initial_flow != 0 (OPTFLOW_USE_INITIAL_FLOW).
- * status: 1 tracked / 0 lost. max_iter_override <= 0 keeps the context value. Synchronous. */
+ * status: 1 tracked / 0 lost. max_iter_override <= 0 keeps the context value. err may be NULL (the
+ * reference discards it: optical_flow.cpp:26); the level-0 range check that can clear status runs
+ * either way. Synchronous. */
 int hv_klt_track(hv_ctx *ctx, int prev_slot, int next_slot, int n, const float *prev_xy,
                  float *next_xy, uint8_t *status, float *err, int use_initial_flow,
                  int max_iter_override);
@@ -104,7 +106,7 @@ int hv_optical_flow_compute(hv_ctx *ctx, int prev_slot, int cur_slot, int n,
                             int use_initial_corners, int override_max_iterations);
 /* Batched: n_pairs independent (prev,next) pyramid pairs with pts_per_pair points each, one
  * launch; point j of pair p is element p*pts_per_pair + j of every array. All arrays are in
- * device memory; asynchronous. */
+ * device memory (err_dev may be NULL); asynchronous. */
 int hv_klt_track_batch_dev(hv_ctx *ctx, int n_pairs, const int *prev_slots_dev,
                            const int *next_slots_dev, int pts_per_pair, const float *prev_xy_dev,
                            float *next_xy_dev, uint8_t *status_dev, float *err_dev,
