@@ -32,28 +32,53 @@ typedef double double4v __attribute__((ext_vector_type(4)));
 
 __device__ const double d_chi2inv95[HV_CHI2INV95_N] = { HV_CHI2INV95_VALUES };
 
-// One wavefront: acc(16x16) += A(16 x K) * B(K x 16); a_at(i, k) / b_at(k, j) return 0 outside
-// their matrices. f64 MFMA operand layout: lane l carries A[l & 15][l >> 4], B[l >> 4][l & 15];
-// result register q of lane l is C[(l >> 4) + 4 q][l & 15].
-template <class FA, class FB>
-__device__ __forceinline__ double4v mfma_tile(int K, FA a_at, FB b_at)
+// developer aid: s_memtime stamps of the update kernel's phases (block 0, thread 0)
+}  // namespace
+__device__ long long g_phase_stamp[8];
+namespace {
+#define PHASE_STAMP(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_phase_stamp[i] = (long long)__builtin_readcyclecounter(); } while (0)
+
+// One wavefront: acc(16x16) = A(16 x K) * B(K x 16) with A(i, k) = Ap[i*sai + k*sak] and
+// B(k, j) = Bp[k*sbk + j*sbj]. f64 MFMA operand layout: lane l carries A[l & 15][l >> 4] and
+// B[l >> 4][l & 15]; result register q of lane l is C[(l >> 4) + 4 q][l & 15].
+// Branch-free on purpose: rows i >= mi / columns j >= nj are clamped to the last valid one (they
+// only produce output rows / columns that the caller never stores), the K tail is zeroed with a
+// select, and the next 4 k-steps are prefetched while the current 4 MFMAs issue. (Bounds-checked
+// lambdas made hipcc emit one exec-masked branch + 64-bit address chain per operand load.)
+__device__ __forceinline__ double4v mfma_tile(const double *Ap, int sai, int sak, int mi,
+                                              const double *Bp, int sbk, int sbj, int nj, int K)
 {
     const int lane = threadIdx.x & 63, r = lane & 15, q = lane >> 4;
+    const double *pa = Ap + min(r, mi - 1) * sai + q * sak;
+    const double *pb = Bp + q * sbk + min(r, nj - 1) * sbj;
+    const int da = 4 * sak, db = 4 * sbk;
     double4v acc = {0.0, 0.0, 0.0, 0.0};
-    // operands come straight from L2/LDS: keep the next 4 k-steps (8 loads) in flight while the
-    // current 4 MFMAs issue, otherwise every MFMA waits a full memory round trip
     constexpr int U = 4;
-    double a0[U], b0[U];
+    const int kfull = (K / (4 * U)) * (4 * U);
+    int k0 = 0;
+    if (kfull > 0) {
+        double a0[U], b0[U];
 #pragma unroll
-    for (int u = 0; u < U; u++) { a0[u] = a_at(r, 4 * u + q); b0[u] = b_at(4 * u + q, r); }
-    for (int k0 = 0; k0 < K; k0 += 4 * U) {
-        double a1[U], b1[U];
+        for (int u = 0; u < U; u++) { a0[u] = pa[u * da]; b0[u] = pb[u * db]; }
+        for (k0 = 4 * U; k0 < kfull; k0 += 4 * U) {
+            pa += U * da; pb += U * db;
+            double a1[U], b1[U];
 #pragma unroll
-        for (int u = 0; u < U; u++) { a1[u] = a_at(r, k0 + 4 * (U + u) + q); b1[u] = b_at(k0 + 4 * (U + u) + q, r); }
+            for (int u = 0; u < U; u++) { a1[u] = pa[u * da]; b1[u] = pb[u * db]; }
+#pragma unroll
+            for (int u = 0; u < U; u++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[u], b0[u], acc, 0, 0, 0);
+#pragma unroll
+            for (int u = 0; u < U; u++) { a0[u] = a1[u]; b0[u] = b1[u]; }
+        }
 #pragma unroll
         for (int u = 0; u < U; u++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[u], b0[u], acc, 0, 0, 0);
-#pragma unroll
-        for (int u = 0; u < U; u++) { a0[u] = a1[u]; b0[u] = b1[u]; }
+        pa += U * da; pb += U * db;
+    }
+    for (k0 = kfull; k0 < K; k0 += 4) {          // tail: clamp the address, zero the value
+        const int k = k0 + q, back = max(k - (K - 1), 0);
+        const double av = pa[-back * sak], bv = pb[-back * sbk];
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(k < K ? av : 0.0, k < K ? bv : 0.0, acc, 0, 0, 0);
+        pa += da; pb += db;
     }
     return acc;
 }
@@ -242,14 +267,16 @@ __global__ __launch_bounds__(UPD_THREADS) void ekf_update_kernel(UpdateArgs a)
     int *s_stop = reinterpret_cast<int *>(red + nwaves);
     const bool gate_only = a.mode == 0;
 
+    PHASE_STAMP(0);
     // ---- A: HP = H * P[0:l, :], stored transposed as rows nr .. nr+n-1 of T; residual row ----
     {
         const int tiles_i = (nr + 15) / 16, tiles_j = (n + 15) / 16;
         for (int tile = wave; tile < tiles_i * tiles_j; tile += nwaves) {
             const int i0 = (tile % tiles_i) * 16, j0 = (tile / tiles_i) * 16;
-            const double4v acc = mfma_tile(l,
-                [&](int i, int k) { return (i0 + i < nr && k < l) ? H[(size_t)k * nr + i0 + i] : 0.0; },
-                [&](int k, int j) { return (k < l && j0 + j < n) ? P[(size_t)(j0 + j) * n + k] : 0.0; });
+            // A(i, k) = H(i0+i, k) = H[k*nr + i0+i];  B(k, j) = P(k, j0+j), read as P(j0+j, k) = P[k*n + j0+j]:
+            // P is symmetric to rounding (predict builds P01/P10 separately, every other step keeps or
+            // restores symmetry) and the transposed element is unit-stride across the 16 lanes of a k-row
+            const double4v acc = mfma_tile(H + i0, 1, nr, nr - i0, P + j0, n, 1, n - j0, l);
             const int j = j0 + (lane & 15);
 #pragma unroll
             for (int q = 0; q < 4; q++) {
@@ -265,6 +292,7 @@ __global__ __launch_bounds__(UPD_THREADS) void ekf_update_kernel(UpdateArgs a)
     }
     __syncthreads();
 
+    PHASE_STAMP(1);
     // ---- B: S = HP[:, 0:l] * H' + R (lower triangle), rows 0 .. nr-1 of T ----
     {
         const int tb = (nr + 15) / 16;
@@ -272,9 +300,8 @@ __global__ __launch_bounds__(UPD_THREADS) void ekf_update_kernel(UpdateArgs a)
             const int ib = tile % tb, cb = tile / tb;
             if (ib < cb) continue;
             const int i0 = ib * 16, c0 = cb * 16;
-            const double4v acc = mfma_tile(l,
-                [&](int i, int k) { return (i0 + i < nr && k < l) ? T[(size_t)(i0 + i) * R + nr + k] : 0.0; },
-                [&](int k, int c) { return (k < l && c0 + c < nr) ? H[(size_t)k * nr + c0 + c] : 0.0; });
+            // A(i, k) = HP(i0+i, k) = T[(i0+i)*R + nr + k];  B(k, c) = H(c0+c, k) = H[k*nr + c0+c]
+            const double4v acc = mfma_tile(T + (size_t)i0 * R + nr, R, 1, nr - i0, H + c0, nr, 1, nr - c0, l);
             const int c = c0 + (lane & 15);
 #pragma unroll
             for (int q = 0; q < 4; q++) {
@@ -285,38 +312,34 @@ __global__ __launch_bounds__(UPD_THREADS) void ekf_update_kernel(UpdateArgs a)
     }
     __syncthreads();
 
-    // ---- C: right-looking Cholesky over the tall matrix, ONE barrier per column: the wavefront
-    // that owns column k+1 in the trailing update finishes it first and immediately scales it into
-    // the other pivot buffer (look-ahead), so the next step can start after a single barrier.
-    // Gate-only skips the (HP)' rows. ----
-    double *colbuf[2] = {colk, colk2};
-    auto scale_column = [&](int k, double *dst, int first, int stride) {
-        const double d = sqrt(T[(size_t)k * R + k]), inv = 1.0 / d;
-        for (int r = k + first; r < R; r += stride) {
-            if (gate_only && r >= nr && r < R - 1) continue;
-            const double val = (r == k) ? d : T[(size_t)k * R + r] * inv;
-            if (r >= nr) T[(size_t)k * R + r] = val;      // only the Y' / z' rows are read again later
-            dst[r] = val;
-        }
-    };
-    scale_column(0, colbuf[0], t, UPD_THREADS);
-    __syncthreads();
-    for (int k = 0; k < nr; k++) {
-        const double *ck = colbuf[k & 1];
-        for (int c = k + 1 + wave; c < nr; c += nwaves) {
-            const double lc = ck[c];
-            for (int r = c + lane; r < R; r += 64) {
-                if (gate_only && r >= nr && r < R - 1) continue;
-                T[(size_t)c * R + r] -= ck[r] * lc;
+    PHASE_STAMP(2);
+    // ---- C: left-looking Cholesky over the tall matrix, one thread per row, ONE barrier per column.
+    // Column k of row r is  (T(r,k) - sum_{p<k} T(r,p) T(k,p)) / d_k  with d_k^2 = T(k,k) - sum_p T(k,p)^2.
+    // Every thread reads the pivot row T(k, 0..k-1) anyway (an LDS broadcast), so it recomputes d_k
+    // itself instead of waiting for the owner of row k: no serial wavefront, no sqrt on a critical
+    // path shared by 16 waves. Rows >= nr become Y' = (L^-1 HP)' and z'. Gate-only skips the Y' rows.
+    {
+        const int row = t;                                   // rows 0 .. R-1 -> threads 0 .. R-1
+        const bool mine = row < R && !(gate_only && row >= nr && row < R - 1);
+        for (int k = 0; k < nr; k++) {
+            if (mine && row >= k) {
+                // two independent accumulator pairs break the FMA dependency chain
+                double s0 = T[(size_t)k * R + row], s1 = 0.0, q0 = T[(size_t)k * R + k], q1 = 0.0;
+                int p = 0;
+                for (; p + 1 < k; p += 2) {
+                    const double l0 = T[(size_t)p * R + k], l1 = T[(size_t)(p + 1) * R + k];
+                    s0 -= T[(size_t)p * R + row] * l0; s1 -= T[(size_t)(p + 1) * R + row] * l1;
+                    q0 -= l0 * l0; q1 -= l1 * l1;
+                }
+                if (p < k) { const double l0 = T[(size_t)p * R + k]; s0 -= T[(size_t)p * R + row] * l0; q0 -= l0 * l0; }
+                const double pk = q0 + q1, inv = rsqrt(pk);          // one rsqrt instead of sqrt + divide
+                T[(size_t)k * R + row] = (row == k) ? pk * inv : (s0 + s1) * inv;
             }
-            if (c == k + 1) {                              // this wavefront owns the next pivot column
-                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                scale_column(k + 1, colbuf[(k + 1) & 1], lane, 64);
-            }
+            __syncthreads();
         }
-        __syncthreads();
     }
 
+    PHASE_STAMP(3);
     // ---- D: chi2 = noise_scale * z'z ----
     {
         double s = 0;
@@ -336,6 +359,7 @@ __global__ __launch_bounds__(UPD_THREADS) void ekf_update_kernel(UpdateArgs a)
         if (*s_stop) return;
     }
 
+    PHASE_STAMP(4);
     // ---- E: m += Y' z ----
     for (int j = t; j < n; j += UPD_THREADS) {
         double s = 0;
@@ -347,18 +371,20 @@ __global__ __launch_bounds__(UPD_THREADS) void ekf_update_kernel(UpdateArgs a)
         const int tb = (n + 15) / 16;
         for (int tile = wave; tile < tb * tb; tile += nwaves) {
             const int i0 = (tile % tb) * 16, j0 = (tile / tb) * 16;
-            const double4v acc = mfma_tile(nr,
-                [&](int i, int c) { return (i0 + i < n && c < nr) ? T[(size_t)c * R + nr + i0 + i] : 0.0; },
-                [&](int c, int j) { return (c < nr && j0 + j < n) ? T[(size_t)c * R + nr + j0 + j] : 0.0; });
+            // A(i, c) = Y(c, i0+i) = T[c*R + nr + i0+i];  B(c, j) = Y(c, j0+j) = T[c*R + nr + j0+j]
+            const double4v acc = mfma_tile(T + nr + i0, 1, R, n - i0, T + nr + j0, R, 1, n - j0, nr);
             const int j = j0 + (lane & 15);
 #pragma unroll
             for (int q = 0; q < 4; q++) {
                 const int i = i0 + (lane >> 4) + 4 * q;
-                if (i < n && j < n) P[(size_t)j * n + i] -= acc[q];
+                // Y'Y is symmetric: apply entry (i, j) to element (j, i) so that the 16 lanes of a row
+                // group touch 16 consecutive doubles
+                if (i < n && j < n) P[(size_t)i * n + j] -= acc[q];
             }
         }
     }
     __syncthreads();
+    PHASE_STAMP(5);
     // ---- G: quaternion normalisation (updateCommon ekf.cpp:29-31 / normalizeQuaternions 1024-1032) ----
     const int nq = a.normalize_all ? 1 + (n - CAM) / POSE : 1;
     if (t < nq) normalize4(m + (t == 0 ? ORI : CAM + POSE * (t - 1) + 3));
@@ -705,6 +731,16 @@ int hv_ekf_create(hv_ctx *ctx, const hv_ekf_params *par, int batch, hv_ekf **out
     }
     if (rc != HV_OK) { hv_ekf_destroy(h); return rc; }
     *out = h;
+    return HV_OK;
+}
+
+/* developer aid (not in the public header): phase time stamps of the last update kernel */
+int hv_debug_ekf_phase_stamps(hv_ekf *h, long long *out8)
+{
+    if (!h || !out8) return HV_ERR_INVALID;
+    Ctx *c = h->e.c;
+    HV_HIP(c, hipStreamSynchronize(c->stream));
+    HV_HIP(c, hipMemcpyFromSymbol(out8, HIP_SYMBOL(hv::g_phase_stamp), sizeof(long long) * 8));
     return HV_OK;
 }
 
