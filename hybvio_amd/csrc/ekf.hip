@@ -323,15 +323,23 @@ __global__ __launch_bounds__(UPD_THREADS) void ekf_update_kernel(UpdateArgs a)
         const bool mine = row < R && !(gate_only && row >= nr && row < R - 1);
         for (int k = 0; k < nr; k++) {
             if (mine && row >= k) {
-                // two independent accumulator pairs break the FMA dependency chain
-                double s0 = T[(size_t)k * R + row], s1 = 0.0, q0 = T[(size_t)k * R + k], q1 = 0.0;
+                // The chain is LDS-latency bound: 8 columns (16 reads) per wait and four independent
+                // accumulator pairs, so one round trip covers 8 steps of the dot products.
+                double s0 = T[(size_t)k * R + row], s1 = 0.0, s2 = 0.0, s3 = 0.0;
+                double q0 = T[(size_t)k * R + k], q1 = 0.0, q2 = 0.0, q3 = 0.0;
                 int p = 0;
-                for (; p + 1 < k; p += 2) {
-                    const double l0 = T[(size_t)p * R + k], l1 = T[(size_t)(p + 1) * R + k];
-                    s0 -= T[(size_t)p * R + row] * l0; s1 -= T[(size_t)(p + 1) * R + row] * l1;
-                    q0 -= l0 * l0; q1 -= l1 * l1;
+                for (; p + 7 < k; p += 8) {
+                    double lr[8], lk[8];
+#pragma unroll
+                    for (int u = 0; u < 8; u++) { lr[u] = T[(size_t)(p + u) * R + row]; lk[u] = T[(size_t)(p + u) * R + k]; }
+#pragma unroll
+                    for (int u = 0; u < 8; u += 4) {
+                        s0 -= lr[u] * lk[u]; s1 -= lr[u + 1] * lk[u + 1]; s2 -= lr[u + 2] * lk[u + 2]; s3 -= lr[u + 3] * lk[u + 3];
+                        q0 -= lk[u] * lk[u]; q1 -= lk[u + 1] * lk[u + 1]; q2 -= lk[u + 2] * lk[u + 2]; q3 -= lk[u + 3] * lk[u + 3];
+                    }
                 }
-                if (p < k) { const double l0 = T[(size_t)p * R + k]; s0 -= T[(size_t)p * R + row] * l0; q0 -= l0 * l0; }
+                for (; p < k; p++) { const double l0 = T[(size_t)p * R + k]; s0 -= T[(size_t)p * R + row] * l0; q0 -= l0 * l0; }
+                s0 += s2; s1 += s3; q0 += q2; q1 += q3;
                 const double pk = q0 + q1, inv = rsqrt(pk);          // one rsqrt instead of sqrt + divide
                 T[(size_t)k * R + row] = (row == k) ? pk * inv : (s0 + s1) * inv;
             }
