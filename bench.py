@@ -237,6 +237,19 @@ def cpu_baseline(budget_s=12.0):
                 sample=f"{frames} stereo frames 752x480 x 200 pts, oracle/pyrlk_oracle.c -O2, 1 thread, {el:.1f} s")
 
 
+def profiled_traffic():
+    """HBM bytes per launch from the committed rocprofv3 PMC summary (profiles/rNN/traffic.json,
+    produced by scripts/collect_profile.sh): bench.py cannot collect PMC counters itself."""
+    import glob
+    cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "traffic.json")))
+    if not cands:
+        return None
+    with open(cands[-1]) as f:
+        t = json.load(f)
+    t["_file"] = os.path.relpath(cands[-1], ROOT)
+    return t
+
+
 class DistEnv:
     """One process per GPU (torch.distributed.run sets RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*).
     The data path has no collective: replicas only. This class only provides the timing contract --
@@ -339,6 +352,14 @@ def main():
         stage_ms = sum(v["total_ms"] for v in kern.values()) / args.steps
         stage_gbs = B * ab["stereo_frame"] / (stage_ms * 1e-3) / 1e9
         dom = max(kern, key=lambda k: kern[k]["total_ms"])
+        prof_t = profiled_traffic()
+        traffic, traffic_note = None, None
+        if prof_t is not None:
+            key = {"klt": "klt_kernel", "pyr_l0": "pyr_level_kernel_L0"}.get(dom)
+            if key in prof_t:
+                traffic = prof_t[key]["hbm_bytes_per_launch"] * B / float(prof_t.get("sequences_per_gpu", B))
+                traffic_note = (f"rocprofv3 FETCH_SIZE x2 + WRITE_SIZE per launch from {prof_t['_file']} "
+                                f"(collected at B={prof_t.get('sequences_per_gpu')}, scaled to B={B})")
         out = {
             "metric": "VIO frames/sec at 752x480 stereo, 200 KLT features; pyramid+KLT HBM GB/s",
             "value": aggregate_value(B, world, args.steps, el), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -348,7 +369,12 @@ def main():
                                    "frame), EKF not in the HIP path", "sequences_per_gpu": B,
                        "frames_per_step": world * B, "parallelism": f"replicas x{world} (no collective)"},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": kern[dom]["achieved_GBs"], "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": kern[dom]["achieved_GBs"] / HBM_PEAK_GBS, "traffic": None},
+                         "unit": "GB/s", "frac": kern[dom]["achieved_GBs"] / HBM_PEAK_GBS, "traffic": traffic,
+                         "algorithmic_bytes_per_launch": per_launch_bytes[dom], "traffic_source": traffic_note,
+                         "limiter": ("klt_kernel is VALU-issue bound (rocprof: VALU busy ~84 %, HBM traffic < algorithmic bytes); "
+                                     "the HBM-bound kernel of the path is pyr_l0, see kernels / measured_ceilings")
+                         if dom == "klt" else None},
+            "measured_ceilings_GBs": (prof_t or {}).get("measured_hbm_ceilings_GBs"),
             "kernels": kern,
             "stage_pyramid_klt": {"ms_per_step": stage_ms, "achieved_GBs": stage_gbs,
                                   "frac_of_8TBs": stage_gbs / HBM_PEAK_GBS,
