@@ -43,8 +43,10 @@ namespace {
 // B[l >> 4][l & 15]; result register q of lane l is C[(l >> 4) + 4 q][l & 15].
 // Branch-free on purpose: rows i >= mi / columns j >= nj are clamped to the last valid one (they
 // only produce output rows / columns that the caller never stores), the K tail is zeroed with a
-// select, and the next 4 k-steps are prefetched while the current 4 MFMAs issue. (Bounds-checked
+// select, and the next U k-steps are prefetched while the current U MFMAs issue (U = 8 where an
+// operand streams from HBM: ~2k cycles of latency against 64 cycles per MFMA and 4 waves per SIMD). (Bounds-checked
 // lambdas made hipcc emit one exec-masked branch + 64-bit address chain per operand load.)
+template <int U = 4>
 __device__ __forceinline__ double4v mfma_tile(const double *Ap, int sai, int sak, int mi,
                                               const double *Bp, int sbk, int sbj, int nj, int K)
 {
@@ -53,7 +55,6 @@ __device__ __forceinline__ double4v mfma_tile(const double *Ap, int sai, int sak
     const double *pb = Bp + q * sbk + min(r, nj - 1) * sbj;
     const int da = 4 * sak, db = 4 * sbk;
     double4v acc = {0.0, 0.0, 0.0, 0.0};
-    constexpr int U = 4;
     const int kfull = (K / (4 * U)) * (4 * U);
     int k0 = 0;
     if (kfull > 0) {
@@ -226,6 +227,49 @@ __global__ __launch_bounds__(256) void ekf_predict_kernel(PredictArgs a)
     }
 }
 
+// Cholesky factor of one 16 x 16 diagonal block AND the inverse of that factor, in one wavefront
+// without LDS traffic or barriers on the dependency chain. Lane r < 16 holds row r of the block,
+// lane 16 + i holds row i of the identity: running the same right-looking column steps over the
+// stacked matrix [D; I] turns it into [L; L^-T] (the tall-matrix identity T L^-T applied to I).
+// Pivot values travel through v_readlane (wave-uniform SGPRs), every array index is a constant.
+// Rows / columns >= w (ragged last block) are padded with the identity.
+__device__ __forceinline__ double lane_bcast(double v, int src_lane)
+{
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), src_lane);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src_lane);
+    return __hiloint2double(hi, lo);
+}
+
+__device__ __forceinline__ void factor_diag_block(double *T, double *W, int R, int j0, int w, int lane)
+{
+    const int r = lane & 15;
+    const bool ident = (lane & 16) != 0;                    // lanes 32..63 mirror 0..31 (results unused)
+    double tr[16];
+#pragma unroll
+    for (int c = 0; c < 16; c++) {
+        const double x = T[(size_t)(j0 + min(c, w - 1)) * R + j0 + min(r, w - 1)];
+        const bool from_t = !ident && c <= r && r < w;      // lower triangle of the block; r < w implies c < w
+        tr[c] = from_t ? x : (c == r ? 1.0 : 0.0);
+    }
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        const double d = lane_bcast(tr[k], k);
+        const double inv = rsqrt(d);                          // one rsqrt instead of sqrt + divide
+        const double lk = tr[k] * inv;                        // lane k: d * rsqrt(d) = sqrt(d)
+        tr[k] = lk;
+#pragma unroll
+        for (int c = k + 1; c < 16; c++) tr[c] -= lk * lane_bcast(lk, c);      // lane c < 16 holds L(c, k)
+    }
+    if (lane < 16) {
+#pragma unroll
+        for (int c = 0; c < 16; c++)
+            if (c <= r && r < w) T[(size_t)(j0 + c) * R + j0 + r] = tr[c];
+    } else if (lane < 32) {
+#pragma unroll
+        for (int c = 0; c < 16; c++) W[r * 16 + c] = tr[c];                    // W[i][c] = Linv(c, i)
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // update / gate (ekf.cpp:57-82, 760-844)
 // ---------------------------------------------------------------------------------------------
@@ -257,18 +301,24 @@ __global__ __launch_bounds__(UPD_THREADS) void ekf_update_kernel(UpdateArgs a)
     double *m = a.m + (size_t)b * n, *P = a.P + (size_t)b * n * n;
     const double *H = a.H + (size_t)b * nr * l;
     const double rd = a.rdiag ? a.rdiag[b] : a.rd0;
-    // all LDS comes from the dynamic region (keeps the base 16-byte aligned): [T] colk[2][R] red[16] flag
-    // USE_LDS is a template parameter so that the common case compiles to ds_read/ds_write (a
-    // run-time select would turn every access into a flat load)
-    double *T = USE_LDS ? smem : a.ws + (size_t)b * R * nr;         // T(r, c) = T[c * R + r]
-    double *colk = USE_LDS ? smem + (((size_t)R * nr + 1) & ~(size_t)1) : smem;     // pivot column (2 buffers)
-    double *colk2 = colk + ((R + 1) & ~1);
-    double *red = colk2 + ((R + 1) & ~1);
+    // Tall matrix T (R rows x nr columns, column-major: T(r, c) = T[c * R + r]):
+    //   rows 0 .. nr-1   S = H P H' + R            -> L           (S = L L')
+    //   row  nr          v'                        -> z' = (L^-1 v)'
+    //   rows nr+1 ..     (H P)'  (n rows)          -> Y' = (L^-1 H P)'
+    // One blocked Cholesky pass over T does the factorisation and both triangular solves. The gate
+    // only needs rows 0 .. nr. All LDS comes from the dynamic region (keeps the base 16-byte aligned):
+    // [T] W[256] red[16] flag. USE_LDS is a template parameter so that the common case compiles to
+    // ds_read / ds_write (a run-time select would turn every access into a flat load).
+    double *T = USE_LDS ? smem : a.ws + (size_t)b * R * nr;
+    double *W = USE_LDS ? smem + (((size_t)R * nr + 1) & ~(size_t)1) : smem;   // inverse of the current diagonal block
+    double *red = W + 256;
     int *s_stop = reinterpret_cast<int *>(red + nwaves);
     const bool gate_only = a.mode == 0;
+    const int rv = nr, ry = nr + 1;
+    const int Rlim = gate_only ? nr + 1 : R;
 
     PHASE_STAMP(0);
-    // ---- A: HP = H * P[0:l, :], stored transposed as rows nr .. nr+n-1 of T; residual row ----
+    // ---- A: HP = H * P[0:l, :], stored transposed as rows ry .. ry+n-1 of T; residual row ----
     {
         const int tiles_i = (nr + 15) / 16, tiles_j = (n + 15) / 16;
         for (int tile = wave; tile < tiles_i * tiles_j; tile += nwaves) {
@@ -276,19 +326,19 @@ __global__ __launch_bounds__(UPD_THREADS) void ekf_update_kernel(UpdateArgs a)
             // A(i, k) = H(i0+i, k) = H[k*nr + i0+i];  B(k, j) = P(k, j0+j), read as P(j0+j, k) = P[k*n + j0+j]:
             // P is symmetric to rounding (predict builds P01/P10 separately, every other step keeps or
             // restores symmetry) and the transposed element is unit-stride across the 16 lanes of a k-row
-            const double4v acc = mfma_tile(H + i0, 1, nr, nr - i0, P + j0, n, 1, n - j0, l);
+            const double4v acc = mfma_tile<8>(H + i0, 1, nr, nr - i0, P + j0, n, 1, n - j0, l);
             const int j = j0 + (lane & 15);
 #pragma unroll
             for (int q = 0; q < 4; q++) {
                 const int i = i0 + (lane >> 4) + 4 * q;
-                if (i < nr && j < n) T[(size_t)i * R + nr + j] = acc[q];
+                if (i < nr && j < n) T[(size_t)i * R + ry + j] = acc[q];
             }
         }
     }
     for (int i = t; i < nr; i += UPD_THREADS) {
         double r = a.v[(size_t)b * nr + i];
         if (a.generic) { double s = 0; for (int k = 0; k < l; k++) s += H[(size_t)k * nr + i] * m[k]; r -= s; }
-        T[(size_t)i * R + R - 1] = r;
+        T[(size_t)i * R + rv] = r;
     }
     __syncthreads();
 
@@ -300,8 +350,8 @@ __global__ __launch_bounds__(UPD_THREADS) void ekf_update_kernel(UpdateArgs a)
             const int ib = tile % tb, cb = tile / tb;
             if (ib < cb) continue;
             const int i0 = ib * 16, c0 = cb * 16;
-            // A(i, k) = HP(i0+i, k) = T[(i0+i)*R + nr + k];  B(k, c) = H(c0+c, k) = H[k*nr + c0+c]
-            const double4v acc = mfma_tile(T + (size_t)i0 * R + nr, R, 1, nr - i0, H + c0, nr, 1, nr - c0, l);
+            // A(i, k) = HP(i0+i, k) = T[(i0+i)*R + ry + k];  B(k, c) = H(c0+c, k) = H[k*nr + c0+c]
+            const double4v acc = mfma_tile<8>(T + (size_t)i0 * R + ry, R, 1, nr - i0, H + c0, nr, 1, nr - c0, l);
             const int c = c0 + (lane & 15);
 #pragma unroll
             for (int q = 0; q < 4; q++) {
@@ -313,45 +363,51 @@ __global__ __launch_bounds__(UPD_THREADS) void ekf_update_kernel(UpdateArgs a)
     __syncthreads();
 
     PHASE_STAMP(2);
-    // ---- C: left-looking Cholesky over the tall matrix, one thread per row, ONE barrier per column.
-    // Column k of row r is  (T(r,k) - sum_{p<k} T(r,p) T(k,p)) / d_k  with d_k^2 = T(k,k) - sum_p T(k,p)^2.
-    // Every thread reads the pivot row T(k, 0..k-1) anyway (an LDS broadcast), so it recomputes d_k
-    // itself instead of waiting for the owner of row k: no serial wavefront, no sqrt on a critical
-    // path shared by 16 waves. Rows >= nr become Y' = (L^-1 HP)' and z'. Gate-only skips the Y' rows.
-    {
-        const int row = t;                                   // rows 0 .. R-1 -> threads 0 .. R-1
-        const bool mine = row < R && !(gate_only && row >= nr && row < R - 1);
-        for (int k = 0; k < nr; k++) {
-            if (mine && row >= k) {
-                // The chain is LDS-latency bound: 8 columns (16 reads) per wait and four independent
-                // accumulator pairs, so one round trip covers 8 steps of the dot products.
-                double s0 = T[(size_t)k * R + row], s1 = 0.0, s2 = 0.0, s3 = 0.0;
-                double q0 = T[(size_t)k * R + k], q1 = 0.0, q2 = 0.0, q3 = 0.0;
-                int p = 0;
-                for (; p + 7 < k; p += 8) {
-                    double lr[8], lk[8];
+    // ---- C: blocked left-looking Cholesky of the tall matrix, 16 columns per block, 3 barriers per
+    // block (a column-at-a-time version needs one barrier + one LDS round trip + one rsqrt per COLUMN
+    // on the critical path of all 16 waves: 1.3-1.7 k cycles per column measured). Per block j:
+    //   U  every 16-row tile of block column j -= T(tile, 0:j0) * T(j0:j0+16, 0:j0)'         (MFMA)
+    //   D  wave 0 factors the diagonal block in registers and inverts the factor   (factor_diag_block)
+    //   P  every tile below the diagonal block *= Linv'                                       (MFMA)
+    // Multiplying by the explicit inverse of a 16 x 16 diagonal block instead of substituting is the
+    // usual blocked-TRSM trade: the error grows with cond(L_jj), not cond(L).
+    for (int j0 = 0; j0 < nr; j0 += 16) {
+        const int w = min(16, nr - j0);
+        const int ntile = (Rlim - j0 + 15) / 16;
+        const int i_l = lane >> 4, c_l = lane & 15;
+        if (j0 > 0) {
+            for (int tile = wave; tile < ntile; tile += nwaves) {
+                const int i0 = j0 + 16 * tile, mi = Rlim - i0;
+                // A(i, k) = T(i0+i, k) = T[k*R + i0+i];  B(k, c) = T(j0+c, k) = T[k*R + j0+c]
+                const double4v acc = mfma_tile(T + i0, 1, R, mi, T + j0, R, 1, w, j0);
 #pragma unroll
-                    for (int u = 0; u < 8; u++) { lr[u] = T[(size_t)(p + u) * R + row]; lk[u] = T[(size_t)(p + u) * R + k]; }
-#pragma unroll
-                    for (int u = 0; u < 8; u += 4) {
-                        s0 -= lr[u] * lk[u]; s1 -= lr[u + 1] * lk[u + 1]; s2 -= lr[u + 2] * lk[u + 2]; s3 -= lr[u + 3] * lk[u + 3];
-                        q0 -= lk[u] * lk[u]; q1 -= lk[u + 1] * lk[u + 1]; q2 -= lk[u + 2] * lk[u + 2]; q3 -= lk[u + 3] * lk[u + 3];
-                    }
+                for (int q = 0; q < 4; q++) {
+                    const int i = i_l + 4 * q;
+                    if (i < mi && c_l < w) T[(size_t)(j0 + c_l) * R + i0 + i] -= acc[q];
                 }
-                for (; p < k; p++) { const double l0 = T[(size_t)p * R + k]; s0 -= T[(size_t)p * R + row] * l0; q0 -= l0 * l0; }
-                s0 += s2; s1 += s3; q0 += q2; q1 += q3;
-                const double pk = q0 + q1, inv = rsqrt(pk);          // one rsqrt instead of sqrt + divide
-                T[(size_t)k * R + row] = (row == k) ? pk * inv : (s0 + s1) * inv;
             }
             __syncthreads();
         }
+        if (wave == 0) factor_diag_block(T, W, R, j0, w, lane);
+        __syncthreads();
+        for (int i0 = j0 + w + 16 * wave; i0 < Rlim; i0 += 16 * nwaves) {        // rows below the w x w diagonal block
+            const int mi = Rlim - i0;
+            // A(i, k) = T(i0+i, j0+k) = T[(j0+k)*R + i0+i];  B(k, c) = Linv(c, k) = W[k*16 + c]
+            const double4v acc = mfma_tile(T + (size_t)j0 * R + i0, 1, R, mi, W, 16, 1, 16, w);
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const int i = i_l + 4 * q;
+                if (i < mi && c_l < w) T[(size_t)(j0 + c_l) * R + i0 + i] = acc[q];
+            }
+        }
+        __syncthreads();
     }
 
     PHASE_STAMP(3);
     // ---- D: chi2 = noise_scale * z'z ----
     {
         double s = 0;
-        for (int c = t; c < nr; c += UPD_THREADS) { const double z = T[(size_t)c * R + R - 1]; s += z * z; }
+        for (int c = t; c < nr; c += UPD_THREADS) { const double z = T[(size_t)c * R + rv]; s += z * z; }
         for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o);
         if (lane == 0) red[wave] = s;
         __syncthreads();
@@ -371,23 +427,38 @@ __global__ __launch_bounds__(UPD_THREADS) void ekf_update_kernel(UpdateArgs a)
     // ---- E: m += Y' z ----
     for (int j = t; j < n; j += UPD_THREADS) {
         double s = 0;
-        for (int c = 0; c < nr; c++) s += T[(size_t)c * R + nr + j] * T[(size_t)c * R + R - 1];
+        for (int c = 0; c < nr; c++) s += T[(size_t)c * R + ry + j] * T[(size_t)c * R + rv];
         m[j] += s;
     }
     // ---- F: P -= Y' Y ----
     {
-        const int tb = (n + 15) / 16;
-        for (int tile = wave; tile < tb * tb; tile += nwaves) {
+        // Y'Y is symmetric: entry (i, j) of a tile is applied to element (j, i), so the 16 lanes of a
+        // row group touch 16 consecutive doubles. The old values of the NEXT tile are requested before
+        // the MFMA loop of the current one: the ~1 us HBM round trip of P hides behind the matrix work
+        // instead of stalling every tile.
+        const int tb = (n + 15) / 16, ntiles = tb * tb;
+        const int cj = lane & 15, ri = lane >> 4;
+        auto p_addr = [&](int tile, int q) -> double * {
+            const int i = min((tile % tb) * 16 + ri + 4 * q, n - 1), j = min((tile / tb) * 16 + cj, n - 1);
+            return P + (size_t)i * n + j;
+        };
+        double cur[4], nxt[4] = {0.0, 0.0, 0.0, 0.0};
+        if (wave < ntiles) {
+#pragma unroll
+            for (int q = 0; q < 4; q++) cur[q] = *p_addr(wave, q);
+        }
+        for (int tile = wave; tile < ntiles; tile += nwaves) {
             const int i0 = (tile % tb) * 16, j0 = (tile / tb) * 16;
-            // A(i, c) = Y(c, i0+i) = T[c*R + nr + i0+i];  B(c, j) = Y(c, j0+j) = T[c*R + nr + j0+j]
-            const double4v acc = mfma_tile(T + nr + i0, 1, R, n - i0, T + nr + j0, R, 1, n - j0, nr);
-            const int j = j0 + (lane & 15);
+            const int tn = min(tile + nwaves, ntiles - 1);
+#pragma unroll
+            for (int q = 0; q < 4; q++) nxt[q] = *p_addr(tn, q);
+            // A(i, c) = Y(c, i0+i) = T[c*R + ry + i0+i];  B(c, j) = Y(c, j0+j) = T[c*R + ry + j0+j]
+            const double4v acc = mfma_tile(T + ry + i0, 1, R, n - i0, T + ry + j0, R, 1, n - j0, nr);
 #pragma unroll
             for (int q = 0; q < 4; q++) {
-                const int i = i0 + (lane >> 4) + 4 * q;
-                // Y'Y is symmetric: apply entry (i, j) to element (j, i) so that the 16 lanes of a row
-                // group touch 16 consecutive doubles
-                if (i < n && j < n) P[(size_t)i * n + j] -= acc[q];
+                const int i = i0 + ri + 4 * q, j = j0 + cj;
+                if (i < n && j < n) P[(size_t)i * n + j] = cur[q] - acc[q];
+                cur[q] = nxt[q];
             }
         }
     }
@@ -638,7 +709,7 @@ static int ekf_launch_update(Ekf *e, int nr, int l, const double *H_dev, const d
     a.m = e->m; a.P = e->P; a.H = H_dev; a.v = v_dev; a.rdiag = rdiag_dev; a.rd0 = rd0; a.noise_scale = e->noise_scale;
     a.ws = e->ws; a.chi2 = chi2_dev; a.status = status_dev; a.active = active_dev;
     const size_t tall = (((size_t)a.R * nr + 1) & ~(size_t)1) * sizeof(double);
-    const size_t small = (size_t)(2 * ((a.R + 1) & ~1) + UPD_THREADS / 64 + 2) * sizeof(double);   // 2 x colk + red + flag
+    const size_t small = (size_t)(256 + UPD_THREADS / 64 + 2) * sizeof(double);                 // W + red + flag
     a.use_lds = tall + small <= 150 * 1024;
     const size_t shmem = a.use_lds ? tall + small : small;
     static bool attr_set = false;
