@@ -21,6 +21,11 @@
 #include "chi2inv95.h"
 #include "hv_internal.hpp"
 
+// The library is built with -ffp-contract=off for the tracker's bit-exact binary32 sequence; the
+// EKF is judged against a relative tolerance, and a fused multiply-add is one rounding fewer and
+// half the f64 instructions of its dependency chains.
+#pragma clang fp contract(fast)
+
 namespace hv {
 
 namespace {
@@ -34,7 +39,7 @@ __device__ const double d_chi2inv95[HV_CHI2INV95_N] = { HV_CHI2INV95_VALUES };
 
 // developer aid: s_memtime stamps of the update kernel's phases (block 0, thread 0)
 }  // namespace
-__device__ long long g_phase_stamp[8];
+__device__ long long g_phase_stamp[16];
 namespace {
 #define PHASE_STAMP(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_phase_stamp[i] = (long long)__builtin_readcyclecounter(); } while (0)
 
@@ -240,7 +245,7 @@ __device__ __forceinline__ double lane_bcast(double v, int src_lane)
     return __hiloint2double(hi, lo);
 }
 
-__device__ __forceinline__ void factor_diag_block(double *T, double *W, int R, int j0, int w, int lane)
+__device__ __forceinline__ void factor_diag_block(double *T, double *W, double *col, int R, int j0, int w, int lane)
 {
     const int r = lane & 15;
     const bool ident = (lane & 16) != 0;                    // lanes 32..63 mirror 0..31 (results unused)
@@ -251,14 +256,27 @@ __device__ __forceinline__ void factor_diag_block(double *T, double *W, int R, i
         const bool from_t = !ident && c <= r && r < w;      // lower triangle of the block; r < w implies c < w
         tr[c] = from_t ? x : (c == r ? 1.0 : 0.0);
     }
+    // Right-looking column steps. The dependency chain of step k -> k+1 is
+    //   pivot d (readlane) -> rsqrt -> scale column k -> update column k+1 (readlane of L(k+1, k)),
+    // all in registers. The updates of columns k+2.. are off that chain: their multipliers L(c, k)
+    // are broadcast through LDS (one ds_write of the column, (15-k)/2 ds_read_b128 of uniform
+    // pairs) instead of two v_readlane each, which halves the instruction count of the step.
 #pragma unroll
     for (int k = 0; k < 16; k++) {
         const double d = lane_bcast(tr[k], k);
         const double inv = rsqrt(d);                          // one rsqrt instead of sqrt + divide
         const double lk = tr[k] * inv;                        // lane k: d * rsqrt(d) = sqrt(d)
         tr[k] = lk;
+        if (k + 1 < 16) {
+            if (k + 2 < 16 && lane < 16) col[k * 16 + r] = lk;
+            tr[k + 1] -= lk * lane_bcast(lk, k + 1);          // lane c < 16 holds L(c, k)
 #pragma unroll
-        for (int c = k + 1; c < 16; c++) tr[c] -= lk * lane_bcast(lk, c);      // lane c < 16 holds L(c, k)
+            for (int c = k + 2; c < 16; c++) tr[c] -= lk * col[k * 16 + c];
+            // pin the updates to this step: left alone, hipcc sinks each one to the last use of tr[c]
+            // and keeps every multiplier read so far alive (128-VGPR budget -> scratch spills)
+#pragma unroll
+            for (int c = k + 2; c < 16; c++) asm volatile("" : "+v"(tr[c]));
+        }
     }
     if (lane < 16) {
 #pragma unroll
@@ -287,15 +305,22 @@ struct UpdateArgs {
     const unsigned char *active;      // optional per-filter enable
 };
 
-constexpr int UPD_THREADS = 1024;
+constexpr int UPD_THREADS = 512;   // 8 waves = 2 per SIMD: 256 VGPRs each (whole column blocks of P stay in registers)
 
-template <bool USE_LDS>
+// MODE 0: T in the global workspace (tall matrix larger than LDS)
+// MODE 1: T in LDS, H streamed from L2
+// MODE 2: T and H in LDS (n <= 160, nr <= 48): K-split products, P read from HBM exactly once
+// TI (MODE 2 only): 16-row tiles of H, nr <= 16 TI: a compile-time count keeps the MFMA loops free of
+// branches (a uniform branch per tile made hipcc wait for each LDS operand right before its MFMA).
+template <int MODE, int TI>
 __global__ __launch_bounds__(UPD_THREADS) void ekf_update_kernel(UpdateArgs a)
 {
+    constexpr bool USE_LDS = MODE >= 1;
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int b = blockIdx.x;
     if (a.active && !a.active[b]) return;
-    const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);     // wave-uniform: tile indices and their addresses stay on the scalar unit
     constexpr int nwaves = UPD_THREADS / 64;
     const int n = a.n, nr = a.nr, l = a.l, R = a.R;
     double *m = a.m + (size_t)b * n, *P = a.P + (size_t)b * n * n;
@@ -307,30 +332,130 @@ __global__ __launch_bounds__(UPD_THREADS) void ekf_update_kernel(UpdateArgs a)
     //   rows nr+1 ..     (H P)'  (n rows)          -> Y' = (L^-1 H P)'
     // One blocked Cholesky pass over T does the factorisation and both triangular solves. The gate
     // only needs rows 0 .. nr. All LDS comes from the dynamic region (keeps the base 16-byte aligned):
-    // [T] W[256] red[16] flag. USE_LDS is a template parameter so that the common case compiles to
+    // [T] W[256] col[256] red[16] flag. USE_LDS is a template parameter so that the common case compiles to
     // ds_read / ds_write (a run-time select would turn every access into a flat load).
     double *T = USE_LDS ? smem : a.ws + (size_t)b * R * nr;
     double *W = USE_LDS ? smem + (((size_t)R * nr + 1) & ~(size_t)1) : smem;   // inverse of the current diagonal block
-    double *red = W + 256;
+    double *col = W + 256;                                                      // column broadcast buffer of the diagonal factor
+    double *red = col + 256;
     int *s_stop = reinterpret_cast<int *>(red + nwaves);
+    double *Hs = red + nwaves + 2;                // MODE 2: H zero-padded to (16 TI) x (16 lb), column-major, stride nrp
+    constexpr int nrp = 16 * (TI > 0 ? TI : 1);
     const bool gate_only = a.mode == 0;
     const int rv = nr, ry = nr + 1;
     const int Rlim = gate_only ? nr + 1 : R;
 
     PHASE_STAMP(0);
-    // ---- A: HP = H * P[0:l, :], stored transposed as rows ry .. ry+n-1 of T; residual row ----
-    {
-        const int tiles_i = (nr + 15) / 16, tiles_j = (n + 15) / 16;
+    const int kq = lane >> 4, cl = lane & 15;      // MFMA lane coordinates: k sub-step / output row group, column
+    // MODE 2 ownership: wavefront w owns the 16-column block J = w of P with all of its 16-row K
+    // blocks ("item 0"); wavefronts 0..3 also own one K half of block 8 or 9 ("item 1": J = 8 + (w & 1),
+    // half w >> 1), which gives every SIMD 2.5 column blocks of matrix work at n = 160. The four B
+    // operands of a K block ARE the 16 x 16 tile P(K, J) in the MFMA C layout (lane (kq, c) holds
+    // rows kq + 4 s), so the tiles fetched for H P stay in registers and serve as the old values of
+    // P -= Y'Y: P crosses HBM once per update. All of a wave's P loads are issued before anything
+    // else; K blocks are consumed in arrival order, so the HBM stream (~10 B/clk/CU when every CU
+    // pulls at once) overlaps the MFMAs.
+    constexpr int NBK = 10, NBH = 5;                // K blocks per column block / per half (n <= 160)
+    double pres0[NBK][4], pres1[NBH][4];
+    const int tiles_j = (n + 15) >> 4, lb = (l + 15) >> 4;
+    const int hs = (tiles_j + 1) >> 1;
+    const int J1 = 8 + (wave & 1), kb0_1 = (wave & 2) ? hs : 0, kb1_1 = (wave & 2) ? tiles_j : hs;
+    const bool have0 = MODE == 2 && wave < tiles_j, have1 = MODE == 2 && wave < 4 && J1 < tiles_j;
+    if constexpr (MODE == 2) {
+        // ---- A: HP = H * P[0:l, :] accumulated into rows ry.. of T (the two K halves of blocks 8, 9
+        // meet through ds_add_f64 on the zeroed tile: two addends commute, the sum is reproducible) ----
+        auto fetch_blk = [&](auto &pv, int bi, int J, int kb, int kend) {
+            if (kb < kend && (kb < lb || !gate_only)) {
+                const int jc = min(J * 16 + cl, n - 1);
+#pragma unroll
+                for (int sx = 0; sx < 4; sx++) pv[bi][sx] = P[(size_t)min(kb * 16 + 4 * sx + kq, n - 1) * n + jc];
+            }
+        };
+        // request order = arrival order: H first (every MFMA needs it), then the P tiles in the order
+        // they are consumed. Only DEPTH K blocks are requested ahead of the MFMAs that use them: a
+        // wave that queues its whole column block up front sits in the issue queue until most of it has
+        // arrived, and the HBM stream no longer overlaps the matrix work.
+        constexpr int HREG = (48 * 160 + UPD_THREADS - 1) / UPD_THREADS, DEPTH = 4;
+        double hreg[HREG];
+#pragma unroll
+        for (int u = 0; u < HREG; u++) {
+            const int i = t + u * UPD_THREADS, k = i / nrp, r = i - k * nrp;
+            hreg[u] = (i < nrp * 16 * lb && k < l && r < nr) ? H[(size_t)k * nr + r] : 0.0;
+        }
+#pragma unroll
+        for (int bi = 0; bi < DEPTH; bi++) if (have0) fetch_blk(pres0, bi, wave, bi, tiles_j);
+        PHASE_STAMP(8);
+        for (int i = t; i < R * nr; i += UPD_THREADS) T[i] = 0.0;
+#pragma unroll
+        for (int u = 0; u < HREG; u++) {
+            const int i = t + u * UPD_THREADS;
+            if (i < nrp * 16 * lb) Hs[i] = hreg[u];
+        }
+        __syncthreads();
+        PHASE_STAMP(9);
+        const double *hbase = Hs + (size_t)kq * nrp + cl;
+        auto mfma_blk = [&](auto &pv, int bi, int kb, int kend, double4v (&acc)[TI]) {
+            if (kb < kend && kb < lb) {
+                double av[4][TI];
+#pragma unroll
+                for (int sx = 0; sx < 4; sx++)
+#pragma unroll
+                    for (int mt = 0; mt < TI; mt++) av[sx][mt] = hbase[(size_t)(kb * 16 + 4 * sx) * nrp + 16 * mt];
+#pragma unroll
+                for (int sx = 0; sx < 4; sx++)
+#pragma unroll
+                    for (int mt = 0; mt < TI; mt++)
+                        acc[mt] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[sx][mt], pv[bi][sx], acc[mt], 0, 0, 0);
+            }
+        };
+        auto flush = [&](int J, double4v (&acc)[TI]) {
+#pragma unroll
+            for (int mt = 0; mt < TI; mt++) {
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const int i = 16 * mt + kq + 4 * q, j = J * 16 + cl;
+                    if (i < nr && j < n) unsafeAtomicAdd(&T[(size_t)i * R + ry + j], acc[mt][q]);
+                }
+            }
+        };
+        {
+            double4v acc[TI];
+#pragma unroll
+            for (int mt = 0; mt < TI; mt++) acc[mt] = double4v{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int bi = 0; bi < NBK; bi++) {
+                if (bi + DEPTH < NBK) { if (have0) fetch_blk(pres0, bi + DEPTH, wave, bi + DEPTH, tiles_j); }
+                else if (bi + DEPTH - NBK < NBH) { if (have1) fetch_blk(pres1, bi + DEPTH - NBK, J1, kb0_1 + bi + DEPTH - NBK, kb1_1); }
+                if (have0) mfma_blk(pres0, bi, bi, tiles_j, acc);
+            }
+            if (have0) flush(wave, acc);
+        }
+        PHASE_STAMP(10);
+        {
+            double4v acc[TI];
+#pragma unroll
+            for (int mt = 0; mt < TI; mt++) acc[mt] = double4v{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int bi = 0; bi < NBH; bi++) {
+                if (bi + DEPTH < NBH) { if (have1) fetch_blk(pres1, bi + DEPTH, J1, kb0_1 + bi + DEPTH, kb1_1); }
+                if (have1) mfma_blk(pres1, bi, kb0_1 + bi, kb1_1, acc);
+            }
+            if (have1) flush(J1, acc);
+        }
+        PHASE_STAMP(11);
+    } else {
+        // ---- A: HP = H * P[0:l, :], stored transposed as rows ry .. ry+n-1 of T; residual row ----
+        const int tiles_i = (nr + 15) / 16;
         for (int tile = wave; tile < tiles_i * tiles_j; tile += nwaves) {
             const int i0 = (tile % tiles_i) * 16, j0 = (tile / tiles_i) * 16;
             // A(i, k) = H(i0+i, k) = H[k*nr + i0+i];  B(k, j) = P(k, j0+j), read as P(j0+j, k) = P[k*n + j0+j]:
             // P is symmetric to rounding (predict builds P01/P10 separately, every other step keeps or
             // restores symmetry) and the transposed element is unit-stride across the 16 lanes of a k-row
             const double4v acc = mfma_tile<8>(H + i0, 1, nr, nr - i0, P + j0, n, 1, n - j0, l);
-            const int j = j0 + (lane & 15);
+            const int j = j0 + cl;
 #pragma unroll
             for (int q = 0; q < 4; q++) {
-                const int i = i0 + (lane >> 4) + 4 * q;
+                const int i = i0 + kq + 4 * q;
                 if (i < nr && j < n) T[(size_t)i * R + ry + j] = acc[q];
             }
         }
@@ -346,17 +471,38 @@ __global__ __launch_bounds__(UPD_THREADS) void ekf_update_kernel(UpdateArgs a)
     // ---- B: S = HP[:, 0:l] * H' + R (lower triangle), rows 0 .. nr-1 of T ----
     {
         const int tb = (nr + 15) / 16;
-        for (int tile = wave; tile < tb * tb; tile += nwaves) {
-            const int ib = tile % tb, cb = tile / tb;
-            if (ib < cb) continue;
-            const int i0 = ib * 16, c0 = cb * 16;
-            // A(i, k) = HP(i0+i, k) = T[(i0+i)*R + ry + k];  B(k, c) = H(c0+c, k) = H[k*nr + c0+c]
-            const double4v acc = mfma_tile<8>(T + (size_t)i0 * R + ry, R, 1, nr - i0, H + c0, nr, 1, nr - c0, l);
-            const int c = c0 + (lane & 15);
+        if constexpr (MODE == 2) {
+            // (tile, K half) items, the halves combined with ds_add_f64 into the zeroed S block
+            const int khalf = ((l / 2) + 15) & ~15;
+            for (int it = wave; it < 2 * tb * tb; it += nwaves) {
+                const int tile = it >> 1, hh = it & 1;
+                const int ib = tile % tb, cb = tile / tb;
+                if (ib < cb) continue;
+                const int i0 = ib * 16, c0 = cb * 16;
+                const int kbeg = hh ? min(khalf, l) : 0, klen = hh ? l - kbeg : min(khalf, l);
+                if (klen <= 0) continue;
+                // A(i, k) = HP(i0+i, k) = T[(i0+i)*R + ry + k];  B(k, c) = H(c0+c, k) = Hs[k*nrp + c0+c]
+                const double4v acc = mfma_tile<4>(T + (size_t)i0 * R + ry + kbeg, R, 1, nr - i0, Hs + (size_t)kbeg * nrp + c0, nrp, 1, nr - c0, klen);
+                const int c = c0 + cl;
 #pragma unroll
-            for (int q = 0; q < 4; q++) {
-                const int i = i0 + (lane >> 4) + 4 * q;
-                if (i < nr && c < nr) T[(size_t)c * R + i] = acc[q] + (i == c ? rd : 0.0);
+                for (int q = 0; q < 4; q++) {
+                    const int i = i0 + kq + 4 * q;
+                    if (i < nr && c < nr) unsafeAtomicAdd(&T[(size_t)c * R + i], acc[q] + ((i == c && hh == 0) ? rd : 0.0));
+                }
+            }
+        } else {
+            for (int tile = wave; tile < tb * tb; tile += nwaves) {
+                const int ib = tile % tb, cb = tile / tb;
+                if (ib < cb) continue;
+                const int i0 = ib * 16, c0 = cb * 16;
+                // A(i, k) = HP(i0+i, k) = T[(i0+i)*R + ry + k];  B(k, c) = H(c0+c, k) = H[k*nr + c0+c]
+                const double4v acc = mfma_tile<8>(T + (size_t)i0 * R + ry, R, 1, nr - i0, H + c0, nr, 1, nr - c0, l);
+                const int c = c0 + cl;
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const int i = i0 + kq + 4 * q;
+                    if (i < nr && c < nr) T[(size_t)c * R + i] = acc[q] + (i == c ? rd : 0.0);
+                }
             }
         }
     }
@@ -388,8 +534,10 @@ __global__ __launch_bounds__(UPD_THREADS) void ekf_update_kernel(UpdateArgs a)
             }
             __syncthreads();
         }
-        if (wave == 0) factor_diag_block(T, W, R, j0, w, lane);
+        if (j0 == 0) PHASE_STAMP(6);
+        if (wave == 0) factor_diag_block(T, W, col, R, j0, w, lane);
         __syncthreads();
+        if (j0 == 0) PHASE_STAMP(7);
         for (int i0 = j0 + w + 16 * wave; i0 < Rlim; i0 += 16 * nwaves) {        // rows below the w x w diagonal block
             const int mi = Rlim - i0;
             // A(i, k) = T(i0+i, j0+k) = T[(j0+k)*R + i0+i];  B(k, c) = Linv(c, k) = W[k*16 + c]
@@ -431,7 +579,45 @@ __global__ __launch_bounds__(UPD_THREADS) void ekf_update_kernel(UpdateArgs a)
         m[j] += s;
     }
     // ---- F: P -= Y' Y ----
-    {
+    if constexpr (MODE == 2) {
+        // tiles P(K, J) of the wave's items; old values are the registers filled in phase A
+        auto down_item = [&](auto &pv, int nblk, int J, int kb0, int kb1) {
+            const int jc = min(J * 16 + cl, n - 1);
+            // B(c, j) = Y(c, J*16 + j) = T[c*R + ry + J*16 + j], c = 4 s + kq: shared by all tiles of the item
+            constexpr int KS = 4 * TI;              // k-steps over the nr <= 16 TI rows of Y (zero beyond nr)
+            double yj[KS];
+#pragma unroll
+            for (int sx = 0; sx < KS; sx++) {
+                const int c = 4 * sx + kq;
+                const double y = T[(size_t)min(c, nr - 1) * R + ry + jc];
+                yj[sx] = c < nr ? y : 0.0;
+            }
+#pragma unroll
+            for (int bi = 0; bi < nblk; bi++) {
+                const int kb = kb0 + bi;
+                if (kb < kb1) {
+                    // A(i, c) = Y(c, kb*16 + i) = T[c*R + ry + kb*16 + i]; rows c >= nr meet yj = 0
+                    const int ic = min(kb * 16 + cl, n - 1);
+                    double av[KS];
+#pragma unroll
+                    for (int sx = 0; sx < KS; sx++) av[sx] = T[(size_t)min(4 * sx + kq, nr - 1) * R + ry + ic];
+                    double4v acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                    for (int sx = 0; sx < KS; sx++) {
+                        // only the last tile of rows can be (partly) empty: skip whole k-steps beyond nr
+                        if (sx < KS - 4 || 4 * sx < nr) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[sx], yj[sx], acc, 0, 0, 0);
+                    }
+#pragma unroll
+                    for (int q = 0; q < 4; q++) {
+                        const int i = kb * 16 + kq + 4 * q, j = J * 16 + cl;
+                        if (i < n && j < n) P[(size_t)i * n + j] = pv[bi][q] - acc[q];
+                    }
+                }
+            }
+        };
+        if (have0) down_item(pres0, NBK, wave, 0, tiles_j);
+        if (have1) down_item(pres1, NBH, J1, kb0_1, kb1_1);
+    } else {
         // Y'Y is symmetric: entry (i, j) of a tile is applied to element (j, i), so the 16 lanes of a
         // row group touch 16 consecutive doubles. The old values of the NEXT tile are requested before
         // the MFMA loop of the current one: the ~1 us HBM round trip of P hides behind the matrix work
@@ -709,17 +895,24 @@ static int ekf_launch_update(Ekf *e, int nr, int l, const double *H_dev, const d
     a.m = e->m; a.P = e->P; a.H = H_dev; a.v = v_dev; a.rdiag = rdiag_dev; a.rd0 = rd0; a.noise_scale = e->noise_scale;
     a.ws = e->ws; a.chi2 = chi2_dev; a.status = status_dev; a.active = active_dev;
     const size_t tall = (((size_t)a.R * nr + 1) & ~(size_t)1) * sizeof(double);
-    const size_t small = (size_t)(256 + UPD_THREADS / 64 + 2) * sizeof(double);                 // W + red + flag
-    a.use_lds = tall + small <= 150 * 1024;
-    const size_t shmem = a.use_lds ? tall + small : small;
+    const size_t small = (size_t)(512 + UPD_THREADS / 64 + 2) * sizeof(double);                 // W + col + red + flag
+    const int ti = (nr + 15) / 16, lbk = (l + 15) / 16;
+    const size_t hbytes = (size_t)(16 * ti) * (16 * lbk) * sizeof(double);                      // zero-padded H
+    const size_t lds_cap = 150 * 1024;
+    a.use_lds = tall + small <= lds_cap;
+    const int kmode = !a.use_lds ? 0 : (e->n <= 160 && nr <= 48 && tall + small + hbytes <= lds_cap) ? 2 : 1;
+    const size_t shmem = kmode == 2 ? tall + small + hbytes : kmode == 1 ? tall + small : small;
+    using Kern = void (*)(UpdateArgs);
+    const Kern kern = kmode == 0 ? (Kern)ekf_update_kernel<0, 0> : kmode == 1 ? (Kern)ekf_update_kernel<1, 0>
+                    : ti == 1 ? (Kern)ekf_update_kernel<2, 1> : ti == 2 ? (Kern)ekf_update_kernel<2, 2> : (Kern)ekf_update_kernel<2, 3>;
     static bool attr_set = false;
     if (!attr_set) {
-        HV_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void *>(ekf_update_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024));
+        for (Kern k : { (Kern)ekf_update_kernel<1, 0>, (Kern)ekf_update_kernel<2, 1>, (Kern)ekf_update_kernel<2, 2>, (Kern)ekf_update_kernel<2, 3> })
+            HV_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024));
         attr_set = true;
     }
     ScopedKernelTime tm(c, HV_K_EKF_UPDATE);
-    if (a.use_lds) hipLaunchKernelGGL(ekf_update_kernel<true>, dim3(e->batch), dim3(UPD_THREADS), shmem, c->stream, a);
-    else           hipLaunchKernelGGL(ekf_update_kernel<false>, dim3(e->batch), dim3(UPD_THREADS), shmem, c->stream, a);
+    hipLaunchKernelGGL(kern, dim3(e->batch), dim3(UPD_THREADS), shmem, c->stream, a);
     HV_HIP(c, hipGetLastError());
     return HV_OK;
 }
@@ -819,7 +1012,7 @@ int hv_debug_ekf_phase_stamps(hv_ekf *h, long long *out8)
     if (!h || !out8) return HV_ERR_INVALID;
     Ctx *c = h->e.c;
     HV_HIP(c, hipStreamSynchronize(c->stream));
-    HV_HIP(c, hipMemcpyFromSymbol(out8, HIP_SYMBOL(hv::g_phase_stamp), sizeof(long long) * 8));
+    HV_HIP(c, hipMemcpyFromSymbol(out8, HIP_SYMBOL(hv::g_phase_stamp), sizeof(long long) * 16));
     return HV_OK;
 }
 

@@ -1,0 +1,158 @@
+// Developer microbenchmark (not part of the library): issue cost and dependent latency of the f64
+// operations the EKF kernels are built from, measured with s_memtime inside one workgroup.
+//   hipcc --offload-arch=gfx950 -O3 -o f64_ubench f64_ubench.hip && ./f64_ubench
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <vector>
+
+typedef double double4v __attribute__((ext_vector_type(4)));
+#define N 512
+
+__global__ void k_mfma_dep(double *out, long long *cyc, long long *wall)
+{
+    double4v acc = {0, 0, 0, 0};
+    double a = threadIdx.x * 1e-3, b = 1.0 + threadIdx.x * 1e-6;
+    __syncthreads();
+    long long w0 = wall_clock64(), t0 = clock64();
+#pragma unroll 16
+    for (int i = 0; i < N; i++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+    long long t1 = clock64(), w1 = wall_clock64();
+    out[threadIdx.x] = acc[0] + acc[1] + acc[2] + acc[3];
+    if (threadIdx.x == 0) { cyc[0] = t1 - t0; wall[0] = w1 - w0; }
+}
+
+__global__ void k_mfma_ind(double *out, long long *cyc)
+{
+    double4v c0 = {0, 0, 0, 0}, c1 = c0, c2 = c0, c3 = c0;
+    double a = threadIdx.x * 1e-3, b = 1.0 + threadIdx.x * 1e-6;
+    __syncthreads();
+    long long t0 = clock64();
+#pragma unroll 4
+    for (int i = 0; i < N / 4; i++) {
+        c0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c0, 0, 0, 0);
+        c1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c1, 0, 0, 0);
+        c2 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c2, 0, 0, 0);
+        c3 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c3, 0, 0, 0);
+    }
+    long long t1 = clock64();
+    out[threadIdx.x] = c0[0] + c1[1] + c2[2] + c3[3];
+    if ((threadIdx.x & 63) == 0) cyc[threadIdx.x >> 6] = t1 - t0;
+}
+
+__global__ void k_fma_dep(double *out, long long *cyc)
+{
+    double x = threadIdx.x * 1e-3, a = 1.0000001, b = 1e-9;
+    long long t0 = clock64();
+#pragma unroll 16
+    for (int i = 0; i < N; i++) x = __builtin_fma(x, a, b);
+    long long t1 = clock64();
+    out[threadIdx.x] = x;
+    if ((threadIdx.x & 63) == 0) cyc[threadIdx.x >> 6] = t1 - t0;
+}
+
+__global__ void k_fma_ind(double *out, long long *cyc)
+{
+    double x[8];
+    for (int j = 0; j < 8; j++) x[j] = threadIdx.x * 1e-3 + j;
+    const double a = 1.0000001, b = 1e-9;
+    long long t0 = clock64();
+#pragma unroll 2
+    for (int i = 0; i < N / 8; i++)
+#pragma unroll
+        for (int j = 0; j < 8; j++) x[j] = __builtin_fma(x[j], a, b);
+    long long t1 = clock64();
+    double s = 0; for (int j = 0; j < 8; j++) s += x[j];
+    out[threadIdx.x] = s;
+    if ((threadIdx.x & 63) == 0) cyc[threadIdx.x >> 6] = t1 - t0;
+}
+
+__global__ void k_rsq_dep(double *out, long long *cyc)
+{
+    double x = 2.0 + threadIdx.x * 1e-3;
+    long long t0 = clock64();
+#pragma unroll 16
+    for (int i = 0; i < N; i++) x = __builtin_amdgcn_rsq(x) + 1.5;
+    long long t1 = clock64();
+    out[threadIdx.x] = x;
+    if ((threadIdx.x & 63) == 0) cyc[threadIdx.x >> 6] = t1 - t0;
+}
+
+__global__ void k_rsqrt_full_dep(double *out, long long *cyc)
+{
+    double x = 2.0 + threadIdx.x * 1e-3;
+    long long t0 = clock64();
+#pragma unroll 16
+    for (int i = 0; i < N; i++) x = rsqrt(x) + 1.5;
+    long long t1 = clock64();
+    out[threadIdx.x] = x;
+    if ((threadIdx.x & 63) == 0) cyc[threadIdx.x >> 6] = t1 - t0;
+}
+
+__global__ void k_lds_chase(double *out, long long *cyc)
+{
+    __shared__ int nxt[1024];
+    for (int i = threadIdx.x; i < 1024; i += blockDim.x) nxt[i] = (i * 17 + 5) & 1023;
+    __syncthreads();
+    int p = threadIdx.x;
+    long long t0 = clock64();
+#pragma unroll 16
+    for (int i = 0; i < N; i++) p = nxt[p];
+    long long t1 = clock64();
+    out[threadIdx.x] = p;
+    if ((threadIdx.x & 63) == 0) cyc[threadIdx.x >> 6] = t1 - t0;
+}
+
+__global__ void k_readlane_fma(double *out, long long *cyc)
+{
+    double x = threadIdx.x * 1e-3 + 1.0, y = 0.5;
+    long long t0 = clock64();
+#pragma unroll 16
+    for (int i = 0; i < N; i++) {
+        const int lo = __builtin_amdgcn_readlane(__double2loint(x), 3), hi = __builtin_amdgcn_readlane(__double2hiint(x), 3);
+        x = __builtin_fma(__hiloint2double(hi, lo), 1e-9, x) ;
+    }
+    long long t1 = clock64();
+    out[threadIdx.x] = x + y;
+    if ((threadIdx.x & 63) == 0) cyc[threadIdx.x >> 6] = t1 - t0;
+}
+
+__global__ void k_barrier(double *out, long long *cyc)
+{
+    long long t0 = clock64();
+#pragma unroll 16
+    for (int i = 0; i < N; i++) __syncthreads();
+    long long t1 = clock64();
+    out[threadIdx.x] = 0;
+    if ((threadIdx.x & 63) == 0) cyc[threadIdx.x >> 6] = t1 - t0;
+}
+
+int main()
+{
+    double *out; long long *cyc, *wall;
+    hipMalloc(&out, 1024 * 8); hipMalloc(&cyc, 64 * 8); hipMalloc(&wall, 8);
+    long long h[64], hw;
+    auto report = [&](const char *name, int waves) {
+        hipDeviceSynchronize();
+        hipMemcpy(h, cyc, sizeof(h), hipMemcpyDeviceToHost);
+        long long mx = 0; for (int i = 0; i < waves; i++) if (h[i] > mx) mx = h[i];
+        printf("%-34s waves=%2d  %8.1f ticks/op (max over waves)\n", name, waves, (double)mx / N);
+    };
+    for (int rep = 0; rep < 2; rep++) {
+        hipLaunchKernelGGL(k_mfma_dep, dim3(1), dim3(64), 0, 0, out, cyc, wall);
+        hipDeviceSynchronize();
+        hipMemcpy(h, cyc, 8, hipMemcpyDeviceToHost); hipMemcpy(&hw, wall, 8, hipMemcpyDeviceToHost);
+        printf("mfma f64 16x16x4 dependent          waves= 1  %8.1f ticks/op   (clock64 ticks %lld, wall_clock64 ticks %lld -> clock64 = %.1f MHz if wall is 100 MHz)\n",
+               (double)h[0] / N, h[0], hw, 100.0 * h[0] / hw);
+    }
+    for (int threads : {64, 256, 1024}) {
+        hipLaunchKernelGGL(k_mfma_ind, dim3(1), dim3(threads), 0, 0, out, cyc); report("mfma f64 16x16x4 4 accumulators", threads / 64);
+    }
+    for (int threads : {64, 256, 1024}) { hipLaunchKernelGGL(k_fma_dep, dim3(1), dim3(threads), 0, 0, out, cyc); report("v_fma_f64 dependent", threads / 64); }
+    for (int threads : {64, 256, 1024}) { hipLaunchKernelGGL(k_fma_ind, dim3(1), dim3(threads), 0, 0, out, cyc); report("v_fma_f64 8 independent", threads / 64); }
+    hipLaunchKernelGGL(k_rsq_dep, dim3(1), dim3(64), 0, 0, out, cyc); report("v_rsq_f64 + add dependent", 1);
+    hipLaunchKernelGGL(k_rsqrt_full_dep, dim3(1), dim3(64), 0, 0, out, cyc); report("rsqrt(double) + add dependent", 1);
+    hipLaunchKernelGGL(k_lds_chase, dim3(1), dim3(64), 0, 0, out, cyc); report("ds_read_b32 pointer chase", 1);
+    hipLaunchKernelGGL(k_readlane_fma, dim3(1), dim3(64), 0, 0, out, cyc); report("2x readlane + fma dependent", 1);
+    for (int threads : {64, 256, 1024}) { hipLaunchKernelGGL(k_barrier, dim3(1), dim3(threads), 0, 0, out, cyc); report("s_barrier", threads / 64); }
+    return 0;
+}
