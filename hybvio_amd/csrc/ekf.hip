@@ -259,24 +259,32 @@ __device__ __forceinline__ void factor_diag_block(double *T, double *W, double *
     // Right-looking column steps. The dependency chain of step k -> k+1 is
     //   pivot d (readlane) -> rsqrt -> scale column k -> update column k+1 (readlane of L(k+1, k)),
     // all in registers. The updates of columns k+2.. are off that chain: their multipliers L(c, k)
-    // are broadcast through LDS (one ds_write of the column, (15-k)/2 ds_read_b128 of uniform
-    // pairs) instead of two v_readlane each, which halves the instruction count of the step.
+    // are broadcast through LDS (one ds_write of the column, (15-k)/2 ds_read_b128 of uniform pairs)
+    // instead of two v_readlane each, and they are applied one step LATE, after the chain work of
+    // step k+1 has been issued: a wavefront issues in order, so a wait for the LDS round trip in
+    // step k would stall the chain behind it.
+    double mprev[16], lprev = 0.0;
 #pragma unroll
     for (int k = 0; k < 16; k++) {
         const double d = lane_bcast(tr[k], k);
+        if (k >= 1) {                                          // step k-1's updates of columns k+1..: fill the rsqrt latency
+#pragma unroll
+            for (int c = k + 1; c < 16; c++) tr[c] -= lprev * mprev[c];
+        }
         const double inv = rsqrt(d);                          // one rsqrt instead of sqrt + divide
         const double lk = tr[k] * inv;                        // lane k: d * rsqrt(d) = sqrt(d)
         tr[k] = lk;
         if (k + 1 < 16) {
             if (k + 2 < 16 && lane < 16) col[k * 16 + r] = lk;
             tr[k + 1] -= lk * lane_bcast(lk, k + 1);          // lane c < 16 holds L(c, k)
-#pragma unroll
-            for (int c = k + 2; c < 16; c++) tr[c] -= lk * col[k * 16 + c];
-            // pin the updates to this step: left alone, hipcc sinks each one to the last use of tr[c]
-            // and keeps every multiplier read so far alive (128-VGPR budget -> scratch spills)
-#pragma unroll
-            for (int c = k + 2; c < 16; c++) asm volatile("" : "+v"(tr[c]));
         }
+#pragma unroll
+        for (int c = k + 2; c < 16; c++) mprev[c] = col[k * 16 + c];         // requested now, used in step k+1
+        lprev = lk;
+        // pin the updates to this step: left alone, hipcc sinks each one to the last use of tr[c]
+        // and keeps every multiplier read so far alive
+#pragma unroll
+        for (int c = k + 1; c < 16; c++) asm volatile("" : "+v"(tr[c]));
     }
     if (lane < 16) {
 #pragma unroll
@@ -292,7 +300,7 @@ __device__ __forceinline__ void factor_diag_block(double *T, double *W, double *
 // update / gate (ekf.cpp:57-82, 760-844)
 // ---------------------------------------------------------------------------------------------
 struct UpdateArgs {
-    int n, nr, l, R;                  // R = nr + n + 1 rows of the tall matrix
+    int n, nr, l, R, Rs;              // R = nr + n + 1 rows of the tall matrix; Rs = its column stride
     int mode;                         // 0 gate only, 1 update, 2 update only if the chi2 gate passes
     int generic;                      // residual = y - H m[0:l] (ekf.cpp:76-79) instead of the given v
     int normalize_all, use_lds;
@@ -322,11 +330,12 @@ __global__ __launch_bounds__(UPD_THREADS) void ekf_update_kernel(UpdateArgs a)
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);     // wave-uniform: tile indices and their addresses stay on the scalar unit
     constexpr int nwaves = UPD_THREADS / 64;
-    const int n = a.n, nr = a.nr, l = a.l, R = a.R;
+    const int n = a.n, nr = a.nr, l = a.l, R = a.Rs;       // R is the column STRIDE of T below; a.R rows are used
     double *m = a.m + (size_t)b * n, *P = a.P + (size_t)b * n * n;
     const double *H = a.H + (size_t)b * nr * l;
     const double rd = a.rdiag ? a.rdiag[b] : a.rd0;
-    // Tall matrix T (R rows x nr columns, column-major: T(r, c) = T[c * R + r]):
+    // Tall matrix T (a.R rows x nr columns, column-major with stride R >= a.R: T(r, c) = T[c * R + r]; in LDS
+    // the stride is padded to 15 or 17 mod 32 doubles, see ekf_launch_update):
     //   rows 0 .. nr-1   S = H P H' + R            -> L           (S = L L')
     //   row  nr          v'                        -> z' = (L^-1 v)'
     //   rows nr+1 ..     (H P)'  (n rows)          -> Y' = (L^-1 H P)'
@@ -343,7 +352,7 @@ __global__ __launch_bounds__(UPD_THREADS) void ekf_update_kernel(UpdateArgs a)
     constexpr int nrp = 16 * (TI > 0 ? TI : 1);
     const bool gate_only = a.mode == 0;
     const int rv = nr, ry = nr + 1;
-    const int Rlim = gate_only ? nr + 1 : R;
+    const int Rlim = gate_only ? nr + 1 : a.R;
 
     PHASE_STAMP(0);
     const int kq = lane >> 4, cl = lane & 15;      // MFMA lane coordinates: k sub-step / output row group, column
@@ -474,15 +483,31 @@ __global__ __launch_bounds__(UPD_THREADS) void ekf_update_kernel(UpdateArgs a)
         if constexpr (MODE == 2) {
             // (tile, K half) items, the halves combined with ds_add_f64 into the zeroed S block
             const int khalf = ((l / 2) + 15) & ~15;
-            for (int it = wave; it < 2 * tb * tb; it += nwaves) {
-                const int tile = it >> 1, hh = it & 1;
-                const int ib = tile % tb, cb = tile / tb;
-                if (ib < cb) continue;
+            for (int it = wave; it < tb * (tb + 1); it += nwaves) {             // lower tiles only, two halves each
+                const int hh = it & 1;
+                int ib = it >> 1, cb = 0;
+                while (ib >= tb - cb) { ib -= tb - cb; cb++; }                   // column cb holds tiles ib = cb .. tb-1
+                ib += cb;
                 const int i0 = ib * 16, c0 = cb * 16;
                 const int kbeg = hh ? min(khalf, l) : 0, klen = hh ? l - kbeg : min(khalf, l);
                 if (klen <= 0) continue;
                 // A(i, k) = HP(i0+i, k) = T[(i0+i)*R + ry + k];  B(k, c) = H(c0+c, k) = Hs[k*nrp + c0+c]
-                const double4v acc = mfma_tile<4>(T + (size_t)i0 * R + ry + kbeg, R, 1, nr - i0, Hs + (size_t)kbeg * nrp + c0, nrp, 1, nr - c0, klen);
+                // (Hs is zero beyond k = l and c = nr; rows i >= nr are clamped and never stored)
+                const double *pa = T + (size_t)min(i0 + cl, nr - 1) * R + ry + kbeg + kq;
+                const double *pb = Hs + (size_t)(kbeg + kq) * nrp + c0 + cl;
+                double4v acc = {0.0, 0.0, 0.0, 0.0};
+                for (int k0 = 0; k0 < klen; k0 += 32) {          // 8 k-steps per trip, all 16 operands requested first
+                    double av[8], bv[8];
+#pragma unroll
+                    for (int u = 0; u < 8; u++) {
+                        const bool live = k0 + 4 * u < klen;             // a partial last step meets the zero padding of Hs
+                        const int kk = live ? k0 + 4 * u : 0;
+                        av[u] = pa[kk]; bv[u] = pb[(size_t)kk * nrp];
+                        if (!live) bv[u] = 0.0;
+                    }
+#pragma unroll
+                    for (int u = 0; u < 8; u++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u], bv[u], acc, 0, 0, 0);
+                }
                 const int c = c0 + cl;
 #pragma unroll
                 for (int q = 0; q < 4; q++) {
@@ -891,15 +916,22 @@ static int ekf_launch_update(Ekf *e, int nr, int l, const double *H_dev, const d
     if (nr < 1 || nr > e->max_rows || l < 1 || l > e->n) return HV_ERR_INVALID;
     UpdateArgs a{};
     a.n = e->n; a.nr = nr; a.l = l; a.R = nr + e->n + 1;
+    // LDS stride of T: 15 or 17 mod 32 doubles. Odd keeps the 16 lanes of a row-strided operand read (S = HP H')
+    // in distinct banks; 2 Rs = 30 or 34 mod 64 dwords puts the k-groups of a column-strided read (the
+    // Cholesky panels, Y'Y) half a bank array apart.
+    int r_pad = a.R;
+    while ((r_pad & 31) != 15 && (r_pad & 31) != 17) r_pad++;
+    a.Rs = r_pad;
     a.mode = mode; a.generic = generic; a.normalize_all = normalize_all;
     a.m = e->m; a.P = e->P; a.H = H_dev; a.v = v_dev; a.rdiag = rdiag_dev; a.rd0 = rd0; a.noise_scale = e->noise_scale;
     a.ws = e->ws; a.chi2 = chi2_dev; a.status = status_dev; a.active = active_dev;
-    const size_t tall = (((size_t)a.R * nr + 1) & ~(size_t)1) * sizeof(double);
+    size_t tall = (((size_t)a.Rs * nr + 1) & ~(size_t)1) * sizeof(double);
     const size_t small = (size_t)(512 + UPD_THREADS / 64 + 2) * sizeof(double);                 // W + col + red + flag
     const int ti = (nr + 15) / 16, lbk = (l + 15) / 16;
     const size_t hbytes = (size_t)(16 * ti) * (16 * lbk) * sizeof(double);                      // zero-padded H
     const size_t lds_cap = 150 * 1024;
     a.use_lds = tall + small <= lds_cap;
+    if (!a.use_lds) { a.Rs = a.R; tall = (((size_t)a.R * nr + 1) & ~(size_t)1) * sizeof(double); }   // global workspace: no padding
     const int kmode = !a.use_lds ? 0 : (e->n <= 160 && nr <= 48 && tall + small + hbytes <= lds_cap) ? 2 : 1;
     const size_t shmem = kmode == 2 ? tall + small + hbytes : kmode == 1 ? tall + small : small;
     using Kern = void (*)(UpdateArgs);

@@ -31,13 +31,17 @@ for nr, l in ((8, 76), (16, 160), (40, 160), (64, 160), (84, 160)):
     H = torch.from_numpy(rng.normal(size=(B, l, nr))).cuda()
     v = torch.from_numpy(0.02 * rng.normal(size=(B, nr))).cuda()
     tg = bench(lambda: ekf.visual_dev(nr, l, H.data_ptr(), v.data_ptr(), 0.05, 0, chi2.data_ptr(), st.data_ptr()))
-    tu = bench(lambda: ekf.visual_dev(nr, l, H.data_ptr(), v.data_ptr(), 0.05, 1, chi2.data_ptr(), st.data_ptr()))
     import ctypes as C
+    capi.lib().hv_debug_ekf_phase_stamps.argtypes = [C.c_void_p, C.POINTER(C.c_longlong)]
+    sg = (C.c_longlong * 16)()
+    capi.lib().hv_debug_ekf_phase_stamps(ekf._h, sg)
+    gph = [sg[i + 1] - sg[i] for i in range(3)]
+    tu = bench(lambda: ekf.visual_dev(nr, l, H.data_ptr(), v.data_ptr(), 0.05, 1, chi2.data_ptr(), st.data_ptr()))
     st8 = (C.c_longlong * 16)()
     capi.lib().hv_debug_ekf_phase_stamps.argtypes = [C.c_void_p, C.POINTER(C.c_longlong)]
     capi.lib().hv_debug_ekf_phase_stamps(ekf._h, st8)
     ph = [st8[i + 1] - st8[i] for i in range(5)]
-    print(f"B={B} nr={nr:3d} l={l:3d}: gate {tg:7.1f} us   update {tu:7.1f} us   update phases [A HP, B S, C chol, D chi2, E+F] ticks={ph} D0={st8[7]-st8[6]} A:[issue,zero+stage,item0,item1]={[st8[8]-st8[0], st8[9]-st8[8], st8[10]-st8[9], st8[11]-st8[10]]}")
+    print(f"B={B} nr={nr:3d} l={l:3d}: gate {tg:7.1f} us [A,B,C]={gph}   update {tu:7.1f} us   update phases [A HP, B S, C chol, D chi2, E+F] ticks={ph} D0={st8[7]-st8[6]} A:[issue,zero+stage,item0,item1]={[st8[8]-st8[0], st8[9]-st8[8], st8[10]-st8[9], st8[11]-st8[10]]}")
 dt = torch.full((B,), 0.005, dtype=torch.float64, device="cuda")
 gy = torch.zeros((B, 3), dtype=torch.float64, device="cuda"); ac = torch.tensor([[0, 0, 9.8]] * B, dtype=torch.float64, device="cuda")
 print(f"predict  {bench(lambda: ekf.predict_dev(dt.data_ptr(), gy.data_ptr(), ac.data_ptr())):7.1f} us")
