@@ -134,6 +134,29 @@ __global__ __launch_bounds__(256) void ekf_predict_kernel(PredictArgs a)
     const double dt = a.dt ? a.dt[b] : a.dt0;
     if (!(dt > 0.0)) return;                       // ekf.cpp:365-368 (the host adapter keeps the clock)
 
+    PHASE_STAMP(12);
+    // Off-diagonal blocks P10 <- P10 F', P01 <- F P01 (ekf.cpp:506-508) as MFMA items: item I < tiles is
+    // the 16-row tile I of P10, item tiles + C the 16-column tile C of P01; either one needs a 16 x 20
+    // slab of P (5 k-steps, one f64 per lane each) and all of F. The slabs of the first five items of
+    // every wave are requested here, before thread 0 starts on the mean / F / L, so that their HBM
+    // round trip hides behind that serial section.
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6), lane = t & 63, kq = lane >> 4, cl = lane & 15;
+    const int tiles = (n - INER + 15) >> 4;
+    constexpr int NIT = 5;
+    auto slab_ptr = [&](int it, int sx) -> double * {
+        const int k = min(4 * sx + kq, INER - 1);
+        if (it < tiles) return P + (size_t)k * n + min(INER + 16 * it + cl, n - 1);          // P10(i, k): lanes along i
+        return P + (size_t)min(INER + 16 * (it - tiles) + cl, n - 1) * n + k;                // P01(k, c): lanes along c
+    };
+    double slab[NIT][5];
+#pragma unroll
+    for (int u = 0; u < NIT; u++) {
+        const int it = wave + 4 * u;
+        if (it < 2 * tiles) {
+#pragma unroll
+            for (int sx = 0; sx < 5; sx++) slab[u][sx] = *slab_ptr(it, sx);
+        }
+    }
     for (int i = t; i < INER * INER; i += 256) F[i] = (i % (INER + 1) == 0) ? 1.0 : 0.0;
     for (int i = t; i < INER * QD; i += 256) Lm[i] = 0.0;
     for (int i = t; i < QD * QD; i += 256) Qs[i] = Q[i];
@@ -197,6 +220,7 @@ __global__ __launch_bounds__(256) void ekf_predict_kernel(PredictArgs a)
     }
     __syncthreads();
 
+    PHASE_STAMP(13);
     // P00 = F P00 F' + L Q L'; P10 = P10 F'; P01 = F P01 (ekf.cpp:504-508). Every output depends only
     // on its own row / column of the old P, so the update is done in place.
     for (int i = t; i < INER * INER; i += 256) { P00[i] = P[(size_t)(i / INER) * n + (i % INER)]; a.dydx[(size_t)b * INER * INER + i] = F[i]; }
@@ -220,16 +244,60 @@ __global__ __launch_bounds__(256) void ekf_predict_kernel(PredictArgs a)
         for (int k = 0; k < QD; k++) s += LQ[k * INER + i] * L_(j, k);
         P[(size_t)j * n + i] = s;
     }
-    for (int i = INER + t; i < n; i += 256) {           // one thread per trailing row / column
-        double row[INER], col[INER];
-        for (int k = 0; k < INER; k++) { row[k] = P[(size_t)k * n + i]; col[k] = P[(size_t)i * n + k]; }
-        for (int c = 0; c < INER; c++) {
-            double s1 = 0, s2 = 0;
-            for (int k = 0; k < INER; k++) { s1 += row[k] * F_(c, k); s2 += F_(c, k) * col[k]; }
-            P[(size_t)c * n + i] = s1;                  // P10 F'
-            P[(size_t)i * n + c] = s2;                  // F P01
+    PHASE_STAMP(14);
+    {
+        // F operand, shared by every item: lane (kq, cl) holds F(cl + 16 tt, 4 s + kq). It is the A operand
+        // of (P10 F')' = F P10' (rows c of F, columns i of the tile) and the B operand of (F P01)' =
+        // P01' F' (rows c of the tile, columns r of F): both products are formed transposed so that the
+        // 16 lanes of an output row group store 16 consecutive doubles.
+        double f0[5], f1[5];
+#pragma unroll
+        for (int sx = 0; sx < 5; sx++) {
+            const int k = 4 * sx + kq;                                                        // < 20
+            f0[sx] = F_(cl, k);
+            f1[sx] = F_(min(16 + cl, INER - 1), k);
+        }
+        for (int base = 0; base < 2 * tiles; base += 4 * NIT) {
+#pragma unroll
+            for (int u = 0; u < NIT; u++) {
+                const int it = base + wave + 4 * u;
+                if (it < 2 * tiles) {
+                    if (base > 0) {
+#pragma unroll
+                        for (int sx = 0; sx < 5; sx++) slab[u][sx] = *slab_ptr(it, sx);
+                    }
+                    double4v a0 = {0.0, 0.0, 0.0, 0.0}, a1 = a0;
+                    const bool p10 = it < tiles;
+#pragma unroll
+                    for (int sx = 0; sx < 5; sx++) {
+                        const double x0 = p10 ? f0[sx] : slab[u][sx], y0 = p10 ? slab[u][sx] : f0[sx];
+                        const double x1 = p10 ? f1[sx] : slab[u][sx], y1 = p10 ? slab[u][sx] : f1[sx];
+                        a0 = __builtin_amdgcn_mfma_f64_16x16x4f64(x0, y0, a0, 0, 0, 0);
+                        a1 = __builtin_amdgcn_mfma_f64_16x16x4f64(x1, y1, a1, 0, 0, 0);
+                    }
+#pragma unroll
+                    for (int q = 0; q < 4; q++) {
+                        const int rr = kq + 4 * q;                                            // output row within the tile
+                        if (p10) {
+                            const int i = INER + 16 * it + cl;                                // (c = rr [+16], i)
+                            if (i < n) {
+                                P[(size_t)rr * n + i] = a0[q];
+                                if (16 + rr < INER) P[(size_t)(16 + rr) * n + i] = a1[q];
+                            }
+                        } else {
+                            const int c = INER + 16 * (it - tiles) + rr;                      // (c, r = cl [+16])
+                            if (c < n) {
+                                P[(size_t)c * n + cl] = a0[q];
+                                if (16 + cl < INER) P[(size_t)c * n + 16 + cl] = a1[q];
+                            }
+                        }
+                    }
+                }
+            }
         }
     }
+    __syncthreads();
+    PHASE_STAMP(15);
 }
 
 // Cholesky factor of one 16 x 16 diagonal block AND the inverse of that factor, in one wavefront
