@@ -18,6 +18,8 @@
 //     fused with the shift A P A' + Q (a gather) and the (P+P')/2 symmetrisation.
 #include <math.h>
 
+#include <utility>
+
 #include "chi2inv95.h"
 #include "hv_internal.hpp"
 
@@ -772,31 +774,61 @@ __device__ __forceinline__ int augh_minus(int i) { return CAM + i; }
 
 constexpr int AUG_THREADS = 1024;
 
+// In-wave transpose of a 16 x 16 f64 tile held in the MFMA C layout (lane (rq, c) holds rows rq + 4 q of
+// column c) through a 16 x 17 LDS scratch private to the wavefront: DS operations of one wave execute
+// in order, so no barrier is involved.
+__device__ __forceinline__ void tile_transpose(double (&v)[4], double *scr, int rq, int c)
+{
+#pragma unroll
+    for (int q = 0; q < 4; q++) scr[(rq + 4 * q) * 17 + c] = v[q];
+#pragma unroll
+    for (int q = 0; q < 4; q++) v[q] = scr[c * 17 + rq + 4 * q];
+}
+
+// triangular pair index p -> (I <= J)
+__device__ __forceinline__ void tri_decode(int p, int &I, int &J)
+{
+    J = 0;
+    while (p > J) { p -= J + 1; J++; }
+    I = p;
+}
+
+// The kernel reads the covariance from P and writes the result to P1 (the host swaps the two
+// afterwards): the shifted matrix A P A' + Q is a gather of P and is never materialised, so the
+// covariance crosses HBM once in each direction instead of three + one times.
 __global__ __launch_bounds__(AUG_THREADS) void ekf_augment_kernel(AugmentArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int b = blockIdx.x, t = threadIdx.x, n = a.n;
-    if (a.active && !a.active[b]) return;
-    double *m = a.m + (size_t)b * n, *P = a.P + (size_t)b * n * n;
-    double *P1 = a.P1 + (size_t)b * n * n, *m1 = a.m1 + (size_t)b * n;
+    double *m = a.m + (size_t)b * n;
+    const double *P = a.P + (size_t)b * n * n;
+    double *Pout = a.P1 + (size_t)b * n * n, *m1 = a.m1 + (size_t)b * n;
+    if (a.active && !a.active[b]) {                                  // untouched filter: carry P over to the new buffer
+        for (int e = t; e < n * n; e += AUG_THREADS) Pout[e] = P[e];
+        return;
+    }
     int dropped = a.dropped ? a.dropped[b] : a.dropped0;
     if (dropped < 0) dropped = a.cam_poses - 1;
-    double *HP = smem, *K = HP + POSE * n, *G = K + POSE * n;       // 7 x n each, row-major [k * n + j]
+    // [HP | K | G]: 7 x n each, row-major [k * n + j] and contiguous: rows 0..13 are the MFMA A operand
+    // (HP; K), rows 7..20 the B operand (K; G) of step 4
+    double *HP = smem, *K = HP + POSE * n, *G = K + POSE * n;
     double *S0 = G + POSE * n, *Lc = S0 + POSE * POSE, *vres = Lc + POSE * POSE;
+    double *scr_all = vres + POSE + 1;                                // 16 waves x 16 x 17 transpose scratch
 
-    // 1. m1 = A m ; P1 = A P A' + Q
-    for (int i = t; i < n; i += AUG_THREADS) { const int s = aug_src(i, dropped, n); m1[i] = s >= 0 ? m[s] : 0.0; }
-    for (int e = t; e < n * n; e += AUG_THREADS) {
-        const int i = e % n, j = e / n, si = aug_src(i, dropped, n), sj = aug_src(j, dropped, n);
+    // P1 = A P A' + Q as a function (ekf.cpp:230-248, 848-871)
+    auto p1 = [&](int i, int j) -> double {
+        const int si = aug_src(i, dropped, n), sj = aug_src(j, dropped, n);
         double v = (si >= 0 && sj >= 0) ? P[(size_t)sj * n + si] : 0.0;
         if (i == j && i >= CAM && i < CAM + POSE) v += (i < CAM + 3) ? a.q_pos : a.q_ori;
-        P1[e] = v;
-    }
-    __syncthreads();
+        return v;
+    };
+
+    // 1. m1 = A m
+    for (int i = t; i < n; i += AUG_THREADS) { const int s = aug_src(i, dropped, n); m1[i] = s >= 0 ? m[s] : 0.0; }
     // 2. HP = H P1 (7 x n), S0 = HP H'
     for (int e = t; e < POSE * n; e += AUG_THREADS) {
         const int k = e / n, j = e % n;
-        HP[e] = P1[(size_t)j * n + augh_plus(k)] - P1[(size_t)j * n + augh_minus(k)];
+        HP[e] = p1(augh_plus(k), j) - p1(augh_minus(k), j);
     }
     __syncthreads();
     if (t < POSE * POSE) { const int i = t / POSE, c = t % POSE; S0[t] = HP[i * n + augh_plus(c)] - HP[i * n + augh_minus(c)]; }
@@ -830,24 +862,64 @@ __global__ __launch_bounds__(AUG_THREADS) void ekf_augment_kernel(AugmentArgs a)
     // 3. G = P1 H' - K S0 - rd K   (n x 7): then P = P1 - K HP - G K' reproduces the Joseph form
     for (int e = t; e < POSE * n; e += AUG_THREADS) {
         const int c = e / n, i = e % n;
-        double g = P1[(size_t)augh_plus(c) * n + i] - P1[(size_t)augh_minus(c) * n + i];
+        double g = p1(i, augh_plus(c)) - p1(i, augh_minus(c));
         for (int k = 0; k < POSE; k++) g -= K[k * n + i] * S0[k * POSE + c];
         G[e] = g - a.rd * K[c * n + i];
     }
     __syncthreads();
-    // 4. P = sym(P1 - K HP - G K')   (maintainPositiveSemiDefinite fused, ekf.cpp:872)
-    for (int e = t; e < n * n; e += AUG_THREADS) {
-        const int i = e % n, j = e / n;
-        if (i > j) continue;
-        double xij = P1[(size_t)j * n + i], xji = P1[(size_t)i * n + j];
+    // 4. Pout = sym(P1 - K HP - G K')   (maintainPositiveSemiDefinite fused, ekf.cpp:872). A wavefront
+    // owns a pair of mirrored 16 x 16 tiles; the rank-14 correction of a tile is 4 f64 MFMA steps,
+    //   X(j, i) = P1(i, j) - sum_kk Aop(kk, j) Bop(kk, i),   Aop = [HP; K],  Bop = [K; G],
+    // accumulated onto the gathered tile, and the two tiles meet through an in-wave LDS transpose, so
+    // every global access is a 128-byte row segment.
+    {
+        const int wave = __builtin_amdgcn_readfirstlane(t >> 6), lane = t & 63, rq = lane >> 4, c = lane & 15;
+        double *scr = scr_all + wave * (16 * 17);
+        const int tb = (n + 15) >> 4, npairs = tb * (tb + 1) / 2;
+        auto corrected_tile = [&](int i0, int j0, double (&x)[4]) {          // x[q] = X(j0 + rq + 4 q, i0 + c)
+            double4v acc;
 #pragma unroll
-        for (int k = 0; k < POSE; k++) {
-            xij -= K[k * n + i] * HP[k * n + j] + G[k * n + i] * K[k * n + j];
-            xji -= K[k * n + j] * HP[k * n + i] + G[k * n + j] * K[k * n + i];
+            for (int q = 0; q < 4; q++) {
+                const int i = i0 + c, j = j0 + rq + 4 * q;
+                acc[q] = (i < n && j < n) ? p1(i, j) : 0.0;
+            }
+#pragma unroll
+            for (int sx = 0; sx < 4; sx++) {
+                const int kk = 4 * sx + rq;
+                const double av = HP[(size_t)min(kk, 13) * n + min(j0 + c, n - 1)];          // Aop(kk, j0 + c)
+                const double bv = K[(size_t)min(kk, 13) * n + min(i0 + c, n - 1)];           // Bop(kk, i0 + c)
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(kk < 14 ? -av : 0.0, kk < 14 ? bv : 0.0, acc, 0, 0, 0);
+            }
+#pragma unroll
+            for (int q = 0; q < 4; q++) x[q] = acc[q];
+        };
+        for (int p = wave; p < npairs; p += AUG_THREADS / 64) {
+            int I, J;
+            tri_decode(p, I, J);
+            const int i0 = 16 * I, j0 = 16 * J;
+            double x[4], y[4];
+            corrected_tile(i0, j0, x);                                        // element (i0 + c, j0 + r)
+            if (I != J) corrected_tile(j0, i0, y);                            // element (j0 + c, i0 + r)
+            else {
+#pragma unroll
+                for (int q = 0; q < 4; q++) y[q] = x[q];
+            }
+            tile_transpose(y, scr, rq, c);                                    // now the mirror of x[q]
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                x[q] = 0.5 * (x[q] + y[q]);
+                const int i = i0 + c, j = j0 + rq + 4 * q;
+                if (i < n && j < n) Pout[(size_t)j * n + i] = x[q];
+            }
+            if (I != J) {
+                tile_transpose(x, scr, rq, c);
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const int i = j0 + c, j = i0 + rq + 4 * q;
+                    if (i < n && j < n) Pout[(size_t)j * n + i] = x[q];
+                }
+            }
         }
-        const double s = 0.5 * (xij + xji);
-        P[(size_t)j * n + i] = s;
-        P[(size_t)i * n + j] = s;
     }
     __syncthreads();
     const int nq = 1 + (n - a.map_dim - CAM) / POSE;
@@ -864,36 +936,61 @@ __device__ __forceinline__ int unaug_src(int i, int n, int map_dim)
     return (i + POSE < trail) ? i + POSE : -1;
 }
 
-__global__ __launch_bounds__(1024) void ekf_unaugment_gather_kernel(ShiftArgs a)
+// writes the shifted covariance to P1 (the host swaps P and P1 afterwards) and the shifted mean in place
+__global__ __launch_bounds__(1024) void ekf_unaugment_kernel(ShiftArgs a)
 {
     const int b = blockIdx.x, t = threadIdx.x, n = a.n;
-    if (a.active && !a.active[b]) return;
-    const double *m = a.m + (size_t)b * n, *P = a.P + (size_t)b * n * n;
+    double *m = a.m + (size_t)b * n;
+    const double *P = a.P + (size_t)b * n * n;
     double *P1 = a.P1 + (size_t)b * n * n, *m1 = a.m1 + (size_t)b * n;
+    if (a.active && !a.active[b]) {
+        for (int e = t; e < n * n; e += 1024) P1[e] = P[e];
+        return;
+    }
     for (int i = t; i < n; i += 1024) { const int s = unaug_src(i, n, a.map_dim); m1[i] = s >= 0 ? m[s] : 0.0; }
     for (int e = t; e < n * n; e += 1024) {
         const int si = unaug_src(e % n, n, a.map_dim), sj = unaug_src(e / n, n, a.map_dim);
         P1[e] = (si >= 0 && sj >= 0) ? P[(size_t)sj * n + si] : 0.0;
     }
+    __syncthreads();
+    for (int i = t; i < n; i += 1024) m[i] = m1[i];
 }
 
-__global__ __launch_bounds__(1024) void ekf_copy_back_kernel(ShiftArgs a)
-{
-    const int b = blockIdx.x, t = threadIdx.x, n = a.n;
-    if (a.active && !a.active[b]) return;
-    for (int i = t; i < n; i += 1024) a.m[(size_t)b * n + i] = a.m1[(size_t)b * n + i];
-    for (int e = t; e < n * n; e += 1024) a.P[(size_t)b * n * n + e] = a.P1[(size_t)b * n * n + e];
-}
-
-// maintainPositiveSemiDefinite (ekf.cpp:1059-1067): P = (P + P') / 2
+// maintainPositiveSemiDefinite (ekf.cpp:1059-1067): P = (P + P') / 2, one wavefront per pair of mirrored
+// 16 x 16 tiles (in-wave LDS transpose: both tiles are read and written as 128-byte row segments)
 __global__ __launch_bounds__(1024) void ekf_symmetrize_kernel(int n, double *Pall)
 {
+    __shared__ double scr_all[16 * 16 * 17];
     double *P = Pall + (size_t)blockIdx.x * n * n;
-    for (int e = threadIdx.x; e < n * n; e += 1024) {
-        const int i = e % n, j = e / n;
-        if (i >= j) continue;
-        const double s = 0.5 * (P[(size_t)j * n + i] + P[(size_t)i * n + j]);
-        P[(size_t)j * n + i] = s; P[(size_t)i * n + j] = s;
+    const int t = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(t >> 6), lane = t & 63, rq = lane >> 4, c = lane & 15;
+    double *scr = scr_all + wave * (16 * 17);
+    const int tb = (n + 15) >> 4, npairs = tb * (tb + 1) / 2;
+    for (int p = wave; p < npairs; p += 16) {
+        int I, J;
+        tri_decode(p, I, J);
+        const int i0 = 16 * I, j0 = 16 * J;
+        double x[4], y[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int r = rq + 4 * q;
+            x[q] = (i0 + c < n && j0 + r < n) ? P[(size_t)(j0 + r) * n + i0 + c] : 0.0;
+            y[q] = (j0 + c < n && i0 + r < n) ? P[(size_t)(i0 + r) * n + j0 + c] : 0.0;
+        }
+        tile_transpose(y, scr, rq, c);
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            x[q] = 0.5 * (x[q] + y[q]);
+            const int r = rq + 4 * q;
+            if (i0 + c < n && j0 + r < n) P[(size_t)(j0 + r) * n + i0 + c] = x[q];
+        }
+        if (I != J) {
+            tile_transpose(x, scr, rq, c);
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const int r = rq + 4 * q;
+                if (j0 + c < n && i0 + r < n) P[(size_t)(i0 + r) * n + j0 + c] = x[q];
+            }
+        }
     }
 }
 
@@ -1292,10 +1389,11 @@ int hv_ekf_augment(hv_ekf *h, const int *discarded, const unsigned char *active)
     a.q_pos = e->par.noiseInitialPosTrail * e->par.noiseInitialPosTrail * e->noise_scale;
     a.q_ori = e->par.noiseInitialOriTrail * e->par.noiseInitialOriTrail * e->noise_scale;
     a.rd = e->par.augmentR * e->noise_scale;
-    const size_t shmem = sizeof(double) * (3 * hv::POSE * e->n + 2 * hv::POSE * hv::POSE + hv::POSE + 1);
+    const size_t shmem = sizeof(double) * (3 * hv::POSE * e->n + 2 * hv::POSE * hv::POSE + hv::POSE + 1 + (hv::AUG_THREADS / 64) * 16 * 17);
     hv::ScopedKernelTime tm(c, HV_K_EKF_AUGMENT);
     hipLaunchKernelGGL(hv::ekf_augment_kernel, dim3(e->batch), dim3(hv::AUG_THREADS), shmem, c->stream, a);
     HV_HIP(c, hipGetLastError());
+    std::swap(e->P, e->P1);                 // the kernel wrote the new covariance to the other buffer
     return HV_OK;
 }
 
@@ -1306,9 +1404,9 @@ int hv_ekf_undo_augment(hv_ekf *h, const unsigned char *active)
     hv::ShiftArgs a{e->n, e->map_dim, e->m, e->P, e->P1, e->m1, nullptr};
     if (active) { HV_HIP(c, hipMemcpyAsync(e->sactive, active, e->batch, hipMemcpyHostToDevice, c->stream)); a.active = e->sactive; }
     hv::ScopedKernelTime tm(c, HV_K_EKF_AUGMENT);
-    hipLaunchKernelGGL(hv::ekf_unaugment_gather_kernel, dim3(e->batch), dim3(1024), 0, c->stream, a);
-    hipLaunchKernelGGL(hv::ekf_copy_back_kernel, dim3(e->batch), dim3(1024), 0, c->stream, a);
+    hipLaunchKernelGGL(hv::ekf_unaugment_kernel, dim3(e->batch), dim3(1024), 0, c->stream, a);
     HV_HIP(c, hipGetLastError());
+    std::swap(e->P, e->P1);
     return HV_OK;
 }
 

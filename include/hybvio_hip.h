@@ -149,6 +149,8 @@ int hv_ekf_get_means(hv_ekf *ekf, double *m_all /* batch * n */);
 int hv_ekf_set_process_noise(hv_ekf *ekf, int filter, const double *Q12x12);   /* setProcessNoise */
 int hv_ekf_get_process_noise(hv_ekf *ekf, int filter, double *Q12x12);
 int hv_ekf_get_dydx(hv_ekf *ekf, int filter, double *dydx20x20);               /* getDydx block   */
+/* device addresses of the means (batch x n) and covariances (batch x n x n). hv_ekf_augment and
+ * hv_ekf_undo_augment ping-pong between two covariance buffers: fetch P_dev again after either. */
 int hv_ekf_device_pointers(hv_ekf *ekf, double **m_dev, double **P_dev);
 /* predict (ekf.cpp:320-514): mean, Jacobians and P <- F P F' + L Q L' on the device. dt[f] <= 0
  * skips filter f. gyro/acc: [batch][3]. */
