@@ -334,6 +334,8 @@ __device__ __forceinline__ void factor_diag_block(double *T, double *W, double *
     // step k+1 has been issued: a wavefront issues in order, so a wait for the LDS round trip in
     // step k would stall the chain behind it.
     double mprev[16], lprev = 0.0;
+    double *col_dst = lane < 16 ? col + r : col + 256 + lane;   // col[256 .. 319]: dump area (an exec-masked store makes
+                                                                  // hipcc wait for the store itself before the next use of LDS data)
 #pragma unroll
     for (int k = 0; k < 16; k++) {
         const double d = lane_bcast(tr[k], k);
@@ -345,7 +347,7 @@ __device__ __forceinline__ void factor_diag_block(double *T, double *W, double *
         const double lk = tr[k] * inv;                        // lane k: d * rsqrt(d) = sqrt(d)
         tr[k] = lk;
         if (k + 1 < 16) {
-            if (k + 2 < 16 && lane < 16) col[k * 16 + r] = lk;
+            if (k + 2 < 16) col_dst[k * 16] = lk;            // branch-free: lanes >= 16 write to a dump row
             tr[k + 1] -= lk * lane_bcast(lk, k + 1);          // lane c < 16 holds L(c, k)
         }
 #pragma unroll
@@ -411,12 +413,12 @@ __global__ __launch_bounds__(UPD_THREADS) void ekf_update_kernel(UpdateArgs a)
     //   rows nr+1 ..     (H P)'  (n rows)          -> Y' = (L^-1 H P)'
     // One blocked Cholesky pass over T does the factorisation and both triangular solves. The gate
     // only needs rows 0 .. nr. All LDS comes from the dynamic region (keeps the base 16-byte aligned):
-    // [T] W[256] col[256] red[16] flag. USE_LDS is a template parameter so that the common case compiles to
+    // [T] W[256] col[320] red[16] flag. USE_LDS is a template parameter so that the common case compiles to
     // ds_read / ds_write (a run-time select would turn every access into a flat load).
     double *T = USE_LDS ? smem : a.ws + (size_t)b * R * nr;
     double *W = USE_LDS ? smem + (((size_t)R * nr + 1) & ~(size_t)1) : smem;   // inverse of the current diagonal block
     double *col = W + 256;                                                      // column broadcast buffer of the diagonal factor
-    double *red = col + 256;
+    double *red = col + 320;
     int *s_stop = reinterpret_cast<int *>(red + nwaves);
     double *Hs = red + nwaves + 2;                // MODE 2: H zero-padded to (16 TI) x (16 lb), column-major, stride nrp
     constexpr int nrp = 16 * (TI > 0 ? TI : 1);
@@ -1091,7 +1093,7 @@ static int ekf_launch_update(Ekf *e, int nr, int l, const double *H_dev, const d
     a.m = e->m; a.P = e->P; a.H = H_dev; a.v = v_dev; a.rdiag = rdiag_dev; a.rd0 = rd0; a.noise_scale = e->noise_scale;
     a.ws = e->ws; a.chi2 = chi2_dev; a.status = status_dev; a.active = active_dev;
     size_t tall = (((size_t)a.Rs * nr + 1) & ~(size_t)1) * sizeof(double);
-    const size_t small = (size_t)(512 + UPD_THREADS / 64 + 2) * sizeof(double);                 // W + col + red + flag
+    const size_t small = (size_t)(576 + UPD_THREADS / 64 + 2) * sizeof(double);                 // W + col + red + flag
     const int ti = (nr + 15) / 16, lbk = (l + 15) / 16;
     const size_t hbytes = (size_t)(16 * ti) * (16 * lbk) * sizeof(double);                      // zero-padded H
     const size_t lds_cap = 150 * 1024;
