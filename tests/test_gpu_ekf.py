@@ -121,7 +121,10 @@ def test_reference_der_predict_on_gpu(oracle, ctx):
     assert np.abs(D - F).max() < 1e-3
 
 
-@pytest.mark.parametrize("nr,l", [(40, 160), (84, 160), (16, 76), (8, 41), (3, 160), (128, 160)])
+# (rows, columns of H): the all-in-LDS kernel with 1 / 2 / 3 row tiles incl. its 47-row limit and ragged
+# K halves (l = 41, 76, 100), the LDS + streamed-H kernel (48, 64) and the global-workspace kernel (84, 128)
+@pytest.mark.parametrize("nr,l", [(40, 160), (84, 160), (16, 76), (8, 41), (3, 160), (128, 160),
+                                  (47, 160), (48, 160), (33, 160), (64, 160), (17, 100), (32, 27)])
 def test_visual_gate_and_update_parity(oracle, ctx, nr, l):
     rng = np.random.default_rng(nr * 7 + l)
     os_, g = make_pair(oracle, ctx, rng, batch=2)
@@ -215,6 +218,29 @@ def test_pose_augmentation_and_undo_parity(oracle, ctx, k):
     for o in os_:
         o.update_undo_augmentation()
     check(os_, g)
+
+
+def test_symmetrize_is_exact_and_undo_respects_active_mask(oracle, ctx):
+    """P = (P + P') / 2 bit for bit on an asymmetric P (tile-pair kernel incl. the ragged last tile), and
+    the undo shift leaves masked-out filters alone although the covariance buffers are ping-ponged."""
+    rng = np.random.default_rng(5)
+    for trail in (20, 5, 1):
+        os_, g = make_pair(oracle, ctx, rng, batch=3, trail=trail)
+        n = g.n
+        Ps = []
+        for b in range(3):
+            m, _ = g.get_state(b)
+            P = rng.normal(size=(n, n))
+            g.set_state(b, m, P)
+            Ps.append(P)
+        g.symmetrize()
+        for b in range(3):
+            assert np.array_equal(g.get_state(b)[1], 0.5 * (Ps[b] + Ps[b].T))
+        g.undo_augment(active=[1, 0, 1])
+        assert np.array_equal(g.get_state(1)[1], 0.5 * (Ps[1] + Ps[1].T))
+        os_[0].set_cov(0.5 * (Ps[0] + Ps[0].T))
+        os_[0].update_undo_augmentation()
+        assert rel(g.get_state(0)[1], os_[0].P) < 1e-15
 
 
 def test_mixed_discard_indices_and_active_mask(oracle, ctx):
