@@ -30,7 +30,8 @@ def build_hip(force: bool = False, verbose: bool = False) -> str:
         return LIB
     os.makedirs(LIBDIR, exist_ok=True)
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc] + HIPCC_FLAGS + ["-o", LIB] + sources()
+    extra = ["-DHV_EKF_PHASE_STAMPS"] if os.environ.get("HV_EKF_PHASE_STAMPS") == "1" else []
+    cmd = [hipcc] + HIPCC_FLAGS + extra + ["-o", LIB] + sources()
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd, cwd=CSRC)

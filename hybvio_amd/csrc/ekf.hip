@@ -2,20 +2,28 @@
 //
 // Replaces the dense parts of odometry::EKF (reference: src/odometry/ekf.cpp; oracle:
 // oracle/ekf_oracle.c). State m (n) and covariance P (n x n, f64, column-major as Eigen) live in
-// HBM / L2; the mean-side scalar bookkeeping (sample times, augment counters, rate limits) stays
-// in the host adapter. Design for CDNA4:
-//   * dense products (H*P, HP*H', P -= Y'Y) run on the f64 matrix cores
-//     (v_mfma_f64_16x16x4_f64): one wavefront owns a 16x16 output tile and streams its A/B
-//     operands straight from L2/LDS -- at n = 160 everything is cache resident, so no staging
-//     pipeline is needed and each MFMA retires 1024 MACs for two operand loads;
-//   * the innovation solve uses ONE right-looking Cholesky sweep over the tall matrix
-//     T = [S ; (HP)' ; v'] held in LDS: afterwards the lower rows are Y' = (L^-1 HP)' and
-//     z' = (L^-1 v)', so K is never formed: chi2 = ns z'z, m += Y'z, P -= Y'Y (symmetric by
-//     construction). The reference forms K = (S^-1 HP)' with a pivoted LDLT and P -= K*HP; the
-//     two are algebraically identical, parity is checked to 1e-5 relative (measured ~1e-13);
+// HBM; the mean-side scalar bookkeeping (sample times, augment counters, rate limits) stays in the
+// host adapter. Design for CDNA4 (numbers: scripts/f64_ubench.hip, scripts/ekf_microbench.py):
+//   * f64 vector and f64 matrix peak are the same 128 flop/clk/CU on gfx950; the matrix cores are
+//     used because one v_mfma_f64_16x16x4_f64 retires 1024 MACs for two operand loads (one f64 per
+//     lane each) where a v_fma_f64 needs two operands per MAC, and because a lone wavefront issues a
+//     dependent v_fma_f64 only every ~7 cycles;
+//   * visual update / chi2 gate (ekf_update_kernel): S = H P H' + R is factored and both triangular
+//     solves are done in ONE blocked Cholesky pass over the tall matrix T = [S ; v' ; (HP)'] in LDS
+//     (16-column blocks: MFMA panel / trailing updates, the 16 x 16 diagonal factor and its inverse
+//     in the registers of one wavefront), after which chi2 = ns z'z, m += Y'z, P -= Y'Y with
+//     Y = L^-1 HP. K is never formed; the reference forms K = (S^-1 HP)' with a pivoted LDLT and
+//     P -= K HP, algebraically identical (parity 1e-9 relative per call, measured ~1e-13). At the
+//     reference's sizes (n = 160, <= 47 rows) H is staged in LDS too and every wavefront owns whole
+//     16-column blocks of P: the tiles it streams from HBM as MFMA operands of H P are already in the
+//     accumulator layout of P -= Y'Y and stay in registers until then, so P is read once per update;
+//   * predict: thread 0 evaluates the mean and the 20 x 20 Jacobians while the other wavefronts
+//     already hold the slabs of P10 / P01 they need; the off-diagonal blocks are MFMA items;
 //   * pose augmentation: the Joseph form (I-KH) P (I-KH)' + K R K' is expanded around the 7-row
-//     +-1 matrix visAugH into two rank-7 corrections, O(14 n^2) instead of two dense n^3 products,
-//     fused with the shift A P A' + Q (a gather) and the (P+P')/2 symmetrisation.
+//     +-1 matrix visAugH into a rank-14 correction (4 MFMA k-steps per 16 x 16 tile) of the shifted
+//     matrix A P A' + Q, which is a gather of P and never materialised; mirrored tile pairs meet
+//     through an in-wave LDS transpose for the fused (P+P')/2, and the result goes to the second of
+//     two ping-pong buffers: one read and one write of P per augmentation.
 #include <math.h>
 
 #include <utility>
@@ -39,11 +47,17 @@ typedef double double4v __attribute__((ext_vector_type(4)));
 
 __device__ const double d_chi2inv95[HV_CHI2INV95_N] = { HV_CHI2INV95_VALUES };
 
-// developer aid: s_memtime stamps of the update kernel's phases (block 0, thread 0)
+// developer aid: s_memtime stamps of the kernels' phases (block 0, thread 0), read back through
+// hv_debug_ekf_phase_stamps. Compiled in only with -DHV_EKF_PHASE_STAMPS (HV_EKF_PHASE_STAMPS=1 in the
+// environment of hybvio_amd/build.py): every stamp is a scalar memory wait in the middle of a pipeline.
 }  // namespace
 __device__ long long g_phase_stamp[16];
 namespace {
+#ifdef HV_EKF_PHASE_STAMPS
 #define PHASE_STAMP(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_phase_stamp[i] = (long long)__builtin_readcyclecounter(); } while (0)
+#else
+#define PHASE_STAMP(i) do { } while (0)
+#endif
 
 // One wavefront: acc(16x16) = A(16 x K) * B(K x 16) with A(i, k) = Ap[i*sai + k*sak] and
 // B(k, j) = Bp[k*sbk + j*sbj]. f64 MFMA operand layout: lane l carries A[l & 15][l >> 4] and
@@ -475,19 +489,21 @@ __global__ __launch_bounds__(UPD_THREADS) void ekf_update_kernel(UpdateArgs a)
         __syncthreads();
         PHASE_STAMP(9);
         const double *hbase = Hs + (size_t)kq * nrp + cl;
-        auto mfma_blk = [&](auto &pv, int bi, int kb, int kend, double4v (&acc)[TI]) {
-            if (kb < kend && kb < lb) {
-                double av[4][TI];
+        // H operands of a K block: 4 k-steps x TI row tiles, double-buffered across blocks (the reads of
+        // block b+1 are issued before the MFMAs of block b: a wavefront that only prefetches one or two
+        // ds_reads ahead issues an MFMA every ~100 cycles instead of every 64)
+        auto load_h = [&](int kb, double (&av)[4][TI]) {
 #pragma unroll
-                for (int sx = 0; sx < 4; sx++)
+            for (int sx = 0; sx < 4; sx++)
 #pragma unroll
-                    for (int mt = 0; mt < TI; mt++) av[sx][mt] = hbase[(size_t)(kb * 16 + 4 * sx) * nrp + 16 * mt];
+                for (int mt = 0; mt < TI; mt++) av[sx][mt] = hbase[(size_t)(kb * 16 + 4 * sx) * nrp + 16 * mt];
+        };
+        auto mfma_blk = [&](auto &pv, int bi, const double (&av)[4][TI], double4v (&acc)[TI]) {
 #pragma unroll
-                for (int sx = 0; sx < 4; sx++)
+            for (int sx = 0; sx < 4; sx++)
 #pragma unroll
-                    for (int mt = 0; mt < TI; mt++)
-                        acc[mt] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[sx][mt], pv[bi][sx], acc[mt], 0, 0, 0);
-            }
+                for (int mt = 0; mt < TI; mt++)
+                    acc[mt] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[sx][mt], pv[bi][sx], acc[mt], 0, 0, 0);
         };
         auto flush = [&](int J, double4v (&acc)[TI]) {
 #pragma unroll
@@ -503,11 +519,17 @@ __global__ __launch_bounds__(UPD_THREADS) void ekf_update_kernel(UpdateArgs a)
             double4v acc[TI];
 #pragma unroll
             for (int mt = 0; mt < TI; mt++) acc[mt] = double4v{0.0, 0.0, 0.0, 0.0};
+            const int nv = have0 ? min(tiles_j, lb) : 0;                   // K blocks with matrix work: 0 .. nv-1
+            double av[2][4][TI];
+            if (nv > 0) load_h(0, av[0]);
 #pragma unroll
             for (int bi = 0; bi < NBK; bi++) {
                 if (bi + DEPTH < NBK) { if (have0) fetch_blk(pres0, bi + DEPTH, wave, bi + DEPTH, tiles_j); }
                 else if (bi + DEPTH - NBK < NBH) { if (have1) fetch_blk(pres1, bi + DEPTH - NBK, J1, kb0_1 + bi + DEPTH - NBK, kb1_1); }
-                if (have0) mfma_blk(pres0, bi, bi, tiles_j, acc);
+                if (bi < nv) {
+                    if (bi + 1 < nv) load_h(bi + 1, av[(bi + 1) & 1]);
+                    mfma_blk(pres0, bi, av[bi & 1], acc);
+                }
             }
             if (have0) flush(wave, acc);
         }
@@ -516,10 +538,16 @@ __global__ __launch_bounds__(UPD_THREADS) void ekf_update_kernel(UpdateArgs a)
             double4v acc[TI];
 #pragma unroll
             for (int mt = 0; mt < TI; mt++) acc[mt] = double4v{0.0, 0.0, 0.0, 0.0};
+            const int nv = have1 ? max(min(kb1_1, lb) - kb0_1, 0) : 0;     // blocks kb0_1 .. kb0_1 + nv - 1
+            double av[2][4][TI];
+            if (nv > 0) load_h(kb0_1, av[0]);
 #pragma unroll
             for (int bi = 0; bi < NBH; bi++) {
                 if (bi + DEPTH < NBH) { if (have1) fetch_blk(pres1, bi + DEPTH, J1, kb0_1 + bi + DEPTH, kb1_1); }
-                if (have1) mfma_blk(pres1, bi, kb0_1 + bi, kb1_1, acc);
+                if (bi < nv) {
+                    if (bi + 1 < nv) load_h(kb0_1 + bi + 1, av[(bi + 1) & 1]);
+                    mfma_blk(pres1, bi, av[bi & 1], acc);
+                }
             }
             if (have1) flush(J1, acc);
         }

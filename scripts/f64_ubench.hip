@@ -6,7 +6,7 @@
 #include <vector>
 
 typedef double double4v __attribute__((ext_vector_type(4)));
-#define N 512
+#define N 480
 
 __global__ void k_mfma_dep(double *out, long long *cyc, long long *wall)
 {
@@ -36,6 +36,33 @@ __global__ void k_mfma_ind(double *out, long long *cyc)
     }
     long long t1 = clock64();
     out[threadIdx.x] = c0[0] + c1[1] + c2[2] + c3[3];
+    if ((threadIdx.x & 63) == 0) cyc[threadIdx.x >> 6] = t1 - t0;
+}
+
+// 3 accumulators, 12 distinct A registers and 4 distinct B registers per block, operands from LDS
+// (the shape of the H P loop in ekf.hip)
+__global__ void k_mfma_lds(double *out, long long *cyc)
+{
+    __shared__ double hs[48 * 64];
+    for (int i = threadIdx.x; i < 48 * 64; i += blockDim.x) hs[i] = 1e-3 * (i % 97);
+    __syncthreads();
+    const int lane = threadIdx.x & 63, kq = lane >> 4, cl = lane & 15;
+    double4v acc[3] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
+    double bv[4] = {1.0 + lane, 2.0 + lane, 3.0 + lane, 4.0 + lane};
+    long long t0 = clock64();
+    for (int blk = 0; blk < N / 12; blk++) {
+        double av[4][3];
+#pragma unroll
+        for (int sx = 0; sx < 4; sx++)
+#pragma unroll
+            for (int mt = 0; mt < 3; mt++) av[sx][mt] = hs[((blk & 3) * 16 + 4 * sx + kq) * 48 + 16 * mt + cl];
+#pragma unroll
+        for (int sx = 0; sx < 4; sx++)
+#pragma unroll
+            for (int mt = 0; mt < 3; mt++) acc[mt] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[sx][mt], bv[sx], acc[mt], 0, 0, 0);
+    }
+    long long t1 = clock64();
+    out[threadIdx.x] = acc[0][0] + acc[1][1] + acc[2][2];
     if ((threadIdx.x & 63) == 0) cyc[threadIdx.x >> 6] = t1 - t0;
 }
 
@@ -147,6 +174,7 @@ int main()
     for (int threads : {64, 256, 1024}) {
         hipLaunchKernelGGL(k_mfma_ind, dim3(1), dim3(threads), 0, 0, out, cyc); report("mfma f64 16x16x4 4 accumulators", threads / 64);
     }
+    for (int threads : {64, 256, 512, 1024}) { hipLaunchKernelGGL(k_mfma_lds, dim3(1), dim3(threads), 0, 0, out, cyc); report("mfma f64, 3 acc, A from LDS per block", threads / 64); }
     for (int threads : {64, 256, 1024}) { hipLaunchKernelGGL(k_fma_dep, dim3(1), dim3(threads), 0, 0, out, cyc); report("v_fma_f64 dependent", threads / 64); }
     for (int threads : {64, 256, 1024}) { hipLaunchKernelGGL(k_fma_ind, dim3(1), dim3(threads), 0, 0, out, cyc); report("v_fma_f64 8 independent", threads / 64); }
     hipLaunchKernelGGL(k_rsq_dep, dim3(1), dim3(64), 0, 0, out, cyc); report("v_rsq_f64 + add dependent", 1);
