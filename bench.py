@@ -83,14 +83,22 @@ class TrackerBench:
         grid = synth.grid_points(W, H, NPTS, margin=40, seed=3)
         self.grid = torch.from_numpy(np.tile(grid, (B, 1))).to(dev)            # [B*N, 2]
         self.pts_left = self.grid.clone()
-        self.disp = torch.full((B * NPTS,), 20.0, dtype=torch.float32, device=dev)
+        self.dispvec = torch.zeros((B * NPTS, 2), dtype=torch.float32, device=dev)   # (predicted disparity, 0)
+        self.dispvec[:, 0] = 20.0
+        self.disp0 = torch.full((B * NPTS,), 20.0, dtype=torch.float32, device=dev)
+        self.lo = torch.tensor([16.0, 16.0], device=dev)
+        self.hi = torch.tensor([W - 16.0, H - 16.0], device=dev)
+        self.side = torch.cuda.Stream(device=dev)
+        self.ev_klt, self.ev_book = torch.cuda.Event(), torch.cuda.Event()
+        self.pending = False
+        self.overlap = True
         self.cur_left = torch.empty_like(self.grid)
         self.cur_right = torch.empty_like(self.grid)
         self.st1 = torch.zeros(B * NPTS, dtype=torch.uint8, device=dev)
         self.st2 = torch.zeros_like(self.st1)
         self.err = torch.zeros(B * NPTS, dtype=torch.float32, device=dev)
         self.k = 0
-        self.tracked = 0.0
+        self.tracked = torch.ones(B * NPTS, dtype=torch.bool, device=dev)
         self._build(0)                                                          # frame 0 primes "prev"
         self.k = 1
 
@@ -98,27 +106,51 @@ class TrackerBench:
         f = self.frames[k % N_CYCLE]
         self.ctx.build_batch_dev(2 * self.B, self.build_slots[k % 2].data_ptr(), f.data_ptr(), W * H, W)
 
+    def _bookkeeping(self):
+        """Stand-in for the host tracker's bookkeeping between two frames (tracker.cpp:441-478,604-670):
+        merge stereo failures, drop out-of-image tracks, re-seed lost tracks so N stays constant."""
+        t = self.torch
+        inside = ((self.cur_left >= self.lo) & (self.cur_left < self.hi)).all(dim=1)
+        ok = inside & ((self.st1 & self.st2) > 0)
+        self.tracked = ok
+        t.where(ok[:, None], self.cur_left, self.grid, out=self.pts_left)
+        t.where(ok, self.cur_left[:, 0] - self.cur_right[:, 0], self.disp0, out=self.dispvec[:, 0])
+
     def step(self):
         t, k, B = self.torch, self.k, self.B
+        main = t.cuda.current_stream()
+        # The bookkeeping of the previous frame's tracks only feeds this frame's LK calls, and this
+        # frame's pyramids only need the images: as in the reference (host logic next to the image
+        # pipeline) the two run concurrently -- a dozen tiny elementwise kernels on a side stream
+        # next to the pyramid build on the context stream.
+        if self.pending and self.overlap:
+            self.side.wait_event(self.ev_klt)
+            with t.cuda.stream(self.side):
+                self._bookkeeping()
+                self.ev_book.record(self.side)
+        elif self.pending:
+            self._bookkeeping()                  # single stream (graph capture): same work, in order
         self._build(k)
+        if self.pending and self.overlap:
+            main.wait_event(self.ev_book)
         prev, cur = self.L[(k - 1) % 2], self.L[k % 2]
-        self.cur_left.copy_(self.pts_left)                                      # zero-flow prediction
+        # zero-flow prediction: use_initial_flow = 0 starts every track at its previous position
         self.ctx.klt_track_batch_dev(B, prev.data_ptr(), cur.data_ptr(), NPTS, self.pts_left.data_ptr(),
-                                     self.cur_left.data_ptr(), self.st1.data_ptr(), 0, True)   # err unused, as in HybVIO
-        self.cur_right.copy_(self.cur_left)
-        self.cur_right[:, 0] -= self.disp                                       # predicted disparity
+                                     self.cur_left.data_ptr(), self.st1.data_ptr(), 0, False)   # err unused, as in HybVIO
+        t.sub(self.cur_left, self.dispvec, out=self.cur_right)                  # predicted disparity
         self.ctx.klt_track_batch_dev(B, cur.data_ptr(), self.R.data_ptr(), NPTS, self.cur_left.data_ptr(),
                                      self.cur_right.data_ptr(), self.st2.data_ptr(), 0, True)
-        # stand-in for the host tracker's bookkeeping (tracker.cpp:441-478,604-670): merge stereo
-        # failures, drop out-of-image tracks, re-seed lost tracks so N stays constant
-        x, y = self.cur_left[:, 0], self.cur_left[:, 1]
-        ok = (self.st1 > 0) & (self.st2 > 0) & (x >= 16) & (x < W - 16) & (y >= 16) & (y < H - 16)
-        self.tracked = ok
-        self.pts_left = t.where(ok[:, None], self.cur_left, self.grid)
-        self.disp = t.where(ok, self.cur_left[:, 0] - self.cur_right[:, 0], t.full_like(self.disp, 20.0))
+        if self.overlap:
+            self.ev_klt.record(main)
+        self.pending = True
         self.k += 1
 
     def tracked_fraction(self):
+        t = self.torch
+        if self.pending:                      # fold in the last frame's results
+            t.cuda.current_stream().wait_event(self.ev_klt)
+            self._bookkeeping()
+            self.pending = False
         return float(self.tracked.float().mean().item())
 
 
@@ -425,6 +457,7 @@ def main():
         try:
             side = torch.cuda.Stream()
             t1.ctx.set_stream(side.cuda_stream)
+            t1.overlap = False                               # one capture stream: no cross-stream events inside a graph
             graphs = []
             with torch.cuda.stream(side):
                 for _ in range(N_CYCLE):
