@@ -44,8 +44,15 @@ def lib():
                                     C.c_int, C.c_double, C.c_int, C.c_double, i32p]
         L.orc_optical_flow_compute.argtypes = [C.c_void_p, C.c_void_p, C.c_int, f32p, f32p, i32p, C.c_int,
                                                C.c_int, C.c_int, C.c_int, C.c_double, C.c_double]
+        L.orc_set_threads.argtypes = [C.c_int]
         _LIB = L
     return _LIB
+
+
+def set_threads(n: int) -> int:
+    """Threads for the row (pyramid, Scharr) and point (LK) loops: 1 = scalar port, 0 = all host cores.
+    Returns the count in effect. Results do not depend on it (integer sums, independent points)."""
+    return int(lib().orc_set_threads(int(n)))
 
 
 def _p(a, t):

@@ -108,6 +108,7 @@ static void pyr_down(const orc_level *S, orc_level *D)
 {
     static const int k[5] = {1, 4, 6, 4, 1};
     const int sw = S->w, sh = S->h;
+#pragma omp parallel for schedule(static)          /* rows: what cv::parallel_for_ does in pyrDown */
     for (int y = 0; y < D->h; y++) {
         for (int x = 0; x < D->w; x++) {
             int acc = 0;
@@ -130,8 +131,11 @@ static void pyr_down(const orc_level *S, orc_level *D)
 static void scharr_deriv(orc_level *L)
 {
     const int w = L->w, h = L->h;
+#pragma omp parallel                                   /* ScharrDerivInvoker is a parallel_for_ over rows */
+    {
     int *t0 = (int *)malloc(sizeof(int) * (size_t)(w + 2));
     int *t1 = (int *)malloc(sizeof(int) * (size_t)(w + 2));
+#pragma omp for schedule(static)
     for (int y = 0; y < h; y++) {
         const uint8_t *r0 = gray_at(L, 0, y > 0 ? y - 1 : (h > 1 ? 1 : 0));
         const uint8_t *r1 = gray_at(L, 0, y);
@@ -150,6 +154,7 @@ static void scharr_deriv(orc_level *L)
         }
     }
     free(t0); free(t1);
+    }
 }
 
 /* cv::buildOpticalFlowPyramid(img, pyr, Size(win,win), maxLevel, withDerivatives=true,
@@ -246,9 +251,12 @@ static void lk_level(const orc_level *I, const orc_level *J, int npts,
 {
     const float half_win = (float)(win - 1) * 0.5f;
     const float FLT_SCALE = 1.f / (float)(1 << 20);
+#pragma omp parallel                                   /* LKTrackerInvoker is a parallel_for_ over points */
+    {
     int16_t *Iwin = (int16_t *)malloc(sizeof(int16_t) * (size_t)win * win);
     int16_t *dIwin = (int16_t *)malloc(sizeof(int16_t) * (size_t)win * win * 2);
 
+#pragma omp for schedule(dynamic, 4)
     for (int pt = 0; pt < npts; pt++) {
         if (iters_out) iters_out[pt] = 0;
         const float lscale = (float)(1. / (double)(1 << level));
@@ -372,7 +380,16 @@ static void lk_level(const orc_level *I, const orc_level *J, int npts,
         }
     }
     free(Iwin); free(dIwin);
+    }
 }
+
+/* threads used by the row / point loops above (1 = the scalar port; 0 = all host cores) */
+#ifdef _OPENMP
+#include <omp.h>
+int orc_set_threads(int n) { if (n > 0) omp_set_num_threads(n); else omp_set_num_threads(omp_get_num_procs()); return omp_get_max_threads(); }
+#else
+int orc_set_threads(int n) { (void)n; return 1; }
+#endif
 
 /* cv::calcOpticalFlowPyrLK(prevPyr, nextPyr, prevPts, nextPts, status, err, Size(win,win),
  *   maxLevel, TermCriteria(COUNT|EPS, maxCount, eps), flags, minEigThreshold)
