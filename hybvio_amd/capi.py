@@ -29,7 +29,7 @@ f32p = C.POINTER(C.c_float)
 f64p = C.POINTER(C.c_double)
 
 HV_MAX_LEVELS = 6
-K_PYR_L0, K_PYR_LN, K_KLT, K_EKF_PREDICT, K_EKF_UPDATE, K_EKF_AUGMENT = range(6)
+K_PYR_L0, K_PYR_LN, K_KLT, K_EKF_PREDICT, K_EKF_UPDATE, K_EKF_AUGMENT, K_GFTT = range(7)
 
 # tracker::Feature::Status (src/tracker/track.hpp:9-21)
 ST_TRACKED, ST_NEW, ST_FAILED_FLOW, ST_RANSAC_OUTLIER, ST_FLOW_OUT_OF_RANGE = 0, 1, 2, 3, 4
@@ -49,6 +49,11 @@ class EkfParams(C.Structure):
             "noiseInitialBGA", "noiseInitialBAA", "noiseInitialBAT", "noiseInitialSFT",
             "noiseProcessAcc", "noiseProcessGyro", "noiseProcessBAA", "noiseProcessBGA",
             "noiseProcessBAARev", "noiseProcessBGARev")]
+
+
+class GfttParams(C.Structure):
+    _fields_ = [("gfttBlockSize", C.c_int), ("gfttMinDistance", C.c_double), ("gfttMinResponse", C.c_float),
+                ("maxTracks", C.c_int)]
 
 
 class HvError(RuntimeError):
@@ -101,6 +106,13 @@ PROTOTYPES = {
     "hv_ekf_symmetrize": (C.c_int, [C.c_void_p]),
     "hv_ekf_normalize_quaternions": (C.c_int, [C.c_void_p, C.c_int]),
     "hv_ekf_transform": (C.c_int, [C.c_void_p, C.c_int, f64p, f64p, f64p]),
+    "hv_gftt_default_params": (None, [C.POINTER(GfttParams)]),
+    "hv_gftt_block_size": (C.c_int, [C.POINTER(GfttParams)]),
+    "hv_gftt_keypoint_count": (C.c_int, [C.c_void_p, C.POINTER(GfttParams)]),
+    "hv_gftt_detect": (C.c_int, [C.c_void_p, C.POINTER(GfttParams), C.c_int, f32p, C.c_int, C.c_int, f32p, C.c_int,
+                                 C.POINTER(C.c_int)]),
+    "hv_gftt_keypoints_batch_dev": (C.c_int, [C.c_void_p, C.POINTER(GfttParams), C.c_int, C.c_void_p, C.c_void_p]),
+    "hv_apply_min_distance": (None, [f32p, C.POINTER(C.c_int), f32p, C.c_int, C.c_int, C.c_int]),
     "hv_profile_enable": (C.c_int, [C.c_void_p, C.c_int]),
     "hv_profile_reset": (C.c_int, [C.c_void_p]),
     "hv_profile_read": (C.c_int, [C.c_void_p, C.c_int, f64p, C.POINTER(C.c_longlong)]),
@@ -241,6 +253,27 @@ class Context:
                                                C.c_void_p(err_dev), int(use_initial_flow), max_iter_override),
                   "hv_klt_track_batch_dev")
 
+    # -- GFTT feature detector --
+    def gftt_detect(self, slot: int, prev=(), mask_radius: int = 0, params: "GfttParams" = None):
+        """FeatureDetector::detect on the level-0 image of a built pyramid slot -> corners [n, 2]."""
+        gp = params if params is not None else gftt_default_params()
+        nk = lib().hv_gftt_keypoint_count(self._h, C.byref(gp))
+        out = np.zeros((max(2 * nk, 1), 2), np.float32)
+        pv = np.ascontiguousarray(prev, np.float32).reshape(-1, 2)
+        n = C.c_int(0)
+        self._chk(lib().hv_gftt_detect(self._h, C.byref(gp), slot, _p(pv, f32p) if len(pv) else None, len(pv),
+                                       int(mask_radius), _p(out, f32p), 2 * nk, C.byref(n)), "hv_gftt_detect")
+        return out[:n.value].copy()
+
+    def gftt_keypoint_count(self, params: "GfttParams" = None) -> int:
+        gp = params if params is not None else gftt_default_params()
+        return int(lib().hv_gftt_keypoint_count(self._h, C.byref(gp)))
+
+    def gftt_keypoints_batch_dev(self, n_images: int, slots_dev: int, kp_dev: int, params: "GfttParams" = None):
+        gp = params if params is not None else gftt_default_params()
+        self._chk(lib().hv_gftt_keypoints_batch_dev(self._h, C.byref(gp), n_images, C.c_void_p(slots_dev),
+                                                    C.c_void_p(kp_dev)), "hv_gftt_keypoints_batch_dev")
+
     # -- timers --
     def profile_enable(self, on=True):
         self._chk(lib().hv_profile_enable(self._h, int(on)), "hv_profile_enable")
@@ -252,6 +285,23 @@ class Context:
         ms, n = C.c_double(), C.c_longlong()
         self._chk(lib().hv_profile_read(self._h, kernel_id, C.byref(ms), C.byref(n)), "hv_profile_read")
         return ms.value, n.value
+
+
+def gftt_default_params(**over) -> GfttParams:
+    p = GfttParams()
+    lib().hv_gftt_default_params(C.byref(p))
+    for k, v in over.items():
+        setattr(p, k, v)
+    return p
+
+
+def apply_min_distance(corners, prev, r: int, max_tracks: int = 200) -> np.ndarray:
+    """FeatureDetector::applyMinDistance (host code of the library)."""
+    c = np.ascontiguousarray(corners, np.float32).reshape(-1, 2).copy()
+    pv = np.ascontiguousarray(prev, np.float32).reshape(-1, 2)
+    n = C.c_int(len(c))
+    lib().hv_apply_min_distance(_p(c, f32p), C.byref(n), _p(pv, f32p) if len(pv) else None, len(pv), int(r), int(max_tracks))
+    return c[:n.value].copy()
 
 
 def ekf_default_params(**over) -> EkfParams:

@@ -185,6 +185,7 @@ void hv_destroy(hv_ctx *h)
     if (c->d_next_xy) (void)hipFree(c->d_next_xy);
     if (c->d_err) (void)hipFree(c->d_err);
     if (c->d_status) (void)hipFree(c->d_status);
+    if (c->d_gftt_kp) (void)hipFree(c->d_gftt_kp);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
     delete h;
 }

@@ -52,6 +52,8 @@ struct Ctx {
     float *d_prev_xy = nullptr, *d_next_xy = nullptr, *d_err = nullptr;
     uint8_t *d_status = nullptr;
     int stage_points = 0;
+    float *d_gftt_kp = nullptr;           // key points of the single-image detector entry point
+    int gftt_cap = 0;
     std::string last_error;
     bool profiling = false;
     KernelTimer timers[HV_K_COUNT];

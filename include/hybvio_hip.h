@@ -181,9 +181,38 @@ int hv_ekf_normalize_quaternions(hv_ekf *ekf, int only_current);    /* ekf.cpp:1
 int hv_ekf_transform(hv_ekf *ekf, int filter, const double *pChange3x3, const double *qChange4x4,
                      const double *translation3);
 
+/* ---- GFTT feature detector ----------------------------------------
+ * Replaces tracker::FeatureDetector (featureDetector "GPU-GFTT" on its CPU path:
+ * src/tracker/feature_detector.cpp:279-315 cv::cornerMinEigenVal, :393-417 CollectMax, :610-634
+ * detect(); src/tracker/feature_detector_legacy.cpp:177-213 applyMinDistance). Field names are the
+ * reference's parameters (codegen/parameter_definitions.c:262,317-324). */
+typedef struct hv_gftt_params {
+    int    gfttBlockSize;      /* box filter of the structure matrix; 3 (the only size on the device path) */
+    double gfttMinDistance;    /* selects the arg-max block edge: >= 32 -> 32, >= 16 -> 16, else 8          */
+    float  gfttMinResponse;    /* key points need 16 * minEigenVal > this                                   */
+    int    maxTracks;          /* applyMinDistance stops after this many corners                            */
+} hv_gftt_params;
+void hv_gftt_default_params(hv_gftt_params *p);
+int hv_gftt_block_size(const hv_gftt_params *p);                    /* CollectMax::blockSize()            */
+int hv_gftt_keypoint_count(hv_ctx *ctx, const hv_gftt_params *p);   /* floor(w/bs) * floor(h/bs)          */
+/* FeatureDetector::detect(image, corners, prevCorners, maskRadius) on the level-0 image of a pyramid
+ * slot that has been built (or is being built on the context stream): response + block arg-max on
+ * the device, then the reference's host tail (stable sort by response, one (0,0) point prepended per
+ * key point -- feature_detector.cpp:629-631 --, applyMinDistance when mask_radius > 0). corners_xy
+ * must hold 2 * hv_gftt_keypoint_count() points. Synchronous. */
+int hv_gftt_detect(hv_ctx *ctx, const hv_gftt_params *p, int slot, const float *prev_xy, int n_prev,
+                   int mask_radius, float *corners_xy, int capacity, int *n_out);
+/* Device half only, batched: kp_dev[n_images][hv_gftt_keypoint_count()][3] = (x, y, 16 * response) per
+ * block in block raster order ((0, 0, -1e10) where no pixel exceeds gfttMinResponse). Asynchronous. */
+int hv_gftt_keypoints_batch_dev(hv_ctx *ctx, const hv_gftt_params *p, int n_images, const int *slots_dev,
+                                float *kp_dev);
+/* FeatureDetector::applyMinDistance (host only, no device work): in place, *n_inout updated. */
+void hv_apply_min_distance(float *corners_xy, int *n_inout, const float *prev_xy, int n_prev, int r,
+                           int max_tracks);
+
 /* ---- per-kernel timing (hipEvents on the context stream) ---------------------------------- */
 enum { HV_K_PYR_L0 = 0, HV_K_PYR_LN = 1, HV_K_KLT = 2, HV_K_EKF_PREDICT = 3, HV_K_EKF_UPDATE = 4,
-       HV_K_EKF_AUGMENT = 5, HV_K_COUNT = 6 };
+       HV_K_EKF_AUGMENT = 5, HV_K_GFTT = 6, HV_K_COUNT = 7 };
 int hv_profile_enable(hv_ctx *ctx, int on);
 int hv_profile_reset(hv_ctx *ctx);
 /* Synchronizes, then returns accumulated device milliseconds and launch count of a kernel class. */

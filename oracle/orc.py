@@ -45,6 +45,12 @@ def lib():
         L.orc_optical_flow_compute.argtypes = [C.c_void_p, C.c_void_p, C.c_int, f32p, f32p, i32p, C.c_int,
                                                C.c_int, C.c_int, C.c_int, C.c_double, C.c_double]
         L.orc_set_threads.argtypes = [C.c_int]
+        L.orc_corner_min_eigen_val.argtypes = [u8p, C.c_int, C.c_int, C.c_int, C.c_int, f32p]
+        L.orc_gftt_block_size.argtypes = [C.c_double]
+        L.orc_gftt_collect_max.argtypes = [f32p, C.c_int, C.c_int, C.c_int, C.c_float, f32p]
+        L.orc_apply_min_distance.argtypes = [f32p, C.c_int, f32p, C.c_int, C.c_int, C.c_int]
+        L.orc_gftt_detect.argtypes = [u8p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_float, f32p, C.c_int,
+                                      C.c_int, C.c_int, f32p, C.c_int]
         _LIB = L
     return _LIB
 
@@ -318,3 +324,52 @@ class Ekf:
 
     def insert_map_point(self, idx, pf):
         _ekf_lib().orc_ekf_insert_map_point(self._h, idx, _p(_d(pf), f64p))
+
+
+# ---- GFTT feature detector (oracle/gftt_oracle.c) ----
+def corner_min_eigen_val(img: np.ndarray, block_size: int = 3) -> np.ndarray:
+    """cv::cornerMinEigenVal(img, blockSize, ksize=3) restatement, float32 response."""
+    img = np.ascontiguousarray(img, np.uint8)
+    h, w = img.shape
+    out = np.zeros((h, w), np.float32)
+    rc = lib().orc_corner_min_eigen_val(_p(img, u8p), w, h, w, block_size, _p(out, f32p))
+    if rc != 0:
+        raise RuntimeError(f"orc_corner_min_eigen_val failed: {rc}")
+    return out
+
+
+def gftt_block_size(min_distance: float = 50.0) -> int:
+    return int(lib().orc_gftt_block_size(float(min_distance)))
+
+
+def gftt_collect_max(response: np.ndarray, bs: int, min_response: float = 1e-3) -> np.ndarray:
+    """CollectMax::cpuImplementation: one (x, y, response) row per bs x bs block."""
+    response = np.ascontiguousarray(response, np.float32)
+    h, w = response.shape
+    kp = np.zeros(((w // bs) * (h // bs), 3), np.float32)
+    n = lib().orc_gftt_collect_max(_p(response, f32p), w, h, bs, min_response, _p(kp, f32p))
+    assert n == len(kp)
+    return kp
+
+
+def apply_min_distance(corners, prev, r: int, max_tracks: int = 200) -> np.ndarray:
+    c = np.ascontiguousarray(corners, np.float32).reshape(-1, 2).copy()
+    pv = np.ascontiguousarray(prev, np.float32).reshape(-1, 2)
+    n = lib().orc_apply_min_distance(_p(c, f32p), len(c), _p(pv, f32p), len(pv), int(r), int(max_tracks))
+    return c[:n].copy()
+
+
+def gftt_detect(img: np.ndarray, prev=(), mask_radius: int = 0, block_size: int = 3, min_distance: float = 50.0,
+                min_response: float = 1e-3, max_tracks: int = 200) -> np.ndarray:
+    """FeatureDetectorImplementation::detect on the CPU-fallback path (incl. the prepended zero points)."""
+    img = np.ascontiguousarray(img, np.uint8)
+    h, w = img.shape
+    bs = gftt_block_size(min_distance)
+    cap = 2 * (w // bs) * (h // bs)
+    out = np.zeros((max(cap, 1), 2), np.float32)
+    pv = np.ascontiguousarray(prev, np.float32).reshape(-1, 2)
+    n = lib().orc_gftt_detect(_p(img, u8p), w, h, w, block_size, float(min_distance), min_response, _p(pv, f32p), len(pv),
+                              int(mask_radius), int(max_tracks), _p(out, f32p), cap)
+    if n < 0:
+        raise RuntimeError(f"orc_gftt_detect failed: {n}")
+    return out[:n].copy()

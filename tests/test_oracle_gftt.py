@@ -1,0 +1,111 @@
+"""CPU tests of oracle/gftt_oracle.c: the restatement of the reference's
+CPU feature detector against an independent numpy binary32 evaluation of the same published OpenCV
+algorithm, analytic known answers, and the reference's own control flow (block scan, sort, the
+zero-point prefix, applyMinDistance). PARITY UNPINNED vs real OpenCV (see the oracle header)."""
+import numpy as np
+import pytest
+
+from hybvio_amd import synth
+from oracle import orc
+
+f32 = np.float32
+
+
+def numpy_min_eigen_val(img, block=3):
+    """cv::cornerMinEigenVal, same evaluation order as the oracle, vectorised in numpy float32."""
+    h, w = img.shape
+    g = np.pad(img.astype(f32), 1, mode="reflect")               # numpy 'reflect' == BORDER_REFLECT_101
+    scale = 1.0 / (4.0 * block * 255.0)
+    k0, k1 = f32(2.0 * scale), f32(1.0 * scale)
+    c = lambda dy, dx: g[1 + dy:1 + dy + h, 1 + dx:1 + dx + w]
+    dt, dm, db = c(-1, 1) - c(-1, -1), c(0, 1) - c(0, -1), c(1, 1) - c(1, -1)
+    vx = k0 * dm + k1 * (dt + db)
+    st = k0 * c(-1, 0) + k1 * (c(-1, -1) + c(-1, 1))
+    sb = k0 * c(1, 0) + k1 * (c(1, -1) + c(1, 1))
+    vy = sb - st
+    assert vx.dtype == f32 and vy.dtype == f32
+    out = []
+    hb = block // 2
+    for cov in (vx * vx, vx * vy, vy * vy):
+        p = np.pad(cov, hb, mode="reflect")
+        rows = p[hb:hb + h, 0:w].copy()
+        for i in range(1, block):
+            rows = rows + p[hb:hb + h, i:i + w]
+        p2 = np.pad(rows, ((hb, hb), (0, 0)), mode="reflect")
+        s = p2[0:h].copy()
+        for j in range(1, block):
+            s = s + p2[j:j + h]
+        out.append(s)
+    a, b, cc = out[0] * f32(0.5), out[1], out[2] * f32(0.5)
+    amc = a - cc
+    return (a + cc) - np.sqrt(amc * amc + b * b)
+
+
+@pytest.mark.parametrize("shape", [(480, 752), (97, 130), (33, 65), (64, 64)])
+def test_response_matches_independent_numpy_evaluation_bit_for_bit(shape):
+    rng = np.random.default_rng(shape[0])
+    img = rng.integers(0, 256, shape, dtype=np.uint8)
+    r = orc.corner_min_eigen_val(img)
+    assert r.dtype == np.float32 and np.array_equal(r, numpy_min_eigen_val(img))
+    smooth = synth.stereo_sequence(7, shape[1], shape[0], 1)[0][0]
+    assert np.array_equal(orc.corner_min_eigen_val(smooth), numpy_min_eigen_val(smooth))
+
+
+def test_response_known_answers():
+    flat = np.full((64, 96), 77, np.uint8)
+    assert np.all(orc.corner_min_eigen_val(flat) == 0.0)                       # no gradient anywhere
+    edge = np.zeros((64, 96), np.uint8); edge[:, 48:] = 200
+    r = orc.corner_min_eigen_val(edge)
+    assert np.abs(r).max() < 1e-9                                              # rank-1 structure: min eigenvalue 0
+    sq = np.zeros((64, 96), np.uint8); sq[20:40, 30:60] = 255
+    r = orc.corner_min_eigen_val(sq)
+    ys, xs = np.nonzero(r > 0.5 * r.max())
+    corners = {(20, 30), (20, 59), (39, 30), (39, 59)}
+    assert all(min(abs(y - cy) + abs(x - cx) for cy, cx in corners) <= 2 for y, x in zip(ys, xs))
+    # Sobel scale: a unit ramp of slope 1 gray level / px gives Dx = 8 * scale -> response 0 (rank 1),
+    # and cov0 summed over the 3x3 box = 9 * (8 / (4*3*255))^2
+    ramp = np.tile(np.arange(96, dtype=np.uint8), (64, 1))
+    rr = orc.corner_min_eigen_val(ramp)
+    assert np.abs(rr[5:-5, 5:-5]).max() < 1e-9
+
+
+def test_block_scan_semantics():
+    assert [orc.gftt_block_size(d) for d in (50, 32, 31.9, 16, 15, 3)] == [32, 32, 16, 16, 8, 8]
+    resp = np.zeros((70, 100), np.float32)
+    resp[3, 5] = 0.01; resp[3, 6] = 0.01                                       # tie: first in raster order wins
+    resp[40, 40] = 0.02; resp[35, 39] = 0.02                                   # tie across rows
+    resp[10, 40] = 1e-3 / 16                                                   # 16 * r == minResponse is NOT a corner (strict >)
+    resp[69, 99] = 1.0                                                         # ragged edge: floor(70/32) x floor(100/32) blocks only
+    kp = orc.gftt_collect_max(resp, 32, 1e-3)
+    assert kp.shape == (2 * 3, 3)
+    assert tuple(kp[0]) == (5.0, 3.0, np.float32(0.16))
+    assert tuple(kp[1]) == (0.0, 0.0, np.float32(-1e10))                       # "no corner" still emits a key point
+    assert tuple(kp[4]) == (39.0, 35.0, np.float32(0.32))
+    assert np.all(kp[[2, 3, 5], 2] == np.float32(-1e10))
+
+
+def test_apply_min_distance_is_the_reference_greedy_filter():
+    c = np.array([[10, 10], [12, 10], [100, 100], [100, 139.9], [100, 140], [300, 300]], np.float32)
+    prev = np.array([[301, 300]], np.float32)
+    out = orc.apply_min_distance(c, prev, 40, 200)
+    assert out.tolist() == [[10, 10], [100, 100], [100, 140]]                  # < r^2 is strict: exactly 40 px apart survives
+    assert orc.apply_min_distance(c, prev, 40, 2).tolist() == [[10, 10], [100, 100]]      # maxTracks stops the scan
+    assert orc.apply_min_distance(c, np.zeros((0, 2)), 0, 200).tolist() == c.tolist()     # r == 0: nothing is near
+
+
+def test_detect_reproduces_the_zero_point_prefix_and_ordering():
+    img = synth.stereo_sequence(11, 752, 480, 1)[0][0]
+    bs = orc.gftt_block_size(50)
+    kp = orc.gftt_collect_max(orc.corner_min_eigen_val(img), bs)
+    nk = len(kp)
+    assert nk == (752 // 32) * (480 // 32) == 345
+    raw = orc.gftt_detect(img, mask_radius=0)
+    assert len(raw) == 2 * nk and np.all(raw[:nk] == 0)                        # corners.resize(n) then push_back
+    order = np.argsort(-kp[:, 2], kind="stable")
+    assert np.array_equal(raw[nk:], kp[order, :2])
+    prev = raw[nk:nk + 5]
+    out = orc.gftt_detect(img, prev=prev, mask_radius=50, max_tracks=200)
+    assert np.array_equal(out, orc.apply_min_distance(raw, prev, 50, 200))
+    assert out[0].tolist() == [0.0, 0.0] and len(out) <= 200                   # the bogus origin corner survives the mask
+    d = np.linalg.norm(out[:, None] - out[None], axis=2) + 1e9 * np.eye(len(out))
+    assert d.min() >= 50 and np.linalg.norm(out[:, None] - prev[None], axis=2).min() >= 50
