@@ -22,6 +22,18 @@ namespace tracker {
 ImagePyramid::~ImagePyramid() = default;
 ImagePyramid::Factory::~Factory() = default;
 OpticalFlow::~OpticalFlow() = default;
+FeatureDetector::~FeatureDetector() = default;
+
+void FeatureDetector::applyMinDistance(std::vector<Feature::Point> &corners, const std::vector<Feature::Point> &prevCorners,
+                                       int minDistance) const
+{
+    static_assert(sizeof(Feature::Point) == 2 * sizeof(float), "Point must be two packed floats");
+    int n = (int)corners.size();
+    hv_apply_min_distance(reinterpret_cast<float *>(corners.data()), &n,
+                          reinterpret_cast<const float *>(prevCorners.data()), (int)prevCorners.size(),
+                          minDistance, parameters.maxTracks);
+    corners.resize((size_t)n);
+}
 
 namespace {
 
@@ -98,7 +110,33 @@ public:
     }
 };
 
+// Counterpart of FeatureDetectorImplementation (src/tracker/feature_detector.cpp:566-652) on its
+// CPU-fallback path: corner response + block arg-max on the device, the reference's sort /
+// zero-prefix / applyMinDistance tail inside hv_gftt_detect.
+class HipFeatureDetector : public FeatureDetector {
+    Session &session;
+public:
+    HipFeatureDetector(Session &s, const hv_gftt_params &p) : FeatureDetector(p), session(s) {}
+    void detect(ImagePyramid &imagePyramid, std::vector<Feature::Point> &corners,
+                const std::vector<Feature::Point> &prevCorners, int maskRadius) final {
+        const int nk = hv_gftt_keypoint_count(session.ctx(), &parameters);
+        assert(nk >= 0);
+        corners.assign((size_t)(2 * nk), Feature::Point{0.f, 0.f});
+        int n = 0;
+        const int rc = hv_gftt_detect(session.ctx(), &parameters, imagePyramid.deviceSlot(),
+                                      reinterpret_cast<const float *>(prevCorners.data()), (int)prevCorners.size(),
+                                      maskRadius, reinterpret_cast<float *>(corners.data()), 2 * nk, &n);
+        assert(rc == HV_OK); (void)rc;
+        corners.resize((size_t)n);
+    }
+};
+
 }  // namespace
+
+std::unique_ptr<FeatureDetector> FeatureDetector::buildHip(Session &s, const hv_gftt_params &p)
+{
+    return std::unique_ptr<FeatureDetector>(new HipFeatureDetector(s, p));
+}
 
 std::unique_ptr<ImagePyramid::Factory> ImagePyramid::Factory::buildHip(Session &s)
 {

@@ -106,6 +106,32 @@ struct OpticalFlow {         // src/tracker/optical_flow.hpp:20-40
         int overrideMaxIterations = -1) = 0;
 };
 
+// tracker::FeatureDetector (src/tracker/feature_detector.hpp:20-78), SURVEY.md 8(f) row f1. The reference
+// passes the tracker::Image whose pixels it detects on; the HIP detector reads the level-0 image of
+// that frame's device-resident pyramid, so the adapter takes the ImagePyramid the Image already owns
+// (image.cpp:209-214 ensureImagePyramid) -- see INTEGRATION.md for the two-line glue in
+// ImageImplementation::findKeypoints (image.cpp:69-85).
+class FeatureDetector {
+public:
+    static std::unique_ptr<FeatureDetector> buildHip(Session &session, const hv_gftt_params &parameters);   // sibling of build()
+    virtual ~FeatureDetector();
+    virtual void detect(
+        ImagePyramid &imagePyramid,
+        std::vector<Feature::Point> &corners,
+        const std::vector<Feature::Point> &prevCorners,
+        int maskRadius) = 0;
+    virtual bool supportsAsync() const { return false; }
+    // feature_detector_legacy.cpp:177-213 (pure host code, same for every detector)
+    void applyMinDistance(
+        std::vector<Feature::Point> &corners,
+        const std::vector<Feature::Point> &prevCorners,
+        int minDistance) const;
+
+protected:
+    explicit FeatureDetector(const hv_gftt_params &parameters) : parameters(parameters) {}
+    const hv_gftt_params parameters;
+};
+
 }  // namespace tracker
 
 namespace odometry {

@@ -189,6 +189,23 @@ static void test_tracker(Session &s, const std::string &dir)
     const auto g1 = cur->getGrayLevel(1, lw, lh);
     REQUIRE(lw == (w + 1) / 2 && lh == (h + 1) / 2 && g1.size() == (size_t)lw * lh);
     std::ofstream(dir + "/gray1.raw", std::ios::binary).write(reinterpret_cast<const char *>(g1.data()), (std::streamsize)g1.size());
+    // Image::findKeypoints (image.cpp:69-85) -> FeatureDetector::detect on the frame's own pyramid, first
+    // without a mask (tracker.cpp:749-764 initialize), then masked by the tracked corners (tracker.cpp:683-700)
+    hv_gftt_params gp; hv_gftt_default_params(&gp);
+    gp.gfttMinDistance = 20; gp.maxTracks = 60;
+    auto detector = tracker::FeatureDetector::buildHip(s, gp);
+    std::vector<tracker::Feature::Point> found, masked;
+    detector->detect(*prev, found, {}, 0);
+    REQUIRE(!found.empty() && found[0].x == 0.f && found[0].y == 0.f);          // feature_detector.cpp:629-631 quirk
+    detector->detect(*cur, masked, prevCorners, 20);
+    REQUIRE(masked.size() <= 60);
+    std::vector<tracker::Feature::Point> again2 = found;
+    detector->applyMinDistance(again2, prevCorners, 20);                          // detect(...,{},0) + applyMinDistance
+    std::ofstream d0(dir + "/detect_raw.txt"), d1(dir + "/detect_masked.txt"), d2(dir + "/detect_raw_then_mask.txt");
+    d0.precision(9); d1.precision(9); d2.precision(9);
+    for (const auto &c : found) d0 << c.x << " " << c.y << "\n";
+    for (const auto &c : masked) d1 << c.x << " " << c.y << "\n";
+    for (const auto &c : again2) d2 << c.x << " " << c.y << "\n";
     // pool recycling: releasing the last reference returns the slot (util::Allocator semantics)
     const int slot = prev->deviceSlot();
     prev.reset();

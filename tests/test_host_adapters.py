@@ -24,7 +24,7 @@ def test_host_library_and_test_program_build():
     assert os.path.exists(lib) and os.access(exe, os.X_OK)
     syms = subprocess.check_output(["nm", "-D", "--defined-only", "-C", lib], text=True)
     for name in ("hybvio::tracker::ImagePyramid::Factory::buildHip", "hybvio::tracker::OpticalFlow::buildHip",
-                 "hybvio::odometry::EKF::buildHip"):
+                 "hybvio::odometry::EKF::buildHip", "hybvio::tracker::FeatureDetector::buildHip"):
         assert name in syms, name
     needed = subprocess.check_output(["readelf", "-d", lib], text=True)
     assert "libhybvio_hip.so" in needed and "amdhip64" not in needed      # only the C ABI is linked
@@ -56,6 +56,8 @@ def test_reference_tests_through_the_cpp_adapters(oracle):
         out = np.loadtxt(os.path.join(d, "flow_out.txt"))
         out2 = np.loadtxt(os.path.join(d, "flow_out_init2.txt"))
         g1 = np.fromfile(os.path.join(d, "gray1.raw"), np.uint8).reshape((h + 1) // 2, (w + 1) // 2)
+        det = [np.loadtxt(os.path.join(d, f), ndmin=2).astype(np.float32)
+               for f in ("detect_raw.txt", "detect_masked.txt", "detect_raw_then_mask.txt")]
     p0, p1 = oracle.Pyramid(img0), oracle.Pyramid(img1)
     o_xy, o_st = oracle.optical_flow_compute(p0, p1, pts)
     np.testing.assert_array_equal(out[:, 2].astype(int), o_st)
@@ -64,3 +66,8 @@ def test_reference_tests_through_the_cpp_adapters(oracle):
     np.testing.assert_array_equal(out2[:, 2].astype(int), o_st2)
     assert np.abs(out2[:, :2] - o_xy2).max() <= 1e-3
     np.testing.assert_array_equal(g1, p1.gray(1))
+    # FeatureDetector::buildHip: detect / applyMinDistance vs the oracle's restatement of the reference flow
+    pts32 = pts.astype(np.float32)
+    np.testing.assert_array_equal(det[0], oracle.gftt_detect(img0, mask_radius=0, min_distance=20))
+    np.testing.assert_array_equal(det[1], oracle.gftt_detect(img1, prev=pts32, mask_radius=20, min_distance=20, max_tracks=60))
+    np.testing.assert_array_equal(det[2], oracle.apply_min_distance(det[0], pts32, 20, 60))
