@@ -270,15 +270,27 @@ def cpu_baseline(budget_s=12.0):
             if el > budget:
                 return frames, el
 
-    cores = orc.set_threads(0)
-    f_all, t_all = run(0.5 * budget_s)
     orc.set_threads(1)
-    f_one, t_one = run(0.5 * budget_s)
-    orc.set_threads(0)
-    return dict(value=f_all / t_all, unit="frames/s", cores=cores, kind="port",
-                single_thread_value=f_one / t_one,
-                sample=f"{f_all} stereo frames 752x480 x 200 pts in {t_all:.1f} s on {cores} threads (OpenMP over rows / points) "
-                       f"+ {f_one} frames in {t_one:.1f} s on 1 thread; oracle/pyrlk_oracle.c -O2")
+    f_one, t_one = run(0.4 * budget_s)
+    # OpenMP on "all cores" is not automatically the fastest here (the GPU box reports 256 hardware
+    # threads; 256 spinning threads on 480-row loops ran 250x SLOWER than one): probe a few team sizes
+    # briefly and time the best one -- the baseline is the best CPU configuration found, `cores` says which.
+    ncpu = os.cpu_count() or 1
+    best_n, best_rate = 1, f_one / t_one
+    for n in (4, 8, 16, 32, 64):
+        if n > ncpu:
+            break
+        orc.set_threads(n)
+        f, t = run(0.08 * budget_s)
+        if f / t > best_rate:
+            best_n, best_rate = n, f / t
+    orc.set_threads(best_n)
+    f_all, t_all = run(0.25 * budget_s)
+    orc.set_threads(1)
+    return dict(value=max(f_all / t_all, f_one / t_one), unit="frames/s", cores=best_n if f_all / t_all >= f_one / t_one else 1,
+                kind="port", single_thread_value=f_one / t_one, host_cpus=ncpu,
+                sample=f"{f_all} stereo frames 752x480 x 200 pts in {t_all:.1f} s on {best_n} threads (OpenMP over rows / points, best of "
+                       f"the team sizes probed) + {f_one} frames in {t_one:.1f} s on 1 thread; oracle/pyrlk_oracle.c -O2")
 
 
 def profiled_traffic():
@@ -358,6 +370,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-latency-mode", action="store_true")
     ap.add_argument("--no-ekf", action="store_true", help="skip the C3 (tracker + HIP EKF) leg")
+    ap.add_argument("--no-gftt", action="store_true", help="skip the f1 (GFTT detector kernel) measurement")
     args = ap.parse_args()
 
     import torch
@@ -426,6 +439,40 @@ def main():
                                   "algorithmic_bytes_per_stereo_frame": ab["stereo_frame"]},
             "tracked_fraction": tracked,
         }
+    # ---- f1: GFTT detector on the left images of the current frame, device half ----
+    if not args.no_gftt and rank == 0:
+        import torch
+        nk = tb.ctx.gftt_keypoint_count()
+        kp = torch.zeros((B, nk, 3), dtype=torch.float32, device=f"cuda:{local_rank}")
+        left_slots = tb.L[(tb.k - 1) % 2]
+        for _ in range(3):
+            tb.ctx.gftt_keypoints_batch_dev(B, left_slots.data_ptr(), kp.data_ptr())
+        tb.ctx.profile_enable(True)
+        tb.ctx.profile_reset()
+        for _ in range(20):
+            tb.ctx.gftt_keypoints_batch_dev(B, left_slots.data_ptr(), kp.data_ptr())
+        ms, n = tb.ctx.profile_read(capi.K_GFTT)
+        tb.ctx.profile_enable(False)
+        gbytes = B * (W * H + 12 * nk)                       # the image read once + one key point per block
+        found = float((kp[:, :, 2] > 0).float().mean().item())
+        out["f1_gftt"] = {
+            "workload": f"GFTT corner response + {32}x{32} block arg-max on {B} images {W}x{H} (device half of FeatureDetector::detect)",
+            "avg_ms": ms / n, "launches": n, "images_per_s": B / (ms / n * 1e-3),
+            "algorithmic_bytes_per_launch": gbytes, "achieved_GBs": gbytes / (ms / n * 1e-3) / 1e9,
+            "frac_of_8TBs": gbytes / (ms / n * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            "blocks_with_a_corner": found,
+            "note": "one workgroup per block: ~90 binary32 ops per pixel on 1 byte of HBM traffic, i.e. VALU/LDS bound by construction "
+                    "(the reference materialises 6 float images = 24 B per pixel instead)"}
+        if not args.no_cpu_baseline:
+            from oracle import orc
+            img = tb.frames[0, 0, 0].cpu().numpy()
+            cores = orc.set_threads(min(8, os.cpu_count() or 1))
+            t0, reps = time.perf_counter(), 0
+            while time.perf_counter() - t0 < 2.0:
+                orc.gftt_collect_max(orc.corner_min_eigen_val(img), 32, 1e-3); reps += 1
+            out["f1_gftt"]["cpu_baseline"] = {"value": reps / (time.perf_counter() - t0), "unit": "images/s", "cores": cores,
+                                              "kind": "port", "sample": f"{reps} images, oracle/gftt_oracle.c -O2, OpenMP over rows"}
+            orc.set_threads(1)
     # ---- C3: the same tracker work + the HIP EKF (configs[2]) ----
     if not args.no_ekf:
         eb = EkfBench(tb.ctx, B, local_rank, seed=rank)

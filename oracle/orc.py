@@ -45,6 +45,7 @@ def lib():
         L.orc_optical_flow_compute.argtypes = [C.c_void_p, C.c_void_p, C.c_int, f32p, f32p, i32p, C.c_int,
                                                C.c_int, C.c_int, C.c_int, C.c_double, C.c_double]
         L.orc_set_threads.argtypes = [C.c_int]
+        L.orc_set_threads(min(8, os.cpu_count() or 1))     # a 256-thread team on 480-row loops is far slower than 1 thread
         L.orc_corner_min_eigen_val.argtypes = [u8p, C.c_int, C.c_int, C.c_int, C.c_int, f32p]
         L.orc_gftt_block_size.argtypes = [C.c_double]
         L.orc_gftt_collect_max.argtypes = [f32p, C.c_int, C.c_int, C.c_int, C.c_float, f32p]
