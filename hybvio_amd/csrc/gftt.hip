@@ -9,7 +9,7 @@
 // Design for CDNA4: the reference materialises five full-size float images (Dx, Dy, three products)
 // plus the response before it scans for block maxima. Here one workgroup owns one bs x bs block of
 // one image: it stages the (bs+4)^2 gray neighbourhood in LDS (BORDER_REFLECT_101), forms the
-// derivative products and their 3x3 box sums there, reduces 16*response to the block's arg-max
+// derivative products and their 3x3 box sums in two register-tiled passes, reduces 16*response to the block's arg-max
 // (first maximum in raster order, as the reference's scan) and writes ONE 12-byte key point. The
 // level-0 image already sits in HBM for the pyramid: the detector's HBM traffic is that image read
 // once (+27 % halo); the response map never exists. Sorting the <= (w/bs)(h/bs) key points and the
@@ -36,13 +36,23 @@ struct GfttArgs {
 // total order of the reference's raster scan with strict '>': higher response wins, ties -> lower index
 __device__ __forceinline__ bool better(float ra, int ia, float rb, int ib) { return ra > rb || (ra == rb && ia < ib); }
 
+typedef float float4v __attribute__((ext_vector_type(4)));
+
+// Two register-tiled passes over LDS instead of one LDS round trip per stencil stage:
+//   pass 1  task (tile row ty in [-1, BS], strip of 4 columns): 3 rows x 8 gray values -> the products of
+//           6 columns -> the 3 row sums of 4 columns (12 floats, three 16-byte LDS stores)
+//   pass 2  task (row y, strip of 4 columns): 3 rows x 3 channels of row sums (nine 16-byte LDS loads) ->
+//           4 responses -> running arg-max
+// ~45 VALU + 5 LDS instructions per pixel. Positions outside the image take the products of their
+// BORDER_REFLECT_101 mirror (that is what box-filtering the product images does): rows by evaluating
+// the task at the mirrored centre row, columns by copying the mirrored column inside the strip.
 template <int BS>
 __global__ __launch_bounds__(256) void gftt_block_kernel(GfttArgs a)
 {
-    constexpr int GW = BS + 4, CW = BS + 2;          // gray tile / product tile edge
-    __shared__ float gray[GW * GW];
-    __shared__ float cov[3][CW * CW];                // products at tile positions -1 .. BS
-    __shared__ float rsum[3][CW * BS];               // row sums at columns 0 .. BS-1, rows -1 .. BS
+    constexpr int GW = BS + 4;                       // gray tile edge: tile column c <-> image x0 - 2 + c
+    constexpr int NS = BS / 4;                       // 4-column strips per row
+    __shared__ __attribute__((aligned(16))) float gray[GW * GW];
+    __shared__ __attribute__((aligned(16))) float rsum[3][(BS + 2) * BS];      // row sums, tile rows -1 .. BS
     __shared__ float red_r[4];
     __shared__ int red_i[4];
 
@@ -55,47 +65,88 @@ __global__ __launch_bounds__(256) void gftt_block_kernel(GfttArgs a)
     const uint8_t *src = a.l0_ptr[slot];
     const int stride = a.l0_stride[slot];
 
-    for (int i = t; i < GW * GW; i += 256) {
-        const int ty = i / GW, tx = i - ty * GW;
-        gray[i] = (float)src[(size_t)reflect101(y0 - 2 + ty, h) * stride + reflect101(x0 - 2 + tx, w)];
-    }
-    __syncthreads();
-
-    // derivative products at tile positions (px, py) in [-1, BS]; positions outside the image take the
-    // value of their BORDER_REFLECT_101 mirror, which is what filtering the product images does
-    const float k0 = a.k0, k1 = a.k1;
-    for (int i = t; i < CW * CW; i += 256) {
-        const int py = i / CW - 1, px = i - (py + 1) * CW - 1;
-        const int gx = reflect101(x0 + px, w) - x0 + 2, gy = reflect101(y0 + py, h) - y0 + 2;     // gray tile index of the centre
-        const float *g = gray + gy * GW + gx;
-        const float dt = g[-GW + 1] - g[-GW - 1], dm = g[1] - g[-1], db = g[GW + 1] - g[GW - 1];
-        const float vx = k0 * dm + k1 * (dt + db);
-        const float st = k0 * g[-GW] + k1 * (g[-GW - 1] + g[-GW + 1]);
-        const float sb = k0 * g[GW] + k1 * (g[GW - 1] + g[GW + 1]);
-        const float vy = sb - st;
-        cov[0][i] = vx * vx; cov[1][i] = vx * vy; cov[2][i] = vy * vy;
-    }
-    __syncthreads();
-    for (int i = t; i < CW * BS; i += 256) {
-        const int ry = i / BS, x = i - ry * BS;                  // row ry - 1, column x
-        const float *c = &cov[0][ry * CW + x];                   // tile position (x - 1, ry - 1)
+    // ---- stage the gray tile as floats: dword loads where the 4 bytes are inside the image ----
+    {
+        const bool aligned = ((reinterpret_cast<uintptr_t>(src) | (uintptr_t)stride) & 3u) == 0;
+        constexpr int DW = (GW + 4 + 3) / 4;          // dwords per row covering image columns x0 - 4 .. x0 + BS + 3
+        for (int i = t; i < GW * DW; i += 256) {
+            const int ty = i / DW, d = i - ty * DW;
+            const uint8_t *row = src + (size_t)reflect101(y0 - 2 + ty, h) * stride;
+            const int x = x0 - 4 + 4 * d;             // image column of byte 0 of this dword
+            uint32_t v;
+            if (aligned && x >= 0 && x + 4 <= w) v = *reinterpret_cast<const uint32_t *>(row + x);
+            else v = (uint32_t)row[reflect101(x, w)] | ((uint32_t)row[reflect101(x + 1, w)] << 8) |
+                     ((uint32_t)row[reflect101(x + 2, w)] << 16) | ((uint32_t)row[reflect101(x + 3, w)] << 24);
 #pragma unroll
-        for (int ch = 0; ch < 3; ch++) rsum[ch][i] = (c[ch * CW * CW] + c[ch * CW * CW + 1]) + c[ch * CW * CW + 2];
+            for (int k = 0; k < 4; k++) {
+                const int c = 4 * d + k - 2;          // tile column
+                if (c >= 0 && c < GW) gray[ty * GW + c] = (float)((v >> (8 * k)) & 0xFFu);
+            }
+        }
     }
     __syncthreads();
 
+    // ---- pass 1: row sums of the derivative products ----
+    const float k0 = a.k0, k1 = a.k1;
+    for (int task = t; task < (BS + 2) * NS; task += 256) {
+        const int ry = task / NS, sx = task - ry * NS;                 // tile row ry - 1, columns 4 sx .. 4 sx + 3
+        const int cy = reflect101(y0 + ry - 1, h) - y0 + 2;           // gray tile row of the (mirrored) centre row
+        // gray tile columns 4 sx .. 4 sx + 7  <->  block columns 4 sx - 2 .. 4 sx + 5
+        float g[3][8];
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+            const float4v lo = *reinterpret_cast<const float4v *>(&gray[(cy - 1 + j) * GW + 4 * sx]);
+            const float4v hi = *reinterpret_cast<const float4v *>(&gray[(cy - 1 + j) * GW + 4 * sx + 4]);
+#pragma unroll
+            for (int k = 0; k < 4; k++) { g[j][k] = lo[k]; g[j][4 + k] = hi[k]; }
+        }
+        float c0[6], c1[6], c2[6];                                      // products at block columns 4 sx - 1 .. 4 sx + 4
+#pragma unroll
+        for (int k = 0; k < 6; k++) {
+            const float dt = g[0][k + 2] - g[0][k], dm = g[1][k + 2] - g[1][k], db = g[2][k + 2] - g[2][k];
+            const float vx = k0 * dm + k1 * (dt + db);
+            const float st = k0 * g[0][k + 1] + k1 * (g[0][k] + g[0][k + 2]);
+            const float sb = k0 * g[2][k + 1] + k1 * (g[2][k] + g[2][k + 2]);
+            const float vy = sb - st;
+            c0[k] = vx * vx; c1[k] = vx * vy; c2[k] = vy * vy;
+        }
+        // columns outside the image: block column -1 mirrors +1 (first strip of a block at x = 0), column BS
+        // mirrors BS - 2 (last strip of a block that ends at the image edge)
+        if (sx == 0 && x0 == 0) { c0[0] = c0[2]; c1[0] = c1[2]; c2[0] = c2[2]; }
+        if (sx == NS - 1 && x0 + BS == w) { c0[5] = c0[3]; c1[5] = c1[3]; c2[5] = c2[3]; }
+        float4v r0, r1, r2;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            r0[k] = (c0[k] + c0[k + 1]) + c0[k + 2];
+            r1[k] = (c1[k] + c1[k + 1]) + c1[k + 2];
+            r2[k] = (c2[k] + c2[k + 1]) + c2[k + 2];
+        }
+        *reinterpret_cast<float4v *>(&rsum[0][ry * BS + 4 * sx]) = r0;
+        *reinterpret_cast<float4v *>(&rsum[1][ry * BS + 4 * sx]) = r1;
+        *reinterpret_cast<float4v *>(&rsum[2][ry * BS + 4 * sx]) = r2;
+    }
+    __syncthreads();
+
+    // ---- pass 2: column sums, min eigenvalue, arg-max in raster order ----
     float best_r = -1e10f;
     int best_i = 0;
-    for (int p = t; p < BS * BS; p += 256) {                     // increasing raster order per thread
-        const int y = p / BS, x = p - y * BS;
-        const float *r = &rsum[0][y * BS + x];                   // rows y-1, y, y+1 are rsum rows y, y+1, y+2
-        const float s0 = (r[0] + r[BS]) + r[2 * BS];
-        const float s1 = (r[CW * BS] + r[CW * BS + BS]) + r[CW * BS + 2 * BS];
-        const float s2 = (r[2 * CW * BS] + r[2 * CW * BS + BS]) + r[2 * CW * BS + 2 * BS];
-        const float aa = s0 * 0.5f, bb = s1, cc = s2 * 0.5f, amc = aa - cc;
-        const float resp = (aa + cc) - sqrtf(amc * amc + bb * bb);
-        const float r16 = resp * 16.0f;                          // CpuCornerResponse::GAIN
-        if (r16 > best_r && r16 > a.min_response) { best_r = r16; best_i = p; }
+    for (int task = t; task < BS * NS; task += 256) {
+        const int y = task / NS, sx = task - y * NS;
+        float4v s[3];
+#pragma unroll
+        for (int ch = 0; ch < 3; ch++) {
+            const float4v up = *reinterpret_cast<const float4v *>(&rsum[ch][y * BS + 4 * sx]);          // tile row y - 1
+            const float4v mid = *reinterpret_cast<const float4v *>(&rsum[ch][(y + 1) * BS + 4 * sx]);
+            const float4v dn = *reinterpret_cast<const float4v *>(&rsum[ch][(y + 2) * BS + 4 * sx]);
+            s[ch] = (up + mid) + dn;
+        }
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const float aa = s[0][k] * 0.5f, bb = s[1][k], cc = s[2][k] * 0.5f, amc = aa - cc;
+            const float resp = (aa + cc) - sqrtf(amc * amc + bb * bb);
+            const float r16 = resp * 16.0f;                          // CpuCornerResponse::GAIN
+            if (r16 > best_r && r16 > a.min_response) { best_r = r16; best_i = y * BS + 4 * sx + k; }
+        }
     }
     // threads without a candidate keep (-1e10, 0): index 0 / response -1e10 is also the reference's "no corner"
     for (int o = 32; o > 0; o >>= 1) {
