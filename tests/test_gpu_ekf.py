@@ -294,8 +294,9 @@ def test_reference_transform_to_round_trip_on_gpu(oracle, ctx):
     assert np.linalg.norm(m2 - fx["m55"]) < 1e-3 and np.linalg.norm(P2 - fx["P55"]) < 1e-3
 
 
-def test_closed_loop_replay(oracle, ctx):
-    """60 frames of the per-frame EKF call sequence: 10 predicts, up to 8 gated
+@pytest.mark.parametrize("frames", [60, 400])
+def test_closed_loop_replay(oracle, ctx, frames):
+    """60 / 400 frames of the per-frame EKF call sequence: 10 predicts, up to 8 gated
     visual updates, symmetrise, augmentation with the Hanoi discard pattern; same inputs to both.
     Visual updates start once every trail slot has been cloned from a real pose (as in the reference,
     where a track needs >= 4 frames): before that P mixes 1e8 prior variances with 1e-6 ones and the
@@ -308,7 +309,7 @@ def test_closed_loop_replay(oracle, ctx):
     g.set_state(0, o.m.copy(), o.P.copy())
     o.set_first_sample_time(0.0)
     t, applied, rejected = 0.0, 0, 0
-    for frame in range(60):
+    for frame in range(frames):
         for _ in range(10):
             t += 0.005
             gy, ac = rng.normal(0, 0.05, 3), acc0 + rng.normal(0, 0.05, 3)
@@ -335,4 +336,5 @@ def test_closed_loop_replay(oracle, ctx):
         g.augment([k])
     assert applied > 10 and rejected > 10
     m, P = g.get_state(0)
+    print(f"closed loop {frames} frames: {applied} updates, {rejected} rejected, rel err m {rel(m, o.m):.2e} P {rel(P, o.P):.2e}")
     assert rel(m, o.m) <= TOL and rel(P, o.P) <= TOL, (rel(m, o.m), rel(P, o.P))
