@@ -96,6 +96,7 @@ PROTOTYPES = {
     "hv_ekf_device_pointers": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]),
     "hv_ekf_predict": (C.c_int, [C.c_void_p, f64p, f64p, f64p]),
     "hv_ekf_predict_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "hv_ekf_predict_n_dev": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "hv_ekf_update": (C.c_int, [C.c_void_p, C.c_int, C.c_int, f64p, f64p, f64p, u8p, C.c_int]),
     "hv_ekf_visual_gate": (C.c_int, [C.c_void_p, C.c_int, C.c_int, f64p, f64p, C.c_double, f64p, i32p]),
     "hv_ekf_visual_update": (C.c_int, [C.c_void_p, C.c_int, C.c_int, f64p, f64p, C.c_double, u8p]),
@@ -379,6 +380,11 @@ class EkfBatch:
         dt, gyro, acc = _f(np.broadcast_to(dt, (self.batch,))), _f(np.broadcast_to(gyro, (self.batch, 3))), _f(np.broadcast_to(acc, (self.batch, 3)))
         self._chk(lib().hv_ekf_predict(self._h, _p(dt, f64p), _p(gyro, f64p), _p(acc, f64p)), "hv_ekf_predict")
         self.ctx.synchronize()
+
+    def predict_n_dev(self, n_samples, dt_dev, gyro_dev, acc_dev):
+        """n_samples predicts in one launch; device arrays [n][batch], [n][batch][3], [n][batch][3]."""
+        self._chk(lib().hv_ekf_predict_n_dev(self._h, int(n_samples), C.c_void_p(dt_dev), C.c_void_p(gyro_dev),
+                                             C.c_void_p(acc_dev)), "hv_ekf_predict_n_dev")
 
     def predict_dev(self, dt_dev, gyro_dev, acc_dev):
         self._chk(lib().hv_ekf_predict_dev(self._h, C.c_void_p(dt_dev), C.c_void_p(gyro_dev), C.c_void_p(acc_dev)),

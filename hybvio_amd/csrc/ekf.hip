@@ -119,6 +119,7 @@ struct PredictArgs {
     double *m, *P, *Q, *dydx;            // per filter: n, n*n, 144, 400
     const double *dt, *gyro, *acc;        // device arrays [batch], [batch*3], [batch*3] (or null -> immediates)
     double dt0, g0[3], a0[3];
+    int nsteps;                           // IMU samples per launch; device arrays are [nsteps][batch](x3)
     double noise_scale, gravity, baa, baa_rev, bga, bga_rev;
 };
 
@@ -145,10 +146,15 @@ __device__ void quat2rmat_d(const double q[4], double R[9], double dR[36])   // 
 __global__ __launch_bounds__(256) void ekf_predict_kernel(PredictArgs a)
 {
     __shared__ double F[INER * INER], Lm[INER * QD], Qs[QD * QD], LQ[INER * QD], P00[INER * INER], FP[INER * INER];
+    __shared__ double Phi[INER * INER], PhiN[INER * INER];
     const int b = blockIdx.x, t = threadIdx.x, n = a.n;
     double *m = a.m + (size_t)b * n, *P = a.P + (size_t)b * n * n, *Q = a.Q + (size_t)b * QD * QD;
-    const double dt = a.dt ? a.dt[b] : a.dt0;
-    if (!(dt > 0.0)) return;                       // ekf.cpp:365-368 (the host adapter keeps the clock)
+    // nsteps IMU samples in one launch: the mean / Jacobian chain and the 20 x 20 block recursion
+    // P00 <- F P00 F' + L Q L' run per sample in LDS; the off-diagonal blocks only ever see the product
+    // Phi = F_n ... F_1 (P10 <- P10 Phi', P01 <- Phi P01), so they are touched once at the end.
+    bool any = false;
+    for (int s = 0; s < a.nsteps; s++) { const double d = a.dt ? a.dt[(size_t)s * a.batch + b] : a.dt0; any = any || d > 0.0; }
+    if (!any) return;                              // ekf.cpp:365-368 (the host adapter keeps the clock)
 
     PHASE_STAMP(12);
     // Off-diagonal blocks P10 <- P10 F', P01 <- F P01 (ekf.cpp:506-508) as MFMA items: item I < tiles is
@@ -173,14 +179,21 @@ __global__ __launch_bounds__(256) void ekf_predict_kernel(PredictArgs a)
             for (int sx = 0; sx < 5; sx++) slab[u][sx] = *slab_ptr(it, sx);
         }
     }
+    for (int i = t; i < INER * INER; i += 256) { Phi[i] = (i % (INER + 1) == 0) ? 1.0 : 0.0; P00[i] = P[(size_t)(i / INER) * n + (i % INER)]; }
+    for (int i = t; i < QD * QD; i += 256) Qs[i] = Q[i];
+
+    for (int step = 0; step < a.nsteps; step++) {
+    const size_t sb = (size_t)step * a.batch + b;
+    const double dt = a.dt ? a.dt[sb] : a.dt0;
+    if (!(dt > 0.0)) continue;                     // uniform per workgroup
+    __syncthreads();
     for (int i = t; i < INER * INER; i += 256) F[i] = (i % (INER + 1) == 0) ? 1.0 : 0.0;
     for (int i = t; i < INER * QD; i += 256) Lm[i] = 0.0;
-    for (int i = t; i < QD * QD; i += 256) Qs[i] = Q[i];
     __syncthreads();
 
     if (t == 0) {
         double xg[3], xa[3];
-        for (int i = 0; i < 3; i++) { xg[i] = a.gyro ? a.gyro[3 * b + i] : a.g0[i]; xa[i] = a.acc ? a.acc[3 * b + i] : a.a0[i]; }
+        for (int i = 0; i < 3; i++) { xg[i] = a.gyro ? a.gyro[3 * sb + i] : a.g0[i]; xa[i] = a.acc ? a.acc[3 * sb + i] : a.a0[i]; }
         if (a.baa > 0.0) {                          // ekf.cpp:397-404
             double v = a.noise_scale * a.baa * a.baa;
             if (a.baa_rev > 0.0) v *= (1 - exp(-2 * dt * a.baa_rev)) / (2 * a.baa_rev);
@@ -237,20 +250,17 @@ __global__ __launch_bounds__(256) void ekf_predict_kernel(PredictArgs a)
     __syncthreads();
 
     PHASE_STAMP(13);
-    // P00 = F P00 F' + L Q L'; P10 = P10 F'; P01 = F P01 (ekf.cpp:504-508). Every output depends only
-    // on its own row / column of the old P, so the update is done in place.
-    for (int i = t; i < INER * INER; i += 256) { P00[i] = P[(size_t)(i / INER) * n + (i % INER)]; a.dydx[(size_t)b * INER * INER + i] = F[i]; }
-    for (int i = t; i < QD * QD; i += 256) Q[i] = Qs[i];
+    // P00 = F P00 F' + L Q L' (ekf.cpp:504-505) in LDS; Phi <- F Phi
     for (int e = t; e < INER * QD; e += 256) {
         const int i = e % INER, j = e / INER;
         double s = 0; for (int k = 0; k < QD; k++) s += L_(i, k) * Qs[j * QD + k];
         LQ[e] = s;
     }
-    __syncthreads();
     for (int e = t; e < INER * INER; e += 256) {
         const int i = e % INER, j = e / INER;
-        double s = 0; for (int k = 0; k < INER; k++) s += F_(i, k) * P00[j * INER + k];
-        FP[e] = s;
+        double s = 0, ph = 0;
+        for (int k = 0; k < INER; k++) { s += F_(i, k) * P00[j * INER + k]; ph += F_(i, k) * Phi[j * INER + k]; }
+        FP[e] = s; PhiN[e] = ph;
     }
     __syncthreads();
     for (int e = t; e < INER * INER; e += 256) {
@@ -258,11 +268,16 @@ __global__ __launch_bounds__(256) void ekf_predict_kernel(PredictArgs a)
         double s = 0;
         for (int k = 0; k < INER; k++) s += FP[k * INER + i] * F_(j, k);
         for (int k = 0; k < QD; k++) s += LQ[k * INER + i] * L_(j, k);
-        P[(size_t)j * n + i] = s;
+        P00[e] = s;
+        Phi[e] = PhiN[e];
     }
+    }
+    __syncthreads();
+    for (int i = t; i < INER * INER; i += 256) { P[(size_t)(i / INER) * n + (i % INER)] = P00[i]; a.dydx[(size_t)b * INER * INER + i] = F[i]; }
+    for (int i = t; i < QD * QD; i += 256) Q[i] = Qs[i];
     PHASE_STAMP(14);
     {
-        // F operand, shared by every item: lane (kq, cl) holds F(cl + 16 tt, 4 s + kq). It is the A operand
+        // F operand (the product Phi of the steps' F), shared by every item: lane (kq, cl) holds Phi(cl + 16 tt, 4 s + kq). It is the A operand
         // of (P10 F')' = F P10' (rows c of F, columns i of the tile) and the B operand of (F P01)' =
         // P01' F' (rows c of the tile, columns r of F): both products are formed transposed so that the
         // 16 lanes of an output row group store 16 consecutive doubles.
@@ -270,8 +285,8 @@ __global__ __launch_bounds__(256) void ekf_predict_kernel(PredictArgs a)
 #pragma unroll
         for (int sx = 0; sx < 5; sx++) {
             const int k = 4 * sx + kq;                                                        // < 20
-            f0[sx] = F_(cl, k);
-            f1[sx] = F_(min(16 + cl, INER - 1), k);
+            f0[sx] = Phi[k * INER + cl];
+            f1[sx] = Phi[k * INER + min(16 + cl, INER - 1)];
         }
         for (int base = 0; base < 2 * tiles; base += 4 * NIT) {
 #pragma unroll
@@ -1311,12 +1326,12 @@ int hv_ekf_device_pointers(hv_ekf *h, double **m_dev, double **P_dev)
 }
 
 static int predict_common(Ekf *e, const double *dt_dev, const double *gyro_dev, const double *acc_dev,
-                          double dt0, const double *g0, const double *a0)
+                          double dt0, const double *g0, const double *a0, int nsteps = 1)
 {
     Ctx *c = e->c;
     hv::PredictArgs a{};
     a.n = e->n; a.batch = e->batch; a.m = e->m; a.P = e->P; a.Q = e->Q; a.dydx = e->dydx;
-    a.dt = dt_dev; a.gyro = gyro_dev; a.acc = acc_dev; a.dt0 = dt0;
+    a.dt = dt_dev; a.gyro = gyro_dev; a.acc = acc_dev; a.dt0 = dt0; a.nsteps = nsteps;
     for (int i = 0; i < 3; i++) { a.g0[i] = g0 ? g0[i] : 0.0; a.a0[i] = a0 ? a0[i] : 0.0; }
     a.noise_scale = e->noise_scale; a.gravity = e->par.gravity;
     a.baa = e->par.noiseProcessBAA; a.baa_rev = e->par.noiseProcessBAARev;
@@ -1343,6 +1358,12 @@ int hv_ekf_predict_dev(hv_ekf *h, const double *dt_dev, const double *gyro_dev, 
 {
     if (!h || !dt_dev || !gyro_dev || !acc_dev) return HV_ERR_INVALID;
     return predict_common(&h->e, dt_dev, gyro_dev, acc_dev, 0.0, nullptr, nullptr);
+}
+
+int hv_ekf_predict_n_dev(hv_ekf *h, int n_samples, const double *dt_dev, const double *gyro_dev, const double *acc_dev)
+{
+    if (!h || n_samples < 1 || !dt_dev || !gyro_dev || !acc_dev) return HV_ERR_INVALID;
+    return predict_common(&h->e, dt_dev, gyro_dev, acc_dev, 0.0, nullptr, nullptr, n_samples);
 }
 
 static int stage_update_inputs(Ekf *e, int nr, int l, const double *H, const double *v, const double *rdiag,

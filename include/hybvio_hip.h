@@ -156,6 +156,12 @@ int hv_ekf_device_pointers(hv_ekf *ekf, double **m_dev, double **P_dev);
  * skips filter f. gyro/acc: [batch][3]. */
 int hv_ekf_predict(hv_ekf *ekf, const double *dt, const double *gyro, const double *acc);
 int hv_ekf_predict_dev(hv_ekf *ekf, const double *dt_dev, const double *gyro_dev, const double *acc_dev);
+/* n_samples consecutive predicts (the IMU samples between two camera frames) in ONE launch: arrays are
+ * [n_samples][batch] (dt) and [n_samples][batch][3]. The mean / Jacobian chain and the 20 x 20 block
+ * run per sample on chip; the off-diagonal covariance blocks see the product of the samples' F once.
+ * Equal to n_samples calls of hv_ekf_predict_dev up to rounding (1e-15 relative). */
+int hv_ekf_predict_n_dev(hv_ekf *ekf, int n_samples, const double *dt_dev, const double *gyro_dev,
+                         const double *acc_dev);
 /* update(m,P,y,H,R,...) (ekf.cpp:57-82) with truncated H (n_rows x l, column-major, per filter),
  * R = r_diag[f] * I: used by ZUPT / ZRUPT / position / height / orientation updates. */
 int hv_ekf_update(hv_ekf *ekf, int n_rows, int l, const double *H, const double *y, const double *r_diag,

@@ -45,6 +45,9 @@ for nr, l in ((8, 76), (16, 160), (40, 160), (64, 160), (84, 160)):
 dt = torch.full((B,), 0.005, dtype=torch.float64, device="cuda")
 gy = torch.zeros((B, 3), dtype=torch.float64, device="cuda"); ac = torch.tensor([[0, 0, 9.8]] * B, dtype=torch.float64, device="cuda")
 print(f"predict  {bench(lambda: ekf.predict_dev(dt.data_ptr(), gy.data_ptr(), ac.data_ptr())):7.1f} us")
+dtn = torch.full((10, B), 0.005, dtype=torch.float64, device="cuda"); gyn = torch.zeros((10, B, 3), dtype=torch.float64, device="cuda")
+acn = torch.tensor([[[0, 0, 9.8]] * B] * 10, dtype=torch.float64, device="cuda")
+print(f"predict x10 in one launch {bench(lambda: ekf.predict_n_dev(10, dtn.data_ptr(), gyn.data_ptr(), acn.data_ptr())):7.1f} us")
 sp = (C.c_longlong * 16)(); capi.lib().hv_debug_ekf_phase_stamps(ekf._h, sp)
 print("predict phases [serial mean/F/L, P00 block, trailing rows] ticks =", [sp[13]-sp[12], sp[14]-sp[13], sp[15]-sp[14]])
 print(f"augment  {bench(lambda: ekf._chk(capi.lib().hv_ekf_augment(ekf._h, None, None), 'aug')):7.1f} us")

@@ -97,6 +97,29 @@ def test_predict_parity_batch(oracle, ctx):
     np.testing.assert_allclose(g.get_dydx(0), os_[0].dydx, rtol=1e-12, atol=1e-14)
 
 
+def test_predict_n_samples_in_one_launch(oracle, ctx):
+    """hv_ekf_predict_n_dev == n sequential predicts (oracle), incl. a skipped sample (dt <= 0) and
+    per-filter inputs; the off-diagonal blocks see the product of the samples' F once."""
+    import torch
+    rng = np.random.default_rng(31)
+    for trail in (20, 5):
+        os_, g = make_pair(oracle, ctx, rng, batch=3, trail=trail)
+        nS = 10
+        dt = np.full((nS, 3), 0.005); dt[4, 1] = 0.0; dt[7, :] = 0.0025
+        gy = rng.normal(0, 0.05, (nS, 3, 3)); ac = rng.normal(0, 0.05, (nS, 3, 3)) + [0.1, -0.2, 9.8]
+        for o in os_:
+            o.set_first_sample_time(1.0)
+        tt = np.full(3, 1.0)
+        for s_ in range(nS):
+            tt += dt[s_]
+            for b, o in enumerate(os_):
+                o.predict(tt[b], gy[s_, b], ac[s_, b])          # dt == 0 -> the oracle skips the sample too
+        d_dt, d_gy, d_ac = (torch.from_numpy(x).cuda() for x in (dt, gy, ac))
+        g.predict_n_dev(nS, d_dt.data_ptr(), d_gy.data_ptr(), d_ac.data_ptr())
+        assert check(os_, g) < 1e-11
+        np.testing.assert_allclose(g.get_dydx(0), os_[0].dydx, rtol=1e-12, atol=1e-14)
+
+
 def test_reference_der_predict_on_gpu(oracle, ctx):
     """test/ekf.cpp:73-117 run against the HIP predict: analytic dydx vs forward differences < 1e-3."""
     fx = np.load(GOLD)
