@@ -97,6 +97,7 @@ PROTOTYPES = {
     "hv_ekf_predict": (C.c_int, [C.c_void_p, f64p, f64p, f64p]),
     "hv_ekf_predict_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "hv_ekf_predict_n_dev": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "hv_ekf_predict_n": (C.c_int, [C.c_void_p, C.c_int, f64p, f64p, f64p]),
     "hv_ekf_update": (C.c_int, [C.c_void_p, C.c_int, C.c_int, f64p, f64p, f64p, u8p, C.c_int]),
     "hv_ekf_visual_gate": (C.c_int, [C.c_void_p, C.c_int, C.c_int, f64p, f64p, C.c_double, f64p, i32p]),
     "hv_ekf_visual_update": (C.c_int, [C.c_void_p, C.c_int, C.c_int, f64p, f64p, C.c_double, u8p]),

@@ -1213,7 +1213,7 @@ int hv_ekf_create(hv_ctx *ctx, const hv_ekf_params *par, int batch, hv_ekf **out
     alloc(e->ws, sizeof(double) * (size_t)(2 * n + 1) * n * batch);
     e->sH_cap = nn * batch;
     alloc(e->sH, sizeof(double) * e->sH_cap); alloc(e->sv, sizeof(double) * n * batch); alloc(e->sr, sizeof(double) * batch);
-    alloc(e->schi2, sizeof(double) * batch); alloc(e->simu, sizeof(double) * 7 * batch);
+    alloc(e->schi2, sizeof(double) * batch); alloc(e->simu, sizeof(double) * 7 * HV_EKF_MAX_PREDICT_SAMPLES * batch);
     alloc(e->sstatus, sizeof(int) * batch); alloc(e->sdrop, sizeof(int) * batch); alloc(e->sactive, batch);
     if (!ok) { hv_ekf_destroy(h); return HV_ERR_NOMEM; }
 
@@ -1358,6 +1358,19 @@ int hv_ekf_predict_dev(hv_ekf *h, const double *dt_dev, const double *gyro_dev, 
 {
     if (!h || !dt_dev || !gyro_dev || !acc_dev) return HV_ERR_INVALID;
     return predict_common(&h->e, dt_dev, gyro_dev, acc_dev, 0.0, nullptr, nullptr);
+}
+
+int hv_ekf_predict_n(hv_ekf *h, int n_samples, const double *dt, const double *gyro, const double *acc)
+{
+    if (!h || n_samples < 1 || n_samples > HV_EKF_MAX_PREDICT_SAMPLES || !dt || !gyro || !acc) return HV_ERR_INVALID;
+    Ekf *e = &h->e; Ctx *c = e->c;
+    if (n_samples == 1 && e->batch == 1) return predict_common(e, nullptr, nullptr, nullptr, dt[0], gyro, acc);
+    const size_t nB = (size_t)n_samples * e->batch;
+    double *d_dt = e->simu, *d_g = e->simu + nB, *d_a = e->simu + 4 * nB;
+    HV_HIP(c, hipMemcpyAsync(d_dt, dt, sizeof(double) * nB, hipMemcpyHostToDevice, c->stream));
+    HV_HIP(c, hipMemcpyAsync(d_g, gyro, sizeof(double) * 3 * nB, hipMemcpyHostToDevice, c->stream));
+    HV_HIP(c, hipMemcpyAsync(d_a, acc, sizeof(double) * 3 * nB, hipMemcpyHostToDevice, c->stream));
+    return predict_common(e, d_dt, d_g, d_a, 0.0, nullptr, nullptr, n_samples);
 }
 
 int hv_ekf_predict_n_dev(hv_ekf *h, int n_samples, const double *dt_dev, const double *gyro_dev, const double *acc_dev)

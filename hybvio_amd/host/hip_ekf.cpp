@@ -52,20 +52,27 @@ struct HipEKF : public EKF {
     ~HipEKF() override { hv_ekf_destroy(ekf); }
 
     void check(int rc) const { assert(rc == HV_OK); (void)rc; }
-    void dirty() { meanFresh = covFresh = false; }
-    void syncMean() const { if (!meanFresh) { check(hv_ekf_get_state(ekf, 0, m.data(), nullptr)); meanFresh = true; } }
-    void syncAll() const {
-        if (!meanFresh || !covFresh) { check(hv_ekf_get_state(ekf, 0, m.data(), P.data.data())); meanFresh = covFresh = true; }
+    mutable std::vector<double> qdt, qg, qa;            // queued IMU samples (dt, gyro, acc)
+    void flushPredicts() const {
+        if (qdt.empty()) return;
+        check(hv_ekf_predict_n(ekf, (int)qdt.size(), qdt.data(), qg.data(), qa.data()));
+        qdt.clear(); qg.clear(); qa.clear();
     }
-    void pushAll() { check(hv_ekf_set_state(ekf, 0, m.data(), P.data.data())); meanFresh = covFresh = true; }
-    void pushMean() { check(hv_ekf_set_state(ekf, 0, m.data(), nullptr)); meanFresh = true; }
+    hv_ekf *dev() const { flushPredicts(); return ekf; }  // every device call goes through here
+    void dirty() { meanFresh = covFresh = false; }
+    void syncMean() const { if (!meanFresh) { check(hv_ekf_get_state(dev(), 0, m.data(), nullptr)); meanFresh = true; } }
+    void syncAll() const {
+        if (!meanFresh || !covFresh) { check(hv_ekf_get_state(dev(), 0, m.data(), P.data.data())); meanFresh = covFresh = true; }
+    }
+    void pushAll() { check(hv_ekf_set_state(dev(), 0, m.data(), P.data.data())); meanFresh = covFresh = true; }
+    void pushMean() { check(hv_ekf_set_state(dev(), 0, m.data(), nullptr)); meanFresh = true; }
 
     std::unique_ptr<EKF> clone() const final {
         std::unique_ptr<HipEKF> c(new HipEKF(session, par));
         syncAll();
         c->m = m; c->P = P; c->pushAll();
         double Q[Q_DIM * Q_DIM];    // process noise follows the filter (drift entries change in predict)
-        check(hv_ekf_get_process_noise(ekf, 0, Q));
+        check(hv_ekf_get_process_noise(dev(), 0, Q));
         check(hv_ekf_set_process_noise(c->ekf, 0, Q));
         c->augmentCount = augmentCount; c->augmentTimes = augmentTimes;
         c->time = time; c->ZUPTtime = ZUPTtime; c->ZRUPTtime = ZRUPTtime; c->initZUPTtime = initZUPTtime;
@@ -97,14 +104,18 @@ struct HipEKF : public EKF {
     }
 
     // ekf.cpp:320-514: the clock stays here, mean + Jacobians + covariance run on the device
+    // The device call is deferred: consecutive IMU samples (10 between two EuRoC frames) are queued and
+    // go out as ONE hv_ekf_predict_n launch when anything else touches the filter (dev()).
     void predict(double t, const Vector3d &xg, const Vector3d &xa) final {
         double dt = 0.0;
         if (!firstSample) { dt = t - prevSampleT; time = t - firstSampleT; }
         else { firstSampleT = t; firstSample = false; }
         prevSampleT = t;
         if (dt <= 0.0) return;
-        check(hv_ekf_predict(ekf, &dt, xg.data(), xa.data()));
+        qdt.push_back(dt);
+        for (int i = 0; i < 3; i++) { qg.push_back(xg[i]); qa.push_back(xa[i]); }
         dirty();
+        if ((int)qdt.size() >= HV_EKF_MAX_PREDICT_SAMPLES) flushPredicts();
     }
 
     Vector3d seg3(int o) const { syncMean(); return {m[o], m[o + 1], m[o + 2]}; }
@@ -141,7 +152,7 @@ struct HipEKF : public EKF {
         const int l = col0 + rows;
         std::vector<double> H((size_t)rows * l, 0.0);
         for (int i = 0; i < rows; i++) H[(size_t)(col0 + i) * rows + i] = 1.0;
-        check(hv_ekf_update(ekf, rows, l, H.data(), y, &rdiag, nullptr, normalizeAll ? 1 : 0));
+        check(hv_ekf_update(dev(), rows, l, H.data(), y, &rdiag, nullptr, normalizeAll ? 1 : 0));
         dirty();
     }
     void updateZupt(double r) final {
@@ -169,7 +180,7 @@ struct HipEKF : public EKF {
         double H[VEL + 2] = {0};
         for (int i = 0; i < 2; i++) H[VEL + i] = m[VEL + i] / h;
         const double rd = r * noiseScale;
-        check(hv_ekf_update(ekf, 1, VEL + 2, H, &defaultSpeed, &rd, nullptr, 0));
+        check(hv_ekf_update(dev(), 1, VEL + 2, H, &defaultSpeed, &rd, nullptr, 0));
         dirty();
     }
     void updatePosition(const Vector3d &pos, double r) final {
@@ -178,7 +189,7 @@ struct HipEKF : public EKF {
     }
     void updateZeroHeight(double r) final {
         const double H[POS + 3] = {0, 0, 1}, y = 0, rd = r * noiseScale;
-        check(hv_ekf_update(ekf, 1, POS + 3, H, &y, &rd, nullptr, 0));
+        check(hv_ekf_update(dev(), 1, POS + 3, H, &y, &rd, nullptr, 0));
         dirty();
         maintainPositiveSemiDefinite();
     }
@@ -229,7 +240,7 @@ struct HipEKF : public EKF {
         const Vector3d refPos = i < 0 ? position() : historyPosition(i);
         double tr[3];
         for (int r = 0; r < 3; r++) tr[r] = pos[r] - (pC[3*r]*refPos[0] + pC[3*r + 1]*refPos[1] + pC[3*r + 2]*refPos[2]);
-        check(hv_ekf_transform(ekf, 0, pC, qC, tr));
+        check(hv_ekf_transform(dev(), 0, pC, qC, tr));
         dirty();
     }
 
@@ -245,7 +256,7 @@ struct HipEKF : public EKF {
         }
         if (r < 0.0) return VuOutlierStatus::INLIER;
         double chi2 = 0; int status = 0;
-        check(hv_ekf_visual_gate(ekf, n, visH.cols, visH.data.data(), v.data(), r, &chi2, &status));
+        check(hv_ekf_visual_gate(dev(), n, visH.cols, visH.data.data(), v.data(), r, &chi2, &status));
         return status == 3 ? VuOutlierStatus::CHI2 : VuOutlierStatus::INLIER;
     }
 
@@ -254,12 +265,12 @@ struct HipEKF : public EKF {
         assert(static_cast<int>(y.size()) == n && static_cast<int>(f.size()) == n);
         VectorXd v(n);
         for (int i = 0; i < n; i++) v[i] = y[i] - f[i];
-        check(hv_ekf_visual_update(ekf, n, visH.cols, visH.data.data(), v.data(), r, nullptr));
+        check(hv_ekf_visual_update(dev(), n, visH.cols, visH.data.data(), v.data(), r, nullptr));
         dirty();
     }
 
     void updateVisualPoseAugmentation(int discardedPoseIndex) final {
-        check(hv_ekf_augment(ekf, &discardedPoseIndex, nullptr));
+        check(hv_ekf_augment(dev(), &discardedPoseIndex, nullptr));
         dirty();
         augmentTimes.push_back(getPlatformTime());
         if (augmentCount < camPoseCount) augmentCount++;
@@ -267,7 +278,7 @@ struct HipEKF : public EKF {
         assert(static_cast<int>(augmentTimes.size()) == augmentCount);
     }
     void updateUndoAugmentation() final {
-        check(hv_ekf_undo_augment(ekf, nullptr));
+        check(hv_ekf_undo_augment(dev(), nullptr));
         dirty();
         assert(augmentCount > 0);
         augmentTimes.pop_back();
@@ -322,7 +333,7 @@ struct HipEKF : public EKF {
         for (int k = BGA; k < BGA + 9; k++) for (int i = 0; i < stateDim; i++) { P(k, i) = 0; P(i, k) = 0; }
         pushAll();
     }
-    void normalizeQuaternions(bool onlyCurrent) final { check(hv_ekf_normalize_quaternions(ekf, onlyCurrent ? 1 : 0)); meanFresh = false; }
+    void normalizeQuaternions(bool onlyCurrent) final { check(hv_ekf_normalize_quaternions(dev(), onlyCurrent ? 1 : 0)); meanFresh = false; }
     void setFirstSampleTime(double t) final { assert(t > 0.0); firstSample = false; firstSampleT = t; prevSampleT = t; time = t; }
     bool isPositiveSemiDefinite() final {   // debug only (ekf.cpp:1043-1057): sign of the pivots of a pivoted LDL'
         syncAll();
@@ -344,9 +355,9 @@ struct HipEKF : public EKF {
     void setState(const VectorXd &_m) final { assert(static_cast<int>(_m.size()) == stateDim); m = _m; pushMean(); }
     void setStateCovariance(const MatrixXd &_P) final {
         assert(_P.rows == stateDim && _P.cols == stateDim);
-        P = _P; check(hv_ekf_set_state(ekf, 0, nullptr, P.data.data())); covFresh = true;
+        P = _P; check(hv_ekf_set_state(dev(), 0, nullptr, P.data.data())); covFresh = true;
     }
-    void setProcessNoise(const MatrixXd &_Q) final { assert(_Q.rows == Q_DIM && _Q.cols == Q_DIM); check(hv_ekf_set_process_noise(ekf, 0, _Q.data.data())); }
+    void setProcessNoise(const MatrixXd &_Q) final { assert(_Q.rows == Q_DIM && _Q.cols == Q_DIM); check(hv_ekf_set_process_noise(dev(), 0, _Q.data.data())); }
     double getPlatformTime() const final { return firstSampleT + time; }
     int getPoseCount() const final { return augmentCount + 1; }
     const VectorXd &getState() const final { syncMean(); return m; }
@@ -376,7 +387,7 @@ struct HipEKF : public EKF {
         MatrixXd full(stateDim, stateDim);
         for (int i = 0; i < stateDim; i++) full(i, i) = 1.0;
         double F[INER_DIM * INER_DIM];
-        check(hv_ekf_get_dydx(ekf, 0, F));
+        check(hv_ekf_get_dydx(dev(), 0, F));
         for (int j = 0; j < INER_DIM; j++) for (int i = 0; i < INER_DIM; i++) full(i, j) = F[j * INER_DIM + i];
         return full;
     }

@@ -162,6 +162,8 @@ int hv_ekf_predict_dev(hv_ekf *ekf, const double *dt_dev, const double *gyro_dev
  * Equal to n_samples calls of hv_ekf_predict_dev up to rounding (1e-15 relative). */
 int hv_ekf_predict_n_dev(hv_ekf *ekf, int n_samples, const double *dt_dev, const double *gyro_dev,
                          const double *acc_dev);
+#define HV_EKF_MAX_PREDICT_SAMPLES 32
+int hv_ekf_predict_n(hv_ekf *ekf, int n_samples, const double *dt, const double *gyro, const double *acc);   /* host arrays */
 /* update(m,P,y,H,R,...) (ekf.cpp:57-82) with truncated H (n_rows x l, column-major, per filter),
  * R = r_diag[f] * I: used by ZUPT / ZRUPT / position / height / orientation updates. */
 int hv_ekf_update(hv_ekf *ekf, int n_rows, int l, const double *H, const double *y, const double *r_diag,
