@@ -511,6 +511,21 @@ def main():
         lat = (time.perf_counter() - t0) / n_lat
         out["latency_mode"] = {"sequences": 1, "ms_per_frame": lat * 1e3, "frames_per_s": 1.0 / lat,
                                "tracked_fraction": t1.tracked_fraction(), "launch": "eager"}
+        if not args.no_ekf:
+            # the same single sequence with its EKF (C3 at B = 1): what one drop-in `main` sees per frame
+            e1 = EkfBench(t1.ctx, 1, local_rank, seed=12345)
+            for _ in range(N_CYCLE):
+                t1.step(); e1.step()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(n_lat):
+                t1.step(); e1.step()
+            torch.cuda.synchronize()
+            lat3 = (time.perf_counter() - t0) / n_lat
+            out["c3"]["latency_mode"] = {"sequences": 1, "ms_per_frame": lat3 * 1e3, "frames_per_s": 1.0 / lat3,
+                                         "launch": "eager", "launches_per_frame": 6 + 1 + EKF_GATES + 2}
+            e1.ekf.close()
+            del e1
         # The eager number is host-launch bound (~16 launches per frame). A step is a fixed launch
         # sequence with period N_CYCLE, so capture it in HIP graphs and replay: GPU-bound latency.
         try:
