@@ -366,7 +366,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--sequences", type=int, default=256, help="independent VIO sequences per GPU (B)")
+    ap.add_argument("--sequences", type=int, default=1024,
+                    help="independent VIO sequences resident per GPU (B): 13 MB each; 256 fills the CUs once, 1024 amortises launch tails (+11 %%)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-latency-mode", action="store_true")
     ap.add_argument("--no-ekf", action="store_true", help="skip the C3 (tracker + HIP EKF) leg")

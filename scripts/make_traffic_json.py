@@ -5,7 +5,13 @@ import csv, json, os, sys
 
 src = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/prof_final"
 dst = sys.argv[2] if len(sys.argv) > 2 else "profiles/r01/traffic.json"
-B, NPTS, LEVEL_SHARE_L0 = 256, 200, 16.0 / 21.0      # <true> launches L0, L1, L2 scale 16 : 4 : 1
+NPTS, LEVEL_SHARE_L0 = 200, 16.0 / 21.0               # <true> launches L0, L1, L2 scale 16 : 4 : 1
+B = 256
+try:                                                   # sequences per GPU of the profiled bench run
+    with open(os.path.join(src, "bench_under_kernel_trace.log")) as f:
+        B = [json.loads(l) for l in f if l.startswith("{")][-1]["config"]["sequences_per_gpu"]
+except Exception:
+    pass
 val = {}
 for i in range(1, 6):
     with open(os.path.join(src, f"pmc{i}.csv")) as f:
@@ -21,7 +27,7 @@ def hbm(k, fetch_x2=True):      # KB -> bytes; gfx950 FETCH_SIZE counts 64 B per
 
 pyr = "pyr_level_kernel<true>"
 out = {
-    "note": "rocprofv3 --pmc (separate passes, scripts/collect_profile.sh), means per dispatch of bench.py at B=256. "
+    "note": f"rocprofv3 --pmc (separate passes, scripts/collect_profile.sh), means per dispatch of bench.py at B={B}. "
             "gfx950: FETCH_SIZE counts 64 B per 128 B request -> x2 (MI355X_MICROARCH.md HBM section); WRITE_SIZE "
             "calibrated against the pyramid's known write bytes (1.03x).",
     "sequences_per_gpu": B,
