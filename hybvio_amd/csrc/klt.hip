@@ -35,6 +35,7 @@ constexpr int WIN = 31;
 constexpr int HALF_ROWS = 16;          // rows per half-wave
 constexpr int TS = 44;                 // staged J tile: TS x TS pixels (one dword each): 10 KB of LDS per wave with `region`
 constexpr int RW = 48;                 // width of the in-image region used to build border tiles
+static_assert(RW / 4 == 12, "the region staging loop divides by 12 with a 24-bit multiply");
 constexpr int GRAY_SHIFT = 7;          // gray samples are pre-scaled by 128 (<= 32640: fits int16)
 // The four bilinear weights always sum to 2^14, so adding 2 to every pre-scaled sample adds exactly
 // 2^15 to the weighted sum: the rounding constant of CV_DESCALE rides along in the data and every
@@ -187,8 +188,9 @@ __global__ __launch_bounds__(64, 4) void klt_kernel(KltArgs a)
             Ig = as_global(prev_base + L.goff[level]); Jg = as_global(next_base + L.goff[level]);
             Igs = Jgs = L.gstride[level];
         }
+        Igs = __builtin_amdgcn_readfirstlane(Igs); Jgs = __builtin_amdgcn_readfirstlane(Jgs);   // wave-uniform: keep them in SGPRs
         const gptr_u32 Id = (gptr_u32)as_global(prev_base + L.doff[level]);
-        const int Ids = L.dstride[level];
+        const int Ids = __builtin_amdgcn_readfirstlane(L.dstride[level]);
 
         // ---- template patch: bilinear samples of I and dI into registers, A = sum(dI dI^T) ----
         // packed int16 pairs (window rows 2m, 2m+1 of this lane): value, x-gradient, y-gradient
@@ -201,8 +203,8 @@ __global__ __launch_bounds__(64, 4) void klt_kernel(KltArgs a)
             const int xa = ipx + cx;
             const bool inside = ipx >= 0 && ipx + 32 <= w && ipy >= 0 && ipy + 32 <= h;   // wave-uniform
             // per-lane part of every address; the per-row part is a scalar base (no VALU per load)
-            const unsigned vg = (unsigned)(half * HALF_ROWS) * (unsigned)Igs + (unsigned)xa;
-            const unsigned vd = (unsigned)(half * HALF_ROWS) * (unsigned)Ids + (unsigned)xa;
+            const unsigned vg = __umul24((unsigned)(half * HALF_ROWS), (unsigned)Igs) + (unsigned)xa;      // rows and strides < 2^24:
+            const unsigned vd = __umul24((unsigned)(half * HALF_ROWS), (unsigned)Ids) + (unsigned)xa;      // full-rate v_mul_u32_u24
             const unsigned gxa = (unsigned)reflect101(xa, w), gxb = (unsigned)reflect101(xa + 1, w);
             const bool ina = (unsigned)xa < (unsigned)w, inb = (unsigned)(xa + 1) < (unsigned)w;
 
@@ -238,8 +240,12 @@ __global__ __launch_bounds__(64, 4) void klt_kernel(KltArgs a)
 #pragma unroll
                     for (int r = 0; r < NB; ++r) {
                         const int ry0 = ipy + r0 + r, ry1 = ry0 + HALF_ROWS;                              // uniform
-                        const unsigned go0 = (unsigned)reflect101(ry0, h) * (unsigned)Igs, go1 = (unsigned)reflect101(ry1, h) * (unsigned)Igs;
-                        const unsigned do0 = (unsigned)min(max(ry0, 0), h - 1) * (unsigned)Ids, do1 = (unsigned)min(max(ry1, 0), h - 1) * (unsigned)Ids;
+                        // readfirstlane pins the four products to the scalar unit: left alone, hipcc turns the select
+                        // of two products into a per-lane (quarter-rate) v_mul_lo_u32 of the selected row index
+                        const unsigned go0 = __builtin_amdgcn_readfirstlane((unsigned)reflect101(ry0, h) * (unsigned)Igs);
+                        const unsigned go1 = __builtin_amdgcn_readfirstlane((unsigned)reflect101(ry1, h) * (unsigned)Igs);
+                        const unsigned do0 = __builtin_amdgcn_readfirstlane((unsigned)min(max(ry0, 0), h - 1) * (unsigned)Ids);
+                        const unsigned do1 = __builtin_amdgcn_readfirstlane((unsigned)min(max(ry1, 0), h - 1) * (unsigned)Ids);
                         const unsigned go = half ? go1 : go0, dof = half ? do1 : do0;
                         ga[r] = Ig[go + gxa]; gb[r] = Ig[go + gxb];
                         da[r] = Id[dof + gxa]; db[r] = Id[dof + gxb];
@@ -332,7 +338,7 @@ __global__ __launch_bounds__(64, 4) void klt_kernel(KltArgs a)
 #pragma unroll
                     for (int i = 0; i < NIT; ++i) {
                         const int rr = min(r, TS - 1);      // the clamped tail items re-read the last row: harmless
-                        __builtin_memcpy(&raw[i], (const void *)(uintptr_t)(Jg + ((unsigned)(toy + rr) * (unsigned)Jgs +
+                        __builtin_memcpy(&raw[i], (const void *)(uintptr_t)(Jg + (__umul24((unsigned)(toy + rr), (unsigned)Jgs) +
                                                                                (unsigned)(tox + 4 * c))), 8);
                         r += 64 / G; c += 64 % G;
                         if (c >= G) { c -= G; r += 1; }
@@ -343,7 +349,7 @@ __global__ __launch_bounds__(64, 4) void klt_kernel(KltArgs a)
 #pragma unroll
                     for (int i = 0; i < NIT; ++i) {
                         const int rr = min(r, TS - 1);
-                        *reinterpret_cast<uint4 *>(&jt[rr * TS + 4 * c]) =
+                        *reinterpret_cast<uint4 *>(&jt[__umul24(rr, TS) + 4 * c]) =
                             make_uint4(scaled_pair<0>(raw[i].x, raw[i].y), scaled_pair<1>(raw[i].x, raw[i].y),
                                        scaled_pair<2>(raw[i].x, raw[i].y), scaled_pair<3>(raw[i].x, raw[i].y));
                         r += 64 / G; c += 64 % G;
@@ -363,8 +369,8 @@ __global__ __launch_bounds__(64, 4) void klt_kernel(KltArgs a)
                     uint32_t raw[(TS * (RW / 4) + 63) / 64];
 #pragma unroll
                     for (int i = 0; i < (TS * (RW / 4) + 63) / 64; ++i) {
-                        const int e = min(ln + 64 * i, TS * (RW / 4) - 1), r = e / (RW / 4), c = e - r * (RW / 4);
-                        __builtin_memcpy(&raw[i], (const void *)(uintptr_t)(Jg + ((unsigned)(ry0 + r) * (unsigned)Jgs +
+                        const int e = min(ln + 64 * i, TS * (RW / 4) - 1), r = (int)(__umul24((unsigned)e, 5462u) >> 16), c = e - __umul24(r, RW / 4);   // e / 12, exact for e < 8190
+                        __builtin_memcpy(&raw[i], (const void *)(uintptr_t)(Jg + (__umul24((unsigned)(ry0 + r), (unsigned)Jgs) +
                                                                                (unsigned)(rx0 + 4 * c))), 4);
                     }
 #pragma unroll
@@ -388,12 +394,12 @@ __global__ __launch_bounds__(64, 4) void klt_kernel(KltArgs a)
 #pragma unroll
                 for (int i = 0; i < (TS * TS / 4 + 63) / 64; ++i) {
                     const int e = min(ln + 64 * i, TS * TS / 4 - 1), r = e / (TS / 4), c = e - r * (TS / 4);
-                    const gptr_u8 row = Jg + (unsigned)reflect101(toy + r, h) * (unsigned)Jgs;
+                    const gptr_u8 row = Jg + __umul24((unsigned)reflect101(toy + r, h), (unsigned)Jgs);
                     const int x = tox + 4 * c;
                     uint32_t b[5];
 #pragma unroll
                     for (int q = 0; q < 5; ++q) b[q] = ((uint32_t)row[(unsigned)reflect101(x + q, w)] << GRAY_SHIFT) + 2u;
-                    *reinterpret_cast<uint4 *>(&jt[r * TS + 4 * c]) =
+                    *reinterpret_cast<uint4 *>(&jt[__umul24(r, TS) + 4 * c]) =
                         make_uint4(b[0] | (b[1] << 16), b[1] | (b[2] << 16), b[2] | (b[3] << 16), b[3] | (b[4] << 16));
                 }
             }
