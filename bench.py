@@ -41,8 +41,9 @@ def level_sizes(w, h, levels=LEVELS, win=31):
     return out
 
 
-def algorithmic_bytes(w=W, h=H, npts=NPTS):
+def algorithmic_bytes(w=None, h=None, npts=None):
     """per image / per LK call / per stereo frame, plus the per-kernel split."""
+    w, h, npts = w or W, h or H, npts or NPTS
     ls = level_sizes(w, h)
     px = [a * b for a, b in ls]
     pyr_image = px[0] + sum(px[1:]) + 4 * sum(px)                 # read L0 + write gray L1.. + write grads
@@ -372,6 +373,8 @@ def main():
     ap.add_argument("--no-latency-mode", action="store_true")
     ap.add_argument("--no-ekf", action="store_true", help="skip the C3 (tracker + HIP EKF) leg")
     ap.add_argument("--no-gftt", action="store_true", help="skip the f1 (GFTT detector kernel) measurement")
+    ap.add_argument("--c4", action="store_true",
+                    help="configs[3] instead of the headline workload: 1280x720 stereo, 400 features (not the default bench line)")
     args = ap.parse_args()
 
     import torch
@@ -384,6 +387,9 @@ def main():
 
     from hybvio_amd import capi
     B = args.sequences
+    if args.c4:
+        global W, H, NPTS
+        W, H, NPTS = 1280, 720, 400
     tb = TrackerBench(B, local_rank, seed=rank)
     for _ in range(args.warmup):
         tb.step()
@@ -423,8 +429,9 @@ def main():
             "value": aggregate_value(B, world, args.steps, el), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u8/int16 pixels, int32/int64 sums, f32 solve", "data": "synthetic",
-            "config": {"workload": "C2: 752x480 stereo, 200 pts, HIP pyramid+KLT tracker (2 builds + 2 LK calls per "
-                                   "frame), EKF not in the HIP path", "sequences_per_gpu": B,
+            "config": {"workload": (f"C4: {W}x{H} stereo, {NPTS} pts" if args.c4 else "C2: 752x480 stereo, 200 pts") +
+                                   ", HIP pyramid+KLT tracker (2 builds + 2 LK calls per frame), EKF not in the HIP path",
+                       "sequences_per_gpu": B,
                        "frames_per_step": world * B, "parallelism": f"replicas x{world} (no collective)"},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": kern[dom]["achieved_GBs"], "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": kern[dom]["achieved_GBs"] / HBM_PEAK_GBS, "traffic": traffic,
