@@ -344,13 +344,16 @@ __device__ __forceinline__ double lane_bcast(double v, int src_lane)
     return __hiloint2double(hi, lo);
 }
 
+// NW = 16, or 8 for a ragged last block of at most 8 columns: only NW column steps are run (the padding
+// columns are identity and every update they would receive is zero), W is still written 16 x 16.
+template <int NW>
 __device__ __forceinline__ void factor_diag_block(double *T, double *W, double *col, int R, int j0, int w, int lane)
 {
     const int r = lane & 15;
     const bool ident = (lane & 16) != 0;                    // lanes 32..63 mirror 0..31 (results unused)
-    double tr[16];
+    double tr[NW];
 #pragma unroll
-    for (int c = 0; c < 16; c++) {
+    for (int c = 0; c < NW; c++) {
         const double x = T[(size_t)(j0 + min(c, w - 1)) * R + j0 + min(r, w - 1)];
         const bool from_t = !ident && c <= r && r < w;      // lower triangle of the block; r < w implies c < w
         tr[c] = from_t ? x : (c == r ? 1.0 : 0.0);
@@ -362,38 +365,38 @@ __device__ __forceinline__ void factor_diag_block(double *T, double *W, double *
     // instead of two v_readlane each, and they are applied one step LATE, after the chain work of
     // step k+1 has been issued: a wavefront issues in order, so a wait for the LDS round trip in
     // step k would stall the chain behind it.
-    double mprev[16], lprev = 0.0;
+    double mprev[NW], lprev = 0.0;
     double *col_dst = lane < 16 ? col + r : col + 256 + lane;   // col[256 .. 319]: dump area (an exec-masked store makes
                                                                   // hipcc wait for the store itself before the next use of LDS data)
 #pragma unroll
-    for (int k = 0; k < 16; k++) {
+    for (int k = 0; k < NW; k++) {
         const double d = lane_bcast(tr[k], k);
         if (k >= 1) {                                          // step k-1's updates of columns k+1..: fill the rsqrt latency
 #pragma unroll
-            for (int c = k + 1; c < 16; c++) tr[c] -= lprev * mprev[c];
+            for (int c = k + 1; c < NW; c++) tr[c] -= lprev * mprev[c];
         }
         const double inv = rsqrt(d);                          // one rsqrt instead of sqrt + divide
         const double lk = tr[k] * inv;                        // lane k: d * rsqrt(d) = sqrt(d)
         tr[k] = lk;
-        if (k + 1 < 16) {
-            if (k + 2 < 16) col_dst[k * 16] = lk;            // branch-free: lanes >= 16 write to a dump row
+        if (k + 1 < NW) {
+            if (k + 2 < NW) col_dst[k * 16] = lk;            // branch-free: lanes >= 16 write to a dump row
             tr[k + 1] -= lk * lane_bcast(lk, k + 1);          // lane c < 16 holds L(c, k)
         }
 #pragma unroll
-        for (int c = k + 2; c < 16; c++) mprev[c] = col[k * 16 + c];         // requested now, used in step k+1
+        for (int c = k + 2; c < NW; c++) mprev[c] = col[k * 16 + c];         // requested now, used in step k+1
         lprev = lk;
         // pin the updates to this step: left alone, hipcc sinks each one to the last use of tr[c]
         // and keeps every multiplier read so far alive
 #pragma unroll
-        for (int c = k + 1; c < 16; c++) asm volatile("" : "+v"(tr[c]));
+        for (int c = k + 1; c < NW; c++) asm volatile("" : "+v"(tr[c]));
     }
     if (lane < 16) {
 #pragma unroll
-        for (int c = 0; c < 16; c++)
+        for (int c = 0; c < NW; c++)
             if (c <= r && r < w) T[(size_t)(j0 + c) * R + j0 + r] = tr[c];
     } else if (lane < 32) {
 #pragma unroll
-        for (int c = 0; c < 16; c++) W[r * 16 + c] = tr[c];                    // W[i][c] = Linv(c, i)
+        for (int c = 0; c < 16; c++) W[r * 16 + c] = c < NW ? tr[c < NW ? c : 0] : (c == r ? 1.0 : 0.0);   // W[i][c] = Linv(c, i)
     }
 }
 
@@ -675,7 +678,7 @@ __global__ __launch_bounds__(UPD_THREADS) void ekf_update_kernel(UpdateArgs a)
             __syncthreads();
         }
         if (j0 == 0) PHASE_STAMP(6);
-        if (wave == 0) factor_diag_block(T, W, col, R, j0, w, lane);
+        if (wave == 0) { if (w <= 8) factor_diag_block<8>(T, W, col, R, j0, w, lane); else factor_diag_block<16>(T, W, col, R, j0, w, lane); }
         __syncthreads();
         if (j0 == 0) PHASE_STAMP(7);
         for (int i0 = j0 + w + 16 * wave; i0 < Rlim; i0 += 16 * nwaves) {        // rows below the w x w diagonal block
