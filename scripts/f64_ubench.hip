@@ -66,6 +66,65 @@ __global__ void k_mfma_lds(double *out, long long *cyc)
     if ((threadIdx.x & 63) == 0) cyc[threadIdx.x >> 6] = t1 - t0;
 }
 
+// ---- MFMA vs plain LDS-tiled VALU on the EKF's own product shape: C(160x160) -= Y'(160x40) Y(40x160),
+// Y resident in LDS (row c of Y at ys[c * 161 ...]), one 512-thread workgroup, C kept in registers and
+// summed into `out` so that nothing is optimised away. This is the covariance downdate P -= Y'Y of
+// ekf_update_kernel (n = 160, 40 measurement rows).
+constexpr int YN = 160, YK = 40, YS = 161;
+__global__ __launch_bounds__(512) void k_yty_mfma(double *out, long long *cyc)
+{
+    __shared__ double ys[YK * YS];
+    for (int i = threadIdx.x; i < YK * YS; i += 512) ys[i] = 1e-3 * ((i * 7) % 113);
+    __syncthreads();
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, kq = lane >> 4, cl = lane & 15;
+    double acc_sum = 0;
+    long long t0 = clock64();
+    for (int tile = wave; tile < 100; tile += 8) {                  // 10 x 10 tiles of 16 x 16
+        const int i0 = (tile % 10) * 16, j0 = (tile / 10) * 16;
+        double4v acc = {0, 0, 0, 0};
+#pragma unroll
+        for (int s = 0; s < YK / 4; s++)
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(ys[(4 * s + kq) * YS + i0 + cl], ys[(4 * s + kq) * YS + j0 + cl], acc, 0, 0, 0);
+        acc_sum += acc[0] + acc[1] + acc[2] + acc[3];
+    }
+    long long t1 = clock64();
+    out[threadIdx.x] = acc_sum;
+    if (lane == 0) cyc[wave] = t1 - t0;
+}
+
+__global__ __launch_bounds__(512) void k_yty_valu(double *out, long long *cyc)
+{
+    __shared__ double ys[YK * YS];
+    for (int i = threadIdx.x; i < YK * YS; i += 512) ys[i] = 1e-3 * ((i * 7) % 113);
+    __syncthreads();
+    // 160 x 160 outputs = 1600 register tiles of 4 x 4; thread t owns tiles t, t + 512, ... (3.125 each):
+    // per k: 4 + 4 LDS operands (two ds_read_b128 were it aligned; plain loads here) feed 16 FMAs
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    double acc_sum = 0;
+    long long t0 = clock64();
+    for (int tile = threadIdx.x; tile < 1600; tile += 512) {
+        const int i0 = (tile % 40) * 4, j0 = (tile / 40) * 4;
+        double c[4][4] = {};
+#pragma unroll 4
+        for (int k = 0; k < YK; k++) {
+            double a[4], b[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) { a[u] = ys[k * YS + i0 + u]; b[u] = ys[k * YS + j0 + u]; }
+#pragma unroll
+            for (int u = 0; u < 4; u++)
+#pragma unroll
+                for (int v = 0; v < 4; v++) c[u][v] = __builtin_fma(a[u], b[v], c[u][v]);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++)
+#pragma unroll
+            for (int v = 0; v < 4; v++) acc_sum += c[u][v];
+    }
+    long long t1 = clock64();
+    out[threadIdx.x] = acc_sum;
+    if (lane == 0) cyc[wave] = t1 - t0;
+}
+
 __global__ void k_fma_dep(double *out, long long *cyc)
 {
     double x = threadIdx.x * 1e-3, a = 1.0000001, b = 1e-9;
@@ -175,6 +234,18 @@ int main()
         hipLaunchKernelGGL(k_mfma_ind, dim3(1), dim3(threads), 0, 0, out, cyc); report("mfma f64 16x16x4 4 accumulators", threads / 64);
     }
     for (int threads : {64, 256, 512, 1024}) { hipLaunchKernelGGL(k_mfma_lds, dim3(1), dim3(threads), 0, 0, out, cyc); report("mfma f64, 3 acc, A from LDS per block", threads / 64); }
+    {
+        auto whole = [&](const char *name) {
+            hipDeviceSynchronize();
+            hipMemcpy(h, cyc, sizeof(h), hipMemcpyDeviceToHost);
+            long long mx = 0; for (int i = 0; i < 8; i++) if (h[i] > mx) mx = h[i];
+            printf("%-58s %8lld ticks for 1.02 M MACs (%.1f MAC/clk/CU)\n", name, mx, 160.0 * 160 * 40 / mx);
+        };
+        for (int rep = 0; rep < 2; rep++) {
+            hipLaunchKernelGGL(k_yty_mfma, dim3(1), dim3(512), 0, 0, out, cyc); whole("P -= Y'Y shape, MFMA 16x16x4 tiles, operands from LDS");
+            hipLaunchKernelGGL(k_yty_valu, dim3(1), dim3(512), 0, 0, out, cyc); whole("P -= Y'Y shape, LDS-tiled VALU (4x4 register tiles)");
+        }
+    }
     for (int threads : {64, 256, 1024}) { hipLaunchKernelGGL(k_fma_dep, dim3(1), dim3(threads), 0, 0, out, cyc); report("v_fma_f64 dependent", threads / 64); }
     for (int threads : {64, 256, 1024}) { hipLaunchKernelGGL(k_fma_ind, dim3(1), dim3(threads), 0, 0, out, cyc); report("v_fma_f64 8 independent", threads / 64); }
     hipLaunchKernelGGL(k_rsq_dep, dim3(1), dim3(64), 0, 0, out, cyc); report("v_rsq_f64 + add dependent", 1);
