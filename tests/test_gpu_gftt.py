@@ -88,3 +88,17 @@ def test_detector_on_the_batched_device_path_and_errors(oracle, seq752):
         gp = capi.gftt_default_params()
         rc = capi.lib().hv_gftt_detect(ctx._h, capi.C.byref(gp), slots[0], None, 0, 0, out.ctypes.data_as(capi.f32p), 3, capi.C.byref(n))
         assert rc == -1                                                     # capacity too small
+
+
+def test_device_detector_against_committed_golden_fixture():
+    """No oracle involved: the HIP detector against tests/golden/gftt_golden.npz."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "gftt_golden.npz"))
+    img = g["img"]
+    with _ctx(img.shape[1], img.shape[0]) as ctx:
+        s = ctx.acquire(); ctx.build(s, img)
+        for bs, md in ((8, 8.0), (16, 20.0), (32, 50.0)):
+            gp = capi.gftt_default_params(gfttMinDistance=md, maxTracks=30)
+            assert np.array_equal(_device_keypoints(ctx, [s], gp)[0], g[f"kp{bs}"])
+            assert np.array_equal(ctx.gftt_detect(s, params=gp), g[f"raw{bs}"])
+            assert np.array_equal(ctx.gftt_detect(s, prev=g["prev"], mask_radius=int(md), params=gp), g[f"masked{bs}"])

@@ -109,3 +109,15 @@ def test_detect_reproduces_the_zero_point_prefix_and_ordering():
     assert out[0].tolist() == [0.0, 0.0] and len(out) <= 200                   # the bogus origin corner survives the mask
     d = np.linalg.norm(out[:, None] - out[None], axis=2) + 1e9 * np.eye(len(out))
     assert d.min() >= 50 and np.linalg.norm(out[:, None] - prev[None], axis=2).min() >= 50
+
+
+def test_oracle_matches_committed_golden_fixture():
+    import os
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "gftt_golden.npz"))
+    resp = orc.corner_min_eigen_val(g["img"])
+    assert resp.astype(np.float64).sum() == g["response_checksum"][0]
+    for bs, md in ((8, 8.0), (16, 20.0), (32, 50.0)):
+        assert np.array_equal(orc.gftt_collect_max(resp, bs, 1e-3), g[f"kp{bs}"])
+        assert np.array_equal(orc.gftt_detect(g["img"], mask_radius=0, min_distance=md), g[f"raw{bs}"])
+        assert np.array_equal(orc.gftt_detect(g["img"], prev=g["prev"], mask_radius=int(md), min_distance=md, max_tracks=30),
+                              g[f"masked{bs}"])
