@@ -234,6 +234,9 @@ int main()
         hipLaunchKernelGGL(k_mfma_ind, dim3(1), dim3(threads), 0, 0, out, cyc); report("mfma f64 16x16x4 4 accumulators", threads / 64);
     }
     for (int threads : {64, 256, 512, 1024}) { hipLaunchKernelGGL(k_mfma_lds, dim3(1), dim3(threads), 0, 0, out, cyc); report("mfma f64, 3 acc, A from LDS per block", threads / 64); }
+    // the same with every CU busy (blocks all write the same stamps; any block's value will do): does the chip
+    // hold its clock under f64 MFMA load on all 256 CUs?
+    for (int rep = 0; rep < 3; rep++) { hipLaunchKernelGGL(k_mfma_lds, dim3(1024), dim3(512), 0, 0, out, cyc); report("same, 1024 workgroups (all CUs busy)", 8); }
     {
         auto whole = [&](const char *name) {
             hipDeviceSynchronize();
