@@ -226,3 +226,32 @@ def test_full_size_property_identity_tracking(oracle, seq752):
         xy, st, err = ctx.klt_track(s, s, pts)
         assert st.all() and not err.any()
         assert np.abs(xy - pts).max() < 1e-4
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_randomised_shapes_motions_and_points(oracle, seed):
+    """Seeded sweep over image sizes (odd / tiny / non-multiple-of-4 strides -> every border and unaligned path),
+    textures from noise to smooth, motions up to several pixels, points anywhere incl. far outside, with and
+    without an initial guess and with iteration caps: pyramid bit-exact, LK status and positions identical."""
+    rng = np.random.default_rng(1000 + seed)
+    h, w = int(rng.integers(48, 300)), int(rng.integers(48, 400))
+    kind = seed % 3
+    if kind == 0:
+        a = rng.integers(0, 256, (h, w), dtype=np.uint8); b = np.roll(a, (int(rng.integers(-3, 4)), int(rng.integers(-3, 4))), (0, 1))
+    else:
+        tex = synth.Texture.make(seed)
+        a = synth.render(tex, w, h, synth.Warp.make(0, 0, 0, w / 2, h / 2))
+        b = synth.render(tex, w, h, synth.Warp.make(*rng.uniform(-1, 1, 1), *rng.uniform(-4, 4, 2), w / 2, h / 2),
+                         noise_seed=seed, noise_sigma=float(rng.uniform(0, 3)))
+    n = int(rng.integers(1, 150))
+    pts = rng.uniform([-40, -40], [w + 40, h + 40], (n, 2)).astype(np.float32)
+    pts[: n // 2] = rng.uniform([0, 0], [w, h], (n // 2, 2)).astype(np.float32)
+    with _ctx(w, h) as ctx:
+        sa, sb = ctx.acquire(), ctx.acquire()
+        ctx.build(sa, a); ctx.build(sb, b)
+        ra = _check_pyramid(ctx, oracle, a, sa)
+        rb = _check_pyramid(ctx, oracle, b, sb)
+        _compare_klt(ctx, oracle, ra, rb, sa, sb, pts)
+        guess = (pts + rng.normal(0, 3.0, pts.shape)).astype(np.float32)
+        _compare_klt(ctx, oracle, ra, rb, sa, sb, pts, guess=guess)
+        _compare_klt(ctx, oracle, rb, ra, sb, sa, pts, max_iter_override=int(rng.integers(1, 6)))
