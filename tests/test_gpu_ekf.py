@@ -361,3 +361,26 @@ def test_closed_loop_replay(oracle, ctx, frames):
     m, P = g.get_state(0)
     print(f"closed loop {frames} frames: {applied} updates, {rejected} rejected, rel err m {rel(m, o.m):.2e} P {rel(P, o.P):.2e}")
     assert rel(m, o.m) <= TOL and rel(P, o.P) <= TOL, (rel(m, o.m), rel(P, o.P))
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_randomised_update_shapes(oracle, ctx, seed):
+    """Seeded sweep over (trail length, measurement rows, columns of H): gate status / chi2 and the updated
+    state against the oracle, whatever kernel variant and tile raggedness the shape selects."""
+    rng = np.random.default_rng(500 + seed)
+    trail = int(rng.choice([1, 3, 5, 12, 20]))
+    os_, g = make_pair(oracle, ctx, rng, batch=2, trail=trail)
+    n = g.n
+    nr = int(rng.integers(1, min(n, 100) + 1))
+    l = int(rng.integers(max(20, min(nr, n) // 2), n + 1))
+    H = rng.normal(size=(2, nr, l))
+    f = rng.normal(size=(2, nr))
+    y = f + 0.05 * rng.normal(size=(2, nr))
+    chi2, st = g.visual_gate(H, y - f, 0.05)
+    for b, o in enumerate(os_):
+        so, co = o.visual_track_outlier_check(H[b], f[b], y[b], 0.05)
+        assert st[b] == so and abs(chi2[b] - co) <= 1e-9 * max(1.0, abs(co)), (trail, nr, l, b, chi2[b], co)
+    g.visual_update(H, y - f, 0.05)
+    for b, o in enumerate(os_):
+        o.update_visual_track(H[b], f[b], y[b], 0.05)
+    assert check(os_, g) < 1e-9, (trail, nr, l)
