@@ -407,7 +407,7 @@ struct UpdateArgs {
     int n, nr, l, R, Rs;              // R = nr + n + 1 rows of the tall matrix; Rs = its column stride
     int mode;                         // 0 gate only, 1 update, 2 update only if the chi2 gate passes
     int generic;                      // residual = y - H m[0:l] (ekf.cpp:76-79) instead of the given v
-    int normalize_all, use_lds;
+    int normalize_all, use_lds, map_dim;
     double *m, *P;
     const double *H, *v;              // per filter: nr*l column-major, nr
     const double *rdiag;              // per filter diagonal of R (already scaled), or null -> rd0
@@ -794,7 +794,7 @@ __global__ __launch_bounds__(UPD_THREADS) void ekf_update_kernel(UpdateArgs a)
     __syncthreads();
     PHASE_STAMP(5);
     // ---- G: quaternion normalisation (updateCommon ekf.cpp:29-31 / normalizeQuaternions 1024-1032) ----
-    const int nq = a.normalize_all ? 1 + (n - CAM) / POSE : 1;
+    const int nq = a.normalize_all ? 1 + (n - a.map_dim - CAM) / POSE : 1;     // map points behind the trail are not poses
     if (t < nq) normalize4(m + (t == 0 ? ORI : CAM + POSE * (t - 1) + 3));
 }
 
@@ -1135,7 +1135,7 @@ static int ekf_launch_update(Ekf *e, int nr, int l, const double *H_dev, const d
     int r_pad = a.R;
     while ((r_pad & 31) != 15 && (r_pad & 31) != 17) r_pad++;
     a.Rs = r_pad;
-    a.mode = mode; a.generic = generic; a.normalize_all = normalize_all;
+    a.mode = mode; a.generic = generic; a.normalize_all = normalize_all; a.map_dim = e->map_dim;
     a.m = e->m; a.P = e->P; a.H = H_dev; a.v = v_dev; a.rdiag = rdiag_dev; a.rd0 = rd0; a.noise_scale = e->noise_scale;
     a.ws = e->ws; a.chi2 = chi2_dev; a.status = status_dev; a.active = active_dev;
     size_t tall = (((size_t)a.Rs * nr + 1) & ~(size_t)1) * sizeof(double);
@@ -1457,6 +1457,14 @@ int hv_ekf_augment(hv_ekf *h, const int *discarded, const unsigned char *active)
     a.q_ori = e->par.noiseInitialOriTrail * e->par.noiseInitialOriTrail * e->noise_scale;
     a.rd = e->par.augmentR * e->noise_scale;
     const size_t shmem = sizeof(double) * (3 * hv::POSE * e->n + 2 * hv::POSE * hv::POSE + hv::POSE + 1 + (hv::AUG_THREADS / 64) * 16 * 17);
+    if (shmem > 64 * 1024) {                 // state vectors with map points (n > ~190): beyond the default dynamic-LDS limit
+        if (shmem > 158 * 1024) return HV_ERR_UNSUPPORTED;
+        static bool aug_attr_set = false;
+        if (!aug_attr_set) {
+            HV_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void *>(hv::ekf_augment_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024));
+            aug_attr_set = true;
+        }
+    }
     hv::ScopedKernelTime tm(c, HV_K_EKF_AUGMENT);
     hipLaunchKernelGGL(hv::ekf_augment_kernel, dim3(e->batch), dim3(hv::AUG_THREADS), shmem, c->stream, a);
     HV_HIP(c, hipGetLastError());

@@ -384,3 +384,49 @@ def test_randomised_update_shapes(oracle, ctx, seed):
     for b, o in enumerate(os_):
         o.update_visual_track(H[b], f[b], y[b], 0.05)
     assert check(os_, g) < 1e-9, (trail, nr, l)
+
+
+def test_hybrid_map_state_n_above_160(oracle, ctx):
+    """hybridMapSize > 0 (state 20 + 7*20 + 3*15 = 205): every kernel on a state wider than the 160-column fast
+    path -- predict (off-diagonal tiles beyond the trail), augmentation / undo (map rows must not shift,
+    dynamic LDS above 64 KB), symmetrise, gate and update (LDS / global-workspace kernels)."""
+    rng = np.random.default_rng(99)
+    po, pg = same_params(oracle, hybridMapSize=15)
+    g = capi.EkfBatch(ctx, pg, 2)
+    os_ = []
+    for b in range(2):
+        o = oracle.Ekf(po)
+        m, P = random_state(rng, o.n, 20)
+        o.set_state(m); o.set_cov(P); g.set_state(b, m, P); os_.append(o)
+    assert g.n == 205
+    for o in os_:
+        o.set_first_sample_time(0.0)
+    t = 0.0
+    for k in (19, 17, -1):
+        for _ in range(3):
+            t += 0.005
+            gy, ac = rng.normal(0, 0.1, (2, 3)), rng.normal(0, 0.5, (2, 3)) + [0, 0, 9.8]
+            g.predict(np.full(2, 0.005), gy, ac)
+            for b, o in enumerate(os_):
+                o.predict(t, gy[b], ac[b])
+        g.augment([k, k])
+        for o in os_:
+            o.update_visual_pose_augmentation(k)
+        assert check(os_, g) < 1e-9
+    g.undo_augment()
+    for o in os_:
+        o.update_undo_augmentation()
+    g.symmetrize()
+    for o in os_:
+        o.maintain_psd()
+    assert check(os_, g) < 1e-9
+    for nr, l in ((24, 205), (60, 160), (8, 97)):
+        H = rng.normal(size=(2, nr, l)); f = rng.normal(size=(2, nr)); y = f + 0.05 * rng.normal(size=(2, nr))
+        chi2, st = g.visual_gate(H, y - f, 0.05)
+        for b, o in enumerate(os_):
+            so, co = o.visual_track_outlier_check(H[b], f[b], y[b], 0.05)
+            assert st[b] == so and abs(chi2[b] - co) <= 1e-9 * max(1.0, abs(co))
+        g.visual_update(H, y - f, 0.05)
+        for b, o in enumerate(os_):
+            o.update_visual_track(H[b], f[b], y[b], 0.05)
+        assert check(os_, g) < 1e-9
