@@ -255,3 +255,47 @@ def test_randomised_shapes_motions_and_points(oracle, seed):
         guess = (pts + rng.normal(0, 3.0, pts.shape)).astype(np.float32)
         _compare_klt(ctx, oracle, ra, rb, sa, sb, pts, guess=guess)
         _compare_klt(ctx, oracle, rb, ra, sb, sa, pts, max_iter_override=int(rng.integers(1, 6)))
+
+
+@pytest.mark.parametrize("levels,max_iter,eps,min_eig", [(1, 20, 0.03, 1e-3), (2, 5, 0.1, 1e-2), (3, 30, 0.01, 1e-4),
+                                                           (4, 1, 0.03, 1e-3), (4, 100, 0.001, 1e-5)])
+def test_tracker_parameters_other_than_the_defaults(oracle, seq752, levels, max_iter, eps, min_eig):
+    """pyrLKMaxLevel / pyrLKMaxIter / pyrLKEpsilon / pyrLKMinEigThreshold (parameter_definitions.c) other than
+    HybVIO's defaults reach the kernel through hv_params."""
+    left, _, _ = seq752
+    rng = np.random.default_rng(levels * 10 + max_iter)
+    pts = np.concatenate([synth.grid_points(752, 480, 120), rng.uniform([-20, -20], [770, 500], (40, 2)).astype(np.float32)])
+    with _ctx(752, 480, levels=levels, max_iter=max_iter, eps=eps, min_eig=min_eig) as ctx:
+        assert ctx.levels == levels
+        s0, s1 = ctx.acquire(), ctx.acquire()
+        ctx.build(s0, left[0]); ctx.build(s1, left[1])
+        r0 = oracle.Pyramid(left[0], max_level=levels - 1); r1 = oracle.Pyramid(left[1], max_level=levels - 1)
+        o_xy, o_st, o_err = oracle.klt_track(r0, r1, pts, max_level=levels - 1, max_count=max_iter, eps=eps, min_eig=min_eig)
+        g_xy, g_st, g_err = ctx.klt_track(s0, s1, pts)
+        np.testing.assert_array_equal(g_st, o_st)
+        np.testing.assert_array_equal(g_xy, o_xy)
+        np.testing.assert_array_equal(g_err, o_err)
+
+
+def test_level0_used_in_place_with_a_padded_row_stride(oracle, seq752):
+    """hv_pyramid_build_batch_dev uses the caller's images as level 0 without copying them: row stride > width
+    (and an image stride that is not the packed size) must reach the pyramid, LK and GFTT kernels alike."""
+    import torch
+    left, right, _ = seq752
+    imgs = np.stack([left[0], left[1], right[1]])
+    stride, pitch = 800, 800 * 480 + 4096
+    buf = np.full((3, pitch), 213, np.uint8)
+    for i in range(3):
+        buf[i, :800 * 480].reshape(480, 800)[:, :752] = imgs[i]
+    with _ctx(752, 480, pool_size=4) as ctx:
+        ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+        d_buf = torch.from_numpy(buf).cuda()
+        slots = [ctx.acquire() for _ in range(3)]
+        d_slots = torch.tensor(slots, dtype=torch.int32, device="cuda")
+        ctx.build_batch_dev(3, d_slots.data_ptr(), d_buf.data_ptr(), pitch, stride)
+        ctx.synchronize()
+        refs = [_check_pyramid(ctx, oracle, imgs[i], slots[i]) for i in range(3)]
+        pts = synth.grid_points(752, 480, 150)
+        xy, st = _compare_klt(ctx, oracle, refs[0], refs[1], slots[0], slots[1], pts)
+        _compare_klt(ctx, oracle, refs[1], refs[2], slots[1], slots[2], xy)
+        assert np.array_equal(ctx.gftt_detect(slots[1], prev=xy, mask_radius=30), oracle.gftt_detect(imgs[1], prev=xy, mask_radius=30))
