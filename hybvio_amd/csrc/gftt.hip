@@ -68,23 +68,31 @@ __global__ __launch_bounds__(256) void gftt_block_kernel(GfttArgs a)
     const uint8_t *src = a.l0_ptr[slot];
     const int stride = a.l0_stride[slot];
 
-    // ---- stage the gray tile as floats: dword loads where the 4 bytes are inside the image ----
+    // ---- stage the gray tile as floats: one (unaligned) 8-byte load and two 16-byte LDS stores per task where
+    // the 8 pixels are inside the image, per-byte BORDER_REFLECT_101 otherwise ----
     {
-        const bool aligned = ((reinterpret_cast<uintptr_t>(src) | (uintptr_t)stride) & 3u) == 0;
-        constexpr int DW = (GW + 4 + 3) / 4;          // dwords per row covering image columns x0 - 4 .. x0 + BS + 3
-        for (int i = t; i < GW * DW; i += 256) {
-            const int ty = i / DW, d = i - ty * DW;
+        constexpr int NC = (GW + 7) / 8;              // 8-pixel chunks per tile row (the last one may be half used)
+        for (int i = t; i < GW * NC; i += 256) {
+            const int ty = i / NC, q = i - ty * NC;
             const uint8_t *row = src + (size_t)reflect101(y0 - 2 + ty, h) * stride;
-            const int x = x0 - 4 + 4 * d;             // image column of byte 0 of this dword
-            uint32_t v;
-            if (aligned && x >= 0 && x + 4 <= w) v = *reinterpret_cast<const uint32_t *>(row + x);
-            else v = (uint32_t)row[reflect101(x, w)] | ((uint32_t)row[reflect101(x + 1, w)] << 8) |
-                     ((uint32_t)row[reflect101(x + 2, w)] << 16) | ((uint32_t)row[reflect101(x + 3, w)] << 24);
+            const int x = x0 - 2 + 8 * q;             // image column of byte 0 of this chunk
+            uint32_t lo, hi;
+            if (x >= 0 && x + 8 <= w) {
+                uint2 v;
+                __builtin_memcpy(&v, row + x, 8);
+                lo = v.x; hi = v.y;
+            } else {
+                lo = hi = 0;
 #pragma unroll
-            for (int k = 0; k < 4; k++) {
-                const int c = 4 * d + k - 2;          // tile column
-                if (c >= 0 && c < GW) gray[ty * GW + c] = (float)((v >> (8 * k)) & 0xFFu);
+                for (int k = 0; k < 4; k++) {
+                    lo |= (uint32_t)row[reflect101(x + k, w)] << (8 * k);
+                    hi |= (uint32_t)row[reflect101(x + 4 + k, w)] << (8 * k);
+                }
             }
+            float *dst = &gray[ty * GW + 8 * q];
+            *reinterpret_cast<float4v *>(dst) = float4v{(float)(lo & 0xFFu), (float)((lo >> 8) & 0xFFu), (float)((lo >> 16) & 0xFFu), (float)(lo >> 24)};
+            if (8 * q + 4 < GW)
+                *reinterpret_cast<float4v *>(dst + 4) = float4v{(float)(hi & 0xFFu), (float)((hi >> 8) & 0xFFu), (float)((hi >> 16) & 0xFFu), (float)(hi >> 24)};
         }
     }
     __syncthreads();
