@@ -1,6 +1,7 @@
 /*
  * hybvio_hip.h -- C ABI of libhybvio_hip.so: the MI355X (gfx950) implementation of HybVIO's
- * per-frame hot path (image pyramid + pyramidal Lucas-Kanade tracker + EKF covariance algebra).
+ * per-frame hot path (image pyramid + pyramidal Lucas-Kanade tracker + EKF covariance algebra) and of
+ * its GFTT feature detector.
  *
  * Plain pointers and sizes only; no C++/torch types cross this boundary. Every entry point
  * returns HV_OK (0) or a negative hv_status; nothing throws. All device work of one hv_ctx is
