@@ -29,7 +29,7 @@ f32p = C.POINTER(C.c_float)
 f64p = C.POINTER(C.c_double)
 
 HV_MAX_LEVELS = 6
-K_PYR_L0, K_PYR_LN, K_KLT, K_EKF_PREDICT, K_EKF_UPDATE, K_EKF_AUGMENT, K_GFTT = range(7)
+K_PYR_L0, K_PYR_LN, K_KLT, K_EKF_PREDICT, K_EKF_UPDATE, K_EKF_AUGMENT, K_GFTT, K_INGEST = range(8)
 
 # tracker::Feature::Status (src/tracker/track.hpp:9-21)
 ST_TRACKED, ST_NEW, ST_FAILED_FLOW, ST_RANSAC_OUTLIER, ST_FLOW_OUT_OF_RANGE = 0, 1, 2, 3, 4
@@ -76,6 +76,9 @@ PROTOTYPES = {
     "hv_pyramid_release": (C.c_int, [C.c_void_p, C.c_int]),
     "hv_pyramid_level_size": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "hv_pyramid_build": (C.c_int, [C.c_void_p, C.c_int, u8p, C.c_int]),
+    "hv_ingest_set_undistort_map": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
+    "hv_ingest_build": (C.c_int, [C.c_void_p, C.c_int, u8p, C.c_int, C.c_int, C.c_int]),
+    "hv_ingest_build_batch_dev": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_longlong, C.c_int, C.c_int, C.c_int]),
     "hv_pyramid_build_batch_dev": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_longlong, C.c_int]),
     "hv_pyramid_download": (C.c_int, [C.c_void_p, C.c_int, C.c_int, u8p, i16p]),
     "hv_klt_track": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, f32p, f32p, u8p, f32p, C.c_int, C.c_int]),
@@ -214,6 +217,32 @@ class Context:
     def build_batch_dev(self, n: int, slots_dev: int, gray_dev: int, image_stride: int, row_stride: int):
         self._chk(lib().hv_pyramid_build_batch_dev(self._h, n, C.c_void_p(slots_dev), C.c_void_p(gray_dev),
                                                    image_stride, row_stride), "hv_pyramid_build_batch_dev")
+
+    # ---- image ingest (f2): colour -> gray and the undistort / rectify remap in front of the pyramid ----
+    def ingest_set_undistort_map(self, camera: int, pix_orig=None, valid=None):
+        """pix_orig (h, w, 2) f64 = original-image position of every rectified pixel (None removes the table)."""
+        if pix_orig is None:
+            self._chk(lib().hv_ingest_set_undistort_map(self._h, camera, None, None), "hv_ingest_set_undistort_map")
+            return
+        pix = np.ascontiguousarray(pix_orig, np.float64)
+        assert pix.shape == (self.params.height, self.params.width, 2), pix.shape
+        v = None if valid is None else np.ascontiguousarray(valid, np.uint8)
+        self._chk(lib().hv_ingest_set_undistort_map(self._h, camera, pix.ctypes.data_as(C.c_void_p),
+                                                    None if v is None else v.ctypes.data_as(C.c_void_p)),
+                  "hv_ingest_set_undistort_map")
+
+    def ingest_build(self, slot: int, image: np.ndarray, camera: int = -1):
+        """image (h, w) gray or (h, w, 3|4) colour, u8."""
+        image = np.ascontiguousarray(image, np.uint8)
+        ch = 1 if image.ndim == 2 else image.shape[2]
+        assert image.shape[:2] == (self.params.height, self.params.width), image.shape
+        self._chk(lib().hv_ingest_build(self._h, slot, _p(image, u8p), image.strides[0], ch, camera), "hv_ingest_build")
+        self.synchronize()
+
+    def ingest_build_batch_dev(self, n: int, slots_dev: int, src_dev: int, image_stride: int, row_stride: int,
+                               channels: int = 1, camera: int = -1):
+        self._chk(lib().hv_ingest_build_batch_dev(self._h, n, C.c_void_p(slots_dev), C.c_void_p(src_dev), image_stride,
+                                                  row_stride, channels, camera), "hv_ingest_build_batch_dev")
 
     def download(self, slot: int, level: int):
         w, h = self.level_sizes[level]

@@ -100,7 +100,18 @@ using hv::Ctx;
 extern "C" {
 struct hv_ctx { Ctx c; };
 }
-namespace hv { Ctx *ctx_of(hv_ctx *h) { return h ? &h->c : nullptr; } }
+namespace hv {
+Ctx *ctx_of(hv_ctx *h) { return h ? &h->c : nullptr; }
+// all level kernels over the level-0 image already sitting in the slot
+int build_levels_of_slot(Ctx *c, int slot)
+{
+    const PyrLayout &L = c->L;
+    IntPack pk{{slot, 0, 0, 0}};
+    hipLaunchKernelGGL(set_ints_kernel, dim3(1), dim3(64), 0, c->stream, c->d_slots, pk, 1);
+    HV_HIP(c, hipGetLastError());
+    return launch_pyramid_levels(c, 1, c->d_slots, c->slab + L.goff[0], L.slot_bytes, L.gstride[0], true);
+}
+}
 
 extern "C" {
 
@@ -186,6 +197,9 @@ void hv_destroy(hv_ctx *h)
     if (c->d_err) (void)hipFree(c->d_err);
     if (c->d_status) (void)hipFree(c->d_status);
     if (c->d_gftt_kp) (void)hipFree(c->d_gftt_kp);
+    if (c->d_ingest_stage) (void)hipFree(c->d_ingest_stage);
+    for (int k = 0; k < HV_INGEST_CAMERAS; ++k)
+        if (c->d_map_xy[k]) { (void)hipFree(c->d_map_xy[k]); (void)hipFree(c->d_map_xf[k]); (void)hipFree(c->d_map_yf[k]); }
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
     delete h;
 }

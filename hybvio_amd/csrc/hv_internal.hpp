@@ -54,6 +54,12 @@ struct Ctx {
     int stage_points = 0;
     float *d_gftt_kp = nullptr;           // key points of the single-image detector entry point
     int gftt_cap = 0;
+    // ingest (f2): per-camera remap tables and the staging buffer of the host entry point
+    uint32_t *d_map_xy[HV_INGEST_CAMERAS] = {};
+    float *d_map_xf[HV_INGEST_CAMERAS] = {}, *d_map_yf[HV_INGEST_CAMERAS] = {};
+    int map_stride = 0;
+    uint8_t *d_ingest_stage = nullptr;
+    size_t ingest_stage_bytes = 0;
     std::string last_error;
     bool profiling = false;
     KernelTimer timers[HV_K_COUNT];
@@ -77,6 +83,8 @@ struct ScopedKernelTime {
 // pyramid.hip
 int launch_pyramid_levels(Ctx *c, int n, const int *slots_dev, const uint8_t *src_base,
                           long long src_step, int src_stride, bool src_indexed_by_slot);
+// capi.hip
+int build_levels_of_slot(Ctx *c, int slot);
 // klt.hip
 int launch_klt(Ctx *c, int n_pairs, const int *prev_slots_dev, const int *next_slots_dev,
                int pts_per_pair, int n_points, const float *prev_xy, float *next_xy,

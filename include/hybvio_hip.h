@@ -219,9 +219,33 @@ int hv_gftt_keypoints_batch_dev(hv_ctx *ctx, const hv_gftt_params *p, int n_imag
 void hv_apply_min_distance(float *corners_xy, int *n_inout, const float *prev_xy, int n_prev, int r,
                            int max_tracks);
 
+/* ---- image ingest --------------------------------------------------
+ * Replaces the per-frame work of tracker::Image::Factory::build / buildStereo (src/tracker/image.cpp:272-306):
+ * the colour -> gray copy (image.cpp:351-367, coefficients 0.299 / 0.587 / 0.114 on channels 0, 1, 2) and
+ * tracker::Undistorter::undistort (src/tracker/undistorter.cpp:71-110, the CPU branch: bilinear remap through
+ * rectifiedCamera.pixelToRay -> originalCamera.rayToPixel), followed by the pyramid level kernels. The result is
+ * level 0 of the slot, so the tracker never sees the raw frame.
+ * channels: 1 (gray), 3 (RGB / BGR) or 4 (RGBA / BGRA), 8 bits each, interleaved.
+ * camera: -1 = no remap (tracker.useRectification false, the default: parameter_definitions.c:356), otherwise the
+ * index (0 first / 1 second camera: image.cpp:322-328) of a table installed with hv_ingest_set_undistort_map. */
+#define HV_INGEST_CAMERAS 2
+/* Installs (pix_orig_xy != NULL) or removes (NULL) the remap table of one camera. pix_orig_xy[(y*w + x)*2 + {0,1}]
+ * = the position in the original image of rectified pixel (x, y), i.e. what undistortCpu (undistorter.cpp:56-60)
+ * returns for it, evaluated by the caller with the reference's own Camera objects; valid[y*w + x] = its boolean
+ * result (NULL = all true). The cameras are constant for a session, so this runs once (the reference's GPU branch
+ * makes the same assumption: undistorter.cpp:113-121). Synchronous. */
+int hv_ingest_set_undistort_map(hv_ctx *ctx, int camera, const double *pix_orig_xy, const uint8_t *valid);
+/* H2D copy of one host frame + ingest + all pyramid level kernels into `slot`; asynchronous like hv_pyramid_build. */
+int hv_ingest_build(hv_ctx *ctx, int slot, const uint8_t *image_host, int stride_bytes, int channels, int camera);
+/* n frames resident in HBM (frame i at src_dev + i*image_stride_bytes; base and strides multiples of 4 bytes).
+ * Unlike hv_pyramid_build_batch_dev the result is written into the slots, so the frames may be reused at once.
+ * Asynchronous. */
+int hv_ingest_build_batch_dev(hv_ctx *ctx, int n, const int *slots_dev, const uint8_t *src_dev,
+                              long long image_stride_bytes, int row_stride_bytes, int channels, int camera);
+
 /* ---- per-kernel timing (hipEvents on the context stream) ---------------------------------- */
 enum { HV_K_PYR_L0 = 0, HV_K_PYR_LN = 1, HV_K_KLT = 2, HV_K_EKF_PREDICT = 3, HV_K_EKF_UPDATE = 4,
-       HV_K_EKF_AUGMENT = 5, HV_K_GFTT = 6, HV_K_COUNT = 7 };
+       HV_K_EKF_AUGMENT = 5, HV_K_GFTT = 6, HV_K_INGEST = 7, HV_K_COUNT = 8 };
 int hv_profile_enable(hv_ctx *ctx, int on);
 int hv_profile_reset(hv_ctx *ctx);
 /* Synchronizes, then returns accumulated device milliseconds and launch count of a kernel class. */

@@ -23,7 +23,7 @@ f64p = C.POINTER(C.c_double)
 
 def build(force: bool = False) -> str:
     so = os.path.join(_DIR, "liboracle.so")
-    srcs = [os.path.join(_DIR, f) for f in ("pyrlk_oracle.c", "ekf_oracle.c", "Makefile")]
+    srcs = [os.path.join(_DIR, f) for f in ("pyrlk_oracle.c", "ekf_oracle.c", "gftt_oracle.c", "ingest_oracle.c", "Makefile")]
     if force or not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
         subprocess.check_call(["make", "-C", _DIR, "-B", "liboracle.so"], stdout=subprocess.DEVNULL)
     return so
@@ -52,6 +52,14 @@ def lib():
         L.orc_apply_min_distance.argtypes = [f32p, C.c_int, f32p, C.c_int, C.c_int, C.c_int]
         L.orc_gftt_detect.argtypes = [u8p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_float, f32p, C.c_int,
                                       C.c_int, C.c_int, f32p, C.c_int]
+        L.orc_camera_create.restype = C.c_void_p
+        L.orc_camera_create.argtypes = [C.c_int, C.c_double, C.c_double, C.c_double, C.c_double, C.c_int, f64p, f64p, C.c_double]
+        L.orc_camera_destroy.argtypes = [C.c_void_p]
+        L.orc_camera_pixel_to_ray.argtypes = [C.c_void_p, C.c_double, C.c_double, f64p]
+        L.orc_camera_ray_to_pixel.argtypes = [C.c_void_p, f64p, f64p]
+        L.orc_undistort_map.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, f64p, u8p]
+        L.orc_undistort_apply.argtypes = [u8p, C.c_int, C.c_int, f64p, u8p, u8p]
+        L.orc_color_to_gray.argtypes = [u8p, C.c_int, C.c_int, C.c_int, C.c_int, u8p]
         _LIB = L
     return _LIB
 
@@ -374,3 +382,61 @@ def gftt_detect(img: np.ndarray, prev=(), mask_radius: int = 0, block_size: int 
     if n < 0:
         raise RuntimeError(f"orc_gftt_detect failed: {n}")
     return out[:n].copy()
+
+
+# ---- image ingest: colour -> gray, undistort / rectify remap (oracle/ingest_oracle.c) ----
+class Camera:
+    """tracker::Camera (camera.cpp): kind 'pinhole' (radial k1..k3, optional rotation) or 'fisheye' (k1..k4)."""
+
+    def __init__(self, kind, fx, fy, ppx, ppy, coeffs=(), rotation=None, max_valid_fov_deg=180.0):
+        co = np.ascontiguousarray(coeffs, np.float64).reshape(-1)
+        rot = None if rotation is None else np.ascontiguousarray(rotation, np.float64).reshape(9)
+        self.h = C.c_void_p(lib().orc_camera_create({"pinhole": 0, "fisheye": 1}[kind], fx, fy, ppx, ppy, len(co),
+                                                    _p(co, f64p) if len(co) else None,
+                                                    _p(rot, f64p) if rot is not None else None, max_valid_fov_deg))
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().orc_camera_destroy(self.h)
+            self.h = None
+
+    def pixel_to_ray(self, x, y):
+        ray = np.zeros(3)
+        ok = lib().orc_camera_pixel_to_ray(self.h, float(x), float(y), _p(ray, f64p))
+        return bool(ok), ray
+
+    def ray_to_pixel(self, ray):
+        r = np.ascontiguousarray(ray, np.float64)
+        pix = np.zeros(2)
+        ok = lib().orc_camera_ray_to_pixel(self.h, _p(r, f64p), _p(pix, f64p))
+        return bool(ok), pix
+
+
+def mono_rectified_camera(w, h, focal_length, zoom=1.0):
+    """Undistorter::buildMono (undistorter.cpp:150-168): equal focal lengths, principal point at the image centre."""
+    f = np.float32(focal_length) * np.float32(zoom)          # float focalLength * float rectificationZoom
+    return Camera("pinhole", float(f), float(f), float(np.float32(w) * np.float32(0.5)), float(np.float32(h) * np.float32(0.5)))
+
+
+def undistort_map(rect: Camera, orig: Camera, w: int, h: int):
+    pix = np.zeros((h, w, 2), np.float64)
+    valid = np.zeros((h, w), np.uint8)
+    lib().orc_undistort_map(rect.h, orig.h, w, h, _p(pix, f64p), _p(valid, u8p))
+    return pix, valid
+
+
+def undistort_apply(img: np.ndarray, pix_orig: np.ndarray, valid: np.ndarray) -> np.ndarray:
+    img = np.ascontiguousarray(img, np.uint8)
+    h, w = img.shape
+    out = np.zeros((h, w), np.uint8)
+    lib().orc_undistort_apply(_p(img, u8p), w, h, _p(np.ascontiguousarray(pix_orig, np.float64), f64p),
+                              _p(np.ascontiguousarray(valid, np.uint8), u8p), _p(out, u8p))
+    return out
+
+
+def color_to_gray(img: np.ndarray) -> np.ndarray:
+    img = np.ascontiguousarray(img, np.uint8)
+    h, w, ch = img.shape
+    out = np.zeros((h, w), np.uint8)
+    lib().orc_color_to_gray(_p(img, u8p), w * ch, w, h, ch, _p(out, u8p))
+    return out
