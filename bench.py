@@ -362,6 +362,64 @@ def aggregate_value(units_per_rank_step: int, world: int, steps: int, seconds: f
     return world * units_per_rank_step * steps / seconds
 
 
+def radial_undistort_map(w, h):
+    """Synthetic remap table of the bench: EuRoC cam0 (pinhole, radial k1 k2) seen through the mono rectified pinhole
+    of Undistorter::buildMono -- rectified pixel -> ray -> forward distortion -> original pixel, in float64 numpy."""
+    import numpy as np
+    fx, fy, cx, cy, k1, k2 = 458.654, 457.296, 367.215, 248.375, -0.28340811, 0.07395907
+    f = 458.0 * 0.9
+    yy, xx = np.mgrid[0:h, 0:w].astype(np.float64)
+    x, y = (xx - w * 0.5) / f, (yy - h * 0.5) / f
+    r2 = x * x + y * y
+    th = 1 + r2 * (k1 + r2 * k2)
+    return np.ascontiguousarray(np.dstack([fx * x * th + cx, fy * y * th + cy]))
+
+
+def bench_ingest(tb, n, local_rank, cpu_baseline):
+    """f2: the ingest kernel alone (HV_K_INGEST events) for n frames per launch in its three shapes."""
+    import numpy as np
+    import torch
+    from hybvio_amd import capi
+    dev = f"cuda:{local_rank}"
+    pix = radial_undistort_map(W, H)
+    gray = tb.frames[0, 0, :n].contiguous()
+    g = torch.Generator(device=dev); g.manual_seed(5)
+    rgb = (gray[..., None].to(torch.int16) + torch.randint(-40, 41, (n, H, W, 3), device=dev, generator=g, dtype=torch.int16)
+           ).clamp_(0, 255).to(torch.uint8).contiguous()
+    res = {"workload": f"{n} frames {W}x{H} per launch written into level 0 of their pyramid slots "
+                       "(Image::Factory::build: colour -> gray copy, Undistorter::undistort), ingest kernel alone",
+           "modes": {}}
+    with capi.Context(width=W, height=H, pool_size=n, max_tracks=8) as ctx:
+        ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+        ctx.ingest_set_undistort_map(0, pix)
+        slots = torch.tensor([ctx.acquire() for _ in range(n)], dtype=torch.int32, device=dev)
+        table = 12 * W * H
+        for name, src, ch, cam in (("rgb_to_gray", rgb, 3, -1), ("gray_remap", gray, 1, 0), ("rgb_remap", rgb, 3, 0)):
+            for _ in range(3):
+                ctx.ingest_build_batch_dev(n, slots.data_ptr(), src.data_ptr(), W * H * ch, W * ch, ch, cam)
+            ctx.profile_enable(True); ctx.profile_reset()
+            for _ in range(20):
+                ctx.ingest_build_batch_dev(n, slots.data_ptr(), src.data_ptr(), W * H * ch, W * ch, ch, cam)
+            ms, cnt = ctx.profile_read(capi.K_INGEST)
+            ctx.profile_enable(False)
+            nbytes = n * W * H * (ch + 1) + (table if cam >= 0 else 0)     # source once + gray out (+ the shared table once)
+            res["modes"][name] = {"avg_ms": ms / cnt, "frames_per_s": n / (ms / cnt * 1e-3), "algorithmic_bytes_per_launch": nbytes,
+                                  "achieved_GBs": nbytes / (ms / cnt * 1e-3) / 1e9,
+                                  "frac_of_8TBs": nbytes / (ms / cnt * 1e-3) / 1e9 / HBM_PEAK_GBS}
+    if cpu_baseline:
+        from oracle import orc
+        img, col = gray[0].cpu().numpy(), rgb[0].cpu().numpy()
+        valid = np.ones((H, W), np.uint8)
+        t0, reps = time.perf_counter(), 0
+        while time.perf_counter() - t0 < 2.0:
+            orc.undistort_apply(orc.color_to_gray(col), pix, valid); reps += 1
+        res["cpu_baseline"] = {"value": reps / (time.perf_counter() - t0), "unit": "frames/s", "cores": 1, "kind": "port",
+                               "sample": f"{reps} frames rgb_remap with the table precomputed, oracle/ingest_oracle.c -O2 (the reference "
+                                         "re-evaluates both camera models per pixel per frame, which this leaves out)"}
+        del img
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -373,6 +431,7 @@ def main():
     ap.add_argument("--no-latency-mode", action="store_true")
     ap.add_argument("--no-ekf", action="store_true", help="skip the C3 (tracker + HIP EKF) leg")
     ap.add_argument("--no-gftt", action="store_true", help="skip the f1 (GFTT detector kernel) measurement")
+    ap.add_argument("--no-ingest", action="store_true", help="skip the f2 (colour->gray / undistort ingest kernel) measurement")
     ap.add_argument("--c4", action="store_true",
                     help="configs[3] instead of the headline workload: 1280x720 stereo, 400 features (not the default bench line)")
     args = ap.parse_args()
@@ -481,6 +540,9 @@ def main():
             out["f1_gftt"]["cpu_baseline"] = {"value": reps / (time.perf_counter() - t0), "unit": "images/s", "cores": cores,
                                               "kind": "port", "sample": f"{reps} images, oracle/gftt_oracle.c -O2, OpenMP over rows"}
             orc.set_threads(1)
+    # ---- f2: image ingest in front of the pyramid: colour -> gray, undistort remap ----
+    if not args.no_ingest and rank == 0:
+        out["f2_ingest"] = bench_ingest(tb, min(B, 256), local_rank, not args.no_cpu_baseline)
     # ---- C3: the same tracker work + the HIP EKF (configs[2]) ----
     if not args.no_ekf:
         eb = EkfBench(tb.ctx, B, local_rank, seed=rank)

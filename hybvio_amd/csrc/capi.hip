@@ -199,6 +199,8 @@ void hv_destroy(hv_ctx *h)
     if (c->d_gftt_kp) (void)hipFree(c->d_gftt_kp);
     if (c->d_ingest_stage) (void)hipFree(c->d_ingest_stage);
     for (int k = 0; k < HV_INGEST_CAMERAS; ++k)
+        if (c->d_tile_box[k]) (void)hipFree(c->d_tile_box[k]);
+    for (int k = 0; k < HV_INGEST_CAMERAS; ++k)
         if (c->d_map_xy[k]) { (void)hipFree(c->d_map_xy[k]); (void)hipFree(c->d_map_xf[k]); (void)hipFree(c->d_map_yf[k]); }
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
     delete h;

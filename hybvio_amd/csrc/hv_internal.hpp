@@ -58,6 +58,8 @@ struct Ctx {
     uint32_t *d_map_xy[HV_INGEST_CAMERAS] = {};
     float *d_map_xf[HV_INGEST_CAMERAS] = {}, *d_map_yf[HV_INGEST_CAMERAS] = {};
     int map_stride = 0;
+    int *d_tile_box[HV_INGEST_CAMERAS] = {};   // per 64 x 16 output tile: source rectangle (remap_tile_kernel)
+    bool map_tiled[HV_INGEST_CAMERAS] = {};
     uint8_t *d_ingest_stage = nullptr;
     size_t ingest_stage_bytes = 0;
     std::string last_error;

@@ -100,6 +100,25 @@ def test_edge_taps_and_invalid_pixels(oracle):
         assert np.array_equal(g, want)
 
 
+@pytest.mark.parametrize("ch", [1, 3])
+def test_maps_whose_tiles_do_not_fit_the_staging_buffer(oracle, ch):
+    """A 4x minification and a transposing map: the source rectangle of a 64 x 16 output tile exceeds the LDS staging
+    buffer, so the library must take its gather kernel -- same results."""
+    h, w = 256, 320
+    rng = np.random.default_rng(8)
+    img = rng.integers(0, 256, (h, w) if ch == 1 else (h, w, ch), dtype=np.uint8)
+    gray = img if ch == 1 else oracle.color_to_gray(img)
+    yy, xx = np.mgrid[0:h, 0:w].astype(np.float64)
+    maps = [np.dstack([np.minimum(xx * 4.03, w + 5.0), np.minimum(yy * 4.01, h + 5.0)]),      # also runs past the frame
+            np.dstack([yy * (w - 1.5) / (h - 1), xx * (h - 1.5) / (w - 1)])]
+    with capi.Context(width=w, height=h) as ctx:
+        s = ctx.acquire()
+        for pix in maps:
+            ctx.ingest_set_undistort_map(0, pix)
+            ctx.ingest_build(s, img, camera=0)
+            assert np.array_equal(ctx.download(s, 0)[0], oracle.undistort_apply(gray, pix, np.ones((h, w), np.uint8)))
+
+
 @pytest.mark.parametrize("ch,camera", [(1, -1), (3, -1), (4, 0), (1, 1)])
 def test_batch_dev_with_padded_rows(oracle, ch, camera):
     import torch
