@@ -23,6 +23,7 @@ ImagePyramid::~ImagePyramid() = default;
 ImagePyramid::Factory::~Factory() = default;
 OpticalFlow::~OpticalFlow() = default;
 FeatureDetector::~FeatureDetector() = default;
+Undistorter::~Undistorter() = default;
 
 void FeatureDetector::applyMinDistance(std::vector<Feature::Point> &corners, const std::vector<Feature::Point> &prevCorners,
                                        int minDistance) const
@@ -81,6 +82,59 @@ public:
         hv_synchronize(session.ctx());
         return pyramid;
     }
+    std::shared_ptr<ImagePyramid> computeFromFrame(const InputImage &img) final {
+        assert(img.width == session.params().width && img.height == session.params().height);
+        int slot = -1;
+        int rc = hv_pyramid_acquire(session.ctx(), &slot);
+        assert(rc == HV_OK && "pyramid pool exhausted: raise hv_params.pool_size");
+        auto pyramid = std::make_shared<HipImagePyramid>(session.ctx(), slot);
+        rc = hv_ingest_build(session.ctx(), slot, img.data, img.strideBytes, img.channels, -1);
+        assert(rc == HV_OK); (void)rc;
+        hv_synchronize(session.ctx());
+        return pyramid;
+    }
+};
+
+// Counterpart of UndistorterImplementation (src/tracker/undistorter.cpp:43-135). Like the reference's GPU branch
+// (:113-121) the remap is built once, from the first camera seen; later per-frame intrinsics are ignored with a
+// warning. The table is the reference's own per-pixel evaluation (undistortCpu, :56-60) done once on the host.
+class HipUndistorter : public Undistorter {
+    Session &session;
+    const int cameraIndex;
+    std::shared_ptr<const Camera> originalCamera, undistortedCamera;
+public:
+    HipUndistorter(Session &s, int idx, std::shared_ptr<const Camera> rectified)
+        : session(s), cameraIndex(idx), undistortedCamera(std::move(rectified)) {}
+    ~HipUndistorter() override { hv_ingest_set_undistort_map(session.ctx(), cameraIndex, nullptr, nullptr); }
+
+    Result undistort(const InputImage &image, std::shared_ptr<const Camera> camera) final {
+        const int w = session.params().width, h = session.params().height;
+        assert(image.width == w && image.height == h);
+        if (originalCamera) {
+            if (originalCamera->getFocalLength() - camera->getFocalLength() > 1e-6)          // undistorter.cpp:114-117
+                std::fprintf(stderr, "Per-frame camera parameters ignored in HIP undistortion\n");
+        } else {
+            originalCamera = camera;
+            std::vector<double> pixOrig((size_t)w * h * 2, 0.0);
+            std::vector<std::uint8_t> valid((size_t)w * h, 0);
+            for (int y = 0; y < h; ++y)
+                for (int x = 0; x < w; ++x) {
+                    const double pixRect[2] = {(double)x, (double)y};
+                    double ray[3], *out = &pixOrig[2 * ((size_t)y * w + x)];
+                    valid[(size_t)y * w + x] = undistortedCamera->pixelToRay(pixRect, ray) && originalCamera->rayToPixel(ray, out);
+                }
+            const int rc = hv_ingest_set_undistort_map(session.ctx(), cameraIndex, pixOrig.data(), valid.data());
+            assert(rc == HV_OK); (void)rc;
+        }
+        int slot = -1;
+        int rc = hv_pyramid_acquire(session.ctx(), &slot);
+        assert(rc == HV_OK && "pyramid pool exhausted: raise hv_params.pool_size");
+        auto pyramid = std::make_shared<HipImagePyramid>(session.ctx(), slot);
+        rc = hv_ingest_build(session.ctx(), slot, image.data, image.strideBytes, image.channels, cameraIndex);
+        assert(rc == HV_OK); (void)rc;
+        hv_synchronize(session.ctx());
+        return {undistortedCamera, pyramid};
+    }
 };
 
 class HipOpticalFlow : public OpticalFlow {
@@ -132,6 +186,12 @@ public:
 };
 
 }  // namespace
+
+std::unique_ptr<Undistorter> Undistorter::buildRectifiedHip(Session &s, int cameraIndex, std::shared_ptr<const Camera> rectified)
+{
+    assert(cameraIndex >= 0 && cameraIndex < HV_INGEST_CAMERAS);
+    return std::unique_ptr<Undistorter>(new HipUndistorter(s, cameraIndex, std::move(rectified)));
+}
 
 std::unique_ptr<FeatureDetector> FeatureDetector::buildHip(Session &s, const hv_gftt_params &p)
 {

@@ -72,6 +72,11 @@ struct GrayImage {           // what accelerated::opencv::ref(cv::Mat) carries a
     int width, height, strideBytes;
 };
 
+struct InputImage {          // the CPU accelerated::Image handed to Image::Factory::build (image.cpp:226-243)
+    const std::uint8_t *data;
+    int width, height, channels, strideBytes;      // channels 1, 3 or 4, 8 bits each
+};
+
 struct ImagePyramid {        // src/tracker/image_pyramid.hpp:18-43
     typedef std::uint8_t GrayType;
     typedef std::int16_t GradientType;
@@ -88,9 +93,36 @@ struct ImagePyramid {        // src/tracker/image_pyramid.hpp:18-43
 
     struct Factory {
         virtual std::shared_ptr<ImagePyramid> compute(const GrayImage &image) = 0;
+        // colour (or gray) frame without rectification: the colorToGrayOp / copy of image.cpp:351-367 on the device
+        virtual std::shared_ptr<ImagePyramid> computeFromFrame(const InputImage &image) = 0;
         virtual ~Factory();
         static std::unique_ptr<Factory> buildHip(Session &session);   // sibling of buildOpenCv
     };
+};
+
+// tracker::Camera (src/tracker/camera.hpp:12-90): the two methods the undistorter calls. In the reference tree the
+// adapter takes the reference's own Camera (Eigen::Vector2d / Vector3d are layout-compatible with these arrays).
+class Camera {
+public:
+    virtual ~Camera() = default;
+    virtual bool pixelToRay(const double pixel[2], double ray[3]) const = 0;
+    virtual bool rayToPixel(const double ray[3], double pixel[2]) const = 0;
+    virtual double getFocalLength() const = 0;
+};
+
+// tracker::Undistorter (src/tracker/undistorter.hpp:14-41), SURVEY.md 8(f) row f2. The reference returns the
+// rectified gray image; here it never leaves the device: the result is the pyramid whose level 0 it is, built by the
+// same call (colour -> gray, remap, pyramid levels: Image::Factory::buildPrivate, image.cpp:272-306).
+// cameraIndex 0 / 1 = first / second camera (image.cpp:322-328).
+struct Undistorter {
+    struct Result {
+        std::shared_ptr<const Camera> camera;
+        std::shared_ptr<ImagePyramid> image;
+    };
+    virtual ~Undistorter();
+    static std::unique_ptr<Undistorter> buildRectifiedHip(Session &session, int cameraIndex,
+                                                          std::shared_ptr<const Camera> rectifiedCamera);
+    virtual Result undistort(const InputImage &image, std::shared_ptr<const Camera> camera) = 0;
 };
 
 struct OpticalFlow {         // src/tracker/optical_flow.hpp:20-40

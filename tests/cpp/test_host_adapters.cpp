@@ -213,6 +213,60 @@ static void test_tracker(Session &s, const std::string &dir)
     REQUIRE(again->deviceSlot() == slot);
 }
 
+// Image::Factory::build with a colour frame (image.cpp:272-306): colour -> gray on the device, then -- with
+// tracker.useRectification -- the Undistorter between two cameras the test implements itself (in the reference
+// tree these are the reference's own Camera objects). Python compares the dumped level-0 images with the oracle.
+struct TestPinhole : tracker::Camera {
+    double fx, fy, cx, cy, k1, k2, k3;
+    TestPinhole(double fx, double fy, double cx, double cy, double k1 = 0, double k2 = 0, double k3 = 0)
+        : fx(fx), fy(fy), cx(cx), cy(cy), k1(k1), k2(k2), k3(k3) {}
+    bool pixelToRay(const double p[2], double ray[3]) const final {        // used for the undistorted camera only
+        const double x = (p[0] - cx) / fx, y = (p[1] - cy) / fy, n = std::sqrt(x * x + y * y + 1.0);
+        ray[0] = x / n; ray[1] = y / n; ray[2] = 1.0 / n;
+        return true;
+    }
+    bool rayToPixel(const double ray[3], double p[2]) const final {
+        if (ray[2] <= 0) return false;
+        const double iz = 1.0 / ray[2];
+        double x = ray[0] * iz, y = ray[1] * iz;
+        const double r2 = x * x + y * y, th = 1 + r2 * (k1 + r2 * (k2 + r2 * k3));
+        x = x * th; y = y * th;
+        p[0] = fx * x + 0 * y + cx * (ray[2] * iz);
+        p[1] = 0 * x + fy * y + cy * (ray[2] * iz);
+        return true;
+    }
+    double getFocalLength() const final { return (fx + fy) * 0.5; }
+};
+
+static void test_ingest(Session &s, const std::string &dir)
+{
+    const int w = s.params().width, h = s.params().height;
+    std::ifstream f(dir + "/rgb0.raw", std::ios::binary);
+    std::vector<std::uint8_t> rgb((size_t)w * h * 3);
+    f.read(reinterpret_cast<char *>(rgb.data()), (std::streamsize)rgb.size());
+    REQUIRE(f.gcount() == (std::streamsize)rgb.size());
+    auto pyramidFactory = tracker::ImagePyramid::Factory::buildHip(s);
+    const tracker::InputImage frame{rgb.data(), w, h, 3, 3 * w};
+    int lw = 0, lh = 0;
+    {
+        auto plain = pyramidFactory->computeFromFrame(frame);
+        const auto g0 = plain->getGrayLevel(0, lw, lh);
+        REQUIRE(lw == w && lh == h);
+        std::ofstream(dir + "/ingest_gray.raw", std::ios::binary).write(reinterpret_cast<const char *>(g0.data()), (std::streamsize)g0.size());
+    }
+    const std::vector<double> cam = load(dir + "/cameras.txt");   // orig fx fy cx cy k1 k2 k3, rect f cx cy
+    auto original = std::make_shared<TestPinhole>(cam[0], cam[1], cam[2], cam[3], cam[4], cam[5], cam[6]);
+    auto rectified = std::make_shared<TestPinhole>(cam[7], cam[7], cam[8], cam[9]);
+    auto undistorter = tracker::Undistorter::buildRectifiedHip(s, 1, rectified);
+    for (int rep = 0; rep < 2; ++rep) {                            // the table is built on the first call only
+        auto res = undistorter->undistort(frame, original);
+        REQUIRE(res.camera == rectified);
+        const auto g0 = res.image->getGrayLevel(0, lw, lh);
+        std::ofstream(dir + (rep ? "/ingest_rect_again.raw" : "/ingest_rect.raw"), std::ios::binary)
+            .write(reinterpret_cast<const char *>(g0.data()), (std::streamsize)g0.size());
+    }
+}
+
 int main(int argc, char **argv)
 {
     if (argc < 2) { std::printf("usage: %s <dir>\n", argv[0]); return 2; }
@@ -226,6 +280,7 @@ int main(int argc, char **argv)
     test_transform_to(session, dir);
     test_pose_trail(session);
     test_tracker(session, dir);
+    test_ingest(session, dir);
     std::printf("%s (%d failure%s)\n", failures ? "FAILED" : "all host adapter tests passed", failures, failures == 1 ? "" : "s");
     return failures ? 1 : 0;
 }

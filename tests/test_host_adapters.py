@@ -24,7 +24,8 @@ def test_host_library_and_test_program_build():
     assert os.path.exists(lib) and os.access(exe, os.X_OK)
     syms = subprocess.check_output(["nm", "-D", "--defined-only", "-C", lib], text=True)
     for name in ("hybvio::tracker::ImagePyramid::Factory::buildHip", "hybvio::tracker::OpticalFlow::buildHip",
-                 "hybvio::odometry::EKF::buildHip", "hybvio::tracker::FeatureDetector::buildHip"):
+                 "hybvio::odometry::EKF::buildHip", "hybvio::tracker::FeatureDetector::buildHip",
+                 "hybvio::tracker::Undistorter::buildRectifiedHip"):
         assert name in syms, name
     needed = subprocess.check_output(["readelf", "-d", lib], text=True)
     assert "libhybvio_hip.so" in needed and "amdhip64" not in needed      # only the C ABI is linked
@@ -49,6 +50,10 @@ def test_reference_tests_through_the_cpp_adapters(oracle):
         img0.tofile(os.path.join(d, "img0.raw"))
         img1.tofile(os.path.join(d, "img1.raw"))
         np.savetxt(os.path.join(d, "pts.txt"), pts.reshape(-1), fmt="%.9g")
+        rgb = np.clip(img0[..., None].astype(np.int32) + rng.integers(-50, 51, (h, w, 3)), 0, 255).astype(np.uint8)
+        rgb.tofile(os.path.join(d, "rgb0.raw"))
+        cams = [195.2, 194.6, 156.3, 121.7, -0.28340811, 0.07395907, 0.0, 170.0, w * 0.5, h * 0.5]
+        np.savetxt(os.path.join(d, "cameras.txt"), cams, fmt="%.17g")
         r = subprocess.run([exe, d], capture_output=True, text=True, timeout=300)
         print(r.stdout, r.stderr)
         assert r.returncode == 0, r.stdout + r.stderr
@@ -58,6 +63,15 @@ def test_reference_tests_through_the_cpp_adapters(oracle):
         g1 = np.fromfile(os.path.join(d, "gray1.raw"), np.uint8).reshape((h + 1) // 2, (w + 1) // 2)
         det = [np.loadtxt(os.path.join(d, f), ndmin=2).astype(np.float32)
                for f in ("detect_raw.txt", "detect_masked.txt", "detect_raw_then_mask.txt")]
+        ing = [np.fromfile(os.path.join(d, f), np.uint8).reshape(h, w)
+               for f in ("ingest_gray.raw", "ingest_rect.raw", "ingest_rect_again.raw")]
+    # Image::Factory::build on a colour frame and Undistorter::buildRectifiedHip vs the oracle
+    gray = oracle.color_to_gray(rgb)
+    np.testing.assert_array_equal(ing[0], gray)
+    pix, valid = oracle.undistort_map(oracle.Camera("pinhole", cams[7], cams[7], cams[8], cams[9]),
+                                      oracle.Camera("pinhole", *cams[:4], coeffs=cams[4:7]), w, h)
+    np.testing.assert_array_equal(ing[1], oracle.undistort_apply(gray, pix, valid))
+    np.testing.assert_array_equal(ing[2], ing[1])
     p0, p1 = oracle.Pyramid(img0), oracle.Pyramid(img1)
     o_xy, o_st = oracle.optical_flow_compute(p0, p1, pts)
     np.testing.assert_array_equal(out[:, 2].astype(int), o_st)
