@@ -23,7 +23,7 @@ f64p = C.POINTER(C.c_double)
 
 def build(force: bool = False) -> str:
     so = os.path.join(_DIR, "liboracle.so")
-    srcs = [os.path.join(_DIR, f) for f in ("pyrlk_oracle.c", "ekf_oracle.c", "gftt_oracle.c", "ingest_oracle.c", "Makefile")]
+    srcs = [os.path.join(_DIR, f) for f in ("pyrlk_oracle.c", "ekf_oracle.c", "gftt_oracle.c", "ingest_oracle.c", "triangulation_oracle.c", "Makefile")]
     if force or not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
         subprocess.check_call(["make", "-C", _DIR, "-B", "liboracle.so"], stdout=subprocess.DEVNULL)
     return so
@@ -60,6 +60,17 @@ def lib():
         L.orc_undistort_map.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, f64p, u8p]
         L.orc_undistort_apply.argtypes = [u8p, C.c_int, C.c_int, f64p, u8p, u8p]
         L.orc_color_to_gray.argtypes = [u8p, C.c_int, C.c_int, C.c_int, C.c_int, u8p]
+        L.orc_tri_default_params.argtypes = [C.c_void_p]
+        L.orc_extract_camera_pose_trail.argtypes = [f64p, i32p, C.c_int, f64p, f64p, C.c_void_p]
+        L.orc_inverse_depth.argtypes = [f64p, f64p, f64p]
+        L.orc_pinv32.argtypes = [f64p, f64p]
+        L.orc_triangulate_with_two_cameras.argtypes = [C.c_void_p, C.c_void_p, f64p, f64p, f64p, f64p, C.c_int, C.c_int, C.c_int,
+                                                       C.c_double, f64p, f64p]
+        L.orc_triangulate.argtypes = [C.c_void_p, C.c_int, C.c_void_p, f64p, f64p, C.c_int, C.c_int, C.c_int, C.c_double,
+                                      f64p, f64p, f64p, f64p]
+        L.orc_prepare_visual_update.argtypes = [f64p, f64p, f64p, f64p, f64p, C.c_void_p, C.c_int, i32p, C.c_int, C.c_int, C.c_int,
+                                                C.c_int, C.c_int, C.c_int, C.c_double, f64p, f64p, i32p]
+        L.orc_visual_track_prepare.argtypes = [C.c_void_p, f64p, C.c_int, i32p, C.c_int, f64p, f64p, f64p, f64p, f64p, f64p, f64p, i32p]
         _LIB = L
     return _LIB
 
@@ -440,3 +451,128 @@ def color_to_gray(img: np.ndarray) -> np.ndarray:
     out = np.zeros((h, w), np.uint8)
     lib().orc_color_to_gray(_p(img, u8p), w * ch, w, h, ch, _p(out, u8p))
     return out
+
+
+# ---- triangulation + prepareVisualUpdate (oracle/triangulation_oracle.c) ----
+class TriParams(C.Structure):
+    _fields_ = [("triangulationConvergenceThreshold", C.c_double), ("triangulationConvergenceR", C.c_double),
+                ("triangulationRcondThreshold", C.c_double), ("triangulationGaussNewtonIterations", C.c_uint),
+                ("triangulationMinDist", C.c_double), ("triangulationMaxDist", C.c_double),
+                ("estimateImuCameraTimeShift", C.c_int)]
+
+
+class CamPose(C.Structure):      # 3x3 matrices row-major
+    _fields_ = [("p", C.c_double * 3), ("R", C.c_double * 9), ("dR", (C.c_double * 9) * 4), ("baseline", C.c_double * 3)]
+
+
+TRI_STATUS = ("OK", "HYBRID", "BEHIND", "BAD_COND", "NO_CONVERGENCE", "BAD_DEPTH", "UNKNOWN_PROBLEM")
+
+
+def tri_default_params(**over):
+    p = TriParams()
+    lib().orc_tri_default_params(C.byref(p))
+    for k, v in over.items():
+        setattr(p, k, v)
+    return p
+
+
+def _f64(a):
+    return np.ascontiguousarray(a, np.float64)
+
+
+def vec2matrix(v):
+    """odometry::util::vec2matrix (util.hpp:92-110): 9 values = column-major rotation, 16 = column-major 4x4."""
+    v = np.asarray(v, np.float64)
+    m = np.eye(4)
+    if v.size == 9:
+        m[:3, :3] = v.reshape(3, 3).T
+    elif v.size == 16:
+        m = v.reshape(4, 4).T.copy()
+    else:
+        raise ValueError(v.size)
+    return m
+
+
+def make_pose(p, q, baseline=(0, 0, 0), imu_to_cam_rot=None):
+    """CameraPose from a camera position and a quaternion (R = imuToCamRot * quat2rmat(q)), as the reference tests do."""
+    T = np.eye(4)
+    if imu_to_cam_rot is not None:
+        T[:3, :3] = imu_to_cam_rot
+    T[:3, 3] = baseline
+    m = np.zeros(20)
+    m[0:3] = np.asarray(p, np.float64)
+    m[6:10] = q
+    tr = extract_camera_pose_trail(m, [0], T)
+    tr[0].p[:] = list(np.asarray(p, np.float64))
+    return tr
+
+
+def extract_camera_pose_trail(m, pose_trail_index, imu_to_cam, imu_to_cam2=None):
+    idx = np.ascontiguousarray(pose_trail_index, np.int32)
+    n = len(idx)
+    trail = (CamPose * (n * (2 if imu_to_cam2 is not None else 1)))()
+    a, b = _f64(imu_to_cam), (None if imu_to_cam2 is None else _f64(imu_to_cam2))
+    lib().orc_extract_camera_pose_trail(_p(_f64(m), f64p), _p(idx, i32p), n, _p(a, f64p), None if b is None else _p(b, f64p), trail)
+    return trail
+
+
+def inverse_depth(p):
+    ip, dip = np.zeros(3), np.zeros((3, 3))
+    lib().orc_inverse_depth(_p(_f64(p), f64p), _p(ip, f64p), _p(dip, f64p))
+    return ip, dip
+
+
+def pinv32(A):
+    out = np.zeros((2, 3))
+    lib().orc_pinv32(_p(_f64(A), f64p), _p(out, f64p))
+    return out
+
+
+def triangulate_with_two_cameras(pose0, pose1, ip0, ip1, vel0=(0, 0), vel1=(0, 0), calc_derivatives=False,
+                                 estimate_time_shift=False, derivative_test=False, time_shift=0.0):
+    pf, dpf = np.zeros(3), np.zeros((3, 15))
+    lib().orc_triangulate_with_two_cameras(C.byref(pose0), C.byref(pose1), _p(_f64(ip0), f64p), _p(_f64(ip1), f64p), _p(_f64(vel0), f64p),
+                                           _p(_f64(vel1), f64p), int(calc_derivatives), int(estimate_time_shift), int(derivative_test),
+                                           float(time_shift), _p(pf, f64p), _p(dpf, f64p))
+    return pf, dpf
+
+
+def triangulate(par, trail, image_features, feature_velocities, stereo=False, calc_derivatives=True, derivative_test=False,
+                time_shift=0.0):
+    n = len(trail)
+    pf, dp, dq, dt = np.zeros(3), np.zeros((n, 3, 3)), np.zeros((n, 3, 4)), np.zeros(3)
+    st = lib().orc_triangulate(C.byref(par), n, trail, _p(_f64(image_features), f64p), _p(_f64(feature_velocities), f64p), int(stereo),
+                               int(calc_derivatives), int(derivative_test), float(time_shift), _p(pf, f64p), _p(dp, f64p), _p(dq, f64p),
+                               _p(dt, f64p))
+    return st, pf, dp, dq, dt
+
+
+def prepare_visual_update(pf, dpfdp, dpfdq, dpfdt, feature_velocities, trail, pose_trail_index, state_dim, truncated=False,
+                          map_point_offset=-1, estimate_time_shift=True, derivative_test=False, time_shift=0.0):
+    idx = np.ascontiguousarray(pose_trail_index, np.int32)
+    nt = len(trail)
+    H = np.zeros((state_dim, 2 * nt))                       # column-major (2 nt) x end
+    f = np.zeros(2 * nt)
+    end = np.zeros(1, np.int32)
+    dp = None if dpfdp is None else _f64(dpfdp)
+    dq = None if dpfdq is None else _f64(dpfdq)
+    st = lib().orc_prepare_visual_update(_p(_f64(pf), f64p), None if dp is None else _p(dp, f64p), None if dq is None else _p(dq, f64p),
+                                         _p(_f64(dpfdt), f64p), _p(_f64(feature_velocities), f64p), trail, nt, _p(idx, i32p), len(idx),
+                                         state_dim, int(truncated), map_point_offset, int(estimate_time_shift), int(derivative_test),
+                                         float(time_shift), _p(H, f64p), _p(f, f64p), _p(end, i32p))
+    e = int(end[0])
+    return st, H.reshape(-1)[:2 * nt * e].reshape(e, 2 * nt).T.copy(), f
+
+
+def visual_track_prepare(par, m, pose_trail_index, imu_to_cam, imu_to_cam2, image_features, feature_velocities):
+    """backend.cpp:1063-1148 for one pose-trail track: (triangulation status, prepare status, pf, H, f)."""
+    m = _f64(m)
+    idx = np.ascontiguousarray(pose_trail_index, np.int32)
+    nt = len(idx) * (2 if imu_to_cam2 is not None else 1)
+    H = np.zeros((len(m), 2 * nt))
+    f, pf, ps = np.zeros(2 * nt), np.zeros(3), np.zeros(1, np.int32)
+    a, b = _f64(imu_to_cam), (None if imu_to_cam2 is None else _f64(imu_to_cam2))
+    st = lib().orc_visual_track_prepare(C.byref(par), _p(m, f64p), len(m), _p(idx, i32p), len(idx), _p(a, f64p),
+                                        None if b is None else _p(b, f64p), _p(_f64(image_features), f64p),
+                                        _p(_f64(feature_velocities), f64p), _p(pf, f64p), _p(H, f64p), _p(f, f64p), _p(ps, i32p))
+    return st, int(ps[0]), pf, H.T.copy(), f

@@ -1,0 +1,206 @@
+"""Pins oracle/triangulation_oracle.c with the reference's OWN tests, re-expressed on the
+reference's inline data (tests/golden/triangulation_reference_fixtures.npz, parsed from test/triangulation.cpp by
+make_triangulation_fixtures.py). Tolerances are the reference's."""
+import os
+
+import numpy as np
+import pytest
+
+FX = os.path.join(os.path.dirname(__file__), "golden", "triangulation_reference_fixtures.npz")
+POS, ORI, SFT, CAM = 0, 6, 19, 20
+
+
+@pytest.fixture(scope="module")
+def fx():
+    return np.load(FX)
+
+
+def der_check(x0, numeric, analytic, h=1e-7):
+    """test/helpers.cpp:39-70: |analytic - forward difference|."""
+    A = analytic(x0)
+    y0 = numeric(x0)
+    N = np.zeros_like(A)
+    for i in range(len(x0)):
+        x = x0.copy(); x[i] += h
+        N[:, i] = (numeric(x) - y0) / h
+    return np.abs(A - N)
+
+
+def state_from_poses(poses, cam_pose_count):
+    m = np.zeros(20 + 7 * cam_pose_count)
+    m[POS:POS + 3], m[ORI:ORI + 4] = poses[0:3], poses[3:7]
+    for i in range(9):
+        m[CAM + 7 * i:CAM + 7 * i + 7] = poses[7 * (i + 1):7 * (i + 2)]
+    return m
+
+
+def state_to_x(m, pose_count, normalize):
+    x = np.zeros(7 * pose_count + 1)
+    for i in range(pose_count):
+        ip = POS if i == 0 else CAM + 7 * (i - 1)
+        io = ORI if i == 0 else CAM + 7 * (i - 1) + 3
+        x[7 * i:7 * i + 3] = m[ip:ip + 3]
+        q = m[io:io + 4]
+        x[7 * i + 3:7 * i + 7] = q / np.linalg.norm(q) if normalize else q
+    return x
+
+
+def x_to_state(m, x, pose_count, normalize):
+    m = m.copy()
+    for i in range(pose_count):
+        ip = POS if i == 0 else CAM + 7 * (i - 1)
+        io = ORI if i == 0 else CAM + 7 * (i - 1) + 3
+        m[ip:ip + 3] = x[7 * i:7 * i + 3]
+        q = x[7 * i + 3:7 * i + 7]
+        m[io:io + 4] = q / np.linalg.norm(q) if normalize else q
+    return m
+
+
+def out_to_dpf(dp, dq, dt):
+    n = len(dp)
+    d = np.zeros((3, 7 * n + 1))
+    for j in range(n):
+        d[:, 7 * j:7 * j + 3] = dp[j]
+        d[:, 7 * j + 3:7 * j + 7] = dq[j]
+    d[:, 7 * n] = dt
+    return d
+
+
+def test_pinv_matlab_values(oracle, fx):
+    """test/triangulation.cpp:477-485."""
+    assert np.abs(oracle.pinv32(fx["pinv_m"].T) - fx["pinv_matlab"].T).sum() < 1e-5
+
+
+def test_triangulate_with_two_cameras_right_triangle(oracle):
+    """test/triangulation.cpp:487-519: rays from (1,1,0) and (1,2,0) meet at (1,2,1); result in pose0's frame."""
+    q_id = [1.0, 0, 0, 0]
+    pose0, pose1 = oracle.make_pose([1, 1, 0], q_id), oracle.make_pose([1, 2, 0], q_id)
+    pf, _ = oracle.triangulate_with_two_cameras(pose0[0], pose1[0], [0, 1], [0, 0])
+    assert np.abs(pf - [0, 1, 1]).sum() < 1e-5
+
+
+def test_der_triangulate_with_two_cameras(oracle, fx):
+    """test/triangulation.cpp:521-580: ||analytic - numeric||_F < 2e-6."""
+    ip0, ip1, v = fx["two_ip0"], fx["two_ip1"], [0.1, 0.1]
+
+    def run(x):
+        p0, p1 = oracle.make_pose(x[0:3], x[3:7]), oracle.make_pose(x[7:10], x[10:14])
+        return oracle.triangulate_with_two_cameras(p0[0], p1[0], ip0, ip1, v, v, True, True, True, x[14])
+    x0 = np.concatenate([fx["two_p0"], fx["two_q0"] / np.linalg.norm(fx["two_q0"]), fx["two_p1"],
+                         fx["two_q1"] / np.linalg.norm(fx["two_q1"]), [0.0]])
+    D = der_check(x0, lambda x: run(x)[0], lambda x: run(x)[1])
+    assert np.linalg.norm(D) < 2e-6
+
+
+def test_der_inverse_depth(oracle, fx):
+    """test/triangulation.cpp:582-601."""
+    D = der_check(fx["inverse_depth_p0"].copy(), lambda x: oracle.inverse_depth(x)[0], lambda x: oracle.inverse_depth(x)[1])
+    assert np.linalg.norm(D) < 1e-5
+
+
+def _visual_setup(oracle, fx):
+    m = state_from_poses(fx["visual_poses"], 20)
+    T = oracle.vec2matrix(fx["imu_default"])
+    uv, vel = fx["visual_uv"], np.full((10, 2), 0.1)
+    par = oracle.tri_default_params(triangulationConvergenceR=11.0)
+    idx = list(range(10))
+    return m, T, uv, vel, par, idx
+
+
+def test_visual_triangulate_matlab_point_and_derivatives(oracle, fx):
+    """test/triangulation.cpp:56-197 SECTION "triangulate": status OK, |pf - pf_e|_1 < 1e-5 (Matlab), derivative check < 1e-3."""
+    m, T, uv, vel, par, idx = _visual_setup(oracle, fx)
+    trail = oracle.extract_camera_pose_trail(m, idx, T)
+    st, pf, dp, dq, dt = oracle.triangulate(par, trail, uv, vel, stereo=False, derivative_test=True, time_shift=0.0)
+    assert st == 0
+    assert np.abs(pf - fx["visual_pf_matlab"]).sum() < 1e-5
+
+    def run(x):
+        tr = oracle.extract_camera_pose_trail(x_to_state(m, x, 10, True), idx, T)
+        s, pf, dp, dq, dt = oracle.triangulate(par, tr, uv, vel, stereo=False, derivative_test=True, time_shift=x[-1])
+        assert s == 0
+        return pf, out_to_dpf(dp, dq, dt)
+    D = der_check(state_to_x(m, 10, True), lambda x: run(x)[0], lambda x: run(x)[1])
+    assert D.max() < 1e-3
+
+
+def test_visual_prepare_visual_update_jacobian(oracle, fx):
+    """test/triangulation.cpp:199-245 SECTION "prepareVisualUpdateCheckJacobian": H vs d f / d x < 1e-6."""
+    m, T, uv, vel, par, idx = _visual_setup(oracle, fx)
+
+    def run(x):
+        tr = oracle.extract_camera_pose_trail(x_to_state(m, x, 10, True), idx, T)
+        s, pf, dp, dq, dt = oracle.triangulate(par, tr, uv, vel, stereo=False, derivative_test=True, time_shift=x[-1])
+        assert s == 0
+        ps, H, f = oracle.prepare_visual_update(pf, dp, dq, dt, vel, tr, idx, len(m), derivative_test=True, time_shift=x[-1])
+        assert ps == 0 and H.shape == (20, len(m))
+        cols = list(range(POS, POS + 3)) + list(range(ORI, ORI + 4)) + list(range(CAM, CAM + 7 * 9)) + [SFT]
+        return f, H[:, cols]
+    D = der_check(state_to_x(m, 10, True), lambda x: run(x)[0], lambda x: run(x)[1])
+    assert D.shape == (20, 71) and D.max() < 1e-6
+
+
+def _stereo_setup(oracle, fx):
+    m = state_from_poses(fx["stereo_poses"], 10)
+    T1 = oracle.vec2matrix(fx["stereo_imu"])
+    T2 = oracle.vec2matrix(fx["stereo_imu2"])
+    T2[:3, 3] += fx["stereo_translation"]                      # tracker/util.cpp:103-105 (a 3x3 matrix was given)
+    uv = np.concatenate([fx["stereo_uv"], fx["stereo_uv2"] * 1.1])
+    vel = np.full((20, 2), 0.1)
+    par = oracle.tri_default_params(triangulationConvergenceR=11.0)
+    return m, T1, T2, uv, vel, par, list(range(10))
+
+
+def _sum_stereo(dp, dq):
+    n = len(dp) // 2
+    return dp[:n] + dp[n:], dq[:n] + dq[n:]
+
+
+def test_stereo_visual_triangulate_derivatives(oracle, fx):
+    """test/triangulation.cpp:248-414 SECTION "triangulate": derivative check < 1e-4 (quaternions not re-normalised)."""
+    m, T1, T2, uv, vel, par, idx = _stereo_setup(oracle, fx)
+
+    def run(x, shift):
+        tr = oracle.extract_camera_pose_trail(x_to_state(m, x, 10, False), idx, T1, T2)
+        s, pf, dp, dq, dt = oracle.triangulate(par, tr, uv, vel, stereo=True, derivative_test=True, time_shift=shift)
+        assert s == 0
+        return pf, out_to_dpf(*_sum_stereo(dp, dq), dt)
+    # the reference's analytic lambda leaves imuToCameraTimeShift at its previous value (0 at x0)
+    D = der_check(state_to_x(m, 10, False), lambda x: run(x, x[-1])[0], lambda x: run(x, 0.0)[1])
+    assert D.max() < 1e-4
+
+
+def test_stereo_visual_prepare_visual_update_jacobian(oracle, fx):
+    """test/triangulation.cpp:416-473: 40 x 71 Jacobian check < 1e-5."""
+    m, T1, T2, uv, vel, par, idx = _stereo_setup(oracle, fx)
+
+    def run(x):
+        tr = oracle.extract_camera_pose_trail(x_to_state(m, x, 10, False), idx, T1, T2)
+        s, pf, dp, dq, dt = oracle.triangulate(par, tr, uv, vel, stereo=True, derivative_test=True, time_shift=x[-1])
+        assert s == 0
+        dp, dq = _sum_stereo(dp, dq)
+        ps, H, f = oracle.prepare_visual_update(pf, dp, dq, dt, vel, tr, idx, len(m), derivative_test=True, time_shift=x[-1])
+        assert ps == 0 and H.shape == (40, len(m))
+        cols = list(range(POS, POS + 3)) + list(range(ORI, ORI + 4)) + list(range(CAM, CAM + 7 * 9)) + [SFT]
+        return f, H[:, cols]
+    D = der_check(state_to_x(m, 10, False), lambda x: run(x)[0], lambda x: run(x)[1])
+    assert D.shape == (40, 71) and D.max() < 1e-5
+
+
+def test_visual_track_prepare_glue_and_failure_statuses(oracle, fx):
+    """backend.cpp:1063-1148: the wrapper equals the step-by-step calls; degenerate tracks report the reference's statuses."""
+    m, T1, T2, uv, vel, par, idx = _stereo_setup(oracle, fx)
+    st, ps, pf, H, f = oracle.visual_track_prepare(par, m, idx, T1, T2, uv, vel)
+    tr = oracle.extract_camera_pose_trail(m, idx, T1, T2)
+    s2, pf2, dp, dq, dt = oracle.triangulate(par, tr, uv, vel, stereo=True)
+    ps2, H2, f2 = oracle.prepare_visual_update(pf2, *_sum_stereo(dp, dq), dt, vel, tr, idx, len(m))
+    assert (st, ps) == (0, 0) == (s2, ps2)
+    assert np.array_equal(pf, pf2) and np.array_equal(H, H2) and np.array_equal(f, f2)
+    assert np.count_nonzero(H[:, SFT]) == 40 and not H[:, 10:19].any()          # biases do not enter the measurement
+    # tracks no static point can explain: mirrored through the image centre / random pixels
+    assert oracle.TRI_STATUS[oracle.visual_track_prepare(par, m, idx, T1, None, -uv[:10], vel[:10])[0]] == "NO_CONVERGENCE"
+    st3, ps3 = oracle.visual_track_prepare(par, m, idx, T1, None, np.random.default_rng(0).normal(size=(10, 2)), vel[:10])[:2]
+    assert oracle.TRI_STATUS[st3] == "BEHIND" and ps3 == 2                         # PREPARE_VU_BEHIND as well
+    # depth window (triangulationMinDist / MaxDist, backend.cpp:1099-1102)
+    near = oracle.tri_default_params(triangulationConvergenceR=11.0, triangulationMaxDist=0.5)
+    assert oracle.TRI_STATUS[oracle.visual_track_prepare(near, m, idx, T1, T2, uv, vel)[0]] == "BAD_DEPTH"
