@@ -29,7 +29,7 @@ f32p = C.POINTER(C.c_float)
 f64p = C.POINTER(C.c_double)
 
 HV_MAX_LEVELS = 6
-K_PYR_L0, K_PYR_LN, K_KLT, K_EKF_PREDICT, K_EKF_UPDATE, K_EKF_AUGMENT, K_GFTT, K_INGEST = range(8)
+K_PYR_L0, K_PYR_LN, K_KLT, K_EKF_PREDICT, K_EKF_UPDATE, K_EKF_AUGMENT, K_GFTT, K_INGEST, K_VU_PREPARE = range(9)
 
 # tracker::Feature::Status (src/tracker/track.hpp:9-21)
 ST_TRACKED, ST_NEW, ST_FAILED_FLOW, ST_RANSAC_OUTLIER, ST_FLOW_OUT_OF_RANGE = 0, 1, 2, 3, 4
@@ -104,6 +104,9 @@ PROTOTYPES = {
     "hv_ekf_update": (C.c_int, [C.c_void_p, C.c_int, C.c_int, f64p, f64p, f64p, u8p, C.c_int]),
     "hv_ekf_visual_gate": (C.c_int, [C.c_void_p, C.c_int, C.c_int, f64p, f64p, C.c_double, f64p, i32p]),
     "hv_ekf_visual_update": (C.c_int, [C.c_void_p, C.c_int, C.c_int, f64p, f64p, C.c_double, u8p]),
+    "hv_vu_default_params": (None, [C.c_void_p]),
+    "hv_ekf_visual_prepare_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int] + [C.c_void_p] * 10),
+    "hv_ekf_visual_track_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int] + [C.c_void_p] * 4 + [C.c_double, C.c_double] + [C.c_void_p] * 4),
     "hv_ekf_visual_dev": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_double, C.c_int,
                                     C.c_void_p, C.c_void_p]),
     "hv_ekf_augment": (C.c_int, [C.c_void_p, i32p, u8p]),
@@ -347,6 +350,28 @@ def _f(a):
     return np.ascontiguousarray(a, np.float64)
 
 
+class VuParams(C.Structure):
+    """hv_vu_params (field names = the reference's parameters)."""
+    _fields_ = [("triangulationConvergenceThreshold", C.c_double), ("triangulationConvergenceR", C.c_double),
+                ("triangulationRcondThreshold", C.c_double), ("triangulationGaussNewtonIterations", C.c_uint),
+                ("triangulationMinDist", C.c_double), ("triangulationMaxDist", C.c_double),
+                ("estimateImuCameraTimeShift", C.c_int), ("useStereo", C.c_int),
+                ("imuToCamera", C.c_double * 16), ("secondImuToCamera", C.c_double * 16)]
+
+
+def vu_default_params(imu_to_camera=None, second_imu_to_camera=None, **over) -> VuParams:
+    p = VuParams()
+    lib().hv_vu_default_params(C.byref(p))
+    if imu_to_camera is not None:
+        p.imuToCamera[:] = list(np.asarray(imu_to_camera, np.float64).reshape(16))
+    if second_imu_to_camera is not None:
+        p.secondImuToCamera[:] = list(np.asarray(second_imu_to_camera, np.float64).reshape(16))
+        p.useStereo = 1
+    for k, v in over.items():
+        setattr(p, k, v)
+    return p
+
+
 class EkfBatch:
     """hv_ekf: a batch of independent filters on one Context (batch = 1: the reference's EKF)."""
 
@@ -452,6 +477,19 @@ class EkfBatch:
         self._chk(lib().hv_ekf_visual_update(self._h, nr, l, _p(Hc, f64p), _p(v, f64p), r, _p(act, u8p)),
                   "hv_ekf_visual_update")
         self.ctx.synchronize()
+
+    def visual_prepare_dev(self, params: VuParams, n_poses, pose_index_dev, features_dev, velocities_dev, y_dev, H_dev, v_dev,
+                           f_dev, pf_dev, status_dev, active_dev=0):
+        """hv_ekf_visual_prepare_dev: device pointers (ints); y_dev / f_dev / active_dev may be 0."""
+        p = [C.c_void_p(x) for x in (pose_index_dev, features_dev, velocities_dev, y_dev, H_dev, v_dev, f_dev, pf_dev, status_dev, active_dev)]
+        self._chk(lib().hv_ekf_visual_prepare_dev(self._h, C.byref(params), n_poses, *p), "hv_ekf_visual_prepare_dev")
+
+    def visual_track_dev(self, params: VuParams, n_poses, pose_index_dev, features_dev, velocities_dev, y_dev, r_gate, r_update,
+                         status_dev, gate_status_dev, chi2_dev=0, pf_dev=0):
+        a = [C.c_void_p(x) for x in (pose_index_dev, features_dev, velocities_dev, y_dev)]
+        b = [C.c_void_p(x) for x in (status_dev, gate_status_dev, chi2_dev, pf_dev)]
+        self._chk(lib().hv_ekf_visual_track_dev(self._h, C.byref(params), n_poses, *a, float(r_gate), float(r_update), *b),
+                  "hv_ekf_visual_track_dev")
 
     def visual_dev(self, nr, l, H_dev, v_dev, r, mode, chi2_dev=0, status_dev=0):
         self._chk(lib().hv_ekf_visual_dev(self._h, nr, l, C.c_void_p(H_dev), C.c_void_p(v_dev), r, mode,

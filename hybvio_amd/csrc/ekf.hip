@@ -415,6 +415,7 @@ struct UpdateArgs {
     double *ws;                       // per filter R*nr doubles (used when the tall matrix exceeds LDS)
     double *chi2; int *status;        // optional outputs
     const unsigned char *active;      // optional per-filter enable
+    const int *require_inlier;        // optional per-filter gate result of an earlier launch: run only where it is 0 (INLIER)
 };
 
 constexpr int UPD_THREADS = 512;   // 8 waves = 2 per SIMD: 256 VGPRs each (whole column blocks of P stay in registers)
@@ -431,6 +432,7 @@ __global__ __launch_bounds__(UPD_THREADS) void ekf_update_kernel(UpdateArgs a)
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int b = blockIdx.x;
     if (a.active && !a.active[b]) return;
+    if (a.require_inlier && a.require_inlier[b] != 0) return;
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);     // wave-uniform: tile indices and their addresses stay on the scalar unit
     constexpr int nwaves = UPD_THREADS / 64;
@@ -1119,11 +1121,15 @@ struct Ekf {
     unsigned char *sactive = nullptr;
     size_t sH_cap = 0;
     int max_rows = 0;
+    // buffers of hv_ekf_visual_track_dev (row f3), sized on first use
+    double *vuH = nullptr, *vuv = nullptr, *vupf = nullptr;
+    unsigned char *vuactive = nullptr;
+    int vu_rows = 0;
 };
 
 static int ekf_launch_update(Ekf *e, int nr, int l, const double *H_dev, const double *v_dev, const double *rdiag_dev,
                              double rd0, int mode, int generic, int normalize_all, double *chi2_dev, int *status_dev,
-                             const unsigned char *active_dev)
+                             const unsigned char *active_dev, const int *require_inlier_dev = nullptr)
 {
     Ctx *c = e->c;
     if (nr < 1 || nr > e->max_rows || l < 1 || l > e->n) return HV_ERR_INVALID;
@@ -1137,7 +1143,7 @@ static int ekf_launch_update(Ekf *e, int nr, int l, const double *H_dev, const d
     a.Rs = r_pad;
     a.mode = mode; a.generic = generic; a.normalize_all = normalize_all; a.map_dim = e->map_dim;
     a.m = e->m; a.P = e->P; a.H = H_dev; a.v = v_dev; a.rdiag = rdiag_dev; a.rd0 = rd0; a.noise_scale = e->noise_scale;
-    a.ws = e->ws; a.chi2 = chi2_dev; a.status = status_dev; a.active = active_dev;
+    a.ws = e->ws; a.chi2 = chi2_dev; a.status = status_dev; a.active = active_dev; a.require_inlier = require_inlier_dev;
     size_t tall = (((size_t)a.Rs * nr + 1) & ~(size_t)1) * sizeof(double);
     const size_t small = (size_t)(576 + UPD_THREADS / 64 + 2) * sizeof(double);                 // W + col + red + flag
     const int ti = (nr + 15) / 16, lbk = (l + 15) / 16;
@@ -1189,7 +1195,7 @@ void hv_ekf_destroy(hv_ekf *h)
     Ekf *e = &h->e;
     if (e->c && e->c->stream) (void)hipStreamSynchronize(e->c->stream);
     void *ptrs[] = { e->m, e->P, e->P1, e->m1, e->Q, e->dydx, e->ws, e->sH, e->sv, e->sr, e->schi2, e->simu,
-                     e->sstatus, e->sdrop, e->sactive };
+                     e->sstatus, e->sdrop, e->sactive, e->vuH, e->vuv, e->vupf, e->vuactive };
     for (void *p : ptrs) if (p) (void)hipFree(p);
     delete h;
 }
@@ -1249,6 +1255,88 @@ int hv_ekf_create(hv_ctx *ctx, const hv_ekf_params *par, int batch, hv_ekf **out
     if (rc != HV_OK) { hv_ekf_destroy(h); return rc; }
     *out = h;
     return HV_OK;
+}
+
+void hv_vu_default_params(hv_vu_params *p)
+{
+    if (!p) return;
+    *p = hv_vu_params{};
+    p->triangulationConvergenceThreshold = 1e-2; p->triangulationConvergenceR = 11.0;            // parameter_definitions.c:37-44
+    p->triangulationRcondThreshold = 1e-8; p->triangulationGaussNewtonIterations = 10;
+    p->triangulationMinDist = 0; p->triangulationMaxDist = 1e300;
+    p->estimateImuCameraTimeShift = 1;                                                          // :163
+    p->useStereo = 0;
+    const double imu[9] = {1, 0, 0, 0, -1, 0, 0, 0, -1};                                         // :178 imuToCameraMatrix (symmetric)
+    for (int r = 0; r < 4; ++r) for (int c = 0; c < 4; ++c) {
+        const double v = r < 3 && c < 3 ? imu[3 * r + c] : (r == c ? 1.0 : 0.0);
+        p->imuToCamera[4 * r + c] = v; p->secondImuToCamera[4 * r + c] = v;
+    }
+    const double tr[3] = {0.0075, 0.013, -0.0003};                                               // :187 stereoCameraTranslation
+    for (int r = 0; r < 3; ++r) p->secondImuToCamera[4 * r + 3] += tr[r];                         // tracker/util.cpp:100-105
+}
+
+static int vu_fill_args(Ekf *e, const hv_vu_params *p, int np, const int *idx, const double *feat, const double *vel,
+                        const double *y, hv::VuPrepareArgs &a)
+{
+    if (!p || !idx || !feat || !vel || np < 2 || np > e->cam + 1) return HV_ERR_INVALID;
+    a = hv::VuPrepareArgs{};
+    a.batch = e->batch; a.n = e->n; a.np = np; a.stereo = p->useStereo ? 1 : 0;
+    a.m = e->m; a.pose_index = idx; a.features = feat; a.velocities = vel; a.y = y;
+    for (int r = 0; r < 3; ++r) for (int c = 0; c < 4; ++c) {
+        a.imu_to_cam[0][4 * r + c] = p->imuToCamera[4 * r + c];
+        a.imu_to_cam[1][4 * r + c] = p->secondImuToCamera[4 * r + c];
+    }
+    a.conv_threshold = p->triangulationConvergenceThreshold; a.conv_r = p->triangulationConvergenceR;
+    a.rcond_threshold = p->triangulationRcondThreshold; a.min_dist = p->triangulationMinDist; a.max_dist = p->triangulationMaxDist;
+    a.gn_iters = (int)p->triangulationGaussNewtonIterations; a.est_shift = p->estimateImuCameraTimeShift ? 1 : 0;
+    return HV_OK;
+}
+
+int hv_ekf_visual_prepare_dev(hv_ekf *h, const hv_vu_params *p, int np, const int *idx, const double *feat, const double *vel,
+                              const double *y, double *H_dev, double *v_dev, double *f_dev, double *pf_dev, int *status_dev,
+                              unsigned char *active_dev)
+{
+    if (!h || !H_dev || !v_dev || !pf_dev || !status_dev) return HV_ERR_INVALID;
+    Ekf *e = &h->e;
+    hv::VuPrepareArgs a;
+    int rc = vu_fill_args(e, p, np, idx, feat, vel, y, a);
+    if (rc != HV_OK) return rc;
+    a.H = H_dev; a.v = v_dev; a.f = f_dev; a.pf = pf_dev; a.status = status_dev; a.active = active_dev;
+    return hv::launch_vu_prepare(e->c, a);
+}
+
+int hv_ekf_visual_track_dev(hv_ekf *h, const hv_vu_params *p, int np, const int *idx, const double *feat, const double *vel,
+                            const double *y, double r_gate, double r_update, int *status_dev, int *gate_status_dev,
+                            double *chi2_dev, double *pf_dev)
+{
+    if (!h || !status_dev || !gate_status_dev || !y) return HV_ERR_INVALID;
+    Ekf *e = &h->e; Ctx *c = e->c;
+    hv::VuPrepareArgs a;
+    int rc = vu_fill_args(e, p, np, idx, feat, vel, y, a);
+    if (rc != HV_OK) return rc;
+    const int rows = 2 * np * (a.stereo ? 2 : 1);
+    if (rows > e->max_rows) return HV_ERR_INVALID;
+    if (e->vu_rows < rows) {
+        HV_HIP(c, hipStreamSynchronize(c->stream));
+        void *old[] = {e->vuH, e->vuv};
+        for (void *q : old) if (q) (void)hipFree(q);
+        e->vuH = e->vuv = nullptr; e->vu_rows = 0;
+        HV_HIP(c, hipMalloc(reinterpret_cast<void **>(&e->vuH), sizeof(double) * (size_t)rows * e->n * e->batch));
+        HV_HIP(c, hipMalloc(reinterpret_cast<void **>(&e->vuv), sizeof(double) * (size_t)rows * e->batch));
+        if (!e->vupf) HV_HIP(c, hipMalloc(reinterpret_cast<void **>(&e->vupf), sizeof(double) * 3 * e->batch));
+        if (!e->vuactive) HV_HIP(c, hipMalloc(reinterpret_cast<void **>(&e->vuactive), e->batch));
+        e->vu_rows = rows;
+    }
+    a.H = e->vuH; a.v = e->vuv; a.f = nullptr; a.pf = pf_dev ? pf_dev : e->vupf; a.status = status_dev; a.active = e->vuactive;
+    a.gate_status = gate_status_dev;                       // preset to NOT_COMPUTED; the gate overwrites it where it runs
+    rc = hv::launch_vu_prepare(c, a);
+    if (rc != HV_OK) return rc;
+    // visualTrackOutlierCheck with chiOutlierR, then updateVisualTrack with visualR where everything passed
+    rc = hv::ekf_launch_update(e, rows, e->n, e->vuH, e->vuv, nullptr, r_gate * r_gate * e->noise_scale, 0, 0, 0, chi2_dev,
+                               gate_status_dev, e->vuactive);
+    if (rc != HV_OK) return rc;
+    return hv::ekf_launch_update(e, rows, e->n, e->vuH, e->vuv, nullptr, r_update * r_update * e->noise_scale, 1, 0, 1, nullptr,
+                                 nullptr, e->vuactive, gate_status_dev);
 }
 
 /* developer aid (not in the public header): phase time stamps of the last update kernel */

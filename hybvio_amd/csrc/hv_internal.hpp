@@ -85,6 +85,22 @@ struct ScopedKernelTime {
 // pyramid.hip
 int launch_pyramid_levels(Ctx *c, int n, const int *slots_dev, const uint8_t *src_base,
                           long long src_step, int src_stride, bool src_indexed_by_slot);
+// vu_prepare.hip: triangulation + prepareVisualUpdate of one track per filter
+struct VuPrepareArgs {
+    int batch, n, np, stereo;          // filters, state dimension, poses of the track, two cameras per pose
+    const double *m;                   // [batch][n] means
+    const int *pose_index;             // [batch][np] poseTrailIndex (0 = current pose, i = trail slot i - 1)
+    const double *features, *velocities;   // [batch][ncam * np][2]: first camera's poses, then the second's
+    const double *y;                   // [batch][2 * ncam * np] measured pixels (NULL: v = -f)
+    double imu_to_cam[2][12];          // per camera the top 3 x 4 of imuToCamera, row-major
+    double conv_threshold, conv_r, rcond_threshold, min_dist, max_dist;
+    int gn_iters, est_shift;
+    double *H, *v, *f, *pf;            // [batch][rows * n] column-major, [batch][rows], optional [batch][rows], [batch][3]
+    int *status;                       // [batch][2]: TriangulatorStatus, PrepareVuStatus
+    unsigned char *active;             // optional [batch]: 1 where both are OK
+    int *gate_status;                  // optional [batch]: preset to VuOutlierStatus::NOT_COMPUTED (1)
+};
+int launch_vu_prepare(Ctx *c, const VuPrepareArgs &a);
 // capi.hip
 int build_levels_of_slot(Ctx *c, int slot);
 // klt.hip

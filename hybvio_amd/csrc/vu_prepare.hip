@@ -1,0 +1,555 @@
+// Per-track triangulation + prepareVisualUpdate on the device: builds the (H, y - f) of one
+// feature track per filter straight from the device-resident EKF mean, so that the chi2 gate and the visual update
+// (ekf.hip) run without the mean travelling to the host and a 2*nPoses x stateDim Jacobian travelling back.
+//
+// Reference: src/odometry/backend.cpp:1063-1148 (the per-track glue), src/odometry/triangulation.cpp:65-103
+// (extractCameraPoseTrail), :120-407 (Triangulator::triangulate, iterative PIVO method with derivatives),
+// :612-716 (triangulateWithTwoCameras), :31-52 (dpinv), :897-987 (prepareVisualUpdate), :1004-1012 (inverseDepth),
+// src/odometry/util.cpp:10-47 (quat2rmat_d). 3x3 matrices are row-major double[9] (like oracle/triangulation_oracle.c).
+//
+// One workgroup per filter. The work is the differentiated Gauss-Newton loop: per iteration every one of the
+// 7 * nPoses + 1 derivative columns visits every pose (<= 42 x 295 pairs, ~120 flops each, f64), so a thread owns a
+// column and walks the poses, whose per-iteration quantities (C, t, h, E, error) are shared through LDS.
+#include "hv_internal.hpp"
+
+#pragma clang fp contract(fast)
+
+namespace hv {
+namespace {
+
+constexpr int VT = 320;                 // threads: >= 7 * 42 + 1 derivative columns
+constexpr int MAXP = 42;                // 2 cameras x (cameraTrailLength + 1 <= 21) poses
+constexpr int MAXC = MAXP * 7 + 1;
+constexpr int POSE_WORDS = 51;          // p[3] R[9] dR[4][9] baseline[3]
+constexpr int ITER_WORDS = 26;          // C[9] t[3] h[3] E[6] err[2] d[3]
+
+__device__ __forceinline__ void mm3(const double *A, const double *B, double *C)
+{
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) C[3 * r + c] = A[3 * r] * B[c] + A[3 * r + 1] * B[3 + c] + A[3 * r + 2] * B[6 + c];
+}
+__device__ __forceinline__ void mmT3(const double *A, const double *B, double *C)   // A B^T
+{
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) C[3 * r + c] = A[3 * r] * B[3 * c] + A[3 * r + 1] * B[3 * c + 1] + A[3 * r + 2] * B[3 * c + 2];
+}
+__device__ __forceinline__ void mv3(const double *A, const double *x, double *y)
+{
+#pragma unroll
+    for (int r = 0; r < 3; ++r) y[r] = A[3 * r] * x[0] + A[3 * r + 1] * x[1] + A[3 * r + 2] * x[2];
+}
+__device__ __forceinline__ void mTv3(const double *A, const double *x, double *y)
+{
+#pragma unroll
+    for (int c = 0; c < 3; ++c) y[c] = A[c] * x[0] + A[3 + c] * x[1] + A[6 + c] * x[2];
+}
+
+__device__ void quat2rmat_d(const double *q, double *R, double *dR /* [4][9] */)    // util.cpp:10-47
+{
+    R[0] = q[0] * q[0] + q[1] * q[1] - q[2] * q[2] - q[3] * q[3]; R[1] = 2 * q[1] * q[2] - 2 * q[0] * q[3]; R[2] = 2 * q[1] * q[3] + 2 * q[0] * q[2];
+    R[3] = 2 * q[1] * q[2] + 2 * q[0] * q[3]; R[4] = q[0] * q[0] - q[1] * q[1] + q[2] * q[2] - q[3] * q[3]; R[5] = 2 * q[2] * q[3] - 2 * q[0] * q[1];
+    R[6] = 2 * q[1] * q[3] - 2 * q[0] * q[2]; R[7] = 2 * q[2] * q[3] + 2 * q[0] * q[1]; R[8] = q[0] * q[0] - q[1] * q[1] - q[2] * q[2] + q[3] * q[3];
+    const double a = 2 * q[0], b = 2 * q[1], c = 2 * q[2], d = 2 * q[3];
+    const double d0[9] = {a, -d, c, d, a, -b, -c, b, a}, d1[9] = {b, c, d, c, -b, -a, d, a, -b};
+    const double d2[9] = {-c, b, a, b, c, d, -a, d, -c}, d3[9] = {-d, -a, b, a, -d, c, b, c, d};
+#pragma unroll
+    for (int k = 0; k < 9; ++k) { dR[k] = d0[k]; dR[9 + k] = d1[k]; dR[18 + k] = d2[k]; dR[27 + k] = d3[k]; }
+}
+
+__device__ __forceinline__ void pos_ori(int i, int &pos, int &ori)                   // triangulation.cpp:989-998
+{
+    pos = i == 0 ? 0 : 20 + 7 * (i - 1);
+    ori = i == 0 ? 6 : 20 + 7 * (i - 1) + 3;
+}
+
+__device__ __forceinline__ void inverse_depth(const double *p, double *ip, double *dip)   // :1004-1012
+{
+    const double iz = 1 / p[2];
+    ip[0] = p[0] * iz; ip[1] = p[1] * iz; ip[2] = iz;
+    dip[0] = iz; dip[1] = 0; dip[2] = -ip[0] * iz; dip[3] = 0; dip[4] = iz; dip[5] = -ip[1] * iz; dip[6] = 0; dip[7] = 0; dip[8] = -ip[2] * iz;
+}
+
+// pseudo-inverse of the full-rank 3x2 A (row-major) and its derivative (Golub & Pereyra 4.12, triangulation.cpp:31-52)
+__device__ void pinv32(const double *A, double *iA)
+{
+    const double a = A[0] * A[0] + A[2] * A[2] + A[4] * A[4], b = A[0] * A[1] + A[2] * A[3] + A[4] * A[5];
+    const double d = A[1] * A[1] + A[3] * A[3] + A[5] * A[5], idet = 1.0 / (a * d - b * b);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        iA[c] = (d * A[2 * c] - b * A[2 * c + 1]) * idet;
+        iA[3 + c] = (-b * A[2 * c] + a * A[2 * c + 1]) * idet;
+    }
+}
+__device__ void dpinv(const double *A, const double *iA, const double *dA, double *out)
+{
+    double iAiAT[4], iATiA[9], AiA[9], iAA[4], iAdA[4], t23[6], t23b[6];
+    for (int r = 0; r < 2; ++r) for (int c = 0; c < 2; ++c) {
+        iAiAT[2 * r + c] = iA[3 * r] * iA[3 * c] + iA[3 * r + 1] * iA[3 * c + 1] + iA[3 * r + 2] * iA[3 * c + 2];
+        iAA[2 * r + c] = iA[3 * r] * A[c] + iA[3 * r + 1] * A[2 + c] + iA[3 * r + 2] * A[4 + c];
+        iAdA[2 * r + c] = iA[3 * r] * dA[c] + iA[3 * r + 1] * dA[2 + c] + iA[3 * r + 2] * dA[4 + c];
+    }
+    for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) {
+        iATiA[3 * r + c] = iA[r] * iA[c] + iA[3 + r] * iA[3 + c];
+        AiA[3 * r + c] = A[2 * r] * iA[c] + A[2 * r + 1] * iA[3 + c];
+    }
+    for (int r = 0; r < 2; ++r) for (int c = 0; c < 3; ++c) {
+        out[3 * r + c] = -(iAdA[2 * r] * iA[c] + iAdA[2 * r + 1] * iA[3 + c]);
+        t23[3 * r + c] = iAiAT[2 * r] * dA[2 * c] + iAiAT[2 * r + 1] * dA[2 * c + 1];
+        t23b[3 * r + c] = ((r == 0 ? 1.0 : 0.0) - iAA[2 * r]) * dA[2 * c] + ((r == 1 ? 1.0 : 0.0) - iAA[2 * r + 1]) * dA[2 * c + 1];
+    }
+    for (int r = 0; r < 2; ++r) for (int c = 0; c < 3; ++c) {
+        double s = 0;
+        for (int k = 0; k < 3; ++k) s += t23[3 * r + k] * ((k == c ? 1.0 : 0.0) - AiA[3 * k + c]) + t23b[3 * r + k] * iATiA[3 * k + c];
+        out[3 * r + c] += s;
+    }
+}
+
+__device__ __forceinline__ double inv3sym(const double *M, double *inv)
+{
+    const double c00 = M[4] * M[8] - M[5] * M[7], c01 = M[5] * M[6] - M[3] * M[8], c02 = M[3] * M[7] - M[4] * M[6];
+    const double det = M[0] * c00 + M[1] * c01 + M[2] * c02, id = 1.0 / det;
+    inv[0] = c00 * id; inv[1] = (M[2] * M[7] - M[1] * M[8]) * id; inv[2] = (M[1] * M[5] - M[2] * M[4]) * id;
+    inv[3] = c01 * id; inv[4] = (M[0] * M[8] - M[2] * M[6]) * id; inv[5] = (M[2] * M[3] - M[0] * M[5]) * id;
+    inv[6] = c02 * id; inv[7] = (M[1] * M[6] - M[0] * M[7]) * id; inv[8] = (M[0] * M[4] - M[1] * M[3]) * id;
+    return det;
+}
+__device__ __forceinline__ double norm1_3(const double *M)
+{
+    double best = 0;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) best = fmax(best, fabs(M[c]) + fabs(M[3 + c]) + fabs(M[6 + c]));
+    return best;
+}
+
+__global__ __launch_bounds__(VT) void vu_prepare_kernel(VuPrepareArgs a)
+{
+    __shared__ double s_trail[MAXP * POSE_WORDS];
+    __shared__ double s_it[MAXP * ITER_WORDS];
+    __shared__ double s_dpfi[3 * MAXC];          // [3][ncol]
+    __shared__ double s_feat[MAXP * 4];          // image feature (2) + velocity (2) per pose
+    __shared__ double s_small[64];               // pfi[3] pf[3] X[9] step[3] ETE[9] Eerror[3] R0T[9] pf0 ... (see offsets)
+    __shared__ double s_dpf[21 * 21];            // summed dpfdp [n][9] and dpfdq [n][12]
+    __shared__ int s_idx[24];
+    __shared__ int s_flag[4];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int n = a.np, ncam = a.stereo ? 2 : 1, nt = n * ncam, N = a.n;
+    const int dDim = nt * 7, ncol = dDim + 1;
+    const double *m = a.m + (size_t)b * N;
+    double *pfi = s_small, *pfw = s_small + 3, *X = s_small + 6, *step = s_small + 15, *R0T = s_small + 18;
+    double *scal = s_small + 36;                 // [0] error2, [1] rcond, [2] Jprev
+    if (tid < n) s_idx[tid] = a.pose_index[(size_t)b * n + tid];
+    if (tid < nt) {
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            s_feat[4 * tid + k] = a.features[((size_t)b * nt + tid) * 2 + k];
+            s_feat[4 * tid + 2 + k] = a.velocities[((size_t)b * nt + tid) * 2 + k];
+        }
+    }
+    __syncthreads();
+    // ---- extractCameraPoseTrail (triangulation.cpp:65-103): pose k of camera c from the mean ----
+    if (tid < nt) {
+        const int cam = tid / n, k = tid - cam * n;
+        const double *T = a.imu_to_cam[cam];                 // 3x4 row-major [R | baseline]
+        const double Ric[9] = {T[0], T[1], T[2], T[4], T[5], T[6], T[8], T[9], T[10]}, base[3] = {T[3], T[7], T[11]};
+        int ip, io;
+        pos_ori(s_idx[k], ip, io);
+        const double q[4] = {m[io], m[io + 1], m[io + 2], m[io + 3]};
+        double Rw[9], dRw[36], R[9], t[3];
+        quat2rmat_d(q, Rw, dRw);
+        mm3(Ric, Rw, R);
+        mTv3(R, base, t);
+        double *o = s_trail + tid * POSE_WORDS;
+#pragma unroll
+        for (int k2 = 0; k2 < 3; ++k2) { o[k2] = m[ip + k2] - t[k2]; o[48 + k2] = base[k2]; }
+#pragma unroll
+        for (int k2 = 0; k2 < 9; ++k2) o[3 + k2] = R[k2];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            double d[9];
+            mm3(Ric, dRw + 9 * j, d);
+#pragma unroll
+            for (int k2 = 0; k2 < 9; ++k2) o[12 + 9 * j + k2] = d[k2];
+        }
+    }
+    for (int i = tid; i < 3 * ncol; i += VT) s_dpfi[i] = 0.0;
+    __syncthreads();
+    // ---- triangulateWithTwoCameras between pose 0 and pose ind1 (triangulation.cpp:154-173, 612-716): thread j < 15
+    // owns derivative column j (p0 q0 p1 q1 t); every one of them recomputes the small shared part ----
+    const int ind1 = a.stereo ? nt / 2 - 1 : nt - 1;
+    const double *P0 = s_trail, *P1 = s_trail + ind1 * POSE_WORDS;
+    if (tid < 15) {
+        const double *R0 = P0 + 3, *R1 = P1 + 3;
+        double C[9], d01[3], bb[3];
+        mmT3(R0, R1, C);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) d01[k] = P1[k] - P0[k];
+        mv3(R0, d01, bb);
+        const double v0[3] = {s_feat[0], s_feat[1], 1.0}, v1[3] = {s_feat[4 * ind1], s_feat[4 * ind1 + 1], 1.0};
+        const double n0 = sqrt(v0[0] * v0[0] + v0[1] * v0[1] + 1.0), n1 = sqrt(v1[0] * v1[0] + v1[1] * v1[1] + 1.0);
+        const double vn0[3] = {v0[0] / n0, v0[1] / n0, v0[2] / n0}, vn1[3] = {v1[0] / n1, v1[1] / n1, v1[2] / n1};
+        double Cvn1[3], A[6], iA[6];
+        mv3(C, vn1, Cvn1);
+#pragma unroll
+        for (int r = 0; r < 3; ++r) { A[2 * r] = vn0[r]; A[2 * r + 1] = -Cvn1[r]; }
+        pinv32(A, iA);
+        const double s0 = iA[0] * bb[0] + iA[1] * bb[1] + iA[2] * bb[2];
+        double pf[3] = {s0 * vn0[0], s0 * vn0[1], s0 * vn0[2]};
+        double ip3[3], dd[9];
+        inverse_depth(pf, ip3, dd);
+        // column tid of dpfTwoCameras
+        double dA[6] = {0, 0, 0, 0, 0, 0}, db[3] = {0, 0, 0}, col[3];
+        const int j = tid;
+        if (j < 14) {
+            const int second = j >= 7, comp = second ? j - 7 : j;
+            if (comp < 3) {
+#pragma unroll
+                for (int r = 0; r < 3; ++r) db[r] = (second ? 1.0 : -1.0) * R0[3 * r + comp];
+            } else {
+                const int qi = comp - 3;
+                double dC[9], t[3];
+                if (!second) { mmT3(P0 + 12 + 9 * qi, R1, dC); mv3(P0 + 12 + 9 * qi, d01, db); }
+                else mmT3(R0, P1 + 12 + 9 * qi, dC);
+                mv3(dC, vn1, t);
+#pragma unroll
+                for (int r = 0; r < 3; ++r) dA[2 * r + 1] = -t[r];
+            }
+            double diA[6];
+            dpinv(A, iA, dA, diA);
+            const double ds = (iA[0] * db[0] + iA[1] * db[1] + iA[2] * db[2]) + (diA[0] * bb[0] + diA[1] * bb[1] + diA[2] * bb[2]);
+#pragma unroll
+            for (int r = 0; r < 3; ++r) col[r] = ds * vn0[r];
+        } else if (a.est_shift) {
+            double w0[3], w1[3], cw1[3], diA[6];
+#pragma unroll
+            for (int r = 0; r < 3; ++r) {
+                w0[r] = 0; w1[r] = 0;
+#pragma unroll
+                for (int c = 0; c < 2; ++c) {
+                    w0[r] += ((r == c ? 1.0 : 0.0) - vn0[r] * vn0[c]) / n0 * s_feat[2 + c];
+                    w1[r] += ((r == c ? 1.0 : 0.0) - vn1[r] * vn1[c]) / n1 * s_feat[4 * ind1 + 2 + c];
+                }
+            }
+            mv3(C, w1, cw1);
+#pragma unroll
+            for (int r = 0; r < 3; ++r) { dA[2 * r] = w0[r]; dA[2 * r + 1] = -cw1[r]; }
+            dpinv(A, iA, dA, diA);
+            const double ds0dt = diA[0] * bb[0] + diA[1] * bb[1] + diA[2] * bb[2];
+#pragma unroll
+            for (int r = 0; r < 3; ++r) col[r] = s0 * w0[r] + vn0[r] * ds0dt;
+        } else { col[0] = col[1] = col[2] = 0.0; }
+        // :181-199: place the two pose blocks and the time-shift column, all mapped through dpfi_dpf
+        double mapped[3];
+        mv3(dd, col, mapped);
+        const int dst = j < 7 ? j : j < 14 ? 7 * ind1 + (j - 7) : dDim;
+        if (!(j < 7 && ind1 == 0)) {                         // (a one-pose trail cannot occur: poseCount >= 2)
+#pragma unroll
+            for (int r = 0; r < 3; ++r) s_dpfi[r * ncol + dst] = mapped[r];
+        }
+        if (tid == 0) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) { pfi[k] = ip3[k]; pfw[k] = pf[k]; }
+#pragma unroll
+            for (int r = 0; r < 3; ++r)
+#pragma unroll
+                for (int c = 0; c < 3; ++c) R0T[3 * r + c] = R0[3 * c + r];
+            scal[1] = 0.0; scal[2] = 1e10;
+            s_flag[0] = 0;                                   // converged
+        }
+    }
+    __syncthreads();
+    // ---- Gauss-Newton with derivatives (triangulation.cpp:206-343) ----
+    const double *p0 = s_trail;
+    for (int it = 0; it < a.gn_iters; ++it) {
+        if (tid < nt) {                                       // per-pose quantities of this iteration
+            const double *cur = s_trail + tid * POSE_WORDS;
+            double *o = s_it + tid * ITER_WORDS;
+            double C[9], t[3], d[3], h[3];
+            mm3(cur + 3, R0T, C);
+#pragma unroll
+            for (int k = 0; k < 3; ++k) d[k] = p0[k] - cur[k];
+            mv3(cur + 3, d, t);
+            const double pfiab[3] = {pfi[0], pfi[1], 1.0};
+            mv3(C, pfiab, h);
+#pragma unroll
+            for (int k = 0; k < 3; ++k) h[k] += pfi[2] * t[k];
+            const double ih2 = 1.0 / h[2], ih2sq = ih2 * ih2;
+#pragma unroll
+            for (int k = 0; k < 9; ++k) o[k] = C[k];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) { o[9 + k] = t[k]; o[12 + k] = h[k]; o[23 + k] = d[k]; }
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+#pragma unroll
+                for (int c = 0; c < 2; ++c) o[15 + 3 * r + c] = -ih2 * C[3 * r + c] + h[r] * ih2sq * C[6 + c];
+                o[15 + 3 * r + 2] = -t[r] * ih2 + h[r] * ih2sq * t[2];
+                o[21 + r] = s_feat[4 * tid + r] - h[r] * ih2;
+            }
+        }
+        __syncthreads();
+        if (tid == 0) {                                       // ETE, Eerror, the step (3x3: one thread)
+            double ETE[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, Ee[3] = {0, 0, 0}, e2 = 0;
+            for (int i = 0; i < nt; ++i) {
+                const double *E = s_it + i * ITER_WORDS + 15, *er = s_it + i * ITER_WORDS + 21;
+                e2 += er[0] * er[0] + er[1] * er[1];
+#pragma unroll
+                for (int r = 0; r < 3; ++r) {
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) ETE[3 * r + c] += E[r] * E[c] + E[3 + r] * E[3 + c];
+                    Ee[r] += E[r] * er[0] + E[3 + r] * er[1];
+                }
+            }
+            double Xl[9], st[3];
+            inv3sym(ETE, Xl);
+            mv3(Xl, Ee, st);
+#pragma unroll
+            for (int k = 0; k < 9; ++k) X[k] = Xl[k];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) step[k] = st[k];
+            scal[0] = e2;
+            scal[1] = 1.0 / (norm1_3(ETE) * norm1_3(Xl));
+        }
+        // derivative columns: dEerror_j and dETE_j accumulated over the poses, with the OLD pfi (:236-312);
+        // VT >= ncol, so a thread owns at most one column and keeps its sums in registers across the barrier
+        const int j = tid;
+        const bool is_t = j == dDim;
+        const bool has = j < ncol && !(is_t && !a.est_shift);
+        double dEe[3] = {0, 0, 0}, dM[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+        if (has) {
+            const int pj = is_t ? -1 : j / 7, comp = is_t ? 0 : j - 7 * pj;
+            const double dpa = s_dpfi[j], dpb = s_dpfi[ncol + j], dpc = s_dpfi[2 * ncol + j];
+            const double pa = pfi[0], pb = pfi[1], pc = pfi[2];
+            for (int i = 0; i < nt; ++i) {
+                const double *o = s_it + i * ITER_WORDS;
+                const double *C = o, *t = o + 9, *h = o + 12, *E = o + 15, *er = o + 21, *d = o + 23;
+                double dC[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, dt[3] = {0, 0, 0};
+                const bool current = pj == i, first = pj == 0;
+                if (current || first) {
+                    const double *cur = s_trail + i * POSE_WORDS;
+                    double dp0[3] = {0, 0, 0}, dpi[3] = {0, 0, 0}, dd[3];
+                    if (comp < 3) {
+                        if (current) dpi[comp] = 1;
+                        if (first) dp0[comp] = 1;
+                    } else {
+                        const int qi = comp - 3;
+                        if (current) {
+                            const double *dRi = cur + 12 + 9 * qi;
+                            double a1[9], t1[3];
+                            mm3(dRi, R0T, a1);
+                            mTv3(dRi, cur + 48, dpi);
+                            mv3(dRi, d, t1);
+#pragma unroll
+                            for (int k = 0; k < 9; ++k) dC[k] += a1[k];
+#pragma unroll
+                            for (int k = 0; k < 3; ++k) { dpi[k] = -dpi[k]; dt[k] += t1[k]; }
+                        }
+                        if (first) {
+                            const double *dR0 = s_trail + 12 + 9 * qi;
+                            double a2[9];
+                            mmT3(cur + 3, dR0, a2);
+                            mTv3(dR0, s_trail + 48, dp0);
+#pragma unroll
+                            for (int k = 0; k < 9; ++k) dC[k] += a2[k];
+#pragma unroll
+                            for (int k = 0; k < 3; ++k) dp0[k] = -dp0[k];
+                        }
+                    }
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) dd[k] = dp0[k] - dpi[k];
+                    double t2[3];
+                    mv3(cur + 3, dd, t2);
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) dt[k] += t2[k];
+                }
+                double dh[3];
+#pragma unroll
+                for (int r = 0; r < 3; ++r)
+                    dh[r] = (dC[3 * r] * pa + dC[3 * r + 1] * pb + dC[3 * r + 2]) + (C[3 * r] * dpa + C[3 * r + 1] * dpb) + dpc * t[r] + pc * dt[r];
+                const double ih2 = 1.0 / h[2], ih2sq = ih2 * ih2;
+                const double dih2 = -dh[2] * ih2sq, dih2sq = -2 * dh[2] * ih2sq * ih2;
+                double dErr[2], dE[6];
+#pragma unroll
+                for (int r = 0; r < 2; ++r) {
+                    dErr[r] = (is_t ? s_feat[4 * i + 2 + r] : 0.0) - dh[r] * ih2 - dih2 * h[r];
+                    const double g = dh[r] * ih2sq + dih2sq * h[r];
+#pragma unroll
+                    for (int c = 0; c < 2; ++c) dE[3 * r + c] = -dih2 * C[3 * r + c] - ih2 * dC[3 * r + c] + g * C[6 + c] + h[r] * ih2sq * dC[6 + c];
+                    dE[3 * r + 2] = -dt[r] * ih2 - t[r] * dih2 + g * t[2] + h[r] * ih2sq * dt[2];
+                }
+#pragma unroll
+                for (int r = 0; r < 3; ++r) {
+                    dEe[r] += dE[r] * er[0] + dE[3 + r] * er[1] + E[r] * dErr[0] + E[3 + r] * dErr[1];
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) dM[3 * r + c] += dE[r] * E[c] + dE[3 + r] * E[3 + c] + E[r] * dE[c] + E[3 + r] * dE[3 + c];
+                }
+            }
+        }
+        __syncthreads();                                      // X, step, error2 are published; everybody is done with the old pfi
+        if (has) {                                            // :324-328: d(A^-1) = -A^-1 dA A^-1
+            double t1[3], t2[3], t3[3];
+            mv3(dM, step, t1);
+            mv3(X, t1, t2);
+            mv3(X, dEe, t3);
+#pragma unroll
+            for (int r = 0; r < 3; ++r) s_dpfi[r * ncol + j] += t2[r] - t3[r];
+        }
+        if (tid == 0) {                                       // :316-342
+#pragma unroll
+            for (int k = 0; k < 3; ++k) pfi[k] -= step[k];
+            const double J = 0.5 * scal[0] / (a.conv_r * a.conv_r), Jd = fabs((J - scal[2]) / J);
+            scal[2] = J;
+            if (Jd < a.conv_threshold) s_flag[0] = 1;
+        }
+        __syncthreads();
+        if (s_flag[0]) break;
+    }
+    // ---- status, back to world coordinates (:345-392) ----
+    int *st_out = a.status + 2 * (size_t)b;
+    double *M = s_small + 40, *pf0 = s_small + 49;           // R0T * dpf0_dpfi, the point in the frame of pose 0
+    if (tid == 0) {
+        int status = HV_TRI_OK;
+        if (!s_flag[0]) status = HV_TRI_NO_CONVERGENCE;
+        else if (scal[1] < a.rcond_threshold) status = HV_TRI_BAD_COND;
+        if (status == HV_TRI_OK) {
+            double d[9], q[3], w[3], Ml[9];
+            inverse_depth(pfi, q, d);
+            mv3(R0T, q, w);
+#pragma unroll
+            for (int k = 0; k < 3; ++k) { pfw[k] = w[k] + p0[k]; pf0[k] = q[k]; }
+            if (pfw[0] == p0[0] && pfw[1] == p0[1] && pfw[2] == p0[2]) status = HV_TRI_UNKNOWN_PROBLEM;
+            mm3(R0T, d, Ml);
+#pragma unroll
+            for (int k = 0; k < 9; ++k) M[k] = Ml[k];
+        }
+        s_flag[1] = status;
+        s_flag[2] = 0;                                        // behind any camera
+    }
+    __syncthreads();
+    int status = s_flag[1];
+    if (status == HV_TRI_OK) {
+        if (tid < ncol) {
+            const int j = tid;
+            double u[3] = {0, 0, 0}, v[3];
+            if (j >= 3 && j < 7) mTv3(s_trail + 12 + 9 * (j - 3), pf0, u);                // dR0T * pf0
+            const double cur[3] = {s_dpfi[j], s_dpfi[ncol + j], s_dpfi[2 * ncol + j]};
+            mv3(M, cur, v);
+#pragma unroll
+            for (int r = 0; r < 3; ++r) s_dpfi[r * ncol + j] = u[r] + v[r] + (j == r ? 1.0 : 0.0);      // dp0 = e_j for j < 3 (r < 3, so j == r implies it)
+        }
+        if (tid < nt) {                                       // isBehind (:54-60)
+            const double *cur = s_trail + tid * POSE_WORDS;
+            const double d[3] = {pfw[0] - cur[0], pfw[1] - cur[1], pfw[2] - cur[2]};
+            if (cur[9] * d[0] + cur[10] * d[1] + cur[11] * d[2] < 0) atomicOr(&s_flag[2], 1);
+        }
+        __syncthreads();
+        if (s_flag[2]) status = HV_TRI_BEHIND;
+    }
+    {   // backend.cpp:1098-1102: depth window on whatever point the triangulation left behind
+        const double dx = pfw[0] - p0[0], dy = pfw[1] - p0[1], dz = pfw[2] - p0[2], depth = sqrt(dx * dx + dy * dy + dz * dz);
+        if (depth < a.min_dist || depth > a.max_dist) status = HV_TRI_BAD_DEPTH;
+    }
+    const bool with_derivatives = status == HV_TRI_OK;
+    // backend.cpp:1108-1119: per-pose derivative blocks, the two cameras of a pose summed
+    if (with_derivatives)
+        for (int i = tid; i < n * 21; i += VT) {
+            const int k = i / 21, e = i - 21 * k, r = e / 7, c = e - 7 * r;              // [k][r][c]: c < 3 position, else quaternion
+            double v = s_dpfi[r * ncol + 7 * k + c];
+            if (a.stereo) v += s_dpfi[r * ncol + 7 * (k + n) + c];
+            s_dpf[i] = v;
+        }
+    // ---- prepareVisualUpdate (triangulation.cpp:897-987), full-width H (batch layout of the update kernel) ----
+    // per trail pose: dip*R (2x3), the own-orientation block dip*dRpt (2x4), f, depth class  -> s_it[i][0..16]
+    if (tid < nt) {
+        const double *pose = s_trail + tid * POSE_WORDS;
+        double *o = s_it + tid * ITER_WORDS;
+        const double pt[3] = {pfw[0] - pose[0], pfw[1] - pose[1], pfw[2] - pose[2]};
+        double pfc[3], ipH[3], dip[9];
+        mv3(pose + 3, pt, pfc);
+        inverse_depth(pfc, ipH, dip);
+        o[16] = pfc[2] == 0 ? 1.0 : pfc[2] < 0 ? 2.0 : 0.0;
+        o[14] = ipH[0]; o[15] = ipH[1];
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) o[3 * r + c] = dip[3 * r] * pose[3 + c] + dip[3 * r + 1] * pose[6 + c] + dip[3 * r + 2] * pose[9 + c];
+#pragma unroll
+        for (int jq = 0; jq < 4; ++jq) {
+            const double *dR = pose + 12 + 9 * jq;
+            double a1[3], b1[3], b2[3];
+            mv3(dR, pt, a1);
+            mTv3(dR, pose + 48, b1);
+            mv3(pose + 3, b1, b2);
+#pragma unroll
+            for (int r = 0; r < 2; ++r) o[6 + 4 * r + jq] = dip[3 * r] * (a1[0] + b2[0]) + dip[3 * r + 1] * (a1[1] + b2[1]) + dip[3 * r + 2] * (a1[2] + b2[2]);
+        }
+    }
+    __syncthreads();
+    const int rows = 2 * nt;
+    double *H = a.H + (size_t)b * rows * N;
+    for (int c = tid; c < N; c += VT) {
+        // which pose of the track (if any) owns state column c, and which of its 7 components
+        int k = -1, comp = 0;
+        for (int q = 0; q < n; ++q) {
+            int ip, io;
+            pos_ori(s_idx[q], ip, io);
+            if (c >= ip && c < ip + 3) { k = q; comp = c - ip; }
+            else if (c >= io && c < io + 4) { k = q; comp = 3 + c - io; }
+        }
+        const bool sft = c == 19 && with_derivatives && a.est_shift;
+        for (int i = 0; i < nt; ++i) {
+            const double *o = s_it + i * ITER_WORDS;
+            double h0 = 0.0, h1 = 0.0;
+            if (k >= 0) {
+                if (k == i % n) {                                                          // own pose: :946-953
+                    if (comp < 3) { h0 = -o[comp]; h1 = -o[3 + comp]; }
+                    else { h0 = o[6 + comp - 3]; h1 = o[10 + comp - 3]; }
+                }
+                if (with_derivatives) {                                                    // :955-964
+                    const double *dp = s_dpf + 21 * k + comp;
+                    h0 += o[0] * dp[0] + o[1] * dp[7] + o[2] * dp[14];
+                    h1 += o[3] * dp[0] + o[4] * dp[7] + o[5] * dp[14];
+                }
+            } else if (sft) {                                                              // :965-967
+                const double t0 = s_dpfi[dDim], t1 = s_dpfi[ncol + dDim], t2 = s_dpfi[2 * ncol + dDim];
+                h0 = o[0] * t0 + o[1] * t1 + o[2] * t2 - s_feat[4 * i + 2];
+                h1 = o[3] * t0 + o[4] * t1 + o[5] * t2 - s_feat[4 * i + 3];
+            }
+            H[(size_t)c * rows + 2 * i] = h0;
+            H[(size_t)c * rows + 2 * i + 1] = h1;
+        }
+    }
+    if (tid < nt) {
+        const double *o = s_it + tid * ITER_WORDS;
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const size_t e = (size_t)b * rows + 2 * tid + r;
+            if (a.f) a.f[e] = o[14 + r];
+            a.v[e] = (a.y ? a.y[e] : 0.0) - o[14 + r];
+        }
+    }
+    if (tid == 0) {
+        int prep = 0;
+        for (int i = 0; i < nt && prep == 0; ++i) prep = (int)s_it[i * ITER_WORDS + 16];   // first failing pose decides (:920-927)
+        st_out[0] = status; st_out[1] = prep;
+        if (a.active) a.active[b] = (status == HV_TRI_OK && prep == 0) ? 1 : 0;
+        if (a.gate_status) a.gate_status[b] = 1;                                       // VuOutlierStatus::NOT_COMPUTED
+#pragma unroll
+        for (int k = 0; k < 3; ++k) a.pf[3 * (size_t)b + k] = pfw[k];
+    }
+}
+
+}  // namespace
+
+int launch_vu_prepare(Ctx *c, const VuPrepareArgs &a)
+{
+    if (a.np < 2 || a.np * (a.stereo ? 2 : 1) > MAXP || a.batch < 1) return HV_ERR_INVALID;
+    ScopedKernelTime tm(c, HV_K_VU_PREPARE);
+    hipLaunchKernelGGL(vu_prepare_kernel, dim3((unsigned)a.batch), dim3(VT), 0, c->stream, a);
+    HV_HIP(c, hipGetLastError());
+    return HV_OK;
+}
+
+}  // namespace hv

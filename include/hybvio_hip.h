@@ -179,6 +179,46 @@ int hv_ekf_visual_update(hv_ekf *ekf, int n_rows, int l, const double *H, const 
 /* Device-resident variant: mode 0 = gate only, 1 = update, 2 = update only where the gate passes. */
 int hv_ekf_visual_dev(hv_ekf *ekf, int n_rows, int l, const double *H_dev, const double *v_dev, double r,
                       int mode, double *chi2_dev, int *status_dev);
+/* ---- per-track triangulation + prepareVisualUpdate on the device ----
+ * Replaces, for one pose-trail track per filter, the host code between two EKF calls of the visual update loop
+ * (src/odometry/backend.cpp:1063-1148): extractCameraPoseTrail (triangulation.cpp:65-103) from the DEVICE mean,
+ * Triangulator::triangulate with derivatives (triangulation.cpp:120-407, the iterative default), the depth window,
+ * the stereo derivative sum, prepareVisualUpdate (triangulation.cpp:897-987, full-width H). Parameter names are the
+ * reference's (codegen/parameter_definitions.c:37-44,163,178-187). */
+typedef struct hv_vu_params {
+    double triangulationConvergenceThreshold, triangulationConvergenceR, triangulationRcondThreshold;
+    unsigned triangulationGaussNewtonIterations;
+    double triangulationMinDist, triangulationMaxDist;
+    int estimateImuCameraTimeShift;
+    int useStereo;
+    double imuToCamera[16], secondImuToCamera[16];     /* 4 x 4 homogeneous, row-major (Parameters::imuToCamera) */
+} hv_vu_params;
+void hv_vu_default_params(hv_vu_params *p);
+/* odometry::TriangulatorStatus (output.hpp:21-29) and PrepareVuStatus (output.hpp:15-19) */
+enum { HV_TRI_OK = 0, HV_TRI_HYBRID = 1, HV_TRI_BEHIND = 2, HV_TRI_BAD_COND = 3, HV_TRI_NO_CONVERGENCE = 4,
+       HV_TRI_BAD_DEPTH = 5, HV_TRI_UNKNOWN_PROBLEM = 6 };
+enum { HV_PREPARE_VU_OK = 0, HV_PREPARE_VU_ZERO_DEPTH = 1, HV_PREPARE_VU_BEHIND = 2 };
+/* All arrays in device memory, one track of n_poses poses per filter:
+ *   pose_index_dev [batch][n_poses]            poseTrailIndex of the track (ekf_state_index: 0 = current pose)
+ *   features_dev / velocities_dev [batch][ncam * n_poses][2]   normalized image points / their velocities, the first
+ *                                              camera's poses then the second's (buildTrackVectors order)
+ *   y_dev [batch][2 * ncam * n_poses]          measured points (the y of buildTrackVectors); may be NULL
+ * Outputs: H_dev [batch][(2 * ncam * n_poses) x stateDim] column-major, v_dev = y - f, f_dev (may be NULL), pf_dev
+ * [batch][3] world point, status_dev [batch][2] = {TriangulatorStatus, PrepareVuStatus}, active_dev (may be NULL)
+ * [batch] = 1 where both are OK -- the inputs hv_ekf_visual_dev takes. Asynchronous. */
+int hv_ekf_visual_prepare_dev(hv_ekf *ekf, const hv_vu_params *p, int n_poses, const int *pose_index_dev,
+                              const double *features_dev, const double *velocities_dev, const double *y_dev,
+                              double *H_dev, double *v_dev, double *f_dev, double *pf_dev, int *status_dev,
+                              unsigned char *active_dev);
+/* The whole per-track step in one call: prepare as above into internal buffers, then the chi2 gate and -- where the
+ * triangulation, prepareVisualUpdate and the gate all pass -- updateVisualTrack (backend.cpp:1150-1185 with
+ * batchVisualUpdate false). r_gate = trackChiTestOutlierR (the R of visualTrackOutlierCheck), r_update = visualR.
+ * status_dev [batch][2] = {TriangulatorStatus, PrepareVuStatus}; gate_status_dev [batch] = VuOutlierStatus (0 INLIER,
+ * 3 CHI2, 1 NOT_COMPUTED where the track never reached the gate); chi2_dev / pf_dev may be NULL. Asynchronous. */
+int hv_ekf_visual_track_dev(hv_ekf *ekf, const hv_vu_params *p, int n_poses, const int *pose_index_dev,
+                            const double *features_dev, const double *velocities_dev, const double *y_dev,
+                            double r_gate, double r_update, int *status_dev, int *gate_status_dev, double *chi2_dev,
+                            double *pf_dev);
 /* updateVisualPoseAugmentation(discarded[f]) (ekf.cpp:848-885; -1 = last pose) incl. the Joseph form,
  * maintainPositiveSemiDefinite and normalizeQuaternions; updateUndoAugmentation (ekf.cpp:888-903). */
 int hv_ekf_augment(hv_ekf *ekf, const int *discarded /* [batch] or NULL */, const unsigned char *active);
@@ -245,7 +285,7 @@ int hv_ingest_build_batch_dev(hv_ctx *ctx, int n, const int *slots_dev, const ui
 
 /* ---- per-kernel timing (hipEvents on the context stream) ---------------------------------- */
 enum { HV_K_PYR_L0 = 0, HV_K_PYR_LN = 1, HV_K_KLT = 2, HV_K_EKF_PREDICT = 3, HV_K_EKF_UPDATE = 4,
-       HV_K_EKF_AUGMENT = 5, HV_K_GFTT = 6, HV_K_INGEST = 7, HV_K_COUNT = 8 };
+       HV_K_EKF_AUGMENT = 5, HV_K_GFTT = 6, HV_K_INGEST = 7, HV_K_VU_PREPARE = 8, HV_K_COUNT = 9 };
 int hv_profile_enable(hv_ctx *ctx, int on);
 int hv_profile_reset(hv_ctx *ctx);
 /* Synchronizes, then returns accumulated device milliseconds and launch count of a kernel class. */

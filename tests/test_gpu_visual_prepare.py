@@ -1,0 +1,235 @@
+"""GPU parity tests of per-track triangulation + prepareVisualUpdate through the C ABI against
+oracle/triangulation_oracle.c, which the reference's own tests pin (tests/test_oracle_triangulation.py):
+TriangulatorStatus / PrepareVuStatus bit-exact, the triangulated point, H and f within 1e-9 relative (f64 with a
+different summation order: parallel derivative columns, FMA contraction)."""
+import os
+
+import numpy as np
+import pytest
+
+from hybvio_amd import capi
+
+pytestmark = pytest.mark.gpu
+FX = os.path.join(os.path.dirname(__file__), "golden", "triangulation_reference_fixtures.npz")
+POS, ORI, SFT, CAM = 0, 6, 19, 20
+TOL = 1e-9
+
+
+def _state_from_poses(poses, cam_pose_count):
+    m = np.zeros(20 + 7 * cam_pose_count)
+    m[POS:POS + 3], m[ORI:ORI + 4] = poses[0:3], poses[3:7]
+    for i in range(9):
+        m[CAM + 7 * i:CAM + 7 * i + 7] = poses[7 * (i + 1):7 * (i + 2)]
+    for i in range(9, cam_pose_count):
+        m[CAM + 7 * i + 3] = 1.0
+    return m
+
+
+def _device_prepare(ctx, trail_len, means, vp, idx, feat, vel, y=None):
+    """Runs hv_ekf_visual_prepare_dev for a batch; all filters share the track length."""
+    import torch
+    B = len(means)
+    g = capi.EkfBatch(ctx, capi.ekf_default_params(cameraTrailLength=trail_len), B)
+    for b in range(B):
+        g.set_state(b, means[b])
+    n, npose = g.n, idx.shape[1]
+    rows = 2 * npose * (2 if vp.useStereo else 1)
+    dev = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a, dt)).cuda()
+    d_idx, d_feat, d_vel = dev(idx, np.int32), dev(feat, np.float64), dev(vel, np.float64)
+    d_y = dev(y, np.float64) if y is not None else None
+    H = torch.full((B, n, rows), np.nan, dtype=torch.float64, device="cuda")
+    v, f = torch.zeros((B, rows), dtype=torch.float64, device="cuda"), torch.zeros((B, rows), dtype=torch.float64, device="cuda")
+    pf = torch.zeros((B, 3), dtype=torch.float64, device="cuda")
+    st = torch.full((B, 2), -1, dtype=torch.int32, device="cuda")
+    act = torch.full((B,), 7, dtype=torch.uint8, device="cuda")
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    g.visual_prepare_dev(vp, npose, d_idx.data_ptr(), d_feat.data_ptr(), d_vel.data_ptr(), d_y.data_ptr() if d_y is not None else 0,
+                         H.data_ptr(), v.data_ptr(), f.data_ptr(), pf.data_ptr(), st.data_ptr(), act.data_ptr())
+    torch.cuda.synchronize()
+    g.close()
+    return (H.cpu().numpy().transpose(0, 2, 1), v.cpu().numpy(), f.cpu().numpy(), pf.cpu().numpy(), st.cpu().numpy(), act.cpu().numpy())
+
+
+def _rel(a, b):
+    return float(np.linalg.norm(np.asarray(a) - np.asarray(b)) / max(np.linalg.norm(b), 1e-300))
+
+
+def test_reference_visual_fixture_matlab_point(oracle):
+    """test/triangulation.cpp "visual": the Matlab point (|.|_1 < 1e-5) and the oracle's H, f -- through the device."""
+    fx = np.load(FX)
+    m = _state_from_poses(fx["visual_poses"], 20)
+    T = oracle.vec2matrix(fx["imu_default"])
+    uv, vel, idx = fx["visual_uv"], np.full((10, 2), 0.1), np.arange(10, dtype=np.int32)
+    vp = capi.vu_default_params(imu_to_camera=T)
+    with capi.Context(width=64, height=64) as ctx:
+        H, v, f, pf, st, act = _device_prepare(ctx, 20, [m], vp, idx[None], uv[None], vel[None], y=uv.reshape(1, -1))
+    assert st[0].tolist() == [0, 0] and act[0] == 1
+    assert np.abs(pf[0] - fx["visual_pf_matlab"]).sum() < 1e-5
+    ost, ops, opf, oH, of = oracle.visual_track_prepare(oracle.tri_default_params(), m, idx, T, None, uv, vel)
+    assert (ost, ops) == (0, 0)
+    assert _rel(pf[0], opf) < TOL and _rel(H[0], oH) < TOL and _rel(f[0], of) < TOL
+    assert np.abs(v[0] - (uv.reshape(-1) - of)).max() < 1e-12
+
+
+def test_reference_stereo_fixture(oracle):
+    """test/triangulation.cpp "stereo_visual" inputs: 10 poses x 2 cameras, 40 x 90 Jacobian."""
+    fx = np.load(FX)
+    m = _state_from_poses(fx["stereo_poses"], 10)
+    T1, T2 = oracle.vec2matrix(fx["stereo_imu"]), oracle.vec2matrix(fx["stereo_imu2"])
+    T2[:3, 3] += fx["stereo_translation"]
+    uv = np.concatenate([fx["stereo_uv"], fx["stereo_uv2"] * 1.1])
+    vel, idx = np.full((20, 2), 0.1), np.arange(10, dtype=np.int32)
+    vp = capi.vu_default_params(imu_to_camera=T1, second_imu_to_camera=T2)
+    with capi.Context(width=64, height=64) as ctx:
+        H, v, f, pf, st, act = _device_prepare(ctx, 10, [m], vp, idx[None], uv[None], vel[None])
+    ost, ops, opf, oH, of = oracle.visual_track_prepare(oracle.tri_default_params(), m, idx, T1, T2, uv, vel)
+    assert st[0].tolist() == [ost, ops] == [0, 0]
+    assert H.shape == (1, 40, 90)
+    assert _rel(pf[0], opf) < TOL and _rel(H[0], oH) < TOL and _rel(f[0], of) < TOL
+
+
+def _quat(axis, angle):
+    axis = np.asarray(axis, float) / np.linalg.norm(axis)
+    return np.concatenate([[np.cos(angle / 2)], np.sin(angle / 2) * axis])
+
+
+def _random_tracks(oracle, rng, B, trail_len, npose, stereo, bad_fraction=0.25):
+    """B filters on smooth random trajectories, one track each: a world point projected into the chosen poses (plus
+    pixel noise), some tracks replaced by nonsense so that every failure status occurs."""
+    n = 20 + 7 * trail_len
+    T1 = oracle.vec2matrix([0, -1, 0, -1, 0, 0, 0, 0, -1])
+    T2 = T1.copy(); T2[:3, 3] += [0.11, 0.002, -0.001]
+    means, idxs, feats, vels = [], [], [], []
+    for b in range(B):
+        m = np.zeros(n)
+        base_q = _quat(rng.normal(size=3), rng.uniform(0, 0.4))
+        vel_dir = rng.normal(size=3) * 0.15
+        for k in range(trail_len + 1):
+            ip = POS if k == 0 else CAM + 7 * (k - 1)
+            io = ORI if k == 0 else CAM + 7 * (k - 1) + 3
+            m[ip:ip + 3] = -vel_dir * k + 0.01 * rng.normal(size=3)
+            q = base_q + 0.02 * k * rng.normal(size=4) * 0.2
+            m[io:io + 4] = q / np.linalg.norm(q)
+        idx = np.sort(rng.choice(trail_len + 1, npose, replace=False)).astype(np.int32)
+        trail = oracle.extract_camera_pose_trail(m, idx, T1, T2 if stereo else None)
+        # a point 2..12 m in front of the first camera of the track
+        R0, p0 = np.array(trail[0].R).reshape(3, 3), np.array(trail[0].p)
+        pw = p0 + R0.T @ np.array([rng.uniform(-1, 1), rng.uniform(-1, 1), rng.uniform(2, 12)])
+        ft = []
+        for t in trail:
+            pc = np.array(t.R).reshape(3, 3) @ (pw - np.array(t.p))
+            ft.append(pc[:2] / pc[2] + 2e-3 * rng.normal(size=2))
+        ft = np.array(ft)
+        if rng.uniform() < bad_fraction:
+            ft = rng.normal(size=ft.shape) * rng.choice([0.05, 1.0])
+        means.append(m); idxs.append(idx); feats.append(ft); vels.append(rng.normal(size=ft.shape) * 0.2)
+    return T1, (T2 if stereo else None), np.array(means), np.array(idxs), np.array(feats), np.array(vels)
+
+
+@pytest.mark.parametrize("trail_len,npose,stereo", [(20, 10, True), (20, 21, True), (20, 4, False), (20, 21, False), (12, 2, True),
+                                                    (20, 7, True), (5, 6, False)])
+def test_random_tracks_match_the_oracle(oracle, trail_len, npose, stereo):
+    rng = np.random.default_rng(100 * trail_len + npose + (7 if stereo else 0))
+    B = 48
+    T1, T2, means, idx, feat, vel = _random_tracks(oracle, rng, B, trail_len, npose, stereo)
+    vp = capi.vu_default_params(imu_to_camera=T1, second_imu_to_camera=T2) if stereo else capi.vu_default_params(imu_to_camera=T1)
+    y = feat.reshape(B, -1) + 1e-3
+    with capi.Context(width=64, height=64) as ctx:
+        H, v, f, pf, st, act = _device_prepare(ctx, trail_len, means, vp, idx, feat, vel, y=y)
+    par = oracle.tri_default_params()
+    seen = set()
+    for b in range(B):
+        ost, ops, opf, oH, of = oracle.visual_track_prepare(par, means[b], idx[b], T1, T2, feat[b], vel[b])
+        assert st[b].tolist() == [ost, ops], (b, st[b], ost, ops)
+        assert act[b] == (1 if (ost, ops) == (0, 0) else 0)
+        seen.add(oracle.TRI_STATUS[ost])
+        if ost == 0 and ops == 0:
+            assert _rel(pf[b], opf) < TOL and _rel(H[b], oH) < TOL and _rel(f[b], of) < TOL, (b, _rel(H[b], oH))
+            assert np.abs(v[b] - (y[b] - of)).max() < 1e-9
+            assert not H[b][:, 3:6].any() and not H[b][:, 10:19].any()          # velocity and biases never enter
+    assert "OK" in seen and len(seen) >= 2, seen
+
+
+def test_parameters_reach_the_kernel(oracle):
+    """Depth window, iteration limit and the time-shift switch change the result exactly as in the oracle."""
+    rng = np.random.default_rng(5)
+    B = 16
+    T1, T2, means, idx, feat, vel = _random_tracks(oracle, rng, B, 20, 8, True, bad_fraction=0.0)
+    for over in ({"triangulationMaxDist": 4.0}, {"triangulationMinDist": 6.0}, {"triangulationGaussNewtonIterations": 1},
+                 {"estimateImuCameraTimeShift": 0}, {"triangulationRcondThreshold": 1e-2}):
+        vp = capi.vu_default_params(imu_to_camera=T1, second_imu_to_camera=T2, **over)
+        par = oracle.tri_default_params(**over)
+        with capi.Context(width=64, height=64) as ctx:
+            H, v, f, pf, st, act = _device_prepare(ctx, 20, means, vp, idx, feat, vel)
+        statuses = set()
+        for b in range(B):
+            ost, ops, opf, oH, of = oracle.visual_track_prepare(par, means[b], idx[b], T1, T2, feat[b], vel[b])
+            assert st[b].tolist() == [ost, ops], (over, b)
+            statuses.add(ost)
+            if (ost, ops) == (0, 0):
+                assert _rel(H[b], oH) < TOL and _rel(f[b], of) < TOL
+                if not par.estimateImuCameraTimeShift:
+                    assert not H[b][:, SFT].any()
+        if "triangulationGaussNewtonIterations" in over:
+            assert statuses == {4}                                                     # NO_CONVERGENCE everywhere
+        if "triangulationMaxDist" in over or "triangulationMinDist" in over:
+            assert 5 in statuses                                                        # BAD_DEPTH
+
+
+def test_visual_track_dev_prepare_gate_update_equals_the_reference_sequence(oracle):
+    """hv_ekf_visual_track_dev = backend.cpp:1063-1185 for one track per filter: prepare from the device mean, gate with
+    trackChiTestOutlierR, update with visualR only where triangulation, prepare and gate pass. Filters that fail stay
+    bit-identical; the others match the oracle's EKF to 1e-9 relative."""
+    import torch
+    rng = np.random.default_rng(11)
+    B, trail_len, npose = 24, 20, 9
+    T1, T2, means, idx, feat, vel = _random_tracks(oracle, rng, B, trail_len, npose, True, bad_fraction=0.3)
+    y = feat.reshape(B, -1) + 2e-3 * rng.normal(size=(B, feat.shape[1] * 2))
+    y[3:12] += 3.0                                                                      # triangulable tracks the gate must reject
+    vp = capi.vu_default_params(imu_to_camera=T1, second_imu_to_camera=T2)
+    par = oracle.tri_default_params()
+    r_gate, r_update = 1.5, 0.05                                                         # parameter_definitions.c:23,91
+    with capi.Context(width=64, height=64) as ctx:
+        g = capi.EkfBatch(ctx, capi.ekf_default_params(cameraTrailLength=trail_len), B)
+        filters = []
+        for b in range(B):
+            o = oracle.Ekf(oracle.ekf_default_params(cameraTrailLength=trail_len))
+            A = rng.normal(size=(o.n, o.n)) * 0.02
+            P = o.P.copy() * 1e-6 + A @ A.T * 1e-3 + np.eye(o.n) * 1e-4
+            o.set_state(means[b]); o.set_cov(P)
+            g.set_state(b, means[b], P)
+            filters.append(o)
+        dev = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a, dt)).cuda()
+        d_idx, d_feat, d_vel, d_y = dev(idx, np.int32), dev(feat, np.float64), dev(vel, np.float64), dev(y, np.float64)
+        st = torch.full((B, 2), -1, dtype=torch.int32, device="cuda")
+        gs = torch.full((B,), -1, dtype=torch.int32, device="cuda")
+        chi = torch.zeros((B,), dtype=torch.float64, device="cuda")
+        pf = torch.zeros((B, 3), dtype=torch.float64, device="cuda")
+        ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+        g.visual_track_dev(vp, npose, d_idx.data_ptr(), d_feat.data_ptr(), d_vel.data_ptr(), d_y.data_ptr(), r_gate, r_update,
+                           st.data_ptr(), gs.data_ptr(), chi.data_ptr(), pf.data_ptr())
+        torch.cuda.synchronize()
+        st, gs, chi = st.cpu().numpy(), gs.cpu().numpy(), chi.cpu().numpy()
+        outcomes = set()
+        for b, o in enumerate(filters):
+            ost, ops, opf, oH, of = oracle.visual_track_prepare(par, means[b], idx[b], T1, T2, feat[b], vel[b])
+            assert st[b].tolist() == [ost, ops]
+            m0, P0 = o.m.copy(), o.P.copy()
+            mg, Pg = g.get_state(b)
+            if (ost, ops) != (0, 0):
+                assert gs[b] == 1                                                         # NOT_COMPUTED
+                assert np.array_equal(mg, m0) and np.array_equal(Pg, P0)
+                outcomes.add("skipped")
+                continue
+            status, chi2 = o.visual_track_outlier_check(oH, of, y[b], r_gate)
+            assert gs[b] == status and abs(chi[b] - chi2) <= 1e-7 * max(1.0, abs(chi2))
+            if status == 0:
+                o.update_visual_track(oH, of, y[b], r_update)
+                assert _rel(mg, o.m) < 1e-8 and _rel(Pg, o.P) < 1e-8, (b, _rel(mg, o.m), _rel(Pg, o.P))
+                assert not np.array_equal(mg, m0)
+                outcomes.add("updated")
+            else:
+                assert np.array_equal(mg, m0) and np.array_equal(Pg, P0)
+                outcomes.add("gated")
+        assert outcomes == {"skipped", "updated", "gated"}, outcomes
+        g.close()
