@@ -15,9 +15,16 @@
 #pragma clang fp contract(fast)
 
 namespace hv {
+// developer aid: s_memtime stamps of workgroup 0 at the phase boundaries (only with -DHV_EKF_PHASE_STAMPS)
+__device__ long long g_vu_stamp[32];
+#ifdef HV_EKF_PHASE_STAMPS
+#define VU_STAMP(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_vu_stamp[i] = (long long)__builtin_readcyclecounter(); } while (0)
+#else
+#define VU_STAMP(i) do { } while (0)
+#endif
 namespace {
 
-constexpr int VT = 320;                 // threads: >= 7 * 42 + 1 derivative columns
+constexpr int VT = 768;                 // threads: G = 2 or 4 per derivative column (<= 7 * 42 + 1 columns)
 constexpr int MAXP = 42;                // 2 cameras x (cameraTrailLength + 1 <= 21) poses
 constexpr int MAXC = MAXP * 7 + 1;
 constexpr int POSE_WORDS = 51;          // p[3] R[9] dR[4][9] baseline[3]
@@ -125,6 +132,67 @@ __device__ __forceinline__ double norm1_3(const double *M)
     return best;
 }
 
+// One (pose, column) pair of the derivative sums (triangulation.cpp:264-311): given dh (the change of h), dC and dt
+// (the change of C and t; zero unless HEAVY) it adds dEblock' * error + Eblock' * dErrorBlock to dEe and
+// dEblock' * Eblock + Eblock' * dEblock to dM. o = the pose record of this iteration (C t h E err d).
+template <bool HEAVY>
+__device__ __forceinline__ void pair_sums(const double *o, const double *dh, const double *dC, const double *dt, double vel0,
+                                          double vel1, double *dEe, double *dM)
+{
+    const double *C = o, *t = o + 9, *h = o + 12, *E = o + 15, *er = o + 21;
+    const double ih2 = 1.0 / h[2], ih2sq = ih2 * ih2;
+    const double dih2 = -dh[2] * ih2sq, dih2sq = -2 * dh[2] * ih2sq * ih2;
+    double dErr[2], dE[6];
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        dErr[r] = (r == 0 ? vel0 : vel1) - dh[r] * ih2 - dih2 * h[r];
+        const double g = dh[r] * ih2sq + dih2sq * h[r];
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            dE[3 * r + c] = -dih2 * C[3 * r + c] + g * C[6 + c];
+            if (HEAVY) dE[3 * r + c] += -ih2 * dC[3 * r + c] + h[r] * ih2sq * dC[6 + c];
+        }
+        dE[3 * r + 2] = -t[r] * dih2 + g * t[2];
+        if (HEAVY) dE[3 * r + 2] += -dt[r] * ih2 + h[r] * ih2sq * dt[2];
+    }
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        dEe[r] += dE[r] * er[0] + dE[3 + r] * er[1] + E[r] * dErr[0] + E[3 + r] * dErr[1];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) dM[3 * r + c] += dE[r] * E[c] + dE[3 + r] * E[3 + c] + E[r] * dE[c] + E[3 + r] * dE[3 + c];
+    }
+}
+
+// dC and dt of pose i for state component comp of pose pj (:269-292), as one instruction stream: the derivative
+// matrices are scaled by 0 or 1 instead of branching on position / quaternion and own pose / pose 0.
+__device__ __forceinline__ void pose_motion(const double *trail, const double *R0T, const double *o, int i, int pj, int comp,
+                                            double *dC, double *dt)
+{
+    const double *cur = trail + i * POSE_WORDS, *d = o + 23;
+    const bool current = pj == i, first = pj == 0;
+    const int qi = comp >= 3 ? comp - 3 : 0;
+    const double wc = current && comp >= 3 ? 1.0 : 0.0, wf = first && comp >= 3 ? 1.0 : 0.0;
+    double dRi[9], dR0[9], a1[9], a2[9], dpi[3], dp0[3], t1[3], t2[3], dd[3];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) { dRi[k] = wc * cur[12 + 9 * qi + k]; dR0[k] = wf * trail[12 + 9 * qi + k]; }
+    mm3(dRi, R0T, a1);
+    mmT3(cur + 3, dR0, a2);
+    mTv3(dRi, cur + 48, dpi);
+    mTv3(dR0, trail + 48, dp0);
+    mv3(dRi, d, t1);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        dpi[k] = (current && comp == k ? 1.0 : 0.0) - dpi[k];
+        dp0[k] = (first && comp == k ? 1.0 : 0.0) - dp0[k];
+        dd[k] = dp0[k] - dpi[k];
+    }
+    mv3(cur + 3, dd, t2);
+#pragma unroll
+    for (int k = 0; k < 9; ++k) dC[k] = a1[k] + a2[k];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) dt[k] = t1[k] + t2[k];
+}
+
 __global__ __launch_bounds__(VT) void vu_prepare_kernel(VuPrepareArgs a)
 {
     __shared__ double s_trail[MAXP * POSE_WORDS];
@@ -133,6 +201,7 @@ __global__ __launch_bounds__(VT) void vu_prepare_kernel(VuPrepareArgs a)
     __shared__ double s_feat[MAXP * 4];          // image feature (2) + velocity (2) per pose
     __shared__ double s_small[64];               // pfi[3] pf[3] X[9] step[3] ETE[9] Eerror[3] R0T[9] pf0 ... (see offsets)
     __shared__ double s_dpf[21 * 21];            // summed dpfdp [n][9] and dpfdq [n][12]
+    __shared__ double s_p0[7 * MAXP * 12 + 7 * 12];   // motion part of the 7 columns of pose 0: [7][pose][12], then their totals [7][12]
     __shared__ int s_idx[24];
     __shared__ int s_flag[4];
     const int b = blockIdx.x, tid = threadIdx.x;
@@ -141,6 +210,7 @@ __global__ __launch_bounds__(VT) void vu_prepare_kernel(VuPrepareArgs a)
     const double *m = a.m + (size_t)b * N;
     double *pfi = s_small, *pfw = s_small + 3, *X = s_small + 6, *step = s_small + 15, *R0T = s_small + 18;
     double *scal = s_small + 36;                 // [0] error2, [1] rcond, [2] Jprev
+    VU_STAMP(0);
     if (tid < n) s_idx[tid] = a.pose_index[(size_t)b * n + tid];
     if (tid < nt) {
 #pragma unroll
@@ -177,6 +247,7 @@ __global__ __launch_bounds__(VT) void vu_prepare_kernel(VuPrepareArgs a)
     }
     for (int i = tid; i < 3 * ncol; i += VT) s_dpfi[i] = 0.0;
     __syncthreads();
+    VU_STAMP(1);
     // ---- triangulateWithTwoCameras between pose 0 and pose ind1 (triangulation.cpp:154-173, 612-716): thread j < 15
     // owns derivative column j (p0 q0 p1 q1 t); every one of them recomputes the small shared part ----
     const int ind1 = a.stereo ? nt / 2 - 1 : nt - 1;
@@ -263,7 +334,19 @@ __global__ __launch_bounds__(VT) void vu_prepare_kernel(VuPrepareArgs a)
     __syncthreads();
     // ---- Gauss-Newton with derivatives (triangulation.cpp:206-343) ----
     const double *p0 = s_trail;
+    // Lanes of the derivative-column phase. Every (pose i, column j) pair contributes through d(pfi)/dx_j (the plain
+    // part); a pair also moves C and t of the pose when j belongs to pose i or to pose 0 (the motion part, ~2.5x the
+    // flops). Both parts are linear in their inputs, so they are summed separately:
+    //   plain part  : G = 2 or 4 adjacent lanes per column walk the poses (stride G), no branch in the loop
+    //   motion part : the 7 (2 nt - 1) such pairs are dealt out one (or two) per lane in a single uniform step --
+    //                 lane 0 of a column's group takes the column's own pair, the other lanes take the pairs of the
+    //                 7 pose-0 columns, whose sums go through LDS in a fixed order.
+    // (With a branch inside the loop the wave holding the pose-0 columns took 16.9 k of an iteration's 19 k cycles.)
+    // The last wave (VT - 64 ..) forms ETE / Eerror / the step concurrently.
+    const int gshift = 4 * ncol <= VT - 64 ? 2 : 1, G = 1 << gshift, col_lanes = ncol << gshift;
+    VU_STAMP(2);
     for (int it = 0; it < a.gn_iters; ++it) {
+        if (it < 6) VU_STAMP(3 + 4 * it);
         if (tid < nt) {                                       // per-pose quantities of this iteration
             const double *cur = s_trail + tid * POSE_WORDS;
             double *o = s_it + tid * ITER_WORDS;
@@ -290,109 +373,114 @@ __global__ __launch_bounds__(VT) void vu_prepare_kernel(VuPrepareArgs a)
             }
         }
         __syncthreads();
-        if (tid == 0) {                                       // ETE, Eerror, the step (3x3: one thread)
-            double ETE[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, Ee[3] = {0, 0, 0}, e2 = 0;
-            for (int i = 0; i < nt; ++i) {
-                const double *E = s_it + i * ITER_WORDS + 15, *er = s_it + i * ITER_WORDS + 21;
-                e2 += er[0] * er[0] + er[1] * er[1];
-#pragma unroll
-                for (int r = 0; r < 3; ++r) {
-#pragma unroll
-                    for (int c = 0; c < 3; ++c) ETE[3 * r + c] += E[r] * E[c] + E[3 + r] * E[3 + c];
-                    Ee[r] += E[r] * er[0] + E[3 + r] * er[1];
+        if (it < 6) VU_STAMP(4 + 4 * it);
+        if (tid >= VT - 64) {                                 // the last wave owns no derivative column: it forms ETE (9),
+            const int k = tid - (VT - 64);                    // Eerror (3) and error2 concurrently, lane k < 13 summing entry k
+            // entry k = sum over poses of o[x0]*o[y0] + o[x0+dx]*o[y0+dy] on the pose record (E rows at 15 and 18, err at 21)
+            const int r = k / 3, c = k - 3 * r;
+            const int x0 = k < 9 ? 15 + r : k < 12 ? 15 + (k - 9) : 21, y0 = k < 9 ? 15 + c : 21;
+            const int dx = k < 12 ? 3 : 1, dy = k < 9 ? 3 : 1;
+            double acc = 0.0;
+            if (k < 13)
+                for (int i = 0; i < nt; ++i) {
+                    const double *o = s_it + i * ITER_WORDS;
+                    acc += o[x0] * o[y0] + o[x0 + dx] * o[y0 + dy];
                 }
+            double ETE[9], Ee[3];
+#pragma unroll
+            for (int q = 0; q < 9; ++q) ETE[q] = __shfl(acc, q);
+#pragma unroll
+            for (int q = 0; q < 3; ++q) Ee[q] = __shfl(acc, 9 + q);
+            const double e2 = __shfl(acc, 12);
+            if (k == 0) {
+                double Xl[9], st[3];
+                inv3sym(ETE, Xl);
+                mv3(Xl, Ee, st);
+#pragma unroll
+                for (int q = 0; q < 9; ++q) X[q] = Xl[q];
+#pragma unroll
+                for (int q = 0; q < 3; ++q) step[q] = st[q];
+                scal[0] = e2;
+                scal[1] = 1.0 / (norm1_3(ETE) * norm1_3(Xl));
             }
-            double Xl[9], st[3];
-            inv3sym(ETE, Xl);
-            mv3(Xl, Ee, st);
-#pragma unroll
-            for (int k = 0; k < 9; ++k) X[k] = Xl[k];
-#pragma unroll
-            for (int k = 0; k < 3; ++k) step[k] = st[k];
-            scal[0] = e2;
-            scal[1] = 1.0 / (norm1_3(ETE) * norm1_3(Xl));
         }
-        // derivative columns: dEerror_j and dETE_j accumulated over the poses, with the OLD pfi (:236-312);
-        // VT >= ncol, so a thread owns at most one column and keeps its sums in registers across the barrier
-        const int j = tid;
+        if (it < 6) VU_STAMP(5 + 4 * it);
+        // derivative columns: dEerror_j and dETE_j accumulated over the poses, with the OLD pfi (:236-312). G adjacent
+        // lanes share a column and split its poses (the loop is the critical path of the kernel: one workgroup per
+        // filter, so the time of a launch is the latency of one track); the sums stay in registers across the barrier
+        const int j = tid >> gshift, part = tid & (G - 1);
         const bool is_t = j == dDim;
-        const bool has = j < ncol && !(is_t && !a.est_shift);
+        const bool has = tid < col_lanes && !(is_t && !a.est_shift);
         double dEe[3] = {0, 0, 0}, dM[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-        if (has) {
-            const int pj = is_t ? -1 : j / 7, comp = is_t ? 0 : j - 7 * pj;
+        if (has) {                                                                      // plain part
             const double dpa = s_dpfi[j], dpb = s_dpfi[ncol + j], dpc = s_dpfi[2 * ncol + j];
-            const double pa = pfi[0], pb = pfi[1], pc = pfi[2];
-            for (int i = 0; i < nt; ++i) {
+            for (int i = part; i < nt; i += G) {
                 const double *o = s_it + i * ITER_WORDS;
-                const double *C = o, *t = o + 9, *h = o + 12, *E = o + 15, *er = o + 21, *d = o + 23;
-                double dC[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, dt[3] = {0, 0, 0};
-                const bool current = pj == i, first = pj == 0;
-                if (current || first) {
-                    const double *cur = s_trail + i * POSE_WORDS;
-                    double dp0[3] = {0, 0, 0}, dpi[3] = {0, 0, 0}, dd[3];
-                    if (comp < 3) {
-                        if (current) dpi[comp] = 1;
-                        if (first) dp0[comp] = 1;
-                    } else {
-                        const int qi = comp - 3;
-                        if (current) {
-                            const double *dRi = cur + 12 + 9 * qi;
-                            double a1[9], t1[3];
-                            mm3(dRi, R0T, a1);
-                            mTv3(dRi, cur + 48, dpi);
-                            mv3(dRi, d, t1);
-#pragma unroll
-                            for (int k = 0; k < 9; ++k) dC[k] += a1[k];
-#pragma unroll
-                            for (int k = 0; k < 3; ++k) { dpi[k] = -dpi[k]; dt[k] += t1[k]; }
-                        }
-                        if (first) {
-                            const double *dR0 = s_trail + 12 + 9 * qi;
-                            double a2[9];
-                            mmT3(cur + 3, dR0, a2);
-                            mTv3(dR0, s_trail + 48, dp0);
-#pragma unroll
-                            for (int k = 0; k < 9; ++k) dC[k] += a2[k];
-#pragma unroll
-                            for (int k = 0; k < 3; ++k) dp0[k] = -dp0[k];
-                        }
-                    }
-#pragma unroll
-                    for (int k = 0; k < 3; ++k) dd[k] = dp0[k] - dpi[k];
-                    double t2[3];
-                    mv3(cur + 3, dd, t2);
-#pragma unroll
-                    for (int k = 0; k < 3; ++k) dt[k] += t2[k];
-                }
                 double dh[3];
 #pragma unroll
-                for (int r = 0; r < 3; ++r)
-                    dh[r] = (dC[3 * r] * pa + dC[3 * r + 1] * pb + dC[3 * r + 2]) + (C[3 * r] * dpa + C[3 * r + 1] * dpb) + dpc * t[r] + pc * dt[r];
-                const double ih2 = 1.0 / h[2], ih2sq = ih2 * ih2;
-                const double dih2 = -dh[2] * ih2sq, dih2sq = -2 * dh[2] * ih2sq * ih2;
-                double dErr[2], dE[6];
-#pragma unroll
-                for (int r = 0; r < 2; ++r) {
-                    dErr[r] = (is_t ? s_feat[4 * i + 2 + r] : 0.0) - dh[r] * ih2 - dih2 * h[r];
-                    const double g = dh[r] * ih2sq + dih2sq * h[r];
-#pragma unroll
-                    for (int c = 0; c < 2; ++c) dE[3 * r + c] = -dih2 * C[3 * r + c] - ih2 * dC[3 * r + c] + g * C[6 + c] + h[r] * ih2sq * dC[6 + c];
-                    dE[3 * r + 2] = -dt[r] * ih2 - t[r] * dih2 + g * t[2] + h[r] * ih2sq * dt[2];
-                }
-#pragma unroll
-                for (int r = 0; r < 3; ++r) {
-                    dEe[r] += dE[r] * er[0] + dE[3 + r] * er[1] + E[r] * dErr[0] + E[3 + r] * dErr[1];
-#pragma unroll
-                    for (int c = 0; c < 3; ++c) dM[3 * r + c] += dE[r] * E[c] + dE[3 + r] * E[3 + c] + E[r] * dE[c] + E[3 + r] * dE[3 + c];
-                }
+                for (int r = 0; r < 3; ++r) dh[r] = (o[3 * r] * dpa + o[3 * r + 1] * dpb) + dpc * o[9 + r];
+                pair_sums<false>(o, dh, nullptr, nullptr, is_t ? s_feat[4 * i + 2] : 0.0, is_t ? s_feat[4 * i + 3] : 0.0, dEe, dM);
             }
         }
+        if (tid < col_lanes) {                                                          // motion part: one pair per lane, one code path
+            // lane 0 of a column's group: the column's own pose (regular columns only); lane p >= 1: pair u = (pose i,
+            // pose-0 column c) with u = j (G - 1) + p - 1 < 7 nt  (7 nt <= ncol (G - 1) always holds)
+            const int u = j * (G - 1) + part - 1;
+            const bool own = part == 0 && j >= 7 && !is_t, p0pair = part > 0 && u < 7 * nt;
+            const int i = own ? j / 7 : p0pair ? u / 7 : 0;
+            const int pj = own ? i : 0, comp = own ? j - 7 * i : p0pair ? u - 7 * i : 0;
+            const double *o = s_it + i * ITER_WORDS;
+            double dC[9], dt[3], dh[3], e3[3] = {0, 0, 0}, m9[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+            pose_motion(s_trail, R0T, o, i, pj, comp, dC, dt);
+#pragma unroll
+            for (int r = 0; r < 3; ++r) dh[r] = (dC[3 * r] * pfi[0] + dC[3 * r + 1] * pfi[1] + dC[3 * r + 2]) + pfi[2] * dt[r];
+            pair_sums<true>(o, dh, dC, dt, 0.0, 0.0, e3, m9);
+            const double keep = own ? 1.0 : 0.0;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) dEe[k] += keep * e3[k];
+#pragma unroll
+            for (int k = 0; k < 9; ++k) dM[k] += keep * m9[k];
+            if (p0pair) {
+                double *dst = s_p0 + (comp * MAXP + i) * 12;
+#pragma unroll
+                for (int k = 0; k < 3; ++k) dst[k] = e3[k];
+#pragma unroll
+                for (int k = 0; k < 9; ++k) dst[3 + k] = m9[k];
+            }
+        }
+        for (int o = 1; o < G; o <<= 1) {                     // the G partial sums of a column sit in adjacent lanes
+#pragma unroll
+            for (int k = 0; k < 3; ++k) dEe[k] += __shfl_xor(dEe[k], o);
+#pragma unroll
+            for (int k = 0; k < 9; ++k) dM[k] += __shfl_xor(dM[k], o);
+        }
         __syncthreads();                                      // X, step, error2 are published; everybody is done with the old pfi
-        if (has) {                                            // :324-328: d(A^-1) = -A^-1 dA A^-1
+        if (it < 6) VU_STAMP(6 + 4 * it);
+        if (tid >= 64 && tid < 64 + 84) {                     // pose-0 columns: entry e of column c, motion part summed over the poses
+            const int c = (tid - 64) / 12, e = tid - 64 - 12 * c;
+            double acc = 0.0;
+            for (int q = 0; q < nt; ++q) acc += s_p0[(c * MAXP + q) * 12 + e];
+            s_p0[7 * MAXP * 12 + tid - 64] = acc;
+        }
+        if (has && part == 0 && j >= 7) {                     // :324-328: d(A^-1) = -A^-1 dA A^-1
             double t1[3], t2[3], t3[3];
             mv3(dM, step, t1);
             mv3(X, t1, t2);
             mv3(X, dEe, t3);
+#pragma unroll
+            for (int r = 0; r < 3; ++r) s_dpfi[r * ncol + j] += t2[r] - t3[r];
+        }
+        __syncthreads();
+        if (has && part == 0 && j < 7) {                      // the same update for the pose-0 columns: plain (registers) + motion (LDS)
+            const double *tot = s_p0 + 7 * MAXP * 12 + 12 * j;
+            double t1[3], t2[3], t3[3], e3[3], m9[9];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) e3[k] = dEe[k] + tot[k];
+#pragma unroll
+            for (int k = 0; k < 9; ++k) m9[k] = dM[k] + tot[3 + k];
+            mv3(m9, step, t1);
+            mv3(X, t1, t2);
+            mv3(X, e3, t3);
 #pragma unroll
             for (int r = 0; r < 3; ++r) s_dpfi[r * ncol + j] += t2[r] - t3[r];
         }
@@ -406,6 +494,7 @@ __global__ __launch_bounds__(VT) void vu_prepare_kernel(VuPrepareArgs a)
         __syncthreads();
         if (s_flag[0]) break;
     }
+    VU_STAMP(27);
     // ---- status, back to world coordinates (:345-392) ----
     int *st_out = a.status + 2 * (size_t)b;
     double *M = s_small + 40, *pf0 = s_small + 49;           // R0T * dpf0_dpfi, the point in the frame of pose 0
@@ -460,6 +549,7 @@ __global__ __launch_bounds__(VT) void vu_prepare_kernel(VuPrepareArgs a)
             if (a.stereo) v += s_dpfi[r * ncol + 7 * (k + n) + c];
             s_dpf[i] = v;
         }
+    VU_STAMP(28);
     // ---- prepareVisualUpdate (triangulation.cpp:897-987), full-width H (batch layout of the update kernel) ----
     // per trail pose: dip*R (2x3), the own-orientation block dip*dRpt (2x4), f, depth class  -> s_it[i][0..16]
     if (tid < nt) {
@@ -487,9 +577,12 @@ __global__ __launch_bounds__(VT) void vu_prepare_kernel(VuPrepareArgs a)
         }
     }
     __syncthreads();
+    VU_STAMP(29);
     const int rows = 2 * nt;
     double *H = a.H + (size_t)b * rows * N;
-    for (int c = tid; c < N; c += VT) {
+    // thread -> (state column c, quarter of the trail poses): 4 N <= VT for N <= 192, otherwise the loop strides
+    for (int w = tid; w < 4 * N; w += VT) {
+        const int c = w >> 2, quarter = w & 3;
         // which pose of the track (if any) owns state column c, and which of its 7 components
         int k = -1, comp = 0;
         for (int q = 0; q < n; ++q) {
@@ -499,7 +592,7 @@ __global__ __launch_bounds__(VT) void vu_prepare_kernel(VuPrepareArgs a)
             else if (c >= io && c < io + 4) { k = q; comp = 3 + c - io; }
         }
         const bool sft = c == 19 && with_derivatives && a.est_shift;
-        for (int i = 0; i < nt; ++i) {
+        for (int i = quarter; i < nt; i += 4) {
             const double *o = s_it + i * ITER_WORDS;
             double h0 = 0.0, h1 = 0.0;
             if (k >= 0) {
@@ -517,8 +610,7 @@ __global__ __launch_bounds__(VT) void vu_prepare_kernel(VuPrepareArgs a)
                 h0 = o[0] * t0 + o[1] * t1 + o[2] * t2 - s_feat[4 * i + 2];
                 h1 = o[3] * t0 + o[4] * t1 + o[5] * t2 - s_feat[4 * i + 3];
             }
-            H[(size_t)c * rows + 2 * i] = h0;
-            H[(size_t)c * rows + 2 * i + 1] = h1;
+            *reinterpret_cast<double2 *>(H + (size_t)c * rows + 2 * i) = double2{h0, h1};
         }
     }
     if (tid < nt) {
@@ -530,6 +622,7 @@ __global__ __launch_bounds__(VT) void vu_prepare_kernel(VuPrepareArgs a)
             a.v[e] = (a.y ? a.y[e] : 0.0) - o[14 + r];
         }
     }
+    VU_STAMP(30);
     if (tid == 0) {
         int prep = 0;
         for (int i = 0; i < nt && prep == 0; ++i) prep = (int)s_it[i * ITER_WORDS + 16];   // first failing pose decides (:920-927)
@@ -553,3 +646,12 @@ int launch_vu_prepare(Ctx *c, const VuPrepareArgs &a)
 }
 
 }  // namespace hv
+
+extern "C" int hv_debug_vu_phase_stamps(hv_ctx *ctx, long long *out32)
+{
+    hv::Ctx *c = hv::ctx_of(ctx);
+    if (!c || !out32) return HV_ERR_INVALID;
+    HV_HIP(c, hipStreamSynchronize(c->stream));
+    HV_HIP(c, hipMemcpyFromSymbol(out32, HIP_SYMBOL(hv::g_vu_stamp), sizeof(long long) * 32));
+    return HV_OK;
+}

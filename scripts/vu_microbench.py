@@ -1,0 +1,109 @@
+"""Times vu_prepare_kernel (row f3) alone and the fused prepare + gate + update call: B filters, one track each.
+usage: python scripts/vu_microbench.py [B] [n_poses] [stereo 0|1]"""
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from hybvio_amd import capi  # noqa: E402
+
+
+def synthetic_tracks(rng, B, trail_len, npose, stereo):
+    """Smooth trajectories + one world point per filter projected into the chosen poses (numpy only, no oracle)."""
+    n = 20 + 7 * trail_len
+    Ric = np.array([[0, -1, 0], [-1, 0, 0], [0, 0, -1.0]])
+    base2 = np.array([0.11, 0.002, -0.001])
+    ncam = 2 if stereo else 1
+    means = np.zeros((B, n)); idx = np.zeros((B, npose), np.int32); feat = np.zeros((B, ncam * npose, 2))
+
+    def rot(q):
+        w, x, y, z = q
+        return np.array([[w*w+x*x-y*y-z*z, 2*x*y-2*w*z, 2*x*z+2*w*y], [2*x*y+2*w*z, w*w-x*x+y*y-z*z, 2*y*z-2*w*x],
+                         [2*x*z-2*w*y, 2*y*z+2*w*x, w*w-x*x-y*y+z*z]])
+    for b in range(B):
+        m = means[b]
+        ax = rng.normal(size=3); ax /= np.linalg.norm(ax); ang = rng.uniform(0, 0.4)
+        q0 = np.concatenate([[np.cos(ang / 2)], np.sin(ang / 2) * ax])
+        vd = rng.normal(size=3) * 0.15
+        for k in range(trail_len + 1):
+            ip = 0 if k == 0 else 20 + 7 * (k - 1); io = 6 if k == 0 else 20 + 7 * (k - 1) + 3
+            m[ip:ip + 3] = -vd * k + 0.01 * rng.normal(size=3)
+            q = q0 + 0.004 * k * rng.normal(size=4); m[io:io + 4] = q / np.linalg.norm(q)
+        m[16:19] = 1.0
+        idx[b] = np.sort(rng.choice(trail_len + 1, npose, replace=False))
+        poses = []
+        for cam in range(ncam):
+            for k in idx[b]:
+                ip = 0 if k == 0 else 20 + 7 * (k - 1); io = 6 if k == 0 else 20 + 7 * (k - 1) + 3
+                R = Ric @ rot(m[io:io + 4]); p = m[ip:ip + 3] - R.T @ (base2 if cam else np.zeros(3))
+                poses.append((R, p))
+        pw = poses[0][1] + poses[0][0].T @ np.array([rng.uniform(-1, 1), rng.uniform(-1, 1), rng.uniform(2, 12)])
+        for i, (R, p) in enumerate(poses):
+            pc = R @ (pw - p); feat[b, i] = pc[:2] / pc[2] + 1e-3 * rng.normal(size=2)
+    T1 = np.eye(4); T1[:3, :3] = Ric
+    T2 = T1.copy(); T2[:3, 3] = base2
+    return T1, (T2 if stereo else None), means, idx, feat
+
+
+def main():
+    B = int(sys.argv[1]) if len(sys.argv) > 1 else 256
+    npose = int(sys.argv[2]) if len(sys.argv) > 2 else 10
+    stereo = bool(int(sys.argv[3])) if len(sys.argv) > 3 else True
+    trail_len = 20
+    rng = np.random.default_rng(0)
+    T1, T2, means, idx, feat = synthetic_tracks(rng, B, trail_len, npose, stereo)
+    vel = rng.normal(size=feat.shape) * 0.1
+    y = feat.reshape(B, -1) + 1e-3 * rng.normal(size=(B, feat.shape[1] * 2))
+    vp = capi.vu_default_params(imu_to_camera=T1, second_imu_to_camera=T2) if stereo else capi.vu_default_params(imu_to_camera=T1)
+    with capi.Context(width=64, height=64) as ctx:
+        g = capi.EkfBatch(ctx, capi.ekf_default_params(cameraTrailLength=trail_len), B)
+        P = None
+        for b in range(B):
+            if P is None:
+                _, P = g.get_state(0)
+                P = P * 1e-6 + np.eye(g.n) * 1e-4
+            g.set_state(b, means[b], P)
+        dev = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a, dt)).cuda()
+        d_idx, d_feat, d_vel, d_y = dev(idx, np.int32), dev(feat, np.float64), dev(vel, np.float64), dev(y, np.float64)
+        rows = 2 * npose * (2 if stereo else 1)
+        H = torch.zeros((B, g.n, rows), dtype=torch.float64, device="cuda")
+        v = torch.zeros((B, rows), dtype=torch.float64, device="cuda"); pf = torch.zeros((B, 3), dtype=torch.float64, device="cuda")
+        st = torch.zeros((B, 2), dtype=torch.int32, device="cuda"); gs = torch.zeros((B,), dtype=torch.int32, device="cuda")
+        ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+        prep = lambda: g.visual_prepare_dev(vp, npose, d_idx.data_ptr(), d_feat.data_ptr(), d_vel.data_ptr(), d_y.data_ptr(), H.data_ptr(),
+                                            v.data_ptr(), 0, pf.data_ptr(), st.data_ptr(), 0)
+        for _ in range(3):
+            prep()
+        ctx.profile_enable(True); ctx.profile_reset()
+        for _ in range(20):
+            prep()
+        ms, cnt = ctx.profile_read(capi.K_VU_PREPARE)
+        ctx.profile_enable(False)
+        ok = int((st.cpu().numpy() == 0).all(1).sum())
+        print(f"vu_prepare_kernel: B={B} poses={npose} stereo={stereo} rows={rows}: {ms / cnt * 1e3:.1f} us per launch "
+              f"({ms / cnt / B * 1e6:.1f} ns per track at this batch), {ok}/{B} tracks OK")
+        if os.environ.get("HV_EKF_PHASE_STAMPS") == "1":
+            import ctypes as C
+            st32 = (C.c_longlong * 32)()
+            capi.lib().hv_debug_vu_phase_stamps.argtypes = [C.c_void_p, C.POINTER(C.c_longlong)]
+            capi.lib().hv_debug_vu_phase_stamps(ctx._h, st32)
+            s_ = list(st32)
+            print("phase ticks (100 MHz s_memtime... or cycles): setup", s_[1] - s_[0], "two-cam", s_[2] - s_[1],
+                  "iters [pose, (wait), columns, update]:", [[s_[4 + 4 * k] - s_[3 + 4 * k], s_[5 + 4 * k] - s_[4 + 4 * k], s_[6 + 4 * k] - s_[5 + 4 * k],
+                                                             (s_[7 + 4 * k] if k < 5 else s_[27]) - s_[6 + 4 * k]] for k in range(6) if s_[6 + 4 * k] > s_[3 + 4 * k] > 0],
+                  "final", s_[28] - s_[27], "prep-pose", s_[29] - s_[28], "H", s_[30] - s_[29], "total", s_[30] - s_[0])
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for _ in range(20):
+            g.visual_track_dev(vp, npose, d_idx.data_ptr(), d_feat.data_ptr(), d_vel.data_ptr(), d_y.data_ptr(), 1.5, 0.05,
+                               st.data_ptr(), gs.data_ptr(), 0, pf.data_ptr())
+        torch.cuda.synchronize()
+        print(f"visual_track_dev (prepare + gate + update): {(time.perf_counter() - t0) / 20 * 1e6:.1f} us per call, "
+              f"gate inliers {int((gs.cpu().numpy() == 0).sum())}/{B}")
+        g.close()
+
+
+if __name__ == "__main__":
+    main()
