@@ -420,6 +420,68 @@ def bench_ingest(tb, n, local_rank, cpu_baseline):
     return res
 
 
+def bench_visual_track(ctx, n, local_rank, cpu_baseline):
+    """f3: one 10-pose stereo track per filter (40 x 160 Jacobian), n filters per launch."""
+    import numpy as np
+    import torch
+    from hybvio_amd import capi, synth
+    dev = f"cuda:{local_rank}"
+    rng = np.random.default_rng(3)
+    npose, trail = 10, 20
+    T1, T2, means, idx, feat = synth.visual_tracks(rng, n, trail, npose, True)
+    vel = rng.normal(size=feat.shape) * 0.1
+    y = feat.reshape(n, -1) + 1e-3 * rng.normal(size=(n, feat.shape[1] * 2))
+    vp = capi.vu_default_params(imu_to_camera=T1, second_imu_to_camera=T2)
+    g = capi.EkfBatch(ctx, capi.ekf_default_params(cameraTrailLength=trail), n)
+    _, P = g.get_state(0)
+    P = P * 1e-6 + np.eye(g.n) * 1e-4
+    for b in range(n):
+        g.set_state(b, means[b], P)
+    to = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a, dt)).to(dev)
+    d_idx, d_feat, d_vel, d_y = to(idx, np.int32), to(feat, np.float64), to(vel, np.float64), to(y, np.float64)
+    rows = 4 * npose
+    H = torch.zeros((n, g.n, rows), dtype=torch.float64, device=dev); v = torch.zeros((n, rows), dtype=torch.float64, device=dev)
+    pf = torch.zeros((n, 3), dtype=torch.float64, device=dev)
+    st = torch.zeros((n, 2), dtype=torch.int32, device=dev); gs = torch.zeros((n,), dtype=torch.int32, device=dev)
+    prep = lambda: g.visual_prepare_dev(vp, npose, d_idx.data_ptr(), d_feat.data_ptr(), d_vel.data_ptr(), d_y.data_ptr(), H.data_ptr(),
+                                        v.data_ptr(), 0, pf.data_ptr(), st.data_ptr(), 0)
+    for _ in range(3):
+        prep()
+    ctx.profile_enable(True); ctx.profile_reset()
+    for _ in range(20):
+        prep()
+    ms, cnt = ctx.profile_read(capi.K_VU_PREPARE)
+    ctx.profile_enable(False)
+    ok = int((st.cpu().numpy() == 0).all(1).sum())
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    fused = lambda: g.visual_track_dev(vp, npose, d_idx.data_ptr(), d_feat.data_ptr(), d_vel.data_ptr(), d_y.data_ptr(), 1.5, 0.05,
+                                       st.data_ptr(), gs.data_ptr(), 0, pf.data_ptr())
+    fused(); torch.cuda.synchronize()
+    e0.record()
+    for _ in range(20):
+        fused()
+    e1.record(); torch.cuda.synchronize()
+    fused_ms = e0.elapsed_time(e1) / 20
+    res = {"workload": f"{n} filters (state dim {g.n}), one {npose}-pose stereo track each: extractCameraPoseTrail + Triangulator::triangulate "
+                       f"with derivatives + prepareVisualUpdate -> H ({rows} x {g.n}), y - f; fused call adds the chi2 gate and the update",
+           "prepare_avg_ms": ms / cnt, "prepare_tracks_per_s": n / (ms / cnt * 1e-3), "tracks_ok": ok,
+           "fused_prepare_gate_update_avg_ms": fused_ms, "fused_tracks_per_s": n / (fused_ms * 1e-3),
+           "host_bytes_per_track": {"device_path": 4 * npose + 3 * 8 * 4 * npose + 40, "reference_path": 8 * g.n + 8 * rows * g.n + 16 * rows},
+           "note": "one workgroup per filter, so a launch costs one track's latency up to 256 filters; f64, the derivative columns "
+                   "(7 * poses + 1) x poses pairs per Gauss-Newton iteration dominate (DESIGN.md 3.6)"}
+    g.close()
+    if cpu_baseline:
+        from oracle import orc
+        par = orc.tri_default_params()
+        t0, reps = time.perf_counter(), 0
+        while time.perf_counter() - t0 < 2.0:
+            b = reps % n
+            orc.visual_track_prepare(par, means[b], idx[b], T1, T2, feat[b], vel[b]); reps += 1
+        res["cpu_baseline"] = {"value": reps / (time.perf_counter() - t0), "unit": "tracks/s", "cores": 1, "kind": "port",
+                               "sample": f"{reps} tracks, oracle/triangulation_oracle.c -O2 (triangulation + prepareVisualUpdate only)"}
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -432,6 +494,7 @@ def main():
     ap.add_argument("--no-ekf", action="store_true", help="skip the C3 (tracker + HIP EKF) leg")
     ap.add_argument("--no-gftt", action="store_true", help="skip the f1 (GFTT detector kernel) measurement")
     ap.add_argument("--no-ingest", action="store_true", help="skip the f2 (colour->gray / undistort ingest kernel) measurement")
+    ap.add_argument("--no-visual-track", action="store_true", help="skip the f3 (device triangulation + prepareVisualUpdate) measurement")
     ap.add_argument("--c4", action="store_true",
                     help="configs[3] instead of the headline workload: 1280x720 stereo, 400 features (not the default bench line)")
     args = ap.parse_args()
@@ -543,6 +606,9 @@ def main():
     # ---- f2: image ingest in front of the pyramid: colour -> gray, undistort remap ----
     if not args.no_ingest and rank == 0:
         out["f2_ingest"] = bench_ingest(tb, min(B, 256), local_rank, not args.no_cpu_baseline)
+    # ---- f3: per-track triangulation + prepareVisualUpdate from the device mean, fused with gate + update ----
+    if not args.no_visual_track and rank == 0:
+        out["f3_visual_track"] = bench_visual_track(tb.ctx, min(B, 256), local_rank, not args.no_cpu_baseline)
     # ---- C3: the same tracker work + the HIP EKF (configs[2]) ----
     if not args.no_ekf:
         eb = EkfBench(tb.ctx, B, local_rank, seed=rank)

@@ -107,6 +107,7 @@ PROTOTYPES = {
     "hv_vu_default_params": (None, [C.c_void_p]),
     "hv_ekf_visual_prepare_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int] + [C.c_void_p] * 10),
     "hv_ekf_visual_track_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int] + [C.c_void_p] * 4 + [C.c_double, C.c_double] + [C.c_void_p] * 4),
+    "hv_ekf_visual_track": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int] + [C.c_void_p] * 4 + [C.c_double, C.c_double] + [C.c_void_p] * 4),
     "hv_ekf_visual_dev": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_double, C.c_int,
                                     C.c_void_p, C.c_void_p]),
     "hv_ekf_augment": (C.c_int, [C.c_void_p, i32p, u8p]),
@@ -490,6 +491,17 @@ class EkfBatch:
         b = [C.c_void_p(x) for x in (status_dev, gate_status_dev, chi2_dev, pf_dev)]
         self._chk(lib().hv_ekf_visual_track_dev(self._h, C.byref(params), n_poses, *a, float(r_gate), float(r_update), *b),
                   "hv_ekf_visual_track_dev")
+
+    def visual_track(self, params: VuParams, pose_index, features, velocities, y, r_gate, r_update):
+        """hv_ekf_visual_track with numpy arrays [batch][...]: returns (status [batch][2], gate_status, chi2, pf)."""
+        idx = np.ascontiguousarray(pose_index, np.int32).reshape(self.batch, -1)
+        ft, vl, yy = _f(features), _f(velocities), _f(y)
+        st, gs = np.zeros((self.batch, 2), np.int32), np.zeros(self.batch, np.int32)
+        chi, pf = np.zeros(self.batch), np.zeros((self.batch, 3))
+        vp = lambda a: a.ctypes.data_as(C.c_void_p)
+        self._chk(lib().hv_ekf_visual_track(self._h, C.byref(params), idx.shape[1], vp(idx), vp(ft), vp(vl), vp(yy), float(r_gate),
+                                            float(r_update), vp(st), vp(gs), vp(chi), vp(pf)), "hv_ekf_visual_track")
+        return st, gs, chi, pf
 
     def visual_dev(self, nr, l, H_dev, v_dev, r, mode, chi2_dev=0, status_dev=0):
         self._chk(lib().hv_ekf_visual_dev(self._h, nr, l, C.c_void_p(H_dev), C.c_void_p(v_dev), r, mode,

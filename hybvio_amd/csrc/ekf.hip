@@ -1125,6 +1125,9 @@ struct Ekf {
     double *vuH = nullptr, *vuv = nullptr, *vupf = nullptr;
     unsigned char *vuactive = nullptr;
     int vu_rows = 0;
+    // device staging of the host-pointer entry hv_ekf_visual_track: idx | features | velocities | y | status | gate | chi2 | pf
+    unsigned char *vustage = nullptr;
+    size_t vustage_bytes = 0;
 };
 
 static int ekf_launch_update(Ekf *e, int nr, int l, const double *H_dev, const double *v_dev, const double *rdiag_dev,
@@ -1195,7 +1198,7 @@ void hv_ekf_destroy(hv_ekf *h)
     Ekf *e = &h->e;
     if (e->c && e->c->stream) (void)hipStreamSynchronize(e->c->stream);
     void *ptrs[] = { e->m, e->P, e->P1, e->m1, e->Q, e->dydx, e->ws, e->sH, e->sv, e->sr, e->schi2, e->simu,
-                     e->sstatus, e->sdrop, e->sactive, e->vuH, e->vuv, e->vupf, e->vuactive };
+                     e->sstatus, e->sdrop, e->sactive, e->vuH, e->vuv, e->vupf, e->vuactive, e->vustage };
     for (void *p : ptrs) if (p) (void)hipFree(p);
     delete h;
 }
@@ -1337,6 +1340,43 @@ int hv_ekf_visual_track_dev(hv_ekf *h, const hv_vu_params *p, int np, const int 
     if (rc != HV_OK) return rc;
     return hv::ekf_launch_update(e, rows, e->n, e->vuH, e->vuv, nullptr, r_update * r_update * e->noise_scale, 1, 0, 1, nullptr,
                                  nullptr, e->vuactive, gate_status_dev);
+}
+
+int hv_ekf_visual_track(hv_ekf *h, const hv_vu_params *p, int np, const int *idx, const double *feat, const double *vel,
+                        const double *y, double r_gate, double r_update, int *status, int *gate_status, double *chi2, double *pf)
+{
+    if (!h || !p || !idx || !feat || !vel || !y || !status || !gate_status || np < 2) return HV_ERR_INVALID;
+    Ekf *e = &h->e; Ctx *c = e->c;
+    const size_t B = (size_t)e->batch, nt = (size_t)np * (p->useStereo ? 2 : 1);
+    // one staging block, 16-byte aligned sections
+    auto up = [](size_t v) { return (v + 15) & ~(size_t)15; };
+    const size_t o_idx = 0, o_feat = up(o_idx + B * np * sizeof(int)), o_vel = up(o_feat + B * nt * 2 * sizeof(double));
+    const size_t o_y = up(o_vel + B * nt * 2 * sizeof(double)), o_st = up(o_y + B * nt * 2 * sizeof(double));
+    const size_t o_gs = up(o_st + B * 2 * sizeof(int)), o_chi = up(o_gs + B * sizeof(int)), o_pf = up(o_chi + B * sizeof(double));
+    const size_t total = up(o_pf + B * 3 * sizeof(double));
+    if (e->vustage_bytes < total) {
+        HV_HIP(c, hipStreamSynchronize(c->stream));
+        if (e->vustage) (void)hipFree(e->vustage);
+        e->vustage = nullptr; e->vustage_bytes = 0;
+        HV_HIP(c, hipMalloc(reinterpret_cast<void **>(&e->vustage), total));
+        e->vustage_bytes = total;
+    }
+    unsigned char *d = e->vustage;
+    HV_HIP(c, hipMemcpyAsync(d + o_idx, idx, B * np * sizeof(int), hipMemcpyHostToDevice, c->stream));
+    HV_HIP(c, hipMemcpyAsync(d + o_feat, feat, B * nt * 2 * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    HV_HIP(c, hipMemcpyAsync(d + o_vel, vel, B * nt * 2 * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    HV_HIP(c, hipMemcpyAsync(d + o_y, y, B * nt * 2 * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    int rc = hv_ekf_visual_track_dev(h, p, np, reinterpret_cast<const int *>(d + o_idx), reinterpret_cast<const double *>(d + o_feat),
+                                     reinterpret_cast<const double *>(d + o_vel), reinterpret_cast<const double *>(d + o_y), r_gate,
+                                     r_update, reinterpret_cast<int *>(d + o_st), reinterpret_cast<int *>(d + o_gs),
+                                     reinterpret_cast<double *>(d + o_chi), reinterpret_cast<double *>(d + o_pf));
+    if (rc != HV_OK) return rc;
+    HV_HIP(c, hipMemcpyAsync(status, d + o_st, B * 2 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HV_HIP(c, hipMemcpyAsync(gate_status, d + o_gs, B * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    if (chi2) HV_HIP(c, hipMemcpyAsync(chi2, d + o_chi, B * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    if (pf) HV_HIP(c, hipMemcpyAsync(pf, d + o_pf, B * 3 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HV_HIP(c, hipStreamSynchronize(c->stream));
+    return HV_OK;
 }
 
 /* developer aid (not in the public header): phase time stamps of the last update kernel */

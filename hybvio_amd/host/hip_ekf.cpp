@@ -269,6 +269,21 @@ struct HipEKF : public EKF {
         dirty();
     }
 
+    VisualTrackResult visualTrack(const hv_vu_params &parameters, const std::vector<int> &poseTrailIndex,
+                                  const std::vector<double> &imageFeatures, const std::vector<double> &featureVelocities,
+                                  const VectorXd &y, double chiOutlierR, double visualR) final {
+        const size_t n = poseTrailIndex.size(), nt = n * (parameters.useStereo ? 2 : 1);
+        assert(imageFeatures.size() == 2 * nt && featureVelocities.size() == 2 * nt && y.size() == 2 * nt);
+        int status[2] = {0, 0}, gate = 1;
+        VisualTrackResult res{};
+        check(hv_ekf_visual_track(dev(), &parameters, (int)n, poseTrailIndex.data(), imageFeatures.data(), featureVelocities.data(),
+                                  y.data(), chiOutlierR, visualR, status, &gate, nullptr, res.pf.data()));
+        res.triangulateStatus = status[0]; res.prepareVuStatus = status[1];
+        res.outlierStatus = gate == 0 ? VuOutlierStatus::INLIER : gate == 3 ? VuOutlierStatus::CHI2 : VuOutlierStatus::NOT_COMPUTED;
+        if (gate == 0) dirty();                       // the filter was updated
+        return res;
+    }
+
     void updateVisualPoseAugmentation(int discardedPoseIndex) final {
         check(hv_ekf_augment(dev(), &discardedPoseIndex, nullptr));
         dirty();

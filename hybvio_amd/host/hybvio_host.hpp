@@ -240,6 +240,22 @@ public:
     virtual std::string stateAsString() const = 0;
     virtual int getStateDim() const = 0;
     virtual bool getWasStationary() const = 0;
+
+    // SURVEY.md 8(f) row f3 -- not part of the reference's EKF interface: the body of the per-track loop of
+    // Session::trackerVisualUpdate (backend.cpp:1063-1185: extractCameraPoseTrail, Triangulator::triangulate with
+    // derivatives, depth window, prepareVisualUpdate, visualTrackOutlierCheck with chiOutlierR, updateVisualTrack with
+    // visualR) as ONE device pass on the resident mean. poseTrailIndex, imageFeatures, featureVelocities and y are what
+    // EKFStateIndex::buildTrackVectors produces (imageFeatures / featureVelocities: x0 y0 x1 y1 ..., first camera's poses
+    // then the second's). Map-point (hybrid) tracks keep the reference's host path.
+    struct VisualTrackResult {
+        int triangulateStatus;          // odometry::TriangulatorStatus (output.hpp:21-29)
+        int prepareVuStatus;            // odometry::PrepareVuStatus (output.hpp:15-19)
+        VuOutlierStatus outlierStatus;  // NOT_COMPUTED unless both of the above are OK
+        Vector3d pf;                    // triangulated point (world)
+    };
+    virtual VisualTrackResult visualTrack(const hv_vu_params &parameters, const std::vector<int> &poseTrailIndex,
+                                          const std::vector<double> &imageFeatures, const std::vector<double> &featureVelocities,
+                                          const VectorXd &y, double chiOutlierR, double visualR) = 0;
 };
 
 }  // namespace odometry

@@ -219,6 +219,12 @@ int hv_ekf_visual_track_dev(hv_ekf *ekf, const hv_vu_params *p, int n_poses, con
                             const double *features_dev, const double *velocities_dev, const double *y_dev,
                             double r_gate, double r_update, int *status_dev, int *gate_status_dev, double *chi2_dev,
                             double *pf_dev);
+/* Host-pointer form of hv_ekf_visual_track_dev (arrays [batch][...] as above): about 1 KB per track goes to the device
+ * and 40 bytes come back, instead of the mean coming back and a (2 * ncam * n_poses) x stateDim Jacobian going up.
+ * chi2 / pf may be NULL. Synchronous. */
+int hv_ekf_visual_track(hv_ekf *ekf, const hv_vu_params *p, int n_poses, const int *pose_index, const double *features,
+                        const double *velocities, const double *y, double r_gate, double r_update, int *status,
+                        int *gate_status, double *chi2, double *pf);
 /* updateVisualPoseAugmentation(discarded[f]) (ekf.cpp:848-885; -1 = last pose) incl. the Joseph form,
  * maintainPositiveSemiDefinite and normalizeQuaternions; updateUndoAugmentation (ekf.cpp:888-903). */
 int hv_ekf_augment(hv_ekf *ekf, const int *discarded /* [batch] or NULL */, const unsigned char *active);

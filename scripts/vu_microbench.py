@@ -11,41 +11,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from hybvio_amd import capi  # noqa: E402
 
 
-def synthetic_tracks(rng, B, trail_len, npose, stereo):
-    """Smooth trajectories + one world point per filter projected into the chosen poses (numpy only, no oracle)."""
-    n = 20 + 7 * trail_len
-    Ric = np.array([[0, -1, 0], [-1, 0, 0], [0, 0, -1.0]])
-    base2 = np.array([0.11, 0.002, -0.001])
-    ncam = 2 if stereo else 1
-    means = np.zeros((B, n)); idx = np.zeros((B, npose), np.int32); feat = np.zeros((B, ncam * npose, 2))
-
-    def rot(q):
-        w, x, y, z = q
-        return np.array([[w*w+x*x-y*y-z*z, 2*x*y-2*w*z, 2*x*z+2*w*y], [2*x*y+2*w*z, w*w-x*x+y*y-z*z, 2*y*z-2*w*x],
-                         [2*x*z-2*w*y, 2*y*z+2*w*x, w*w-x*x-y*y+z*z]])
-    for b in range(B):
-        m = means[b]
-        ax = rng.normal(size=3); ax /= np.linalg.norm(ax); ang = rng.uniform(0, 0.4)
-        q0 = np.concatenate([[np.cos(ang / 2)], np.sin(ang / 2) * ax])
-        vd = rng.normal(size=3) * 0.15
-        for k in range(trail_len + 1):
-            ip = 0 if k == 0 else 20 + 7 * (k - 1); io = 6 if k == 0 else 20 + 7 * (k - 1) + 3
-            m[ip:ip + 3] = -vd * k + 0.01 * rng.normal(size=3)
-            q = q0 + 0.004 * k * rng.normal(size=4); m[io:io + 4] = q / np.linalg.norm(q)
-        m[16:19] = 1.0
-        idx[b] = np.sort(rng.choice(trail_len + 1, npose, replace=False))
-        poses = []
-        for cam in range(ncam):
-            for k in idx[b]:
-                ip = 0 if k == 0 else 20 + 7 * (k - 1); io = 6 if k == 0 else 20 + 7 * (k - 1) + 3
-                R = Ric @ rot(m[io:io + 4]); p = m[ip:ip + 3] - R.T @ (base2 if cam else np.zeros(3))
-                poses.append((R, p))
-        pw = poses[0][1] + poses[0][0].T @ np.array([rng.uniform(-1, 1), rng.uniform(-1, 1), rng.uniform(2, 12)])
-        for i, (R, p) in enumerate(poses):
-            pc = R @ (pw - p); feat[b, i] = pc[:2] / pc[2] + 1e-3 * rng.normal(size=2)
-    T1 = np.eye(4); T1[:3, :3] = Ric
-    T2 = T1.copy(); T2[:3, 3] = base2
-    return T1, (T2 if stereo else None), means, idx, feat
+from hybvio_amd.synth import visual_tracks as synthetic_tracks  # noqa: E402
 
 
 def main():

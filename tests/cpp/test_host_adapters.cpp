@@ -267,6 +267,42 @@ static void test_ingest(Session &s, const std::string &dir)
     }
 }
 
+// test/triangulation.cpp "visual" (:56-197) through EKF::visualTrack: the track of the reference test is triangulated from
+// the DEVICE mean (Matlab point within 1e-5), gated and applied in one call (backend.cpp:1063-1185)
+static void test_visual_track(Session &s, const std::string &dir)
+{
+    hv_ekf_params par; hv_ekf_default_params(&par);
+    par.cameraTrailLength = 20; par.noiseScale = 1000.0;
+    auto e = odometry::EKF::buildHip(s, par);
+    const std::vector<double> poses = load(dir + "/visual_poses.txt"), uv = load(dir + "/visual_uv.txt"), pfe = load(dir + "/visual_pf.txt");
+    VectorXd m = e->getState();
+    for (int k = 0; k < 3; k++) m[odometry::POS + k] = poses[k];
+    for (int k = 0; k < 4; k++) m[odometry::ORI + k] = poses[3 + k];
+    for (int i = 0; i < 9; i++) for (int k = 0; k < 7; k++) m[odometry::CAM + 7 * i + k] = poses[7 * (i + 1) + k];
+    e->setState(m);
+    hv_vu_params vp; hv_vu_default_params(&vp);                  // default imuToCameraMatrix, mono
+    std::vector<int> idx(10);
+    for (int i = 0; i < 10; i++) idx[i] = i;
+    std::vector<double> vel(20, 0.1);
+    VectorXd y(uv.begin(), uv.end());
+    const VectorXd before = e->getState();
+    const auto res = e->visualTrack(vp, idx, uv, vel, y, 1.5, 0.05);
+    REQUIRE(res.triangulateStatus == HV_TRI_OK && res.prepareVuStatus == HV_PREPARE_VU_OK);
+    REQUIRE(std::fabs(res.pf[0] - pfe[0]) + std::fabs(res.pf[1] - pfe[1]) + std::fabs(res.pf[2] - pfe[2]) < 1e-5);
+    REQUIRE(res.outlierStatus == odometry::VuOutlierStatus::INLIER);
+    const VectorXd &after = e->getState();
+    double moved = 0; for (size_t i = 0; i < after.size(); i++) moved += std::fabs(after[i] - before[i]);
+    REQUIRE(moved > 0.0 && moved < 1.0);
+    // a track no static point explains: nothing reaches the gate, the filter stays as it is
+    std::vector<double> bad(uv); for (auto &x : bad) x = -x;
+    const VectorXd mid = e->getState();
+    const auto res2 = e->visualTrack(vp, idx, bad, vel, y, 1.5, 0.05);
+    REQUIRE(res2.triangulateStatus != HV_TRI_OK && res2.outlierStatus == odometry::VuOutlierStatus::NOT_COMPUTED);
+    const VectorXd &same = e->getState();
+    double diff = 0; for (size_t i = 0; i < same.size(); i++) diff += std::fabs(same[i] - mid[i]);
+    REQUIRE(diff == 0.0);
+}
+
 int main(int argc, char **argv)
 {
     if (argc < 2) { std::printf("usage: %s <dir>\n", argv[0]); return 2; }
@@ -281,6 +317,7 @@ int main(int argc, char **argv)
     test_pose_trail(session);
     test_tracker(session, dir);
     test_ingest(session, dir);
+    test_visual_track(session, dir);
     std::printf("%s (%d failure%s)\n", failures ? "FAILED" : "all host adapter tests passed", failures, failures == 1 ? "" : "s");
     return failures ? 1 : 0;
 }

@@ -54,6 +54,9 @@ def test_reference_tests_through_the_cpp_adapters(oracle):
         rgb.tofile(os.path.join(d, "rgb0.raw"))
         cams = [195.2, 194.6, 156.3, 121.7, -0.28340811, 0.07395907, 0.0, 170.0, w * 0.5, h * 0.5]
         np.savetxt(os.path.join(d, "cameras.txt"), cams, fmt="%.17g")
+        tri = np.load(os.path.join(os.path.dirname(__file__), "golden", "triangulation_reference_fixtures.npz"))
+        for key, name in (("visual_poses", "visual_poses"), ("visual_uv", "visual_uv"), ("visual_pf_matlab", "visual_pf")):
+            np.savetxt(os.path.join(d, name + ".txt"), np.asarray(tri[key]).reshape(-1), fmt="%.17g")
         r = subprocess.run([exe, d], capture_output=True, text=True, timeout=300)
         print(r.stdout, r.stderr)
         assert r.returncode == 0, r.stdout + r.stderr
