@@ -23,7 +23,7 @@ f64p = C.POINTER(C.c_double)
 
 def build(force: bool = False) -> str:
     so = os.path.join(_DIR, "liboracle.so")
-    srcs = [os.path.join(_DIR, f) for f in ("pyrlk_oracle.c", "ekf_oracle.c", "gftt_oracle.c", "ingest_oracle.c", "triangulation_oracle.c", "Makefile")]
+    srcs = [os.path.join(_DIR, f) for f in ("pyrlk_oracle.c", "ekf_oracle.c", "gftt_oracle.c", "ingest_oracle.c", "triangulation_oracle.c", "rot_ransac_oracle.c", "Makefile")]
     if force or not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
         subprocess.check_call(["make", "-C", _DIR, "-B", "liboracle.so"], stdout=subprocess.DEVNULL)
     return so
@@ -71,6 +71,11 @@ def lib():
         L.orc_prepare_visual_update.argtypes = [f64p, f64p, f64p, f64p, f64p, C.c_void_p, C.c_int, i32p, C.c_int, C.c_int, C.c_int,
                                                 C.c_int, C.c_int, C.c_int, C.c_double, f64p, f64p, i32p]
         L.orc_visual_track_prepare.argtypes = [C.c_void_p, f64p, C.c_int, i32p, C.c_int, f64p, f64p, f64p, f64p, f64p, f64p, f64p, i32p]
+        u32p = C.POINTER(C.c_uint32)
+        L.orc_mt19937_draws.argtypes = [C.c_uint32, C.c_int, C.c_int, u32p]
+        L.orc_kabsch_rotation.argtypes = [f32p, f32p]
+        L.orc_solve_rotation.argtypes = [f32p, f32p, i32p, C.c_int, f32p]
+        L.orc_rot_ransac_fit.argtypes = [f32p, f32p, C.c_int, C.c_void_p, C.c_void_p, u32p, C.c_float, i32p, f32p, i32p]
         _LIB = L
     return _LIB
 
@@ -576,3 +581,30 @@ def visual_track_prepare(par, m, pose_trail_index, imu_to_cam, imu_to_cam2, imag
                                         None if b is None else _p(b, f64p), _p(_f64(image_features), f64p),
                                         _p(_f64(feature_velocities), f64p), _p(pf, f64p), _p(H, f64p), _p(f, f64p), _p(ps, i32p))
     return st, int(ps[0]), pf, H.T.copy(), f
+
+
+# ---- 2-point rotation RANSAC (oracle/rot_ransac_oracle.c) ----
+def mt19937_draws(seed: int, n: int, skip: int = 0) -> np.ndarray:
+    """Raw outputs of std::mt19937(seed) after `skip` draws."""
+    out = np.zeros(n, np.uint32)
+    lib().orc_mt19937_draws(int(seed), int(skip), int(n), out.ctypes.data_as(C.POINTER(C.c_uint32)))
+    return out
+
+
+def solve_rotation(p1, p2, inds) -> np.ndarray:
+    a, b = np.ascontiguousarray(p1, np.float32), np.ascontiguousarray(p2, np.float32)
+    ii = np.ascontiguousarray(inds, np.int32)
+    R = np.zeros((3, 3), np.float32)
+    lib().orc_solve_rotation(_p(a, f32p), _p(b, f32p), _p(ii, i32p), len(ii), _p(R, f32p))
+    return R
+
+
+def rot_ransac_fit(c1, c2, cam1: "Camera", cam2: "Camera", draws, threshold_pow2: float):
+    """RotRansac::fit: returns (status [n] 0 TRACKED / 3 RANSAC_OUTLIER, R 3x3 f32, bestInlierCount, draws consumed)."""
+    a, b = np.ascontiguousarray(c1, np.float32).reshape(-1, 2), np.ascontiguousarray(c2, np.float32).reshape(-1, 2)
+    d = np.ascontiguousarray(draws, np.uint32)
+    assert len(d) >= 200
+    st, R, best = np.zeros(len(a), np.int32), np.zeros((3, 3), np.float32), np.zeros(1, np.int32)
+    used = lib().orc_rot_ransac_fit(_p(a, f32p), _p(b, f32p), len(a), cam1.h, cam2.h, d.ctypes.data_as(C.POINTER(C.c_uint32)),
+                                    float(threshold_pow2), _p(st, i32p), _p(R, f32p), _p(best, i32p))
+    return st, R, int(best[0]), int(used)
