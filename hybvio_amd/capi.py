@@ -29,7 +29,7 @@ f32p = C.POINTER(C.c_float)
 f64p = C.POINTER(C.c_double)
 
 HV_MAX_LEVELS = 6
-K_PYR_L0, K_PYR_LN, K_KLT, K_EKF_PREDICT, K_EKF_UPDATE, K_EKF_AUGMENT, K_GFTT, K_INGEST, K_VU_PREPARE = range(9)
+K_PYR_L0, K_PYR_LN, K_KLT, K_EKF_PREDICT, K_EKF_UPDATE, K_EKF_AUGMENT, K_GFTT, K_INGEST, K_VU_PREPARE, K_ROT_RANSAC = range(10)
 
 # tracker::Feature::Status (src/tracker/track.hpp:9-21)
 ST_TRACKED, ST_NEW, ST_FAILED_FLOW, ST_RANSAC_OUTLIER, ST_FLOW_OUT_OF_RANGE = 0, 1, 2, 3, 4
@@ -104,6 +104,9 @@ PROTOTYPES = {
     "hv_ekf_update": (C.c_int, [C.c_void_p, C.c_int, C.c_int, f64p, f64p, f64p, u8p, C.c_int]),
     "hv_ekf_visual_gate": (C.c_int, [C.c_void_p, C.c_int, C.c_int, f64p, f64p, C.c_double, f64p, i32p]),
     "hv_ekf_visual_update": (C.c_int, [C.c_void_p, C.c_int, C.c_int, f64p, f64p, C.c_double, u8p]),
+    "hv_camera_model_init": (C.c_int, [C.c_void_p]),
+    "hv_rot_ransac": (C.c_int, [C.c_void_p, C.c_int] + [C.c_void_p] * 5 + [C.c_float] + [C.c_void_p] * 4),
+    "hv_rot_ransac_batch_dev": (C.c_int, [C.c_void_p, C.c_int, C.c_int] + [C.c_void_p] * 6 + [C.c_float] + [C.c_void_p] * 3),
     "hv_vu_default_params": (None, [C.c_void_p]),
     "hv_ekf_visual_prepare_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int] + [C.c_void_p] * 10),
     "hv_ekf_visual_track_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int] + [C.c_void_p] * 4 + [C.c_double, C.c_double] + [C.c_void_p] * 4),
@@ -221,6 +224,25 @@ class Context:
     def build_batch_dev(self, n: int, slots_dev: int, gray_dev: int, image_stride: int, row_stride: int):
         self._chk(lib().hv_pyramid_build_batch_dev(self._h, n, C.c_void_p(slots_dev), C.c_void_p(gray_dev),
                                                    image_stride, row_stride), "hv_pyramid_build_batch_dev")
+
+    # ---- 2-point rotation RANSAC (f4) ----
+    def rot_ransac(self, c1, c2, cam1: "CameraModel", cam2: "CameraModel", pairs, threshold_pow2: float):
+        """hv_rot_ransac: returns (status [n], R 3x3 f32, bestInlierCount, hypotheses visited)."""
+        a, b = np.ascontiguousarray(c1, np.float32).reshape(-1, 2), np.ascontiguousarray(c2, np.float32).reshape(-1, 2)
+        pr = np.ascontiguousarray(pairs, np.int32).reshape(100, 2)
+        st, R = np.zeros(len(a), np.int32), np.zeros((3, 3), np.float32)
+        best, vis = C.c_int(0), C.c_int(0)
+        vp = lambda x: x.ctypes.data_as(C.c_void_p)
+        self._chk(lib().hv_rot_ransac(self._h, len(a), vp(a), vp(b), C.byref(cam1), C.byref(cam2), vp(pr), float(threshold_pow2),
+                                      vp(st), vp(R), C.byref(best), C.byref(vis)), "hv_rot_ransac")
+        return st, R, best.value, vis.value
+
+    def rot_ransac_batch_dev(self, n_sets, max_points, n_points_dev, c1_dev, c2_dev, cam1, cam2, pairs_dev, threshold_pow2,
+                             status_dev, R_dev, summary_dev):
+        p = lambda x: C.c_void_p(x)
+        self._chk(lib().hv_rot_ransac_batch_dev(self._h, n_sets, max_points, p(n_points_dev), p(c1_dev), p(c2_dev), C.byref(cam1),
+                                                C.byref(cam2), p(pairs_dev), float(threshold_pow2), p(status_dev), p(R_dev),
+                                                p(summary_dev)), "hv_rot_ransac_batch_dev")
 
     # ---- image ingest (f2): colour -> gray and the undistort / rectify remap in front of the pyramid ----
     def ingest_set_undistort_map(self, camera: int, pix_orig=None, valid=None):
@@ -349,6 +371,31 @@ def ekf_default_params(**over) -> EkfParams:
 
 def _f(a):
     return np.ascontiguousarray(a, np.float64)
+
+
+class CameraModel(C.Structure):
+    """hv_camera_model (tracker::Camera, camera.cpp)."""
+    _fields_ = [("kind", C.c_int), ("fx", C.c_double), ("fy", C.c_double), ("ppx", C.c_double), ("ppy", C.c_double),
+                ("n_coeffs", C.c_int), ("coeffs", C.c_double * 4), ("rotation_enabled", C.c_int), ("rotation", C.c_double * 9),
+                ("max_valid_fov_deg", C.c_double), ("distortion_enabled", C.c_int), ("kinv", C.c_double * 9),
+                ("max_theta", C.c_double), ("max_r", C.c_double), ("n_table", C.c_int), ("table", C.c_double * 50)]
+
+
+def camera_model(kind, fx, fy, ppx, ppy, coeffs=(), rotation=None, max_valid_fov_deg=180.0) -> CameraModel:
+    m = CameraModel()
+    m.kind = {"pinhole": 0, "fisheye": 1}[kind]
+    m.fx, m.fy, m.ppx, m.ppy = fx, fy, ppx, ppy
+    m.n_coeffs = len(coeffs)
+    for i, c in enumerate(coeffs):
+        m.coeffs[i] = c
+    if rotation is not None:
+        m.rotation_enabled = 1
+        m.rotation[:] = list(np.asarray(rotation, np.float64).reshape(9))
+    m.max_valid_fov_deg = max_valid_fov_deg
+    rc = lib().hv_camera_model_init(C.byref(m))
+    if rc != 0:
+        raise HvError(f"hv_camera_model_init: {lib().hv_status_string(rc).decode()}")
+    return m
 
 
 class VuParams(C.Structure):

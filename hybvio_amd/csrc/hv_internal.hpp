@@ -62,6 +62,8 @@ struct Ctx {
     bool map_tiled[HV_INGEST_CAMERAS] = {};
     uint8_t *d_ingest_stage = nullptr;
     size_t ingest_stage_bytes = 0;
+    unsigned char *d_ransac_stage = nullptr;   // staging of the host-pointer rotation-RANSAC entry (f4)
+    size_t ransac_stage_bytes = 0;
     std::string last_error;
     bool profiling = false;
     KernelTimer timers[HV_K_COUNT];

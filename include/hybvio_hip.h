@@ -289,9 +289,42 @@ int hv_ingest_build(hv_ctx *ctx, int slot, const uint8_t *image_host, int stride
 int hv_ingest_build_batch_dev(hv_ctx *ctx, int n, const int *slots_dev, const uint8_t *src_dev,
                               long long image_stride_bytes, int row_stride_bytes, int channels, int camera);
 
+/* ---- 2-point rotation RANSAC -----------------------------------------
+ * Replaces tracker::rot_ransac::RotRansac::fit (src/tracker/rot_ransac.cpp:41-120) as doRansac2 calls it on the
+ * TRACKED features of every frame (src/tracker/ransac_pipeline.cpp:197-216). The camera models are the reference's
+ * (src/tracker/camera.cpp): fill the first block of fields and call hv_camera_model_init. */
+typedef struct hv_camera_model {
+    int kind;                         /* 0 pinhole (radial k1 k2 k3, camera.cpp:93-221), 1 fisheye (k1..k4, :264-398) */
+    double fx, fy, ppx, ppy;          /* api::CameraParameters */
+    int n_coeffs; double coeffs[4];   /* distortionCoeffs: 0 or 3 (pinhole), 0 or 4 (fisheye) */
+    int rotation_enabled; double rotation[9];   /* pinhole only (rectified cameras), row-major */
+    double max_valid_fov_deg;         /* fisheye: validCameraFov */
+    /* derived by hv_camera_model_init (the constructors of camera.cpp) */
+    int distortion_enabled;
+    double kinv[9], max_theta, max_r;
+    int n_table; double table[50];
+} hv_camera_model;
+int hv_camera_model_init(hv_camera_model *m);
+/* One point set = the n TRACKED features of one frame: c1 / c2 = pixel coordinates in the previous / current frame
+ * (cameras[0][0] / cameras[0][1]). pairs[k] = {rng() % n, rng() % n} for k = 0..99 drawn by the caller from its
+ * std::mt19937 (rot_ransac.cpp:82-83); afterwards the caller discards nothing and keeps 2 * hypotheses_visited draws
+ * consumed (the reference loop stops at the first hypothesis that makes every point an inlier). threshold_pow2 =
+ * RotRansac::threshold_pow2 (ransac_pipeline.cpp:91-93). status[i] = 0 TRACKED / 3 RANSAC_OUTLIER (track.hpp:9-21),
+ * R = the returned cv::Matx33f (row-major), best_inlier_count = RotRansac::bestInlierCount. Synchronous. */
+int hv_rot_ransac(hv_ctx *ctx, int n, const float *c1_xy, const float *c2_xy, const hv_camera_model *camera1,
+                  const hv_camera_model *camera2, const int *pairs, float threshold_pow2, int *status, float *R,
+                  int *best_inlier_count, int *hypotheses_visited);
+/* n_sets point sets in device memory, set s holding n_points_dev[s] <= max_points (<= 1024) points at
+ * c*_dev + s * max_points * 2, pairs_dev [n_sets][100][2], status_dev [n_sets][max_points], R_dev [n_sets][9],
+ * summary_dev [n_sets][2] = {bestInlierCount, hypotheses_visited}. Sets with fewer than 2 points are skipped
+ * (ransac_pipeline.cpp:209). Asynchronous. */
+int hv_rot_ransac_batch_dev(hv_ctx *ctx, int n_sets, int max_points, const int *n_points_dev, const float *c1_dev,
+                            const float *c2_dev, const hv_camera_model *camera1, const hv_camera_model *camera2,
+                            const int *pairs_dev, float threshold_pow2, int *status_dev, float *R_dev, int *summary_dev);
+
 /* ---- per-kernel timing (hipEvents on the context stream) ---------------------------------- */
 enum { HV_K_PYR_L0 = 0, HV_K_PYR_LN = 1, HV_K_KLT = 2, HV_K_EKF_PREDICT = 3, HV_K_EKF_UPDATE = 4,
-       HV_K_EKF_AUGMENT = 5, HV_K_GFTT = 6, HV_K_INGEST = 7, HV_K_VU_PREPARE = 8, HV_K_COUNT = 9 };
+       HV_K_EKF_AUGMENT = 5, HV_K_GFTT = 6, HV_K_INGEST = 7, HV_K_VU_PREPARE = 8, HV_K_ROT_RANSAC = 9, HV_K_COUNT = 10 };
 int hv_profile_enable(hv_ctx *ctx, int on);
 int hv_profile_reset(hv_ctx *ctx);
 /* Synchronizes, then returns accumulated device milliseconds and launch count of a kernel class. */
