@@ -24,6 +24,7 @@ ImagePyramid::Factory::~Factory() = default;
 OpticalFlow::~OpticalFlow() = default;
 FeatureDetector::~FeatureDetector() = default;
 Undistorter::~Undistorter() = default;
+rot_ransac::RotRansac::~RotRansac() = default;
 
 void FeatureDetector::applyMinDistance(std::vector<Feature::Point> &corners, const std::vector<Feature::Point> &prevCorners,
                                        int minDistance) const
@@ -186,6 +187,46 @@ public:
 };
 
 }  // namespace
+
+namespace {
+class HipRotRansac : public rot_ransac::RotRansac {
+    Session &session;
+    std::vector<int> pairs, status;
+public:
+    explicit HipRotRansac(Session &s) : session(s), pairs(200) {}
+    std::array<float, 9> fit(const std::vector<Feature::Point> &c1, const std::vector<Feature::Point> &c2,
+                             const hv_camera_model &camera1, const hv_camera_model &camera2,
+                             std::vector<Feature::Status> &bestInliers, std::mt19937 &rng) final {
+        assert(c1.size() == c2.size());
+        const std::size_t n = c1.size();
+        assert(n >= 2 && bestInliers.size() >= n);
+        // draw the 100 index pairs from a COPY of the generator, then advance the real one by what the reference loop
+        // would have consumed (it stops at the first hypothesis that makes every point an inlier)
+        std::mt19937 ahead = rng;
+        for (int k = 0; k < 100; ++k) {
+            pairs[2 * k] = static_cast<int>(ahead() % n);
+            pairs[2 * k + 1] = static_cast<int>(ahead() % n);
+        }
+        status.assign(n, 3);
+        std::array<float, 9> R{};
+        int best = 0, visited = 0;
+        static_assert(sizeof(Feature::Point) == 2 * sizeof(float), "Point must be two packed floats");
+        const int rc = hv_rot_ransac(session.ctx(), static_cast<int>(n), reinterpret_cast<const float *>(c1.data()),
+                                     reinterpret_cast<const float *>(c2.data()), &camera1, &camera2, pairs.data(), threshold_pow2,
+                                     status.data(), R.data(), &best, &visited);
+        assert(rc == HV_OK); (void)rc;
+        rng.discard(2ull * static_cast<unsigned long long>(visited));
+        bestInlierCount = static_cast<std::size_t>(best);
+        for (std::size_t i = 0; i < n; ++i) bestInliers.at(i) = static_cast<Feature::Status>(status[i]);
+        return R;
+    }
+};
+}  // namespace
+
+std::unique_ptr<rot_ransac::RotRansac> rot_ransac::RotRansac::buildHip(Session &s)
+{
+    return std::unique_ptr<rot_ransac::RotRansac>(new HipRotRansac(s));
+}
 
 std::unique_ptr<Undistorter> Undistorter::buildRectifiedHip(Session &s, int cameraIndex, std::shared_ptr<const Camera> rectified)
 {

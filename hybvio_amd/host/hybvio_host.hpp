@@ -21,6 +21,7 @@
 #include <array>
 #include <cstdint>
 #include <memory>
+#include <random>
 #include <string>
 #include <vector>
 
@@ -163,6 +164,27 @@ protected:
     explicit FeatureDetector(const hv_gftt_params &parameters) : parameters(parameters) {}
     const hv_gftt_params parameters;
 };
+
+// tracker::rot_ransac::RotRansac (src/tracker/rot_ransac.hpp:14-41), SURVEY.md 8(f) row f4. Same members and call:
+// fit() consumes rng exactly as the reference loop does (two draws per visited hypothesis, rot_ransac.cpp:82-83,104), so
+// every later user of the pipeline's generator sees the same stream. The cameras are described by hv_camera_model
+// (the reference's tracker::Camera parameters); the returned rotation is the cv::Matx33f, row-major.
+namespace rot_ransac {
+class RotRansac {
+public:
+    static std::unique_ptr<RotRansac> buildHip(Session &session);
+    virtual ~RotRansac();
+    virtual std::array<float, 9> fit(
+        const std::vector<Feature::Point> &c1,
+        const std::vector<Feature::Point> &c2,
+        const hv_camera_model &camera1,
+        const hv_camera_model &camera2,
+        std::vector<Feature::Status> &bestInliers,
+        std::mt19937 &rng) = 0;
+    std::size_t bestInlierCount = 0;
+    float threshold_pow2 = 2.0f * 2.0f;      // "Likely set later with information of the frame size." (rot_ransac.cpp:164)
+};
+}  // namespace rot_ransac
 
 }  // namespace tracker
 

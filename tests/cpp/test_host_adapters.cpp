@@ -303,6 +303,35 @@ static void test_visual_track(Session &s, const std::string &dir)
     REQUIRE(diff == 0.0);
 }
 
+// RotRansac::fit as doRansac2 calls it (ransac_pipeline.cpp:197-216): two consecutive frames share ONE std::mt19937, so
+// the second call only agrees with the oracle if the first consumed exactly what the reference loop would have
+static void test_rot_ransac(Session &s, const std::string &dir)
+{
+    const std::vector<double> cam = load(dir + "/ransac_camera.txt");   // fx fy cx cy k1 k2 k3
+    hv_camera_model m{};
+    m.kind = 0; m.fx = cam[0]; m.fy = cam[1]; m.ppx = cam[2]; m.ppy = cam[3]; m.n_coeffs = 3;
+    for (int i = 0; i < 3; i++) m.coeffs[i] = cam[4 + i];
+    REQUIRE(hv_camera_model_init(&m) == HV_OK);
+    auto ransac = tracker::rot_ransac::RotRansac::buildHip(s);
+    ransac->threshold_pow2 = (float)cam[7];
+    std::mt19937 rng(4649);                                              // ransacRngSeed
+    std::ofstream out(dir + "/ransac_out.txt");
+    out.precision(9);
+    for (int frame = 0; frame < 3; frame++) {
+        const std::vector<double> pts = load(dir + "/ransac_pts" + std::to_string(frame) + ".txt");   // x1 y1 x2 y2 per row
+        const size_t n = pts.size() / 4;
+        std::vector<tracker::Feature::Point> c1(n), c2(n);
+        for (size_t i = 0; i < n; i++) { c1[i] = {(float)pts[4 * i], (float)pts[4 * i + 1]}; c2[i] = {(float)pts[4 * i + 2], (float)pts[4 * i + 3]}; }
+        std::vector<tracker::Feature::Status> st(n, tracker::Feature::Status::CULLED);
+        const auto R = ransac->fit(c1, c2, m, m, st, rng);
+        out << ransac->bestInlierCount;
+        for (float v : R) out << " " << v;
+        for (auto v : st) out << " " << (int)v;
+        out << "\n";
+    }
+    out << rng() << "\n";                                               // the generator's next output after three frames
+}
+
 int main(int argc, char **argv)
 {
     if (argc < 2) { std::printf("usage: %s <dir>\n", argv[0]); return 2; }
@@ -318,6 +347,7 @@ int main(int argc, char **argv)
     test_tracker(session, dir);
     test_ingest(session, dir);
     test_visual_track(session, dir);
+    test_rot_ransac(session, dir);
     std::printf("%s (%d failure%s)\n", failures ? "FAILED" : "all host adapter tests passed", failures, failures == 1 ? "" : "s");
     return failures ? 1 : 0;
 }

@@ -25,7 +25,7 @@ def test_host_library_and_test_program_build():
     syms = subprocess.check_output(["nm", "-D", "--defined-only", "-C", lib], text=True)
     for name in ("hybvio::tracker::ImagePyramid::Factory::buildHip", "hybvio::tracker::OpticalFlow::buildHip",
                  "hybvio::odometry::EKF::buildHip", "hybvio::tracker::FeatureDetector::buildHip",
-                 "hybvio::tracker::Undistorter::buildRectifiedHip"):
+                 "hybvio::tracker::Undistorter::buildRectifiedHip", "hybvio::tracker::rot_ransac::RotRansac::buildHip"):
         assert name in syms, name
     needed = subprocess.check_output(["readelf", "-d", lib], text=True)
     assert "libhybvio_hip.so" in needed and "amdhip64" not in needed      # only the C ABI is linked
@@ -54,6 +54,23 @@ def test_reference_tests_through_the_cpp_adapters(oracle):
         rgb.tofile(os.path.join(d, "rgb0.raw"))
         cams = [195.2, 194.6, 156.3, 121.7, -0.28340811, 0.07395907, 0.0, 170.0, w * 0.5, h * 0.5]
         np.savetxt(os.path.join(d, "cameras.txt"), cams, fmt="%.17g")
+        # f4: three frames of RANSAC input sharing one generator; frame 1 has no outliers (early exit of the reference loop)
+        rcam = [458.654 * w / 752, 457.296 * w / 752, 367.215 * w / 752, 248.375 * w / 752, -0.28340811, 0.07395907, 0.0]
+        thr = float(np.float32((4.0 * min(w, h) / 720.0) ** 2))
+        np.savetxt(os.path.join(d, "ransac_camera.txt"), rcam + [thr], fmt="%.17g")
+        ocam = oracle.Camera("pinhole", *rcam[:4], coeffs=rcam[4:])
+        rsets = []
+        for frame, (npts, nbad) in enumerate(((120, 30), (60, 0), (90, 20))):
+            ax = rng.normal(size=3); ax /= np.linalg.norm(ax)
+            K = np.array([[0, -ax[2], ax[1]], [ax[2], 0, -ax[0]], [-ax[1], ax[0], 0]])
+            Rt = np.eye(3) + np.sin(0.02) * K + (1 - np.cos(0.02)) * K @ K
+            a = rng.uniform([30, 30], [w - 30, h - 30], (npts, 2)).astype(np.float32)
+            b = np.array([ocam.ray_to_pixel(Rt @ ocam.pixel_to_ray(*p)[1])[1] for p in a]) + rng.normal(size=(npts, 2)) * (0.02 if nbad == 0 else 0.2)
+            b = b.astype(np.float32)
+            bad = rng.choice(npts, nbad, replace=False)
+            b[bad] += (rng.uniform(6, 25, (nbad, 2)) * rng.choice([-1, 1], (nbad, 2))).astype(np.float32)
+            rsets.append((a, b))
+            np.savetxt(os.path.join(d, f"ransac_pts{frame}.txt"), np.hstack([a, b]).reshape(-1), fmt="%.9g")
         tri = np.load(os.path.join(os.path.dirname(__file__), "golden", "triangulation_reference_fixtures.npz"))
         for key, name in (("visual_poses", "visual_poses"), ("visual_uv", "visual_uv"), ("visual_pf_matlab", "visual_pf")):
             np.savetxt(os.path.join(d, name + ".txt"), np.asarray(tri[key]).reshape(-1), fmt="%.17g")
@@ -68,6 +85,17 @@ def test_reference_tests_through_the_cpp_adapters(oracle):
                for f in ("detect_raw.txt", "detect_masked.txt", "detect_raw_then_mask.txt")]
         ing = [np.fromfile(os.path.join(d, f), np.uint8).reshape(h, w)
                for f in ("ingest_gray.raw", "ingest_rect.raw", "ingest_rect_again.raw")]
+        rout = open(os.path.join(d, "ransac_out.txt")).read().split("\n")
+    # RotRansac::buildHip: three frames on one std::mt19937 vs the oracle consuming the same stream
+    skip = 0
+    for frame, (a, b) in enumerate(rsets):
+        st_o, R_o, best_o, used_o = oracle.rot_ransac_fit(a, b, ocam, ocam, oracle.mt19937_draws(4649, 200, skip=skip), thr)
+        skip += used_o
+        vals = rout[frame].split()
+        assert int(vals[0]) == best_o
+        np.testing.assert_allclose(np.array(vals[1:10], np.float64), R_o.reshape(-1), rtol=0, atol=1e-7)
+        np.testing.assert_array_equal(np.array(vals[10:], np.int32), st_o)
+    assert skip < 600 and int(rout[3]) == int(oracle.mt19937_draws(4649, 1, skip=skip)[0])    # frame 1 stopped early; the stream stays in step
     # Image::Factory::build on a colour frame and Undistorter::buildRectifiedHip vs the oracle
     gray = oracle.color_to_gray(rgb)
     np.testing.assert_array_equal(ing[0], gray)
