@@ -110,6 +110,7 @@ PROTOTYPES = {
     "hv_vu_default_params": (None, [C.c_void_p]),
     "hv_ekf_visual_prepare_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int] + [C.c_void_p] * 10),
     "hv_ekf_visual_track_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int] + [C.c_void_p] * 4 + [C.c_double, C.c_double] + [C.c_void_p] * 4),
+    "hv_ekf_visual_track_limited_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int] + [C.c_void_p] * 4 + [C.c_double, C.c_double] + [C.c_void_p] * 5 + [C.c_int]),
     "hv_ekf_visual_track": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int] + [C.c_void_p] * 4 + [C.c_double, C.c_double] + [C.c_void_p] * 4),
     "hv_ekf_visual_dev": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_double, C.c_int,
                                     C.c_void_p, C.c_void_p]),
@@ -538,6 +539,13 @@ class EkfBatch:
         b = [C.c_void_p(x) for x in (status_dev, gate_status_dev, chi2_dev, pf_dev)]
         self._chk(lib().hv_ekf_visual_track_dev(self._h, C.byref(params), n_poses, *a, float(r_gate), float(r_update), *b),
                   "hv_ekf_visual_track_dev")
+
+    def visual_track_limited_dev(self, params: VuParams, n_poses, pose_index_dev, features_dev, velocities_dev, y_dev, r_gate, r_update,
+                                 status_dev, gate_status_dev, success_counter_dev, max_successful, chi2_dev=0, pf_dev=0):
+        a = [C.c_void_p(x) for x in (pose_index_dev, features_dev, velocities_dev, y_dev)]
+        b = [C.c_void_p(x) for x in (status_dev, gate_status_dev, chi2_dev, pf_dev, success_counter_dev)]
+        self._chk(lib().hv_ekf_visual_track_limited_dev(self._h, C.byref(params), n_poses, *a, float(r_gate), float(r_update), *b,
+                                                        int(max_successful)), "hv_ekf_visual_track_limited_dev")
 
     def visual_track(self, params: VuParams, pose_index, features, velocities, y, r_gate, r_update):
         """hv_ekf_visual_track with numpy arrays [batch][...]: returns (status [batch][2], gate_status, chi2, pf)."""

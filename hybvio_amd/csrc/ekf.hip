@@ -416,6 +416,7 @@ struct UpdateArgs {
     double *chi2; int *status;        // optional outputs
     const unsigned char *active;      // optional per-filter enable
     const int *require_inlier;        // optional per-filter gate result of an earlier launch: run only where it is 0 (INLIER)
+    int *success_counter;             // optional per-filter count of applied visual updates (updateSuccessCount, backend.cpp:1183)
 };
 
 constexpr int UPD_THREADS = 512;   // 8 waves = 2 per SIMD: 256 VGPRs each (whole column blocks of P stay in registers)
@@ -798,6 +799,7 @@ __global__ __launch_bounds__(UPD_THREADS) void ekf_update_kernel(UpdateArgs a)
     // ---- G: quaternion normalisation (updateCommon ekf.cpp:29-31 / normalizeQuaternions 1024-1032) ----
     const int nq = a.normalize_all ? 1 + (n - a.map_dim - CAM) / POSE : 1;     // map points behind the trail are not poses
     if (t < nq) normalize4(m + (t == 0 ? ORI : CAM + POSE * (t - 1) + 3));
+    if (a.success_counter && t == 0) a.success_counter[b] += 1;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1132,7 +1134,8 @@ struct Ekf {
 
 static int ekf_launch_update(Ekf *e, int nr, int l, const double *H_dev, const double *v_dev, const double *rdiag_dev,
                              double rd0, int mode, int generic, int normalize_all, double *chi2_dev, int *status_dev,
-                             const unsigned char *active_dev, const int *require_inlier_dev = nullptr)
+                             const unsigned char *active_dev, const int *require_inlier_dev = nullptr,
+                             int *success_counter_dev = nullptr)
 {
     Ctx *c = e->c;
     if (nr < 1 || nr > e->max_rows || l < 1 || l > e->n) return HV_ERR_INVALID;
@@ -1146,7 +1149,7 @@ static int ekf_launch_update(Ekf *e, int nr, int l, const double *H_dev, const d
     a.Rs = r_pad;
     a.mode = mode; a.generic = generic; a.normalize_all = normalize_all; a.map_dim = e->map_dim;
     a.m = e->m; a.P = e->P; a.H = H_dev; a.v = v_dev; a.rdiag = rdiag_dev; a.rd0 = rd0; a.noise_scale = e->noise_scale;
-    a.ws = e->ws; a.chi2 = chi2_dev; a.status = status_dev; a.active = active_dev; a.require_inlier = require_inlier_dev;
+    a.ws = e->ws; a.chi2 = chi2_dev; a.status = status_dev; a.active = active_dev; a.require_inlier = require_inlier_dev; a.success_counter = success_counter_dev;
     size_t tall = (((size_t)a.Rs * nr + 1) & ~(size_t)1) * sizeof(double);
     const size_t small = (size_t)(576 + UPD_THREADS / 64 + 2) * sizeof(double);                 // W + col + red + flag
     const int ti = (nr + 15) / 16, lbk = (l + 15) / 16;
@@ -1308,9 +1311,29 @@ int hv_ekf_visual_prepare_dev(hv_ekf *h, const hv_vu_params *p, int np, const in
     return hv::launch_vu_prepare(e->c, a);
 }
 
+static int visual_track_dev_impl(hv_ekf *h, const hv_vu_params *p, int np, const int *idx, const double *feat, const double *vel,
+                                 const double *y, double r_gate, double r_update, int *status_dev, int *gate_status_dev,
+                                 double *chi2_dev, double *pf_dev, int *success_counter_dev, int max_successful);
+
 int hv_ekf_visual_track_dev(hv_ekf *h, const hv_vu_params *p, int np, const int *idx, const double *feat, const double *vel,
                             const double *y, double r_gate, double r_update, int *status_dev, int *gate_status_dev,
                             double *chi2_dev, double *pf_dev)
+{
+    return visual_track_dev_impl(h, p, np, idx, feat, vel, y, r_gate, r_update, status_dev, gate_status_dev, chi2_dev, pf_dev, nullptr, 0);
+}
+
+int hv_ekf_visual_track_limited_dev(hv_ekf *h, const hv_vu_params *p, int np, const int *idx, const double *feat, const double *vel,
+                                    const double *y, double r_gate, double r_update, int *status_dev, int *gate_status_dev,
+                                    double *chi2_dev, double *pf_dev, int *success_counter_dev, int max_successful)
+{
+    if (!success_counter_dev || max_successful < 1) return HV_ERR_INVALID;
+    return visual_track_dev_impl(h, p, np, idx, feat, vel, y, r_gate, r_update, status_dev, gate_status_dev, chi2_dev, pf_dev,
+                                 success_counter_dev, max_successful);
+}
+
+static int visual_track_dev_impl(hv_ekf *h, const hv_vu_params *p, int np, const int *idx, const double *feat, const double *vel,
+                                 const double *y, double r_gate, double r_update, int *status_dev, int *gate_status_dev,
+                                 double *chi2_dev, double *pf_dev, int *success_counter_dev, int max_successful)
 {
     if (!h || !status_dev || !gate_status_dev || !y) return HV_ERR_INVALID;
     Ekf *e = &h->e; Ctx *c = e->c;
@@ -1332,6 +1355,7 @@ int hv_ekf_visual_track_dev(hv_ekf *h, const hv_vu_params *p, int np, const int 
     }
     a.H = e->vuH; a.v = e->vuv; a.f = nullptr; a.pf = pf_dev ? pf_dev : e->vupf; a.status = status_dev; a.active = e->vuactive;
     a.gate_status = gate_status_dev;                       // preset to NOT_COMPUTED; the gate overwrites it where it runs
+    a.success_counter = success_counter_dev; a.max_successful = max_successful;
     rc = hv::launch_vu_prepare(c, a);
     if (rc != HV_OK) return rc;
     // visualTrackOutlierCheck with chiOutlierR, then updateVisualTrack with visualR where everything passed
@@ -1339,7 +1363,7 @@ int hv_ekf_visual_track_dev(hv_ekf *h, const hv_vu_params *p, int np, const int 
                                gate_status_dev, e->vuactive);
     if (rc != HV_OK) return rc;
     return hv::ekf_launch_update(e, rows, e->n, e->vuH, e->vuv, nullptr, r_update * r_update * e->noise_scale, 1, 0, 1, nullptr,
-                                 nullptr, e->vuactive, gate_status_dev);
+                                 nullptr, e->vuactive, gate_status_dev, success_counter_dev);
 }
 
 int hv_ekf_visual_track(hv_ekf *h, const hv_vu_params *p, int np, const int *idx, const double *feat, const double *vel,

@@ -101,6 +101,8 @@ struct VuPrepareArgs {
     int *status;                       // [batch][2]: TriangulatorStatus, PrepareVuStatus
     unsigned char *active;             // optional [batch]: 1 where both are OK
     int *gate_status;                  // optional [batch]: preset to VuOutlierStatus::NOT_COMPUTED (1)
+    const int *success_counter;        // optional [batch]: filters that already applied max_successful updates this frame are skipped
+    int max_successful;
 };
 int launch_vu_prepare(Ctx *c, const VuPrepareArgs &a);
 // capi.hip

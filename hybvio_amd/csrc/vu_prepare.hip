@@ -211,6 +211,15 @@ __global__ __launch_bounds__(VT) void vu_prepare_kernel(VuPrepareArgs a)
     double *pfi = s_small, *pfw = s_small + 3, *X = s_small + 6, *step = s_small + 15, *R0T = s_small + 18;
     double *scal = s_small + 36;                 // [0] error2, [1] rcond, [2] Jprev
     VU_STAMP(0);
+    if (a.success_counter && a.success_counter[b] >= a.max_successful) {
+        // backend.cpp:1233-1238: the frame's quota of successful visual updates is used up, the loop does not visit this track
+        if (tid == 0) {
+            a.status[2 * (size_t)b] = HV_TRI_NOT_VISITED; a.status[2 * (size_t)b + 1] = HV_TRI_NOT_VISITED;
+            if (a.active) a.active[b] = 0;
+            if (a.gate_status) a.gate_status[b] = 1;
+        }
+        return;
+    }
     if (tid < n) s_idx[tid] = a.pose_index[(size_t)b * n + tid];
     if (tid < nt) {
 #pragma unroll

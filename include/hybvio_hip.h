@@ -196,7 +196,8 @@ typedef struct hv_vu_params {
 void hv_vu_default_params(hv_vu_params *p);
 /* odometry::TriangulatorStatus (output.hpp:21-29) and PrepareVuStatus (output.hpp:15-19) */
 enum { HV_TRI_OK = 0, HV_TRI_HYBRID = 1, HV_TRI_BEHIND = 2, HV_TRI_BAD_COND = 3, HV_TRI_NO_CONVERGENCE = 4,
-       HV_TRI_BAD_DEPTH = 5, HV_TRI_UNKNOWN_PROBLEM = 6 };
+       HV_TRI_BAD_DEPTH = 5, HV_TRI_UNKNOWN_PROBLEM = 6,
+       HV_TRI_NOT_VISITED = -1 /* not a reference value: the track was not processed (see hv_ekf_visual_track_limited_dev) */ };
 enum { HV_PREPARE_VU_OK = 0, HV_PREPARE_VU_ZERO_DEPTH = 1, HV_PREPARE_VU_BEHIND = 2 };
 /* All arrays in device memory, one track of n_poses poses per filter:
  *   pose_index_dev [batch][n_poses]            poseTrailIndex of the track (ekf_state_index: 0 = current pose)
@@ -219,6 +220,14 @@ int hv_ekf_visual_track_dev(hv_ekf *ekf, const hv_vu_params *p, int n_poses, con
                             const double *features_dev, const double *velocities_dev, const double *y_dev,
                             double r_gate, double r_update, int *status_dev, int *gate_status_dev, double *chi2_dev,
                             double *pf_dev);
+/* The same with the reference's per-frame stopping rule for a BATCH of sequences: success_counter_dev [batch] counts the
+ * visual updates applied to each filter (the caller zeroes it at the start of a frame); a filter whose count has reached
+ * max_successful (odometry.maxSuccessfulVisualUpdates = 5, parameter_definitions.c:10) is not visited any more
+ * (backend.cpp:1233-1238: status {HV_TRI_NOT_VISITED, HV_TRI_NOT_VISITED}, gate NOT_COMPUTED, filter untouched). */
+int hv_ekf_visual_track_limited_dev(hv_ekf *ekf, const hv_vu_params *p, int n_poses, const int *pose_index_dev,
+                                    const double *features_dev, const double *velocities_dev, const double *y_dev,
+                                    double r_gate, double r_update, int *status_dev, int *gate_status_dev, double *chi2_dev,
+                                    double *pf_dev, int *success_counter_dev, int max_successful);
 /* Host-pointer form of hv_ekf_visual_track_dev (arrays [batch][...] as above): about 1 KB per track goes to the device
  * and 40 bytes come back, instead of the mean coming back and a (2 * ncam * n_poses) x stateDim Jacobian going up.
  * chi2 / pf may be NULL. Synchronous. */

@@ -93,7 +93,7 @@ def _quat(axis, angle):
     return np.concatenate([[np.cos(angle / 2)], np.sin(angle / 2) * axis])
 
 
-def _random_tracks(oracle, rng, B, trail_len, npose, stereo, bad_fraction=0.25):
+def _random_tracks(oracle, rng, B, trail_len, npose, stereo, bad_fraction=0.25, given_means=None):
     """B filters on smooth random trajectories, one track each: a world point projected into the chosen poses (plus
     pixel noise), some tracks replaced by nonsense so that every failure status occurs."""
     n = 20 + 7 * trail_len
@@ -104,12 +104,14 @@ def _random_tracks(oracle, rng, B, trail_len, npose, stereo, bad_fraction=0.25):
         m = np.zeros(n)
         base_q = _quat(rng.normal(size=3), rng.uniform(0, 0.4))
         vel_dir = rng.normal(size=3) * 0.15
-        for k in range(trail_len + 1):
+        for k in range(trail_len + 1 if given_means is None else 0):
             ip = POS if k == 0 else CAM + 7 * (k - 1)
             io = ORI if k == 0 else CAM + 7 * (k - 1) + 3
             m[ip:ip + 3] = -vel_dir * k + 0.01 * rng.normal(size=3)
             q = base_q + 0.02 * k * rng.normal(size=4) * 0.2
             m[io:io + 4] = q / np.linalg.norm(q)
+        if given_means is not None:
+            m = given_means[b].copy()
         idx = np.sort(rng.choice(trail_len + 1, npose, replace=False)).astype(np.int32)
         trail = oracle.extract_camera_pose_trail(m, idx, T1, T2 if stereo else None)
         # a point 2..12 m in front of the first camera of the track
@@ -232,4 +234,67 @@ def test_visual_track_dev_prepare_gate_update_equals_the_reference_sequence(orac
                 assert np.array_equal(mg, m0) and np.array_equal(Pg, P0)
                 outcomes.add("gated")
         assert outcomes == {"skipped", "updated", "gated"}, outcomes
+        g.close()
+
+
+def test_frame_loop_with_the_successful_update_quota(oracle):
+    """A frame's visual-update loop for a batch (backend.cpp:1012-1240): K tracks per filter, visited in order, each seeing the
+    mean the previous one left; a filter stops being visited once maxSuccessfulVisualUpdates updates were applied."""
+    import torch
+    rng = np.random.default_rng(23)
+    B, trail_len, npose, K, quota = 12, 20, 6, 9, 3
+    T1, T2, means, _, _, _ = _random_tracks(oracle, rng, B, trail_len, npose, True, bad_fraction=0.0)
+    tracks = [_random_tracks(oracle, rng, B, trail_len, npose, True, bad_fraction=0.3, given_means=means)[3:] for _ in range(K)]
+    ys = [t[1].reshape(B, -1) + 2e-3 * rng.normal(size=(B, t[1].shape[1] * 2)) for t in tracks]
+    for k in (1, 4):
+        ys[k][::3] += 3.0                                                                 # some gate rejections
+    vp = capi.vu_default_params(imu_to_camera=T1, second_imu_to_camera=T2)
+    par = oracle.tri_default_params()
+    r_gate, r_update = 1.5, 0.05
+    with capi.Context(width=64, height=64) as ctx:
+        g = capi.EkfBatch(ctx, capi.ekf_default_params(cameraTrailLength=trail_len), B)
+        filters = []
+        for b in range(B):
+            o = oracle.Ekf(oracle.ekf_default_params(cameraTrailLength=trail_len))
+            P = o.P.copy() * 1e-6 + np.eye(o.n) * 1e-4
+            o.set_state(means[b]); o.set_cov(P)
+            g.set_state(b, means[b], P)
+            filters.append(o)
+        dev = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a, dt)).cuda()
+        counter = torch.zeros((B,), dtype=torch.int32, device="cuda")
+        ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+        got = []
+        for k in range(K):
+            idx, feat, vel = tracks[k]
+            d = [dev(idx, np.int32), dev(feat, np.float64), dev(vel, np.float64), dev(ys[k], np.float64)]
+            st = torch.full((B, 2), -9, dtype=torch.int32, device="cuda"); gs = torch.full((B,), -9, dtype=torch.int32, device="cuda")
+            g.visual_track_limited_dev(vp, npose, d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(), d[3].data_ptr(), r_gate, r_update,
+                                       st.data_ptr(), gs.data_ptr(), counter.data_ptr(), quota)
+            torch.cuda.synchronize()
+            got.append((st.cpu().numpy(), gs.cpu().numpy()))
+        counts = counter.cpu().numpy()
+        reached = 0
+        for b, o in enumerate(filters):
+            done = 0
+            for k in range(K):
+                idx, feat, vel = tracks[k]
+                st, gs = got[k]
+                if done >= quota:
+                    assert st[b].tolist() == [-1, -1] and gs[b] == 1                       # not visited any more
+                    continue
+                ost, ops, opf, oH, of = oracle.visual_track_prepare(par, o.m.copy(), idx[b], T1, T2, feat[b], vel[b])
+                assert st[b].tolist() == [ost, ops], (b, k)
+                if (ost, ops) != (0, 0):
+                    assert gs[b] == 1
+                    continue
+                status, _ = o.visual_track_outlier_check(oH, of, ys[k][b], r_gate)
+                assert gs[b] == status, (b, k)
+                if status == 0:
+                    o.update_visual_track(oH, of, ys[k][b], r_update)
+                    done += 1
+            assert counts[b] == done
+            reached += done >= quota
+            mg, Pg = g.get_state(b)
+            assert _rel(mg, o.m) < 1e-8 and _rel(Pg, o.P) < 1e-7, (b, _rel(mg, o.m), _rel(Pg, o.P))
+        assert 0 < reached <= B
         g.close()
