@@ -527,6 +527,37 @@ def bench_visual_track(ctx, n, local_rank, cpu_baseline):
            "host_bytes_per_track": {"device_path": 4 * npose + 3 * 8 * 4 * npose + 40, "reference_path": 8 * g.n + 8 * rows * g.n + 16 * rows},
            "note": "one workgroup per filter, so a launch costs one track's latency up to 256 filters; f64, the derivative columns "
                    "(7 * poses + 1) x poses pairs per Gauss-Newton iteration dominate (DESIGN.md 3.6)"}
+    # the visual-update loop of one frame (backend.cpp:1012-1240): maxVisualUpdates = 20 track visits in order, each seeing the
+    # mean the previous one left, a filter dropping out after maxSuccessfulVisualUpdates = 5 applied updates; the filters are
+    # put back to their start state before every repetition (device copy, inside the timed region)
+    K, quota = 20, 5
+    more = [synth.visual_tracks(rng, n, trail, npose, True, given_means=means)[3:] for _ in range(K)]
+    d_tracks = [(to(i_, np.int32), to(f_, np.float64), to(rng.normal(size=f_.shape) * 0.1, np.float64),
+                 to(f_.reshape(n, -1) + 1e-3 * rng.normal(size=(n, f_.shape[1] * 2)), np.float64)) for i_, f_ in more]
+    m_ptr, P_ptr = g.device_pointers()
+    nn = g.n
+
+    class _DevView:                                     # zero-copy torch view of the library's device buffers
+        def __init__(self, ptr, shape):
+            self.__cuda_array_interface__ = {"shape": shape, "typestr": "<f8", "data": (ptr, False), "version": 2}
+    m_view = torch.as_tensor(_DevView(m_ptr, (n, nn)), device=dev); P_view = torch.as_tensor(_DevView(P_ptr, (n, nn, nn)), device=dev)
+    m0, P0 = m_view.clone(), P_view.clone()
+    counter = torch.zeros((n,), dtype=torch.int32, device=dev)
+
+    def frame_loop():
+        m_view.copy_(m0); P_view.copy_(P0)
+        counter.zero_()
+        for di, df, dv, dy in d_tracks:
+            g.visual_track_limited_dev(vp, npose, di.data_ptr(), df.data_ptr(), dv.data_ptr(), dy.data_ptr(), 1.5, 0.05, st.data_ptr(),
+                                       gs.data_ptr(), counter.data_ptr(), quota)
+    frame_loop(); torch.cuda.synchronize()
+    e0.record()
+    for _ in range(5):
+        frame_loop()
+    e1.record(); torch.cuda.synchronize()
+    loop_ms = e0.elapsed_time(e1) / 5
+    res["frame_loop"] = {"workload": f"{K} track visits per filter in order, quota {quota} applied updates, {n} filters, state restored per repetition",
+                         "ms_per_frame_loop": loop_ms, "frames_per_s": n / (loop_ms * 1e-3), "applied_updates_per_filter": float(counter.float().mean().item())}
     g.close()
     if cpu_baseline:
         from oracle import orc
