@@ -317,9 +317,9 @@ def test_reference_transform_to_round_trip_on_gpu(oracle, ctx):
     assert np.linalg.norm(m2 - fx["m55"]) < 1e-3 and np.linalg.norm(P2 - fx["P55"]) < 1e-3
 
 
-@pytest.mark.parametrize("frames", [60, 400])
+@pytest.mark.parametrize("frames", [60, 400, 2000])
 def test_closed_loop_replay(oracle, ctx, frames):
-    """60 / 400 frames of the per-frame EKF call sequence: 10 predicts, up to 8 gated
+    """60 / 400 / 2000 (the length SURVEY.md 8(d) names) frames of the per-frame EKF call sequence: 10 predicts, up to 8 gated
     visual updates, symmetrise, augmentation with the Hanoi discard pattern; same inputs to both.
     Visual updates start once every trail slot has been cloned from a real pose (as in the reference,
     where a track needs >= 4 frames): before that P mixes 1e8 prior variances with 1e-6 ones and the
