@@ -106,6 +106,7 @@ PROTOTYPES = {
     "hv_ekf_visual_update": (C.c_int, [C.c_void_p, C.c_int, C.c_int, f64p, f64p, C.c_double, u8p]),
     "hv_camera_model_init": (C.c_int, [C.c_void_p]),
     "hv_rot_ransac": (C.c_int, [C.c_void_p, C.c_int] + [C.c_void_p] * 5 + [C.c_float] + [C.c_void_p] * 4),
+    "hv_rot_ransac_lk_batch_dev": (C.c_int, [C.c_void_p, C.c_int, C.c_int] + [C.c_void_p] * 4 + [C.c_int] + [C.c_void_p] * 3 + [C.c_float] + [C.c_void_p] * 3),
     "hv_rot_ransac_batch_dev": (C.c_int, [C.c_void_p, C.c_int, C.c_int] + [C.c_void_p] * 6 + [C.c_float] + [C.c_void_p] * 3),
     "hv_vu_default_params": (None, [C.c_void_p]),
     "hv_ekf_visual_prepare_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int] + [C.c_void_p] * 10),
@@ -244,6 +245,14 @@ class Context:
         self._chk(lib().hv_rot_ransac_batch_dev(self._h, n_sets, max_points, p(n_points_dev), p(c1_dev), p(c2_dev), C.byref(cam1),
                                                 C.byref(cam2), p(pairs_dev), float(threshold_pow2), p(status_dev), p(R_dev),
                                                 p(summary_dev)), "hv_rot_ransac_batch_dev")
+
+    def rot_ransac_lk_batch_dev(self, n_sets, max_points, n_points_dev, c1_dev, c2_dev, lk_status_dev, lk_tracked_value, cam1, cam2,
+                                draws_dev, threshold_pow2, status_dev, R_dev, summary_dev):
+        p = lambda x: C.c_void_p(x)
+        self._chk(lib().hv_rot_ransac_lk_batch_dev(self._h, n_sets, max_points, p(n_points_dev), p(c1_dev), p(c2_dev), p(lk_status_dev),
+                                                   int(lk_tracked_value), C.byref(cam1), C.byref(cam2), p(draws_dev),
+                                                   float(threshold_pow2), p(status_dev), p(R_dev), p(summary_dev)),
+                  "hv_rot_ransac_lk_batch_dev")
 
     # ---- image ingest (f2): colour -> gray and the undistort / rectify remap in front of the pyramid ----
     def ingest_set_undistort_map(self, camera: int, pix_orig=None, valid=None):

@@ -27,7 +27,10 @@ struct RansacArgs {
     int max_points;
     const int *n_points;              // [sets]
     const float *c1, *c2;             // [sets][max_points][2]
-    const int *pairs;                 // [sets][HYP][2]
+    const int *pairs;                 // [sets][HYP][2], or NULL when draws is given
+    const uint32_t *draws;            // [sets][2 HYP] raw generator outputs: pair k = (draws[2k] % n, draws[2k+1] % n)
+    const uint8_t *lk_status;         // optional [sets][max_points]: only features with lk_status == lk_tracked take part
+    int lk_tracked;                   // (c1 / c2 / status are then indexed by the ORIGINAL feature number)
     float threshold_pow2;
     int *status;                      // [sets][max_points]: 0 TRACKED / 3 RANSAC_OUTLIER
     float *R;                         // [sets][9]
@@ -260,10 +263,41 @@ __global__ __launch_bounds__(RT) void rot_ransac_kernel(RansacArgs a)
     __shared__ unsigned char s_in[MAX_PTS];
     __shared__ float s_Rb[9];
     __shared__ int s_best[4];
+    __shared__ unsigned short s_map[MAX_PTS];     // compacted index -> original feature number
+    __shared__ int s_chunk[MAX_PTS / 64 + 1];
     const int set = blockIdx.x, tid = threadIdx.x;
-    const int n = a.n_points[set];
+    const int n_all = a.n_points[set];
     const float *c1 = a.c1 + (size_t)set * a.max_points * 2, *c2 = a.c2 + (size_t)set * a.max_points * 2;
     int *status = a.status + (size_t)set * a.max_points;
+    // ---- "Pick the left camera features for which track was found" (ransac_pipeline.cpp:106-112), in feature order:
+    // 64-feature chunks counted with a ballot, chunk offsets by a short serial scan ----
+    int n = n_all;
+    if (a.lk_status) {
+        const uint8_t *ls = a.lk_status + (size_t)set * a.max_points;
+        const int nchunk = (n_all + 63) / 64, wave = tid >> 6, lane = tid & 63;
+        for (int ch = wave; ch < nchunk; ch += RT / 64) {
+            const int i = ch * 64 + lane;
+            const unsigned long long m = __ballot(i < n_all && ls[i] == a.lk_tracked);
+            if (lane == 0) s_chunk[ch] = __popcll(m);
+        }
+        __syncthreads();
+        if (tid == 0) {
+            int acc = 0;
+            for (int ch = 0; ch < nchunk; ++ch) { const int cnt = s_chunk[ch]; s_chunk[ch] = acc; acc += cnt; }
+            s_chunk[nchunk] = acc;
+        }
+        __syncthreads();
+        n = s_chunk[nchunk];
+        for (int ch = wave; ch < nchunk; ch += RT / 64) {
+            const int i = ch * 64 + lane;
+            const bool on = i < n_all && ls[i] == a.lk_tracked;
+            const unsigned long long m = __ballot(on);
+            if (on) s_map[s_chunk[ch] + __popcll(m & ((1ull << lane) - 1ull))] = (unsigned short)i;
+        }
+    } else {
+        for (int i = tid; i < n_all; i += RT) s_map[i] = (unsigned short)i;
+    }
+    __syncthreads();
     if (n < 2) {                                                             // ransac_pipeline.cpp:209: nothing to fit
         if (tid == 0) { a.summary[2 * set] = 0; a.summary[2 * set + 1] = 0; }
         return;
@@ -271,18 +305,25 @@ __global__ __launch_bounds__(RT) void rot_ransac_kernel(RansacArgs a)
     const double thr = (double)a.threshold_pow2;
     // ---- rays of both frames (rot_ransac.cpp:63-66; pixelToRay's success is not checked there either) ----
     for (int i = tid; i < n; i += RT) {
+        const int src = s_map[i];
         double r[3];
-        pixel_to_ray(a.cam1, (double)c1[2 * i], (double)c1[2 * i + 1], r);
+        pixel_to_ray(a.cam1, (double)c1[2 * src], (double)c1[2 * src + 1], r);
         s_p1[3 * i] = (float)r[0]; s_p1[3 * i + 1] = (float)r[1]; s_p1[3 * i + 2] = (float)r[2];
-        pixel_to_ray(a.cam2, (double)c2[2 * i], (double)c2[2 * i + 1], r);
+        pixel_to_ray(a.cam2, (double)c2[2 * src], (double)c2[2 * src + 1], r);
         s_p2[3 * i] = (float)r[0]; s_p2[3 * i + 1] = (float)r[1]; s_p2[3 * i + 2] = (float)r[2];
-        s_c2[2 * i] = c2[2 * i]; s_c2[2 * i + 1] = c2[2 * i + 1];
+        s_c2[2 * i] = c2[2 * src]; s_c2[2 * i + 1] = c2[2 * src + 1];
     }
     if (tid < HYP) s_count[tid] = 0;
     __syncthreads();
     // ---- hypothesis k: the rotation of its two pairs (:80-87) ----
     if (tid < HYP) {
-        const int i1 = a.pairs[((size_t)set * HYP + tid) * 2], i2 = a.pairs[((size_t)set * HYP + tid) * 2 + 1];
+        int i1, i2;
+        if (a.draws) {                                                       // rng() % n (rot_ransac.cpp:82-83), n known only here
+            i1 = (int)(a.draws[((size_t)set * HYP + tid) * 2] % (uint32_t)n);
+            i2 = (int)(a.draws[((size_t)set * HYP + tid) * 2 + 1] % (uint32_t)n);
+        } else {
+            i1 = a.pairs[((size_t)set * HYP + tid) * 2]; i2 = a.pairs[((size_t)set * HYP + tid) * 2 + 1];
+        }
         const int ok = i1 != i2;
         s_valid[tid] = ok;
         if (ok) {
@@ -357,7 +398,7 @@ __global__ __launch_bounds__(RT) void rot_ransac_kernel(RansacArgs a)
     }
     __syncthreads();
     // ---- final classification (:120-130) ----
-    for (int i = tid; i < n; i += RT) status[i] = inlier(s_Rb, s_p1 + 3 * i, s_c2[2 * i], s_c2[2 * i + 1], a.cam2, thr) ? 0 : 3;
+    for (int i = tid; i < n; i += RT) status[s_map[i]] = inlier(s_Rb, s_p1 + 3 * i, s_c2[2 * i], s_c2[2 * i + 1], a.cam2, thr) ? 0 : 3;
     if (tid < 9) a.R[9 * (size_t)set + tid] = s_Rb[tid];
 }
 
@@ -432,6 +473,27 @@ int hv_rot_ransac_batch_dev(hv_ctx *h, int n_sets, int max_points, const int *n_
     if (n_sets == 0) return HV_OK;
     hv::RansacArgs a{};
     a.max_points = max_points; a.n_points = n_points_dev; a.c1 = c1_dev; a.c2 = c2_dev; a.pairs = pairs_dev;
+    a.threshold_pow2 = threshold_pow2; a.status = status_dev; a.R = R_dev; a.summary = summary_dev;
+    a.cam1 = *cam1; a.cam2 = *cam2;
+    hv::ScopedKernelTime tm(c, HV_K_ROT_RANSAC);
+    hipLaunchKernelGGL(hv::rot_ransac_kernel, dim3((unsigned)n_sets), dim3(hv::RT), 0, c->stream, a);
+    HV_HIP(c, hipGetLastError());
+    return HV_OK;
+}
+
+int hv_rot_ransac_lk_batch_dev(hv_ctx *h, int n_sets, int max_points, const int *n_points_dev, const float *c1_dev, const float *c2_dev,
+                               const uint8_t *lk_status_dev, int lk_tracked_value, const hv_camera_model *cam1,
+                               const hv_camera_model *cam2, const uint32_t *draws_dev, float threshold_pow2, int *status_dev,
+                               float *R_dev, int *summary_dev)
+{
+    Ctx *c = hv::ctx_of(h);
+    if (!c || n_sets < 0 || max_points < 2 || max_points > hv::MAX_PTS || !cam1 || !cam2) return HV_ERR_INVALID;
+    if (n_sets > 0 && (!n_points_dev || !c1_dev || !c2_dev || !lk_status_dev || !draws_dev || !status_dev || !R_dev || !summary_dev))
+        return HV_ERR_INVALID;
+    if (n_sets == 0) return HV_OK;
+    hv::RansacArgs a{};
+    a.max_points = max_points; a.n_points = n_points_dev; a.c1 = c1_dev; a.c2 = c2_dev; a.draws = draws_dev;
+    a.lk_status = lk_status_dev; a.lk_tracked = lk_tracked_value;
     a.threshold_pow2 = threshold_pow2; a.status = status_dev; a.R = R_dev; a.summary = summary_dev;
     a.cam1 = *cam1; a.cam2 = *cam2;
     hv::ScopedKernelTime tm(c, HV_K_ROT_RANSAC);

@@ -331,6 +331,17 @@ int hv_rot_ransac_batch_dev(hv_ctx *ctx, int n_sets, int max_points, const int *
                             const float *c2_dev, const hv_camera_model *camera1, const hv_camera_model *camera2,
                             const int *pairs_dev, float threshold_pow2, int *status_dev, float *R_dev, int *summary_dev);
 
+/* The same fed straight from the LK outputs of hv_klt_track_batch_dev, nothing passing through the host: set s = the
+ * n_points_dev[s] features of pair s (prev_xy / next_xy / status of the LK call, max_points = pts_per_pair); only features
+ * whose lk_status equals lk_tracked_value (1 for hv_klt_track_batch_dev) take part, in feature order -- the c1 / c2 of
+ * ransac_pipeline.cpp:106-112. draws_dev [n_sets][200] = the next 200 raw outputs of each set's std::mt19937; the kernel
+ * forms rng() % n itself because n is only known on the device. status_dev [n_sets][max_points] is written at the ORIGINAL
+ * feature numbers (0 / 3), other entries stay; summary_dev as above. Asynchronous. */
+int hv_rot_ransac_lk_batch_dev(hv_ctx *ctx, int n_sets, int max_points, const int *n_points_dev, const float *c1_dev,
+                               const float *c2_dev, const uint8_t *lk_status_dev, int lk_tracked_value,
+                               const hv_camera_model *camera1, const hv_camera_model *camera2, const uint32_t *draws_dev,
+                               float threshold_pow2, int *status_dev, float *R_dev, int *summary_dev);
+
 /* ---- per-kernel timing (hipEvents on the context stream) ---------------------------------- */
 enum { HV_K_PYR_L0 = 0, HV_K_PYR_LN = 1, HV_K_KLT = 2, HV_K_EKF_PREDICT = 3, HV_K_EKF_UPDATE = 4,
        HV_K_EKF_AUGMENT = 5, HV_K_GFTT = 6, HV_K_INGEST = 7, HV_K_VU_PREPARE = 8, HV_K_ROT_RANSAC = 9, HV_K_COUNT = 10 };

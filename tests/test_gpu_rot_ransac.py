@@ -151,3 +151,47 @@ def test_batch_dev_ragged_sets(oracle):
         assert np.array_equal(st[s, :n], st_o) and (st[s, n:] == -5).all()
         assert summ[s].tolist() == [best_o, used_o // 2]
         assert np.array_equal(R[s].view(np.uint32), R_o.reshape(-1).view(np.uint32))
+
+
+def test_lk_output_feeds_ransac_on_the_device(oracle):
+    """LK -> RANSAC without the host in between (ransac_pipeline.cpp:106-119): the batched tracker's device outputs go
+    straight into hv_rot_ransac_lk_batch_dev, which keeps the TRACKED features in order, forms rng() % n itself and writes
+    the statuses back at the original feature numbers. Must equal oracle LK -> host compaction -> oracle RANSAC."""
+    import torch
+    from hybvio_amd import synth
+    w, h, npts, S = 376, 240, 120, 3
+    cam_args = ("pinhole", 229.3, 228.6, 183.6, 124.2)
+    ocam, gcam = oracle.Camera(*cam_args, coeffs=RADIAL), capi.camera_model(*cam_args, coeffs=RADIAL)
+    thr = float(np.float32((4.0 * min(w, h) / 720.0) ** 2))
+    seqs = [synth.stereo_sequence(40 + s, w, h, 2)[0] for s in range(S)]
+    rng = np.random.default_rng(6)
+    pts = np.stack([np.concatenate([synth.grid_points(w, h, npts - 12, margin=12, seed=s),
+                                    rng.uniform([-15, -15], [w + 15, h + 15], (6, 2)).astype(np.float32),
+                                    rng.uniform([-70, -70], [-50, -50], (6, 2)).astype(np.float32)])[rng.permutation(npts)] for s in range(S)])   # 6 far outside: lost
+    draws = np.stack([oracle.mt19937_draws(4649 + s, 200) for s in range(S)])
+    with capi.Context(width=w, height=h, pool_size=2 * S, max_tracks=npts) as ctx:
+        prev = [ctx.acquire() for _ in range(S)]; cur = [ctx.acquire() for _ in range(S)]
+        for s in range(S):
+            ctx.build(prev[s], seqs[s][0]); ctx.build(cur[s], seqs[s][1])
+        dev = lambda x, dt: torch.from_numpy(np.ascontiguousarray(x, dt)).cuda()
+        d_prev, d_cur, d_pts = dev(prev, np.int32), dev(cur, np.int32), dev(pts, np.float32)
+        d_next = torch.zeros_like(d_pts); d_lk = torch.zeros((S, npts), dtype=torch.uint8, device="cuda")
+        ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+        ctx.klt_track_batch_dev(S, d_prev.data_ptr(), d_cur.data_ptr(), npts, d_pts.data_ptr(), d_next.data_ptr(), d_lk.data_ptr(), 0, use_initial_flow=False)
+        d_n, d_draws = dev(np.full(S, npts, np.int32), np.int32), dev(draws, np.uint32)
+        st = torch.full((S, npts), -7, dtype=torch.int32, device="cuda")
+        R = torch.zeros((S, 9), dtype=torch.float32, device="cuda"); summ = torch.zeros((S, 2), dtype=torch.int32, device="cuda")
+        ctx.rot_ransac_lk_batch_dev(S, npts, d_n.data_ptr(), d_pts.data_ptr(), d_next.data_ptr(), d_lk.data_ptr(), 1, gcam, gcam,
+                                    d_draws.data_ptr(), thr, st.data_ptr(), R.data_ptr(), summ.data_ptr())
+        torch.cuda.synchronize()
+        st, R, summ, lk = st.cpu().numpy(), R.cpu().numpy(), summ.cpu().numpy(), d_lk.cpu().numpy()
+        nxt = d_next.cpu().numpy()
+    for s in range(S):
+        oxy, ost, _ = oracle.klt_track(oracle.Pyramid(seqs[s][0]), oracle.Pyramid(seqs[s][1]), pts[s])
+        assert np.array_equal(lk[s], ost) and 20 < ost.sum() < npts                    # some features are lost: compaction matters
+        keep = np.nonzero(ost == 1)[0]
+        assert np.abs(nxt[s][keep] - oxy[keep]).max() <= 1e-3
+        # the RANSAC input is the DEVICE LK output (positions equal the oracle's to 1e-3 px; use the device's own bits)
+        st_o, R_o, best_o, used_o = oracle.rot_ransac_fit(pts[s][keep], nxt[s][keep], ocam, ocam, draws[s], thr)
+        assert np.array_equal(st[s][keep], st_o) and (st[s][ost == 0] == -7).all()
+        assert summ[s].tolist() == [best_o, used_o // 2] and np.array_equal(R[s].view(np.uint32), R_o.reshape(-1).view(np.uint32))
