@@ -17,7 +17,7 @@ for C in "FETCH_SIZE" "WRITE_SIZE" \
          "GRBM_GUI_ACTIVE"; do
   i=$((i+1))
   rocprofv3 --pmc $C --output-format csv -d /tmp/pf_pmc$i -o p -- $B > /tmp/pf_pmc$i.log 2>&1
-  python $R/scripts/pmc_summary.py /tmp/pf_pmc$i | grep -E "^kernel|klt_kernel|pyr_level|ekf_|gftt_|ingest_|remap_tile|vu_prepare" > $OUT/pmc$i.csv
+  python $R/scripts/pmc_summary.py /tmp/pf_pmc$i | grep -E "^kernel|klt_kernel|pyr_level|ekf_|gftt_|ingest_|remap_tile|vu_prepare|rot_ransac" > $OUT/pmc$i.csv
 done
 tail -1 $OUT/bench_under_kernel_trace.log | cut -c1-400
 ls -la $OUT
