@@ -699,6 +699,10 @@ def main():
     # ---- f3: per-track triangulation + prepareVisualUpdate from the device mean, fused with gate + update ----
     if not args.no_visual_track and rank == 0:
         out["f3_visual_track"] = bench_visual_track(tb.ctx, min(B, 256), local_rank, not args.no_cpu_baseline)
+        one = bench_visual_track(tb.ctx, 1, local_rank, False)
+        out["f3_visual_track"]["single_sequence"] = {"prepare_ms": one["prepare_avg_ms"], "fused_prepare_gate_update_ms": one["fused_prepare_gate_update_avg_ms"],
+                                                     "frame_loop_ms": one["frame_loop"]["ms_per_frame_loop"],
+                                                     "note": "what one `main` process pays per frame for its 20 track visits (quota 5)"}
     # ---- f4: 2-point rotation RANSAC on the tracked features of every sequence ----
     if not args.no_ransac and rank == 0:
         out["f4_rot_ransac"] = bench_rot_ransac(tb.ctx, min(B, 1024), local_rank, not args.no_cpu_baseline)
