@@ -412,6 +412,7 @@ struct UpdateArgs {
     const double *H, *v;              // per filter: nr*l column-major, nr
     const double *rdiag;              // per filter diagonal of R (already scaled), or null -> rd0
     double rd0, noise_scale;
+    double rd1;                       // mode 3 only: R of the update (rd0 is then the R of the gate)
     double *ws;                       // per filter R*nr doubles (used when the tall matrix exceeds LDS)
     double *chi2; int *status;        // optional outputs
     const unsigned char *active;      // optional per-filter enable
@@ -459,7 +460,11 @@ __global__ __launch_bounds__(UPD_THREADS) void ekf_update_kernel(UpdateArgs a)
     constexpr int nrp = 16 * (TI > 0 ? TI : 1);
     const bool gate_only = a.mode == 0;
     const int rv = nr, ry = nr + 1;
-    const int Rlim = gate_only ? nr + 1 : a.R;
+    // mode 3 (MODE 2 kernels only): visualTrackOutlierCheck with R = rd0, then -- where it passes -- updateVisualTrack with
+    // R = rd1 on the SAME H P: S (without R) and v are parked in the H staging area after phase B, the gate runs the
+    // Cholesky on the measurement rows only, and an inlier restores S + rd1 I and v and runs the full factorisation.
+    const bool two_r = MODE == 2 && a.mode == 3;
+    int Rlim = (gate_only || two_r) ? nr + 1 : a.R;
 
     PHASE_STAMP(0);
     const int kq = lane >> 4, cl = lane & 15;      // MFMA lane coordinates: k sub-step / output row group, column
@@ -653,8 +658,16 @@ __global__ __launch_bounds__(UPD_THREADS) void ekf_update_kernel(UpdateArgs a)
         }
     }
     __syncthreads();
+    if constexpr (MODE == 2) {
+        if (two_r) {                                          // Hs is dead after phase B: (nr + 1) x nr doubles fit (nrp x 16 lb >= that)
+            // (+ 256: factor_diag_block's branch-free dump stores run up to col[527], i.e. into the first ~200 doubles of Hs)
+            for (int e = t; e < (nr + 1) * nr; e += UPD_THREADS) { const int c = e / (nr + 1), i = e - c * (nr + 1); Hs[256 + e] = T[(size_t)c * R + i]; }
+            __syncthreads();
+        }
+    }
 
     PHASE_STAMP(2);
+    for (int pass = 0; pass < (two_r ? 2 : 1); ++pass) {
     // ---- C: blocked left-looking Cholesky of the tall matrix, 16 columns per block, 3 barriers per
     // block (a column-at-a-time version needs one barrier + one LDS round trip + one rsqrt per COLUMN
     // on the critical path of all 16 waves: 1.3-1.7 k cycles per column measured). Per block j:
@@ -709,13 +722,27 @@ __global__ __launch_bounds__(UPD_THREADS) void ekf_update_kernel(UpdateArgs a)
             double tot = 0; for (int w2 = 0; w2 < nwaves; w2++) tot += red[w2];
             tot *= a.noise_scale;
             const int outlier = (nr < HV_CHI2INV95_N) ? (tot > d_chi2inv95[nr]) : 0;
-            if (a.chi2) a.chi2[b] = tot;
-            if (a.status) a.status[b] = outlier ? 3 /*CHI2*/ : 0 /*INLIER*/;
-            *s_stop = (a.mode == 0) || (a.mode == 2 && outlier);
+            if (pass == 0) {
+                if (a.chi2) a.chi2[b] = tot;
+                if (a.status) a.status[b] = outlier ? 3 /*CHI2*/ : 0 /*INLIER*/;
+            }
+            *s_stop = (a.mode == 0) || ((a.mode == 2 || (two_r && pass == 0)) && outlier);
         }
         __syncthreads();
         if (*s_stop) return;
     }
+    if constexpr (MODE == 2) {
+        if (two_r && pass == 0) {                             // inlier: S + rd1 I and v back, then the full factorisation
+            const double shift = a.rd1 - rd;
+            for (int e = t; e < (nr + 1) * nr; e += UPD_THREADS) {
+                const int c = e / (nr + 1), i = e - c * (nr + 1);
+                T[(size_t)c * R + i] = Hs[256 + e] + (i == c ? shift : 0.0);
+            }
+            Rlim = a.R;
+            __syncthreads();
+        }
+    }
+    }   // pass
 
     PHASE_STAMP(4);
     // ---- E: m += Y' z ----
@@ -1135,7 +1162,7 @@ struct Ekf {
 static int ekf_launch_update(Ekf *e, int nr, int l, const double *H_dev, const double *v_dev, const double *rdiag_dev,
                              double rd0, int mode, int generic, int normalize_all, double *chi2_dev, int *status_dev,
                              const unsigned char *active_dev, const int *require_inlier_dev = nullptr,
-                             int *success_counter_dev = nullptr)
+                             int *success_counter_dev = nullptr, double rd1 = 0.0, bool *two_r_done = nullptr)
 {
     Ctx *c = e->c;
     if (nr < 1 || nr > e->max_rows || l < 1 || l > e->n) return HV_ERR_INVALID;
@@ -1148,7 +1175,7 @@ static int ekf_launch_update(Ekf *e, int nr, int l, const double *H_dev, const d
     while ((r_pad & 31) != 15 && (r_pad & 31) != 17) r_pad++;
     a.Rs = r_pad;
     a.mode = mode; a.generic = generic; a.normalize_all = normalize_all; a.map_dim = e->map_dim;
-    a.m = e->m; a.P = e->P; a.H = H_dev; a.v = v_dev; a.rdiag = rdiag_dev; a.rd0 = rd0; a.noise_scale = e->noise_scale;
+    a.m = e->m; a.P = e->P; a.H = H_dev; a.v = v_dev; a.rdiag = rdiag_dev; a.rd0 = rd0; a.rd1 = rd1; a.noise_scale = e->noise_scale;
     a.ws = e->ws; a.chi2 = chi2_dev; a.status = status_dev; a.active = active_dev; a.require_inlier = require_inlier_dev; a.success_counter = success_counter_dev;
     size_t tall = (((size_t)a.Rs * nr + 1) & ~(size_t)1) * sizeof(double);
     const size_t small = (size_t)(576 + UPD_THREADS / 64 + 2) * sizeof(double);                 // W + col + red + flag
@@ -1158,6 +1185,11 @@ static int ekf_launch_update(Ekf *e, int nr, int l, const double *H_dev, const d
     a.use_lds = tall + small <= lds_cap;
     if (!a.use_lds) { a.Rs = a.R; tall = (((size_t)a.R * nr + 1) & ~(size_t)1) * sizeof(double); }   // global workspace: no padding
     const int kmode = !a.use_lds ? 0 : (e->n <= 160 && nr <= 48 && tall + small + hbytes <= lds_cap) ? 2 : 1;
+    if (mode == 3) {                                     // gate (rd0) + update (rd1) in one launch: MODE 2 kernels only
+        const bool can = kmode == 2 && ((size_t)(nr + 1) * nr + 256) * sizeof(double) <= hbytes;
+        if (two_r_done) *two_r_done = can;
+        if (!can) return HV_OK;                          // the caller falls back to two launches
+    }
     const size_t shmem = kmode == 2 ? tall + small + hbytes : kmode == 1 ? tall + small : small;
     using Kern = void (*)(UpdateArgs);
     const Kern kern = kmode == 0 ? (Kern)ekf_update_kernel<0, 0> : kmode == 1 ? (Kern)ekf_update_kernel<1, 0>
@@ -1358,7 +1390,12 @@ static int visual_track_dev_impl(hv_ekf *h, const hv_vu_params *p, int np, const
     a.success_counter = success_counter_dev; a.max_successful = max_successful;
     rc = hv::launch_vu_prepare(c, a);
     if (rc != HV_OK) return rc;
-    // visualTrackOutlierCheck with chiOutlierR, then updateVisualTrack with visualR where everything passed
+    // visualTrackOutlierCheck with chiOutlierR, then updateVisualTrack with visualR where everything passed: one launch when
+    // the shape runs on the register-resident kernel (mode 3), otherwise a gate launch and an update launch
+    bool fused = false;
+    rc = hv::ekf_launch_update(e, rows, e->n, e->vuH, e->vuv, nullptr, r_gate * r_gate * e->noise_scale, 3, 0, 1, chi2_dev,
+                               gate_status_dev, e->vuactive, nullptr, success_counter_dev, r_update * r_update * e->noise_scale, &fused);
+    if (rc != HV_OK || fused) return rc;
     rc = hv::ekf_launch_update(e, rows, e->n, e->vuH, e->vuv, nullptr, r_gate * r_gate * e->noise_scale, 0, 0, 0, chi2_dev,
                                gate_status_dev, e->vuactive);
     if (rc != HV_OK) return rc;
