@@ -4,8 +4,10 @@
  * TEST INFRASTRUCTURE ONLY. Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load
  * this file; the product path (hybvio_amd/csrc, hybvio_amd/host) never does.
  *
- * PARITY UNPINNED: the reference has no test or golden vector for this stage, and its own build cannot be
- * compiled here (OpenCV, Eigen and accelerated-arrays are absent: SURVEY.md 8(c)). What is restated:
+ * PARITY UNPINNED for the image operations: the reference has no test or golden vector for the remap or the gray copy,
+ * and its own build cannot be compiled here (OpenCV, Eigen and accelerated-arrays are absent: SURVEY.md 8(c)). The CAMERA
+ * MODELS are pinned by the reference's own tests (test/camera.cpp:7-168: the Matlab pinhole projection, the distorted
+ * pinhole ray <-> pixel pair, the fisheye cases), re-expressed in tests/test_oracle_ingest.py. What is restated:
  *
  *   remap            src/tracker/undistorter.cpp:71-110   the CPU branch of UndistorterImplementation::undistort
  *                    (per rectified pixel: pixelToRay of the rectified camera, rayToPixel of the original camera,

@@ -137,3 +137,37 @@ def test_golden_fixture(oracle):
     gray = oracle.color_to_gray(gold["rgb"])
     assert np.array_equal(gray, gold["gray"])
     assert np.array_equal(oracle.undistort_apply(gray, pix, valid), gold["rectified"])
+
+
+# ---- the camera models are pinned by the reference's own tests (test/camera.cpp), values copied from there ----
+@pytest.mark.parametrize("distorted", [False, True])
+def test_reference_fisheye_camera_case(oracle, distorted):
+    """test/camera.cpp:7-81 "fisheye camera" (coefficients "from a RealSense camera")."""
+    coeff = [-0.00200599804520607, 0.03895416110754013, -0.03715667128562927, 0.0061612860299646854] if distorted else []
+    cam = oracle.Camera("fisheye", 10, 11, 5, 5.5, coeffs=coeff)
+    ok, axis = cam.pixel_to_ray(5, 5.5)
+    assert np.linalg.norm(axis[:2]) < 1e-6 and abs(axis[2] - 1) < 1e-6
+    v = np.array([1.0, -2.0, 3.0])
+    ok, p = cam.ray_to_pixel(v)
+    assert ok and p[0] > 5 and p[1] < 5.5
+    assert cam.pixel_to_ray(*p)[0] and not cam.pixel_to_ray(1000, 10000)[0]               # isValidPixel (camera.cpp:400-403)
+    ok, proj = cam.pixel_to_ray(*p)
+    assert abs(v[2] / np.linalg.norm(v) - proj[2]) < 1e-6
+
+
+def test_reference_pinhole_matlab_projection(oracle):
+    """test/camera.cpp:83-114: ip = (235, 695) "given by our matlab function"."""
+    cam = oracle.Camera("pinhole", 1000, 1000, 360, 640)
+    ok, ip = cam.ray_to_pixel([-0.25, 0.11, 2])
+    assert ok and np.abs(ip - [235, 695]).sum() < 1e-5
+
+
+def test_reference_distorted_pinhole_case(oracle):
+    """test/camera.cpp:116-168: ray0 <-> pixel0 through k1 k2 k3, both directions."""
+    cam = oracle.Camera("pinhole", 1.31841527e+03, 1.31745365e+03, 9.49043714e+02, 5.31894317e+02,
+                        coeffs=[0.20740335, -0.28361953, -0.10090323])
+    ray0, pixel0 = np.array([0.26726124, 0.53452248, 0.80178373]), np.array([1393.07961912, 1419.31839027])
+    ok, pixelp = cam.ray_to_pixel(ray0)
+    ok2, rayp = cam.pixel_to_ray(*pixel0)
+    assert ok and ok2
+    assert np.abs(pixelp - pixel0).sum() < 1e-3 and np.abs(rayp - ray0).sum() < 1e-4
