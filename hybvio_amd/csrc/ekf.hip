@@ -366,7 +366,7 @@ __device__ __forceinline__ void factor_diag_block(double *T, double *W, double *
     // step k+1 has been issued: a wavefront issues in order, so a wait for the LDS round trip in
     // step k would stall the chain behind it.
     double mprev[NW], lprev = 0.0;
-    double *col_dst = lane < 16 ? col + r : col + 256 + lane;   // col[256 .. 319]: dump area (an exec-masked store makes
+    double *col_dst = lane < 16 ? col + r : col + 256 + lane;   // col[256 .. 527]: dump area (an exec-masked store makes
                                                                   // hipcc wait for the store itself before the next use of LDS data)
 #pragma unroll
     for (int k = 0; k < NW; k++) {
@@ -454,7 +454,7 @@ __global__ __launch_bounds__(UPD_THREADS) void ekf_update_kernel(UpdateArgs a)
     double *T = USE_LDS ? smem : a.ws + (size_t)b * R * nr;
     double *W = USE_LDS ? smem + (((size_t)R * nr + 1) & ~(size_t)1) : smem;   // inverse of the current diagonal block
     double *col = W + 256;                                                      // column broadcast buffer of the diagonal factor
-    double *red = col + 320;
+    double *red = col + 544;                                                    // col[256 .. 527] is the dump area of factor_diag_block's branch-free stores
     int *s_stop = reinterpret_cast<int *>(red + nwaves);
     double *Hs = red + nwaves + 2;                // MODE 2: H zero-padded to (16 TI) x (16 lb), column-major, stride nrp
     constexpr int nrp = 16 * (TI > 0 ? TI : 1);
@@ -660,7 +660,7 @@ __global__ __launch_bounds__(UPD_THREADS) void ekf_update_kernel(UpdateArgs a)
     __syncthreads();
     if constexpr (MODE == 2) {
         if (two_r) {                                          // Hs is dead after phase B: (nr + 1) x nr doubles fit (nrp x 16 lb >= that)
-            // (+ 256: factor_diag_block's branch-free dump stores run up to col[527], i.e. into the first ~200 doubles of Hs)
+            // (+ 256: slack after the header area)
             for (int e = t; e < (nr + 1) * nr; e += UPD_THREADS) { const int c = e / (nr + 1), i = e - c * (nr + 1); Hs[256 + e] = T[(size_t)c * R + i]; }
             __syncthreads();
         }
@@ -1178,7 +1178,7 @@ static int ekf_launch_update(Ekf *e, int nr, int l, const double *H_dev, const d
     a.m = e->m; a.P = e->P; a.H = H_dev; a.v = v_dev; a.rdiag = rdiag_dev; a.rd0 = rd0; a.rd1 = rd1; a.noise_scale = e->noise_scale;
     a.ws = e->ws; a.chi2 = chi2_dev; a.status = status_dev; a.active = active_dev; a.require_inlier = require_inlier_dev; a.success_counter = success_counter_dev;
     size_t tall = (((size_t)a.Rs * nr + 1) & ~(size_t)1) * sizeof(double);
-    const size_t small = (size_t)(576 + UPD_THREADS / 64 + 2) * sizeof(double);                 // W + col + red + flag
+    const size_t small = (size_t)(256 + 544 + UPD_THREADS / 64 + 2) * sizeof(double);           // W + col (incl. dump area) + red + flag
     const int ti = (nr + 15) / 16, lbk = (l + 15) / 16;
     const size_t hbytes = (size_t)(16 * ti) * (16 * lbk) * sizeof(double);                      // zero-padded H
     const size_t lds_cap = 150 * 1024;
