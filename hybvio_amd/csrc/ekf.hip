@@ -1194,7 +1194,9 @@ static int ekf_launch_update(Ekf *e, int nr, int l, const double *H_dev, const d
     using Kern = void (*)(UpdateArgs);
     const Kern kern = kmode == 0 ? (Kern)ekf_update_kernel<0, 0> : kmode == 1 ? (Kern)ekf_update_kernel<1, 0>
                     : ti == 1 ? (Kern)ekf_update_kernel<2, 1> : ti == 2 ? (Kern)ekf_update_kernel<2, 2> : (Kern)ekf_update_kernel<2, 3>;
-    static bool attr_set = false;
+    // the attribute is per device: one flag per device ordinal (several contexts / devices may live in one process)
+    static bool attr_set_dev[64] = {};
+    bool &attr_set = attr_set_dev[c->p.device & 63];
     if (!attr_set) {
         for (Kern k : { (Kern)ekf_update_kernel<1, 0>, (Kern)ekf_update_kernel<2, 1>, (Kern)ekf_update_kernel<2, 2>, (Kern)ekf_update_kernel<2, 3> })
             HV_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024));
@@ -1648,7 +1650,8 @@ int hv_ekf_augment(hv_ekf *h, const int *discarded, const unsigned char *active)
     const size_t shmem = sizeof(double) * (3 * hv::POSE * e->n + 2 * hv::POSE * hv::POSE + hv::POSE + 1 + (hv::AUG_THREADS / 64) * 16 * 17);
     if (shmem > 64 * 1024) {                 // state vectors with map points (n > ~190): beyond the default dynamic-LDS limit
         if (shmem > 158 * 1024) return HV_ERR_UNSUPPORTED;
-        static bool aug_attr_set = false;
+        static bool aug_attr_set_dev[64] = {};
+        bool &aug_attr_set = aug_attr_set_dev[c->p.device & 63];
         if (!aug_attr_set) {
             HV_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void *>(hv::ekf_augment_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024));
             aug_attr_set = true;
