@@ -299,3 +299,27 @@ def test_level0_used_in_place_with_a_padded_row_stride(oracle, seq752):
         xy, st = _compare_klt(ctx, oracle, refs[0], refs[1], slots[0], slots[1], pts)
         _compare_klt(ctx, oracle, refs[1], refs[2], slots[1], slots[2], xy)
         assert np.array_equal(ctx.gftt_detect(slots[1], prev=xy, mask_radius=30), oracle.gftt_detect(imgs[1], prev=xy, mask_radius=30))
+
+
+def test_two_contexts_interleaved_are_independent(oracle):
+    """Two sessions in one process (different resolutions, own streams and pools), their calls interleaved: each equals the
+    oracle as if it ran alone (the library keeps no cross-context state)."""
+    from hybvio_amd import synth
+    sizes = [(376, 240), (330, 250)]
+    seqs = [synth.stereo_sequence(60 + i, w, h, 2)[0] for i, (w, h) in enumerate(sizes)]
+    pts = [synth.grid_points(w, h, 50, margin=10, seed=i) for i, (w, h) in enumerate(sizes)]
+    ctxs = [capi.Context(width=w, height=h) for (w, h) in sizes]
+    try:
+        slots = [[c.acquire(), c.acquire()] for c in ctxs]
+        for k in range(2):                       # frame k of context 0, then of context 1, ...
+            for c, s, q in zip(ctxs, slots, seqs):
+                c.build(s[k], q[k])
+        out = [c.klt_track(s[0], s[1], p) for c, s, p in zip(ctxs, slots, pts)]
+        det = [c.gftt_detect(s[1], mask_radius=20) for c, s in zip(ctxs, slots)]
+    finally:
+        for c in ctxs:
+            c.close()
+    for q, p, (xy, st, err), d in zip(seqs, pts, out, det):
+        oxy, ost, _ = oracle.klt_track(oracle.Pyramid(q[0]), oracle.Pyramid(q[1]), p)
+        assert np.array_equal(st, ost) and np.abs(xy - oxy)[ost == 1].max() <= 1e-3
+        assert np.array_equal(d, oracle.gftt_detect(q[1], mask_radius=20))
