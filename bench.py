@@ -420,6 +420,53 @@ def bench_ingest(tb, n, local_rank, cpu_baseline):
     return res
 
 
+def bench_pcie_inclusive(local_rank, n_seq=256, steps=10):
+    """C2 with the frames of every step copied from pinned host memory first (2 x n_seq images of 361 KB per step): once with the
+    copy in line on the compute stream, once double-buffered on a copy stream one step ahead. Never the headline `value`."""
+    import torch
+    dev = f"cuda:{local_rank}"
+    tb = TrackerBench(n_seq, local_rank, seed=5)
+    host = [torch.empty((2, n_seq, H, W), dtype=torch.uint8).pin_memory() for _ in range(N_CYCLE)]
+    for k in range(N_CYCLE):
+        host[k].copy_(tb.frames[k].cpu())
+    nbytes = 2 * n_seq * H * W
+    res = {"sequences": n_seq, "host_bytes_per_step": nbytes}
+
+    def run(overlap):
+        copy_stream = torch.cuda.Stream(device=dev)
+        done = [torch.cuda.Event() for _ in range(N_CYCLE)]
+        main = torch.cuda.current_stream()
+        def upload(k):
+            if overlap:
+                copy_stream.wait_stream(main)                 # the slot being overwritten was last read two steps ago
+                with torch.cuda.stream(copy_stream):
+                    tb.frames[k % N_CYCLE].copy_(host[k % N_CYCLE], non_blocking=True)
+                    done[k % N_CYCLE].record(copy_stream)
+            else:
+                tb.frames[k % N_CYCLE].copy_(host[k % N_CYCLE], non_blocking=True)
+        upload(tb.k)
+        for _ in range(2):
+            if overlap:
+                main.wait_event(done[tb.k % N_CYCLE])
+            nxt = tb.k + 1
+            tb.step()
+            upload(nxt)
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for _ in range(steps):
+            if overlap:
+                main.wait_event(done[tb.k % N_CYCLE])
+            nxt = tb.k + 1
+            tb.step()
+            upload(nxt)
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / steps
+    for name, ov in (("copy_in_line", False), ("copy_one_step_ahead", True)):
+        dt = run(ov)
+        res[name] = {"ms_per_step": dt * 1e3, "frames_per_s": n_seq / dt, "h2d_GBs": nbytes / dt / 1e9}
+    tb.ctx.close()
+    return res
+
+
 def bench_rot_ransac(ctx, n_sets, local_rank, cpu_baseline):
     """f4: RotRansac::fit for n_sets frames of 200 tracked features each (100 hypotheses x 200 inlier tests + refit)."""
     import numpy as np
@@ -585,6 +632,7 @@ def main():
     ap.add_argument("--no-ingest", action="store_true", help="skip the f2 (colour->gray / undistort ingest kernel) measurement")
     ap.add_argument("--no-visual-track", action="store_true", help="skip the f3 (device triangulation + prepareVisualUpdate) measurement")
     ap.add_argument("--no-ransac", action="store_true", help="skip the f4 (2-point rotation RANSAC kernel) measurement")
+    ap.add_argument("--no-pcie", action="store_true", help="skip the PCIe-inclusive measurement (frames handed over as host buffers)")
     ap.add_argument("--c4", action="store_true",
                     help="configs[3] instead of the headline workload: 1280x720 stereo, 400 features (not the default bench line)")
     args = ap.parse_args()
@@ -703,6 +751,9 @@ def main():
         out["f3_visual_track"]["single_sequence"] = {"prepare_ms": one["prepare_avg_ms"], "fused_prepare_gate_update_ms": one["fused_prepare_gate_update_avg_ms"],
                                                      "frame_loop_ms": one["frame_loop"]["ms_per_frame_loop"],
                                                      "note": "what one `main` process pays per frame for its 20 track visits (quota 5)"}
+    # ---- the same C2 step when every frame arrives as a HOST buffer (the reference's boundary: main.cpp hands cv::Mat frames) ----
+    if not args.no_pcie and rank == 0:
+        out["pcie_inclusive"] = bench_pcie_inclusive(local_rank)
     # ---- f4: 2-point rotation RANSAC on the tracked features of every sequence ----
     if not args.no_ransac and rank == 0:
         out["f4_rot_ransac"] = bench_rot_ransac(tb.ctx, min(B, 1024), local_rank, not args.no_cpu_baseline)
