@@ -420,7 +420,7 @@ def bench_ingest(tb, n, local_rank, cpu_baseline):
     return res
 
 
-def bench_pcie_inclusive(local_rank, n_seq=256, steps=10):
+def bench_pcie_inclusive(local_rank, n_seq=128, steps=10):
     """C2 with the frames of every step copied from pinned host memory first (2 x n_seq images of 361 KB per step): once with the
     copy in line on the compute stream, once double-buffered on a copy stream one step ahead. Never the headline `value`."""
     import torch
