@@ -589,38 +589,43 @@ __global__ __launch_bounds__(VT) void vu_prepare_kernel(VuPrepareArgs a)
     VU_STAMP(29);
     const int rows = 2 * nt;
     double *H = a.H + (size_t)b * rows * N;
-    // thread -> (state column c, quarter of the trail poses): 4 N <= VT for N <= 192, otherwise the loop strides
-    for (int w = tid; w < 4 * N; w += VT) {
-        const int c = w >> 2, quarter = w & 3;
-        // which pose of the track (if any) owns state column c, and which of its 7 components
-        int k = -1, comp = 0;
+    // which pose of the track (if any) owns state column c, and which of its 7 components: once per column
+    int *s_colmap = reinterpret_cast<int *>(s_p0);                          // s_p0 is free after the Gauss-Newton loop
+    for (int c = tid; c < N; c += VT) {
+        int code = -1;
         for (int q = 0; q < n; ++q) {
             int ip, io;
             pos_ori(s_idx[q], ip, io);
-            if (c >= ip && c < ip + 3) { k = q; comp = c - ip; }
-            else if (c >= io && c < io + 4) { k = q; comp = 3 + c - io; }
+            if (c >= ip && c < ip + 3) code = 8 * q + (c - ip);
+            else if (c >= io && c < io + 4) code = 8 * q + 3 + (c - io);
         }
+        s_colmap[c] = code;
+    }
+    __syncthreads();
+    // work item = (state column c, trail pose i), i fastest: the 2 * nt rows of a column are contiguous in the column-major
+    // H, so consecutive lanes write consecutive 16-byte pairs (a thread per column wrote 16 bytes every 2 * nt * 8)
+    for (int w = tid; w < N * nt; w += VT) {
+        const int c = w / nt, i = w - c * nt;
+        const int code = s_colmap[c], k = code >> 3, comp = code & 7;
         const bool sft = c == 19 && with_derivatives && a.est_shift;
-        for (int i = quarter; i < nt; i += 4) {
-            const double *o = s_it + i * ITER_WORDS;
-            double h0 = 0.0, h1 = 0.0;
-            if (k >= 0) {
-                if (k == i % n) {                                                          // own pose: :946-953
-                    if (comp < 3) { h0 = -o[comp]; h1 = -o[3 + comp]; }
-                    else { h0 = o[6 + comp - 3]; h1 = o[10 + comp - 3]; }
-                }
-                if (with_derivatives) {                                                    // :955-964
-                    const double *dp = s_dpf + 21 * k + comp;
-                    h0 += o[0] * dp[0] + o[1] * dp[7] + o[2] * dp[14];
-                    h1 += o[3] * dp[0] + o[4] * dp[7] + o[5] * dp[14];
-                }
-            } else if (sft) {                                                              // :965-967
-                const double t0 = s_dpfi[dDim], t1 = s_dpfi[ncol + dDim], t2 = s_dpfi[2 * ncol + dDim];
-                h0 = o[0] * t0 + o[1] * t1 + o[2] * t2 - s_feat[4 * i + 2];
-                h1 = o[3] * t0 + o[4] * t1 + o[5] * t2 - s_feat[4 * i + 3];
+        const double *o = s_it + i * ITER_WORDS;
+        double h0 = 0.0, h1 = 0.0;
+        if (code >= 0) {
+            if (k == i % n) {                                                              // own pose: :946-953
+                if (comp < 3) { h0 = -o[comp]; h1 = -o[3 + comp]; }
+                else { h0 = o[6 + comp - 3]; h1 = o[10 + comp - 3]; }
             }
-            *reinterpret_cast<double2 *>(H + (size_t)c * rows + 2 * i) = double2{h0, h1};
+            if (with_derivatives) {                                                        // :955-964
+                const double *dp = s_dpf + 21 * k + comp;
+                h0 += o[0] * dp[0] + o[1] * dp[7] + o[2] * dp[14];
+                h1 += o[3] * dp[0] + o[4] * dp[7] + o[5] * dp[14];
+            }
+        } else if (sft) {                                                                  // :965-967
+            const double t0 = s_dpfi[dDim], t1 = s_dpfi[ncol + dDim], t2 = s_dpfi[2 * ncol + dDim];
+            h0 = o[0] * t0 + o[1] * t1 + o[2] * t2 - s_feat[4 * i + 2];
+            h1 = o[3] * t0 + o[4] * t1 + o[5] * t2 - s_feat[4 * i + 3];
         }
+        *reinterpret_cast<double2 *>(H + (size_t)c * rows + 2 * i) = double2{h0, h1};
     }
     if (tid < nt) {
         const double *o = s_it + tid * ITER_WORDS;
