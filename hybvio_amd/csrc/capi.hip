@@ -92,6 +92,49 @@ int ensure_point_staging(Ctx *c, int n)
 
 bool slot_ok(Ctx *c, int s) { return s >= 0 && s < c->p.pool_size && c->slot_used[s]; }
 
+// level-0 pointers that refer to the slot's own copy move with the slab; pointers into caller buffers stay
+__global__ void rebase_l0_kernel(const uint8_t **dst, const uint8_t *const *src, int *dst_stride, const int *src_stride, int n_old,
+                                 int n_new, const uint8_t *old_slab, long long old_bytes, const uint8_t *new_slab)
+{
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n_new) return;
+    const uint8_t *p = nullptr;
+    int st = 0;
+    if (s < n_old) {
+        p = src[s]; st = src_stride[s];
+        if (p >= old_slab && p < old_slab + old_bytes) p = new_slab + (p - old_slab);
+    }
+    dst[s] = p; dst_stride[s] = st;
+}
+
+// util::Allocator (src/util/allocator.hpp:55-67) creates a new pyramid whenever every pooled one is still referenced;
+// the device pool does the same by doubling the slab (contents and slot numbers are kept). Synchronises the stream;
+// HIP graphs captured before the growth hold the old addresses and must be re-captured.
+int grow_pool(Ctx *c)
+{
+    const int n_old = c->p.pool_size, n_new = n_old * 2;
+    const long long old_bytes = c->L.slot_bytes * n_old;
+    HV_HIP(c, hipStreamSynchronize(c->stream));
+    uint8_t *slab = nullptr; const uint8_t **l0p = nullptr; int *l0s = nullptr;
+    if (hipMalloc(&slab, (size_t)c->L.slot_bytes * n_new) != hipSuccess) return HV_ERR_NOMEM;
+    if (hipMalloc(&l0p, sizeof(void *) * n_new) != hipSuccess) { (void)hipFree(slab); return HV_ERR_NOMEM; }
+    if (hipMalloc(&l0s, sizeof(int) * n_new) != hipSuccess) { (void)hipFree(slab); (void)hipFree(l0p); return HV_ERR_NOMEM; }
+    hipError_t e = hipMemcpyAsync(slab, c->slab, (size_t)old_bytes, hipMemcpyDeviceToDevice, c->stream);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(rebase_l0_kernel, dim3((n_new + 255) / 256), dim3(256), 0, c->stream, l0p, c->d_l0_ptr, l0s, c->d_l0_stride,
+                           n_old, n_new, c->slab, old_bytes, slab);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (e != hipSuccess) { (void)hipFree(slab); (void)hipFree(l0p); (void)hipFree(l0s); return hip_fail(c, e, "grow_pool"); }
+    (void)hipFree(c->slab); (void)hipFree(c->d_l0_ptr); (void)hipFree(c->d_l0_stride);
+    c->slab = slab; c->d_l0_ptr = l0p; c->d_l0_stride = l0s;
+    c->slot_used.resize(n_new, 0);
+    for (int s = n_new - 1; s >= n_old; --s) c->free_slots.push_back(s);
+    c->p.pool_size = n_new;
+    return HV_OK;
+}
+
 }  // namespace
 }  // namespace hv
 
@@ -232,7 +275,10 @@ int hv_pyramid_acquire(hv_ctx *h, int *slot_out)
 {
     if (!h || !slot_out) return HV_ERR_INVALID;
     Ctx *c = &h->c;
-    if (c->free_slots.empty()) return HV_ERR_POOL;
+    if (c->free_slots.empty()) {
+        const int rc = hv::grow_pool(c);
+        if (rc != HV_OK) return rc == HV_ERR_NOMEM ? HV_ERR_POOL : rc;
+    }
     const int s = c->free_slots.back();
     c->free_slots.pop_back();
     c->slot_used[s] = 1;

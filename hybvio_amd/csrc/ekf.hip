@@ -1166,6 +1166,9 @@ static int ekf_launch_update(Ekf *e, int nr, int l, const double *H_dev, const d
 {
     Ctx *c = e->c;
     if (nr < 1 || nr > e->max_rows || l < 1 || l > e->n) return HV_ERR_INVALID;
+    // the chi2 gate needs chi2inv95[nr] (the reference asserts n < chi2inv95.size(): ekf.cpp:806); mode 1 with an
+    // inlier requirement is the update half of a gate that already ran
+    if (!generic && mode != 1 && nr >= HV_CHI2INV95_N) return HV_ERR_INVALID;
     UpdateArgs a{};
     a.n = e->n; a.nr = nr; a.l = l; a.R = nr + e->n + 1;
     // LDS stride of T: 15 or 17 mod 32 doubles. Odd keeps the 16 lanes of a row-strided operand read (S = HP H')

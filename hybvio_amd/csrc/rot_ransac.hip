@@ -266,7 +266,7 @@ __global__ __launch_bounds__(RT) void rot_ransac_kernel(RansacArgs a)
     __shared__ unsigned short s_map[MAX_PTS];     // compacted index -> original feature number
     __shared__ int s_chunk[MAX_PTS / 64 + 1];
     const int set = blockIdx.x, tid = threadIdx.x;
-    const int n_all = a.n_points[set];
+    const int n_all = min(max(a.n_points[set], 0), a.max_points);      // a device-supplied count never indexes past the set's arrays
     const float *c1 = a.c1 + (size_t)set * a.max_points * 2, *c2 = a.c2 + (size_t)set * a.max_points * 2;
     int *status = a.status + (size_t)set * a.max_points;
     // ---- "Pick the left camera features for which track was found" (ransac_pipeline.cpp:106-112), in feature order:
@@ -324,7 +324,8 @@ __global__ __launch_bounds__(RT) void rot_ransac_kernel(RansacArgs a)
         } else {
             i1 = a.pairs[((size_t)set * HYP + tid) * 2]; i2 = a.pairs[((size_t)set * HYP + tid) * 2 + 1];
         }
-        const int ok = i1 != i2;
+        // caller-supplied index pairs outside [0, n) make the hypothesis invalid instead of reading outside the set
+        const int ok = i1 != i2 && (unsigned)i1 < (unsigned)n && (unsigned)i2 < (unsigned)n;
         s_valid[tid] = ok;
         if (ok) {
             float H[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, R[9];

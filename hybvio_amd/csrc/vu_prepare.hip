@@ -27,6 +27,7 @@ namespace {
 constexpr int VT = 768;                 // threads: G = 2 or 4 per derivative column (<= 7 * 42 + 1 columns)
 constexpr int MAXP = 42;                // 2 cameras x (cameraTrailLength + 1 <= 21) poses
 constexpr int MAXC = MAXP * 7 + 1;
+constexpr int MAXNP = 21;              // poses per camera: s_dpf is [MAXNP][21], s_idx holds MAXNP (+3 spare) indices
 constexpr int POSE_WORDS = 51;          // p[3] R[9] dR[4][9] baseline[3]
 constexpr int ITER_WORDS = 26;          // C[9] t[3] h[3] E[6] err[2] d[3]
 
@@ -200,9 +201,9 @@ __global__ __launch_bounds__(VT) void vu_prepare_kernel(VuPrepareArgs a)
     __shared__ double s_dpfi[3 * MAXC];          // [3][ncol]
     __shared__ double s_feat[MAXP * 4];          // image feature (2) + velocity (2) per pose
     __shared__ double s_small[64];               // pfi[3] pf[3] X[9] step[3] ETE[9] Eerror[3] R0T[9] pf0 ... (see offsets)
-    __shared__ double s_dpf[21 * 21];            // summed dpfdp [n][9] and dpfdq [n][12]
+    __shared__ double s_dpf[MAXNP * 21];           // summed dpfdp [n][9] and dpfdq [n][12]
     __shared__ double s_p0[7 * MAXP * 12 + 7 * 12];   // motion part of the 7 columns of pose 0: [7][pose][12], then their totals [7][12]
-    __shared__ int s_idx[24];
+    __shared__ int s_idx[MAXNP + 3];
     __shared__ int s_flag[4];
     const int b = blockIdx.x, tid = threadIdx.x;
     const int n = a.np, ncam = a.stereo ? 2 : 1, nt = n * ncam, N = a.n;
@@ -652,7 +653,10 @@ __global__ __launch_bounds__(VT) void vu_prepare_kernel(VuPrepareArgs a)
 
 int launch_vu_prepare(Ctx *c, const VuPrepareArgs &a)
 {
-    if (a.np < 2 || a.np * (a.stereo ? 2 : 1) > MAXP || a.batch < 1) return HV_ERR_INVALID;
+    if (a.np < 2 || a.batch < 1) return HV_ERR_INVALID;
+    // the kernel's LDS arrays hold at most MAXNP poses per camera (the reference's cameraTrailLength 20 + the current pose);
+    // a longer trail (cameraTrailLength > 20) is a supported filter size but not a supported track length here
+    if (a.np > MAXNP || a.np * (a.stereo ? 2 : 1) > MAXP) return HV_ERR_UNSUPPORTED;
     ScopedKernelTime tm(c, HV_K_VU_PREPARE);
     hipLaunchKernelGGL(vu_prepare_kernel, dim3((unsigned)a.batch), dim3(VT), 0, c->stream, a);
     HV_HIP(c, hipGetLastError());

@@ -51,7 +51,7 @@ struct HipEKF : public EKF {
     }
     ~HipEKF() override { hv_ekf_destroy(ekf); }
 
-    void check(int rc) const { assert(rc == HV_OK); (void)rc; }
+    void check(int rc) const { session.check(rc, "hv_ekf"); }   // throws DeviceError, also under NDEBUG
     mutable std::vector<double> qdt, qg, qa;            // queued IMU samples (dt, gyro, acc)
     void flushPredicts() const {
         if (qdt.empty()) return;
@@ -366,7 +366,7 @@ struct HipEKF : public EKF {
         }
         return true;
     }
-    void maintainPositiveSemiDefinite() final { check(hv_ekf_symmetrize(ekf)); covFresh = false; }
+    void maintainPositiveSemiDefinite() final { check(hv_ekf_symmetrize(dev())); covFresh = false; }
     void setState(const VectorXd &_m) final { assert(static_cast<int>(_m.size()) == stateDim); m = _m; pushMean(); }
     void setStateCovariance(const MatrixXd &_P) final {
         assert(_P.rows == stateDim && _P.cols == stateDim);

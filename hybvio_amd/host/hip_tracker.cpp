@@ -17,6 +17,14 @@ Session::Session(const hv_params &params) : params_(params)
 
 Session::~Session() { hv_destroy(ctx_); }
 
+void Session::check(int rc, const char *what) const
+{
+    if (rc == HV_OK) return;
+    std::string msg = std::string(what) + ": " + hv_status_string(rc);
+    if (rc == HV_ERR_HIP) msg += std::string(" (") + hv_last_error(ctx_) + ")";
+    throw DeviceError(rc, msg);
+}
+
 namespace tracker {
 
 ImagePyramid::~ImagePyramid() = default;
@@ -43,26 +51,23 @@ namespace {
 // only the pool still references it; here the shared_ptr's last owner returns the slot to the
 // device pool, which has the same effect: a pyramid lives exactly as long as an Image refers to it.
 struct HipImagePyramid : ImagePyramid {
+    Session &session;
     hv_ctx *ctx;
     int slot;
-    HipImagePyramid(hv_ctx *c, int s) : ctx(c), slot(s) {}
+    HipImagePyramid(Session &s, int sl) : session(s), ctx(s.ctx()), slot(sl) {}
     ~HipImagePyramid() override { hv_pyramid_release(ctx, slot); }
     int deviceSlot() const final { return slot; }
 
     std::vector<GrayType> getGrayLevel(std::size_t i, int &w, int &h) final {
-        const int rc0 = hv_pyramid_level_size(ctx, (int)i, &w, &h);
-        assert(rc0 == HV_OK); (void)rc0;
+        session.check(hv_pyramid_level_size(ctx, (int)i, &w, &h), "hv_pyramid_level_size");
         std::vector<GrayType> out((size_t)w * h);
-        const int rc = hv_pyramid_download(ctx, slot, (int)i, out.data(), nullptr);
-        assert(rc == HV_OK); (void)rc;
+        session.check(hv_pyramid_download(ctx, slot, (int)i, out.data(), nullptr), "hv_pyramid_download");
         return out;
     }
     std::vector<GradientType> getGradientLevel(std::size_t i, int &w, int &h) final {
-        const int rc0 = hv_pyramid_level_size(ctx, (int)i, &w, &h);
-        assert(rc0 == HV_OK); (void)rc0;
+        session.check(hv_pyramid_level_size(ctx, (int)i, &w, &h), "hv_pyramid_level_size");
         std::vector<GradientType> out((size_t)w * h * GRADIENT_CHANNELS);
-        const int rc = hv_pyramid_download(ctx, slot, (int)i, nullptr, out.data());
-        assert(rc == HV_OK); (void)rc;
+        session.check(hv_pyramid_download(ctx, slot, (int)i, nullptr, out.data()), "hv_pyramid_download");
         return out;
     }
 };
@@ -74,24 +79,20 @@ public:
     std::shared_ptr<ImagePyramid> compute(const GrayImage &img) final {
         assert(img.width == session.params().width && img.height == session.params().height);
         int slot = -1;
-        int rc = hv_pyramid_acquire(session.ctx(), &slot);
-        assert(rc == HV_OK && "pyramid pool exhausted: raise hv_params.pool_size");
-        auto pyramid = std::make_shared<HipImagePyramid>(session.ctx(), slot);
-        rc = hv_pyramid_build(session.ctx(), slot, img.data, img.strideBytes);   // H2D + kernels, asynchronous
-        assert(rc == HV_OK); (void)rc;
+        session.check(hv_pyramid_acquire(session.ctx(), &slot), "hv_pyramid_acquire");   // the pool grows on demand
+        auto pyramid = std::make_shared<HipImagePyramid>(session, slot);
+        session.check(hv_pyramid_build(session.ctx(), slot, img.data, img.strideBytes), "hv_pyramid_build");   // H2D + kernels, asynchronous
         // the caller's pixels were handed to an asynchronous copy: fence before they may be reused
-        hv_synchronize(session.ctx());
+        session.check(hv_synchronize(session.ctx()), "hv_synchronize");
         return pyramid;
     }
     std::shared_ptr<ImagePyramid> computeFromFrame(const InputImage &img) final {
         assert(img.width == session.params().width && img.height == session.params().height);
         int slot = -1;
-        int rc = hv_pyramid_acquire(session.ctx(), &slot);
-        assert(rc == HV_OK && "pyramid pool exhausted: raise hv_params.pool_size");
-        auto pyramid = std::make_shared<HipImagePyramid>(session.ctx(), slot);
-        rc = hv_ingest_build(session.ctx(), slot, img.data, img.strideBytes, img.channels, -1);
-        assert(rc == HV_OK); (void)rc;
-        hv_synchronize(session.ctx());
+        session.check(hv_pyramid_acquire(session.ctx(), &slot), "hv_pyramid_acquire");   // the pool grows on demand
+        auto pyramid = std::make_shared<HipImagePyramid>(session, slot);
+        session.check(hv_ingest_build(session.ctx(), slot, img.data, img.strideBytes, img.channels, -1), "hv_ingest_build");
+        session.check(hv_synchronize(session.ctx()), "hv_synchronize");
         return pyramid;
     }
 };
@@ -124,16 +125,13 @@ public:
                     double ray[3], *out = &pixOrig[2 * ((size_t)y * w + x)];
                     valid[(size_t)y * w + x] = undistortedCamera->pixelToRay(pixRect, ray) && originalCamera->rayToPixel(ray, out);
                 }
-            const int rc = hv_ingest_set_undistort_map(session.ctx(), cameraIndex, pixOrig.data(), valid.data());
-            assert(rc == HV_OK); (void)rc;
+            session.check(hv_ingest_set_undistort_map(session.ctx(), cameraIndex, pixOrig.data(), valid.data()), "hv_ingest_set_undistort_map");
         }
         int slot = -1;
-        int rc = hv_pyramid_acquire(session.ctx(), &slot);
-        assert(rc == HV_OK && "pyramid pool exhausted: raise hv_params.pool_size");
-        auto pyramid = std::make_shared<HipImagePyramid>(session.ctx(), slot);
-        rc = hv_ingest_build(session.ctx(), slot, image.data, image.strideBytes, image.channels, cameraIndex);
-        assert(rc == HV_OK); (void)rc;
-        hv_synchronize(session.ctx());
+        session.check(hv_pyramid_acquire(session.ctx(), &slot), "hv_pyramid_acquire");   // the pool grows on demand
+        auto pyramid = std::make_shared<HipImagePyramid>(session, slot);
+        session.check(hv_ingest_build(session.ctx(), slot, image.data, image.strideBytes, image.channels, cameraIndex), "hv_ingest_build");
+        session.check(hv_synchronize(session.ctx()), "hv_synchronize");
         return {undistortedCamera, pyramid};
     }
 };
@@ -156,11 +154,10 @@ public:
         assert(corners.size() == n);
         workStatus.assign(n, 2);
         static_assert(sizeof(Feature::Point) == 2 * sizeof(float), "Point must be two packed floats (optical_flow.cpp:21-22)");
-        const int rc = hv_optical_flow_compute(session.ctx(), prevImagePyramid.deviceSlot(), imagePyramid.deviceSlot(),
+        session.check(hv_optical_flow_compute(session.ctx(), prevImagePyramid.deviceSlot(), imagePyramid.deviceSlot(),
                                                (int)n, reinterpret_cast<const float *>(prevCorners.data()),
                                                reinterpret_cast<float *>(corners.data()), workStatus.data(),
-                                               useInitialCorners ? 1 : 0, overrideMaxIterations);
-        assert(rc == HV_OK); (void)rc;
+                                               useInitialCorners ? 1 : 0, overrideMaxIterations), "hv_optical_flow_compute");
         for (size_t i = 0; i < n; ++i) trackStatus[i] = static_cast<Feature::Status>(workStatus[i]);
     }
 };
@@ -178,10 +175,9 @@ public:
         assert(nk >= 0);
         corners.assign((size_t)(2 * nk), Feature::Point{0.f, 0.f});
         int n = 0;
-        const int rc = hv_gftt_detect(session.ctx(), &parameters, imagePyramid.deviceSlot(),
+        session.check(hv_gftt_detect(session.ctx(), &parameters, imagePyramid.deviceSlot(),
                                       reinterpret_cast<const float *>(prevCorners.data()), (int)prevCorners.size(),
-                                      maskRadius, reinterpret_cast<float *>(corners.data()), 2 * nk, &n);
-        assert(rc == HV_OK); (void)rc;
+                                      maskRadius, reinterpret_cast<float *>(corners.data()), 2 * nk, &n), "hv_gftt_detect");
         corners.resize((size_t)n);
     }
 };
@@ -211,10 +207,9 @@ public:
         std::array<float, 9> R{};
         int best = 0, visited = 0;
         static_assert(sizeof(Feature::Point) == 2 * sizeof(float), "Point must be two packed floats");
-        const int rc = hv_rot_ransac(session.ctx(), static_cast<int>(n), reinterpret_cast<const float *>(c1.data()),
+        session.check(hv_rot_ransac(session.ctx(), static_cast<int>(n), reinterpret_cast<const float *>(c1.data()),
                                      reinterpret_cast<const float *>(c2.data()), &camera1, &camera2, pairs.data(), threshold_pow2,
-                                     status.data(), R.data(), &best, &visited);
-        assert(rc == HV_OK); (void)rc;
+                                     status.data(), R.data(), &best, &visited), "hv_rot_ransac");
         rng.discard(2ull * static_cast<unsigned long long>(visited));
         bestInlierCount = static_cast<std::size_t>(best);
         for (std::size_t i = 0; i < n; ++i) bestInliers.at(i) = static_cast<Feature::Status>(status[i]);

@@ -23,6 +23,7 @@
 #include <memory>
 #include <random>
 #include <string>
+#include <stdexcept>
 #include <vector>
 
 #include "../../include/hybvio_hip.h"
@@ -42,6 +43,11 @@ struct MatrixXd {                       // column-major, like Eigen::MatrixXd
     double operator()(int i, int j) const { return data[(size_t)j * rows + i]; }
 };
 
+struct DeviceError : std::runtime_error {
+    int status;
+    DeviceError(int rc, const std::string &msg) : std::runtime_error(msg), status(rc) {}
+};
+
 // One device session: the hv_ctx (stream + pyramid pool) shared by the tracker adapters and the EKF.
 class Session {
 public:
@@ -51,6 +57,9 @@ public:
     Session &operator=(const Session &) = delete;
     hv_ctx *ctx() const { return ctx_; }
     const hv_params &params() const { return params_; }
+    // Every C-ABI return code of the adapters passes through here: a device failure throws DeviceError (also under
+    // NDEBUG) instead of leaving the caller with stale outputs. Contract violations stay asserts like the reference's.
+    void check(int rc, const char *what) const;
 private:
     hv_ctx *ctx_ = nullptr;
     hv_params params_{};

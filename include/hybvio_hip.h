@@ -73,7 +73,10 @@ int hv_synchronize(hv_ctx *ctx);
  * Device layout is compact (no 31-px border); borders are applied virtually by the tracker:
  * BORDER_REFLECT_101 for gray, 0 for gradients, exactly as OpenCV pads.
  * Slots are pooled like util::Allocator (src/util/allocator.hpp:55-67): acquire when an Image
- * first needs its pyramid (image.cpp:209-214), release when the Image dies. */
+ * first needs its pyramid (image.cpp:209-214), release when the Image dies. Like the reference's
+ * allocator the pool grows on demand: when every slot is in use hv_pyramid_acquire doubles the slab
+ * (synchronises the stream; slot numbers and contents are kept; HIP graphs captured earlier hold stale
+ * addresses) and only reports HV_ERR_POOL when the device is out of memory. pool_size is the initial size. */
 int hv_pyramid_acquire(hv_ctx *ctx, int *slot_out);
 int hv_pyramid_release(hv_ctx *ctx, int slot);
 int hv_pyramid_level_size(hv_ctx *ctx, int level, int *width, int *height);
@@ -170,7 +173,11 @@ int hv_ekf_predict_n(hv_ekf *ekf, int n_samples, const double *dt, const double 
 int hv_ekf_update(hv_ekf *ekf, int n_rows, int l, const double *H, const double *y, const double *r_diag,
                   const unsigned char *active /* optional [batch] */, int normalize_all_quaternions);
 /* visualTrackOutlierCheck (ekf.cpp:787-819) given v = y - f: chi2[f] = noiseScale * v' S^-1 v and
- * status[f] = 0 (INLIER) / 3 (CHI2, chi2 > chi2inv95[n_rows]). Does not modify the filter. Synchronous. */
+ * status[f] = 0 (INLIER) / 3 (CHI2, chi2 > chi2inv95[n_rows]). Does not modify the filter. Synchronous.
+ * n_rows must be < 201 (the size of the reference's chi2inv95 table, odometry/util.hpp:23; the reference asserts it):
+ * HV_ERR_INVALID otherwise. Only the reference's defaults of the two optional branches are implemented: r > 0 (the
+ * r < 0 "visualR-scaled" branch is not) and trackRmseThreshold = -1 (no RMSE test). S must be positive definite
+ * (r > 0 guarantees it); the blocked Cholesky has no pivot guard where the reference's LDLT tolerates a singular S. */
 int hv_ekf_visual_gate(hv_ekf *ekf, int n_rows, int l, const double *H, const double *v, double r,
                        double *chi2, int *status);
 /* updateVisualTrack (ekf.cpp:829-844) given v = y - f; R = r^2 * noiseScale * I. */

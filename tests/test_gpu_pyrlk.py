@@ -48,6 +48,31 @@ def test_pyramid_bit_exact(oracle, shape):
         _check_pyramid(ctx, oracle, np.ascontiguousarray(img[::-1]), s2)
 
 
+def test_pool_grows_on_demand_like_the_reference_allocator(oracle, seq752):
+    """util::Allocator (allocator.hpp:55-67) hands out a new pyramid when every pooled one is referenced; the device pool
+    doubles its slab instead of failing. Pyramids built before the growth (own level-0 copy AND caller-owned level 0) stay
+    valid and keep their slot numbers; LK across the growth equals the oracle."""
+    import torch
+    left, right, _ = seq752
+    pts = synth.grid_points(752, 480, 200, margin=4, seed=3)
+    with _ctx(752, 480, pool_size=2) as ctx:
+        ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+        s0 = ctx.acquire(); ctx.build(s0, left[0])                      # own copy of level 0 inside the slab
+        s1 = ctx.acquire()
+        d_img = torch.from_numpy(left[1]).cuda()                        # level 0 stays in the caller's buffer
+        ctx.build_batch_dev(1, torch.tensor([s1], dtype=torch.int32, device="cuda").data_ptr(), d_img.data_ptr(), 752 * 480, 752)
+        more = [ctx.acquire() for _ in range(5)]                        # 2 -> 4 -> 8 slots
+        assert len(set([s0, s1] + more)) == 7
+        ctx.build(more[-1], right[0])
+        r0 = _check_pyramid(ctx, oracle, left[0], s0)
+        r1 = _check_pyramid(ctx, oracle, left[1], s1)
+        _check_pyramid(ctx, oracle, right[0], more[-1])
+        xy, st, _ = ctx.klt_track(s0, s1, pts)
+        oxy, ost, _ = oracle.klt_track(r0, r1, pts)
+        np.testing.assert_array_equal(st, ost)
+        np.testing.assert_array_equal(xy[st > 0], oxy[ost > 0])
+
+
 def test_pyramid_extreme_images(oracle):
     for img in (np.zeros((480, 752), np.uint8), np.full((480, 752), 255, np.uint8),
                 (np.indices((480, 752)).sum(0) % 2 * 255).astype(np.uint8)):    # checkerboard: max |gradient|
@@ -65,8 +90,6 @@ def test_pyramid_batch_dev_path_and_pool(oracle, seq752):
     with _ctx(752, 480, pool_size=8) as ctx:
         ctx.set_stream(torch.cuda.current_stream().cuda_stream)
         slots = [ctx.acquire() for _ in range(8)]
-        with pytest.raises(capi.HvError, match="pool"):
-            ctx.acquire()
         for s in slots[:2]:
             ctx.release(s)
         use = slots[2:]                                        # non-contiguous, non-zero-based

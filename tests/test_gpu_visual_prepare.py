@@ -7,7 +7,7 @@ import os
 import numpy as np
 import pytest
 
-from hybvio_amd import capi
+from hybvio_amd import capi, synth
 
 pytestmark = pytest.mark.gpu
 FX = os.path.join(os.path.dirname(__file__), "golden", "triangulation_reference_fixtures.npz")
@@ -297,4 +297,23 @@ def test_frame_loop_with_the_successful_update_quota(oracle):
             mg, Pg = g.get_state(b)
             assert _rel(mg, o.m) < 1e-8 and _rel(Pg, o.P) < 1e-7, (b, _rel(mg, o.m), _rel(Pg, o.P))
         assert 0 < reached <= B
+        g.close()
+
+
+def test_long_trail_track_is_rejected_not_corrupted():
+    """cameraTrailLength > 20 is a valid filter size, but the prepare kernel's LDS arrays hold 21 poses per camera:
+    a 22-pose mono track must come back as HV_ERR_UNSUPPORTED (r01 advisor: it used to overrun s_dpf / s_idx silently);
+    a 21-pose track on the same filter still works."""
+    rng = np.random.default_rng(5)
+    with capi.Context(width=64, height=64, levels=1, pool_size=1) as ctx:
+        g = capi.EkfBatch(ctx, capi.ekf_default_params(cameraTrailLength=24), 1)
+        assert g.n == 20 + 7 * 24
+        T1, _, means, idx, feat = synth.visual_tracks(rng, 1, 24, 22, False)
+        g.set_state(0, means[0], np.eye(g.n) * 1e-4)
+        vp = capi.vu_default_params(imu_to_camera=T1)
+        with pytest.raises(capi.HvError, match="unsupported"):
+            g.visual_track(vp, idx, feat, np.zeros_like(feat), feat.reshape(1, -1), 1.5, 0.05)
+        T1, _, _, idx21, feat21 = synth.visual_tracks(rng, 1, 24, 21, False, given_means=means)
+        st, gs, _, _ = g.visual_track(vp, idx21, feat21, np.zeros_like(feat21), feat21.reshape(1, -1), 1.5, 0.05)
+        assert st[0, 0] != -1
         g.close()
