@@ -42,6 +42,9 @@ def lib():
         L.orc_pyramid_copy_deriv.argtypes = [C.c_void_p, C.c_int, C.c_int, i16p]
         L.orc_klt_track.argtypes = [C.c_void_p, C.c_void_p, C.c_int, f32p, f32p, u8p, f32p, C.c_int, C.c_int,
                                     C.c_int, C.c_double, C.c_int, C.c_double, i32p]
+        L.orc_klt_track_mode.argtypes = L.orc_klt_track.argtypes + [C.c_int]
+        L.orc_lk_acc_A.argtypes = [C.c_int, i16p, C.c_int, f32p]
+        L.orc_lk_acc_b.argtypes = [C.c_int, i32p, i16p, C.c_int, f32p]
         L.orc_optical_flow_compute.argtypes = [C.c_void_p, C.c_void_p, C.c_int, f32p, f32p, i32p, C.c_int,
                                                C.c_int, C.c_int, C.c_int, C.c_double, C.c_double]
         L.orc_set_threads.argtypes = [C.c_int]
@@ -130,8 +133,28 @@ class Pyramid:
 USE_INITIAL_FLOW = 4
 
 
+# accumulator modes of the five LK sums (oracle/pyrlk_oracle.c header): INT64 is the kernel's; the F32 ones restate what
+# OpenCV builds off-ARM compute and exist to MEASURE the sensitivity (scripts/lk_accumulator_study.py)
+ACC_MODES = {"int64": 0, "f32_scalar": 1, "f32_simd128": 2, "f32_simd128_fma": 3, "f32_sse2_legacy": 4, "f32_wide8": 5}
+
+
+def lk_acc_A(mode: str, dI, win=31):
+    """(A11, A12, A22) float sums of an int16 [win][win][2] derivative window in the order of an F32 mode (unscaled)."""
+    dI = np.ascontiguousarray(dI, np.int16)
+    out = np.zeros(3, np.float32)
+    lib().orc_lk_acc_A(ACC_MODES[mode], _p(dI, i16p), win, _p(out, f32p))
+    return out
+
+
+def lk_acc_b(mode: str, diff, dI, win=31):
+    diff, dI = np.ascontiguousarray(diff, np.int32), np.ascontiguousarray(dI, np.int16)
+    out = np.zeros(2, np.float32)
+    lib().orc_lk_acc_b(ACC_MODES[mode], _p(diff, i32p), _p(dI, i16p), win, _p(out, f32p))
+    return out
+
+
 def klt_track(prev: Pyramid, nxt: Pyramid, prev_pts, next_pts=None, win=31, max_level=3, max_count=20,
-              eps=0.03, min_eig=1e-3, want_iters=False):
+              eps=0.03, min_eig=1e-3, want_iters=False, acc_mode="int64"):
     """cv::calcOpticalFlowPyrLK restatement. Returns (next_pts, status u8, err f32[, iters])."""
     prev_pts = np.ascontiguousarray(prev_pts, np.float32).reshape(-1, 2)
     n = prev_pts.shape[0]
@@ -144,9 +167,9 @@ def klt_track(prev: Pyramid, nxt: Pyramid, prev_pts, next_pts=None, win=31, max_
     status = np.zeros(n, np.uint8)
     err = np.zeros(n, np.float32)
     iters = np.zeros((max_level + 1, n), np.int32) if want_iters else None
-    rc = lib().orc_klt_track(prev._h, nxt._h, n, _p(prev_pts, f32p), _p(out, f32p), _p(status, u8p),
-                             _p(err, f32p), win, max_level, max_count, eps, flags, min_eig,
-                             _p(iters, i32p) if want_iters else None)
+    rc = lib().orc_klt_track_mode(prev._h, nxt._h, n, _p(prev_pts, f32p), _p(out, f32p), _p(status, u8p),
+                                  _p(err, f32p), win, max_level, max_count, eps, flags, min_eig,
+                                  _p(iters, i32p) if want_iters else None, ACC_MODES[acc_mode])
     assert rc == 0
     return (out, status, err, iters) if want_iters else (out, status, err)
 

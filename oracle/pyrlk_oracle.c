@@ -37,6 +37,24 @@
  * reduction. All remaining float arithmetic is a per-point scalar sequence that
  * is executed identically (IEEE-754 binary32, no FMA contraction, round-half-even
  * conversions) on both sides. Build with -ffp-contract=off.
+ *
+ * Accumulator MODES (r02): the float-accumulator variants OpenCV compiles off-ARM are
+ * restated as well (orc_klt_track_mode), from the published lkpyramid.cpp, so that the distance
+ * between what an x86 OpenCV build computes and the exact-integer variant the kernel implements can
+ * be MEASURED (scripts/lk_accumulator_study.py, tests/test_oracle_lk_accumulators.py):
+ *   ORC_ACC_INT64        exact integer sums (`__arm__ && !CV_NEON` typedefs)   -- the kernel's mode
+ *   ORC_ACC_F32_SCALAR   `float acctype`, row-major scalar loop (a build without SIMD)
+ *   ORC_ACC_F32_SIMD128  `CV_SIMD128 && !CV_NEON` universal-intrinsic code of OpenCV >= 4.1: A in 8-pixel steps as two
+ *                        4-lane v_muladd groups (lane = pixel mod 4), b in 8-pixel steps through v_dotprod pairs
+ *                        (pixel i with pixel i+4, exact int32) converted to f32 and added into two 4-lane vectors,
+ *                        the 31 - 24 = 7 tail columns of every row in the scalar float accumulator, v_reduce_sum =
+ *                        (a0 + a2) + (a1 + a3)
+ *   ORC_ACC_F32_SIMD128_FMA  the same with v_muladd fused (CV_FMA3 builds: -mfma / AVX2 baseline)
+ *   ORC_ACC_F32_SSE2_LEGACY  the hand-written `#if CV_SSE2` code of OpenCV 2.4 .. 4.0: A in 4-pixel steps
+ *                        (_mm_add_ps(q, _mm_mul_ps(f, f))), 3 tail columns, buf[0] + buf[1] + buf[2] + buf[3]; b as above
+ *   ORC_ACC_F32_WIDE8    NOT an OpenCV code path (LKTrackerInvoker is written with 128-bit types and stays 4-lane in
+ *                        AVX2 builds): an 8-lane order, included as a sensitivity probe only
+ * The CV_NEON block (ARM builds) is not restated. The modes differ ONLY in the five sums; everything else is shared.
  */
 #include <math.h>
 #include <stdint.h>
@@ -242,12 +260,92 @@ static inline void bilinear_weights(float a, float b, int *iw00, int *iw01, int 
     *iw11 = (1 << W_BITS) - *iw00 - *iw01 - *iw10;
 }
 
+
+enum { ORC_ACC_INT64 = 0, ORC_ACC_F32_SCALAR = 1, ORC_ACC_F32_SIMD128 = 2, ORC_ACC_F32_SIMD128_FMA = 3,
+       ORC_ACC_F32_SSE2_LEGACY = 4, ORC_ACC_F32_WIDE8 = 5, ORC_ACC_MODES = 6 };
+
+/* A11/A12/A22 of one window in the float order of `mode` (lkpyramid.cpp LKTrackerInvoker, "extract the patch from the
+ * first image, compute covariation matrix of derivatives"). dI = interleaved [Ix, Iy] int16, row-major win x win. */
+static void acc_A_f32(int mode, const int16_t *dI, int win, float *A11, float *A12, float *A22)
+{
+    float s11 = 0.f, s12 = 0.f, s22 = 0.f;                   /* `acctype iA11` = float: the scalar (tail) accumulator */
+    const int lanes = mode == ORC_ACC_F32_WIDE8 ? 8 : 4;
+    const int step = mode == ORC_ACC_F32_SSE2_LEGACY ? 4 : 8;   /* pixels consumed per SIMD loop trip */
+    float q11[8] = {0}, q12[8] = {0}, q22[8] = {0};
+    const int fused = mode == ORC_ACC_F32_SIMD128_FMA;
+    for (int y = 0; y < win; y++) {
+        int x = 0;
+        if (mode != ORC_ACC_F32_SCALAR)
+            for (; x <= win - step; x += step)
+                for (int g = 0; g < step; g += lanes)          /* SIMD128: two 4-lane groups per trip, first pixels x..x+3 */
+                    for (int l = 0; l < lanes; l++) {
+                        const float fx = (float)dI[2 * (y * win + x + g + l)], fy = (float)dI[2 * (y * win + x + g + l) + 1];
+                        if (fused) { q22[l] = fmaf(fy, fy, q22[l]); q12[l] = fmaf(fx, fy, q12[l]); q11[l] = fmaf(fx, fx, q11[l]); }
+                        else { q22[l] = q22[l] + fy * fy; q12[l] = q12[l] + fx * fy; q11[l] = q11[l] + fx * fx; }
+                    }
+        for (; x < win; x++) {                                  /* iA11 += (itemtype)(ixval*ixval) */
+            const int ix = dI[2 * (y * win + x)], iy = dI[2 * (y * win + x) + 1];
+            s11 += (float)(ix * ix); s12 += (float)(ix * iy); s22 += (float)(iy * iy);
+        }
+    }
+    if (mode == ORC_ACC_F32_SIMD128 || mode == ORC_ACC_F32_SIMD128_FMA) {        /* iA11 += v_reduce_sum(qA11) */
+        s11 += (q11[0] + q11[2]) + (q11[1] + q11[3]); s12 += (q12[0] + q12[2]) + (q12[1] + q12[3]);
+        s22 += (q22[0] + q22[2]) + (q22[1] + q22[3]);
+    } else if (mode == ORC_ACC_F32_SSE2_LEGACY) {                                /* iA11 += buf[0] + buf[1] + buf[2] + buf[3] */
+        s11 += q11[0] + q11[1] + q11[2] + q11[3]; s12 += q12[0] + q12[1] + q12[2] + q12[3]; s22 += q22[0] + q22[1] + q22[2] + q22[3];
+    } else if (mode == ORC_ACC_F32_WIDE8) {                                      /* halves folded, then the 4-lane reduce */
+        float h11[4], h12[4], h22[4];
+        for (int l = 0; l < 4; l++) { h11[l] = q11[l] + q11[l + 4]; h12[l] = q12[l] + q12[l + 4]; h22[l] = q22[l] + q22[l + 4]; }
+        s11 += (h11[0] + h11[2]) + (h11[1] + h11[3]); s12 += (h12[0] + h12[2]) + (h12[1] + h12[3]); s22 += (h22[0] + h22[2]) + (h22[1] + h22[3]);
+    }
+    *A11 = s11; *A12 = s12; *A22 = s22;
+}
+
+/* b1/b2 of one iteration: diff = It (int, |diff| <= 8160) per pixel, row-major win x win, against dI. In every SIMD variant
+ * v_dotprod / _mm_madd_epi16 forms It_i*I_i + It_(i+4)*I_(i+4) exactly in int32 (i = 0..3 of an 8-pixel step), converts that to
+ * f32 and adds it into lane pair (qb0: i = 0, 1; qb1: i = 2, 3); the end is (qb0 + qb1) lane-wise, then lanes 0 + 2 (x) and
+ * 1 + 3 (y) added to the scalar tail accumulator. */
+static void acc_b_f32(int mode, const int *diff, const int16_t *dI, int win, float *b1, float *b2)
+{
+    float sb1 = 0.f, sb2 = 0.f;
+    float qx[8] = {0}, qy[8] = {0};                             /* [0..1] = qb0's pixel pairs, [2..3] = qb1's (WIDE8: 8 pairs) */
+    const int half = mode == ORC_ACC_F32_WIDE8 ? 8 : 4, step = 2 * half;
+    for (int y = 0; y < win; y++) {
+        int x = 0;
+        if (mode != ORC_ACC_F32_SCALAR)
+            for (; x <= win - step; x += step)
+                for (int i = 0; i < half; i++) {
+                    const int p0 = y * win + x + i, p1 = p0 + half;
+                    qx[i] = qx[i] + (float)(diff[p0] * dI[2 * p0] + diff[p1] * dI[2 * p1]);
+                    qy[i] = qy[i] + (float)(diff[p0] * dI[2 * p0 + 1] + diff[p1] * dI[2 * p1 + 1]);
+                }
+        for (; x < win; x++) {
+            const int p = y * win + x;
+            sb1 += (float)(diff[p] * dI[2 * p]); sb2 += (float)(diff[p] * dI[2 * p + 1]);
+        }
+    }
+    if (mode == ORC_ACC_F32_WIDE8) {
+        for (int i = 0; i < 4; i++) { qx[i] = qx[i] + qx[i + 4]; qy[i] = qy[i] + qy[i + 4]; }
+    }
+    if (mode != ORC_ACC_F32_SCALAR) {
+        /* qb0 + qb1: lanes [x(0)+x(2), y(0)+y(2), x(1)+x(3), y(1)+y(3)]; reduce: lane0 + lane2 / lane1 + lane3 */
+        sb1 += (qx[0] + qx[2]) + (qx[1] + qx[3]);
+        sb2 += (qy[0] + qy[2]) + (qy[1] + qy[3]);
+    }
+    *b1 = sb1; *b2 = sb2;
+}
+
+/* test hooks: the two accumulations on a caller-supplied window (tests/test_oracle_lk_accumulators.py pins them to an
+ * independent numpy binary32 evaluation of the same lane orders) */
+void orc_lk_acc_A(int mode, const int16_t *dI, int win, float *out3) { acc_A_f32(mode, dI, win, out3, out3 + 1, out3 + 2); }
+void orc_lk_acc_b(int mode, const int *diff, const int16_t *dI, int win, float *out2) { acc_b_f32(mode, diff, dI, win, out2, out2 + 1); }
+
 /* One pyramid level of LKTrackerInvoker::operator() for all points.
  * iters_out (optional): Gauss-Newton iterations executed per point at this level. */
 static void lk_level(const orc_level *I, const orc_level *J, int npts,
                      const float *prev_pts, float *next_pts, uint8_t *status, float *err,
                      int win, int level, int max_level, int max_count, double epsilon,
-                     int flags, float min_eig_threshold, int *iters_out)
+                     int flags, float min_eig_threshold, int *iters_out, int acc_mode)
 {
     const float half_win = (float)(win - 1) * 0.5f;
     const float FLT_SCALE = 1.f / (float)(1 << 20);
@@ -255,6 +353,7 @@ static void lk_level(const orc_level *I, const orc_level *J, int npts,
     {
     int16_t *Iwin = (int16_t *)malloc(sizeof(int16_t) * (size_t)win * win);
     int16_t *dIwin = (int16_t *)malloc(sizeof(int16_t) * (size_t)win * win * 2);
+    int *diffwin = (int *)malloc(sizeof(int) * (size_t)win * win);
 
 #pragma omp for schedule(dynamic, 4)
     for (int pt = 0; pt < npts; pt++) {
@@ -305,7 +404,11 @@ static void lk_level(const orc_level *I, const orc_level *J, int npts,
             }
         }
 
-        const float A11 = (float)iA11 * FLT_SCALE, A12 = (float)iA12 * FLT_SCALE, A22 = (float)iA22 * FLT_SCALE;
+        float A11 = (float)iA11 * FLT_SCALE, A12 = (float)iA12 * FLT_SCALE, A22 = (float)iA22 * FLT_SCALE;
+        if (acc_mode != ORC_ACC_INT64) {
+            acc_A_f32(acc_mode, dIwin, win, &A11, &A12, &A22);
+            A11 *= FLT_SCALE; A12 *= FLT_SCALE; A22 *= FLT_SCALE;
+        }
         float D = A11 * A22 - A12 * A12;
         const float min_eig = (A22 + A11 - sqrtf((A11 - A22) * (A11 - A22) + 4.f * A12 * A12)) /
                               (float)(2 * win * win);
@@ -338,9 +441,14 @@ static void lk_level(const orc_level *I, const orc_level *J, int npts,
                                              J1[x] * iw10 + J1[x + 1] * iw11, W_BITS - 5) - Iwin[y * win + x];
                     ib1 += (int64_t)(diff * dIwin[2 * (y * win + x)]);
                     ib2 += (int64_t)(diff * dIwin[2 * (y * win + x) + 1]);
+                    diffwin[y * win + x] = diff;
                 }
             }
-            const float b1 = (float)ib1 * FLT_SCALE, b2 = (float)ib2 * FLT_SCALE;
+            float b1 = (float)ib1 * FLT_SCALE, b2 = (float)ib2 * FLT_SCALE;
+            if (acc_mode != ORC_ACC_INT64) {
+                acc_b_f32(acc_mode, diffwin, dIwin, win, &b1, &b2);
+                b1 *= FLT_SCALE; b2 *= FLT_SCALE;
+            }
             const float dx = (float)((A12 * b2 - A22 * b1) * D);
             const float dy = (float)((A12 * b1 - A11 * b2) * D);
 
@@ -379,7 +487,7 @@ static void lk_level(const orc_level *I, const orc_level *J, int npts,
             err[pt] = errval * 1.f / (float)(32 * win * win);
         }
     }
-    free(Iwin); free(dIwin);
+    free(Iwin); free(dIwin); free(diffwin);
     }
 }
 
@@ -396,12 +504,27 @@ int orc_set_threads(int n) { (void)n; return 1; }
  * (reference call site: src/tracker/optical_flow.cpp:46-49).
  * next_pts is in/out (input only when flags & ORC_USE_INITIAL_FLOW).
  * iters_out (optional): [nlevels][npts] iteration counts (level-major). */
+int orc_klt_track_mode(const orc_pyramid *prev, const orc_pyramid *next, int npts,
+                       const float *prev_pts, float *next_pts, uint8_t *status, float *err,
+                       int win, int max_level, int max_count, double eps, int flags,
+                       double min_eig_threshold, int *iters_out, int acc_mode);
+
 int orc_klt_track(const orc_pyramid *prev, const orc_pyramid *next, int npts,
                   const float *prev_pts, float *next_pts, uint8_t *status, float *err,
                   int win, int max_level, int max_count, double eps, int flags,
                   double min_eig_threshold, int *iters_out)
 {
-    if (!prev || !next) return -1;
+    return orc_klt_track_mode(prev, next, npts, prev_pts, next_pts, status, err, win, max_level, max_count, eps, flags,
+                              min_eig_threshold, iters_out, ORC_ACC_INT64);
+}
+
+/* acc_mode: ORC_ACC_* (see the header). ORC_ACC_INT64 is the oracle the HIP kernel is checked against. */
+int orc_klt_track_mode(const orc_pyramid *prev, const orc_pyramid *next, int npts,
+                       const float *prev_pts, float *next_pts, uint8_t *status, float *err,
+                       int win, int max_level, int max_count, double eps, int flags,
+                       double min_eig_threshold, int *iters_out, int acc_mode)
+{
+    if (!prev || !next || acc_mode < 0 || acc_mode >= ORC_ACC_MODES) return -1;
     if (max_level > prev->nlevels - 1) max_level = prev->nlevels - 1;
     if (max_level > next->nlevels - 1) max_level = next->nlevels - 1;
     if (max_count < 0) max_count = 0;
@@ -413,7 +536,7 @@ int orc_klt_track(const orc_pyramid *prev, const orc_pyramid *next, int npts,
     for (int level = max_level; level >= 0; level--) {
         lk_level(&prev->lv[level], &next->lv[level], npts, prev_pts, next_pts, status, err,
                  win, level, max_level, max_count, epsilon, flags, (float)min_eig_threshold,
-                 iters_out ? iters_out + (size_t)level * npts : NULL);
+                 iters_out ? iters_out + (size_t)level * npts : NULL, acc_mode);
     }
     return 0;
 }
