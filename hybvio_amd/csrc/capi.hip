@@ -1,6 +1,7 @@
 // extern "C" entry points of libhybvio_hip.so (see include/hybvio_hip.h): context, pyramid
 // pool, host-pointer convenience paths, per-kernel timers.
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <new>
@@ -37,6 +38,9 @@ ScopedKernelTime::~ScopedKernelTime()
 
 namespace {
 
+// LK tile loads of a padded level may run a few bytes past the last row of the last slot (unused tile cells)
+constexpr size_t SLAB_SLACK = 4096;
+
 inline int align_up(int v, int a) { return (v + a - 1) / a * a; }
 inline long long align_up_ll(long long v, long long a) { return (v + a - 1) / a * a; }
 
@@ -60,16 +64,22 @@ int compute_layout(const hv_params &p, PyrLayout &L)
         if (w <= p.win || h <= p.win) break;
     }
     L.levels = n;
+    // HV_PAD_FROM_LEVEL (environment, experiments only): first level with a physical border; >= levels turns it off
+    int pad_from = 2;
+    if (const char *e = getenv("HV_PAD_FROM_LEVEL")) pad_from = atoi(e);
+    if (pad_from < 1) pad_from = 1;                     // level 0 may be the caller's image: never padded
     long long off = 0;
     for (int l = 0; l < n; ++l) {
-        L.gstride[l] = align_up(L.w[l], 16);
-        L.goff[l] = off;
-        off = align_up_ll(off + (long long)L.gstride[l] * L.h[l], 256);
+        const int pd = L.pad[l] = l >= pad_from ? PYR_PAD : 0;
+        L.gstride[l] = align_up(L.w[l] + 2 * pd, 16);
+        L.goff[l] = off + (long long)pd * L.gstride[l] + pd;
+        off = align_up_ll(off + (long long)L.gstride[l] * (L.h[l] + 2 * pd), 256);
     }
     for (int l = 0; l < n; ++l) {
-        L.dstride[l] = align_up(L.w[l], 4);
-        L.doff[l] = off;
-        off = align_up_ll(off + (long long)L.dstride[l] * 4 * L.h[l], 256);
+        const int pd = L.pad[l];
+        L.dstride[l] = align_up(L.w[l] + 2 * pd, 4);
+        L.doff[l] = off + ((long long)pd * L.dstride[l] + pd) * 4;
+        off = align_up_ll(off + (long long)L.dstride[l] * 4 * (L.h[l] + 2 * pd), 256);
     }
     L.slot_bytes = off;
     return HV_OK;
@@ -116,7 +126,7 @@ int grow_pool(Ctx *c)
     const long long old_bytes = c->L.slot_bytes * n_old;
     HV_HIP(c, hipStreamSynchronize(c->stream));
     uint8_t *slab = nullptr; const uint8_t **l0p = nullptr; int *l0s = nullptr;
-    if (hipMalloc(&slab, (size_t)c->L.slot_bytes * n_new) != hipSuccess) return HV_ERR_NOMEM;
+    if (hipMalloc(&slab, (size_t)c->L.slot_bytes * n_new + SLAB_SLACK) != hipSuccess) return HV_ERR_NOMEM;
     if (hipMalloc(&l0p, sizeof(void *) * n_new) != hipSuccess) { (void)hipFree(slab); return HV_ERR_NOMEM; }
     if (hipMalloc(&l0s, sizeof(int) * n_new) != hipSuccess) { (void)hipFree(slab); (void)hipFree(l0p); return HV_ERR_NOMEM; }
     hipError_t e = hipMemcpyAsync(slab, c->slab, (size_t)old_bytes, hipMemcpyDeviceToDevice, c->stream);
@@ -132,7 +142,7 @@ int grow_pool(Ctx *c)
     c->slot_used.resize(n_new, 0);
     for (int s = n_new - 1; s >= n_old; --s) c->free_slots.push_back(s);
     c->p.pool_size = n_new;
-    return HV_OK;
+    return fill_gradient_borders(c, n_old, n_new - n_old);
 }
 
 }  // namespace
@@ -207,7 +217,7 @@ int hv_create(const hv_params *params, hv_ctx **out)
         if (hipSetDevice(p.device) != hipSuccess) { rc = HV_ERR_NO_DEVICE; break; }
         if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { rc = HV_ERR_HIP; break; }
         c->own_stream = true;
-        const size_t slab_bytes = (size_t)c->L.slot_bytes * p.pool_size;
+        const size_t slab_bytes = (size_t)c->L.slot_bytes * p.pool_size + hv::SLAB_SLACK;
         if (hipMalloc(&c->slab, slab_bytes) != hipSuccess) { rc = HV_ERR_NOMEM; break; }
         if (hipMalloc(&c->d_l0_ptr, sizeof(void *) * p.pool_size) != hipSuccess) { rc = HV_ERR_NOMEM; break; }
         if (hipMalloc(&c->d_l0_stride, sizeof(int) * p.pool_size) != hipSuccess) { rc = HV_ERR_NOMEM; break; }
@@ -216,6 +226,7 @@ int hv_create(const hv_params *params, hv_ctx **out)
         c->slot_used.assign(p.pool_size, 0);
         for (int s = p.pool_size - 1; s >= 0; --s) c->free_slots.push_back(s);
         rc = hv::ensure_point_staging(c, p.max_tracks);
+        if (rc == HV_OK) rc = hv::fill_gradient_borders(c, 0, p.pool_size);
     } while (0);
     if (rc != HV_OK) { hv_destroy(h); return rc; }
     *out = h;

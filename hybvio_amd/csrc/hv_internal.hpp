@@ -16,9 +16,15 @@ namespace hv {
 //                       table (l0_ptr / l0_stride) says which.
 //   gradient level l  : one dword per pixel = int16 4*dx+2 | int16 (4*dy+2) << 16, row stride
 //                       dstride[l] dwords (multiple of 4), at doff[l]
+//   levels l >= pad_from (default 2; never level 0) carry a PHYSICAL border of pad[l] = 32 pixels on every side, the one
+//   OpenCV's padded pyramid holds: BORDER_REFLECT_101 for gray (pyr_border_kernel, per build), the constant 0 -- stored as
+//   4*0+2 -- for gradients (written once per slot). goff / doff still address pixel (0, 0); strides include the border.
+//   At the coarse levels most LK windows cross the image edge (68 % at level 3 of 752x480); with the border in memory the
+//   tracker takes its border-free paths there. Levels 0 and 1 (94 % of the pyramid bytes) keep virtual borders.
 struct PyrLayout {
     int levels;
     int win;
+    int pad[HV_MAX_LEVELS];
     int w[HV_MAX_LEVELS], h[HV_MAX_LEVELS];
     int gstride[HV_MAX_LEVELS];
     int dstride[HV_MAX_LEVELS];
@@ -85,6 +91,8 @@ struct ScopedKernelTime {
 };
 
 // pyramid.hip
+constexpr int PYR_PAD = 32;            // physical border width of the padded levels (window 31 + the pair column)
+int fill_gradient_borders(Ctx *c, int first_slot, int n_slots);   // once per slot (create / grow)
 int launch_pyramid_levels(Ctx *c, int n, const int *slots_dev, const uint8_t *src_base,
                           long long src_step, int src_stride, bool src_indexed_by_slot);
 // vu_prepare.hip: triangulation + prepareVisualUpdate of one track per filter

@@ -24,6 +24,7 @@
 // The per-point float sequence (weights, 2x2 solve, termination tests) is evaluated redundantly
 // by all lanes in IEEE binary32 without FMA contraction (-ffp-contract=off).
 #include <float.h>
+#include <stdlib.h>
 
 #include "hv_internal.hpp"
 
@@ -33,16 +34,18 @@ namespace {
 
 constexpr int WIN = 31;
 constexpr int HALF_ROWS = 16;          // rows per half-wave
-constexpr int TS = 44;                 // staged J tile: TS x TS pixels (one dword each): 10 KB of LDS per wave with `region`
-constexpr int RW = 48;                 // width of the in-image region used to build border tiles
+// staged J tile: TSX x TSY pixels (one dword each) around the 32 x 32 window, MX / MY pixels of slack on the low side (the
+// rest on the high side); restaged only when an iteration moves the window out of it. Template parameters of the kernel:
+// {44, 44, 6, 6} is the r01 shape (10 KB of LDS per wave with `region`), smaller tiles cost less to stage.
+constexpr int RW = 48;                 // width of the in-image region used to build border tiles (>= TSX + 4)
 static_assert(RW / 4 == 12, "the region staging loop divides by 12 with a 24-bit multiply");
 constexpr int GRAY_SHIFT = 7;          // gray samples are pre-scaled by 128 (<= 32640: fits int16)
 // The four bilinear weights always sum to 2^14, so adding 2 to every pre-scaled sample adds exactly
 // 2^15 to the weighted sum: the rounding constant of CV_DESCALE rides along in the data and every
 // dot2 chain starts from 0. Gradients are stored as 4*d + 2 for the same reason (pyramid.hip).
 constexpr uint32_t ROUND_PAIR = 0x00020002u;
-constexpr int MARGIN = 6;
 constexpr int W_BITS = 14;
+constexpr int KLT_TILE_DEFAULT = 5;
 
 struct KltArgs {
     PyrLayout L;
@@ -119,21 +122,28 @@ __device__ __forceinline__ bool all_small(int a, int b, int c)
     return __builtin_amdgcn_ballot_w64(t >= 2 * C) == 0;
 }
 
+// cv: iw00 = cvRound((1-a)(1-b) 2^14), iw01 = cvRound(a (1-b) 2^14), iw10 = cvRound((1-a) b 2^14), iw11 = 2^14 - the rest.
+// Scaling by 2^14 is exact in binary32 (no product here is subnormal), so it is applied to (1-b) and b once instead of to the
+// three products; cvRound (round-half-even) of 0 <= x <= 2^14 is the low half of the bit pattern of x + 1.5 * 2^23 (the add
+// rounds to the integer grid, ties to even), which is also where v_perm picks the packed weights from: 18 VALU, was 28.
 __device__ __forceinline__ void bilinear_weights(float a, float b, uint32_t &wA, uint32_t &wB)
 {
-    const int iw00 = __float2int_rn((1.f - a) * (1.f - b) * (float)(1 << W_BITS));
-    const int iw01 = __float2int_rn(a * (1.f - b) * (float)(1 << W_BITS));
-    const int iw10 = __float2int_rn((1.f - a) * b * (float)(1 << W_BITS));
-    const int iw11 = (1 << W_BITS) - iw00 - iw01 - iw10;
-    wA = pack16(iw00, iw01);     // top row weights
-    wB = pack16(iw10, iw11);     // bottom row weights
+    const float MAGIC = 12582912.f;                        // 0x4B400000
+    const float a1 = 1.f - a, b1 = 1.f - b;
+    const float b1s = b1 * (float)(1 << W_BITS), bs = b * (float)(1 << W_BITS);
+    const uint32_t f00 = __float_as_uint(a1 * b1s + MAGIC), f01 = __float_as_uint(a * b1s + MAGIC), f10 = __float_as_uint(a1 * bs + MAGIC);
+    const uint32_t i11 = (uint32_t)(1 << W_BITS) + 3u * 0x4B400000u - (f00 + f01 + f10);   // mod 2^32: the three biases cancel
+    wA = lo16_pair(f00, f01);    // top row weights (iw00, iw01)
+    wB = lo16_pair(f10, i11);    // bottom row weights (iw10, iw11)
 }
 
-__global__ __launch_bounds__(64, 4) void klt_kernel(KltArgs a)
+template <int TSX, int TSY, int MX, int MY, int WPS>
+__global__ __launch_bounds__(64, WPS) void klt_kernel(KltArgs a)
 {
+    static_assert(TSX % 4 == 0 && TSX + 4 <= RW && TSX >= 32 + MX + 3 && TSY >= 32 + MY, "tile must hold the window at any alignment");
     // one dword per pixel: (J[x] << 7) | (J[x+1] << 23); +1 row for the unused 17th row of half 1
-    __shared__ __attribute__((aligned(16))) uint32_t jt[(TS + 1) * TS];
-    __shared__ __attribute__((aligned(16))) uint32_t region[TS * (RW / 4)];   // raw bytes, border tiles only
+    __shared__ __attribute__((aligned(16))) uint32_t jt[(TSY + 1) * TSX];
+    __shared__ __attribute__((aligned(16))) uint32_t region[TSY * (RW / 4)];   // raw bytes, border tiles only
 
     const int pt = (int)xcd_remap(blockIdx.x, gridDim.x);
     const int lane = threadIdx.x;
@@ -150,6 +160,11 @@ __global__ __launch_bounds__(64, 4) void klt_kernel(KltArgs a)
     float2 guess = make_float2(0.f, 0.f);
     if (a.use_init) guess = a.next_xy[pt];
 
+    // fast tile staging: lane (st_lr, st_c) = row-in-pass, 4-pixel group; lanes beyond RPI * G repeat the last item
+    constexpr int G = TSX / 4, RPI = 64 / G, NIT = TSY / RPI;
+    static_assert(TSY % RPI == 0, "whole passes: no row clamp in the staging loop");
+    const int st_ln = min(lane, RPI * G - 1), st_lr = st_ln / G, st_c = st_ln - st_lr * G;
+    const int st_loff = st_lr * TSX + 4 * st_c;
     const float half_win = (float)(WIN - 1) * 0.5f;
     const float FLT_SCALE = 1.f / (float)(1 << 20);
     const float eps_lo = (float)(a.epsilon * (1.0 - 1e-5)), eps_hi = (float)(a.epsilon * (1.0 + 1e-5));
@@ -191,6 +206,48 @@ __global__ __launch_bounds__(64, 4) void klt_kernel(KltArgs a)
         Igs = __builtin_amdgcn_readfirstlane(Igs); Jgs = __builtin_amdgcn_readfirstlane(Jgs);   // wave-uniform: keep them in SGPRs
         const gptr_u32 Id = (gptr_u32)as_global(prev_base + L.doff[level]);
         const int Ids = __builtin_amdgcn_readfirstlane(L.dstride[level]);
+        // levels with a physical 32-px border (REFLECT_101 gray, zero gradients in memory, see PyrLayout): every window the
+        // range test above lets through lies inside the padded rectangle, so the border-free paths serve all of them
+        const bool padded = L.pad[level] != 0;                                             // wave-uniform
+
+        // ---- J tile bookkeeping (declared before the template: on the common path the first tile of the level is requested
+        // together with the template rows, one memory round trip per level instead of three) ----
+        float cxn = nx - half_win, cyn = ny - half_win;
+        int tox = -(1 << 28), toy = -(1 << 28);
+        const unsigned st_goff = __umul24((unsigned)st_lr, (unsigned)Jgs) + 4u * (unsigned)st_c;   // lane part of the staging loads
+        const bool j_aligned = ((reinterpret_cast<uintptr_t>(Jg) | (uintptr_t)Jgs) & 3u) == 0;
+        // origin of the tile that holds window (ix, iy); true when the plain coalesced staging loop can load it
+        auto plan_tile = [&](int ix, int iy, int &ox, int &oy) -> bool {
+            ox = (ix - MX) & ~3; oy = iy - MY;
+            // keep the (TSX+4) x TSY load footprint inside the image whenever the window allows it, so
+            // only windows that really cross the border take the reflecting path
+            const int bp = padded ? PYR_PAD : 0;                 // the rectangle that exists in memory: [-bp, w + bp) x [-bp, h + bp)
+            const int cx0 = min(max(ox, -bp), (w + bp - TSX - 4) & ~3), cy0 = min(max(oy, -bp), h + bp - TSY);
+            if (w + 2 * bp >= TSX + 4 && h + 2 * bp >= TSY && ix >= cx0 && ix + 32 <= cx0 + TSX && iy >= cy0 && iy + 32 <= cy0 + TSY) {
+                ox = cx0; oy = cy0;
+            }
+            // padded level: where the clamp above cannot hold the window (right edge, ix > w + bp - 36) the load footprint runs a
+            // few bytes past the row into the next row / the slab slack; those tile cells are never read by a window lane
+            return j_aligned && (padded || (ox >= 0 && ox + TSX + 4 <= w && oy >= 0 && oy + TSY <= h));
+        };
+        // G = TSX / 4 lanes cover a tile row (8 source bytes -> 4 pixel pairs each), RPI = 64 / G rows per pass: pass i of
+        // lane (lr, c) is row i * RPI + lr. The per-pass part of both addresses is scalar (row base) resp. an immediate
+        // (LDS offset); the per-lane part (st_goff, st_loff) is formed once per level. r01 stepped a flat item index
+        // through the tile instead: ~9 VALU of index arithmetic per item, 163 per staging against ~9 per pass here.
+        auto tile_request = [&](uint2 (&raw)[NIT]) {
+#pragma unroll
+            for (int i = 0; i < NIT; ++i) {
+                const long long rowbase = (long long)((toy + i * RPI) * Jgs + tox);                          // scalar, signed
+                __builtin_memcpy(&raw[i], (const void *)(uintptr_t)(Jg + rowbase + st_goff), 8);
+            }
+        };
+        auto tile_commit = [&](const uint2 (&raw)[NIT]) {
+#pragma unroll
+            for (int i = 0; i < NIT; ++i)
+                *reinterpret_cast<uint4 *>(&jt[st_loff + i * RPI * TSX]) =
+                    make_uint4(scaled_pair<0>(raw[i].x, raw[i].y), scaled_pair<1>(raw[i].x, raw[i].y),
+                               scaled_pair<2>(raw[i].x, raw[i].y), scaled_pair<3>(raw[i].x, raw[i].y));
+        };
 
         // ---- template patch: bilinear samples of I and dI into registers, A = sum(dI dI^T) ----
         // packed int16 pairs (window rows 2m, 2m+1 of this lane): value, x-gradient, y-gradient
@@ -201,16 +258,77 @@ __global__ __launch_bounds__(64, 4) void klt_kernel(KltArgs a)
             bilinear_weights(px - (float)ipx, py - (float)ipy, wA, wB);
             if (!col_ok) { wA = 0; wB = 0; }          // zero weights => every sample of this lane is 0
             const int xa = ipx + cx;
-            const bool inside = ipx >= 0 && ipx + 32 <= w && ipy >= 0 && ipy + 32 <= h;   // wave-uniform
+            const bool inside = padded || (ipx >= 0 && ipx + 32 <= w && ipy >= 0 && ipy + 32 <= h);   // wave-uniform
             // per-lane part of every address; the per-row part is a scalar base (no VALU per load)
-            const unsigned vg = __umul24((unsigned)(half * HALF_ROWS), (unsigned)Igs) + (unsigned)xa;      // rows and strides < 2^24:
-            const unsigned vd = __umul24((unsigned)(half * HALF_ROWS), (unsigned)Ids) + (unsigned)xa;      // full-rate v_mul_u32_u24
+            // (on a padded level ipx / ipy may be negative: the signed part of every address is the scalar row base, the lane part
+            // -- an unsigned VGPR offset of the saddr addressing mode -- stays >= 0)
+            const unsigned vg = __umul24((unsigned)(half * HALF_ROWS), (unsigned)Igs) + (unsigned)cx;      // rows and strides < 2^24:
+            const unsigned vd = __umul24((unsigned)(half * HALF_ROWS), (unsigned)Ids) + (unsigned)cx;      // full-rate v_mul_u32_u24
+
+            // DESCALE(s, 9) == (128 s + 32768) >> 16 and DESCALE(s, 14) == (4 s + 32768) >> 16: the
+            // inputs are pre-scaled by 128 / 4 and carry the +2 that sums to 32768, so each sample is
+            // the high half of one dot2 chain started from 0. Rows r0 .. r0 + nk of the pre-scaled packed pairs -> window rows
+            // r0 .. r0 + nk - 1 (r0 even).
+            int vi_prev = 0, vx_prev = 0, vy_prev = 0;
+            auto window_row = [&](int k, uint32_t g0, uint32_t g1, uint32_t dx0, uint32_t dx1, uint32_t dy0, uint32_t dy1) {
+                const uint32_t wAk = (k == HALF_ROWS - 1 && half) ? 0u : wA;   // row 31 does not exist
+                const uint32_t wBk = (k == HALF_ROWS - 1 && half) ? 0u : wB;
+                const int vi = dot2(g1, wBk, dot2(g0, wAk, 0));
+                const int vx = dot2(dx1, wBk, dot2(dx0, wAk, 0));
+                const int vy = dot2(dy1, wBk, dot2(dy0, wAk, 0));
+                if (k & 1) {
+                    const int m = k >> 1;
+                    Ivp[m] = hi16_pair((uint32_t)vi_prev, (uint32_t)vi);
+                    IXp[m] = hi16_pair((uint32_t)vx_prev, (uint32_t)vx);
+                    IYp[m] = hi16_pair((uint32_t)vy_prev, (uint32_t)vy);
+                    sA11 = dot2(IXp[m], IXp[m], sA11);
+                    sA12 = dot2(IXp[m], IYp[m], sA12);
+                    sA22 = dot2(IYp[m], IYp[m], sA22);
+                }
+                vi_prev = vi; vx_prev = vx; vy_prev = vy;
+            };
+
+            // Where will the first iteration look? If that window's tile can be loaded by the plain staging loop, its loads are
+            // issued FIRST, then all 17 template rows (63 VGPRs in flight): by the time the template rows are back the tile is
+            // too, and the level has cost one HBM round trip. (A tile wasted on a level that fails the eigenvalue test is rare.)
+            bool early = false;
+            if (inside && a.max_count > 0) {
+                const int inx0 = __builtin_amdgcn_readfirstlane((int)floorf(cxn)), iny0 = __builtin_amdgcn_readfirstlane((int)floorf(cyn));
+                if (!(inx0 < -WIN || inx0 >= w || iny0 < -WIN || iny0 >= h)) {
+                    int ox, oy;
+                    early = plan_tile(inx0, iny0, ox, oy);
+                    if (early) { tox = ox; toy = oy; }
+                }
+            }
+            if (early) {
+                constexpr int NR = HALF_ROWS + 1;
+                uint2 raw[NIT];
+                uint16_t graw[NR];
+                uint2 draw[NR];
+                tile_request(raw);
+#pragma unroll
+                for (int r = 0; r < NR; ++r) {
+                    const gptr_u8 grow = Ig + (long long)((ipy + r) * Igs + ipx);                 // scalar, signed
+                    const gptr_u32 drow = Id + (long long)((ipy + r) * Ids + ipx);
+                    __builtin_memcpy(&graw[r], (const void *)(uintptr_t)(grow + vg), 2);
+                    __builtin_memcpy(&draw[r], (const void *)(uintptr_t)(drow + vd), 8);
+                }
+                __builtin_amdgcn_sched_barrier(0);       // everything in flight before the first use
+                tile_commit(raw);
+                uint32_t g0 = scaled_pair<0>((uint32_t)graw[0], 0u), dx0 = lo16_pair(draw[0].x, draw[0].y), dy0 = hi16_pair(draw[0].x, draw[0].y);
+#pragma unroll
+                for (int k = 0; k < HALF_ROWS; ++k) {
+                    const uint32_t g1 = scaled_pair<0>((uint32_t)graw[k + 1], 0u);
+                    const uint32_t dx1 = lo16_pair(draw[k + 1].x, draw[k + 1].y), dy1 = hi16_pair(draw[k + 1].x, draw[k + 1].y);
+                    window_row(k, g0, g1, dx0, dx1, dy0, dy1);
+                    g0 = g1; dx0 = dx1; dy0 = dy1;
+                }
+            } else {
             const unsigned gxa = (unsigned)reflect101(xa, w), gxb = (unsigned)reflect101(xa + 1, w);
             const bool ina = (unsigned)xa < (unsigned)w, inb = (unsigned)(xa + 1) < (unsigned)w;
-
             // The 17 source rows are processed in two batches of 9 (rows 0-8, 8-16): all loads of a
             // batch are issued before the first use (one memory round trip each) while the in-flight
-            // registers stay below what 4 waves per SIMD allow.
+            // registers stay within the budget of the border path (4 loads per row).
             constexpr int NB = HALF_ROWS / 2 + 1;
 #pragma unroll
             for (int batch = 0; batch < 2; ++batch) {
@@ -221,8 +339,8 @@ __global__ __launch_bounds__(64, 4) void klt_kernel(KltArgs a)
                     uint2 draw[NB];
 #pragma unroll
                     for (int r = 0; r < NB; ++r) {
-                        const gptr_u8 grow = Ig + (unsigned)(ipy + r0 + r) * (unsigned)Igs;      // scalar
-                        const gptr_u32 drow = Id + (unsigned)(ipy + r0 + r) * (unsigned)Ids;
+                        const gptr_u8 grow = Ig + (long long)((ipy + r0 + r) * Igs + ipx);        // scalar, signed
+                        const gptr_u32 drow = Id + (long long)((ipy + r0 + r) * Ids + ipx);
                         __builtin_memcpy(&graw[r], (const void *)(uintptr_t)(grow + vg), 2);
                         __builtin_memcpy(&draw[r], (const void *)(uintptr_t)(drow + vd), 8);
                     }
@@ -262,29 +380,10 @@ __global__ __launch_bounds__(64, 4) void klt_kernel(KltArgs a)
                         dyp[r] = hi16_pair(qa, qb);
                     }
                 }
-                // DESCALE(s, 9) == (128 s + 32768) >> 16 and DESCALE(s, 14) == (4 s + 32768) >> 16: the
-                // inputs are pre-scaled by 128 / 4 and carry the +2 that sums to 32768, so each sample is
-                // the high half of one dot2 chain started from 0.
-                int vi_prev = 0, vx_prev = 0, vy_prev = 0;
 #pragma unroll
-                for (int kk = 0; kk < HALF_ROWS / 2; ++kk) {
-                    const int k = r0 + kk;
-                    const uint32_t wAk = (k == HALF_ROWS - 1 && half) ? 0u : wA;   // row 31 does not exist
-                    const uint32_t wBk = (k == HALF_ROWS - 1 && half) ? 0u : wB;
-                    const int vi = dot2(gp[kk + 1], wBk, dot2(gp[kk], wAk, 0));
-                    const int vx = dot2(dxp[kk + 1], wBk, dot2(dxp[kk], wAk, 0));
-                    const int vy = dot2(dyp[kk + 1], wBk, dot2(dyp[kk], wAk, 0));
-                    if (k & 1) {
-                        const int m = k >> 1;
-                        Ivp[m] = hi16_pair((uint32_t)vi_prev, (uint32_t)vi);
-                        IXp[m] = hi16_pair((uint32_t)vx_prev, (uint32_t)vx);
-                        IYp[m] = hi16_pair((uint32_t)vy_prev, (uint32_t)vy);
-                        sA11 = dot2(IXp[m], IXp[m], sA11);
-                        sA12 = dot2(IXp[m], IYp[m], sA12);
-                        sA22 = dot2(IYp[m], IYp[m], sA22);
-                    }
-                    vi_prev = vi; vx_prev = vx; vy_prev = vy;
-                }
+                for (int kk = 0; kk < HALF_ROWS / 2; ++kk)
+                    window_row(r0 + kk, gp[kk], gp[kk + 1], dxp[kk], dxp[kk + 1], dyp[kk], dyp[kk + 1]);
+            }
             }
         }
         float A11, A12, A22;
@@ -308,98 +407,61 @@ __global__ __launch_bounds__(64, 4) void klt_kernel(KltArgs a)
         }
         D = 1.f / D;
 
-        float cxn = nx - half_win, cyn = ny - half_win;
         float pdx = 0.f, pdy = 0.f;
-        int tox = -(1 << 28), toy = -(1 << 28);
-        const bool j_aligned = ((reinterpret_cast<uintptr_t>(Jg) | (uintptr_t)Jgs) & 3u) == 0;
 
-        // Stage the J tile covering window origin (ix, iy) with an 8 px margin. A single wavefront
+        // Stage the J tile covering window origin (ix, iy) with MX / MY px of slack. A single wavefront
         // issues its LDS accesses in order, so no workgroup barrier is needed.
         auto ensure_tile = [&](int ix, int iy) {
-            if (ix >= tox && ix + 32 <= tox + TS && iy >= toy && iy + 32 <= toy + TS) return;
-            tox = (ix - MARGIN) & ~3; toy = iy - MARGIN;
-            // keep the (TS+4) x TS load footprint inside the image whenever the window allows it, so
-            // only windows that really cross the border take the reflecting path
-            const int cx0 = min(max(tox, 0), (w - TS - 4) & ~3), cy0 = min(max(toy, 0), h - TS);
-            if (w >= TS + 4 && h >= TS && ix >= cx0 && ix + 32 <= cx0 + TS && iy >= cy0 && iy + 32 <= cy0 + TS) {
-                tox = cx0; toy = cy0;
-            }
-            const bool fast = j_aligned && tox >= 0 && tox + TS + 4 <= w && toy >= 0 && toy + TS <= h;
+            if (ix >= tox && ix + 32 <= tox + TSX && iy >= toy && iy + 32 <= toy + TSY) return;
+            const bool fast = plan_tile(ix, iy, tox, toy);
             if (fast) {
-                constexpr int NITEM = TS * TS / 4, NIT = (NITEM + 63) / 64, G = TS / 4;   // TS rows x G groups of 4 pixels
-                // item e = lane + 64 i -> (row, group). The 2-D index is stepped (64 = 5 G + 9) from an
-                // opaque copy of the lane id: otherwise hipcc hoists all 2 NIT divisions out of the level
-                // loop and keeps them in ~30 VGPRs for the whole kernel (costs a wave of occupancy).
-                int ln = lane;
-                asm volatile("" : "+v"(ln));
                 uint2 raw[NIT];
-                {
-                    int r = ln / G, c = ln - r * G;
-#pragma unroll
-                    for (int i = 0; i < NIT; ++i) {
-                        const int rr = min(r, TS - 1);      // the clamped tail items re-read the last row: harmless
-                        __builtin_memcpy(&raw[i], (const void *)(uintptr_t)(Jg + (__umul24((unsigned)(toy + rr), (unsigned)Jgs) +
-                                                                               (unsigned)(tox + 4 * c))), 8);
-                        r += 64 / G; c += 64 % G;
-                        if (c >= G) { c -= G; r += 1; }
-                    }
-                }
-                {
-                    int r = ln / G, c = ln - r * G;
-#pragma unroll
-                    for (int i = 0; i < NIT; ++i) {
-                        const int rr = min(r, TS - 1);
-                        *reinterpret_cast<uint4 *>(&jt[__umul24(rr, TS) + 4 * c]) =
-                            make_uint4(scaled_pair<0>(raw[i].x, raw[i].y), scaled_pair<1>(raw[i].x, raw[i].y),
-                                       scaled_pair<2>(raw[i].x, raw[i].y), scaled_pair<3>(raw[i].x, raw[i].y));
-                        r += 64 / G; c += 64 % G;
-                        if (c >= G) { c -= G; r += 1; }
-                    }
-                }
-            } else if (w >= RW && h >= TS) {
+                tile_request(raw);
+                tile_commit(raw);
+            } else if (w >= RW && h >= TSY) {
                 // The window crosses the image border. Every pixel the virtual (reflected) tile needs
                 // lies in an RW x TS in-image region next to that border: copy the region with plain
                 // coalesced loads into LDS, then build the tile by reflected LDS byte reads (row index
                 // on the scalar unit, column index once per lane) -- ~3x fewer VALU than reflecting
                 // every global load.
-                const int rx0 = min(max(tox, 0), w - RW), ry0 = min(max(toy, 0), h - TS);
+                const int rx0 = min(max(tox, 0), w - RW), ry0 = min(max(toy, 0), h - TSY);
                 int ln = lane;
                 asm volatile("" : "+v"(ln));
                 {
-                    uint32_t raw[(TS * (RW / 4) + 63) / 64];
+                    uint32_t raw[(TSY * (RW / 4) + 63) / 64];
 #pragma unroll
-                    for (int i = 0; i < (TS * (RW / 4) + 63) / 64; ++i) {
-                        const int e = min(ln + 64 * i, TS * (RW / 4) - 1), r = (int)(__umul24((unsigned)e, 5462u) >> 16), c = e - __umul24(r, RW / 4);   // e / 12, exact for e < 8190
+                    for (int i = 0; i < (TSY * (RW / 4) + 63) / 64; ++i) {
+                        const int e = min(ln + 64 * i, TSY * (RW / 4) - 1), r = (int)(__umul24((unsigned)e, 5462u) >> 16), c = e - __umul24(r, RW / 4);   // e / 12, exact for e < 8190
                         __builtin_memcpy(&raw[i], (const void *)(uintptr_t)(Jg + (__umul24((unsigned)(ry0 + r), (unsigned)Jgs) +
                                                                                (unsigned)(rx0 + 4 * c))), 4);
                     }
 #pragma unroll
-                    for (int i = 0; i < (TS * (RW / 4) + 63) / 64; ++i) {
-                        const int e = min(ln + 64 * i, TS * (RW / 4) - 1);
+                    for (int i = 0; i < (TSY * (RW / 4) + 63) / 64; ++i) {
+                        const int e = min(ln + 64 * i, TSY * (RW / 4) - 1);
                         region[e] = raw[i];
                     }
                 }
-                const int c = min(ln, TS - 1);                                     // lanes 0..TS-1: one tile column each
+                const int c = min(ln, TSX - 1);                                    // lanes 0..TSX-1: one tile column each
                 const uint8_t *rb = reinterpret_cast<const uint8_t *>(region);
                 const int sx0 = reflect101(tox + c, w) - rx0, sx1 = reflect101(tox + c + 1, w) - rx0;
 #pragma unroll 4
-                for (int r = 0; r < TS; ++r) {
+                for (int r = 0; r < TSY; ++r) {
                     const int sr = (reflect101(toy + r, h) - ry0) * RW;              // uniform
                     const uint32_t v = (((uint32_t)rb[sr + sx0] | ((uint32_t)rb[sr + sx1] << 16)) << GRAY_SHIFT) + ROUND_PAIR;
-                    if (lane < TS) jt[r * TS + c] = v;
+                    if (lane < TSX) jt[r * TSX + c] = v;
                 }
             } else {
                 int ln = lane;
                 asm volatile("" : "+v"(ln));
 #pragma unroll
-                for (int i = 0; i < (TS * TS / 4 + 63) / 64; ++i) {
-                    const int e = min(ln + 64 * i, TS * TS / 4 - 1), r = e / (TS / 4), c = e - r * (TS / 4);
+                for (int i = 0; i < (TSY * TSX / 4 + 63) / 64; ++i) {
+                    const int e = min(ln + 64 * i, TSY * TSX / 4 - 1), r = e / (TSX / 4), c = e - r * (TSX / 4);
                     const gptr_u8 row = Jg + __umul24((unsigned)reflect101(toy + r, h), (unsigned)Jgs);
                     const int x = tox + 4 * c;
                     uint32_t b[5];
 #pragma unroll
                     for (int q = 0; q < 5; ++q) b[q] = ((uint32_t)row[(unsigned)reflect101(x + q, w)] << GRAY_SHIFT) + 2u;
-                    *reinterpret_cast<uint4 *>(&jt[__umul24(r, TS) + 4 * c]) =
+                    *reinterpret_cast<uint4 *>(&jt[__umul24(r, TSX) + 4 * c]) =
                         make_uint4(b[0] | (b[1] << 16), b[1] | (b[2] << 16), b[2] | (b[3] << 16), b[3] | (b[4] << 16));
                 }
             }
@@ -416,12 +478,12 @@ __global__ __launch_bounds__(64, 4) void klt_kernel(KltArgs a)
             uint32_t wA, wB;
             bilinear_weights(cxn - (float)inx, cyn - (float)iny, wA, wB);
 
-            const uint32_t *jrow = jt + (iny - toy + half * HALF_ROWS) * TS + (inx - tox + cx);
+            const uint32_t *jrow = jt + (iny - toy + half * HALF_ROWS) * TSX + (inx - tox + cx);
             uint32_t jp = jrow[0];
             int sb1 = 0, sb2 = 0;
 #pragma unroll
             for (int m = 0; m < HALF_ROWS / 2; ++m) {
-                const uint32_t r1 = jrow[(2 * m + 1) * TS], r2 = jrow[(2 * m + 2) * TS];
+                const uint32_t r1 = jrow[(2 * m + 1) * TSX], r2 = jrow[(2 * m + 2) * TSX];
                 const int v0 = dot2(r1, wB, dot2(jp, wA, 0));
                 const int v1 = dot2(r2, wB, dot2(r1, wA, 0));
                 const uint32_t dp = pk_sub16(hi16_pair((uint32_t)v0, (uint32_t)v1), Ivp[m]);   // |diff| <= 8160
@@ -472,13 +534,13 @@ __global__ __launch_bounds__(64, 4) void klt_kernel(KltArgs a)
                 ensure_tile(inx, iny);
                 uint32_t wA, wB;
                 bilinear_weights(ex - (float)inx, ey - (float)iny, wA, wB);
-                const uint32_t *jrow = jt + (iny - toy + half * HALF_ROWS) * TS + (inx - tox + cx);
+                const uint32_t *jrow = jt + (iny - toy + half * HALF_ROWS) * TSX + (inx - tox + cx);
                 uint32_t jp = jrow[0];
                 int sabs = 0;
                 const uint32_t ones = col_ok ? 0x00010001u : 0u;
 #pragma unroll
                 for (int m = 0; m < HALF_ROWS / 2; ++m) {
-                    const uint32_t r1 = jrow[(2 * m + 1) * TS], r2 = jrow[(2 * m + 2) * TS];
+                    const uint32_t r1 = jrow[(2 * m + 1) * TSX], r2 = jrow[(2 * m + 2) * TSX];
                     const int v0 = dot2(r1, wB, dot2(jp, wA, 0));
                     const int v1 = dot2(r2, wB, dot2(r1, wA, 0));
                     const short2v d = __builtin_bit_cast(short2v, pk_sub16(hi16_pair((uint32_t)v0, (uint32_t)v1), Ivp[m]));
@@ -524,7 +586,13 @@ int launch_klt(Ctx *c, int n_pairs, const int *prev_slots_dev, const int *next_s
     a.epsilon = e * e;
     a.min_eig = (float)c->p.min_eig;
     ScopedKernelTime tm(c, HV_K_KLT);
-    hipLaunchKernelGGL(klt_kernel, dim3((unsigned)n_points), dim3(64), 0, c->stream, a);
+    // HV_KLT_TILE (environment, experiments only): tile columns x rows / slack on the low side: 0 = 44 x 40 / 6, 4 (8 staging
+    // passes of 5 rows), 1 = 40 x 36 / 2, 1 (6 passes of 6 rows), 2 = 40 x 42 / 2, 4 (7 passes), 5 = shape 1 compiled for 5 waves per SIMD (96 VGPRs; its 7.6 KB of LDS allow 20 waves per CU)
+    static const int tile_variant = [] { const char *e = getenv("HV_KLT_TILE"); return e ? atoi(e) : KLT_TILE_DEFAULT; }();
+    if (tile_variant == 1)      hipLaunchKernelGGL((klt_kernel<40, 36, 2, 1, 4>), dim3((unsigned)n_points), dim3(64), 0, c->stream, a);
+    else if (tile_variant == 2) hipLaunchKernelGGL((klt_kernel<40, 42, 2, 4, 4>), dim3((unsigned)n_points), dim3(64), 0, c->stream, a);
+    else if (tile_variant == 5) hipLaunchKernelGGL((klt_kernel<40, 36, 2, 1, 5>), dim3((unsigned)n_points), dim3(64), 0, c->stream, a);
+    else                        hipLaunchKernelGGL((klt_kernel<44, 40, 6, 4, 4>), dim3((unsigned)n_points), dim3(64), 0, c->stream, a);
     HV_HIP(c, hipGetLastError());
     return HV_OK;
 }

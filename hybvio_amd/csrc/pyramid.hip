@@ -201,7 +201,84 @@ __global__ __launch_bounds__(256) void pyr_level_kernel(PyrLevelArgs a)
     }
 }
 
+// ---- physical borders of the padded (coarse) levels, see PyrLayout ----
+struct BorderArgs {
+    PyrLayout L;
+    uint8_t *slab;
+    const int *slots;          // [n] (gray borders) or NULL: slot = first_slot + blockIdx.y
+    int first_slot;
+    int first_level;           // levels first_level .. L.levels-1 are padded
+};
+
+// BORDER_REFLECT_101 frame of every padded gray level of one image, from the interior the level kernels just wrote
+// (what cv::buildOpticalFlowPyramid's copyMakeBorder does). One dword = 4 border pixels per thread step; dwords that lie
+// entirely inside the image are skipped. ~66 KB per 752x480 image (levels 2 and 3).
+__global__ __launch_bounds__(256) void pyr_border_kernel(BorderArgs a)
+{
+    const PyrLayout &L = a.L;
+    uint8_t *slot = a.slab + (long long)a.slots[blockIdx.y] * L.slot_bytes;
+    int item = blockIdx.x * 256 + threadIdx.x;
+    for (int l = a.first_level; l < L.levels; ++l) {
+        const int pd = L.pad[l], w = L.w[l], h = L.h[l], gs = L.gstride[l];
+        const int gw = (w + 2 * pd + 3) >> 2, rows = h + 2 * pd, n = gw * rows;
+        if (item < n) {
+            const int r = item / gw, g = item - r * gw;
+            const int y = r - pd, x = 4 * g - pd;
+            if (!(y >= 0 && y < h && x >= 0 && x + 4 <= w)) {
+                uint8_t *img = slot + L.goff[l];
+                const uint8_t *src = img + (long long)reflect101(y, h) * gs;
+                uint8_t *dst = img + (long long)y * gs + x;
+                if (y >= 0 && y < h) {                      // a row of the image: only the pixels outside it are written
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        if ((x + i < 0 || x + i >= w) && x + i < w + pd) dst[i] = src[reflect101(x + i, w)];
+                } else {
+                    const uint32_t v = (uint32_t)src[reflect101(x, w)] | ((uint32_t)src[reflect101(x + 1, w)] << 8) |
+                                       ((uint32_t)src[reflect101(x + 2, w)] << 16) | ((uint32_t)src[reflect101(x + 3, w)] << 24);
+                    if (x + 4 <= w + pd) *reinterpret_cast<uint32_t *>(dst) = v;
+                    else
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) if (x + i < w + pd) dst[i] = (uint8_t)(v >> (8 * i));
+                }
+            }
+            return;
+        }
+        item -= n;
+    }
+}
+
+// Gradient planes of the padded levels, whole padded rectangle = "0" (stored 4*0+2 in both halves). The level kernels only
+// ever write the interior, so this runs once per slot.
+__global__ __launch_bounds__(256) void grad_border_fill_kernel(BorderArgs a)
+{
+    const PyrLayout &L = a.L;
+    uint8_t *slot = a.slab + (long long)(a.first_slot + (int)blockIdx.y) * L.slot_bytes;
+    for (int l = a.first_level; l < L.levels; ++l) {
+        const int pd = L.pad[l];
+        uint32_t *base = reinterpret_cast<uint32_t *>(slot + L.doff[l]) - ((long long)pd * L.dstride[l] + pd);
+        const int n = L.dstride[l] * (L.h[l] + 2 * pd);
+        for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) base[i] = 0x00020002u;
+    }
+}
+
+int first_padded_level(const PyrLayout &L)
+{
+    for (int l = 0; l < L.levels; ++l) if (L.pad[l]) return l;
+    return L.levels;
+}
+
 }  // namespace
+
+int fill_gradient_borders(Ctx *c, int first_slot, int n_slots)
+{
+    const int fl = first_padded_level(c->L);
+    if (fl >= c->L.levels || n_slots <= 0) return HV_OK;
+    BorderArgs a{};
+    a.L = c->L; a.slab = c->slab; a.slots = nullptr; a.first_slot = first_slot; a.first_level = fl;
+    hipLaunchKernelGGL(grad_border_fill_kernel, dim3(16, (unsigned)n_slots), dim3(256), 0, c->stream, a);
+    HV_HIP(c, hipGetLastError());
+    return HV_OK;
+}
 
 int launch_pyramid_levels(Ctx *c, int n, const int *slots_dev, const uint8_t *src_base,
                           long long src_step, int src_stride, bool src_indexed_by_slot)
@@ -228,6 +305,16 @@ int launch_pyramid_levels(Ctx *c, int n, const int *slots_dev, const uint8_t *sr
         ScopedKernelTime tm(c, l == 0 ? HV_K_PYR_L0 : HV_K_PYR_LN);
         if (down) hipLaunchKernelGGL(pyr_level_kernel<true>, dim3(grid), dim3(256), 0, c->stream, a);
         else      hipLaunchKernelGGL(pyr_level_kernel<false>, dim3(grid), dim3(256), 0, c->stream, a);
+        HV_HIP(c, hipGetLastError());
+    }
+    const int fl = first_padded_level(L);
+    if (fl < L.levels) {
+        BorderArgs a{};
+        a.L = L; a.slab = c->slab; a.slots = slots_dev; a.first_level = fl;
+        int items = 0;
+        for (int l = fl; l < L.levels; ++l) items += ((L.w[l] + 2 * L.pad[l] + 3) >> 2) * (L.h[l] + 2 * L.pad[l]);
+        ScopedKernelTime tm(c, HV_K_PYR_LN);
+        hipLaunchKernelGGL(pyr_border_kernel, dim3((unsigned)((items + 255) / 256), (unsigned)n), dim3(256), 0, c->stream, a);
         HV_HIP(c, hipGetLastError());
     }
     return HV_OK;
