@@ -54,6 +54,12 @@ def algorithmic_bytes(w=None, h=None, npts=None):
                 stereo_frame=2 * pyr_image + 2 * klt_call)
 
 
+def crop_offsets(B, seed, M=32):
+    """Where sequence s of a replica crops its frames out of the rendered canvas: seeded by the RANK, so the N replicas of a
+    multi-GPU job work on different inputs (tests/test_bench_distributed.py)."""
+    return np.random.default_rng(seed).integers(0, 2 * M + 1, (B, 2))
+
+
 class TrackerBench:
     """B sequences x (2 pyramid builds + 2 LK calls) per step, everything device resident."""
 
@@ -70,8 +76,7 @@ class TrackerBench:
         left, right, _ = synth.stereo_sequence(1000 + seed, W + 2 * M, H + 2 * M, N_CYCLE)
         canvas = torch.from_numpy(np.stack([left, right], 1)).to(dev)          # [K, 2, H+2M, W+2M]
         self.frames = torch.empty((N_CYCLE, 2, B, H, W), dtype=torch.uint8, device=dev)
-        rng = np.random.default_rng(seed)
-        offs = rng.integers(0, 2 * M + 1, (B, 2))
+        offs = crop_offsets(B, seed, M)
         for s in range(B):
             ox, oy = int(offs[s, 0]), int(offs[s, 1])
             self.frames[:, :, s] = canvas[:, :, oy:oy + H, ox:ox + W]
@@ -226,30 +231,38 @@ def cpu_baseline_ekf(budget_s=8.0):
     H = rng.normal(size=(EKF_ROWS, EKF_COLS))
     zeros = np.zeros(EKF_ROWS)
     frames, t0 = 0, time.perf_counter()
+    tm = {"KF predict": 0.0, "trackerVisualUpdate": 0.0, "augmentation": 0.0}        # the reference's -timer keys
     while True:
+        ta = time.perf_counter()
         for i in range(EKF_PREDICTS):
             t += 0.005
             e.predict(t, rng.normal(0, 0.05, 3), np.array([0.0, 0.0, 9.819]) + rng.normal(0, 0.05, 3))
+        tb = time.perf_counter()
         for j in range(EKF_GATES):
             passing = j % (EKF_GATES // EKF_UPDATES) == 0
             v = rng.normal(size=EKF_ROWS) * (0.02 if passing else 2.0)
             st, _ = e.visual_track_outlier_check(H, zeros, v, 0.05)
             if st == 0:
                 e.update_visual_track(H, zeros, v, 0.05)
+        tc = time.perf_counter()
         e.maintain_psd()
         e.update_visual_pose_augmentation(HANOI[frames % len(HANOI)])
+        td = time.perf_counter()
+        tm["KF predict"] += tb - ta; tm["trackerVisualUpdate"] += tc - tb; tm["augmentation"] += td - tc
         frames += 1
         el = time.perf_counter() - t0
         if el > budget_s:
             break
-    return frames / el, f"{frames} frames of the EKF sequence, oracle/ekf_oracle.c -O2, 1 thread, {el:.1f} s"
+    flags = "-O3 -march=native" if os.environ.get("ORC_NATIVE") == "1" else "-O2"
+    return frames / el, f"{frames} frames of the EKF sequence, oracle/ekf_oracle.c {flags}, 1 thread, {el:.1f} s", \
+        {k: 1e3 * v / frames for k, v in tm.items()}
 
 
-def cpu_baseline(budget_s=12.0):
+def cpu_baseline(budget_s=10.0):
     """The CPU oracle (a restatement of the OpenCV path HybVIO calls; NOT SIMD OpenCV) timed on this
-    box on the same per-frame work: 2 pyramid builds + 2 LK calls x 200 points. Timed twice: on all
-    host cores with the decomposition OpenCV's parallel_for_ uses (rows for pyramid / Scharr, points
-    for LK) -- the headline, `cores` = threads used -- and single-threaded."""
+    box on the same per-frame work: 2 pyramid builds + 2 LK calls x 200 points. Timed twice: on the best
+    OpenMP team found (the decomposition OpenCV's parallel_for_ uses: rows for pyramid / Scharr, points
+    for LK; `cores` = threads used) and single-threaded. Stage times carry the reference's `-timer` names."""
     from hybvio_amd import synth
     from oracle import orc
     left, right, _ = synth.stereo_sequence(1000, W, H, 3)
@@ -257,41 +270,61 @@ def cpu_baseline(budget_s=12.0):
 
     def run(budget):
         prev = orc.Pyramid(left[0])
-        frames, t0 = 0, time.perf_counter()
+        frames, t0, t_pyr, t_flow = 0, time.perf_counter(), 0.0, 0.0
         while True:
             k = 1 + frames % 2
+            ta = time.perf_counter()
             cl, cr = orc.Pyramid(left[k]), orc.Pyramid(right[k])
+            tb = time.perf_counter()
             xy, st, _ = orc.klt_track(prev, cl, pts, next_pts=pts)
             guess = xy.copy()
             guess[:, 0] -= 20.0
             orc.klt_track(cl, cr, xy, next_pts=guess)
+            tc = time.perf_counter()
+            t_pyr += tb - ta; t_flow += tc - tb
             prev = cl
             frames += 1
             el = time.perf_counter() - t0
             if el > budget:
-                return frames, el
+                return frames, el, {"pyramid": 1e3 * t_pyr / frames, "computeOpticalFlow": 1e3 * t_flow / frames}
 
     orc.set_threads(1)
-    f_one, t_one = run(0.4 * budget_s)
+    f_one, t_one, tm_one = run(0.4 * budget_s)
     # OpenMP on "all cores" is not automatically the fastest here (the GPU box reports 256 hardware
     # threads; 256 spinning threads on 480-row loops ran 250x SLOWER than one): probe a few team sizes
     # briefly and time the best one -- the baseline is the best CPU configuration found, `cores` says which.
-    ncpu = os.cpu_count() or 1
+    ncpu = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     best_n, best_rate = 1, f_one / t_one
     for n in (4, 8, 16, 32, 64):
         if n > ncpu:
             break
         orc.set_threads(n)
-        f, t = run(0.08 * budget_s)
+        f, t, _ = run(0.08 * budget_s)
         if f / t > best_rate:
             best_n, best_rate = n, f / t
     orc.set_threads(best_n)
-    f_all, t_all = run(0.25 * budget_s)
+    f_all, t_all, tm_all = run(0.25 * budget_s)
     orc.set_threads(1)
+    flags = "-O3 -march=native" if os.environ.get("ORC_NATIVE") == "1" else "-O2 (the reference's flags, CMakeLists.txt:5)"
     return dict(value=max(f_all / t_all, f_one / t_one), unit="frames/s", cores=best_n if f_all / t_all >= f_one / t_one else 1,
-                kind="port", single_thread_value=f_one / t_one, host_cpus=ncpu,
+                kind="port", single_thread_value=f_one / t_one, host_cpus=ncpu, compiler_flags=flags,
+                timers_ms_per_frame={"threads_1": tm_one, f"threads_{best_n}": tm_all},
                 sample=f"{f_all} stereo frames 752x480 x 200 pts in {t_all:.1f} s on {best_n} threads (OpenMP over rows / points, best of "
-                       f"the team sizes probed) + {f_one} frames in {t_one:.1f} s on 1 thread; oracle/pyrlk_oracle.c -O2")
+                       f"the team sizes probed) + {f_one} frames in {t_one:.1f} s on 1 thread; oracle/pyrlk_oracle.c {flags}")
+
+
+def cpu_baseline_native(budget_s=6.0):
+    """The same two CPU legs with the oracle compiled -O3 -march=native ON THIS BOX (SURVEY.md 8(d) asks for both
+    columns): a child process, because the -O2 library is already loaded in this one."""
+    import subprocess
+    env = dict(os.environ, ORC_NATIVE="1")
+    try:
+        p = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-child", str(budget_s)], env=env,
+                           capture_output=True, text=True, timeout=180)
+        line = [l for l in p.stdout.splitlines() if l.startswith("{")]
+        return json.loads(line[-1]) if line else {"error": (p.stderr or "no output")[-300:]}
+    except Exception as ex:                                   # pragma: no cover
+        return {"error": repr(ex)[:200]}
 
 
 def profiled_traffic():
@@ -309,18 +342,23 @@ def profiled_traffic():
 
 class DistEnv:
     """One process per GPU (torch.distributed.run sets RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*).
-    The data path has no collective: replicas only. This class only provides the timing contract --
-    barrier + device sync on both sides of the timed region and MAX over ranks of the elapsed time.
-    backend "nccl" is RCCL on ROCm; "gloo" lets the same code run in the CPU tests."""
+    The data path has no collective: replicas only (north_star: "no RCCL"). This class only provides the timing
+    contract -- barrier + device sync on both sides of the timed region and MAX over ranks of the elapsed time --
+    over a HOST-side process group (gloo) by default; backend "nccl" (= RCCL on ROCm) is accepted for comparison.
+    Every rank pins itself to its own slice of the host cores: at 8 GPUs the per-GPU feeder thread is the scarce
+    resource, and unpinned ranks migrate onto each other's cores."""
 
-    def __init__(self, backend="nccl"):
+    def __init__(self, backend="gloo", use_cuda=True):
         import torch
         self.torch = torch
         self.world = int(os.environ.get("WORLD_SIZE", "1"))
         self.rank = int(os.environ.get("RANK", "0"))
         self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
         self.backend = backend
+        self.use_cuda = use_cuda
         self.dist = None
+        self.cores = self._pin()
+        self.max_barrier_wait_s = 0.0
         if self.world > 1:
             import torch.distributed as dist
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -328,11 +366,28 @@ class DistEnv:
             dist.init_process_group(backend, **kw)
             self.dist = dist
 
+    def _pin(self):
+        if not hasattr(os, "sched_setaffinity"):
+            return None
+        try:
+            avail = sorted(os.sched_getaffinity(0))
+            local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(self.world)))
+            if local_world <= 1 or len(avail) < local_world:
+                return len(avail)
+            per = len(avail) // local_world
+            mine = avail[self.local_rank * per:(self.local_rank + 1) * per]
+            os.sched_setaffinity(0, mine)
+            return len(mine)
+        except OSError:                                        # pragma: no cover
+            return None
+
     def barrier(self):
-        if self.dist is not None:
-            self.dist.barrier()
-        if self.backend == "nccl":
+        if self.use_cuda:
             self.torch.cuda.synchronize()
+        if self.dist is not None:
+            t0 = time.perf_counter()
+            self.dist.barrier()
+            self.max_barrier_wait_s = max(self.max_barrier_wait_s, time.perf_counter() - t0)
 
     def max_over_ranks(self, seconds: float) -> float:
         if self.dist is None:
@@ -343,13 +398,16 @@ class DistEnv:
         return float(t.item())
 
     def timed(self, fn, steps: int) -> float:
-        """barrier+sync, `steps` calls of fn, barrier+sync; returns the MAX over ranks of the wall time."""
+        """barrier+sync, `steps` calls of fn, sync+barrier; returns the MAX over ranks of the wall time."""
         self.barrier()
         t0 = time.perf_counter()
         for _ in range(steps):
             fn()
+        if self.use_cuda:
+            self.torch.cuda.synchronize()
+        dt = time.perf_counter() - t0              # this rank's time: taken BEFORE the closing barrier
         self.barrier()
-        return self.max_over_ranks(time.perf_counter() - t0)
+        return self.max_over_ranks(dt)
 
     def close(self):
         if self.dist is not None:
@@ -420,22 +478,24 @@ def bench_ingest(tb, n, local_rank, cpu_baseline):
     return res
 
 
-def bench_pcie_inclusive(local_rank, n_seq=128, steps=10):
+def bench_pcie_inclusive(env, local_rank, rank, n_seq=128, steps=10):
     """C2 with the frames of every step copied from pinned host memory first (2 x n_seq images of 361 KB per step): once with the
-    copy in line on the compute stream, once double-buffered on a copy stream one step ahead. Never the headline `value`."""
+    copy in line on the compute stream, once double-buffered on a copy stream one step ahead. Every rank feeds its own GPU (the
+    8-GPU case is feeder-bound: SURVEY.md 8(e)); the figure is the whole-job rate under the barrier / MAX contract. Never `value`."""
     import torch
     dev = f"cuda:{local_rank}"
-    tb = TrackerBench(n_seq, local_rank, seed=5)
+    tb = TrackerBench(n_seq, local_rank, seed=5 + rank)
     host = [torch.empty((2, n_seq, H, W), dtype=torch.uint8).pin_memory() for _ in range(N_CYCLE)]
     for k in range(N_CYCLE):
         host[k].copy_(tb.frames[k].cpu())
     nbytes = 2 * n_seq * H * W
-    res = {"sequences": n_seq, "host_bytes_per_step": nbytes}
+    res = {"sequences_per_gpu": n_seq, "host_bytes_per_step_per_gpu": nbytes, "n_gpus": env.world}
 
     def run(overlap):
         copy_stream = torch.cuda.Stream(device=dev)
         done = [torch.cuda.Event() for _ in range(N_CYCLE)]
         main = torch.cuda.current_stream()
+
         def upload(k):
             if overlap:
                 copy_stream.wait_stream(main)                 # the slot being overwritten was last read two steps ago
@@ -444,25 +504,20 @@ def bench_pcie_inclusive(local_rank, n_seq=128, steps=10):
                     done[k % N_CYCLE].record(copy_stream)
             else:
                 tb.frames[k % N_CYCLE].copy_(host[k % N_CYCLE], non_blocking=True)
+
+        def one():
+            if overlap:
+                main.wait_event(done[tb.k % N_CYCLE])
+            nxt = tb.k + 1
+            tb.step()
+            upload(nxt)
         upload(tb.k)
         for _ in range(2):
-            if overlap:
-                main.wait_event(done[tb.k % N_CYCLE])
-            nxt = tb.k + 1
-            tb.step()
-            upload(nxt)
-        torch.cuda.synchronize(); t0 = time.perf_counter()
-        for _ in range(steps):
-            if overlap:
-                main.wait_event(done[tb.k % N_CYCLE])
-            nxt = tb.k + 1
-            tb.step()
-            upload(nxt)
-        torch.cuda.synchronize()
-        return (time.perf_counter() - t0) / steps
+            one()
+        return env.timed(one, steps) / steps
     for name, ov in (("copy_in_line", False), ("copy_one_step_ahead", True)):
         dt = run(ov)
-        res[name] = {"ms_per_step": dt * 1e3, "frames_per_s": n_seq / dt, "h2d_GBs": nbytes / dt / 1e9}
+        res[name] = {"ms_per_step": dt * 1e3, "frames_per_s": env.world * n_seq / dt, "h2d_GBs_per_gpu": nbytes / dt / 1e9}
     tb.ctx.close()
     return res
 
@@ -618,38 +673,9 @@ def bench_visual_track(ctx, n, local_rank, cpu_baseline):
     return res
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--sequences", type=int, default=1024,
-                    help="independent VIO sequences resident per GPU (B): 13 MB each; 256 fills the CUs once, 1024 amortises launch tails (+11 %%)")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-latency-mode", action="store_true")
-    ap.add_argument("--no-ekf", action="store_true", help="skip the C3 (tracker + HIP EKF) leg")
-    ap.add_argument("--no-gftt", action="store_true", help="skip the f1 (GFTT detector kernel) measurement")
-    ap.add_argument("--no-ingest", action="store_true", help="skip the f2 (colour->gray / undistort ingest kernel) measurement")
-    ap.add_argument("--no-visual-track", action="store_true", help="skip the f3 (device triangulation + prepareVisualUpdate) measurement")
-    ap.add_argument("--no-ransac", action="store_true", help="skip the f4 (2-point rotation RANSAC kernel) measurement")
-    ap.add_argument("--no-pcie", action="store_true", help="skip the PCIe-inclusive measurement (frames handed over as host buffers)")
-    ap.add_argument("--c4", action="store_true",
-                    help="configs[3] instead of the headline workload: 1280x720 stereo, 400 features (not the default bench line)")
-    args = ap.parse_args()
-
-    import torch
-
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
-    torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
-    env = DistEnv("nccl")
-    world, rank, local_rank = env.world, env.rank, env.local_rank
-
+def tracker_leg(env, args, B, local_rank, rank, label):
+    """The C2 step (2 pyramid builds + 2 LK calls per sequence) timed under the contract, with per-kernel event times."""
     from hybvio_amd import capi
-    B = args.sequences
-    if args.c4:
-        global W, H, NPTS
-        W, H, NPTS = 1280, 720, 400
     tb = TrackerBench(B, local_rank, seed=rank)
     for _ in range(args.warmup):
         tb.step()
@@ -659,57 +685,78 @@ def main():
     prof = {name: tb.ctx.profile_read(kid) for name, kid in
             (("pyr_l0", capi.K_PYR_L0), ("pyr_ln", capi.K_PYR_LN), ("klt", capi.K_KLT))}
     tb.ctx.profile_enable(False)
-    tracked = tb.tracked_fraction()
+    ab = algorithmic_bytes()
+    # per-kernel achieved algorithmic GB/s from HIP-event durations on the context stream; pyr_ln = every launch that is not the
+    # level-0 kernel (levels 1.. and the border fill of the padded levels), accounted per STEP, not per launch
+    kern = {}
+    for name, (ms, n) in prof.items():
+        if n:
+            per_step = {"pyr_l0": 2 * B * ab["pyr_l0"], "pyr_ln": 2 * B * ab["pyr_ln"], "klt": 2 * B * ab["klt_call"]}[name]
+            kern[name] = dict(avg_ms=ms / n, launches=n, total_ms=ms, ms_per_step=ms / args.steps,
+                              achieved_GBs=per_step / (ms / args.steps * 1e-3) / 1e9,
+                              algorithmic_bytes_per_launch=per_step * args.steps / n)
+    stage_ms = sum(v["total_ms"] for v in kern.values()) / args.steps
+    stage_gbs = B * ab["stereo_frame"] / (stage_ms * 1e-3) / 1e9
+    res = {"workload": label, "value": aggregate_value(B, env.world, args.steps, el), "unit": "frames/s",
+           "ms_per_step": el / args.steps * 1e3, "sequences_per_gpu": B, "kernels": kern,
+           "stage_pyramid_klt": {"ms_per_step": stage_ms, "achieved_GBs": stage_gbs, "frac_of_8TBs": stage_gbs / HBM_PEAK_GBS,
+                                 "frac_of_measured_copy_ceiling": stage_gbs / HBM_COPY_CEILING_GBS,
+                                 "algorithmic_bytes_per_stereo_frame": ab["stereo_frame"]},
+           "tracked_fraction": tb.tracked_fraction()}
+    return tb, res
 
-    out = None
-    if rank == 0:
-        ab = algorithmic_bytes()
-        ms_step = el / args.steps * 1e3
-        # per-kernel achieved algorithmic GB/s from HIP-event durations on the context stream
-        per_launch_bytes = dict(pyr_l0=2 * B * ab["pyr_l0"], pyr_ln=2 * B * ab["pyr_ln"] / 3.0, klt=B * ab["klt_call"])
-        kern = {}
-        for name, (ms, n) in prof.items():
-            if n:
-                avg = ms / n
-                kern[name] = dict(avg_ms=avg, launches=n, total_ms=ms,
-                                  achieved_GBs=per_launch_bytes[name] / (avg * 1e-3) / 1e9)
-        stage_ms = sum(v["total_ms"] for v in kern.values()) / args.steps
-        stage_gbs = B * ab["stereo_frame"] / (stage_ms * 1e-3) / 1e9
-        dom = max(kern, key=lambda k: kern[k]["total_ms"])
-        prof_t = profiled_traffic()
-        traffic, traffic_note = None, None
-        if prof_t is not None:
-            key = {"klt": "klt_kernel", "pyr_l0": "pyr_level_kernel_L0"}.get(dom)
-            if key in prof_t:
-                traffic = prof_t[key]["hbm_bytes_per_launch"] * B / float(prof_t.get("sequences_per_gpu", B))
-                traffic_note = (f"rocprofv3 FETCH_SIZE x2 + WRITE_SIZE per launch from {prof_t['_file']} "
-                                f"(collected at B={prof_t.get('sequences_per_gpu')}, scaled to B={B})")
-        out = {
-            "metric": "VIO frames/sec at 752x480 stereo, 200 KLT features; pyramid+KLT HBM GB/s",
-            "value": aggregate_value(B, world, args.steps, el), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": ms_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "u8/int16 pixels, int32/int64 sums, f32 solve", "data": "synthetic",
-            "config": {"workload": (f"C4: {W}x{H} stereo, {NPTS} pts" if args.c4 else "C2: 752x480 stereo, 200 pts") +
-                                   ", HIP pyramid+KLT tracker (2 builds + 2 LK calls per frame), EKF not in the HIP path",
-                       "sequences_per_gpu": B,
-                       "frames_per_step": world * B, "parallelism": f"replicas x{world} (no collective)"},
-            "roofline": {"bound": "hbm", "kernel": dom, "achieved": kern[dom]["achieved_GBs"], "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": kern[dom]["achieved_GBs"] / HBM_PEAK_GBS, "traffic": traffic,
-                         "algorithmic_bytes_per_launch": per_launch_bytes[dom], "traffic_source": traffic_note,
-                         "limiter": ("klt_kernel is VALU-issue bound (rocprof: VALU busy ~84 %, HBM traffic < algorithmic bytes); "
-                                     "the HBM-bound kernel of the path is pyr_l0, see kernels / measured_ceilings")
-                         if dom == "klt" else None},
-            "measured_ceilings_GBs": (prof_t or {}).get("measured_hbm_ceilings_GBs"),
-            "kernels": kern,
-            "stage_pyramid_klt": {"ms_per_step": stage_ms, "achieved_GBs": stage_gbs,
-                                  "frac_of_8TBs": stage_gbs / HBM_PEAK_GBS,
-                                  "frac_of_measured_copy_ceiling": stage_gbs / HBM_COPY_CEILING_GBS,
-                                  "algorithmic_bytes_per_stereo_frame": ab["stereo_frame"]},
-            "tracked_fraction": tracked,
-        }
-    # ---- f1: GFTT detector on the left images of the current frame, device half ----
-    if not args.no_gftt and rank == 0:
-        import torch
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--sequences", type=int, default=1024,
+                    help="independent VIO sequences resident per GPU (B): 13 MB each; 256 fills the CUs once, 1024 amortises launch tails (+11 %%)")
+    ap.add_argument("--dist-backend", default="gloo", choices=["gloo", "nccl"],
+                    help="process group of the timing barrier / MAX reduce only (the data path has no collective)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-latency-mode", action="store_true")
+    ap.add_argument("--no-c4", action="store_true", help="skip configs[3] (1280x720 stereo, 400 features)")
+    ap.add_argument("--no-gftt", action="store_true", help="skip the f1 (GFTT detector kernel) measurement")
+    ap.add_argument("--no-ingest", action="store_true", help="skip the f2 (colour->gray / undistort ingest kernel) measurement")
+    ap.add_argument("--no-visual-track", action="store_true", help="skip the f3 (device triangulation + prepareVisualUpdate) measurement")
+    ap.add_argument("--no-ransac", action="store_true", help="skip the f4 (2-point rotation RANSAC kernel) measurement")
+    ap.add_argument("--no-pcie", action="store_true", help="skip the PCIe-inclusive measurement (frames handed over as host buffers)")
+    ap.add_argument("--only-headline", action="store_true", help="C2 + C3 legs only (what the rocprofv3 collection runs)")
+    ap.add_argument("--cpu-baseline-child", type=float, default=None, help=argparse.SUPPRESS)
+    args = ap.parse_args()
+
+    if args.cpu_baseline_child is not None:                 # child of cpu_baseline_native(): CPU only
+        out = cpu_baseline(args.cpu_baseline_child)
+        fps_ekf, sample, tm = cpu_baseline_ekf(0.5 * args.cpu_baseline_child)
+        out["ekf_only_frames_per_s"], out["ekf_sample"], out["ekf_timers_ms_per_frame"] = fps_ekf, sample, tm
+        print(json.dumps(out))
+        return
+    if args.only_headline:
+        args.no_c4 = args.no_gftt = args.no_ingest = args.no_visual_track = args.no_ransac = args.no_pcie = True
+        args.no_latency_mode = args.no_cpu_baseline = True
+
+    import torch
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
+    env = DistEnv(args.dist_backend)
+    world, rank, local_rank = env.world, env.rank, env.local_rank
+    solo = world == 1                # legs that characterise single kernels run on a 1-GPU job only: at N > 1 every rank
+                                     # does the same work in every region, no rank waits for another one's extras
+
+    from hybvio_amd import capi
+    global W, H, NPTS
+    B = args.sequences
+
+    # ---- C2: tracker only (configs[1]) ----
+    tb, c2 = tracker_leg(env, args, B, local_rank, rank,
+                         "C2: 752x480 stereo, 200 pts, HIP pyramid+KLT tracker (2 builds + 2 LK calls per frame), EKF on the host")
+    out = {}
+    # ---- f1..f4, PCIe: single-kernel characterisation, 1-GPU job only ----
+    if solo and not args.no_gftt:
         nk = tb.ctx.gftt_keypoint_count()
         kp = torch.zeros((B, nk, 3), dtype=torch.float32, device=f"cuda:{local_rank}")
         left_slots = tb.L[(tb.k - 1) % 2]
@@ -741,47 +788,107 @@ def main():
             out["f1_gftt"]["cpu_baseline"] = {"value": reps / (time.perf_counter() - t0), "unit": "images/s", "cores": cores,
                                               "kind": "port", "sample": f"{reps} images, oracle/gftt_oracle.c -O2, OpenMP over rows"}
             orc.set_threads(1)
-    # ---- f2: image ingest in front of the pyramid: colour -> gray, undistort remap ----
-    if not args.no_ingest and rank == 0:
+    if solo and not args.no_ingest:
         out["f2_ingest"] = bench_ingest(tb, min(B, 256), local_rank, not args.no_cpu_baseline)
-    # ---- f3: per-track triangulation + prepareVisualUpdate from the device mean, fused with gate + update ----
-    if not args.no_visual_track and rank == 0:
+    if solo and not args.no_visual_track:
         out["f3_visual_track"] = bench_visual_track(tb.ctx, min(B, 256), local_rank, not args.no_cpu_baseline)
         one = bench_visual_track(tb.ctx, 1, local_rank, False)
         out["f3_visual_track"]["single_sequence"] = {"prepare_ms": one["prepare_avg_ms"], "fused_prepare_gate_update_ms": one["fused_prepare_gate_update_avg_ms"],
                                                      "frame_loop_ms": one["frame_loop"]["ms_per_frame_loop"],
                                                      "note": "what one `main` process pays per frame for its 20 track visits (quota 5)"}
-    # ---- the same C2 step when every frame arrives as a HOST buffer (the reference's boundary: main.cpp hands cv::Mat frames) ----
-    if not args.no_pcie and rank == 0:
-        out["pcie_inclusive"] = bench_pcie_inclusive(local_rank)
-    # ---- f4: 2-point rotation RANSAC on the tracked features of every sequence ----
-    if not args.no_ransac and rank == 0:
+    if solo and not args.no_ransac:
         out["f4_rot_ransac"] = bench_rot_ransac(tb.ctx, min(B, 1024), local_rank, not args.no_cpu_baseline)
-    # ---- C3: the same tracker work + the HIP EKF (configs[2]) ----
-    if not args.no_ekf:
-        eb = EkfBench(tb.ctx, B, local_rank, seed=rank)
-        for _ in range(args.warmup):
-            tb.step(); eb.step()
-        tb.ctx.profile_enable(True)
-        tb.ctx.profile_reset()
-        el3 = env.timed(lambda: (tb.step(), eb.step()), args.steps)
-        prof3 = {name: tb.ctx.profile_read(kid) for name, kid in
-                 (("ekf_predict", capi.K_EKF_PREDICT), ("ekf_update_gate", capi.K_EKF_UPDATE), ("ekf_augment", capi.K_EKF_AUGMENT))}
-        tb.ctx.profile_enable(False)
-        accepted = int(eb.accepted.item())
-        if rank == 0:
-            out["c3"] = {
-                "workload": "C3: C2 + HIP EKF per frame (10 predicts in one launch, 20 chi2 gates n=40 l=160 of which 5 update, "
-                            "symmetrise, 1 Joseph-form augmentation), state dim 160, f64",
-                "value": aggregate_value(B, world, args.steps, el3), "unit": "frames/s", "ms_per_step": el3 / args.steps * 1e3,
-                "kernels": {k: {"avg_ms": ms / n, "launches": n, "total_ms": ms} for k, (ms, n) in prof3.items() if n},
-                "updates_accepted_fraction": accepted / float(B * args.steps * EKF_UPDATES * (1 + args.warmup / args.steps)),
-            }
-        eb.ekf.close()
-        del eb
+
+    # ---- C3 (configs[2], the headline): the same tracker work + the HIP EKF ----
+    eb = EkfBench(tb.ctx, B, local_rank, seed=rank)
+    for _ in range(args.warmup):
+        tb.step(); eb.step()
+    tb.ctx.profile_enable(True)
+    tb.ctx.profile_reset()
+    el3 = env.timed(lambda: (tb.step(), eb.step()), args.steps)
+    names = (("pyr_l0", capi.K_PYR_L0), ("pyr_ln", capi.K_PYR_LN), ("klt", capi.K_KLT), ("ekf_predict", capi.K_EKF_PREDICT),
+             ("ekf_update_gate", capi.K_EKF_UPDATE), ("ekf_augment", capi.K_EKF_AUGMENT))
+    prof3 = {name: tb.ctx.profile_read(kid) for name, kid in names}
+    tb.ctx.profile_enable(False)
+    accepted = int(eb.accepted.item())
+    eb.ekf.close()
+    del eb
+    n_state = 160
+    p_bytes = n_state * n_state * 8
+    ab = algorithmic_bytes()
+    k3 = {k: {"avg_ms": ms / n, "launches": n, "total_ms": ms, "ms_per_step": ms / args.steps} for k, (ms, n) in prof3.items() if n}
+    # algorithmic bytes per launch of the kernel classes that can dominate the step (SURVEY.md 8(d) / DESIGN.md 3):
+    #   klt: B x 200 points x 4 levels x 6144 B; pyr_l0: 2B x 1 895 040 B; ekf gate / update: B x P read once (+ written by the 1 in 4
+    #   launches that update): 204 800 B x (1 + 5/20)
+    alg = {"klt": B * ab["klt_call"], "pyr_l0": 2 * B * ab["pyr_l0"], "pyr_ln": 2 * B * ab["pyr_ln"] * args.steps / max(1, prof3["pyr_ln"][1]),
+           "ekf_update_gate": B * p_bytes * (1.0 + EKF_UPDATES / EKF_GATES), "ekf_augment": B * p_bytes * 2, "ekf_predict": B * p_bytes * 2}
+    for k in k3:
+        k3[k]["algorithmic_bytes_per_launch"] = alg[k]
+        k3[k]["achieved_GBs"] = alg[k] / (k3[k]["avg_ms"] * 1e-3) / 1e9
+    dom = max(k3, key=lambda k: k3[k]["total_ms"])
+    prof_t = profiled_traffic() if rank == 0 else None
+    traffic, traffic_note = None, None
+    if prof_t is not None:
+        key = {"klt": "klt_kernel", "pyr_l0": "pyr_level_kernel_L0", "ekf_update_gate": "ekf_update_kernel"}.get(dom)
+        if key in prof_t and prof_t[key].get("hbm_bytes_per_launch") is not None:
+            traffic = prof_t[key]["hbm_bytes_per_launch"] * B / float(prof_t.get("sequences_per_gpu", B))
+            traffic_note = (f"rocprofv3 FETCH_SIZE x2 + WRITE_SIZE per launch from {prof_t['_file']} "
+                            f"(collected at B={prof_t.get('sequences_per_gpu')}, scaled to B={B})")
+    stage_ms = sum(k3[k]["ms_per_step"] for k in ("pyr_l0", "pyr_ln", "klt") if k in k3)
+    stage_gbs = B * ab["stereo_frame"] / (stage_ms * 1e-3) / 1e9
+    if rank == 0:
+        head = {
+            "metric": "VIO frames/sec at 752x480 stereo, 200 KLT features; pyramid+KLT HBM GB/s",
+            "value": aggregate_value(B, world, args.steps, el3), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": el3 / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u8/int16 pixels, int32/int64 sums, f32 solve (tracker); f64 (EKF)", "data": "synthetic",
+            "config": {"workload": "C3: 752x480 stereo, 200 pts -- per sequence and frame 2 pyramid builds + 2 LK calls (HIP tracker) and the HIP EKF: "
+                                   "10 predicts in one launch, 20 chi2 gates (n=40, l=160) of which 5 update, symmetrise, 1 Joseph-form augmentation; "
+                                   "state dim 160",
+                       "sequences_per_gpu": B, "frames_per_step": world * B, "parallelism": f"replicas x{world} (no collective)",
+                       "timing_process_group": args.dist_backend if world > 1 else None, "host_cores_per_rank": env.cores},
+            "roofline": {"bound": "hbm", "kernel": dom, "achieved": k3[dom]["achieved_GBs"], "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": k3[dom]["achieved_GBs"] / HBM_PEAK_GBS, "traffic": traffic,
+                         "algorithmic_bytes_per_launch": alg[dom], "avg_launch_ms": k3[dom]["avg_ms"], "traffic_source": traffic_note,
+                         "limiter": ("klt_kernel is VALU-issue bound (rocprof: VALU busy > 80 %, HBM traffic < algorithmic bytes); "
+                                     "the HBM-bound kernel of the path is pyr_l0, see kernels / measured_ceilings") if dom == "klt" else None},
+            "measured_ceilings_GBs": (prof_t or {}).get("measured_hbm_ceilings_GBs"),
+            "kernels": k3,
+            # the reference's own `-timer` keys -> device ms per step of B frames
+            "timers_ms_per_step": {"pyramid": sum(k3[k]["ms_per_step"] for k in ("pyr_l0", "pyr_ln") if k in k3),
+                                   "computeOpticalFlow": k3.get("klt", {}).get("ms_per_step"),
+                                   "KF predict": k3.get("ekf_predict", {}).get("ms_per_step"),
+                                   "trackerVisualUpdate": k3.get("ekf_update_gate", {}).get("ms_per_step"),
+                                   "augmentation": k3.get("ekf_augment", {}).get("ms_per_step")},
+            "stage_pyramid_klt": {"ms_per_step": stage_ms, "achieved_GBs": stage_gbs, "frac_of_8TBs": stage_gbs / HBM_PEAK_GBS,
+                                  "frac_of_measured_copy_ceiling": stage_gbs / HBM_COPY_CEILING_GBS,
+                                  "algorithmic_bytes_per_stereo_frame": ab["stereo_frame"]},
+            "updates_accepted_fraction": accepted / float(B * args.steps * EKF_UPDATES * (1 + args.warmup / args.steps)),
+            "tracked_fraction": c2["tracked_fraction"],
+            "c2": c2,
+        }
+        head.update(out)
+        out = head
     del tb
 
-    if rank == 0 and not args.no_latency_mode:
+    # ---- frames handed over as HOST buffers (the reference's boundary): every rank feeds its own GPU from pinned memory ----
+    if not args.no_pcie:
+        pc = bench_pcie_inclusive(env, local_rank, rank)
+        if rank == 0:
+            out["pcie_inclusive"] = pc
+
+    # ---- C4 (configs[3]): 1280x720 stereo, 400 features, tracker stage ----
+    if not args.no_c4:
+        W0, H0, N0 = W, H, NPTS
+        W, H, NPTS = 1280, 720, 400
+        B4 = max(1, min(B, 256))
+        tb4, c4 = tracker_leg(env, args, B4, local_rank, rank, "C4: 1280x720 stereo, 400 pts, HIP pyramid+KLT tracker (HBM-bandwidth stress)")
+        del tb4
+        W, H, NPTS = W0, H0, N0
+        if rank == 0:
+            out["c4"] = c4
+
+    if rank == 0 and solo and not args.no_latency_mode:
         # latency mode: ONE sequence, one frame at a time (what a single `main` process sees)
         t1 = TrackerBench(1, local_rank, seed=12345)
         for _ in range(2 * N_CYCLE):
@@ -793,25 +900,24 @@ def main():
             t1.step()
         torch.cuda.synchronize()
         lat = (time.perf_counter() - t0) / n_lat
-        out["latency_mode"] = {"sequences": 1, "ms_per_frame": lat * 1e3, "frames_per_s": 1.0 / lat,
-                               "tracked_fraction": t1.tracked_fraction(), "launch": "eager"}
-        if not args.no_ekf:
-            # the same single sequence with its EKF (C3 at B = 1): what one drop-in `main` sees per frame
-            e1 = EkfBench(t1.ctx, 1, local_rank, seed=12345)
-            for _ in range(N_CYCLE):
-                t1.step(); e1.step()
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            for _ in range(n_lat):
-                t1.step(); e1.step()
-            torch.cuda.synchronize()
-            lat3 = (time.perf_counter() - t0) / n_lat
-            out["c3"]["latency_mode"] = {"sequences": 1, "ms_per_frame": lat3 * 1e3, "frames_per_s": 1.0 / lat3,
-                                         "launch": "eager", "launches_per_frame": 6 + 1 + EKF_GATES + 2}
-            e1.ekf.close()
-            del e1
-        # The eager number is host-launch bound (~16 launches per frame). A step is a fixed launch
-        # sequence with period N_CYCLE, so capture it in HIP graphs and replay: GPU-bound latency.
+        out["c2"]["latency_mode"] = {"sequences": 1, "ms_per_frame": lat * 1e3, "frames_per_s": 1.0 / lat,
+                                     "tracked_fraction": t1.tracked_fraction(), "launch": "eager"}
+        # the same single sequence with its EKF (C3 at B = 1): what one drop-in `main` sees per frame
+        e1 = EkfBench(t1.ctx, 1, local_rank, seed=12345)
+        for _ in range(N_CYCLE):
+            t1.step(); e1.step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n_lat):
+            t1.step(); e1.step()
+        torch.cuda.synchronize()
+        lat3 = (time.perf_counter() - t0) / n_lat
+        out["latency_mode"] = {"sequences": 1, "ms_per_frame": lat3 * 1e3, "frames_per_s": 1.0 / lat3,
+                               "launch": "eager", "launches_per_frame": 7 + 1 + EKF_GATES + 2}
+        e1.ekf.close()
+        del e1
+        # The eager number is host-launch bound. A step is a fixed launch sequence with period N_CYCLE, so capture it in
+        # HIP graphs and replay: GPU-bound latency (tracker half).
         try:
             side = torch.cuda.Stream()
             t1.ctx.set_stream(side.cuda_stream)
@@ -835,20 +941,33 @@ def main():
                     graphs[i % N_CYCLE].replay()
                 side.synchronize()
             latg = (time.perf_counter() - t0) / n_lat
-            out["latency_mode_graph"] = {"sequences": 1, "ms_per_frame": latg * 1e3, "frames_per_s": 1.0 / latg,
-                                         "tracked_fraction": t1.tracked_fraction(), "launch": "hipGraph replay"}
+            out["c2"]["latency_mode_graph"] = {"sequences": 1, "ms_per_frame": latg * 1e3, "frames_per_s": 1.0 / latg,
+                                               "tracked_fraction": t1.tracked_fraction(), "launch": "hipGraph replay"}
             del graphs
         except Exception as ex:                               # pragma: no cover
-            out["latency_mode_graph"] = {"error": repr(ex)[:200]}
+            out["c2"]["latency_mode_graph"] = {"error": repr(ex)[:200]}
         del t1
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline()
-        if "c3" in out:
-            fps_ekf, sample = cpu_baseline_ekf()
-            fps_trk = out["cpu_baseline"]["value"]
-            out["c3"]["cpu_baseline"] = {"value": 1.0 / (1.0 / fps_trk + 1.0 / fps_ekf), "unit": "frames/s", "cores": 1,
-                                         "kind": "port", "ekf_only_frames_per_s": fps_ekf, "sample": sample}
+    if rank == 0 and solo and not args.no_cpu_baseline:
+        trk = cpu_baseline()
+        fps_ekf, sample, tm_ekf = cpu_baseline_ekf()
+        out["c2"]["cpu_baseline"] = trk
+        nat = cpu_baseline_native()
+        # headline baseline = the C3 frame (tracker + EKF) on the CPU: the tracker on its best thread count, the EKF on one
+        # thread as the reference runs it (EIGEN_DONT_PARALLELIZE, CMakeLists.txt:43-48)
+        comb = lambda f_trk, f_ekf: 1.0 / (1.0 / f_trk + 1.0 / f_ekf)
+        out["cpu_baseline"] = {
+            "value": comb(trk["value"], fps_ekf), "unit": "frames/s", "cores": trk["cores"], "kind": "port",
+            "single_thread_value": comb(trk["single_thread_value"], fps_ekf), "tracker_only_frames_per_s": trk["value"],
+            "ekf_only_frames_per_s": fps_ekf, "compiler_flags": trk["compiler_flags"],
+            "timers_ms_per_frame": dict(trk["timers_ms_per_frame"][f"threads_{trk['cores']}"] if f"threads_{trk['cores']}" in trk["timers_ms_per_frame"]
+                                        else trk["timers_ms_per_frame"]["threads_1"], **tm_ekf),
+            "sample": trk["sample"] + " | " + sample,
+            "O3_march_native": ({"value": comb(nat["value"], nat["ekf_only_frames_per_s"]), "single_thread_value": comb(nat["single_thread_value"], nat["ekf_only_frames_per_s"]),
+                                 "tracker_only_frames_per_s": nat["value"], "ekf_only_frames_per_s": nat["ekf_only_frames_per_s"], "cores": nat["cores"],
+                                 "timers_ms_per_frame": dict(list(nat["timers_ms_per_frame"].values())[-1], **nat["ekf_timers_ms_per_frame"])}
+                                if "error" not in nat else nat)}
     if rank == 0:
+        out["max_barrier_wait_s"] = env.max_barrier_wait_s
         print(json.dumps(out))
     env.close()
 

@@ -399,9 +399,17 @@ __global__ __launch_bounds__(64, WPS) void klt_kernel(KltArgs a)
         }
 
         float D = A11 * A22 - A12 * A12;
-        const float min_eig = (A22 + A11 - sqrtf((A11 - A22) * (A11 - A22) + 4.f * A12 * A12)) /
-                              (float)(2 * WIN * WIN);
-        if (min_eig < a.min_eig || D < FLT_EPSILON) {
+        // cv: minEig = (A22 + A11 - sqrt((A11-A22)^2 + 4 A12^2)) / (2 win^2) < minEigThreshold. Only the comparison is live
+        // (the value would go to err under OPTFLOW_LK_GET_MIN_EIGENVALS, which the reference does not set), so it is decided
+        // from the raw v_sqrt_f32 (1 ulp, no denormal fix-up, no division) unless the numerator lies within a few ulps of
+        // its operands of the threshold; only then the correctly rounded sqrt and the IEEE division of the oracle run.
+        const float tr = A22 + A11, disc = (A11 - A22) * (A11 - A22) + 4.f * A12 * A12;
+        const float num_fast = tr - __builtin_amdgcn_sqrtf(disc), bound = a.min_eig * (float)(2 * WIN * WIN);
+        const float margin = 4e-6f * fabsf(tr) + 1e-5f * bound + 1e-30f;
+        bool weak;
+        if (fabsf(num_fast - bound) > margin) weak = num_fast < bound;
+        else weak = (tr - sqrtf(disc)) / (float)(2 * WIN * WIN) < a.min_eig;
+        if (weak || D < FLT_EPSILON) {
             if (level == 0) st = 0;
             continue;
         }

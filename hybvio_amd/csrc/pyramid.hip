@@ -220,30 +220,44 @@ __global__ __launch_bounds__(256) void pyr_border_kernel(BorderArgs a)
     int item = blockIdx.x * 256 + threadIdx.x;
     for (int l = a.first_level; l < L.levels; ++l) {
         const int pd = L.pad[l], w = L.w[l], h = L.h[l], gs = L.gstride[l];
-        const int gw = (w + 2 * pd + 3) >> 2, rows = h + 2 * pd, n = gw * rows;
-        if (item < n) {
-            const int r = item / gw, g = item - r * gw;
-            const int y = r - pd, x = 4 * g - pd;
-            if (!(y >= 0 && y < h && x >= 0 && x + 4 <= w)) {
-                uint8_t *img = slot + L.goff[l];
-                const uint8_t *src = img + (long long)reflect101(y, h) * gs;
-                uint8_t *dst = img + (long long)y * gs + x;
-                if (y >= 0 && y < h) {                      // a row of the image: only the pixels outside it are written
+        // items of a level: the pd rows above and below the image at full padded width, then the left and right pd columns
+        // of the image rows -- all in dwords (the padded width and pd are multiples of 4 up to the ragged right end)
+        const int gw = (w + 2 * pd + 3) >> 2, n_tb = 2 * pd * gw;
+        const int wq = w & ~3;                              // columns [wq, w + pd) form the right strip (dword aligned start)
+        const int gr = (w + pd - wq + 3) >> 2, gl = pd >> 2, n_lr = h * (gl + gr);
+        if (item < n_tb + n_lr) {
+            uint8_t *img = slot + L.goff[l];
+            int x, y;
+            if (item < n_tb) {
+                const int r = item / gw;
+                x = 4 * (item - r * gw) - pd;
+                y = r < pd ? r - pd : h + (r - pd);
+            } else {
+                const int e = item - n_tb, r = e / (gl + gr), g = e - r * (gl + gr);
+                y = r;
+                x = g < gl ? 4 * g - pd : wq + 4 * (g - gl);
+            }
+            const uint8_t *src = img + (long long)reflect101(y, h) * gs;
+            uint8_t *dst = img + (long long)y * gs + x;
+            if (x >= 0 && x + 4 <= w) {                      // above / below the image, inside its columns: a dword copy
+                *reinterpret_cast<uint32_t *>(dst) = *reinterpret_cast<const uint32_t *>(src + x);
+            } else {
+                uint32_t v = 0;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) v |= (uint32_t)src[reflect101(x + i, w)] << (8 * i);
+                // the right strip of an image row may start inside the image (w % 4 != 0): those bytes are rewritten with
+                // their own values (reflect101 of an inside column is the column)
+                if (x + 4 <= w + pd) {
+                    *reinterpret_cast<uint32_t *>(dst) = v;
+                } else {
 #pragma unroll
                     for (int i = 0; i < 4; ++i)
-                        if ((x + i < 0 || x + i >= w) && x + i < w + pd) dst[i] = src[reflect101(x + i, w)];
-                } else {
-                    const uint32_t v = (uint32_t)src[reflect101(x, w)] | ((uint32_t)src[reflect101(x + 1, w)] << 8) |
-                                       ((uint32_t)src[reflect101(x + 2, w)] << 16) | ((uint32_t)src[reflect101(x + 3, w)] << 24);
-                    if (x + 4 <= w + pd) *reinterpret_cast<uint32_t *>(dst) = v;
-                    else
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) if (x + i < w + pd) dst[i] = (uint8_t)(v >> (8 * i));
+                        if (x + i < w + pd) dst[i] = (uint8_t)(v >> (8 * i));
                 }
             }
             return;
         }
-        item -= n;
+        item -= n_tb + n_lr;
     }
 }
 
@@ -312,7 +326,10 @@ int launch_pyramid_levels(Ctx *c, int n, const int *slots_dev, const uint8_t *sr
         BorderArgs a{};
         a.L = L; a.slab = c->slab; a.slots = slots_dev; a.first_level = fl;
         int items = 0;
-        for (int l = fl; l < L.levels; ++l) items += ((L.w[l] + 2 * L.pad[l] + 3) >> 2) * (L.h[l] + 2 * L.pad[l]);
+        for (int l = fl; l < L.levels; ++l) {
+            const int pd = L.pad[l], w = L.w[l], h = L.h[l];
+            items += 2 * pd * ((w + 2 * pd + 3) >> 2) + h * ((pd >> 2) + ((w + pd - (w & ~3) + 3) >> 2));
+        }
         ScopedKernelTime tm(c, HV_K_PYR_LN);
         hipLaunchKernelGGL(pyr_border_kernel, dim3((unsigned)((items + 255) / 256), (unsigned)n), dim3(256), 0, c->stream, a);
         HV_HIP(c, hipGetLastError());

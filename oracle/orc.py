@@ -22,6 +22,12 @@ f64p = C.POINTER(C.c_double)
 
 
 def build(force: bool = False) -> str:
+    if os.environ.get("ORC_NATIVE") == "1":
+        # -O3 -march=native build for bench.py's second CPU column: compiled on the machine that runs it, outside the tree
+        import tempfile
+        so = os.path.join(tempfile.gettempdir(), f"liboracle_native_{os.getuid()}.so")
+        subprocess.check_call(["make", "-C", _DIR, "-B", "native", f"NATIVE_OUT={so}"], stdout=subprocess.DEVNULL)
+        return so
     so = os.path.join(_DIR, "liboracle.so")
     srcs = [os.path.join(_DIR, f) for f in ("pyrlk_oracle.c", "ekf_oracle.c", "gftt_oracle.c", "ingest_oracle.c", "triangulation_oracle.c", "rot_ransac_oracle.c", "Makefile")]
     if force or not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):

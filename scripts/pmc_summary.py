@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
-"""Aggregate a rocprofv3 --pmc counter_collection CSV per (kernel, counter): mean per dispatch."""
-import csv
+"""Aggregate a rocprofv3 --pmc counter_collection CSV per (kernel, grid size, counter): mean per dispatch.
+Keyed by GRID SIZE as well as by name: the three level launches of pyr_level_kernel<true> share a name, and legs at other
+batch sizes must not pollute the figure of the launch bench.py's roofline refers to."""
 import collections
+import csv
 import glob
 import re
 import sys
@@ -11,10 +13,11 @@ for path in glob.glob(sys.argv[1] + "/**/*counter_collection.csv", recursive=Tru
     with open(path) as f:
         for r in csv.DictReader(f):
             name = r["Kernel_Name"]
-            m = re.search(r"(klt_kernel|pyr_level_kernel<\w+>|ekf_\w+)", name)
-            k = (m.group(1) if m else name[:48].replace(",", ";"), r["Counter_Name"])
+            m = re.search(r"(klt_kernel|pyr_level_kernel<\w+>|pyr_border_kernel|ekf_\w+?_kernel|vu_prepare_kernel|gftt_\w+|rot_ransac_kernel)", name)
+            grid = r.get("Grid_Size", r.get("Grid_Size_X", "?"))
+            k = (m.group(1) if m else name[:48].replace(",", ";"), grid, r["Counter_Name"])
             acc[k][0] += float(r["Counter_Value"])
             acc[k][1] += 1
-print("kernel,counter,mean_per_dispatch,dispatches")
-for (k, c), (s, n) in sorted(acc.items()):
-    print(f"{k},{c},{s / n:.6g},{n}")
+print("kernel,grid,counter,mean_per_dispatch,dispatches")
+for (k, g, c), (s, n) in sorted(acc.items()):
+    print(f"{k},{g},{c},{s / n:.6g},{n}")

@@ -8,7 +8,7 @@ import time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench  # noqa: E402
 
-env = bench.DistEnv("gloo")
+env = bench.DistEnv("gloo", use_cuda=False)
 work = {"calls": 0}
 
 
@@ -18,7 +18,15 @@ def step():                      # rank r is slower than rank 0: the reported ti
 
 
 seconds = env.timed(step, 5)
+# every replica works on its own inputs: the per-rank seed must give different crops (gathered over the host group)
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+mine = torch.from_numpy(bench.crop_offsets(16, env.rank).astype("int64"))
+allo = [torch.zeros_like(mine) for _ in range(env.world)]
+dist.all_gather(allo, mine)
 if env.rank == 0:
     print(json.dumps({"world": env.world, "seconds": seconds, "calls": work["calls"],
-                      "value": bench.aggregate_value(7, env.world, 5, seconds)}))
+                      "value": bench.aggregate_value(7, env.world, 5, seconds),
+                      "inputs_differ": bool(any((allo[0] != a).any() for a in allo[1:])),
+                      "max_barrier_wait_s": env.max_barrier_wait_s, "cores": env.cores}))
 env.close()

@@ -27,10 +27,12 @@ def test_two_rank_timing_contract_over_gloo():
     assert d["world"] == 2 and d["calls"] == 5
     assert d["seconds"] >= 5 * 0.03 * 0.9                      # rank 1 sleeps 30 ms per step: MAX over ranks
     assert abs(d["value"] - 2 * 7 * 5 / d["seconds"]) < 1e-9   # whole-job aggregate: all ranks' units / max time
+    assert d["inputs_differ"]                                   # rank-seeded inputs: replicas do not repeat each other
+    assert d["max_barrier_wait_s"] < 1.0                        # no rank sits at a barrier while another does extra legs
 
 
 def test_single_process_needs_no_rendezvous():
-    env = bench.DistEnv("gloo")
+    env = bench.DistEnv("gloo", use_cuda=False)
     assert env.world == 1 and env.dist is None
     assert env.max_over_ranks(1.5) == 1.5
     assert bench.aggregate_value(256, 1, 10, 2.0) == 1280.0
