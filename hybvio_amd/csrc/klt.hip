@@ -45,7 +45,7 @@ constexpr int GRAY_SHIFT = 7;          // gray samples are pre-scaled by 128 (<=
 // dot2 chain starts from 0. Gradients are stored as 4*d + 2 for the same reason (pyramid.hip).
 constexpr uint32_t ROUND_PAIR = 0x00020002u;
 constexpr int W_BITS = 14;
-constexpr int KLT_TILE_DEFAULT = 5;
+constexpr int KLT_TILE_DEFAULT = 1;   // 5 (96 VGPRs) spills 3 dwords to scratch: after a kernel with a large scratch frame ran on the queue (vu_prepare) it lost 35 % (bench r02)
 
 struct KltArgs {
     PyrLayout L;

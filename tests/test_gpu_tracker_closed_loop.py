@@ -1,24 +1,36 @@
 """Closed-loop tracker parity (north star: "tracked-feature IDs/status bit-exact"): a miniature of
-TrackerImplementation::add (src/tracker/tracker.cpp:178-239, 378-559, 675-703) -- detect, temporal LK,
-stereo LK, failure merge, track bookkeeping with the reference's ID rule (nextTrackId = frameNum * maxTracks
-+ 1, tracker.cpp:199) and re-detection masked by the live tracks -- driven once through the HIP library
-and once through the CPU oracle on the same synthetic stereo sequence. Because every frame's inputs are the
-previous frame's outputs, any single differing status or sub-pixel position would fork the two runs: IDs,
-statuses and positions must stay identical for the whole sequence. (RANSAC, the epipolar check and the
-flow predictor are host code outside SURVEY.md section 8 and are left out of both runs.)"""
+TrackerImplementation::add (src/tracker/tracker.cpp:178-239, 378-559, 675-703) -- detect, temporal LK started from a flow
+prediction (useInitialCorners), 2-point rotation RANSAC on the tracked features with ONE std::mt19937 shared by all frames
+(ransac_pipeline.cpp:197-216, rot_ransac.cpp:41-120), stereo LK, failure merge, track bookkeeping with the reference's ID rule
+(nextTrackId = frameNum * maxTracks + 1, tracker.cpp:199) and re-detection masked by the live tracks -- driven once through the
+HIP library and once through the CPU oracle on the same synthetic stereo sequence. Because every frame's inputs are the
+previous frame's outputs (positions, the generator's state), any single differing status or sub-pixel position would fork the
+two runs: IDs, statuses and positions must stay identical for the whole sequence.
+
+Configurations: the r01 miniature, BASELINE.json's 752x480 / 200 tracks over 200 frames and one
+1280x720 / 400 run. (The epipolar check and the IMU-driven flow predictor are host code outside SURVEY.md section 8; the
+prediction used here is the constant-velocity one, the same in both runs.)"""
 import numpy as np
 import pytest
 
 from hybvio_amd import capi, synth
 
 pytestmark = pytest.mark.gpu
-MAX_TRACKS, MIN_DIST = 120, 20
+SEED = 4649                       # ransacRngSeed-like constant: one generator for the whole sequence
+
+
+def cam_args(w, h):
+    f = 0.61 * w                   # EuRoC-like: 458 px at 752
+    return ("pinhole", f, f * 0.997, w * 0.488, h * 0.517), [-0.2834, 0.0740, 0.0]
 
 
 class HipBackend:
-    def __init__(self, w, h):
-        self.ctx = capi.Context(width=w, height=h, max_tracks=4 * MAX_TRACKS, pool_size=8)
-        self.gp = capi.gftt_default_params(gfttMinDistance=float(MIN_DIST), maxTracks=MAX_TRACKS)
+    def __init__(self, w, h, max_tracks, min_dist):
+        self.ctx = capi.Context(width=w, height=h, max_tracks=4 * max_tracks, pool_size=4)      # the pool grows on demand
+        self.gp = capi.gftt_default_params(gfttMinDistance=float(min_dist), maxTracks=max_tracks)
+        a, c = cam_args(w, h)
+        self.cam = capi.camera_model(*a, coeffs=c)
+        self.pos = 0               # draws consumed from the shared generator
 
     def build(self, img):
         s = self.ctx.acquire(); self.ctx.build(s, img); return s
@@ -32,10 +44,22 @@ class HipBackend:
     def detect(self, handle, mask, r):
         return self.ctx.gftt_detect(handle, prev=mask, mask_radius=r, params=self.gp)
 
+    def ransac(self, oracle, c1, c2, thr):
+        # what RotRansac::buildHip does (hybvio_amd/host/hip_tracker.cpp): pairs from a COPY of the generator, then advance
+        # the real one by what the reference loop would have consumed
+        draws = oracle.mt19937_draws(SEED, 200, skip=self.pos)
+        pairs = (draws.astype(np.uint64) % np.uint64(len(c1))).astype(np.int32).reshape(100, 2)
+        st, R, best, visited = self.ctx.rot_ransac(c1, c2, self.cam, self.cam, pairs, thr)
+        self.pos += 2 * visited
+        return st, best
+
 
 class OracleBackend:
-    def __init__(self, oracle):
-        self.o = oracle
+    def __init__(self, oracle, w, h, max_tracks, min_dist):
+        self.o, self.max_tracks, self.min_dist = oracle, max_tracks, min_dist
+        a, c = cam_args(w, h)
+        self.cam = oracle.Camera(*a, coeffs=c)
+        self.pos = 0
 
     def build(self, img):
         return (self.o.Pyramid(img), img)
@@ -47,58 +71,90 @@ class OracleBackend:
         return self.o.optical_flow_compute(prev[0], cur[0], pts, corners=guess)
 
     def detect(self, handle, mask, r):
-        return self.o.gftt_detect(handle[1], prev=mask, mask_radius=r, min_distance=float(MIN_DIST), max_tracks=MAX_TRACKS)
+        return self.o.gftt_detect(handle[1], prev=mask, mask_radius=r, min_distance=float(self.min_dist), max_tracks=self.max_tracks)
+
+    def ransac(self, oracle, c1, c2, thr):
+        st, R, best, used = self.o.rot_ransac_fit(c1, c2, self.cam, self.cam, self.o.mt19937_draws(SEED, 200, skip=self.pos), thr)
+        self.pos += used
+        return st, best
 
 
-def run_tracker(be, left, right):
-    """Returns per frame: (ids, left points, right points, per-track status of the temporal+stereo merge)."""
-    log, tracks = [], []                       # track = [id, (x, y) left, (x, y) right]
+def run_tracker(be, oracle, left, right, w, h, max_tracks, min_dist):
+    """Returns per frame: (ids, left points, right points, per-track status after temporal LK / RANSAC / stereo merge)."""
+    log, tracks = [], []                       # track = [id, (x, y) left, (x, y) right, (vx, vy) last displacement]
     prev_l = prev_r = None
+    # RotRansac::threshold_pow2 (ransac_pipeline.cpp:91-93) with a 1 px threshold at 720p: the reference default (4 px) makes every
+    # point an inlier of the first hypothesis on these clean synthetic frames; 1 px gives ~24 hypotheses per frame and real outliers
+    thr = float(np.float32((1.0 * min(w, h) / 720.0) ** 2))
     for frame in range(len(left)):
         cur_l, cur_r = be.build(left[frame]), be.build(right[frame])
-        next_id = frame * MAX_TRACKS + 1                                               # tracker.cpp:199
+        next_id = frame * max_tracks + 1                                               # tracker.cpp:199
         status = np.zeros(0, np.int32)
         if frame > 0 and len(tracks) >= 5:                                             # tracker.cpp:209
             p0 = np.array([t[1] for t in tracks], np.float32)
-            xy, st = be.flow(prev_l, cur_l, p0)                                        # temporal, zero-flow start
+            vel = np.array([t[3] for t in tracks], np.float32)
+            xy, st = be.flow(prev_l, cur_l, p0, guess=p0 + vel)                        # predicted corners, useInitialCorners
+            status = st.copy()
+            ok = np.flatnonzero(st == 0)
+            if len(ok) >= 2:                                                           # ransac_pipeline.cpp:209
+                rs, _ = be.ransac(oracle, p0[ok], xy[ok], thr)
+                status[ok] = np.where(rs == 3, 3, status[ok])                          # RANSAC_OUTLIER
             xr, st2 = be.flow(cur_l, cur_r, xy, guess=np.array([t[2] for t in tracks], np.float32) + (xy - p0))
-            status = np.where(st2 == 2, 2, st)                                         # FAILED_FLOW merge, tracker.cpp:441-447
-            tracks = [[t[0], tuple(xy[i]), tuple(xr[i])] for i, t in enumerate(tracks) if status[i] == 0]
-        missing = MAX_TRACKS - len(tracks)
-        if frame == 0 or missing >= MAX_TRACKS // 10:                                  # tracker.cpp:683-700
+            status = np.where((st2 == 2) & (status == 0), 2, status)                   # FAILED_FLOW merge, tracker.cpp:441-447
+            tracks = [[t[0], tuple(xy[i]), tuple(xr[i]), tuple(xy[i] - p0[i])] for i, t in enumerate(tracks) if status[i] == 0]
+        missing = max_tracks - len(tracks)
+        if frame == 0 or missing >= max_tracks // 10:                                  # tracker.cpp:683-700
             mask = np.array([t[1] for t in tracks], np.float32).reshape(-1, 2)
-            corners = be.detect(cur_l, mask, MIN_DIST)
+            corners = be.detect(cur_l, mask, min_dist)
             if len(corners):
                 cr, sts = be.flow(cur_l, cur_r, corners)                               # detectFeatures: stereo LK for new corners
                 for i in range(len(corners)):
                     if sts[i] == 0 and missing > 0:
-                        tracks.append([next_id, tuple(corners[i]), tuple(cr[i])]); next_id += 1; missing -= 1
-        log.append((np.array([t[0] for t in tracks]), np.array([t[1] for t in tracks], np.float32),
-                    np.array([t[2] for t in tracks], np.float32), status.copy()))
+                        tracks.append([next_id, tuple(corners[i]), tuple(cr[i]), (0.0, 0.0)]); next_id += 1; missing -= 1
+        log.append((np.array([t[0] for t in tracks]), np.array([t[1] for t in tracks], np.float32).reshape(-1, 2),
+                    np.array([t[2] for t in tracks], np.float32).reshape(-1, 2), status.copy()))
         for s in (prev_l, prev_r):
             if s is not None:
                 be.release(s)
         prev_l, prev_r = cur_l, cur_r
-    return log
+    return log, be.pos
 
 
-def test_track_ids_statuses_and_positions_identical_over_a_sequence(oracle):
-    w, h, frames = 376, 240, 14
-    left, right, _ = synth.stereo_sequence(77, w, h, frames)
-    hip = HipBackend(w, h)
+def moving_sequence(seed, w, h, unique, frames, radius, rot):
+    """`frames` stereo frames cycling through a closed camera path of `unique` poses: ~2 pi radius / unique px per frame."""
+    tex = synth.Texture.make(seed)
+    warps = synth.camera_path(unique, w, h, radius_px=radius, rot_amp_deg=rot)
+    left, right = [], []
+    for k, wk in enumerate(warps):
+        left.append(synth.render(tex, w, h, wk, noise_seed=seed * 1000 + 2 * k, noise_sigma=1.0))
+        wr = synth.Warp(wk.A.copy(), wk.t + wk.A @ np.array([20.0, 0.0]))
+        right.append(synth.render(tex, w, h, wr, noise_seed=seed * 1000 + 2 * k + 1, noise_sigma=2.0))
+    idx = [k % unique for k in range(frames)]
+    return [left[i] for i in idx], [right[i] for i in idx]
+
+
+@pytest.mark.parametrize("w,h,max_tracks,min_dist,unique,frames", [
+    (376, 240, 120, 20, 14, 14),              # the r01 miniature
+    (752, 480, 200, 30, 40, 200),             # BASELINE.json configs[1]: 752x480, 200 tracks, 200 frames
+    (1280, 720, 400, 30, 16, 24),             # configs[3]: 1280x720, 400 tracks
+])
+def test_track_ids_statuses_and_positions_identical_over_a_sequence(oracle, w, h, max_tracks, min_dist, unique, frames):
+    left, right = moving_sequence(77, w, h, unique, frames, radius=0.5 * unique, rot=1.2)    # ~3 px and ~0.2 deg per frame
+    hip = HipBackend(w, h, max_tracks, min_dist)
     try:
-        got = run_tracker(hip, left, right)
+        got, pos_hip = run_tracker(hip, oracle, left, right, w, h, max_tracks, min_dist)
     finally:
         hip.ctx.close()
-    ref = run_tracker(OracleBackend(oracle), left, right)
-    born, lost = set(), 0
+    ref, pos_ref = run_tracker(OracleBackend(oracle, w, h, max_tracks, min_dist), oracle, left, right, w, h, max_tracks, min_dist)
+    born, lost, ransac_out = set(), 0, 0
     for f, ((gi, gl, gr, gs), (oi, ol, orr, os_)) in enumerate(zip(got, ref)):
         np.testing.assert_array_equal(gs, os_, err_msg=f"frame {f}: status")
         np.testing.assert_array_equal(gi, oi, err_msg=f"frame {f}: track ids")
         np.testing.assert_array_equal(gl, ol, err_msg=f"frame {f}: left positions")
         np.testing.assert_array_equal(gr, orr, err_msg=f"frame {f}: right positions")
-        born |= set(gi.tolist()); lost += int((gs != 0).sum())
+        born |= set(gi.tolist()); lost += int((gs != 0).sum()); ransac_out += int((gs == 3).sum())
+    assert pos_hip == pos_ref and pos_hip > 0                                       # the shared generator ends in the same state
     ids_last = got[-1][0]
-    assert len(ids_last) >= MAX_TRACKS // 2 and len(born) > len(ids_last)          # tracks were lost and re-detected on the way
-    assert ids_last.min() <= MAX_TRACKS and ids_last.max() > MAX_TRACKS             # survivors from frame 0 next to later births
-    assert lost > 0
+    assert len(ids_last) >= max_tracks // 2 and len(born) > len(ids_last)          # tracks were lost and re-detected on the way
+    assert ids_last.max() > max_tracks                                             # later births next to earlier tracks
+    assert lost > 0 and ransac_out > 0 and pos_hip > 8 * frames                    # the hypothesis loop did real work
