@@ -63,10 +63,10 @@ def crop_offsets(B, seed, M=32):
 class TrackerBench:
     """B sequences x (2 pyramid builds + 2 LK calls) per step, everything device resident."""
 
-    def __init__(self, B, device, seed=0):
+    def __init__(self, B, device, seed=0, chain=False):
         import torch
         from hybvio_amd import capi, synth
-        self.torch, self.B = torch, B
+        self.torch, self.B, self.chain = torch, B, chain
         dev = torch.device("cuda", device)
         self.ctx = capi.Context(width=W, height=H, levels=LEVELS, max_tracks=NPTS, pool_size=3 * B,
                                 max_pairs=B, device=device)
@@ -105,8 +105,29 @@ class TrackerBench:
         self.err = torch.zeros(B * NPTS, dtype=torch.float32, device=dev)
         self.k = 0
         self.tracked = torch.ones(B * NPTS, dtype=torch.bool, device=dev)
+        if chain:
+            self.enable_chain(seed)
         self._build(0)                                                          # frame 0 primes "prev"
         self.k = 1
+
+    def enable_chain(self, seed=0):
+        import torch
+        from hybvio_amd import capi
+        B, dev = self.B, self.grid.device
+        self.chain = True
+        if True:
+            # the tracker stages either side of LK that exist on the device: 2-point rotation RANSAC on the
+            # temporal matches straight from the LK outputs, GFTT key points of the new left image on every second frame (the
+            # reference detects when >= 10 % of the tracks are missing: tracker.cpp:683-700)
+            self.cam = capi.camera_model("pinhole", 458.654, 457.296, 367.215, 248.375, coeffs=[-0.28340811, 0.07395907, 0.0])
+            bg = np.random.MT19937(); bg._legacy_seeding(4649 + seed)           # std::mt19937(ransacRngSeed), N_CYCLE frames of draws
+            self.draws = torch.from_numpy(bg.random_raw(N_CYCLE * B * 200).astype(np.uint32).view(np.int32).reshape(N_CYCLE, B, 200)).to(dev)
+            self.npts_dev = torch.full((B,), NPTS, dtype=torch.int32, device=dev)
+            self.rst = torch.zeros((B, NPTS), dtype=torch.int32, device=dev)
+            self.rR = torch.zeros((B, 9), dtype=torch.float32, device=dev)
+            self.rsum = torch.zeros((B, 2), dtype=torch.int32, device=dev)
+            self.ransac_thr = float(np.float32((4.0 * min(W, H) / 720.0) ** 2))
+            self.kp = torch.zeros((B, self.ctx.gftt_keypoint_count(), 3), dtype=torch.float32, device=dev)
 
     def _build(self, k):
         f = self.frames[k % N_CYCLE]
@@ -118,6 +139,8 @@ class TrackerBench:
         t = self.torch
         inside = ((self.cur_left >= self.lo) & (self.cur_left < self.hi)).all(dim=1)
         ok = inside & ((self.st1 & self.st2) > 0)
+        if self.chain:
+            ok = ok & (self.rst.reshape(-1) != 3)                                # RANSAC_OUTLIER (rot_ransac.cpp:110-118)
         self.tracked = ok
         t.where(ok[:, None], self.cur_left, self.grid, out=self.pts_left)
         t.where(ok, self.cur_left[:, 0] - self.cur_right[:, 0], self.disp0, out=self.dispvec[:, 0])
@@ -143,6 +166,13 @@ class TrackerBench:
         # zero-flow prediction: use_initial_flow = 0 starts every track at its previous position
         self.ctx.klt_track_batch_dev(B, prev.data_ptr(), cur.data_ptr(), NPTS, self.pts_left.data_ptr(),
                                      self.cur_left.data_ptr(), self.st1.data_ptr(), 0, False)   # err unused, as in HybVIO
+        if self.chain:
+            self.rst.zero_()
+            self.ctx.rot_ransac_lk_batch_dev(B, NPTS, self.npts_dev.data_ptr(), self.pts_left.data_ptr(), self.cur_left.data_ptr(),
+                                             self.st1.data_ptr(), 1, self.cam, self.cam, self.draws[k % N_CYCLE].data_ptr(), self.ransac_thr,
+                                             self.rst.data_ptr(), self.rR.data_ptr(), self.rsum.data_ptr())
+            if k % 2 == 0:
+                self.ctx.gftt_keypoints_batch_dev(B, cur.data_ptr(), self.kp.data_ptr())
         t.sub(self.cur_left, self.dispvec, out=self.cur_right)                  # predicted disparity
         self.ctx.klt_track_batch_dev(B, cur.data_ptr(), self.R.data_ptr(), NPTS, self.cur_left.data_ptr(),
                                      self.cur_right.data_ptr(), self.st2.data_ptr(), 0, True)
@@ -212,6 +242,93 @@ class EkfBench:
         self.ekf.symmetrize()
         d = np.full(self.B, HANOI[self.k % len(HANOI)], np.int32)
         self.ekf._chk(capi.lib().hv_ekf_augment(self.ekf._h, d.ctypes.data_as(capi.i32p), None), "hv_ekf_augment")
+        self.k += 1
+
+
+VISITS, QUOTA, NPOSE = 20, 5, 10       # maxVisualUpdates, maxSuccessfulVisualUpdates (parameter_definitions.c:8,10); 10 stereo poses = 40 rows
+
+
+def make_visual_frame(rng, B, distinct=32):
+    """Means with a filled pose trail + VISITS stereo tracks per filter that are geometrically consistent with them (numpy only):
+    visits 3, 7, 11, 15, 19 are inliers, the others carry a gross measurement error (0.05 in normalised coordinates, ~23 px) and
+    are rejected by the chi2 gate -- SURVEY.md 8(d)'s per-frame mix of 20 gates and 5 updates. `distinct` filters are generated
+    and tiled over the batch."""
+    from hybvio_amd import synth
+    d = min(B, distinct)
+    T1, T2, means, idx0, feat0 = synth.visual_tracks(rng, d, 20, NPOSE, True)
+    idx, feat, vel, y = [idx0], [feat0], [], []
+    for k in range(1, VISITS):
+        _, _, _, i_, f_ = synth.visual_tracks(rng, d, 20, NPOSE, True, given_means=means)
+        idx.append(i_); feat.append(f_)
+    for k in range(VISITS):
+        vel.append(rng.normal(size=feat[k].shape) * 0.1)
+        yy = feat[k].reshape(d, -1) + 1e-3 * rng.normal(size=(d, feat[k].shape[1] * 2))
+        if k % (VISITS // QUOTA) != VISITS // QUOTA - 1:
+            yy = yy + 0.05 * rng.choice([-1.0, 1.0], size=yy.shape)
+        y.append(yy)
+    rep = (B + d - 1) // d
+    tile = lambda a: np.concatenate([a] * rep, axis=1)[:, :B]
+    return (T1, T2, np.concatenate([means] * rep)[:B], tile(np.stack(idx)), tile(np.stack(feat)), tile(np.stack(vel)), tile(np.stack(y)))
+
+
+class _DevView:                                     # zero-copy torch view of the library's device buffers
+    def __init__(self, ptr, shape):
+        self.__cuda_array_interface__ = {"shape": shape, "typestr": "<f8", "data": (ptr, False), "version": 2}
+
+
+class VisualEkfBench:
+    """The EKF half of a frame as the backend drives it (backend.cpp:716-867), every call on the device and batched over B filters:
+    hv_ekf_visual_frame_dev -- 20 track visits, each triangulated and linearised FROM THE DEVICE MEAN (row f3), chi2-gated and,
+    for the 5 inliers, applied --, symmetrise, pose augmentation, then the 10 IMU predicts up to the next frame.
+    The filters are put back to the same trail state at the start of every step (device copy, inside the timed region) so that
+    the synthetic tracks stay geometrically consistent with the means frame after frame."""
+
+    def __init__(self, ctx, B, device, seed=0):
+        import torch
+        from hybvio_amd import capi
+        self.torch, self.B, self.ctx = torch, B, ctx
+        dev = torch.device("cuda", device)
+        rng = np.random.default_rng(300 + seed)
+        T1, T2, means, idx, feat, vel, y = make_visual_frame(rng, B)
+        self.vp = capi.vu_default_params(imu_to_camera=T1, second_imu_to_camera=T2)
+        self.ekf = capi.EkfBatch(ctx, capi.ekf_default_params(cameraTrailLength=20), B)
+        _, P = self.ekf.get_state(0)
+        P = P * 1e-6 + np.eye(self.ekf.n) * 1e-4
+        to = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a, dt)).to(dev)
+        self.m0 = to(means, np.float64)
+        self.P0 = to(np.broadcast_to(P, (B,) + P.shape), np.float64)
+        self.idx, self.feat, self.vel, self.y = to(idx, np.int32), to(feat, np.float64), to(vel, np.float64), to(y, np.float64)
+        self.st = torch.zeros((VISITS, B, 2), dtype=torch.int32, device=dev)
+        self.gs = torch.zeros((VISITS, B), dtype=torch.int32, device=dev)
+        self.counter = torch.zeros((B,), dtype=torch.int32, device=dev)
+        self.dtn = torch.full((EKF_PREDICTS, B), 0.005, dtype=torch.float64, device=dev)
+        self.gyro = torch.from_numpy(rng.normal(0, 0.05, (EKF_PREDICTS, B, 3))).to(dev)
+        self.acc = torch.from_numpy(rng.normal(0, 0.05, (EKF_PREDICTS, B, 3)) + [0.0, 0.0, 9.819]).to(dev)
+        self.drop = [torch.full((B,), h, dtype=torch.int32, device=dev) for h in HANOI]
+        self.views = {}
+        self.k = 0
+        self.applied = torch.zeros((), dtype=torch.int64, device=dev)
+        self.step(); self.step()                      # first use allocates the library's work buffers (both covariance buffers seen)
+        torch.cuda.synchronize()
+        self.applied.zero_()
+
+    def _views(self):
+        mp, pp = self.ekf.device_pointers()            # augmentation ping-pongs the covariance buffer: look it up every frame
+        if pp not in self.views:
+            n, B, t = self.ekf.n, self.B, self.torch
+            self.views[pp] = (t.as_tensor(_DevView(mp, (B, n)), device=self.m0.device), t.as_tensor(_DevView(pp, (B, n, n)), device=self.m0.device))
+        return self.views[pp]
+
+    def step(self):
+        mv, Pv = self._views()
+        mv.copy_(self.m0); Pv.copy_(self.P0)
+        e = self.ekf
+        e.visual_frame_dev(self.vp, VISITS, NPOSE, self.idx.data_ptr(), self.feat.data_ptr(), self.vel.data_ptr(), self.y.data_ptr(),
+                           1.5, 0.05, self.st.data_ptr(), self.gs.data_ptr(), self.counter.data_ptr(), QUOTA)
+        self.applied += self.counter.sum()
+        e.symmetrize()
+        e.augment_dev(self.drop[self.k % len(HANOI)].data_ptr())
+        e.predict_n_dev(EKF_PREDICTS, self.dtn.data_ptr(), self.gyro.data_ptr(), self.acc.data_ptr())
         self.k += 1
 
 
@@ -311,6 +428,52 @@ def cpu_baseline(budget_s=10.0):
                 timers_ms_per_frame={"threads_1": tm_one, f"threads_{best_n}": tm_all},
                 sample=f"{f_all} stereo frames 752x480 x 200 pts in {t_all:.1f} s on {best_n} threads (OpenMP over rows / points, best of "
                        f"the team sizes probed) + {f_one} frames in {t_one:.1f} s on 1 thread; oracle/pyrlk_oracle.c {flags}")
+
+
+def cpu_baseline_visual_chain(budget_s=8.0):
+    """The EKF half of the chained frame on the CPU oracle, one thread as the reference runs it: per frame 20 x (triangulate +
+    prepareVisualUpdate from the current mean, chi2 gate, update for the 5 inliers), maintainPSD, augmentation, 10 predicts; the
+    filter is reset to the same trail state per frame exactly as VisualEkfBench does."""
+    from oracle import orc
+    rng = np.random.default_rng(300)
+    T1, T2, means, idx, feat, vel, y = make_visual_frame(rng, 1, distinct=1)
+    par = orc.tri_default_params()
+    e = orc.Ekf()
+    P0 = e.P.copy() * 1e-6 + np.eye(e.n) * 1e-4
+    frames, t0, applied = 0, time.perf_counter(), 0
+    tm = {"trackerVisualUpdate": 0.0, "augmentation": 0.0, "KF predict": 0.0}
+    e.set_first_sample_time(0.0)
+    t = 0.0
+    while True:
+        ta = time.perf_counter()
+        e.set_state(means[0]); e.set_cov(P0)
+        ok = 0
+        for k in range(VISITS):
+            if ok >= QUOTA:
+                break
+            ts, ps, pf, Hm, f = orc.visual_track_prepare(par, e.m, idx[k, 0], T1, T2, feat[k, 0], vel[k, 0])
+            if ts != 0 or ps != 0:
+                continue
+            st, _ = e.visual_track_outlier_check(Hm, f, y[k, 0], 1.5)
+            if st == 0:
+                e.update_visual_track(Hm, f, y[k, 0], 0.05); ok += 1
+        applied += ok
+        tb_ = time.perf_counter()
+        e.maintain_psd()
+        e.update_visual_pose_augmentation(HANOI[frames % len(HANOI)])
+        tc = time.perf_counter()
+        for i in range(EKF_PREDICTS):
+            t += 0.005
+            e.predict(t, rng.normal(0, 0.05, 3), np.array([0.0, 0.0, 9.819]) + rng.normal(0, 0.05, 3))
+        td = time.perf_counter()
+        tm["trackerVisualUpdate"] += tb_ - ta; tm["augmentation"] += tc - tb_; tm["KF predict"] += td - tc
+        frames += 1
+        el = time.perf_counter() - t0
+        if el > budget_s:
+            break
+    flags = "-O3 -march=native" if os.environ.get("ORC_NATIVE") == "1" else "-O2"
+    return frames / el, (f"{frames} frames of the chained EKF sequence ({applied / frames:.1f} updates applied per frame), oracle/ekf_oracle.c + "
+                         f"triangulation_oracle.c {flags}, 1 thread, {el:.1f} s"), {k: 1e3 * v / frames for k, v in tm.items()}
 
 
 def cpu_baseline_native(budget_s=6.0):
@@ -729,7 +892,7 @@ def main():
 
     if args.cpu_baseline_child is not None:                 # child of cpu_baseline_native(): CPU only
         out = cpu_baseline(args.cpu_baseline_child)
-        fps_ekf, sample, tm = cpu_baseline_ekf(0.5 * args.cpu_baseline_child)
+        fps_ekf, sample, tm = cpu_baseline_visual_chain(0.5 * args.cpu_baseline_child)
         out["ekf_only_frames_per_s"], out["ekf_sample"], out["ekf_timers_ms_per_frame"] = fps_ekf, sample, tm
         print(json.dumps(out))
         return
@@ -799,18 +962,24 @@ def main():
     if solo and not args.no_ransac:
         out["f4_rot_ransac"] = bench_rot_ransac(tb.ctx, min(B, 1024), local_rank, not args.no_cpu_baseline)
 
-    # ---- C3 (configs[2], the headline): the same tracker work + the HIP EKF ----
-    eb = EkfBench(tb.ctx, B, local_rank, seed=rank)
+    # ---- C3 (configs[2], the headline): the whole frame chained on one stream -- tracker (pyramids, temporal LK, rotation RANSAC on
+    # its output, stereo LK, GFTT on every second frame, bookkeeping) and the HIP EKF driven from the DEVICE mean (f3): 20 track
+    # visits of which 5 update, symmetrise, augmentation, 10 predicts ----
+    tb.enable_chain(rank)
+    eb = VisualEkfBench(tb.ctx, B, local_rank, seed=rank)
     for _ in range(args.warmup):
         tb.step(); eb.step()
+    eb.applied.zero_()
     tb.ctx.profile_enable(True)
     tb.ctx.profile_reset()
     el3 = env.timed(lambda: (tb.step(), eb.step()), args.steps)
-    names = (("pyr_l0", capi.K_PYR_L0), ("pyr_ln", capi.K_PYR_LN), ("klt", capi.K_KLT), ("ekf_predict", capi.K_EKF_PREDICT),
-             ("ekf_update_gate", capi.K_EKF_UPDATE), ("ekf_augment", capi.K_EKF_AUGMENT))
+    names = (("pyr_l0", capi.K_PYR_L0), ("pyr_ln", capi.K_PYR_LN), ("klt", capi.K_KLT), ("rot_ransac", capi.K_ROT_RANSAC), ("gftt", capi.K_GFTT),
+             ("ekf_predict", capi.K_EKF_PREDICT), ("vu_prepare", capi.K_VU_PREPARE), ("ekf_update_gate", capi.K_EKF_UPDATE),
+             ("ekf_augment", capi.K_EKF_AUGMENT))
     prof3 = {name: tb.ctx.profile_read(kid) for name, kid in names}
     tb.ctx.profile_enable(False)
-    accepted = int(eb.accepted.item())
+    applied = float(eb.applied.item()) / (B * args.steps)
+    gate_hist = [int((eb.gs[k] == 0).sum().item()) for k in range(VISITS)]
     eb.ekf.close()
     del eb
     n_state = 160
@@ -818,10 +987,12 @@ def main():
     ab = algorithmic_bytes()
     k3 = {k: {"avg_ms": ms / n, "launches": n, "total_ms": ms, "ms_per_step": ms / args.steps} for k, (ms, n) in prof3.items() if n}
     # algorithmic bytes per launch of the kernel classes that can dominate the step (SURVEY.md 8(d) / DESIGN.md 3):
-    #   klt: B x 200 points x 4 levels x 6144 B; pyr_l0: 2B x 1 895 040 B; ekf gate / update: B x P read once (+ written by the 1 in 4
-    #   launches that update): 204 800 B x (1 + 5/20)
+    #   klt: B x 200 points x 4 levels x 6144 B; pyr_l0: 2B x 1 895 040 B; fused gate(+update): B x P read once (+ written by the 1 in 4
+    #   launches that update) + the 40 x 160 Jacobian; vu_prepare: B x (mean in, Jacobian out); augment / predict: P read + written
+    h_bytes = 4 * NPOSE * n_state * 8
     alg = {"klt": B * ab["klt_call"], "pyr_l0": 2 * B * ab["pyr_l0"], "pyr_ln": 2 * B * ab["pyr_ln"] * args.steps / max(1, prof3["pyr_ln"][1]),
-           "ekf_update_gate": B * p_bytes * (1.0 + EKF_UPDATES / EKF_GATES), "ekf_augment": B * p_bytes * 2, "ekf_predict": B * p_bytes * 2}
+           "ekf_update_gate": B * (p_bytes * (1.0 + QUOTA / VISITS) + h_bytes), "vu_prepare": B * (n_state * 8 + h_bytes),
+           "ekf_augment": B * p_bytes * 2, "ekf_predict": B * p_bytes * 2, "rot_ransac": B * NPTS * 20, "gftt": B * W * H}
     for k in k3:
         k3[k]["algorithmic_bytes_per_launch"] = alg[k]
         k3[k]["achieved_GBs"] = alg[k] / (k3[k]["avg_ms"] * 1e-3) / 1e9
@@ -829,7 +1000,7 @@ def main():
     prof_t = profiled_traffic() if rank == 0 else None
     traffic, traffic_note = None, None
     if prof_t is not None:
-        key = {"klt": "klt_kernel", "pyr_l0": "pyr_level_kernel_L0", "ekf_update_gate": "ekf_update_kernel"}.get(dom)
+        key = {"klt": "klt_kernel", "pyr_l0": "pyr_level_kernel_L0", "ekf_update_gate": "ekf_update_kernel", "vu_prepare": "vu_prepare_kernel"}.get(dom)
         if key in prof_t and prof_t[key].get("hbm_bytes_per_launch") is not None:
             traffic = prof_t[key]["hbm_bytes_per_launch"] * B / float(prof_t.get("sequences_per_gpu", B))
             traffic_note = (f"rocprofv3 FETCH_SIZE x2 + WRITE_SIZE per launch from {prof_t['_file']} "
@@ -842,9 +1013,10 @@ def main():
             "value": aggregate_value(B, world, args.steps, el3), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": el3 / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u8/int16 pixels, int32/int64 sums, f32 solve (tracker); f64 (EKF)", "data": "synthetic",
-            "config": {"workload": "C3: 752x480 stereo, 200 pts -- per sequence and frame 2 pyramid builds + 2 LK calls (HIP tracker) and the HIP EKF: "
-                                   "10 predicts in one launch, 20 chi2 gates (n=40, l=160) of which 5 update, symmetrise, 1 Joseph-form augmentation; "
-                                   "state dim 160",
+            "config": {"workload": "C3: 752x480 stereo, 200 pts -- the whole frame chained on one stream per sequence: 2 pyramid builds, temporal LK, "
+                                   "2-point rotation RANSAC on its output, stereo LK, GFTT key points every 2nd frame (HIP tracker), then the HIP EKF "
+                                   "from the device mean: 20 track visits (triangulation + prepareVisualUpdate, 10 stereo poses = 40 x 160 Jacobian, "
+                                   "chi2 gate) of which 5 update, symmetrise, 1 Joseph-form augmentation, 10 predicts in one launch; state dim 160",
                        "sequences_per_gpu": B, "frames_per_step": world * B, "parallelism": f"replicas x{world} (no collective)",
                        "timing_process_group": args.dist_backend if world > 1 else None, "host_cores_per_rank": env.cores},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": k3[dom]["achieved_GBs"], "peak": HBM_PEAK_GBS,
@@ -858,17 +1030,35 @@ def main():
             "timers_ms_per_step": {"pyramid": sum(k3[k]["ms_per_step"] for k in ("pyr_l0", "pyr_ln") if k in k3),
                                    "computeOpticalFlow": k3.get("klt", {}).get("ms_per_step"),
                                    "KF predict": k3.get("ekf_predict", {}).get("ms_per_step"),
-                                   "trackerVisualUpdate": k3.get("ekf_update_gate", {}).get("ms_per_step"),
+                                   "trackerVisualUpdate": sum(k3[k]["ms_per_step"] for k in ("vu_prepare", "ekf_update_gate") if k in k3),
                                    "augmentation": k3.get("ekf_augment", {}).get("ms_per_step")},
             "stage_pyramid_klt": {"ms_per_step": stage_ms, "achieved_GBs": stage_gbs, "frac_of_8TBs": stage_gbs / HBM_PEAK_GBS,
                                   "frac_of_measured_copy_ceiling": stage_gbs / HBM_COPY_CEILING_GBS,
                                   "algorithmic_bytes_per_stereo_frame": ab["stereo_frame"]},
-            "updates_accepted_fraction": accepted / float(B * args.steps * EKF_UPDATES * (1 + args.warmup / args.steps)),
+            "visual_updates_applied_per_frame": applied, "inlier_gates_per_visit_last_step": gate_hist,
             "tracked_fraction": c2["tracked_fraction"],
             "c2": c2,
         }
         head.update(out)
         out = head
+    # ---- the r01 definition of the EKF leg (dense random 40 x 160 Jacobians handed to the gate, no triangulation): kept for
+    # round-over-round comparison, not the headline ----
+    if not args.only_headline:
+        tb.chain = False
+        ed = EkfBench(tb.ctx, B, local_rank, seed=rank)
+        for _ in range(args.warmup):
+            tb.step(); ed.step()
+        tb.ctx.profile_enable(True); tb.ctx.profile_reset()
+        eld = env.timed(lambda: (tb.step(), ed.step()), args.steps)
+        profd = {name: tb.ctx.profile_read(kid) for name, kid in (("ekf_predict", capi.K_EKF_PREDICT), ("ekf_update_gate", capi.K_EKF_UPDATE),
+                                                                    ("ekf_augment", capi.K_EKF_AUGMENT), ("klt", capi.K_KLT))}
+        tb.ctx.profile_enable(False)
+        ed.ekf.close()
+        del ed
+        if rank == 0:
+            out["c3_dense_h"] = {"workload": "r01's C3: C2 + 10 predicts, 20 chi2 gates on given random dense H (n=40, l=160) of which 5 update, symmetrise, augmentation",
+                                 "value": aggregate_value(B, world, args.steps, eld), "unit": "frames/s", "ms_per_step": eld / args.steps * 1e3,
+                                 "kernels": {k: {"avg_ms": ms / n, "launches": n, "ms_per_step": ms / args.steps} for k, (ms, n) in profd.items() if n}}
     del tb
 
     # ---- frames handed over as HOST buffers (the reference's boundary): every rank feeds its own GPU from pinned memory ----
@@ -902,8 +1092,9 @@ def main():
         lat = (time.perf_counter() - t0) / n_lat
         out["c2"]["latency_mode"] = {"sequences": 1, "ms_per_frame": lat * 1e3, "frames_per_s": 1.0 / lat,
                                      "tracked_fraction": t1.tracked_fraction(), "launch": "eager"}
-        # the same single sequence with its EKF (C3 at B = 1): what one drop-in `main` sees per frame
-        e1 = EkfBench(t1.ctx, 1, local_rank, seed=12345)
+        # the same single sequence through the whole chain (C3 at B = 1): what one drop-in `main` sees per frame
+        t1.enable_chain(12345)
+        e1 = VisualEkfBench(t1.ctx, 1, local_rank, seed=12345)
         for _ in range(N_CYCLE):
             t1.step(); e1.step()
         torch.cuda.synchronize()
@@ -912,10 +1103,43 @@ def main():
             t1.step(); e1.step()
         torch.cuda.synchronize()
         lat3 = (time.perf_counter() - t0) / n_lat
-        out["latency_mode"] = {"sequences": 1, "ms_per_frame": lat3 * 1e3, "frames_per_s": 1.0 / lat3,
-                               "launch": "eager", "launches_per_frame": 7 + 1 + EKF_GATES + 2}
+        out["latency_mode"] = {"sequences": 1, "ms_per_frame": lat3 * 1e3, "frames_per_s": 1.0 / lat3, "launch": "eager",
+                               "launches_per_frame": 5 + 2 + 2 + 2 + 2 * VISITS + 3}
+        # The whole frame captured in HIP graphs: period N_CYCLE (camera path, RANSAC draws, GFTT every 2nd frame, the augmentation's
+        # discard pattern and the covariance ping-pong all repeat with it), replayed in order
+        try:
+            side = torch.cuda.Stream()
+            t1.ctx.set_stream(side.cuda_stream)
+            t1.overlap = False
+            graphs = []
+            with torch.cuda.stream(side):
+                for _ in range(N_CYCLE):
+                    t1.step(); e1.step()
+                side.synchronize()
+                for _ in range(N_CYCLE):
+                    g = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g, stream=side):
+                        t1.step(); e1.step()
+                    graphs.append(g)
+                side.synchronize()
+                for i in range(2 * N_CYCLE):
+                    graphs[i % N_CYCLE].replay()
+                side.synchronize()
+                t0 = time.perf_counter()
+                for i in range(n_lat):
+                    graphs[i % N_CYCLE].replay()
+                side.synchronize()
+            latg = (time.perf_counter() - t0) / n_lat
+            out["latency_mode_graph"] = {"sequences": 1, "ms_per_frame": latg * 1e3, "frames_per_s": 1.0 / latg, "launch": "hipGraph replay",
+                                         "visual_updates_applied_last_frame": int(e1.counter.sum().item())}
+            del graphs
+        except Exception as ex:                               # pragma: no cover
+            out["latency_mode_graph"] = {"error": repr(ex)[:300]}
         e1.ekf.close()
         del e1
+        t1.chain = False
+        t1.overlap = True
+        t1.ctx.set_stream(torch.cuda.current_stream().cuda_stream)
         # The eager number is host-launch bound. A step is a fixed launch sequence with period N_CYCLE, so capture it in
         # HIP graphs and replay: GPU-bound latency (tracker half).
         try:
@@ -949,7 +1173,7 @@ def main():
         del t1
     if rank == 0 and solo and not args.no_cpu_baseline:
         trk = cpu_baseline()
-        fps_ekf, sample, tm_ekf = cpu_baseline_ekf()
+        fps_ekf, sample, tm_ekf = cpu_baseline_visual_chain()
         out["c2"]["cpu_baseline"] = trk
         nat = cpu_baseline_native()
         # headline baseline = the C3 frame (tracker + EKF) on the CPU: the tracker on its best thread count, the EKF on one

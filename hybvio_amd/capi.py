@@ -113,6 +113,8 @@ PROTOTYPES = {
     "hv_ekf_visual_track_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int] + [C.c_void_p] * 4 + [C.c_double, C.c_double] + [C.c_void_p] * 4),
     "hv_ekf_visual_track_limited_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int] + [C.c_void_p] * 4 + [C.c_double, C.c_double] + [C.c_void_p] * 5 + [C.c_int]),
     "hv_ekf_visual_track": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int] + [C.c_void_p] * 4 + [C.c_double, C.c_double] + [C.c_void_p] * 4),
+    "hv_ekf_visual_frame_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int] + [C.c_void_p] * 4 + [C.c_double, C.c_double] + [C.c_void_p] * 4 + [C.c_int]),
+    "hv_ekf_augment_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "hv_ekf_visual_dev": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_double, C.c_int,
                                     C.c_void_p, C.c_void_p]),
     "hv_ekf_augment": (C.c_int, [C.c_void_p, i32p, u8p]),
@@ -576,6 +578,18 @@ class EkfBatch:
         act = np.ascontiguousarray(active, np.uint8) if active is not None else None
         self._chk(lib().hv_ekf_augment(self._h, _p(d, i32p), _p(act, u8p)), "hv_ekf_augment")
         self.ctx.synchronize()
+
+    def augment_dev(self, discarded_dev=0, active_dev=0):
+        """hv_ekf_augment_dev: device arrays (or 0), asynchronous."""
+        self._chk(lib().hv_ekf_augment_dev(self._h, C.c_void_p(discarded_dev), C.c_void_p(active_dev)), "hv_ekf_augment_dev")
+
+    def visual_frame_dev(self, params: VuParams, n_tracks, n_poses, pose_index_dev, features_dev, velocities_dev, y_dev, r_gate, r_update,
+                         status_dev, gate_status_dev, success_counter_dev, max_successful, chi2_dev=0):
+        """hv_ekf_visual_frame_dev: the whole visual-update loop of a frame, track-major device arrays."""
+        a = [C.c_void_p(x) for x in (pose_index_dev, features_dev, velocities_dev, y_dev)]
+        b = [C.c_void_p(x) for x in (status_dev, gate_status_dev, chi2_dev, success_counter_dev)]
+        self._chk(lib().hv_ekf_visual_frame_dev(self._h, C.byref(params), int(n_tracks), int(n_poses), *a, float(r_gate), float(r_update), *b,
+                                                int(max_successful)), "hv_ekf_visual_frame_dev")
 
     def undo_augment(self, active=None):
         act = np.ascontiguousarray(active, np.uint8) if active is not None else None

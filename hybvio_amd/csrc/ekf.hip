@@ -1408,6 +1408,24 @@ static int visual_track_dev_impl(hv_ekf *h, const hv_vu_params *p, int np, const
                                  nullptr, e->vuactive, gate_status_dev, success_counter_dev);
 }
 
+int hv_ekf_visual_frame_dev(hv_ekf *h, const hv_vu_params *p, int n_tracks, int np, const int *idx, const double *feat, const double *vel,
+                            const double *y, double r_gate, double r_update, int *status_dev, int *gate_status_dev, double *chi2_dev,
+                            int *success_counter_dev, int max_successful)
+{
+    if (!h || n_tracks < 0 || !success_counter_dev || max_successful < 1) return HV_ERR_INVALID;
+    Ekf *e = &h->e; Ctx *c = e->c;
+    const size_t B = (size_t)e->batch, nt = (size_t)np * (p && p->useStereo ? 2 : 1);
+    HV_HIP(c, hipMemsetAsync(success_counter_dev, 0, sizeof(int) * B, c->stream));          // updateSuccessCount = 0 (backend.cpp:1017)
+    for (int k = 0; k < n_tracks; ++k) {
+        const int rc = visual_track_dev_impl(h, p, np, idx + (size_t)k * B * np, feat + (size_t)k * B * nt * 2, vel + (size_t)k * B * nt * 2,
+                                             y + (size_t)k * B * nt * 2, r_gate, r_update, status_dev + (size_t)k * B * 2,
+                                             gate_status_dev + (size_t)k * B, chi2_dev ? chi2_dev + (size_t)k * B : nullptr, nullptr,
+                                             success_counter_dev, max_successful);
+        if (rc != HV_OK) return rc;
+    }
+    return HV_OK;
+}
+
 int hv_ekf_visual_track(hv_ekf *h, const hv_vu_params *p, int np, const int *idx, const double *feat, const double *vel,
                         const double *y, double r_gate, double r_update, int *status, int *gate_status, double *chi2, double *pf)
 {
@@ -1664,6 +1682,26 @@ int hv_ekf_augment(hv_ekf *h, const int *discarded, const unsigned char *active)
     hipLaunchKernelGGL(hv::ekf_augment_kernel, dim3(e->batch), dim3(hv::AUG_THREADS), shmem, c->stream, a);
     HV_HIP(c, hipGetLastError());
     std::swap(e->P, e->P1);                 // the kernel wrote the new covariance to the other buffer
+    return HV_OK;
+}
+
+int hv_ekf_augment_dev(hv_ekf *h, const int *discarded_dev, const unsigned char *active_dev)
+{
+    if (!h) return HV_ERR_INVALID;
+    Ekf *e = &h->e; Ctx *c = e->c;
+    hv::AugmentArgs a{};
+    a.n = e->n; a.cam_poses = e->cam; a.map_dim = e->map_dim;
+    a.m = e->m; a.P = e->P; a.P1 = e->P1; a.m1 = e->m1;
+    a.dropped0 = -1; a.dropped = discarded_dev; a.active = active_dev;
+    a.q_pos = e->par.noiseInitialPosTrail * e->par.noiseInitialPosTrail * e->noise_scale;
+    a.q_ori = e->par.noiseInitialOriTrail * e->par.noiseInitialOriTrail * e->noise_scale;
+    a.rd = e->par.augmentR * e->noise_scale;
+    const size_t shmem = sizeof(double) * (3 * hv::POSE * e->n + 2 * hv::POSE * hv::POSE + hv::POSE + 1 + (hv::AUG_THREADS / 64) * 16 * 17);
+    if (shmem > 64 * 1024) return HV_ERR_UNSUPPORTED;        // map-point states: use hv_ekf_augment (it raises the LDS limit)
+    hv::ScopedKernelTime tm(c, HV_K_EKF_AUGMENT);
+    hipLaunchKernelGGL(hv::ekf_augment_kernel, dim3(e->batch), dim3(hv::AUG_THREADS), shmem, c->stream, a);
+    HV_HIP(c, hipGetLastError());
+    std::swap(e->P, e->P1);
     return HV_OK;
 }
 

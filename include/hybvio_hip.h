@@ -235,6 +235,18 @@ int hv_ekf_visual_track_limited_dev(hv_ekf *ekf, const hv_vu_params *p, int n_po
                                     const double *features_dev, const double *velocities_dev, const double *y_dev,
                                     double r_gate, double r_update, int *status_dev, int *gate_status_dev, double *chi2_dev,
                                     double *pf_dev, int *success_counter_dev, int max_successful);
+/* The whole visual-update loop of one frame (Session::trackerVisualUpdate, backend.cpp:1012-1252, with batchVisualUpdate false)
+ * in ONE call: n_tracks track visits in the caller's order (the reference's score order), each seeing the mean the previous one
+ * left, a filter leaving the loop after max_successful applied updates. Arrays are TRACK-major so that a visit is one contiguous
+ * batch: pose_index_dev [n_tracks][batch][n_poses], features_dev / velocities_dev [n_tracks][batch][ncam * n_poses][2], y_dev
+ * [n_tracks][batch][2 * ncam * n_poses]; outputs status_dev [n_tracks][batch][2], gate_status_dev [n_tracks][batch], chi2_dev
+ * (may be NULL) [n_tracks][batch]. success_counter_dev [batch] is zeroed here and holds the applied updates on return.
+ * Nothing crosses the host between the visits; the call is asynchronous and HIP-graph capturable once it has run once
+ * (its work buffers are allocated on first use). */
+int hv_ekf_visual_frame_dev(hv_ekf *ekf, const hv_vu_params *p, int n_tracks, int n_poses, const int *pose_index_dev,
+                            const double *features_dev, const double *velocities_dev, const double *y_dev, double r_gate,
+                            double r_update, int *status_dev, int *gate_status_dev, double *chi2_dev, int *success_counter_dev,
+                            int max_successful);
 /* Host-pointer form of hv_ekf_visual_track_dev (arrays [batch][...] as above): about 1 KB per track goes to the device
  * and 40 bytes come back, instead of the mean coming back and a (2 * ncam * n_poses) x stateDim Jacobian going up.
  * chi2 / pf may be NULL. Synchronous. */
@@ -244,6 +256,8 @@ int hv_ekf_visual_track(hv_ekf *ekf, const hv_vu_params *p, int n_poses, const i
 /* updateVisualPoseAugmentation(discarded[f]) (ekf.cpp:848-885; -1 = last pose) incl. the Joseph form,
  * maintainPositiveSemiDefinite and normalizeQuaternions; updateUndoAugmentation (ekf.cpp:888-903). */
 int hv_ekf_augment(hv_ekf *ekf, const int *discarded /* [batch] or NULL */, const unsigned char *active);
+/* The same with device arrays (either may be NULL): no host copy, so a batch of sequences stays HIP-graph capturable. */
+int hv_ekf_augment_dev(hv_ekf *ekf, const int *discarded_dev, const unsigned char *active_dev);
 int hv_ekf_undo_augment(hv_ekf *ekf, const unsigned char *active);
 int hv_ekf_symmetrize(hv_ekf *ekf);                                 /* maintainPositiveSemiDefinite */
 int hv_ekf_normalize_quaternions(hv_ekf *ekf, int only_current);    /* ekf.cpp:1024-1032            */
