@@ -246,6 +246,8 @@ class EkfBench:
 
 
 VISITS, QUOTA, NPOSE = 20, 5, 10       # maxVisualUpdates, maxSuccessfulVisualUpdates (parameter_definitions.c:8,10); 10 stereo poses = 40 rows
+FOCAL = 458.654                        # EuRoC cam0; the backend divides both measurement noises by it (backend.cpp:996-997)
+R_GATE, R_UPDATE = 1.5 / FOCAL, 0.05 / FOCAL    # trackChiTestOutlierR, visualR (parameter_definitions.c:23,91) in normalised image units
 
 
 def make_visual_frame(rng, B, distinct=32):
@@ -255,14 +257,14 @@ def make_visual_frame(rng, B, distinct=32):
     and tiled over the batch."""
     from hybvio_amd import synth
     d = min(B, distinct)
-    T1, T2, means, idx0, feat0 = synth.visual_tracks(rng, d, 20, NPOSE, True)
+    T1, T2, means, idx0, feat0 = synth.visual_tracks(rng, d, 20, NPOSE, True, noise=1e-4)      # 0.05 px: the reference's visualR
     idx, feat, vel, y = [idx0], [feat0], [], []
     for k in range(1, VISITS):
-        _, _, _, i_, f_ = synth.visual_tracks(rng, d, 20, NPOSE, True, given_means=means)
+        _, _, _, i_, f_ = synth.visual_tracks(rng, d, 20, NPOSE, True, given_means=means, noise=1e-4)
         idx.append(i_); feat.append(f_)
     for k in range(VISITS):
         vel.append(rng.normal(size=feat[k].shape) * 0.1)
-        yy = feat[k].reshape(d, -1) + 1e-3 * rng.normal(size=(d, feat[k].shape[1] * 2))
+        yy = feat[k].reshape(d, -1) + 1e-4 * rng.normal(size=(d, feat[k].shape[1] * 2))
         if k % (VISITS // QUOTA) != VISITS // QUOTA - 1:
             yy = yy + 0.05 * rng.choice([-1.0, 1.0], size=yy.shape)
         y.append(yy)
@@ -294,7 +296,7 @@ class VisualEkfBench:
         self.ekf = capi.EkfBatch(ctx, capi.ekf_default_params(cameraTrailLength=20), B)
         _, P = self.ekf.get_state(0)
         P = P * 1e-6 + np.eye(self.ekf.n) * 1e-4
-        to = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a, dt)).to(dev)
+        to = lambda a, dt: torch.from_numpy(np.array(a, dt, order="C")).to(dev)
         self.m0 = to(means, np.float64)
         self.P0 = to(np.broadcast_to(P, (B,) + P.shape), np.float64)
         self.idx, self.feat, self.vel, self.y = to(idx, np.int32), to(feat, np.float64), to(vel, np.float64), to(y, np.float64)
@@ -324,7 +326,7 @@ class VisualEkfBench:
         mv.copy_(self.m0); Pv.copy_(self.P0)
         e = self.ekf
         e.visual_frame_dev(self.vp, VISITS, NPOSE, self.idx.data_ptr(), self.feat.data_ptr(), self.vel.data_ptr(), self.y.data_ptr(),
-                           1.5, 0.05, self.st.data_ptr(), self.gs.data_ptr(), self.counter.data_ptr(), QUOTA)
+                           R_GATE, R_UPDATE, self.st.data_ptr(), self.gs.data_ptr(), self.counter.data_ptr(), QUOTA)
         self.applied += self.counter.sum()
         e.symmetrize()
         e.augment_dev(self.drop[self.k % len(HANOI)].data_ptr())
@@ -454,9 +456,9 @@ def cpu_baseline_visual_chain(budget_s=8.0):
             ts, ps, pf, Hm, f = orc.visual_track_prepare(par, e.m, idx[k, 0], T1, T2, feat[k, 0], vel[k, 0])
             if ts != 0 or ps != 0:
                 continue
-            st, _ = e.visual_track_outlier_check(Hm, f, y[k, 0], 1.5)
+            st, _ = e.visual_track_outlier_check(Hm, f, y[k, 0], R_GATE)
             if st == 0:
-                e.update_visual_track(Hm, f, y[k, 0], 0.05); ok += 1
+                e.update_visual_track(Hm, f, y[k, 0], R_UPDATE); ok += 1
         applied += ok
         tb_ = time.perf_counter()
         e.maintain_psd()

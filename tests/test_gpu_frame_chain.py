@@ -1,0 +1,182 @@
+"""The whole frame chained on the device against the oracle chain, 200 frames.
+
+Per frame and per sequence, nothing but device buffers between the stages:
+    hv_pyramid_build_batch_dev (left + right) -> hv_klt_track_batch_dev (temporal) -> hv_rot_ransac_lk_batch_dev on the LK outputs
+    -> hv_klt_track_batch_dev (stereo) -> hv_gftt_keypoints_batch_dev,
+    hv_ekf_predict_n_dev -> hv_ekf_visual_frame_dev (12 track visits from the DEVICE mean, quota 4) -> hv_ekf_symmetrize ->
+    hv_ekf_augment_dev.
+The outputs are read back once per frame and compared with the same chain on the CPU oracle (reference order: predict ->
+tracker -> visual updates -> augmentation, backend.cpp:716-867). The tracker half must be bit-identical (statuses, positions,
+RANSAC statuses and rotation, key points); because every frame's tracked points are the next frame's inputs, one differing bit
+would fork the runs. The EKF half evolves for 200 frames without being reset: its tracks are regenerated every frame from the
+device mean (a front end consistent with the state) and handed to both filters; state and covariance must agree to 1e-5
+relative (north star) at the end."""
+import numpy as np
+import pytest
+
+from hybvio_amd import capi, synth
+
+pytestmark = pytest.mark.gpu
+W, H, NPTS, B, FRAMES, UNIQUE = 376, 240, 96, 2, 200, 20
+VISITS, QUOTA, NPOSE, TRAIL, NIMU = 12, 4, 6, 20, 10
+FOCAL = 229.3
+R_GATE, R_UPD = 1.5 / FOCAL, 0.05 / FOCAL             # backend.cpp:996-997: both noises are divided by the focal length
+RADIAL = [-0.2834, 0.0740, 0.0]
+HANOI = [19, 16, 17, 16, 18, 16, 17, 16]
+
+
+def _rel(a, b):
+    return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-300))
+
+
+def _frames(seed):
+    tex = synth.Texture.make(seed)
+    warps = synth.camera_path(UNIQUE, W, H, radius_px=0.4 * UNIQUE, rot_amp_deg=1.0)
+    left = [synth.render(tex, W, H, w, noise_seed=seed * 100 + 2 * k, noise_sigma=1.0) for k, w in enumerate(warps)]
+    right = [synth.render(tex, W, H, synth.Warp(w.A.copy(), w.t + w.A @ np.array([12.0, 0.0])), noise_seed=seed * 100 + 2 * k + 1,
+                          noise_sigma=1.5) for k, w in enumerate(warps)]
+    return np.stack(left), np.stack(right)
+
+
+def test_chained_frames_equal_the_oracle_chain(oracle):
+    import torch
+    rng = np.random.default_rng(17)
+    seqs = [_frames(60 + s) for s in range(B)]
+    cam_args = ("pinhole", FOCAL, FOCAL * 0.997, W * 0.488, H * 0.517)
+    ocam, gcam = oracle.Camera(*cam_args, coeffs=RADIAL), capi.camera_model(*cam_args, coeffs=RADIAL)
+    thr = float(np.float32((1.0 * min(W, H) / 720.0) ** 2))        # tight: the hypothesis loop has to work (see the closed-loop test)
+    grid = np.stack([synth.grid_points(W, H, NPTS, margin=10, seed=s) for s in range(B)])
+    par = oracle.tri_default_params()
+    dev = lambda a, dt: torch.from_numpy(np.array(a, dt, order="C")).cuda()
+    with capi.Context(width=W, height=H, pool_size=3 * B, max_tracks=NPTS, max_pairs=B) as ctx:
+        ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+        slots = np.array([ctx.acquire() for _ in range(3 * B)], np.int32).reshape(3, B)
+        s_left = [dev(slots[0], np.int32), dev(slots[1], np.int32)]
+        s_right = dev(slots[2], np.int32)
+        s_build = [dev(np.concatenate([slots[p], slots[2]]), np.int32) for p in (0, 1)]
+        d_npts = dev(np.full(B, NPTS), np.int32)
+        nk = ctx.gftt_keypoint_count()
+        bs = capi.lib().hv_gftt_block_size(capi.C.byref(capi.gftt_default_params()))
+        # EKF: B filters with a filled trail
+        T1, T2, means, _, _ = synth.visual_tracks(rng, B, TRAIL, NPOSE, True, noise=1e-4)
+        vp = capi.vu_default_params(imu_to_camera=T1, second_imu_to_camera=T2)
+        g = capi.EkfBatch(ctx, capi.ekf_default_params(cameraTrailLength=TRAIL), B)
+        filters = []
+        for b in range(B):
+            o = oracle.Ekf(oracle.ekf_default_params(cameraTrailLength=TRAIL))
+            P = o.P.copy() * 1e-6 + np.eye(o.n) * 1e-4
+            o.set_state(means[b]); o.set_cov(P); o.set_first_sample_time(0.0)
+            g.set_state(b, means[b], P)
+            filters.append(o)
+        d_counter = torch.zeros((B,), dtype=torch.int32, device="cuda")
+        pts = grid.copy()                                   # [B][NPTS][2], carried from frame to frame
+        disp = np.full((B, NPTS), 12.0, np.float32)
+        prev_pyr = None
+        t_imu, applied_total, ransac_out, lost, gate_rejects = 0.0, 0, 0, 0, 0
+        for f in range(FRAMES):
+            k = f % UNIQUE
+            imgs = np.concatenate([np.stack([seqs[s][0][k] for s in range(B)]), np.stack([seqs[s][1][k] for s in range(B)])])   # lefts, rights
+            d_imgs = dev(imgs, np.uint8)
+            ctx.build_batch_dev(2 * B, s_build[f % 2].data_ptr(), d_imgs.data_ptr(), W * H, W)
+            cur_pyr = [(oracle.Pyramid(seqs[s][0][k]), oracle.Pyramid(seqs[s][1][k])) for s in range(B)]
+            if f == 0:
+                torch.cuda.synchronize()
+                prev_pyr = cur_pyr
+                continue
+            # ================= device: tracker chain =================
+            draws = np.stack([oracle.mt19937_draws(4649 + s, 200, skip=200 * f) for s in range(B)])
+            d_pts, d_draws = dev(pts, np.float32), dev(draws, np.uint32)
+            d_cur = torch.zeros_like(d_pts); d_st1 = torch.zeros((B, NPTS), dtype=torch.uint8, device="cuda"); d_st2 = torch.zeros_like(d_st1)
+            d_rst = torch.zeros((B, NPTS), dtype=torch.int32, device="cuda"); d_rot = torch.zeros((B, 9), dtype=torch.float32, device="cuda")
+            d_sum = torch.zeros((B, 2), dtype=torch.int32, device="cuda"); d_kp = torch.zeros((B, nk, 3), dtype=torch.float32, device="cuda")
+            d_disp = dev(np.stack([disp, np.zeros_like(disp)], -1), np.float32)
+            d_rxy = torch.zeros_like(d_pts)
+            prev_s, cur_s = s_left[(f - 1) % 2], s_left[f % 2]
+            ctx.klt_track_batch_dev(B, prev_s.data_ptr(), cur_s.data_ptr(), NPTS, d_pts.data_ptr(), d_cur.data_ptr(), d_st1.data_ptr(), 0, False)
+            ctx.rot_ransac_lk_batch_dev(B, NPTS, d_npts.data_ptr(), d_pts.data_ptr(), d_cur.data_ptr(), d_st1.data_ptr(), 1, gcam, gcam,
+                                        d_draws.data_ptr(), thr, d_rst.data_ptr(), d_rot.data_ptr(), d_sum.data_ptr())
+            torch.sub(d_cur, d_disp, out=d_rxy)                                     # stereo guess = tracked position - last disparity
+            ctx.klt_track_batch_dev(B, cur_s.data_ptr(), s_right.data_ptr(), NPTS, d_cur.data_ptr(), d_rxy.data_ptr(), d_st2.data_ptr(), 0, True)
+            ctx.gftt_keypoints_batch_dev(B, cur_s.data_ptr(), d_kp.data_ptr())
+            # ================= device: EKF chain (tracks regenerated from the device mean) =================
+            t_imu_samples = [(0.005, rng.normal(0, 0.02, (B, 3)), rng.normal(0, 0.05, (B, 3)) + [0.0, 0.0, 9.819]) for _ in range(NIMU)]
+            d_dt = dev(np.full((NIMU, B), 0.005), np.float64)
+            d_gy, d_ac = dev(np.stack([s_[1] for s_ in t_imu_samples]), np.float64), dev(np.stack([s_[2] for s_ in t_imu_samples]), np.float64)
+            g.predict_n_dev(NIMU, d_dt.data_ptr(), d_gy.data_ptr(), d_ac.data_ptr())
+            torch.cuda.synchronize()
+            m_dev = np.stack([g.get_state(b)[0] for b in range(B)])
+            tr = [synth.visual_tracks(rng, B, TRAIL, NPOSE, True, given_means=m_dev, noise=1e-4)[3:] for _ in range(VISITS)]
+            idx = np.stack([t[0] for t in tr]); feat = np.stack([t[1] for t in tr])
+            vel = rng.normal(size=feat.shape) * 0.05
+            y = feat.reshape(VISITS, B, -1) + 1e-4 * rng.normal(size=(VISITS, B, feat.shape[2] * 2))
+            y[1::3] += 0.04 * rng.choice([-1.0, 1.0], size=y[1::3].shape)           # every third visit is a gross outlier (~9 px)
+            d_in = [dev(idx, np.int32), dev(feat, np.float64), dev(vel, np.float64), dev(y, np.float64)]
+            d_vst = torch.full((VISITS, B, 2), -9, dtype=torch.int32, device="cuda"); d_gs = torch.full((VISITS, B), -9, dtype=torch.int32, device="cuda")
+            g.visual_frame_dev(vp, VISITS, NPOSE, d_in[0].data_ptr(), d_in[1].data_ptr(), d_in[2].data_ptr(), d_in[3].data_ptr(), R_GATE, R_UPD,
+                               d_vst.data_ptr(), d_gs.data_ptr(), d_counter.data_ptr(), QUOTA)
+            g.symmetrize()
+            d_drop = dev(np.full(B, HANOI[f % len(HANOI)]), np.int32)
+            g.augment_dev(d_drop.data_ptr())
+            torch.cuda.synchronize()
+            cur, st1, st2 = d_cur.cpu().numpy(), d_st1.cpu().numpy(), d_st2.cpu().numpy()
+            rst, rot, rsum, rxy, kp = d_rst.cpu().numpy(), d_rot.cpu().numpy(), d_sum.cpu().numpy(), d_rxy.cpu().numpy(), d_kp.cpu().numpy()
+            vst, gs, counts = d_vst.cpu().numpy(), d_gs.cpu().numpy(), d_counter.cpu().numpy()
+            # ================= oracle chain, same inputs =================
+            new_pts, new_disp = pts.copy(), disp.copy()
+            for s in range(B):
+                oxy, ost, _ = oracle.klt_track(prev_pyr[s][0], cur_pyr[s][0], pts[s])
+                assert np.array_equal(st1[s], ost), f"frame {f} seq {s}: temporal LK status"
+                keep = np.flatnonzero(ost == 1)
+                assert np.array_equal(cur[s][keep], oxy[keep]), f"frame {f} seq {s}: temporal LK positions"
+                ors = np.zeros(NPTS, np.int32)
+                if len(keep) >= 2:
+                    rs, oR, obest, oused = oracle.rot_ransac_fit(pts[s][keep], oxy[keep], ocam, ocam, draws[s], thr)
+                    ors[keep] = rs
+                    assert rsum[s].tolist() == [obest, oused // 2] and np.array_equal(rot[s].view(np.uint32), oR.reshape(-1).view(np.uint32)), f"frame {f}: RANSAC"
+                assert np.array_equal(rst[s], ors), f"frame {f} seq {s}: RANSAC statuses"
+                # the stereo call runs on ALL points with the tracker's guess; positions of points the temporal call lost are whatever
+                # the device wrote (the oracle's own bits may differ there): feed the device's positions of this frame
+                guess = cur[s] - np.stack([disp[s], np.zeros(NPTS, np.float32)], -1)
+                oxr, ost2, _ = oracle.klt_track(cur_pyr[s][0], cur_pyr[s][1], cur[s], next_pts=guess)
+                assert np.array_equal(st2[s], ost2), f"frame {f} seq {s}: stereo LK status"
+                k2 = np.flatnonzero(ost2 == 1)
+                assert np.array_equal(rxy[s][k2], oxr[k2]), f"frame {f} seq {s}: stereo LK positions"
+                okp = oracle.gftt_collect_max(oracle.corner_min_eigen_val(seqs[s][0][k]), bs, 1e-3)
+                assert np.array_equal(kp[s], okp), f"frame {f} seq {s}: GFTT key points"
+                # bookkeeping (host logic in the reference): keep what every stage tracked inside the image, re-seed the rest
+                ok = (ost == 1) & (ost2 == 1) & (ors != 3) & (oxy[:, 0] >= 8) & (oxy[:, 0] < W - 8) & (oxy[:, 1] >= 8) & (oxy[:, 1] < H - 8)
+                new_pts[s] = np.where(ok[:, None], oxy, grid[s]); new_disp[s] = np.where(ok, oxy[:, 0] - oxr[:, 0], 12.0)
+                ransac_out += int((ors == 3).sum()); lost += int((~ok).sum())
+                # EKF
+                o = filters[s]
+                for j, (dt, gy, ac) in enumerate(t_imu_samples):
+                    o.predict(t_imu + dt * (j + 1), gy[s], ac[s])                  # the oracle takes absolute sample times
+                done = 0
+                for v in range(VISITS):
+                    if done >= QUOTA:
+                        assert vst[v, s].tolist() == [-1, -1] and gs[v, s] == 1
+                        continue
+                    ots, ops, opf, oH, of = oracle.visual_track_prepare(par, o.m.copy(), idx[v, s], T1, T2, feat[v, s], vel[v, s])
+                    assert vst[v, s].tolist() == [ots, ops], (f, s, v)
+                    if (ots, ops) != (0, 0):
+                        assert gs[v, s] == 1
+                        continue
+                    status, _ = o.visual_track_outlier_check(oH, of, y[v, s], R_GATE)
+                    assert gs[v, s] == status, (f, s, v)
+                    if status == 0:
+                        o.update_visual_track(oH, of, y[v, s], R_UPD); done += 1
+                    else:
+                        gate_rejects += 1
+                assert counts[s] == done
+                applied_total += done
+                o.maintain_psd()
+                o.update_visual_pose_augmentation(HANOI[f % len(HANOI)])
+            t_imu += NIMU * 0.005
+            pts, disp, prev_pyr = new_pts, new_disp, cur_pyr
+        # ---- after 200 frames ----
+        for s, o in enumerate(filters):
+            mg, Pg = g.get_state(s)
+            em, eP = _rel(mg, o.m), _rel(Pg, o.P)
+            assert em <= 1e-5 and eP <= 1e-5, (s, em, eP)
+        assert applied_total >= (FRAMES - 1) * B * 2 and gate_rejects > FRAMES and ransac_out > 0 and lost > 0
+        g.close()
