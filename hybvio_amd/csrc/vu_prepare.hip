@@ -10,6 +10,8 @@
 // One workgroup per filter. The work is the differentiated Gauss-Newton loop: per iteration every one of the
 // 7 * nPoses + 1 derivative columns visits every pose (<= 42 x 295 pairs, ~120 flops each, f64), so a thread owns a
 // column and walks the poses, whose per-iteration quantities (C, t, h, E, error) are shared through LDS.
+#include <stdlib.h>
+
 #include "hv_internal.hpp"
 
 #pragma clang fp contract(fast)
@@ -24,7 +26,11 @@ __device__ long long g_vu_stamp[32];
 #endif
 namespace {
 
-constexpr int VT = 768;                 // threads: G = 2 or 4 per derivative column (<= 7 * 42 + 1 columns)
+// threads per workgroup (template parameter VT): G = 2 or 4 lanes per derivative column (<= 7 * 42 + 1 columns) + one wave.
+// 768 gives the longest track (21 stereo poses) its G = 2 and a 10-pose stereo track G = 4: the shortest latency of ONE track.
+// 384 still covers tracks of up to 22 camera poses with G = 2; it was built to let two workgroups share a CU, but the kernel is
+// f64-issue bound per SIMD (the same wave-instructions either way) and measured no faster at any batch size: experiment knob only.
+constexpr int VT_LATENCY = 768, VT_THROUGHPUT = 384;
 constexpr int MAXP = 42;                // 2 cameras x (cameraTrailLength + 1 <= 21) poses
 constexpr int MAXC = MAXP * 7 + 1;
 constexpr int MAXNP = 21;              // poses per camera: s_dpf is [MAXNP][21], s_idx holds MAXNP (+3 spare) indices
@@ -159,17 +165,23 @@ __device__ __forceinline__ void pair_sums(const double *o, const double *dh, con
 #pragma unroll
     for (int r = 0; r < 3; ++r) {
         dEe[r] += dE[r] * er[0] + dE[3 + r] * er[1] + E[r] * dErr[0] + E[3 + r] * dErr[1];
+        // dEblock' Eblock + Eblock' dEblock is symmetric: only the upper triangle is accumulated (6 of 9 entries, a seventh of the
+        // pair's flops); sym3() completes the matrix where it is used
 #pragma unroll
-        for (int c = 0; c < 3; ++c) dM[3 * r + c] += dE[r] * E[c] + dE[3 + r] * E[3 + c] + E[r] * dE[c] + E[3 + r] * dE[3 + c];
+        for (int c = r; c < 3; ++c) dM[3 * r + c] += dE[r] * E[c] + dE[3 + r] * E[3 + c] + E[r] * dE[c] + E[3 + r] * dE[3 + c];
     }
 }
 
+__device__ __forceinline__ void sym3(double *M) { M[3] = M[1]; M[6] = M[2]; M[7] = M[5]; }
+
 // dC and dt of pose i for state component comp of pose pj (:269-292), as one instruction stream: the derivative
 // matrices are scaled by 0 or 1 instead of branching on position / quaternion and own pose / pose 0.
-__device__ __forceinline__ void pose_motion(const double *trail, const double *R0T, const double *o, int i, int pj, int comp,
-                                            double *dC, double *dt)
+// Nothing in here depends on the Gauss-Newton iterate (C, t and d = p0 - p_i are fixed by the pose trail): evaluated once per
+// lane before the loop and parked in LDS (s_mot), ~250 of the ~600 f64 instructions a lane spent on its motion pair per iteration.
+__device__ __forceinline__ void pose_motion(const double *trail, const double *R0T, int i, int pj, int comp, double *dC, double *dt)
 {
-    const double *cur = trail + i * POSE_WORDS, *d = o + 23;
+    const double *cur = trail + i * POSE_WORDS;
+    const double d[3] = {trail[0] - cur[0], trail[1] - cur[1], trail[2] - cur[2]};
     const bool current = pj == i, first = pj == 0;
     const int qi = comp >= 3 ? comp - 3 : 0;
     const double wc = current && comp >= 3 ? 1.0 : 0.0, wf = first && comp >= 3 ? 1.0 : 0.0;
@@ -194,7 +206,8 @@ __device__ __forceinline__ void pose_motion(const double *trail, const double *R
     for (int k = 0; k < 3; ++k) dt[k] = t1[k] + t2[k];
 }
 
-__global__ __launch_bounds__(VT) void vu_prepare_kernel(VuPrepareArgs a)
+template <int VT>
+__global__ __launch_bounds__(VT, 3) void vu_prepare_kernel(VuPrepareArgs a)
 {
     __shared__ double s_trail[MAXP * POSE_WORDS];
     __shared__ double s_it[MAXP * ITER_WORDS];
@@ -205,6 +218,10 @@ __global__ __launch_bounds__(VT) void vu_prepare_kernel(VuPrepareArgs a)
     __shared__ double s_p0[7 * MAXP * 12 + 7 * 12];   // motion part of the 7 columns of pose 0: [7][pose][12], then their totals [7][12]
     __shared__ int s_idx[MAXNP + 3];
     __shared__ int s_flag[4];
+    constexpr int MOT_STRIDE = 13;                     // dC[9] dt[3] (+1: lanes 13 doubles apart hit the LDS banks two-way at worst)
+    constexpr int MAXPAIRS = 14 * MAXP - 7;            // motion pairs: 7 nt with a pose-0 column + 7 (nt - 1) with the pose's own column
+    __shared__ double s_mot[MAXPAIRS * MOT_STRIDE];
+    __shared__ double s_own[MAXC * 12];                // motion sums of the own pairs, by column
     const int b = blockIdx.x, tid = threadIdx.x;
     const int n = a.np, ncam = a.stereo ? 2 : 1, nt = n * ncam, N = a.n;
     const int dDim = nt * 7, ncol = dDim + 1;
@@ -354,6 +371,26 @@ __global__ __launch_bounds__(VT) void vu_prepare_kernel(VuPrepareArgs a)
     // (With a branch inside the loop the wave holding the pose-0 columns took 16.9 k of an iteration's 19 k cycles.)
     // The last wave (VT - 64 ..) forms ETE / Eerror / the step concurrently.
     const int gshift = 4 * ncol <= VT - 64 ? 2 : 1, G = 1 << gshift, col_lanes = ncol << gshift;
+    // The motion pairs are dealt out densely, one per lane, to as few waves as hold them -- and to waves chosen by the SIMD they
+    // sit on (wave w runs on SIMD w % 4): the column waves 0 .. 8 already load SIMD 0 with three waves of plain work, so the
+    // pairs go to the two idle waves 9, 10 first, then to waves of SIMDs 1 - 3. (r01 gave every column lane a pair, own or
+    // dummy: the motion code ran on all 9 column waves at 25 - 75 % lane use.) Pair slot ms -> pose, state component:
+    //   ms < 7 nt: pose-0 column  (i = ms / 7, comp = ms % 7, sums through s_p0);  else the own pair of column j = ms - 7 nt + 7.
+    constexpr unsigned long long WAVE_POS = VT == 768 ? 0xF10A43297658ull : 0xF42103ull;   // nibble w = position of wave w in that order
+    const int wpos = (int)((WAVE_POS >> (4 * (tid >> 6))) & 0xF);
+    const int ms = wpos * 64 + (tid & 63), npairs = 14 * nt - 7;
+    const bool m_has = wpos != 0xF && ms < npairs, m_p0pair = ms < 7 * nt;
+    const int m_col = m_p0pair ? ms : ms - 7 * nt + 7;                       // p0 pairs: u = 7 i + comp;  own pairs: the column
+    const int m_i = m_col / 7, m_comp = m_col - 7 * m_i;
+    if (m_has) {
+        double dC[9], dt[3];
+        pose_motion(s_trail, R0T, m_i, m_p0pair ? 0 : m_i, m_comp, dC, dt);
+        double *dst = s_mot + ms * MOT_STRIDE;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) dst[k] = dC[k];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) dst[9 + k] = dt[k];
+    }
     VU_STAMP(2);
     for (int it = 0; it < a.gn_iters; ++it) {
         if (it < 6) VU_STAMP(3 + 4 * it);
@@ -432,37 +469,28 @@ __global__ __launch_bounds__(VT) void vu_prepare_kernel(VuPrepareArgs a)
                 pair_sums<false>(o, dh, nullptr, nullptr, is_t ? s_feat[4 * i + 2] : 0.0, is_t ? s_feat[4 * i + 3] : 0.0, dEe, dM);
             }
         }
-        if (tid < col_lanes) {                                                          // motion part: one pair per lane, one code path
-            // lane 0 of a column's group: the column's own pose (regular columns only); lane p >= 1: pair u = (pose i,
-            // pose-0 column c) with u = j (G - 1) + p - 1 < 7 nt  (7 nt <= ncol (G - 1) always holds)
-            const int u = j * (G - 1) + part - 1;
-            const bool own = part == 0 && j >= 7 && !is_t, p0pair = part > 0 && u < 7 * nt;
-            const int i = own ? j / 7 : p0pair ? u / 7 : 0;
-            const int pj = own ? i : 0, comp = own ? j - 7 * i : p0pair ? u - 7 * i : 0;
-            const double *o = s_it + i * ITER_WORDS;
+        if (m_has) {                                                                    // motion part: one pair per lane, one code path
+            const double *o = s_it + m_i * ITER_WORDS;
             double dC[9], dt[3], dh[3], e3[3] = {0, 0, 0}, m9[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-            pose_motion(s_trail, R0T, o, i, pj, comp, dC, dt);
+            const double *mot = s_mot + ms * MOT_STRIDE;
+#pragma unroll
+            for (int k = 0; k < 9; ++k) dC[k] = mot[k];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) dt[k] = mot[9 + k];
 #pragma unroll
             for (int r = 0; r < 3; ++r) dh[r] = (dC[3 * r] * pfi[0] + dC[3 * r + 1] * pfi[1] + dC[3 * r + 2]) + pfi[2] * dt[r];
             pair_sums<true>(o, dh, dC, dt, 0.0, 0.0, e3, m9);
-            const double keep = own ? 1.0 : 0.0;
+            double *dst = m_p0pair ? s_p0 + (m_comp * MAXP + m_i) * 12 : s_own + m_col * 12;
 #pragma unroll
-            for (int k = 0; k < 3; ++k) dEe[k] += keep * e3[k];
+            for (int k = 0; k < 3; ++k) dst[k] = e3[k];
 #pragma unroll
-            for (int k = 0; k < 9; ++k) dM[k] += keep * m9[k];
-            if (p0pair) {
-                double *dst = s_p0 + (comp * MAXP + i) * 12;
-#pragma unroll
-                for (int k = 0; k < 3; ++k) dst[k] = e3[k];
-#pragma unroll
-                for (int k = 0; k < 9; ++k) dst[3 + k] = m9[k];
-            }
+            for (int k = 0; k < 9; ++k) dst[3 + k] = m9[k];
         }
         for (int o = 1; o < G; o <<= 1) {                     // the G partial sums of a column sit in adjacent lanes
 #pragma unroll
             for (int k = 0; k < 3; ++k) dEe[k] += __shfl_xor(dEe[k], o);
 #pragma unroll
-            for (int k = 0; k < 9; ++k) dM[k] += __shfl_xor(dM[k], o);
+            for (int k = 0; k < 9; ++k) if (k != 3 && k != 6 && k != 7) dM[k] += __shfl_xor(dM[k], o);    // upper triangle only
         }
         __syncthreads();                                      // X, step, error2 are published; everybody is done with the old pfi
         if (it < 6) VU_STAMP(6 + 4 * it);
@@ -474,6 +502,14 @@ __global__ __launch_bounds__(VT) void vu_prepare_kernel(VuPrepareArgs a)
         }
         if (has && part == 0 && j >= 7) {                     // :324-328: d(A^-1) = -A^-1 dA A^-1
             double t1[3], t2[3], t3[3];
+            if (!is_t) {                                      // + the motion sums of the column's own pair
+                const double *own = s_own + j * 12;
+#pragma unroll
+                for (int k = 0; k < 3; ++k) dEe[k] += own[k];
+#pragma unroll
+                for (int k = 0; k < 9; ++k) dM[k] += own[3 + k];
+            }
+            sym3(dM);
             mv3(dM, step, t1);
             mv3(X, t1, t2);
             mv3(X, dEe, t3);
@@ -488,6 +524,7 @@ __global__ __launch_bounds__(VT) void vu_prepare_kernel(VuPrepareArgs a)
             for (int k = 0; k < 3; ++k) e3[k] = dEe[k] + tot[k];
 #pragma unroll
             for (int k = 0; k < 9; ++k) m9[k] = dM[k] + tot[3 + k];
+            sym3(m9);
             mv3(m9, step, t1);
             mv3(X, t1, t2);
             mv3(X, e3, t3);
@@ -658,7 +695,13 @@ int launch_vu_prepare(Ctx *c, const VuPrepareArgs &a)
     // a longer trail (cameraTrailLength > 20) is a supported filter size but not a supported track length here
     if (a.np > MAXNP || a.np * (a.stereo ? 2 : 1) > MAXP) return HV_ERR_UNSUPPORTED;
     ScopedKernelTime tm(c, HV_K_VU_PREPARE);
-    hipLaunchKernelGGL(vu_prepare_kernel, dim3((unsigned)a.batch), dim3(VT), 0, c->stream, a);
+    const int ncol = 7 * a.np * (a.stereo ? 2 : 1) + 1;
+    // HV_VU_THREADS (environment, experiments only): 384 / 768 forces a variant
+    static const int forced = [] { const char *e = getenv("HV_VU_THREADS"); return e ? atoi(e) : 0; }();
+    const bool small_ok = 2 * ncol <= VT_THROUGHPUT - 64;
+    const bool small = small_ok && forced == VT_THROUGHPUT;   // measured r02: 768 threads are faster at every batch size
+    if (small) hipLaunchKernelGGL(vu_prepare_kernel<VT_THROUGHPUT>, dim3((unsigned)a.batch), dim3(VT_THROUGHPUT), 0, c->stream, a);
+    else       hipLaunchKernelGGL(vu_prepare_kernel<VT_LATENCY>, dim3((unsigned)a.batch), dim3(VT_LATENCY), 0, c->stream, a);
     HV_HIP(c, hipGetLastError());
     return HV_OK;
 }

@@ -71,12 +71,13 @@ def test_chained_frames_equal_the_oracle_chain(oracle):
         d_counter = torch.zeros((B,), dtype=torch.int32, device="cuda")
         pts = grid.copy()                                   # [B][NPTS][2], carried from frame to frame
         disp = np.full((B, NPTS), 12.0, np.float32)
-        prev_pyr = None
+        prev_pyr, alive = None, [None, None]
         t_imu, applied_total, ransac_out, lost, gate_rejects = 0.0, 0, 0, 0, 0
         for f in range(FRAMES):
             k = f % UNIQUE
             imgs = np.concatenate([np.stack([seqs[s][0][k] for s in range(B)]), np.stack([seqs[s][1][k] for s in range(B)])])   # lefts, rights
             d_imgs = dev(imgs, np.uint8)
+            alive[f % 2] = d_imgs                           # level 0 is used IN PLACE: the previous frame's buffer must outlive this frame
             ctx.build_batch_dev(2 * B, s_build[f % 2].data_ptr(), d_imgs.data_ptr(), W * H, W)
             cur_pyr = [(oracle.Pyramid(seqs[s][0][k]), oracle.Pyramid(seqs[s][1][k])) for s in range(B)]
             if f == 0:
