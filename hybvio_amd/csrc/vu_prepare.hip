@@ -172,8 +172,6 @@ __device__ __forceinline__ void pair_sums(const double *o, const double *dh, con
     }
 }
 
-__device__ __forceinline__ void sym3(double *M) { M[3] = M[1]; M[6] = M[2]; M[7] = M[5]; }
-
 // dC and dt of pose i for state component comp of pose pj (:269-292), as one instruction stream: the derivative
 // matrices are scaled by 0 or 1 instead of branching on position / quaternion and own pose / pose 0.
 // Nothing in here depends on the Gauss-Newton iterate (C, t and d = p0 - p_i are fixed by the pose trail): evaluated once per
@@ -207,7 +205,7 @@ __device__ __forceinline__ void pose_motion(const double *trail, const double *R
 }
 
 template <int VT>
-__global__ __launch_bounds__(VT, 3) void vu_prepare_kernel(VuPrepareArgs a)
+__global__ __launch_bounds__(VT, VT / 256) void vu_prepare_kernel(VuPrepareArgs a)
 {
     __shared__ double s_trail[MAXP * POSE_WORDS];
     __shared__ double s_it[MAXP * ITER_WORDS];
@@ -215,13 +213,14 @@ __global__ __launch_bounds__(VT, 3) void vu_prepare_kernel(VuPrepareArgs a)
     __shared__ double s_feat[MAXP * 4];          // image feature (2) + velocity (2) per pose
     __shared__ double s_small[64];               // pfi[3] pf[3] X[9] step[3] ETE[9] Eerror[3] R0T[9] pf0 ... (see offsets)
     __shared__ double s_dpf[MAXNP * 21];           // summed dpfdp [n][9] and dpfdq [n][12]
-    __shared__ double s_p0[7 * MAXP * 12 + 7 * 12];   // motion part of the 7 columns of pose 0: [7][pose][12], then their totals [7][12]
+    __shared__ double s_p0[7 * MAXP * 9 + 7 * 9];     // motion part of the 7 columns of pose 0: [7][pose][9] (dEe, upper dM), then their totals [7][9]
     __shared__ int s_idx[MAXNP + 3];
     __shared__ int s_flag[4];
     constexpr int MOT_STRIDE = 13;                     // dC[9] dt[3] (+1: lanes 13 doubles apart hit the LDS banks two-way at worst)
     constexpr int MAXPAIRS = 14 * MAXP - 7;            // motion pairs: 7 nt with a pose-0 column + 7 (nt - 1) with the pose's own column
     __shared__ double s_mot[MAXPAIRS * MOT_STRIDE];
-    __shared__ double s_own[MAXC * 12];                // motion sums of the own pairs, by column
+    __shared__ double s_own[MAXC * 9];                 // motion sums of the own pairs, by column (dEe[3], upper triangle of dM[6])
+    __shared__ double s_lin[3 * MAXP * 9 + 32];        // plain part: per (pose, unit vector) 3 + 6 numbers, then L[3][9] and c_t[3]
     const int b = blockIdx.x, tid = threadIdx.x;
     const int n = a.np, ncam = a.stereo ? 2 : 1, nt = n * ncam, N = a.n;
     const int dDim = nt * 7, ncol = dDim + 1;
@@ -370,7 +369,6 @@ __global__ __launch_bounds__(VT, 3) void vu_prepare_kernel(VuPrepareArgs a)
     //                 7 pose-0 columns, whose sums go through LDS in a fixed order.
     // (With a branch inside the loop the wave holding the pose-0 columns took 16.9 k of an iteration's 19 k cycles.)
     // The last wave (VT - 64 ..) forms ETE / Eerror / the step concurrently.
-    const int gshift = 4 * ncol <= VT - 64 ? 2 : 1, G = 1 << gshift, col_lanes = ncol << gshift;
     // The motion pairs are dealt out densely, one per lane, to as few waves as hold them -- and to waves chosen by the SIMD they
     // sit on (wave w runs on SIMD w % 4): the column waves 0 .. 8 already load SIMD 0 with three waves of plain work, so the
     // pairs go to the two idle waves 9, 10 first, then to waves of SIMDs 1 - 3. (r01 gave every column lane a pair, own or
@@ -452,22 +450,22 @@ __global__ __launch_bounds__(VT, 3) void vu_prepare_kernel(VuPrepareArgs a)
             }
         }
         if (it < 6) VU_STAMP(5 + 4 * it);
-        // derivative columns: dEerror_j and dETE_j accumulated over the poses, with the OLD pfi (:236-312). G adjacent
-        // lanes share a column and split its poses (the loop is the critical path of the kernel: one workgroup per
-        // filter, so the time of a launch is the latency of one track); the sums stay in registers across the barrier
-        const int j = tid >> gshift, part = tid & (G - 1);
-        const bool is_t = j == dDim;
-        const bool has = tid < col_lanes && !(is_t && !a.est_shift);
-        double dEe[3] = {0, 0, 0}, dM[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-        if (has) {                                                                      // plain part
-            const double dpa = s_dpfi[j], dpb = s_dpfi[ncol + j], dpc = s_dpfi[2 * ncol + j];
-            for (int i = part; i < nt; i += G) {
-                const double *o = s_it + i * ITER_WORDS;
-                double dh[3];
-#pragma unroll
-                for (int r = 0; r < 3; ++r) dh[r] = (o[3 * r] * dpa + o[3 * r + 1] * dpb) + dpc * o[9 + r];
-                pair_sums<false>(o, dh, nullptr, nullptr, is_t ? s_feat[4 * i + 2] : 0.0, is_t ? s_feat[4 * i + 3] : 0.0, dEe, dM);
-            }
+        // derivative columns: dEerror_j and dETE_j accumulated over the poses, with the OLD pfi (:236-312).
+        // PLAIN part (the change of pfi seen by every pose): dh_i = [C_i(:, 0:2) | t_i] d_j with d_j = column j of dpfi, and everything
+        // downstream of dh is linear in it -- so the sum over the poses is taken ONCE, of the linear maps, not per column:
+        //   task (pose i, unit vector u)  ->  the 3 + 6 numbers (dEe, upper dM) pair_sums gives for dh = column u of [C_i | t_i]   (3 nt lanes)
+        //   L[u][9] = sum over the poses                                                                                         (27 lanes)
+        //   column j:  (dEe_j, dM_j) = L' d_j   (+ the velocity term c_t for the time-shift column)                             (27 FMAs)
+        // r01 walked the poses per column: nt x ~90 f64 instructions in each of 9 waves, the critical path of the kernel.
+        if (tid >= 64 && tid < 64 + 3 * nt) {
+            const int task = tid - 64, i = task / 3, u = task - 3 * i;
+            const double *o = s_it + i * ITER_WORDS;
+            const double dh[3] = {u < 2 ? o[u] : o[9], u < 2 ? o[3 + u] : o[10], u < 2 ? o[6 + u] : o[11]};
+            double e3[3] = {0, 0, 0}, m9[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+            pair_sums<false>(o, dh, nullptr, nullptr, 0.0, 0.0, e3, m9);
+            double *dst = s_lin + task * 9;
+            dst[0] = e3[0]; dst[1] = e3[1]; dst[2] = e3[2];
+            dst[3] = m9[0]; dst[4] = m9[1]; dst[5] = m9[2]; dst[6] = m9[4]; dst[7] = m9[5]; dst[8] = m9[8];
         }
         if (m_has) {                                                                    // motion part: one pair per lane, one code path
             const double *o = s_it + m_i * ITER_WORDS;
@@ -480,54 +478,52 @@ __global__ __launch_bounds__(VT, 3) void vu_prepare_kernel(VuPrepareArgs a)
 #pragma unroll
             for (int r = 0; r < 3; ++r) dh[r] = (dC[3 * r] * pfi[0] + dC[3 * r + 1] * pfi[1] + dC[3 * r + 2]) + pfi[2] * dt[r];
             pair_sums<true>(o, dh, dC, dt, 0.0, 0.0, e3, m9);
-            double *dst = m_p0pair ? s_p0 + (m_comp * MAXP + m_i) * 12 : s_own + m_col * 12;
-#pragma unroll
-            for (int k = 0; k < 3; ++k) dst[k] = e3[k];
-#pragma unroll
-            for (int k = 0; k < 9; ++k) dst[3 + k] = m9[k];
-        }
-        for (int o = 1; o < G; o <<= 1) {                     // the G partial sums of a column sit in adjacent lanes
-#pragma unroll
-            for (int k = 0; k < 3; ++k) dEe[k] += __shfl_xor(dEe[k], o);
-#pragma unroll
-            for (int k = 0; k < 9; ++k) if (k != 3 && k != 6 && k != 7) dM[k] += __shfl_xor(dM[k], o);    // upper triangle only
+            double *dst = m_p0pair ? s_p0 + (m_comp * MAXP + m_i) * 9 : s_own + m_col * 9;
+            dst[0] = e3[0]; dst[1] = e3[1]; dst[2] = e3[2];
+            dst[3] = m9[0]; dst[4] = m9[1]; dst[5] = m9[2]; dst[6] = m9[4]; dst[7] = m9[5]; dst[8] = m9[8];
         }
         __syncthreads();                                      // X, step, error2 are published; everybody is done with the old pfi
         if (it < 6) VU_STAMP(6 + 4 * it);
-        if (tid >= 64 && tid < 64 + 84) {                     // pose-0 columns: entry e of column c, motion part summed over the poses
-            const int c = (tid - 64) / 12, e = tid - 64 - 12 * c;
+        if (tid >= 64 && tid < 64 + 63) {                     // pose-0 columns: entry e of column c, motion part summed over the poses
+            const int c = (tid - 64) / 9, e = tid - 64 - 9 * c;
             double acc = 0.0;
-            for (int q = 0; q < nt; ++q) acc += s_p0[(c * MAXP + q) * 12 + e];
-            s_p0[7 * MAXP * 12 + tid - 64] = acc;
+            for (int q = 0; q < nt; ++q) acc += s_p0[(c * MAXP + q) * 9 + e];
+            s_p0[7 * MAXP * 9 + tid - 64] = acc;
+        } else if (tid >= 192 && tid < 192 + 27) {            // L[u][e]: the linear maps of the plain part summed over the poses
+            const int u = (tid - 192) / 9, e = tid - 192 - 9 * u;
+            double acc = 0.0;
+            for (int q = 0; q < nt; ++q) acc += s_lin[(3 * q + u) * 9 + e];
+            s_lin[3 * MAXP * 9 + 9 * u + e] = acc;
+        } else if (tid >= 224 && tid < 224 + 3) {             // c_t = sum_i E_i' vel_i: the constant the time-shift column adds to dEe
+            const int r = tid - 224;
+            double acc = 0.0;
+            for (int q = 0; q < nt; ++q) acc += s_it[q * ITER_WORDS + 15 + r] * s_feat[4 * q + 2] + s_it[q * ITER_WORDS + 18 + r] * s_feat[4 * q + 3];
+            s_lin[3 * MAXP * 9 + 27 + r] = acc;
         }
-        if (has && part == 0 && j >= 7) {                     // :324-328: d(A^-1) = -A^-1 dA A^-1
-            double t1[3], t2[3], t3[3];
-            if (!is_t) {                                      // + the motion sums of the column's own pair
-                const double *own = s_own + j * 12;
+        __syncthreads();
+        if (tid < ncol && !(tid == dDim && !a.est_shift)) {   // :324-328: d(A^-1) = -A^-1 dA A^-1, one lane per column
+            const int j = tid;
+            const double *Lm = s_lin + 3 * MAXP * 9;
+            const double d0 = s_dpfi[j], d1 = s_dpfi[ncol + j], d2 = s_dpfi[2 * ncol + j];
+            double v[9];
 #pragma unroll
-                for (int k = 0; k < 3; ++k) dEe[k] += own[k];
+            for (int e = 0; e < 9; ++e) v[e] = (Lm[e] * d0 + Lm[9 + e] * d1) + Lm[18 + e] * d2;
+            double dEe[3] = {v[0], v[1], v[2]}, dM[9] = {v[3], v[4], v[5], v[4], v[6], v[7], v[5], v[7], v[8]};
+            // + the motion sums: the pose-0 totals (columns 0 .. 6), the column's own pair (regular columns), the velocity term (time shift)
+            const double *add = j < 7 ? s_p0 + 7 * MAXP * 9 + 9 * j : s_own + j * 9;
+            if (j != dDim) {
 #pragma unroll
-                for (int k = 0; k < 9; ++k) dM[k] += own[3 + k];
+                for (int k = 0; k < 3; ++k) dEe[k] += add[k];
+                dM[0] += add[3]; dM[1] += add[4]; dM[2] += add[5]; dM[4] += add[6]; dM[5] += add[7]; dM[8] += add[8];
+                dM[3] = dM[1]; dM[6] = dM[2]; dM[7] = dM[5];
+            } else {
+#pragma unroll
+                for (int k = 0; k < 3; ++k) dEe[k] += Lm[27 + k];
             }
-            sym3(dM);
+            double t1[3], t2[3], t3[3];
             mv3(dM, step, t1);
             mv3(X, t1, t2);
             mv3(X, dEe, t3);
-#pragma unroll
-            for (int r = 0; r < 3; ++r) s_dpfi[r * ncol + j] += t2[r] - t3[r];
-        }
-        __syncthreads();
-        if (has && part == 0 && j < 7) {                      // the same update for the pose-0 columns: plain (registers) + motion (LDS)
-            const double *tot = s_p0 + 7 * MAXP * 12 + 12 * j;
-            double t1[3], t2[3], t3[3], e3[3], m9[9];
-#pragma unroll
-            for (int k = 0; k < 3; ++k) e3[k] = dEe[k] + tot[k];
-#pragma unroll
-            for (int k = 0; k < 9; ++k) m9[k] = dM[k] + tot[3 + k];
-            sym3(m9);
-            mv3(m9, step, t1);
-            mv3(X, t1, t2);
-            mv3(X, e3, t3);
 #pragma unroll
             for (int r = 0; r < 3; ++r) s_dpfi[r * ncol + j] += t2[r] - t3[r];
         }
