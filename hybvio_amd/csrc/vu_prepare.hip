@@ -28,11 +28,10 @@ namespace {
 
 // threads per workgroup (template parameter VT): G = 2 or 4 lanes per derivative column (<= 7 * 42 + 1 columns) + one wave.
 // 768 gives the longest track (21 stereo poses) its G = 2 and a 10-pose stereo track G = 4: the shortest latency of ONE track.
-// 384 still covers tracks of up to 22 camera poses with G = 2; it was built to let two workgroups share a CU, but the kernel is
-// f64-issue bound per SIMD (the same wave-instructions either way) and measured no faster at any batch size: experiment knob only.
+// 384 threads cover tracks of up to 22 camera poses (see the kernel's template parameters).
 constexpr int VT_LATENCY = 768, VT_THROUGHPUT = 384;
-constexpr int MAXP = 42;                // 2 cameras x (cameraTrailLength + 1 <= 21) poses
-constexpr int MAXC = MAXP * 7 + 1;
+constexpr int MAXP_ALL = 42;            // 2 cameras x (cameraTrailLength + 1 <= 21) poses: the largest track
+constexpr int MAXP_SMALL = 22;          // the 384-thread build: up to 22 camera poses (10 or 11 stereo poses, 21 mono poses)
 constexpr int MAXNP = 21;              // poses per camera: s_dpf is [MAXNP][21], s_idx holds MAXNP (+3 spare) indices
 constexpr int POSE_WORDS = 51;          // p[3] R[9] dR[4][9] baseline[3]
 constexpr int ITER_WORDS = 26;          // C[9] t[3] h[3] E[6] err[2] d[3]
@@ -204,23 +203,42 @@ __device__ __forceinline__ void pose_motion(const double *trail, const double *R
     for (int k = 0; k < 3; ++k) dt[k] = t1[k] + t2[k];
 }
 
-template <int VT>
-__global__ __launch_bounds__(VT, VT / 256) void vu_prepare_kernel(VuPrepareArgs a)
+// LDS layout of the kernel in doubles, for MAXP camera poses
+template <int MAXP>
+struct VuLds {
+    static constexpr int MAXC = MAXP * 7 + 1, MOT_STRIDE = 13;
+    static constexpr int MAXPAIRS = 14 * MAXP - 7;            // motion pairs: 7 nt with a pose-0 column + 7 (nt - 1) with the pose's own column
+    static constexpr int TRAIL = 0, IT = TRAIL + MAXP * POSE_WORDS, DPFI = IT + MAXP * ITER_WORDS, FEAT = DPFI + 3 * MAXC,
+                         SMALL = FEAT + MAXP * 4, DPF = SMALL + 64, P0 = DPF + MAXNP * 21, MOT = P0 + 7 * MAXP * 9 + 7 * 9,
+                         OWN = MOT + MAXPAIRS * MOT_STRIDE, LIN = OWN + MAXC * 9, INTS = LIN + 3 * MAXP * 9 + 32,
+                         TOTAL = INTS + (MAXNP + 3 + 4 + 1) / 2 + 1;
+    static constexpr size_t BYTES = sizeof(double) * TOTAL;
+};
+
+// MAXP (camera poses the LDS arrays are sized for) is a template parameter next to VT: <768, 42> holds every track (151 KB of LDS,
+// one workgroup per CU); <384, 22> holds the common sizes in 75 KB and 6 waves of 138 VGPRs, so TWO filters share a CU and one's
+// serial sections (pose records, 3 x 3 solves, barriers: most of the kernel since r02 took the column work off the critical path)
+// overlap the other's.
+template <int VT, int MAXP>
+__device__ __forceinline__ void vu_prepare_body(const VuPrepareArgs &a)
 {
-    __shared__ double s_trail[MAXP * POSE_WORDS];
-    __shared__ double s_it[MAXP * ITER_WORDS];
-    __shared__ double s_dpfi[3 * MAXC];          // [3][ncol]
-    __shared__ double s_feat[MAXP * 4];          // image feature (2) + velocity (2) per pose
-    __shared__ double s_small[64];               // pfi[3] pf[3] X[9] step[3] ETE[9] Eerror[3] R0T[9] pf0 ... (see offsets)
-    __shared__ double s_dpf[MAXNP * 21];           // summed dpfdp [n][9] and dpfdq [n][12]
-    __shared__ double s_p0[7 * MAXP * 9 + 7 * 9];     // motion part of the 7 columns of pose 0: [7][pose][9] (dEe, upper dM), then their totals [7][9]
-    __shared__ int s_idx[MAXNP + 3];
-    __shared__ int s_flag[4];
-    constexpr int MOT_STRIDE = 13;                     // dC[9] dt[3] (+1: lanes 13 doubles apart hit the LDS banks two-way at worst)
-    constexpr int MAXPAIRS = 14 * MAXP - 7;            // motion pairs: 7 nt with a pose-0 column + 7 (nt - 1) with the pose's own column
-    __shared__ double s_mot[MAXPAIRS * MOT_STRIDE];
-    __shared__ double s_own[MAXC * 9];                 // motion sums of the own pairs, by column (dEe[3], upper triangle of dM[6])
-    __shared__ double s_lin[3 * MAXP * 9 + 32];        // plain part: per (pose, unit vector) 3 + 6 numbers, then L[3][9] and c_t[3]
+    // All LDS comes from the dynamic region (carved below): with static arrays the compiler derives the occupancy from their size
+    // and stops honouring the register cap that lets two of the small workgroups share a CU.
+    using Lay = VuLds<MAXP>;
+    constexpr int MOT_STRIDE = Lay::MOT_STRIDE;
+    extern __shared__ __attribute__((aligned(16))) double vu_lds[];
+    double *s_trail = vu_lds + Lay::TRAIL;       // [MAXP][POSE_WORDS]
+    double *s_it = vu_lds + Lay::IT;             // [MAXP][ITER_WORDS]
+    double *s_dpfi = vu_lds + Lay::DPFI;         // [3][ncol]
+    double *s_feat = vu_lds + Lay::FEAT;         // image feature (2) + velocity (2) per pose
+    double *s_small = vu_lds + Lay::SMALL;       // pfi[3] pf[3] X[9] step[3] ETE[9] Eerror[3] R0T[9] pf0 ... (see offsets)
+    double *s_dpf = vu_lds + Lay::DPF;           // summed dpfdp [n][9] and dpfdq [n][12]
+    double *s_p0 = vu_lds + Lay::P0;             // motion part of the 7 columns of pose 0: [7][pose][9] (dEe, upper dM), then their totals [7][9]
+    double *s_mot = vu_lds + Lay::MOT;           // dC[9] dt[3] of every motion pair (+1: lanes 13 doubles apart hit the LDS banks two-way at worst)
+    double *s_own = vu_lds + Lay::OWN;           // motion sums of the own pairs, by column (dEe[3], upper triangle of dM[6])
+    double *s_lin = vu_lds + Lay::LIN;           // plain part: per (pose, unit vector) 3 + 6 numbers, then L[3][9] and c_t[3]
+    int *s_idx = reinterpret_cast<int *>(vu_lds + Lay::INTS);      // [MAXNP + 3]
+    int *s_flag = s_idx + MAXNP + 3;                               // [4]
     const int b = blockIdx.x, tid = threadIdx.x;
     const int n = a.np, ncam = a.stereo ? 2 : 1, nt = n * ncam, N = a.n;
     const int dDim = nt * 7, ncol = dDim + 1;
@@ -682,6 +700,13 @@ __global__ __launch_bounds__(VT, VT / 256) void vu_prepare_kernel(VuPrepareArgs 
     }
 }
 
+__global__ __launch_bounds__(VT_LATENCY, 3) void vu_prepare_kernel(VuPrepareArgs a) { vu_prepare_body<VT_LATENCY, MAXP_ALL>(a); }
+// 4 waves per SIMD = 128 VGPRs: two workgroups of 6 waves may put 4 waves on one SIMD (512 VGPRs per lane there)
+__global__ __launch_bounds__(VT_THROUGHPUT, 4) void vu_prepare_kernel_2percu(VuPrepareArgs a)
+{
+    vu_prepare_body<VT_THROUGHPUT, MAXP_SMALL>(a);
+}
+
 }  // namespace
 
 int launch_vu_prepare(Ctx *c, const VuPrepareArgs &a)
@@ -689,15 +714,23 @@ int launch_vu_prepare(Ctx *c, const VuPrepareArgs &a)
     if (a.np < 2 || a.batch < 1) return HV_ERR_INVALID;
     // the kernel's LDS arrays hold at most MAXNP poses per camera (the reference's cameraTrailLength 20 + the current pose);
     // a longer trail (cameraTrailLength > 20) is a supported filter size but not a supported track length here
-    if (a.np > MAXNP || a.np * (a.stereo ? 2 : 1) > MAXP) return HV_ERR_UNSUPPORTED;
+    if (a.np > MAXNP || a.np * (a.stereo ? 2 : 1) > MAXP_ALL) return HV_ERR_UNSUPPORTED;
     ScopedKernelTime tm(c, HV_K_VU_PREPARE);
-    const int ncol = 7 * a.np * (a.stereo ? 2 : 1) + 1;
-    // HV_VU_THREADS (environment, experiments only): 384 / 768 forces a variant
+    const int nt = a.np * (a.stereo ? 2 : 1);
+    // HV_VU_THREADS (environment, experiments only): 384 / 768 forces a variant where it applies
     static const int forced = [] { const char *e = getenv("HV_VU_THREADS"); return e ? atoi(e) : 0; }();
-    const bool small_ok = 2 * ncol <= VT_THROUGHPUT - 64;
-    const bool small = small_ok && forced == VT_THROUGHPUT;   // measured r02: 768 threads are faster at every batch size
-    if (small) hipLaunchKernelGGL(vu_prepare_kernel<VT_THROUGHPUT>, dim3((unsigned)a.batch), dim3(VT_THROUGHPUT), 0, c->stream, a);
-    else       hipLaunchKernelGGL(vu_prepare_kernel<VT_LATENCY>, dim3((unsigned)a.batch), dim3(VT_LATENCY), 0, c->stream, a);
+    const bool small_ok = nt <= MAXP_SMALL;
+    // two filters per CU pay off once the launch holds more filters than the GPU has CUs; below that the big build's latency wins
+    const bool small = small_ok && (forced == VT_THROUGHPUT || (forced == 0 && a.batch > 256));
+    static bool attr_set_dev[64] = {};                       // per device: both kernels need more than the default 64 KB of dynamic LDS
+    bool &attr_set = attr_set_dev[c->p.device & 63];
+    if (!attr_set) {
+        HV_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void *>(vu_prepare_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)VuLds<MAXP_ALL>::BYTES));
+        HV_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void *>(vu_prepare_kernel_2percu), hipFuncAttributeMaxDynamicSharedMemorySize, (int)VuLds<MAXP_SMALL>::BYTES));
+        attr_set = true;
+    }
+    if (small) hipLaunchKernelGGL(vu_prepare_kernel_2percu, dim3((unsigned)a.batch), dim3(VT_THROUGHPUT), VuLds<MAXP_SMALL>::BYTES, c->stream, a);
+    else       hipLaunchKernelGGL(vu_prepare_kernel, dim3((unsigned)a.batch), dim3(VT_LATENCY), VuLds<MAXP_ALL>::BYTES, c->stream, a);
     HV_HIP(c, hipGetLastError());
     return HV_OK;
 }
