@@ -906,9 +906,12 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
-    torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
+    # HV_BENCH_FORCE_DEVICE=0 maps every rank onto one GPU: a smoke test of the N > 1 code path on a 1-GPU box (never a measurement)
+    forced_dev = os.environ.get("HV_BENCH_FORCE_DEVICE")
+    torch.cuda.set_device(int(forced_dev) if forced_dev is not None else int(os.environ.get("LOCAL_RANK", "0")))
     env = DistEnv(args.dist_backend)
-    world, rank, local_rank = env.world, env.rank, env.local_rank
+    world, rank = env.world, env.rank
+    local_rank = int(forced_dev) if forced_dev is not None else env.local_rank            # = the device ordinal from here on
     solo = world == 1                # legs that characterise single kernels run on a 1-GPU job only: at N > 1 every rank
                                      # does the same work in every region, no rank waits for another one's extras
 
@@ -1015,6 +1018,7 @@ def main():
             "value": aggregate_value(B, world, args.steps, el3), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": el3 / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u8/int16 pixels, int32/int64 sums, f32 solve (tracker); f64 (EKF)", "data": "synthetic",
+            "smoke_all_ranks_on_one_device": forced_dev is not None or None,
             "config": {"workload": "C3: 752x480 stereo, 200 pts -- the whole frame chained on one stream per sequence: 2 pyramid builds, temporal LK, "
                                    "2-point rotation RANSAC on its output, stereo LK, GFTT key points every 2nd frame (HIP tracker), then the HIP EKF "
                                    "from the device mean: 20 track visits (triangulation + prepareVisualUpdate, 10 stereo poses = 40 x 160 Jacobian, "

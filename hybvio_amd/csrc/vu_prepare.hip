@@ -502,21 +502,31 @@ __device__ __forceinline__ void vu_prepare_body(const VuPrepareArgs &a)
         }
         __syncthreads();                                      // X, step, error2 are published; everybody is done with the old pfi
         if (it < 6) VU_STAMP(6 + 4 * it);
-        if (tid >= 64 && tid < 64 + 63) {                     // pose-0 columns: entry e of column c, motion part summed over the poses
-            const int c = (tid - 64) / 9, e = tid - 64 - 9 * c;
+        // 93 sums over the poses, LPS adjacent lanes each (a lane per sum walked nt dependent LDS reads + adds: 1.4 k cycles):
+        //   sigma < 63       pose-0 columns: entry e of column c, motion part            -> totals at s_p0 + 7 MAXP 9
+        //   63 <= sigma < 90 L[u][e]: the linear maps of the plain part                  -> s_lin + 3 MAXP 9
+        //   90 <= sigma < 93 c_t = sum_i E_i' vel_i: the constant of the time-shift column -> s_lin + 3 MAXP 9 + 27
+        constexpr int LPS = VT >= 768 ? 4 : 2;
+        if (tid >= 64 && tid < 64 + 93 * LPS) {
+            const int g = tid - 64, sigma = g / LPS, part = g - sigma * LPS;
             double acc = 0.0;
-            for (int q = 0; q < nt; ++q) acc += s_p0[(c * MAXP + q) * 9 + e];
-            s_p0[7 * MAXP * 9 + tid - 64] = acc;
-        } else if (tid >= 192 && tid < 192 + 27) {            // L[u][e]: the linear maps of the plain part summed over the poses
-            const int u = (tid - 192) / 9, e = tid - 192 - 9 * u;
-            double acc = 0.0;
-            for (int q = 0; q < nt; ++q) acc += s_lin[(3 * q + u) * 9 + e];
-            s_lin[3 * MAXP * 9 + 9 * u + e] = acc;
-        } else if (tid >= 224 && tid < 224 + 3) {             // c_t = sum_i E_i' vel_i: the constant the time-shift column adds to dEe
-            const int r = tid - 224;
-            double acc = 0.0;
-            for (int q = 0; q < nt; ++q) acc += s_it[q * ITER_WORDS + 15 + r] * s_feat[4 * q + 2] + s_it[q * ITER_WORDS + 18 + r] * s_feat[4 * q + 3];
-            s_lin[3 * MAXP * 9 + 27 + r] = acc;
+            if (sigma < 63) {
+                const int c = sigma / 9, e = sigma - 9 * c;
+                for (int q = part; q < nt; q += LPS) acc += s_p0[(c * MAXP + q) * 9 + e];
+            } else if (sigma < 90) {
+                const int u = (sigma - 63) / 9, e = sigma - 63 - 9 * u;
+                for (int q = part; q < nt; q += LPS) acc += s_lin[(3 * q + u) * 9 + e];
+            } else {
+                const int r = sigma - 90;
+                for (int q = part; q < nt; q += LPS)
+                    acc += s_it[q * ITER_WORDS + 15 + r] * s_feat[4 * q + 2] + s_it[q * ITER_WORDS + 18 + r] * s_feat[4 * q + 3];
+            }
+#pragma unroll
+            for (int o = 1; o < LPS; o <<= 1) acc += __shfl_xor(acc, o);
+            if (part == 0) {
+                if (sigma < 63) s_p0[7 * MAXP * 9 + sigma] = acc;
+                else s_lin[3 * MAXP * 9 + sigma - 63] = acc;
+            }
         }
         __syncthreads();
         if (tid < ncol && !(tid == dDim && !a.est_shift)) {   // :324-328: d(A^-1) = -A^-1 dA A^-1, one lane per column
@@ -656,8 +666,9 @@ __device__ __forceinline__ void vu_prepare_body(const VuPrepareArgs &a)
     __syncthreads();
     // work item = (state column c, trail pose i), i fastest: the 2 * nt rows of a column are contiguous in the column-major
     // H, so consecutive lanes write consecutive 16-byte pairs (a thread per column wrote 16 bytes every 2 * nt * 8)
+    const unsigned inv_nt = (unsigned)((0x100000000ull + (unsigned)nt - 1) / (unsigned)nt);   // w / nt = umulhi(w, ceil(2^32 / nt)) for w nt < 2^32
     for (int w = tid; w < N * nt; w += VT) {
-        const int c = w / nt, i = w - c * nt;
+        const int c = (int)__umulhi((unsigned)w, inv_nt), i = w - c * nt;
         const int code = s_colmap[c], k = code >> 3, comp = code & 7;
         const bool sft = c == 19 && with_derivatives && a.est_shift;
         const double *o = s_it + i * ITER_WORDS;
