@@ -29,6 +29,8 @@
 #include <utility>
 
 #include "chi2inv95.h"
+#include <stdlib.h>
+
 #include "hv_internal.hpp"
 
 // The library is built with -ffp-contract=off for the tracker's bit-exact binary32 sequence; the
@@ -418,6 +420,12 @@ struct UpdateArgs {
     const unsigned char *active;      // optional per-filter enable
     const int *require_inlier;        // optional per-filter gate result of an earlier launch: run only where it is 0 (INLIER)
     int *success_counter;             // optional per-filter count of applied visual updates (updateSuccessCount, backend.cpp:1183)
+    // speculative frame loop (small batches, hv_ekf_visual_frame_dev): inputs / outputs are [n_tracks][batch] records
+    //   spec 1: grid (batch, n_tracks), chi2 gate of EVERY pending track (index >= cursor[filter]) against the current (m, P)
+    //   spec 2: grid (batch): the first pending track whose gate said INLIER is applied (mode 1), cursor moves behind it
+    int spec, n_tracks, max_successful;
+    int *cursor;                      // [batch] first track of the filter that is not final yet
+    const int *gate_in;               // spec 2: [n_tracks][batch] gate results of spec 1 (a.status stays free for this launch's own output)
 };
 
 constexpr int UPD_THREADS = 512;   // 8 waves = 2 per SIMD: 256 VGPRs each (whole column blocks of P stay in registers)
@@ -433,14 +441,35 @@ __global__ __launch_bounds__(UPD_THREADS) void ekf_update_kernel(UpdateArgs a)
     constexpr bool USE_LDS = MODE >= 1;
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int b = blockIdx.x;
-    if (a.active && !a.active[b]) return;
+    int e = b;                                             // record of this workgroup's H, v, active, chi2, status
+    int sel = -1;
+    if (a.spec == 1) {
+        const int j = blockIdx.y;
+        if (j < a.cursor[b] || a.success_counter[b] >= a.max_successful) return;
+        e = j * (int)gridDim.x + b;
+    } else if (a.spec == 2) {
+        // every thread runs the same short scan (uniform): the first pending track that passed its gate
+        const int c0 = a.cursor[b];
+        if (c0 >= a.n_tracks || a.success_counter[b] >= a.max_successful) return;
+        for (int j = c0; j < a.n_tracks && sel < 0; ++j) {
+            const int ee = j * (int)gridDim.x + b;
+            if (a.active[ee] && a.gate_in[ee] == 0) sel = j;
+        }
+        if (sel < 0) {                                     // nothing applicable is left: every pending status is final
+            __syncthreads();
+            if (threadIdx.x == 0) a.cursor[b] = a.n_tracks;
+            return;
+        }
+        e = sel * (int)gridDim.x + b;
+    }
+    if (a.active && !a.active[e]) return;
     if (a.require_inlier && a.require_inlier[b] != 0) return;
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);     // wave-uniform: tile indices and their addresses stay on the scalar unit
     constexpr int nwaves = UPD_THREADS / 64;
     const int n = a.n, nr = a.nr, l = a.l, R = a.Rs;       // R is the column STRIDE of T below; a.R rows are used
     double *m = a.m + (size_t)b * n, *P = a.P + (size_t)b * n * n;
-    const double *H = a.H + (size_t)b * nr * l;
+    const double *H = a.H + (size_t)e * nr * l;
     const double rd = a.rdiag ? a.rdiag[b] : a.rd0;
     // Tall matrix T (a.R rows x nr columns, column-major with stride R >= a.R: T(r, c) = T[c * R + r]; in LDS
     // the stride is padded to 15 or 17 mod 32 doubles, see ekf_launch_update):
@@ -596,7 +625,7 @@ __global__ __launch_bounds__(UPD_THREADS) void ekf_update_kernel(UpdateArgs a)
         }
     }
     for (int i = t; i < nr; i += UPD_THREADS) {
-        double r = a.v[(size_t)b * nr + i];
+        double r = a.v[(size_t)e * nr + i];
         if (a.generic) { double s = 0; for (int k = 0; k < l; k++) s += H[(size_t)k * nr + i] * m[k]; r -= s; }
         T[(size_t)i * R + rv] = r;
     }
@@ -723,8 +752,8 @@ __global__ __launch_bounds__(UPD_THREADS) void ekf_update_kernel(UpdateArgs a)
             tot *= a.noise_scale;
             const int outlier = (nr < HV_CHI2INV95_N) ? (tot > d_chi2inv95[nr]) : 0;
             if (pass == 0) {
-                if (a.chi2) a.chi2[b] = tot;
-                if (a.status) a.status[b] = outlier ? 3 /*CHI2*/ : 0 /*INLIER*/;
+                if (a.chi2) a.chi2[e] = tot;
+                if (a.status) a.status[e] = outlier ? 3 /*CHI2*/ : 0 /*INLIER*/;
             }
             *s_stop = (a.mode == 0) || ((a.mode == 2 || (two_r && pass == 0)) && outlier);
         }
@@ -827,6 +856,7 @@ __global__ __launch_bounds__(UPD_THREADS) void ekf_update_kernel(UpdateArgs a)
     const int nq = a.normalize_all ? 1 + (n - a.map_dim - CAM) / POSE : 1;     // map points behind the trail are not poses
     if (t < nq) normalize4(m + (t == 0 ? ORI : CAM + POSE * (t - 1) + 3));
     if (a.success_counter && t == 0) a.success_counter[b] += 1;
+    if (a.spec == 2 && t == 0) a.cursor[b] = sel + 1;      // the tracks up to the applied one are final, the rest is re-examined
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1154,6 +1184,11 @@ struct Ekf {
     double *vuH = nullptr, *vuv = nullptr, *vupf = nullptr;
     unsigned char *vuactive = nullptr;
     int vu_rows = 0;
+    // speculative frame loop: per (track, filter) records + per-filter cursor and the update count each record was prepared at
+    double *spH = nullptr, *spv = nullptr, *sppf = nullptr;
+    unsigned char *spactive = nullptr;
+    int *spcursor = nullptr, *spepoch = nullptr;
+    size_t sp_records = 0; int sp_rows = 0;
     // device staging of the host-pointer entry hv_ekf_visual_track: idx | features | velocities | y | status | gate | chi2 | pf
     unsigned char *vustage = nullptr;
     size_t vustage_bytes = 0;
@@ -1162,7 +1197,9 @@ struct Ekf {
 static int ekf_launch_update(Ekf *e, int nr, int l, const double *H_dev, const double *v_dev, const double *rdiag_dev,
                              double rd0, int mode, int generic, int normalize_all, double *chi2_dev, int *status_dev,
                              const unsigned char *active_dev, const int *require_inlier_dev = nullptr,
-                             int *success_counter_dev = nullptr, double rd1 = 0.0, bool *two_r_done = nullptr)
+                             int *success_counter_dev = nullptr, double rd1 = 0.0, bool *two_r_done = nullptr,
+                             int spec = 0, int n_tracks = 0, int *cursor_dev = nullptr, int max_successful = 0,
+                             const int *gate_in_dev = nullptr)
 {
     Ctx *c = e->c;
     if (nr < 1 || nr > e->max_rows || l < 1 || l > e->n) return HV_ERR_INVALID;
@@ -1180,6 +1217,7 @@ static int ekf_launch_update(Ekf *e, int nr, int l, const double *H_dev, const d
     a.mode = mode; a.generic = generic; a.normalize_all = normalize_all; a.map_dim = e->map_dim;
     a.m = e->m; a.P = e->P; a.H = H_dev; a.v = v_dev; a.rdiag = rdiag_dev; a.rd0 = rd0; a.rd1 = rd1; a.noise_scale = e->noise_scale;
     a.ws = e->ws; a.chi2 = chi2_dev; a.status = status_dev; a.active = active_dev; a.require_inlier = require_inlier_dev; a.success_counter = success_counter_dev;
+    a.spec = spec; a.n_tracks = n_tracks; a.cursor = cursor_dev; a.max_successful = max_successful; a.gate_in = gate_in_dev;
     size_t tall = (((size_t)a.Rs * nr + 1) & ~(size_t)1) * sizeof(double);
     const size_t small = (size_t)(256 + 544 + UPD_THREADS / 64 + 2) * sizeof(double);           // W + col (incl. dump area) + red + flag
     const int ti = (nr + 15) / 16, lbk = (l + 15) / 16;
@@ -1193,6 +1231,7 @@ static int ekf_launch_update(Ekf *e, int nr, int l, const double *H_dev, const d
         if (two_r_done) *two_r_done = can;
         if (!can) return HV_OK;                          // the caller falls back to two launches
     }
+    if (spec && kmode != 2) return HV_ERR_UNSUPPORTED;   // the speculative loop keeps every record in the LDS-resident kernel
     const size_t shmem = kmode == 2 ? tall + small + hbytes : kmode == 1 ? tall + small : small;
     using Kern = void (*)(UpdateArgs);
     const Kern kern = kmode == 0 ? (Kern)ekf_update_kernel<0, 0> : kmode == 1 ? (Kern)ekf_update_kernel<1, 0>
@@ -1206,7 +1245,7 @@ static int ekf_launch_update(Ekf *e, int nr, int l, const double *H_dev, const d
         attr_set = true;
     }
     ScopedKernelTime tm(c, HV_K_EKF_UPDATE);
-    hipLaunchKernelGGL(kern, dim3(e->batch), dim3(UPD_THREADS), shmem, c->stream, a);
+    hipLaunchKernelGGL(kern, dim3(e->batch, spec == 1 ? n_tracks : 1), dim3(UPD_THREADS), shmem, c->stream, a);
     HV_HIP(c, hipGetLastError());
     return HV_OK;
 }
@@ -1238,7 +1277,8 @@ void hv_ekf_destroy(hv_ekf *h)
     Ekf *e = &h->e;
     if (e->c && e->c->stream) (void)hipStreamSynchronize(e->c->stream);
     void *ptrs[] = { e->m, e->P, e->P1, e->m1, e->Q, e->dydx, e->ws, e->sH, e->sv, e->sr, e->schi2, e->simu,
-                     e->sstatus, e->sdrop, e->sactive, e->vuH, e->vuv, e->vupf, e->vuactive, e->vustage };
+                     e->sstatus, e->sdrop, e->sactive, e->vuH, e->vuv, e->vupf, e->vuactive, e->vustage,
+                     e->spH, e->spv, e->sppf, e->spactive, e->spcursor, e->spepoch };
     for (void *p : ptrs) if (p) (void)hipFree(p);
     delete h;
 }
@@ -1416,6 +1456,49 @@ int hv_ekf_visual_frame_dev(hv_ekf *h, const hv_vu_params *p, int n_tracks, int 
     Ekf *e = &h->e; Ctx *c = e->c;
     const size_t B = (size_t)e->batch, nt = (size_t)np * (p && p->useStereo ? 2 : 1);
     HV_HIP(c, hipMemsetAsync(success_counter_dev, 0, sizeof(int) * B, c->stream));          // updateSuccessCount = 0 (backend.cpp:1017)
+    // Few sequences (one, for the reference's `main`): the frame is latency bound -- 20 dependent visits of a ~26 us prepare and a
+    // ~34 us gate. While the GPU has idle CUs the loop is run SPECULATIVELY instead: a pass prepares and gates
+    // EVERY pending track of a filter against the current (m, P) in parallel, applies the first inlier in visit order, and only the
+    // tracks behind it are re-examined: <= max_successful + 1 passes of 3 launches, the same statuses and the same filter as the
+    // sequential loop (tracks in front of the first inlier saw the state they would have seen anyway).
+    static const int spec_off = [] { const char *e_ = getenv("HV_EKF_NO_SPECULATION"); return e_ ? atoi(e_) : 0; }();
+    const int rows = 2 * (int)nt;
+    if (!spec_off && n_tracks >= 2 && B * (size_t)n_tracks <= 256 && e->n <= 160 && rows <= 48 && p && idx && feat && vel && y) {
+        const size_t rec = B * (size_t)n_tracks;
+        if (e->sp_records < rec || e->sp_rows < rows) {
+            HV_HIP(c, hipStreamSynchronize(c->stream));
+            void *old[] = {e->spH, e->spv, e->sppf, e->spactive, e->spcursor, e->spepoch};
+            for (void *q : old) if (q) (void)hipFree(q);
+            e->spH = e->spv = e->sppf = nullptr; e->spactive = nullptr; e->spcursor = e->spepoch = nullptr; e->sp_records = 0;
+            HV_HIP(c, hipMalloc(reinterpret_cast<void **>(&e->spH), sizeof(double) * rec * rows * e->n));
+            HV_HIP(c, hipMalloc(reinterpret_cast<void **>(&e->spv), sizeof(double) * rec * rows));
+            HV_HIP(c, hipMalloc(reinterpret_cast<void **>(&e->sppf), sizeof(double) * rec * 3));
+            HV_HIP(c, hipMalloc(reinterpret_cast<void **>(&e->spactive), rec));
+            HV_HIP(c, hipMalloc(reinterpret_cast<void **>(&e->spcursor), sizeof(int) * B));
+            HV_HIP(c, hipMalloc(reinterpret_cast<void **>(&e->spepoch), sizeof(int) * rec));
+            e->sp_records = rec; e->sp_rows = rows;
+        }
+        HV_HIP(c, hipMemsetAsync(e->spcursor, 0, sizeof(int) * B, c->stream));
+        HV_HIP(c, hipMemsetAsync(e->spepoch, 0xFF, sizeof(int) * rec, c->stream));               // -1: nothing prepared yet
+        hv::VuPrepareArgs a;
+        int rc = vu_fill_args(e, p, np, idx, feat, vel, y, a);
+        if (rc != HV_OK) return rc;
+        a.H = e->spH; a.v = e->spv; a.f = nullptr; a.pf = e->sppf; a.status = status_dev; a.active = e->spactive;
+        a.gate_status = gate_status_dev; a.success_counter = success_counter_dev; a.max_successful = max_successful;
+        a.spec_tracks = n_tracks; a.cursor = e->spcursor; a.epoch = e->spepoch;
+        for (int pass = 0; pass <= max_successful; ++pass) {
+            rc = hv::launch_vu_prepare(c, a);
+            if (rc != HV_OK) return rc;
+            rc = hv::ekf_launch_update(e, rows, e->n, e->spH, e->spv, nullptr, r_gate * r_gate * e->noise_scale, 0, 0, 0, chi2_dev,
+                                       gate_status_dev, e->spactive, nullptr, success_counter_dev, 0.0, nullptr, 1, n_tracks, e->spcursor, max_successful);
+            if (rc != HV_OK) return rc;
+            rc = hv::ekf_launch_update(e, rows, e->n, e->spH, e->spv, nullptr, r_update * r_update * e->noise_scale, 1, 0, 1, nullptr,
+                                       nullptr, e->spactive, nullptr, success_counter_dev, 0.0, nullptr, 2, n_tracks, e->spcursor, max_successful,
+                                       gate_status_dev);
+            if (rc != HV_OK) return rc;
+        }
+        return HV_OK;
+    }
     for (int k = 0; k < n_tracks; ++k) {
         const int rc = visual_track_dev_impl(h, p, np, idx + (size_t)k * B * np, feat + (size_t)k * B * nt * 2, vel + (size_t)k * B * nt * 2,
                                              y + (size_t)k * B * nt * 2, r_gate, r_update, status_dev + (size_t)k * B * 2,

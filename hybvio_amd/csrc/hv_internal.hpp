@@ -111,6 +111,11 @@ struct VuPrepareArgs {
     int *gate_status;                  // optional [batch]: preset to VuOutlierStatus::NOT_COMPUTED (1)
     const int *success_counter;        // optional [batch]: filters that already applied max_successful updates this frame are skipped
     int max_successful;
+    // speculative frame loop (ekf.hip, hv_ekf_visual_frame_dev): grid (batch, spec_tracks), every array a [track][filter] record.
+    // A record is prepared when its track is pending (>= cursor[filter]) and was last prepared at another update count (epoch).
+    int spec_tracks;
+    const int *cursor;                 // [batch]
+    int *epoch;                        // [spec_tracks][batch]
 };
 int launch_vu_prepare(Ctx *c, const VuPrepareArgs &a);
 // capi.hip

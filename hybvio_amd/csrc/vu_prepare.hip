@@ -246,21 +246,28 @@ __device__ __forceinline__ void vu_prepare_body(const VuPrepareArgs &a)
     double *pfi = s_small, *pfw = s_small + 3, *X = s_small + 6, *step = s_small + 15, *R0T = s_small + 18;
     double *scal = s_small + 36;                 // [0] error2, [1] rcond, [2] Jprev
     VU_STAMP(0);
-    if (a.success_counter && a.success_counter[b] >= a.max_successful) {
+    // rec: the (track, filter) record this workgroup reads its inputs from and writes its outputs to (the filter itself without speculation)
+    const size_t rec = a.spec_tracks > 0 ? (size_t)blockIdx.y * gridDim.x + b : (size_t)b;
+    const bool quota_used = a.success_counter && a.success_counter[b] >= a.max_successful;
+    if (a.spec_tracks > 0) {
+        if ((int)blockIdx.y < a.cursor[b]) return;                               // final already
+        if (!quota_used && a.epoch[rec] == a.success_counter[b]) return;          // prepared against the current mean
+    }
+    if (quota_used) {
         // backend.cpp:1233-1238: the frame's quota of successful visual updates is used up, the loop does not visit this track
         if (tid == 0) {
-            a.status[2 * (size_t)b] = HV_TRI_NOT_VISITED; a.status[2 * (size_t)b + 1] = HV_TRI_NOT_VISITED;
-            if (a.active) a.active[b] = 0;
-            if (a.gate_status) a.gate_status[b] = 1;
+            a.status[2 * rec] = HV_TRI_NOT_VISITED; a.status[2 * rec + 1] = HV_TRI_NOT_VISITED;
+            if (a.active) a.active[rec] = 0;
+            if (a.gate_status) a.gate_status[rec] = 1;
         }
         return;
     }
-    if (tid < n) s_idx[tid] = a.pose_index[(size_t)b * n + tid];
+    if (tid < n) s_idx[tid] = a.pose_index[rec * n + tid];
     if (tid < nt) {
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
-            s_feat[4 * tid + k] = a.features[((size_t)b * nt + tid) * 2 + k];
-            s_feat[4 * tid + 2 + k] = a.velocities[((size_t)b * nt + tid) * 2 + k];
+            s_feat[4 * tid + k] = a.features[(rec * nt + tid) * 2 + k];
+            s_feat[4 * tid + 2 + k] = a.velocities[(rec * nt + tid) * 2 + k];
         }
     }
     __syncthreads();
@@ -567,7 +574,7 @@ __device__ __forceinline__ void vu_prepare_body(const VuPrepareArgs &a)
     }
     VU_STAMP(27);
     // ---- status, back to world coordinates (:345-392) ----
-    int *st_out = a.status + 2 * (size_t)b;
+    int *st_out = a.status + 2 * rec;
     double *M = s_small + 40, *pf0 = s_small + 49;           // R0T * dpf0_dpfi, the point in the frame of pose 0
     if (tid == 0) {
         int status = HV_TRI_OK;
@@ -650,7 +657,7 @@ __device__ __forceinline__ void vu_prepare_body(const VuPrepareArgs &a)
     __syncthreads();
     VU_STAMP(29);
     const int rows = 2 * nt;
-    double *H = a.H + (size_t)b * rows * N;
+    double *H = a.H + rec * rows * N;
     // which pose of the track (if any) owns state column c, and which of its 7 components: once per column
     int *s_colmap = reinterpret_cast<int *>(s_p0);                          // s_p0 is free after the Gauss-Newton loop
     for (int c = tid; c < N; c += VT) {
@@ -694,7 +701,7 @@ __device__ __forceinline__ void vu_prepare_body(const VuPrepareArgs &a)
         const double *o = s_it + tid * ITER_WORDS;
 #pragma unroll
         for (int r = 0; r < 2; ++r) {
-            const size_t e = (size_t)b * rows + 2 * tid + r;
+            const size_t e = rec * rows + 2 * tid + r;
             if (a.f) a.f[e] = o[14 + r];
             a.v[e] = (a.y ? a.y[e] : 0.0) - o[14 + r];
         }
@@ -704,10 +711,11 @@ __device__ __forceinline__ void vu_prepare_body(const VuPrepareArgs &a)
         int prep = 0;
         for (int i = 0; i < nt && prep == 0; ++i) prep = (int)s_it[i * ITER_WORDS + 16];   // first failing pose decides (:920-927)
         st_out[0] = status; st_out[1] = prep;
-        if (a.active) a.active[b] = (status == HV_TRI_OK && prep == 0) ? 1 : 0;
-        if (a.gate_status) a.gate_status[b] = 1;                                       // VuOutlierStatus::NOT_COMPUTED
+        if (a.active) a.active[rec] = (status == HV_TRI_OK && prep == 0) ? 1 : 0;
+        if (a.gate_status) a.gate_status[rec] = 1;                                     // VuOutlierStatus::NOT_COMPUTED
+        if (a.spec_tracks > 0) a.epoch[rec] = a.success_counter[b];                    // (written last: every thread has read it by now)
 #pragma unroll
-        for (int k = 0; k < 3; ++k) a.pf[3 * (size_t)b + k] = pfw[k];
+        for (int k = 0; k < 3; ++k) a.pf[3 * rec + k] = pfw[k];
     }
 }
 
@@ -740,8 +748,9 @@ int launch_vu_prepare(Ctx *c, const VuPrepareArgs &a)
         HV_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void *>(vu_prepare_kernel_2percu), hipFuncAttributeMaxDynamicSharedMemorySize, (int)VuLds<MAXP_SMALL>::BYTES));
         attr_set = true;
     }
-    if (small) hipLaunchKernelGGL(vu_prepare_kernel_2percu, dim3((unsigned)a.batch), dim3(VT_THROUGHPUT), VuLds<MAXP_SMALL>::BYTES, c->stream, a);
-    else       hipLaunchKernelGGL(vu_prepare_kernel, dim3((unsigned)a.batch), dim3(VT_LATENCY), VuLds<MAXP_ALL>::BYTES, c->stream, a);
+    const dim3 grid((unsigned)a.batch, (unsigned)(a.spec_tracks > 0 ? a.spec_tracks : 1));
+    if (small) hipLaunchKernelGGL(vu_prepare_kernel_2percu, grid, dim3(VT_THROUGHPUT), VuLds<MAXP_SMALL>::BYTES, c->stream, a);
+    else       hipLaunchKernelGGL(vu_prepare_kernel, grid, dim3(VT_LATENCY), VuLds<MAXP_ALL>::BYTES, c->stream, a);
     HV_HIP(c, hipGetLastError());
     return HV_OK;
 }

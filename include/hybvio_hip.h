@@ -242,7 +242,11 @@ int hv_ekf_visual_track_limited_dev(hv_ekf *ekf, const hv_vu_params *p, int n_po
  * [n_tracks][batch][2 * ncam * n_poses]; outputs status_dev [n_tracks][batch][2], gate_status_dev [n_tracks][batch], chi2_dev
  * (may be NULL) [n_tracks][batch]. success_counter_dev [batch] is zeroed here and holds the applied updates on return.
  * Nothing crosses the host between the visits; the call is asynchronous and HIP-graph capturable once it has run once
- * (its work buffers are allocated on first use). */
+ * (its work buffers are allocated on first use). r_gate stays constant over the frame, i.e. the reference's default
+ * trackOutlierThresholdGrowthFactor = 1 (backend.cpp:1192); other factors need the per-visit entry points.
+ * With few sequences (batch * n_tracks <= 256, n_rows <= 48) the loop runs speculatively: each pass prepares and gates every
+ * pending track of a filter in parallel against the current (m, P), applies the first inlier in visit order and re-examines only
+ * the tracks behind it -- at most max_successful + 1 passes, the same statuses and the same filter as the sequential loop. */
 int hv_ekf_visual_frame_dev(hv_ekf *ekf, const hv_vu_params *p, int n_tracks, int n_poses, const int *pose_index_dev,
                             const double *features_dev, const double *velocities_dev, const double *y_dev, double r_gate,
                             double r_update, int *status_dev, int *gate_status_dev, double *chi2_dev, int *success_counter_dev,

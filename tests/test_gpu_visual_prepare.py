@@ -300,6 +300,69 @@ def test_frame_loop_with_the_successful_update_quota(oracle):
         g.close()
 
 
+@pytest.mark.parametrize("B,speculative", [(12, True), (40, False)])
+def test_whole_frame_loop_in_one_call(oracle, B, speculative):
+    """hv_ekf_visual_frame_dev = the frame's visit loop in ONE call. For few sequences (B * K <= 256) it runs speculatively: every
+    pending track prepared and gated in parallel, the first inlier applied, the rest re-examined (<= quota + 1 passes); for more it
+    is the sequential per-visit loop. Both must give the reference's sequential result: statuses per visit, the quota, the filter."""
+    import torch
+    rng = np.random.default_rng(31 + B)
+    trail_len, npose, K, quota = 20, 6, 9, 3
+    assert (B * K <= 256) == speculative
+    T1, T2, means, _, _, _ = _random_tracks(oracle, rng, B, trail_len, npose, True, bad_fraction=0.0)
+    tracks = [_random_tracks(oracle, rng, B, trail_len, npose, True, bad_fraction=0.3, given_means=means)[3:] for _ in range(K)]
+    ys = [t[1].reshape(B, -1) + 2e-3 * rng.normal(size=(B, t[1].shape[1] * 2)) for t in tracks]
+    for k in (0, 1, 4, 6):
+        ys[k][::2] += 3.0                                                                 # gate rejections, also on the first visits
+    vp = capi.vu_default_params(imu_to_camera=T1, second_imu_to_camera=T2)
+    par = oracle.tri_default_params()
+    r_gate, r_update = 1.5, 0.05
+    with capi.Context(width=64, height=64) as ctx:
+        g = capi.EkfBatch(ctx, capi.ekf_default_params(cameraTrailLength=trail_len), B)
+        filters = []
+        for b in range(B):
+            o = oracle.Ekf(oracle.ekf_default_params(cameraTrailLength=trail_len))
+            P = o.P.copy() * 1e-6 + np.eye(o.n) * 1e-4
+            o.set_state(means[b]); o.set_cov(P)
+            g.set_state(b, means[b], P)
+            filters.append(o)
+        dev = lambda a, dt: torch.from_numpy(np.array(a, dt, order="C")).cuda()
+        d = [dev(np.stack([t[0] for t in tracks]), np.int32), dev(np.stack([t[1] for t in tracks]), np.float64),
+             dev(np.stack([t[2] for t in tracks]), np.float64), dev(np.stack(ys), np.float64)]
+        st = torch.full((K, B, 2), -9, dtype=torch.int32, device="cuda"); gs = torch.full((K, B), -9, dtype=torch.int32, device="cuda")
+        counter = torch.full((B,), 77, dtype=torch.int32, device="cuda")                  # zeroed by the call
+        ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+        g.visual_frame_dev(vp, K, npose, d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(), d[3].data_ptr(), r_gate, r_update,
+                           st.data_ptr(), gs.data_ptr(), counter.data_ptr(), quota)
+        torch.cuda.synchronize()
+        st, gs, counts = st.cpu().numpy(), gs.cpu().numpy(), counter.cpu().numpy()
+        reached, rejected = 0, 0
+        for b, o in enumerate(filters):
+            done = 0
+            for k in range(K):
+                idx, feat, vel = tracks[k]
+                if done >= quota:
+                    assert st[k, b].tolist() == [-1, -1] and gs[k, b] == 1, (b, k)         # not visited any more
+                    continue
+                ost, ops, opf, oH, of = oracle.visual_track_prepare(par, o.m.copy(), idx[b], T1, T2, feat[b], vel[b])
+                assert st[k, b].tolist() == [ost, ops], (b, k)
+                if (ost, ops) != (0, 0):
+                    assert gs[k, b] == 1
+                    continue
+                status, _ = o.visual_track_outlier_check(oH, of, ys[k][b], r_gate)
+                assert gs[k, b] == status, (b, k)
+                if status == 0:
+                    o.update_visual_track(oH, of, ys[k][b], r_update); done += 1
+                else:
+                    rejected += 1
+            assert counts[b] == done
+            reached += done >= quota
+            mg, Pg = g.get_state(b)
+            assert _rel(mg, o.m) < 1e-8 and _rel(Pg, o.P) < 1e-7, (b, _rel(mg, o.m), _rel(Pg, o.P))
+        assert 0 < reached <= B and rejected > 0
+        g.close()
+
+
 def test_long_trail_track_is_rejected_not_corrupted():
     """cameraTrailLength > 20 is a valid filter size, but the prepare kernel's LDS arrays hold 21 poses per camera:
     a 22-pose mono track must come back as HV_ERR_UNSUPPORTED (r01 advisor: it used to overrun s_dpf / s_idx silently);
