@@ -113,7 +113,8 @@ PROTOTYPES = {
     "hv_ekf_visual_track_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int] + [C.c_void_p] * 4 + [C.c_double, C.c_double] + [C.c_void_p] * 4),
     "hv_ekf_visual_track_limited_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int] + [C.c_void_p] * 4 + [C.c_double, C.c_double] + [C.c_void_p] * 5 + [C.c_int]),
     "hv_ekf_visual_track": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int] + [C.c_void_p] * 4 + [C.c_double, C.c_double] + [C.c_void_p] * 4),
-    "hv_ekf_visual_frame_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int] + [C.c_void_p] * 4 + [C.c_double, C.c_double] + [C.c_void_p] * 4 + [C.c_int]),
+    "hv_ekf_visual_frame_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int] + [C.c_void_p] * 4 + [C.c_double, C.c_double] + [C.c_void_p] * 5 + [C.c_int]),
+    "hv_ekf_visual_frame": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int] + [C.c_void_p] * 4 + [C.c_double, C.c_double] + [C.c_void_p] * 5 + [C.c_int]),
     "hv_ekf_augment_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "hv_ekf_visual_dev": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_double, C.c_int,
                                     C.c_void_p, C.c_void_p]),
@@ -584,12 +585,25 @@ class EkfBatch:
         self._chk(lib().hv_ekf_augment_dev(self._h, C.c_void_p(discarded_dev), C.c_void_p(active_dev)), "hv_ekf_augment_dev")
 
     def visual_frame_dev(self, params: VuParams, n_tracks, n_poses, pose_index_dev, features_dev, velocities_dev, y_dev, r_gate, r_update,
-                         status_dev, gate_status_dev, success_counter_dev, max_successful, chi2_dev=0):
+                         status_dev, gate_status_dev, success_counter_dev, max_successful, chi2_dev=0, pf_dev=0):
         """hv_ekf_visual_frame_dev: the whole visual-update loop of a frame, track-major device arrays."""
         a = [C.c_void_p(x) for x in (pose_index_dev, features_dev, velocities_dev, y_dev)]
-        b = [C.c_void_p(x) for x in (status_dev, gate_status_dev, chi2_dev, success_counter_dev)]
+        b = [C.c_void_p(x) for x in (status_dev, gate_status_dev, chi2_dev, pf_dev, success_counter_dev)]
         self._chk(lib().hv_ekf_visual_frame_dev(self._h, C.byref(params), int(n_tracks), int(n_poses), *a, float(r_gate), float(r_update), *b,
                                                 int(max_successful)), "hv_ekf_visual_frame_dev")
+
+    def visual_frame(self, params: VuParams, pose_index, features, velocities, y, r_gate, r_update, max_successful):
+        """hv_ekf_visual_frame with numpy arrays [n_tracks][batch][...]: returns (status [K][B][2], gate_status [K][B], chi2, pf, applied [B])."""
+        idx = np.ascontiguousarray(pose_index, np.int32)
+        K = idx.shape[0]
+        idx = idx.reshape(K, self.batch, -1)
+        ft, vl, yy = _f(features), _f(velocities), _f(y)
+        st, gs = np.zeros((K, self.batch, 2), np.int32), np.zeros((K, self.batch), np.int32)
+        chi, pf, cnt = np.zeros((K, self.batch)), np.zeros((K, self.batch, 3)), np.zeros(self.batch, np.int32)
+        vp = lambda a: a.ctypes.data_as(C.c_void_p)
+        self._chk(lib().hv_ekf_visual_frame(self._h, C.byref(params), K, idx.shape[2], vp(idx), vp(ft), vp(vl), vp(yy), float(r_gate),
+                                            float(r_update), vp(st), vp(gs), vp(chi), vp(pf), vp(cnt), int(max_successful)), "hv_ekf_visual_frame")
+        return st, gs, chi, pf, cnt
 
     def undo_augment(self, active=None):
         act = np.ascontiguousarray(active, np.uint8) if active is not None else None

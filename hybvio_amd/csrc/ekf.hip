@@ -1450,7 +1450,7 @@ static int visual_track_dev_impl(hv_ekf *h, const hv_vu_params *p, int np, const
 
 int hv_ekf_visual_frame_dev(hv_ekf *h, const hv_vu_params *p, int n_tracks, int np, const int *idx, const double *feat, const double *vel,
                             const double *y, double r_gate, double r_update, int *status_dev, int *gate_status_dev, double *chi2_dev,
-                            int *success_counter_dev, int max_successful)
+                            double *pf_dev, int *success_counter_dev, int max_successful)
 {
     if (!h || n_tracks < 0 || !success_counter_dev || max_successful < 1) return HV_ERR_INVALID;
     Ekf *e = &h->e; Ctx *c = e->c;
@@ -1483,7 +1483,7 @@ int hv_ekf_visual_frame_dev(hv_ekf *h, const hv_vu_params *p, int n_tracks, int 
         hv::VuPrepareArgs a;
         int rc = vu_fill_args(e, p, np, idx, feat, vel, y, a);
         if (rc != HV_OK) return rc;
-        a.H = e->spH; a.v = e->spv; a.f = nullptr; a.pf = e->sppf; a.status = status_dev; a.active = e->spactive;
+        a.H = e->spH; a.v = e->spv; a.f = nullptr; a.pf = pf_dev ? pf_dev : e->sppf; a.status = status_dev; a.active = e->spactive;
         a.gate_status = gate_status_dev; a.success_counter = success_counter_dev; a.max_successful = max_successful;
         a.spec_tracks = n_tracks; a.cursor = e->spcursor; a.epoch = e->spepoch;
         for (int pass = 0; pass <= max_successful; ++pass) {
@@ -1502,8 +1502,8 @@ int hv_ekf_visual_frame_dev(hv_ekf *h, const hv_vu_params *p, int n_tracks, int 
     for (int k = 0; k < n_tracks; ++k) {
         const int rc = visual_track_dev_impl(h, p, np, idx + (size_t)k * B * np, feat + (size_t)k * B * nt * 2, vel + (size_t)k * B * nt * 2,
                                              y + (size_t)k * B * nt * 2, r_gate, r_update, status_dev + (size_t)k * B * 2,
-                                             gate_status_dev + (size_t)k * B, chi2_dev ? chi2_dev + (size_t)k * B : nullptr, nullptr,
-                                             success_counter_dev, max_successful);
+                                             gate_status_dev + (size_t)k * B, chi2_dev ? chi2_dev + (size_t)k * B : nullptr,
+                                             pf_dev ? pf_dev + (size_t)k * B * 3 : nullptr, success_counter_dev, max_successful);
         if (rc != HV_OK) return rc;
     }
     return HV_OK;
@@ -1542,6 +1542,44 @@ int hv_ekf_visual_track(hv_ekf *h, const hv_vu_params *p, int np, const int *idx
     HV_HIP(c, hipMemcpyAsync(gate_status, d + o_gs, B * sizeof(int), hipMemcpyDeviceToHost, c->stream));
     if (chi2) HV_HIP(c, hipMemcpyAsync(chi2, d + o_chi, B * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     if (pf) HV_HIP(c, hipMemcpyAsync(pf, d + o_pf, B * 3 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HV_HIP(c, hipStreamSynchronize(c->stream));
+    return HV_OK;
+}
+
+int hv_ekf_visual_frame(hv_ekf *h, const hv_vu_params *p, int n_tracks, int np, const int *idx, const double *feat, const double *vel,
+                        const double *y, double r_gate, double r_update, int *status, int *gate_status, double *chi2, double *pf,
+                        int *success_count, int max_successful)
+{
+    if (!h || !p || !idx || !feat || !vel || !y || !status || !gate_status || np < 2 || n_tracks < 1 || max_successful < 1) return HV_ERR_INVALID;
+    Ekf *e = &h->e; Ctx *c = e->c;
+    const size_t B = (size_t)e->batch * n_tracks, nt = (size_t)np * (p->useStereo ? 2 : 1);
+    auto up = [](size_t v) { return (v + 15) & ~(size_t)15; };
+    const size_t o_idx = 0, o_feat = up(o_idx + B * np * sizeof(int)), o_vel = up(o_feat + B * nt * 2 * sizeof(double));
+    const size_t o_y = up(o_vel + B * nt * 2 * sizeof(double)), o_st = up(o_y + B * nt * 2 * sizeof(double));
+    const size_t o_gs = up(o_st + B * 2 * sizeof(int)), o_chi = up(o_gs + B * sizeof(int)), o_pf = up(o_chi + B * sizeof(double));
+    const size_t o_cnt = up(o_pf + B * 3 * sizeof(double)), total = up(o_cnt + (size_t)e->batch * sizeof(int));
+    if (e->vustage_bytes < total) {
+        HV_HIP(c, hipStreamSynchronize(c->stream));
+        if (e->vustage) (void)hipFree(e->vustage);
+        e->vustage = nullptr; e->vustage_bytes = 0;
+        HV_HIP(c, hipMalloc(reinterpret_cast<void **>(&e->vustage), total));
+        e->vustage_bytes = total;
+    }
+    unsigned char *d = e->vustage;
+    HV_HIP(c, hipMemcpyAsync(d + o_idx, idx, B * np * sizeof(int), hipMemcpyHostToDevice, c->stream));
+    HV_HIP(c, hipMemcpyAsync(d + o_feat, feat, B * nt * 2 * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    HV_HIP(c, hipMemcpyAsync(d + o_vel, vel, B * nt * 2 * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    HV_HIP(c, hipMemcpyAsync(d + o_y, y, B * nt * 2 * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    const int rc = hv_ekf_visual_frame_dev(h, p, n_tracks, np, reinterpret_cast<const int *>(d + o_idx), reinterpret_cast<const double *>(d + o_feat),
+                                           reinterpret_cast<const double *>(d + o_vel), reinterpret_cast<const double *>(d + o_y), r_gate, r_update,
+                                           reinterpret_cast<int *>(d + o_st), reinterpret_cast<int *>(d + o_gs), reinterpret_cast<double *>(d + o_chi),
+                                           reinterpret_cast<double *>(d + o_pf), reinterpret_cast<int *>(d + o_cnt), max_successful);
+    if (rc != HV_OK) return rc;
+    HV_HIP(c, hipMemcpyAsync(status, d + o_st, B * 2 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HV_HIP(c, hipMemcpyAsync(gate_status, d + o_gs, B * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    if (chi2) HV_HIP(c, hipMemcpyAsync(chi2, d + o_chi, B * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    if (pf) HV_HIP(c, hipMemcpyAsync(pf, d + o_pf, B * 3 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    if (success_count) HV_HIP(c, hipMemcpyAsync(success_count, d + o_cnt, (size_t)e->batch * sizeof(int), hipMemcpyDeviceToHost, c->stream));
     HV_HIP(c, hipStreamSynchronize(c->stream));
     return HV_OK;
 }

@@ -284,6 +284,35 @@ struct HipEKF : public EKF {
         return res;
     }
 
+    std::vector<VisualTrackResult> visualFrame(const hv_vu_params &parameters, const std::vector<VisualFrameTrack> &tracks,
+                                               double chiOutlierR, double visualR, int maxSuccessfulVisualUpdates,
+                                               int *updateSuccessCount) final {
+        std::vector<VisualTrackResult> out(tracks.size());
+        if (tracks.empty()) return out;
+        const size_t K = tracks.size(), n = tracks[0].poseTrailIndex.size(), nt = n * (parameters.useStereo ? 2 : 1);
+        std::vector<int> idx(K * n), status(2 * K), gate(K);
+        std::vector<double> feat(K * 2 * nt), vel(K * 2 * nt), y(K * 2 * nt), pf(3 * K);
+        for (size_t k = 0; k < K; ++k) {
+            const VisualFrameTrack &t = tracks[k];
+            assert(t.poseTrailIndex.size() == n && t.imageFeatures.size() == 2 * nt && t.featureVelocities.size() == 2 * nt && t.y.size() == 2 * nt);
+            std::copy(t.poseTrailIndex.begin(), t.poseTrailIndex.end(), idx.begin() + k * n);
+            std::copy(t.imageFeatures.begin(), t.imageFeatures.end(), feat.begin() + k * 2 * nt);
+            std::copy(t.featureVelocities.begin(), t.featureVelocities.end(), vel.begin() + k * 2 * nt);
+            std::copy(t.y.begin(), t.y.end(), y.begin() + k * 2 * nt);
+        }
+        int applied = 0;
+        check(hv_ekf_visual_frame(dev(), &parameters, (int)K, (int)n, idx.data(), feat.data(), vel.data(), y.data(), chiOutlierR, visualR,
+                                  status.data(), gate.data(), nullptr, pf.data(), &applied, maxSuccessfulVisualUpdates));
+        for (size_t k = 0; k < K; ++k) {
+            out[k].triangulateStatus = status[2 * k]; out[k].prepareVuStatus = status[2 * k + 1];
+            out[k].outlierStatus = gate[k] == 0 ? VuOutlierStatus::INLIER : gate[k] == 3 ? VuOutlierStatus::CHI2 : VuOutlierStatus::NOT_COMPUTED;
+            for (int q = 0; q < 3; ++q) out[k].pf[q] = pf[3 * k + q];
+        }
+        if (updateSuccessCount) *updateSuccessCount = applied;
+        if (applied > 0) dirty();
+        return out;
+    }
+
     void updateVisualPoseAugmentation(int discardedPoseIndex) final {
         check(hv_ekf_augment(dev(), &discardedPoseIndex, nullptr));
         dirty();

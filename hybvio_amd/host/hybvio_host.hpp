@@ -287,6 +287,20 @@ public:
     virtual VisualTrackResult visualTrack(const hv_vu_params &parameters, const std::vector<int> &poseTrailIndex,
                                           const std::vector<double> &imageFeatures, const std::vector<double> &featureVelocities,
                                           const VectorXd &y, double chiOutlierR, double visualR) = 0;
+    // The whole loop `for (trackIndex : tmp.trackOrder)` of Session::trackerVisualUpdate (backend.cpp:1012-1252) for pose-trail tracks
+    // of ONE length in ONE device call (hv_ekf_visual_frame: a single round trip instead of one per track; with one session the
+    // device runs it speculatively, see include/hybvio_hip.h). tracks[k] are in the backend's visit order; the loop stops applying
+    // updates after maxSuccessfulVisualUpdates (results of unvisited tracks: triangulateStatus = -1). The backend replays its
+    // per-track side effects (blacklist, statistics, point cloud) from the returned statuses. Requires the default
+    // trackOutlierThresholdGrowthFactor = 1.
+    struct VisualFrameTrack {
+        std::vector<int> poseTrailIndex;
+        std::vector<double> imageFeatures, featureVelocities;
+        VectorXd y;
+    };
+    virtual std::vector<VisualTrackResult> visualFrame(const hv_vu_params &parameters, const std::vector<VisualFrameTrack> &tracks,
+                                                       double chiOutlierR, double visualR, int maxSuccessfulVisualUpdates,
+                                                       int *updateSuccessCount = nullptr) = 0;
 };
 
 }  // namespace odometry

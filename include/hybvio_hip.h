@@ -240,7 +240,8 @@ int hv_ekf_visual_track_limited_dev(hv_ekf *ekf, const hv_vu_params *p, int n_po
  * left, a filter leaving the loop after max_successful applied updates. Arrays are TRACK-major so that a visit is one contiguous
  * batch: pose_index_dev [n_tracks][batch][n_poses], features_dev / velocities_dev [n_tracks][batch][ncam * n_poses][2], y_dev
  * [n_tracks][batch][2 * ncam * n_poses]; outputs status_dev [n_tracks][batch][2], gate_status_dev [n_tracks][batch], chi2_dev
- * (may be NULL) [n_tracks][batch]. success_counter_dev [batch] is zeroed here and holds the applied updates on return.
+ * (may be NULL) [n_tracks][batch], pf_dev (may be NULL) the triangulated world points. success_counter_dev [batch] is zeroed here and
+ * holds the applied updates on return.
  * Nothing crosses the host between the visits; the call is asynchronous and HIP-graph capturable once it has run once
  * (its work buffers are allocated on first use). r_gate stays constant over the frame, i.e. the reference's default
  * trackOutlierThresholdGrowthFactor = 1 (backend.cpp:1192); other factors need the per-visit entry points.
@@ -249,8 +250,13 @@ int hv_ekf_visual_track_limited_dev(hv_ekf *ekf, const hv_vu_params *p, int n_po
  * the tracks behind it -- at most max_successful + 1 passes, the same statuses and the same filter as the sequential loop. */
 int hv_ekf_visual_frame_dev(hv_ekf *ekf, const hv_vu_params *p, int n_tracks, int n_poses, const int *pose_index_dev,
                             const double *features_dev, const double *velocities_dev, const double *y_dev, double r_gate,
-                            double r_update, int *status_dev, int *gate_status_dev, double *chi2_dev, int *success_counter_dev,
-                            int max_successful);
+                            double r_update, int *status_dev, int *gate_status_dev, double *chi2_dev, double *pf_dev /* [n_tracks][batch][3] or NULL */,
+                            int *success_counter_dev, int max_successful);
+/* Host-pointer form (arrays track-major as above): what a single session calls once per frame instead of n_tracks round trips
+ * through hv_ekf_visual_track. chi2, pf and success_count may be NULL. Synchronous. */
+int hv_ekf_visual_frame(hv_ekf *ekf, const hv_vu_params *p, int n_tracks, int n_poses, const int *pose_index, const double *features,
+                        const double *velocities, const double *y, double r_gate, double r_update, int *status, int *gate_status,
+                        double *chi2, double *pf, int *success_count, int max_successful);
 /* Host-pointer form of hv_ekf_visual_track_dev (arrays [batch][...] as above): about 1 KB per track goes to the device
  * and 40 bytes come back, instead of the mean coming back and a (2 * ncam * n_poses) x stateDim Jacobian going up.
  * chi2 / pf may be NULL. Synchronous. */

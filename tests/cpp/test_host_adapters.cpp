@@ -303,6 +303,51 @@ static void test_visual_track(Session &s, const std::string &dir)
     REQUIRE(diff == 0.0);
 }
 
+// EKF::visualFrame = the frame's whole visit loop in one call (backend.cpp:1012-1252): must equal the same tracks sent one by one
+// through EKF::visualTrack on a clone (statuses, points, the quota, the filter), including a nonsense track
+static void test_visual_frame(Session &s, const std::string &dir)
+{
+    hv_ekf_params par; hv_ekf_default_params(&par);
+    par.cameraTrailLength = 20; par.noiseScale = 1000.0;
+    auto a = odometry::EKF::buildHip(s, par);
+    const std::vector<double> poses = load(dir + "/visual_poses.txt"), uv = load(dir + "/visual_uv.txt");
+    VectorXd m = a->getState();
+    for (int k = 0; k < 3; k++) m[odometry::POS + k] = poses[k];
+    for (int k = 0; k < 4; k++) m[odometry::ORI + k] = poses[3 + k];
+    for (int i = 0; i < 9; i++) for (int k = 0; k < 7; k++) m[odometry::CAM + 7 * i + k] = poses[7 * (i + 1) + k];
+    a->setState(m);
+    auto b = a->clone();
+    hv_vu_params vp; hv_vu_default_params(&vp);
+    std::vector<odometry::EKF::VisualFrameTrack> tracks(5);
+    for (size_t k = 0; k < tracks.size(); k++) {
+        auto &t = tracks[k];
+        t.poseTrailIndex.resize(10);
+        for (int i = 0; i < 10; i++) t.poseTrailIndex[i] = i;
+        t.imageFeatures = uv; t.featureVelocities.assign(20, 0.1);
+        t.y = VectorXd(uv.begin(), uv.end());
+        if (k == 1) for (auto &x : t.imageFeatures) x = -x;              // nothing explains it: never reaches the gate
+        if (k >= 3) for (size_t i = 0; i < t.y.size(); i++) t.y[i] += 1e-4 * ((i + k) % 3);
+    }
+    int applied = -1;
+    const auto res = a->visualFrame(vp, tracks, 1.5, 0.05, 2, &applied);
+    int done = 0;
+    for (size_t k = 0; k < tracks.size(); k++) {
+        if (done >= 2) { REQUIRE(res[k].triangulateStatus == HV_TRI_NOT_VISITED); continue; }
+        const auto one = b->visualTrack(vp, tracks[k].poseTrailIndex, tracks[k].imageFeatures, tracks[k].featureVelocities, tracks[k].y, 1.5, 0.05);
+        REQUIRE(res[k].triangulateStatus == one.triangulateStatus && res[k].prepareVuStatus == one.prepareVuStatus);
+        REQUIRE(res[k].outlierStatus == one.outlierStatus);
+        if (one.triangulateStatus == HV_TRI_OK)
+            REQUIRE(std::fabs(res[k].pf[0] - one.pf[0]) + std::fabs(res[k].pf[1] - one.pf[1]) + std::fabs(res[k].pf[2] - one.pf[2]) < 1e-9);
+        done += one.outlierStatus == odometry::VuOutlierStatus::INLIER;
+    }
+    REQUIRE(applied == done && done == 2);
+    REQUIRE(res[1].outlierStatus == odometry::VuOutlierStatus::NOT_COMPUTED);      // (gate rejections: tests/test_gpu_visual_prepare.py)
+    const VectorXd &ma = a->getState(), &mb = b->getState();
+    double diff = 0, norm = 0;
+    for (size_t i = 0; i < ma.size(); i++) { diff += std::fabs(ma[i] - mb[i]); norm += std::fabs(mb[i]); }
+    REQUIRE(diff <= 1e-9 * norm);
+}
+
 // RotRansac::fit as doRansac2 calls it (ransac_pipeline.cpp:197-216): two consecutive frames share ONE std::mt19937, so
 // the second call only agrees with the oracle if the first consumed exactly what the reference loop would have
 static void test_rot_ransac(Session &s, const std::string &dir)
@@ -347,6 +392,7 @@ int main(int argc, char **argv)
     test_tracker(session, dir);
     test_ingest(session, dir);
     test_visual_track(session, dir);
+    test_visual_frame(session, dir);
     test_rot_ransac(session, dir);
     std::printf("%s (%d failure%s)\n", failures ? "FAILED" : "all host adapter tests passed", failures, failures == 1 ? "" : "s");
     return failures ? 1 : 0;
