@@ -759,12 +759,15 @@ __global__ __launch_bounds__(UPD_THREADS) void ekf_update_kernel(UpdateArgs a)
         if (t == 0) {
             double tot = 0; for (int w2 = 0; w2 < nwaves; w2++) tot += red[w2];
             tot *= a.noise_scale;
-            const int outlier = (nr < HV_CHI2INV95_N) ? (tot > d_chi2inv95[nr]) : 0;
+            // A non-positive pivot (S not positive definite: r = 0 with a rank-deficient H) leaves NaN / inf in z: such a filter is
+            // reported as CHI2 and left untouched in EVERY mode, where the reference's pivoted LDLT would carry on (r01 advisor)
+            const bool broken = !(tot < 1e300);
+            const int outlier = broken || ((nr < HV_CHI2INV95_N) ? (tot > d_chi2inv95[nr]) : 0);
             if (pass == 0) {
                 if (a.chi2) a.chi2[e] = tot;
                 if (a.status) a.status[e] = outlier ? 3 /*CHI2*/ : 0 /*INLIER*/;
             }
-            *s_stop = (a.mode == 0) || ((a.mode == 2 || (two_r && pass == 0)) && outlier);
+            *s_stop = (a.mode == 0) || broken || ((a.mode == 2 || (two_r && pass == 0)) && outlier);
         }
         __syncthreads();
         if (*s_stop) return;

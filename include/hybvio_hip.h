@@ -177,7 +177,8 @@ int hv_ekf_update(hv_ekf *ekf, int n_rows, int l, const double *H, const double 
  * n_rows must be < 201 (the size of the reference's chi2inv95 table, odometry/util.hpp:23; the reference asserts it):
  * HV_ERR_INVALID otherwise. Only the reference's defaults of the two optional branches are implemented: r > 0 (the
  * r < 0 "visualR-scaled" branch is not) and trackRmseThreshold = -1 (no RMSE test). S must be positive definite
- * (r > 0 guarantees it); the blocked Cholesky has no pivot guard where the reference's LDLT tolerates a singular S. */
+ * (r > 0 guarantees it): where a pivot of the blocked Cholesky is not positive (the reference's pivoted LDLT would carry on) the
+ * filter is reported as CHI2 and left untouched, by the gate and by every update entry point. */
 int hv_ekf_visual_gate(hv_ekf *ekf, int n_rows, int l, const double *H, const double *v, double r,
                        double *chi2, int *status);
 /* updateVisualTrack (ekf.cpp:829-844) given v = y - f; R = r^2 * noiseScale * I. */

@@ -430,3 +430,23 @@ def test_hybrid_map_state_n_above_160(oracle, ctx):
         for b, o in enumerate(os_):
             o.update_visual_track(H[b], f[b], y[b], 0.05)
         assert check(os_, g) < 1e-9
+
+
+def test_singular_innovation_covariance_leaves_the_filter_untouched(oracle, ctx):
+    """r = 0 with a rank-deficient H makes S = H P H' singular: the blocked Cholesky meets a non-positive pivot. The filter must
+    come back unchanged and flagged (status CHI2) from the gate AND from a plain update, never with NaNs in m / P (r01 advisor)."""
+    rng = np.random.default_rng(8)
+    os_, g = make_pair(oracle, ctx, rng, batch=2)
+    nr, l = 12, 76
+    H = rng.normal(size=(2, nr, l))
+    H[0, 6:] = H[0, :6]                                     # filter 0: duplicated rows -> S exactly singular at r = 0
+    v = 0.01 * rng.normal(size=(2, nr))
+    before = [[x.copy() for x in g.get_state(b)] for b in range(2)]
+    chi2, st = g.visual_gate(H, v, 0.0)
+    assert st[0] == 3                                       # broken pivot reported as an outlier
+    g.visual_update(H, v, 0.0)
+    m0, P0 = g.get_state(0)
+    assert np.isfinite(m0).all() and np.isfinite(P0).all()
+    assert rel(m0, before[0][0]) == 0.0 and rel(P0, before[0][1]) == 0.0
+    m1, P1 = g.get_state(1)                                 # filter 1 (full rank, r = 0 still positive definite) was updated
+    assert np.isfinite(P1).all() and rel(m1, before[1][0]) > 0.0
