@@ -41,16 +41,23 @@ def level_sizes(w, h, levels=LEVELS, win=31):
     return out
 
 
+L0_GRADIENTS_STORED = os.environ.get("HV_L0_GRADIENTS", "0") not in ("", "0")
+
+
 def algorithmic_bytes(w=None, h=None, npts=None):
     """per image / per LK call / per stereo frame, plus the per-kernel split."""
     w, h, npts = w or W, h or H, npts or NPTS
     ls = level_sizes(w, h)
     px = [a * b for a, b in ls]
     pyr_image = px[0] + sum(px[1:]) + 4 * sum(px)                 # read L0 + write gray L1.. + write grads
-    pyr_l0 = px[0] + 4 * px[0] + (px[1] if len(px) > 1 else 0)    # the level-0 launch's share
+    pyr_l0_ref = px[0] + 4 * px[0] + (px[1] if len(px) > 1 else 0)    # the level-0 share of the agreed figure
+    # the level-0 launch's OWN bytes: the level-0 gradient plane is not stored unless HV_L0_GRADIENTS=1 (the LK kernel forms those
+    # gradients from the gray rows of its template window), so the launch reads L0 and writes the L1 gray level only. The STAGE
+    # figure (pyr_image, stereo_frame) stays the agreed one of SURVEY 8(d): bytes the algorithm as specified moves.
+    pyr_l0 = pyr_l0_ref if L0_GRADIENTS_STORED else px[0] + (px[1] if len(px) > 1 else 0)
     klt_point_level = 32 * 32 * 1 + 32 * 32 * 4 + 32 * 32 * 1     # I + dI + J windows, first touch
     klt_call = npts * len(ls) * klt_point_level
-    return dict(pyr_image=pyr_image, pyr_l0=pyr_l0, pyr_ln=pyr_image - pyr_l0, klt_call=klt_call,
+    return dict(pyr_image=pyr_image, pyr_l0=pyr_l0, pyr_ln=pyr_image - pyr_l0_ref, klt_call=klt_call,
                 stereo_frame=2 * pyr_image + 2 * klt_call)
 
 

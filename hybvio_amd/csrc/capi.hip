@@ -68,6 +68,9 @@ int compute_layout(const hv_params &p, PyrLayout &L)
     int pad_from = 2;
     if (const char *e = getenv("HV_PAD_FROM_LEVEL")) pad_from = atoi(e);
     if (pad_from < 1) pad_from = 1;                     // level 0 may be the caller's image: never padded
+    // HV_L0_GRADIENTS (environment, experiments only): 1 keeps the level-0 gradient plane in memory (the r01 / early r02 design)
+    L.l0_grad = 0;
+    if (const char *e = getenv("HV_L0_GRADIENTS")) L.l0_grad = atoi(e) != 0;
     long long off = 0;
     for (int l = 0; l < n; ++l) {
         const int pd = L.pad[l] = l >= pad_from ? PYR_PAD : 0;
@@ -78,6 +81,7 @@ int compute_layout(const hv_params &p, PyrLayout &L)
     for (int l = 0; l < n; ++l) {
         const int pd = L.pad[l];
         L.dstride[l] = align_up(L.w[l] + 2 * pd, 4);
+        if (l == 0 && !L.l0_grad) { L.doff[0] = -1; continue; }      // formed inside the LK kernel, never stored
         L.doff[l] = off + ((long long)pd * L.dstride[l] + pd) * 4;
         off = align_up_ll(off + (long long)L.dstride[l] * 4 * (L.h[l] + 2 * pd), 256);
     }
@@ -358,9 +362,14 @@ int hv_pyramid_download(hv_ctx *h, int slot, int level, uint8_t *gray, int16_t *
         }
         HV_HIP(c, hipMemcpy2D(gray, L.w[level], src, stride, L.w[level], L.h[level], hipMemcpyDeviceToHost));
     }
-    if (grad) {
+    if (grad && level == 0 && !L.l0_grad) {
+        const int rc = hv::download_l0_gradient(c, slot, grad);
+        if (rc != HV_OK) return rc;
+    } else if (grad) {
         HV_HIP(c, hipMemcpy2D(grad, (size_t)L.w[level] * 4, base + L.doff[level], (size_t)L.dstride[level] * 4,
                               (size_t)L.w[level] * 4, L.h[level], hipMemcpyDeviceToHost));
+    }
+    if (grad) {
         const size_t n = (size_t)L.w[level] * L.h[level] * 2;      // device stores 4*d (exact): undo
         for (size_t i = 0; i < n; ++i) grad[i] = (int16_t)(grad[i] >> hv::GRAD_SHIFT);
     }

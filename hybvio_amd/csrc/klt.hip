@@ -92,6 +92,34 @@ __device__ __forceinline__ uint32_t scaled_pair(uint32_t lo, uint32_t hi)
     return __builtin_amdgcn_perm(hi, lo, sel) * (1u << GRAY_SHIFT) + ROUND_PAIR;   // no carry between halves
 }
 
+// Level-0 gradients formed in the kernel (PyrLayout::l0_grad == 0). q is the dword of gray bytes I(x-1 .. x+2) of one source
+// row: the Scharr stencils of pixels x and x+1 (cv::calcSharrDeriv: smooth [3 10 3] across, difference [-1 0 1] along) are
+// separable, so a row contributes its horizontal difference d = I(x+1) - I(x-1) and smoothed value s4 = 4 (3 I(x-1) + 10 I(x)
+// + 3 I(x+1)) as packed 16-bit pairs for the two columns, and a gradient row is a vertical combination of three of those:
+//   4 dx + 2 = 12 (d[r-1] + d[r+1]) + 40 d[r] + 2        4 dy + 2 = s4[r+1] - s4[r-1] + 2
+// -- the pre-scaled form the pyramid stores (pyramid.hip). Every intermediate fits 16 bits (|.| <= 16322): v_pk_* arithmetic.
+typedef unsigned short us2v __attribute__((ext_vector_type(2)));
+struct ScharrRow { us2v d, s4; uint32_t g; };
+__device__ __forceinline__ ScharrRow scharr_row(uint32_t q)
+{
+    const us2v l = __builtin_bit_cast(us2v, __builtin_amdgcn_perm(0u, q, 0x0C010C00u));    // (I(x-1), I(x))
+    const us2v c = __builtin_bit_cast(us2v, __builtin_amdgcn_perm(0u, q, 0x0C020C01u));    // (I(x),   I(x+1))
+    const us2v r = __builtin_bit_cast(us2v, __builtin_amdgcn_perm(0u, q, 0x0C030C02u));    // (I(x+1), I(x+2))
+    ScharrRow o;
+    o.d = r - l;
+    o.s4 = (l + r) * us2v{12, 12} + c * us2v{40, 40};
+    o.g = __builtin_bit_cast(uint32_t, c) * (1u << GRAY_SHIFT) + ROUND_PAIR;                // the pre-scaled gray pair of the row
+    return o;
+}
+__device__ __forceinline__ uint32_t scharr_dx(const ScharrRow &a, const ScharrRow &b, const ScharrRow &c)
+{
+    return __builtin_bit_cast(uint32_t, (a.d + c.d) * us2v{12, 12} + (b.d * us2v{40, 40} + us2v{2, 2}));
+}
+__device__ __forceinline__ uint32_t scharr_dy(const ScharrRow &a, const ScharrRow &c)
+{
+    return __builtin_bit_cast(uint32_t, (c.s4 - a.s4) + us2v{2, 2});
+}
+
 // Wavefront sum of a small integer (|sum| < 2^31) entirely in DPP: 4 in-row steps, then
 // row_bcast:15 / row_bcast:31 carry the row totals forward; lane 63 holds the result.
 __device__ __forceinline__ int wave_sum_small(int v)
@@ -209,6 +237,8 @@ __global__ __launch_bounds__(64, WPS) void klt_kernel(KltArgs a)
         // levels with a physical 32-px border (REFLECT_101 gray, zero gradients in memory, see PyrLayout): every window the
         // range test above lets through lies inside the padded rectangle, so the border-free paths serve all of them
         const bool padded = L.pad[level] != 0;                                             // wave-uniform
+        // level 0 without a stored gradient plane: the template's gradients come from the gray rows (scharr_row above)
+        const bool fly = level == 0 && !L.l0_grad;                                         // wave-uniform
 
         // ---- J tile bookkeeping (declared before the template: on the common path the first tile of the level is requested
         // together with the template rows, one memory round trip per level instead of three) ----
@@ -258,7 +288,12 @@ __global__ __launch_bounds__(64, WPS) void klt_kernel(KltArgs a)
             bilinear_weights(px - (float)ipx, py - (float)ipy, wA, wB);
             if (!col_ok) { wA = 0; wB = 0; }          // zero weights => every sample of this lane is 0
             const int xa = ipx + cx;
-            const bool inside = padded || (ipx >= 0 && ipx + 32 <= w && ipy >= 0 && ipy + 32 <= h);   // wave-uniform
+            // border-free paths: every byte the lanes load exists. The loads span columns ipx .. ipx + 32 and rows ipy .. ipy + 32
+            // (one more on each side when the gradients are formed here). Level 0 may be the caller's buffer -- nothing is
+            // read past its last row or column; levels >= 1 live in the slab, where the one row / column beyond the image that
+            // the zero-weight lanes touch is slab memory.
+            const int in_lo = fly ? 1 : 0, in_hi = level == 0 ? (fly ? 34 : 33) : 32;
+            const bool inside = padded || (ipx >= in_lo && ipx + in_hi <= w && ipy >= in_lo && ipy + in_hi <= h);   // wave-uniform
             // per-lane part of every address; the per-row part is a scalar base (no VALU per load)
             // (on a padded level ipx / ipy may be negative: the signed part of every address is the scalar row base, the lane part
             // -- an unsigned VGPR offset of the saddr addressing mode -- stays >= 0)
@@ -300,7 +335,28 @@ __global__ __launch_bounds__(64, WPS) void klt_kernel(KltArgs a)
                     if (early) { tox = ox; toy = oy; }
                 }
             }
-            if (early) {
+            if (early && fly) {
+                constexpr int NQ = HALF_ROWS + 3;        // source rows -1 .. 17 of this half
+                uint2 raw[NIT];
+                uint32_t q[NQ];
+                tile_request(raw);
+#pragma unroll
+                for (int r = 0; r < NQ; ++r) {
+                    const gptr_u8 grow = Ig + (long long)((ipy - 1 + r) * Igs + ipx - 1);         // scalar, signed
+                    __builtin_memcpy(&q[r], (const void *)(uintptr_t)(grow + vg), 4);
+                }
+                __builtin_amdgcn_sched_barrier(0);       // everything in flight before the first use
+                tile_commit(raw);
+                ScharrRow ra = scharr_row(q[0]), rb = scharr_row(q[1]), rc = scharr_row(q[2]);
+                uint32_t g0 = rb.g, dx0 = scharr_dx(ra, rb, rc), dy0 = scharr_dy(ra, rc);
+#pragma unroll
+                for (int k = 0; k < HALF_ROWS; ++k) {
+                    ra = rb; rb = rc; rc = scharr_row(q[k + 3]);
+                    const uint32_t g1 = rb.g, dx1 = scharr_dx(ra, rb, rc), dy1 = scharr_dy(ra, rc);
+                    window_row(k, g0, g1, dx0, dx1, dy0, dy1);
+                    g0 = g1; dx0 = dx1; dy0 = dy1;
+                }
+            } else if (early) {
                 constexpr int NR = HALF_ROWS + 1;
                 uint2 raw[NIT];
                 uint16_t graw[NR];
@@ -334,7 +390,50 @@ __global__ __launch_bounds__(64, WPS) void klt_kernel(KltArgs a)
             for (int batch = 0; batch < 2; ++batch) {
                 const int r0 = batch * (HALF_ROWS / 2);
                 uint32_t gp[NB], dxp[NB], dyp[NB];     // pre-scaled packed pairs of columns (xa, xa+1)
-                if (inside) {
+                if (fly) {
+                    // source rows r0 - 1 .. r0 + NB of this half as dwords of the gray bytes at columns xa - 1 .. xa + 2
+                    uint32_t q[NB + 2];
+                    if (inside) {
+#pragma unroll
+                        for (int r = 0; r < NB + 2; ++r) {
+                            const gptr_u8 grow = Ig + (long long)((ipy + r0 - 1 + r) * Igs + ipx - 1);   // scalar, signed
+                            __builtin_memcpy(&q[r], (const void *)(uintptr_t)(grow + vg), 4);
+                        }
+                    } else {
+                        // virtual border: BORDER_REFLECT_101 gray for the samples AND for the stencils of the pixels inside the
+                        // image (what cv::calcSharrDeriv sees on the padded level); gradients outside the image are 0
+                        const unsigned gxl = (unsigned)reflect101(xa - 1, w), gxr = (unsigned)reflect101(xa + 2, w);
+                        uint32_t b0[NB + 2], b1[NB + 2], b2[NB + 2], b3[NB + 2];
+#pragma unroll
+                        for (int r = 0; r < NB + 2; ++r) {
+                            const int ry0 = ipy + r0 - 1 + r, ry1 = ry0 + HALF_ROWS;                      // uniform
+                            const unsigned go0 = __builtin_amdgcn_readfirstlane((unsigned)reflect101(ry0, h) * (unsigned)Igs);
+                            const unsigned go1 = __builtin_amdgcn_readfirstlane((unsigned)reflect101(ry1, h) * (unsigned)Igs);
+                            const unsigned go = half ? go1 : go0;
+                            b0[r] = Ig[go + gxl]; b1[r] = Ig[go + gxa]; b2[r] = Ig[go + gxb]; b3[r] = Ig[go + gxr];
+                        }
+                        __builtin_amdgcn_sched_barrier(0);   // keep the whole batch in flight before the first use
+#pragma unroll
+                        for (int r = 0; r < NB + 2; ++r) q[r] = b0[r] | (b1[r] << 8) | (b2[r] << 16) | (b3[r] << 24);
+                    }
+                    ScharrRow ra = scharr_row(q[0]), rb = scharr_row(q[1]);
+#pragma unroll
+                    for (int r = 0; r < NB; ++r) {
+                        const ScharrRow rc = scharr_row(q[r + 2]);
+                        gp[r] = rb.g; dxp[r] = scharr_dx(ra, rb, rc); dyp[r] = scharr_dy(ra, rc);
+                        ra = rb; rb = rc;
+                    }
+                    if (!inside) {
+#pragma unroll
+                        for (int r = 0; r < NB; ++r) {
+                            const bool rin0 = (unsigned)(ipy + r0 + r) < (unsigned)h, rin1 = (unsigned)(ipy + r0 + r + HALF_ROWS) < (unsigned)h;
+                            const bool rin = half ? rin1 : rin0;
+                            const uint32_t keep = ((ina && rin) ? 0x0000FFFFu : 0u) | ((inb && rin) ? 0xFFFF0000u : 0u);
+                            dxp[r] = (dxp[r] & keep) | (ROUND_PAIR & ~keep);     // border value 0 is 4*0 + 2
+                            dyp[r] = (dyp[r] & keep) | (ROUND_PAIR & ~keep);
+                        }
+                    }
+                } else if (inside) {
                     uint16_t graw[NB];
                     uint2 draw[NB];
 #pragma unroll

@@ -32,6 +32,8 @@ struct PyrLevelArgs {
     uint8_t *slab;
     long long slot_bytes;
     long long doff;            // gradient level offset inside the slot
+    uint32_t *grad_out;        // non-null: gradients go to this plain buffer (read-back of a level that is not stored)
+    int write_grad;            // 0: skip the gradient half (level 0 by default: the LK kernel forms them itself)
     int dstride;               // dwords per gradient row
     long long goff_next;       // next gray level offset inside the slot
     int gstride_next;
@@ -118,8 +120,8 @@ __global__ __launch_bounds__(256) void pyr_level_kernel(PyrLevelArgs a)
     uint8_t *slot_base = a.slab + (long long)slot * a.slot_bytes;
 
     // ---- Scharr gradients: lane = 4 consecutive pixels x 4 consecutive rows ----
-    {
-        uint32_t *dbase = reinterpret_cast<uint32_t *>(slot_base + a.doff);
+    if (a.write_grad) {
+        uint32_t *dbase = a.grad_out ? a.grad_out : reinterpret_cast<uint32_t *>(slot_base + a.doff);
         const int cg = t % CG, rg = t / CG;
         const int x = x0 + 4 * cg, yb = y0 + 4 * rg;
         if (x < a.w && yb < a.h) {
@@ -294,6 +296,37 @@ int fill_gradient_borders(Ctx *c, int first_slot, int n_slots)
     return HV_OK;
 }
 
+// hv_pyramid_download of the level-0 gradients when the plane is not stored: the same stencil, written to a scratch buffer
+int download_l0_gradient(Ctx *c, int slot, int16_t *grad)
+{
+    const PyrLayout &L = c->L;
+    const uint8_t *src = nullptr;
+    int stride = 0;
+    HV_HIP(c, hipMemcpy(&src, c->d_l0_ptr + slot, sizeof(void *), hipMemcpyDeviceToHost));
+    HV_HIP(c, hipMemcpy(&stride, c->d_l0_stride + slot, sizeof(int), hipMemcpyDeviceToHost));
+    if (!src) return HV_ERR_INVALID;
+    uint32_t *tmp = nullptr;
+    int *d_slot = nullptr;
+    if (hipMalloc(&tmp, (size_t)L.dstride[0] * L.h[0] * 4) != hipSuccess) return HV_ERR_NOMEM;
+    if (hipMalloc(&d_slot, sizeof(int)) != hipSuccess) { (void)hipFree(tmp); return HV_ERR_NOMEM; }
+    int rc = HV_OK;
+    PyrLevelArgs a{};
+    a.src_base = src; a.src_step = 0; a.src_stride = stride; a.src_by_slot = 0;
+    a.slots = d_slot; a.slab = c->slab; a.slot_bytes = L.slot_bytes;
+    a.grad_out = tmp; a.write_grad = 1; a.dstride = L.dstride[0];
+    a.w = L.w[0]; a.h = L.h[0];
+    a.tiles_x = (a.w + TW - 1) / TW; a.tiles_y = (a.h + TH - 1) / TH;
+    if (hipMemcpy(d_slot, &slot, sizeof(int), hipMemcpyHostToDevice) != hipSuccess) rc = HV_ERR_HIP;
+    if (rc == HV_OK) {
+        hipLaunchKernelGGL(pyr_level_kernel<false>, dim3((unsigned)(a.tiles_x * a.tiles_y)), dim3(256), 0, c->stream, a);
+        if (hipGetLastError() != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess) rc = HV_ERR_HIP;
+    }
+    if (rc == HV_OK && hipMemcpy2D(grad, (size_t)L.w[0] * 4, tmp, (size_t)L.dstride[0] * 4, (size_t)L.w[0] * 4, L.h[0],
+                                   hipMemcpyDeviceToHost) != hipSuccess) rc = HV_ERR_HIP;
+    (void)hipFree(tmp); (void)hipFree(d_slot);
+    return rc;
+}
+
 int launch_pyramid_levels(Ctx *c, int n, const int *slots_dev, const uint8_t *src_base,
                           long long src_step, int src_stride, bool src_indexed_by_slot)
 {
@@ -311,6 +344,7 @@ int launch_pyramid_levels(Ctx *c, int n, const int *slots_dev, const uint8_t *sr
         a.slots = slots_dev;
         a.slab = c->slab; a.slot_bytes = L.slot_bytes;
         a.doff = L.doff[l]; a.dstride = L.dstride[l];
+        a.write_grad = (l > 0 || L.l0_grad) ? 1 : 0;
         a.w = L.w[l]; a.h = L.h[l];
         const bool down = l + 1 < L.levels;
         if (down) { a.goff_next = L.goff[l + 1]; a.gstride_next = L.gstride[l + 1]; a.wn = L.w[l + 1]; a.hn = L.h[l + 1]; }
