@@ -203,6 +203,123 @@ __global__ __launch_bounds__(256) void pyr_level_kernel(PyrLevelArgs a)
     }
 }
 
+
+// ---- level 0 when its gradient plane is not stored: the launch is a pure 5x5 binomial down-sample (read L0 once, write the
+// L1 gray level). No LDS, no barrier: a work item produces 4 columns x 2 rows of L1 from seven 16-byte row loads (source columns
+// 8g-4 .. 8g+11 of rows 4p-2 .. 4p+4; vertically adjacent items share 3 of the 7 rows through L2), so the latency of the HBM
+// stream is hidden by ~8 independent wavefronts per SIMD instead of by workgroups that load, synchronise and then compute.
+// Items whose 16-byte loads would leave the row (the first and the last column group) come AFTER the interior items of an
+// image in the index space: they gather their bytes with BORDER_REFLECT_101 columns, and wavefronts stay homogeneous.
+// Rows reflect through the row index on both paths. Measured at 752x480, 2048 images: DESIGN.md 3.1.
+struct DownL0Args {
+    const uint8_t *src_base;
+    long long src_step;
+    int src_stride, src_by_slot;
+    const int *slots;
+    uint8_t *slab;
+    long long slot_bytes, goff_next;
+    int gstride_next;
+    int w, h, wn, hn;
+    int groups, g_lo, n_gi;    // 4-column output groups per row; interior groups g_lo .. g_lo + n_gi - 1
+    int nrp;                   // output row pairs
+    int edge_shift;            // w % 8 == 0: every group takes the vector-load path (g_lo = 0, n_gi = groups)
+    int wgs_per_img;
+    const uint8_t **l0_ptr;
+    int *l0_stride;
+};
+
+// horizontal [1 4 6 4 1] at the 4 even columns 8g, 8g+2, 8g+4, 8g+6 from the 16 bytes of columns 8g-4 .. 8g+11
+__device__ __forceinline__ void hpass(uint32_t q0, uint32_t q1, uint32_t q2, uint32_t q3, us2 &h01, us2 &h23)
+{
+    const us2 e24 = bytes2<2, 4>(q0, q1), e35 = bytes2<3, 5>(q0, q1), e46 = bytes2<0, 2>(q1, q1), e57 = bytes2<1, 3>(q1, q1);
+    const us2 e68 = bytes2<2, 4>(q1, q2), e79 = bytes2<3, 5>(q1, q2), e8a = bytes2<0, 2>(q2, q2), e9b = bytes2<1, 3>(q2, q2);
+    const us2 eac = bytes2<2, 4>(q2, q3);
+    h01 = (e24 + e68) + (e35 + e57) * splat(4) + e46 * splat(6);
+    h23 = (e68 + eac) + (e79 + e9b) * splat(4) + e8a * splat(6);
+}
+
+__global__ __launch_bounds__(256) void pyr_down_l0_kernel(DownL0Args a)
+{
+    const unsigned lb = xcd_remap(blockIdx.x, gridDim.x);
+    const int img = lb / a.wgs_per_img;
+    const int item = (int)(lb - (unsigned)img * a.wgs_per_img) * 256 + (int)threadIdx.x;
+    const int slot = a.slots[img];
+    const uint8_t *src = a.src_base + (long long)(a.src_by_slot ? slot : img) * a.src_step;
+    if (item == 0) {
+        a.l0_ptr[slot] = src;
+        a.l0_stride[slot] = a.src_stride;
+    }
+    const int n_int = a.n_gi * a.nrp;
+    if (item >= a.groups * a.nrp) return;
+    int g, rp;
+    const bool interior = item < n_int;
+    if (interior) {
+        rp = item / a.n_gi; g = a.g_lo + (item - rp * a.n_gi);
+    } else {
+        const int nb = a.groups - a.n_gi, e = item - n_int;
+        rp = e / nb;
+        const int k = e - rp * nb;                       // border groups: 0 .. g_lo - 1, then g_lo + n_gi .. groups - 1
+        g = k < a.g_lo ? k : k + a.n_gi;
+    }
+    const int oy = 2 * rp, ox = 4 * g;
+    us2 H01[7], H23[7];
+    if (interior) {
+        // a.edge_shift (w % 8 == 0): the first and the last column group ride along -- their 16 bytes are loaded one dword to the
+        // right / left of where they belong (inside the row) and the two reflected columns they need are bytes of the same load:
+        //   first group: columns -2, -1 = columns 2, 1          last group: column w = column w - 2
+        const int sh = a.edge_shift ? (g == 0 ? 1 : g == a.groups - 1 ? -1 : 0) : 0;
+        uint4 q[7];
+#pragma unroll
+        for (int j = 0; j < 7; ++j) {
+            const uint8_t *row = src + (long long)reflect101(2 * oy - 2 + j, a.h) * a.src_stride + (8 * g - 4 + 4 * sh);
+            __builtin_memcpy(&q[j], row, 16);
+        }
+#pragma unroll
+        for (int j = 0; j < 7; ++j) {
+            uint32_t q0 = q[j].x, q1 = q[j].y, q2 = q[j].z, q3 = q[j].w;
+            if (a.edge_shift) {
+                const uint32_t refl = __builtin_amdgcn_perm(q[j].y, q[j].x, 0x01020304u);      // (c4, c3, c2, c1) of a load at column 0
+                q0 = sh > 0 ? refl : sh < 0 ? q[j].y : q[j].x;
+                q1 = sh > 0 ? q[j].x : sh < 0 ? q[j].z : q[j].y;
+                q2 = sh > 0 ? q[j].y : sh < 0 ? q[j].w : q[j].z;
+                q3 = sh > 0 ? q[j].z : sh < 0 ? (q[j].w >> 16) : q[j].w;
+            }
+            hpass(q0, q1, q2, q3, H01[j], H23[j]);
+        }
+    } else {
+        int cx[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) cx[k] = reflect101(8 * g - 4 + k, a.w);
+#pragma unroll
+        for (int j = 0; j < 7; ++j) {
+            const uint8_t *row = src + (long long)reflect101(2 * oy - 2 + j, a.h) * a.src_stride;
+            uint32_t q[4];
+#pragma unroll
+            for (int d = 0; d < 4; ++d)
+                q[d] = (uint32_t)row[cx[4 * d]] | ((uint32_t)row[cx[4 * d + 1]] << 8) | ((uint32_t)row[cx[4 * d + 2]] << 16) | ((uint32_t)row[cx[4 * d + 3]] << 24);
+            hpass(q[0], q[1], q[2], q[3], H01[j], H23[j]);
+        }
+    }
+    uint8_t *gbase = a.slab + (long long)slot * a.slot_bytes + a.goff_next;
+#pragma unroll
+    for (int o = 0; o < 2; ++o) {
+        if (oy + o >= a.hn) break;
+        const int j0 = 2 * o;
+        // vertical [1 4 6 4 1] + 128, >> 8: sums <= 255*256 + 128 = 65408 still fit 16 bits
+        const us2 V01 = ((H01[j0] + H01[j0 + 4]) + (H01[j0 + 1] + H01[j0 + 3]) * splat(4) + (H01[j0 + 2] * splat(6) + splat(128))) >> splat(8);
+        const us2 V23 = ((H23[j0] + H23[j0 + 4]) + (H23[j0 + 1] + H23[j0 + 3]) * splat(4) + (H23[j0 + 2] * splat(6) + splat(128))) >> splat(8);
+        const uint32_t packed = __builtin_amdgcn_perm(__builtin_bit_cast(uint32_t, V23), __builtin_bit_cast(uint32_t, V01), 0x06040200u);
+        uint8_t *gp = gbase + (long long)(oy + o) * a.gstride_next + ox;
+        if (ox + 3 < a.wn) {
+            *reinterpret_cast<uint32_t *>(gp) = packed;
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (ox + k < a.wn) gp[k] = (uint8_t)(packed >> (8 * k));
+        }
+    }
+}
+
 // ---- physical borders of the padded (coarse) levels, see PyrLayout ----
 struct BorderArgs {
     PyrLayout L;
@@ -351,6 +468,25 @@ int launch_pyramid_levels(Ctx *c, int n, const int *slots_dev, const uint8_t *sr
         a.tiles_x = (a.w + TW - 1) / TW; a.tiles_y = (a.h + TH - 1) / TH;
         const unsigned grid = (unsigned)(a.tiles_x * a.tiles_y * n);
         ScopedKernelTime tm(c, l == 0 ? HV_K_PYR_L0 : HV_K_PYR_LN);
+        // level 0 without a stored gradient plane is a pure down-sample: the direct kernel, when the 16-byte row loads are legal
+        static const bool no_direct = [] { const char *e = getenv("HV_PYR_L0_TILED"); return e && atoi(e) != 0; }();
+        if (l == 0 && down && !a.write_grad && !no_direct && a.w >= 24 &&
+            ((reinterpret_cast<uintptr_t>(src_base) | (uintptr_t)src_stride | (uintptr_t)(src_step & 3)) & 3u) == 0) {
+            DownL0Args d{};
+            d.src_base = a.src_base; d.src_step = a.src_step; d.src_stride = a.src_stride; d.src_by_slot = a.src_by_slot;
+            d.slots = slots_dev; d.slab = c->slab; d.slot_bytes = L.slot_bytes; d.goff_next = a.goff_next; d.gstride_next = a.gstride_next;
+            d.w = a.w; d.h = a.h; d.wn = a.wn; d.hn = a.hn;
+            d.groups = (a.wn + 3) / 4; d.g_lo = 1;
+            d.n_gi = (a.w - 12) / 8;                       // interior: 8g - 4 >= 0 and 8g + 12 <= w  <=>  1 <= g <= (w - 12) / 8
+            if (d.n_gi > d.groups - 1) d.n_gi = d.groups - 1;
+            if (a.w % 8 == 0 && a.w >= 32) { d.edge_shift = 1; d.g_lo = 0; d.n_gi = d.groups; }
+            d.nrp = (a.hn + 1) / 2;
+            d.wgs_per_img = (d.groups * d.nrp + 255) / 256;
+            d.l0_ptr = c->d_l0_ptr; d.l0_stride = c->d_l0_stride;
+            hipLaunchKernelGGL(pyr_down_l0_kernel, dim3((unsigned)(d.wgs_per_img * n)), dim3(256), 0, c->stream, d);
+            HV_HIP(c, hipGetLastError());
+            continue;
+        }
         if (down) hipLaunchKernelGGL(pyr_level_kernel<true>, dim3(grid), dim3(256), 0, c->stream, a);
         else      hipLaunchKernelGGL(pyr_level_kernel<false>, dim3(grid), dim3(256), 0, c->stream, a);
         HV_HIP(c, hipGetLastError());
