@@ -1397,7 +1397,7 @@ static int ekf_launch_update(Ekf *e, int nr, int l, const double *H_dev, const d
     const size_t small = (size_t)(256 + 544 + UPD_THREADS / 64 + 2) * sizeof(double);           // W + col (incl. dump area) + red + flag
     const int ti = (nr + 15) / 16, lbk = (l + 15) / 16;
     const size_t hbytes = (size_t)(16 * ti) * (16 * lbk) * sizeof(double);                      // zero-padded H
-    const size_t lds_cap = 150 * 1024;
+    const size_t lds_cap = 160 * 1024;                       // the whole LDS of a CU: T alone reaches 154 KB at 80 rows (20 stereo poses)
     a.use_lds = tall + small <= lds_cap;
     if (!a.use_lds) { a.Rs = a.R; tall = (((size_t)a.R * nr + 1) & ~(size_t)1) * sizeof(double); }   // global workspace: no padding
     int kmode = !a.use_lds ? 0 : (e->n <= 160 && nr <= 48 && tall + small + hbytes <= lds_cap) ? 2 : 1;
@@ -1419,7 +1419,7 @@ static int ekf_launch_update(Ekf *e, int nr, int l, const double *H_dev, const d
     bool &attr_set = attr_set_dev[c->p.device & 63];
     if (!attr_set) {
         for (Kern k : { (Kern)ekf_update_kernel<1, 0>, (Kern)ekf_update_kernel<2, 1>, (Kern)ekf_update_kernel<2, 2>, (Kern)ekf_update_kernel<2, 3> })
-            HV_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024));
+            HV_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set = true;
     }
     ScopedKernelTime tm(c, HV_K_EKF_UPDATE);

@@ -287,17 +287,22 @@ __global__ __launch_bounds__(256) void pyr_down_l0_kernel(DownL0Args a)
             hpass(q0, q1, q2, q3, H01[j], H23[j]);
         }
     } else {
-        int cx[16];
+        // rare (first / last column group of an image whose width is not a multiple of 8): bytes gathered with reflected columns,
+        // one row at a time (kept rolled: the unrolled form raised the kernel to 125 VGPRs, half the occupancy of the main path)
 #pragma unroll
-        for (int k = 0; k < 16; ++k) cx[k] = reflect101(8 * g - 4 + k, a.w);
-#pragma unroll
+        for (int j = 0; j < 7; ++j) { H01[j] = splat(0); H23[j] = splat(0); }
+#pragma unroll 1
         for (int j = 0; j < 7; ++j) {
             const uint8_t *row = src + (long long)reflect101(2 * oy - 2 + j, a.h) * a.src_stride;
-            uint32_t q[4];
+            uint32_t q[4] = {0, 0, 0, 0};
+#pragma unroll 1
+            for (int k = 2; k < 13; ++k)           // columns 8g-2 .. 8g+8: the bytes hpass reads
+                q[k >> 2] |= (uint32_t)row[reflect101(8 * g - 4 + k, a.w)] << (8 * (k & 3));
+            us2 h01, h23;
+            hpass(q[0], q[1], q[2], q[3], h01, h23);
 #pragma unroll
-            for (int d = 0; d < 4; ++d)
-                q[d] = (uint32_t)row[cx[4 * d]] | ((uint32_t)row[cx[4 * d + 1]] << 8) | ((uint32_t)row[cx[4 * d + 2]] << 16) | ((uint32_t)row[cx[4 * d + 3]] << 24);
-            hpass(q[0], q[1], q[2], q[3], H01[j], H23[j]);
+            for (int jj = 0; jj < 7; ++jj)
+                if (jj == j) { H01[jj] = h01; H23[jj] = h23; }
         }
     }
     uint8_t *gbase = a.slab + (long long)slot * a.slot_bytes + a.goff_next;
@@ -316,6 +321,211 @@ __global__ __launch_bounds__(256) void pyr_down_l0_kernel(DownL0Args a)
 #pragma unroll
             for (int k = 0; k < 4; ++k)
                 if (ox + k < a.wn) gp[k] = (uint8_t)(packed >> (8 * k));
+        }
+    }
+}
+
+// ---- the coarse tail (levels >= 2) of one image in ONE workgroup: the level fits LDS whole (188x120 = 22 KB, 320x180 = 58 KB),
+// so its gradients, its physical REFLECT_101 border, the next gray level and that level's gradients and border all come from
+// LDS copies -- one launch instead of three (two level launches + pyr_border_kernel, 0.18 ms per 2048 images for 0.4 GB),
+// and the only HBM read is the level-2 interior the level-1 launch just wrote. Same packed 16-bit arithmetic as
+// pyr_level_kernel (the LDS image has that kernel's tile layout: columns -4 .. w+3, rows -2 .. h+1, halo by REFLECT_101).
+struct TailArgs {
+    PyrLayout L;
+    uint8_t *slab;
+    const int *slots;
+    int first;                 // first level handled here
+    int buf1;                  // dword offset of the second level buffer
+};
+constexpr int TAIL_THREADS = 512;
+
+// i / d for 0 <= i < 2^22, d > 0 given rcp = 1.f / d: the float quotient is off by at most one (a hardware integer division is ~30
+// instructions and every work item of the tail kernel starts with one or two)
+__device__ __forceinline__ int fast_div(int i, int d, float rcp)
+{
+    int q = (int)((float)i * rcp);
+    if (q * d > i) --q;
+    else if ((q + 1) * d <= i) ++q;
+    return q;
+}
+__device__ __forceinline__ int tail_lwd(int w) { return (w + 8 + 3) >> 2; }
+__device__ __forceinline__ int tail_rows(int h) { return 4 * ((h + 3) >> 2) + 4; }
+
+// halo (and the ragged right end) of a level image in LDS from its interior
+__device__ __forceinline__ void tail_fill_halo(uint32_t *img, int w, int h, int lwd, int t)
+{
+    const uint8_t *b = reinterpret_cast<const uint8_t *>(img);
+    const float rcp = 1.f / (float)lwd;
+    for (int i = t; i < (h + 4) * lwd; i += TAIL_THREADS) {
+        const int r = fast_div(i, lwd, rcp), k = i - r * lwd;
+        const int y = r - 2, x = 4 * k - 4;
+        if (y >= 0 && y < h && x >= 0 && x + 4 <= w) continue;              // interior dword
+        const int rb = (reflect101(y, h) + 2) * lwd * 4 + 4;
+        uint32_t v = 0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v |= (uint32_t)b[rb + reflect101(x + q, w)] << (8 * q);
+        img[i] = v;
+    }
+}
+
+__global__ __launch_bounds__(TAIL_THREADS) void pyr_tail_kernel(TailArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t tl[];
+    const PyrLayout &L = a.L;
+    const int t = threadIdx.x;
+    uint8_t *slot_base = a.slab + (long long)a.slots[blockIdx.x] * L.slot_bytes;
+    uint32_t *cur = tl, *nxt = tl + a.buf1;
+
+    // ---- the first level from HBM: interior dwords by aligned loads, the rest by reflection ----
+    {
+        const int l = a.first, w = L.w[l], h = L.h[l], lwd = tail_lwd(w), gs = L.gstride[l];
+        const uint8_t *g = slot_base + L.goff[l];
+        const float rcp = 1.f / (float)lwd;
+        // four loads in flight per thread before the first LDS store (a load -> store loop pays the HBM latency per iteration)
+        constexpr int U = 4;
+        for (int base = t; base < (h + 4) * lwd; base += U * TAIL_THREADS) {
+            uint32_t v[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int i = min(base + u * TAIL_THREADS, (h + 4) * lwd - 1);
+                const int r = fast_div(i, lwd, rcp), k = i - r * lwd;
+                const int x = 4 * k - 4;
+                const uint8_t *row = g + (long long)reflect101(r - 2, h) * gs;
+                if (x >= 0 && x + 4 <= w) {
+                    v[u] = *reinterpret_cast<const uint32_t *>(row + x);
+                } else {
+                    v[u] = 0;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) v[u] |= (uint32_t)row[reflect101(x + q, w)] << (8 * q);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int i = base + u * TAIL_THREADS;
+                if (i < (h + 4) * lwd) cur[i] = v[u];
+            }
+        }
+    }
+    __syncthreads();
+
+    for (int l = a.first; l < L.levels; ++l) {
+        const int w = L.w[l], h = L.h[l], lwd = tail_lwd(w);
+        const bool down = l + 1 < L.levels;
+        const int wn = down ? L.w[l + 1] : 0, hn = down ? L.h[l + 1] : 0, lwdn = tail_lwd(wn);
+
+        // ---- Scharr gradients: item = 4 pixels x 4 rows ----
+        {
+            uint32_t *dbase = reinterpret_cast<uint32_t *>(slot_base + L.doff[l]);
+            const int ncg = (w + 3) >> 2, nrg = (h + 3) >> 2, ds = L.dstride[l];
+            const float rcp = 1.f / (float)ncg;
+            for (int it = t; it < ncg * nrg; it += TAIL_THREADS) {
+                const int rg = fast_div(it, ncg, rcp), cg = it - rg * ncg;
+                const int x = 4 * cg, yb = 4 * rg;
+                us2 R[6][3];
+#pragma unroll
+                for (int k = 0; k < 6; ++k) {
+                    const uint32_t *p = cur + (yb + 1 + k) * lwd + cg;
+                    const uint32_t a0 = p[0], a1 = p[1], a2 = p[2];
+                    R[k][0] = bytes2<3, 4>(a0, a1);
+                    R[k][1] = bytes2<1, 2>(a1, a1);
+                    R[k][2] = bytes2<3, 4>(a1, a2);
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int y = yb + j;
+                    us2 T0[3], T1[3];
+#pragma unroll
+                    for (int q = 0; q < 3; ++q) {
+                        T0[q] = (R[j][q] + R[j + 2][q]) * splat(3) + R[j + 1][q] * splat(10);
+                        T1[q] = R[j + 2][q] - R[j][q];
+                    }
+                    const us2 dxA = (T0[1] - T0[0]) * splat(4) + splat(2);
+                    const us2 dxB = (T0[2] - T0[1]) * splat(4) + splat(2);
+                    const us2 dyA = (T1[0] + T1[1]) * splat(12) + (cross(T1[0], T1[1]) * splat(40) + splat(2));
+                    const us2 dyB = (T1[1] + T1[2]) * splat(12) + (cross(T1[1], T1[2]) * splat(40) + splat(2));
+                    const uint32_t o[4] = {lo_pair(dxA, dyA), hi_pair(dxA, dyA), lo_pair(dxB, dyB), hi_pair(dxB, dyB)};
+                    if (y < h) {
+                        uint32_t *d = dbase + (long long)y * ds + x;
+                        if (x + 3 < w) {
+                            typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+                            const u32x4 pk = {o[0], o[1], o[2], o[3]};
+                            __builtin_nontemporal_store(pk, reinterpret_cast<u32x4 *>(d));
+                        } else {
+#pragma unroll
+                            for (int i = 0; i < 4; ++i)
+                                if (x + i < w) d[i] = o[i];
+                        }
+                    }
+                }
+            }
+        }
+
+        // ---- physical REFLECT_101 border of this gray level (what pyr_border_kernel writes) ----
+        if (L.pad[l]) {
+            const int pd = L.pad[l], gs = L.gstride[l];
+            uint8_t *img = slot_base + L.goff[l];
+            const uint8_t *b = reinterpret_cast<const uint8_t *>(cur);
+            const int gw = (w + 2 * pd + 3) >> 2, n_tb = 2 * pd * gw;
+            const int wq = w & ~3;
+            const int gr = (w + pd - wq + 3) >> 2, gl = pd >> 2, n_lr = h * (gl + gr);
+            const float rcp_gw = 1.f / (float)gw, rcp_lr = 1.f / (float)(gl + gr);
+            for (int item = t; item < n_tb + n_lr; item += TAIL_THREADS) {
+                int x, y;
+                if (item < n_tb) {
+                    const int r = fast_div(item, gw, rcp_gw);
+                    x = 4 * (item - r * gw) - pd;
+                    y = r < pd ? r - pd : h + (r - pd);
+                } else {
+                    const int e = item - n_tb, r = fast_div(e, gl + gr, rcp_lr), g = e - r * (gl + gr);
+                    y = r;
+                    x = g < gl ? 4 * g - pd : wq + 4 * (g - gl);
+                }
+                const int rb = (reflect101(y, h) + 2) * lwd * 4 + 4;
+                uint32_t v = 0;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) v |= (uint32_t)b[rb + reflect101(x + i, w)] << (8 * i);
+                uint8_t *dst = img + (long long)y * gs + x;
+                if (x + 4 <= w + pd) {
+                    *reinterpret_cast<uint32_t *>(dst) = v;
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        if (x + i < w + pd) dst[i] = (uint8_t)(v >> (8 * i));
+                }
+            }
+        }
+
+        // ---- next gray level: to HBM and into the other LDS buffer ----
+        if (down) {
+            const int nocg = (wn + 3) >> 2, gsn = L.gstride[l + 1];
+            uint8_t *gn = slot_base + L.goff[l + 1];
+            const float rcp = 1.f / (float)nocg;
+            for (int it = t; it < nocg * hn; it += TAIL_THREADS) {
+                const int oy = fast_div(it, nocg, rcp), ocg = it - oy * nocg;
+                const int ox = 4 * ocg;
+                us2 H01[5], H23[5];
+#pragma unroll
+                for (int j = 0; j < 5; ++j) {
+                    const uint32_t *p = cur + (2 * oy + j) * lwd + 2 * ocg;
+                    hpass(p[0], p[1], p[2], p[3], H01[j], H23[j]);
+                }
+                const us2 V01 = ((H01[0] + H01[4]) + (H01[1] + H01[3]) * splat(4) + (H01[2] * splat(6) + splat(128))) >> splat(8);
+                const us2 V23 = ((H23[0] + H23[4]) + (H23[1] + H23[3]) * splat(4) + (H23[2] * splat(6) + splat(128))) >> splat(8);
+                const uint32_t packed = __builtin_amdgcn_perm(__builtin_bit_cast(uint32_t, V23), __builtin_bit_cast(uint32_t, V01), 0x06040200u);
+                nxt[(oy + 2) * lwdn + 1 + ocg] = packed;            // bytes beyond wn are rewritten by the halo fill
+                uint8_t *gp = gn + (long long)oy * gsn + ox;
+                if (ox + 3 < wn) {
+                    *reinterpret_cast<uint32_t *>(gp) = packed;
+                } else {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+                        if (ox + k < wn) gp[k] = (uint8_t)(packed >> (8 * k));
+                }
+            }
+            __syncthreads();
+            tail_fill_halo(nxt, wn, hn, lwdn, t);
+            __syncthreads();
+            uint32_t *sw = cur; cur = nxt; nxt = sw;
         }
     }
 }
@@ -444,11 +654,27 @@ int download_l0_gradient(Ctx *c, int slot, int16_t *grad)
     return rc;
 }
 
+// levels >= 2 in one launch (pyr_tail_kernel) when they fit LDS and no finer level is padded; HV_PYR_TAIL=0 turns it off
+static int tail_first_level(const PyrLayout &L, size_t *shmem, int *buf1)
+{
+    static const bool off = [] { const char *e = getenv("HV_PYR_TAIL"); return e && atoi(e) == 0; }();
+    const int first = 2;
+    if (off || L.levels <= first || first_padded_level(L) < first) return L.levels;
+    auto dwords = [&](int l) { return (size_t)((L.w[l] + 8 + 3) >> 2) * (4 * ((L.h[l] + 3) >> 2) + 4) + 8; };
+    const size_t b0 = dwords(first), b1 = first + 1 < L.levels ? dwords(first + 1) : 0;
+    if ((b0 + b1) * 4 > 150 * 1024) return L.levels;
+    *shmem = (b0 + b1) * 4; *buf1 = (int)b0;
+    return first;
+}
+
 int launch_pyramid_levels(Ctx *c, int n, const int *slots_dev, const uint8_t *src_base,
                           long long src_step, int src_stride, bool src_indexed_by_slot)
 {
     const PyrLayout &L = c->L;
-    for (int l = 0; l < L.levels; ++l) {
+    size_t tail_shmem = 0;
+    int tail_buf1 = 0;
+    const int tail_first = tail_first_level(L, &tail_shmem, &tail_buf1);
+    for (int l = 0; l < tail_first && l < L.levels; ++l) {
         PyrLevelArgs a{};
         if (l == 0) {
             a.src_base = src_base; a.src_step = src_step; a.src_stride = src_stride;
@@ -490,6 +716,20 @@ int launch_pyramid_levels(Ctx *c, int n, const int *slots_dev, const uint8_t *sr
         if (down) hipLaunchKernelGGL(pyr_level_kernel<true>, dim3(grid), dim3(256), 0, c->stream, a);
         else      hipLaunchKernelGGL(pyr_level_kernel<false>, dim3(grid), dim3(256), 0, c->stream, a);
         HV_HIP(c, hipGetLastError());
+    }
+    if (tail_first < L.levels) {
+        TailArgs a{};
+        a.L = L; a.slab = c->slab; a.slots = slots_dev; a.first = tail_first; a.buf1 = tail_buf1;
+        static bool attr_set_dev[64] = {};
+        bool &attr_set = attr_set_dev[c->p.device & 63];
+        if (!attr_set) {
+            HV_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void *>(pyr_tail_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024));
+            attr_set = true;
+        }
+        ScopedKernelTime tm(c, HV_K_PYR_LN);
+        hipLaunchKernelGGL(pyr_tail_kernel, dim3((unsigned)n), dim3(TAIL_THREADS), tail_shmem, c->stream, a);
+        HV_HIP(c, hipGetLastError());
+        return HV_OK;
     }
     const int fl = first_padded_level(L);
     if (fl < L.levels) {
