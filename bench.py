@@ -41,7 +41,8 @@ def level_sizes(w, h, levels=LEVELS, win=31):
     return out
 
 
-L0_GRADIENTS_STORED = os.environ.get("HV_L0_GRADIENTS", "0") not in ("", "0")
+GRAD_FROM_LEVEL = 0 if os.environ.get("HV_L0_GRADIENTS", "0") not in ("", "0") else int(os.environ.get("HV_GRAD_FROM_LEVEL", "2"))
+L0_GRADIENTS_STORED = GRAD_FROM_LEVEL == 0
 
 
 def algorithmic_bytes(w=None, h=None, npts=None):

@@ -68,9 +68,14 @@ int compute_layout(const hv_params &p, PyrLayout &L)
     int pad_from = 2;
     if (const char *e = getenv("HV_PAD_FROM_LEVEL")) pad_from = atoi(e);
     if (pad_from < 1) pad_from = 1;                     // level 0 may be the caller's image: never padded
-    // HV_L0_GRADIENTS (environment, experiments only): 1 keeps the level-0 gradient plane in memory (the r01 / early r02 design)
-    L.l0_grad = 0;
-    if (const char *e = getenv("HV_L0_GRADIENTS")) L.l0_grad = atoi(e) != 0;
+    // HV_GRAD_FROM_LEVEL (environment, experiments only): first level whose gradient plane is stored; 0 = all (the r01 design).
+    // HV_L0_GRADIENTS=1 is the older spelling of 0.
+    L.grad_from = 2;
+    if (const char *e = getenv("HV_GRAD_FROM_LEVEL")) L.grad_from = atoi(e);
+    if (const char *e = getenv("HV_L0_GRADIENTS")) if (atoi(e) != 0) L.grad_from = 0;
+    if (L.grad_from < 0) L.grad_from = 0;
+    if (L.grad_from > pad_from) L.grad_from = pad_from;       // a padded level keeps its plane (constant-0 border)
+    if (L.grad_from > n) L.grad_from = n;
     long long off = 0;
     for (int l = 0; l < n; ++l) {
         const int pd = L.pad[l] = l >= pad_from ? PYR_PAD : 0;
@@ -81,7 +86,7 @@ int compute_layout(const hv_params &p, PyrLayout &L)
     for (int l = 0; l < n; ++l) {
         const int pd = L.pad[l];
         L.dstride[l] = align_up(L.w[l] + 2 * pd, 4);
-        if (l == 0 && !L.l0_grad) { L.doff[0] = -1; continue; }      // formed inside the LK kernel, never stored
+        if (l < L.grad_from) { L.doff[l] = -1; continue; }           // formed inside the LK kernel, never stored
         L.doff[l] = off + ((long long)pd * L.dstride[l] + pd) * 4;
         off = align_up_ll(off + (long long)L.dstride[l] * 4 * (L.h[l] + 2 * pd), 256);
     }
@@ -362,8 +367,8 @@ int hv_pyramid_download(hv_ctx *h, int slot, int level, uint8_t *gray, int16_t *
         }
         HV_HIP(c, hipMemcpy2D(gray, L.w[level], src, stride, L.w[level], L.h[level], hipMemcpyDeviceToHost));
     }
-    if (grad && level == 0 && !L.l0_grad) {
-        const int rc = hv::download_l0_gradient(c, slot, grad);
+    if (grad && level < L.grad_from) {
+        const int rc = hv::download_unstored_gradient(c, slot, level, grad);
         if (rc != HV_OK) return rc;
     } else if (grad) {
         HV_HIP(c, hipMemcpy2D(grad, (size_t)L.w[level] * 4, base + L.doff[level], (size_t)L.dstride[level] * 4,

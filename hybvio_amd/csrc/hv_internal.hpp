@@ -21,13 +21,15 @@ namespace hv {
 //   4*0+2 -- for gradients (written once per slot). goff / doff still address pixel (0, 0); strides include the border.
 //   At the coarse levels most LK windows cross the image edge (68 % at level 3 of 752x480); with the border in memory the
 //   tracker takes its border-free paths there. Levels 0 and 1 (94 % of the pyramid bytes) keep virtual borders.
-//   The level-0 gradient plane (70 % of a slot's bytes at 752x480) is NOT materialised by default: the LK kernel forms the
-//   Scharr gradients of its level-0 template window from the gray rows it loads anyway (klt.hip), so the pyramid build never
-//   writes them (l0_grad == 0, doff[0] == -1). HV_L0_GRADIENTS=1 restores the plane (experiments / A-B measurements).
+//   The gradient planes of the fine levels l < grad_from (default 2: levels 0 and 1, 88 % of a slot's bytes at 752x480) are
+//   NOT materialised: the LK kernel forms the Scharr gradients of its template window from the gray rows it loads anyway
+//   (klt.hip), so the pyramid build never writes them (doff[l] == -1). HV_GRAD_FROM_LEVEL=0 restores every plane, =1 only
+//   level 0 is formed in the LK kernel (experiments / A-B measurements). Padded levels always store their plane (its border
+//   is the constant 0, which the gray border cannot reproduce).
 struct PyrLayout {
     int levels;
     int win;
-    int l0_grad;                           // 1: the level-0 gradient plane exists in the slot
+    int grad_from;                         // first level whose gradient plane exists in the slot
     int pad[HV_MAX_LEVELS];
     int w[HV_MAX_LEVELS], h[HV_MAX_LEVELS];
     int gstride[HV_MAX_LEVELS];
@@ -97,7 +99,7 @@ struct ScopedKernelTime {
 // pyramid.hip
 constexpr int PYR_PAD = 32;            // physical border width of the padded levels (window 31 + the pair column)
 int fill_gradient_borders(Ctx *c, int first_slot, int n_slots);   // once per slot (create / grow)
-int download_l0_gradient(Ctx *c, int slot, int16_t *grad);          // level-0 gradients computed on demand (test / debug read-back)
+int download_unstored_gradient(Ctx *c, int slot, int level, int16_t *grad);   // computed on demand (test / debug read-back)
 int launch_pyramid_levels(Ctx *c, int n, const int *slots_dev, const uint8_t *src_base,
                           long long src_step, int src_stride, bool src_indexed_by_slot);
 // vu_prepare.hip: triangulation + prepareVisualUpdate of one track per filter

@@ -92,7 +92,7 @@ __device__ __forceinline__ uint32_t scaled_pair(uint32_t lo, uint32_t hi)
     return __builtin_amdgcn_perm(hi, lo, sel) * (1u << GRAY_SHIFT) + ROUND_PAIR;   // no carry between halves
 }
 
-// Level-0 gradients formed in the kernel (PyrLayout::l0_grad == 0). q is the dword of gray bytes I(x-1 .. x+2) of one source
+// Gradients of the fine levels formed in the kernel (level < PyrLayout::grad_from). q is the dword of gray bytes I(x-1 .. x+2) of one source
 // row: the Scharr stencils of pixels x and x+1 (cv::calcSharrDeriv: smooth [3 10 3] across, difference [-1 0 1] along) are
 // separable, so a row contributes its horizontal difference d = I(x+1) - I(x-1) and smoothed value s4 = 4 (3 I(x-1) + 10 I(x)
 // + 3 I(x+1)) as packed 16-bit pairs for the two columns, and a gradient row is a vertical combination of three of those:
@@ -237,8 +237,8 @@ __global__ __launch_bounds__(64, WPS) void klt_kernel(KltArgs a)
         // levels with a physical 32-px border (REFLECT_101 gray, zero gradients in memory, see PyrLayout): every window the
         // range test above lets through lies inside the padded rectangle, so the border-free paths serve all of them
         const bool padded = L.pad[level] != 0;                                             // wave-uniform
-        // level 0 without a stored gradient plane: the template's gradients come from the gray rows (scharr_row above)
-        const bool fly = level == 0 && !L.l0_grad;                                         // wave-uniform
+        // a level without a stored gradient plane: the template's gradients come from the gray rows (scharr_row above)
+        const bool fly = level < L.grad_from;                                              // wave-uniform
 
         // ---- J tile bookkeeping (declared before the template: on the common path the first tile of the level is requested
         // together with the template rows, one memory round trip per level instead of three) ----
@@ -292,7 +292,7 @@ __global__ __launch_bounds__(64, WPS) void klt_kernel(KltArgs a)
             // (one more on each side when the gradients are formed here). Level 0 may be the caller's buffer -- nothing is
             // read past its last row or column; levels >= 1 live in the slab, where the one row / column beyond the image that
             // the zero-weight lanes touch is slab memory.
-            const int in_lo = fly ? 1 : 0, in_hi = level == 0 ? (fly ? 34 : 33) : 32;
+            const int in_lo = fly ? 1 : 0, in_hi = fly ? 34 : level == 0 ? 33 : 32;
             const bool inside = padded || (ipx >= in_lo && ipx + in_hi <= w && ipy >= in_lo && ipy + in_hi <= h);   // wave-uniform
             // per-lane part of every address; the per-row part is a scalar base (no VALU per load)
             // (on a padded level ipx / ipy may be negative: the signed part of every address is the scalar row base, the lane part

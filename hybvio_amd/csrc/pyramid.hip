@@ -245,7 +245,7 @@ __global__ __launch_bounds__(256) void pyr_down_l0_kernel(DownL0Args a)
     const int item = (int)(lb - (unsigned)img * a.wgs_per_img) * 256 + (int)threadIdx.x;
     const int slot = a.slots[img];
     const uint8_t *src = a.src_base + (long long)(a.src_by_slot ? slot : img) * a.src_step;
-    if (item == 0) {
+    if (a.l0_ptr != nullptr && item == 0) {
         a.l0_ptr[slot] = src;
         a.l0_stride[slot] = a.src_stride;
     }
@@ -623,32 +623,34 @@ int fill_gradient_borders(Ctx *c, int first_slot, int n_slots)
     return HV_OK;
 }
 
-// hv_pyramid_download of the level-0 gradients when the plane is not stored: the same stencil, written to a scratch buffer
-int download_l0_gradient(Ctx *c, int slot, int16_t *grad)
+// hv_pyramid_download of the gradients of a level whose plane is not stored: the same stencil, written to a scratch buffer
+int download_unstored_gradient(Ctx *c, int slot, int lv, int16_t *grad)
 {
     const PyrLayout &L = c->L;
-    const uint8_t *src = nullptr;
-    int stride = 0;
-    HV_HIP(c, hipMemcpy(&src, c->d_l0_ptr + slot, sizeof(void *), hipMemcpyDeviceToHost));
-    HV_HIP(c, hipMemcpy(&stride, c->d_l0_stride + slot, sizeof(int), hipMemcpyDeviceToHost));
+    const uint8_t *src = c->slab + (long long)slot * L.slot_bytes + L.goff[lv];
+    int stride = L.gstride[lv];
+    if (lv == 0) {
+        HV_HIP(c, hipMemcpy(&src, c->d_l0_ptr + slot, sizeof(void *), hipMemcpyDeviceToHost));
+        HV_HIP(c, hipMemcpy(&stride, c->d_l0_stride + slot, sizeof(int), hipMemcpyDeviceToHost));
+    }
     if (!src) return HV_ERR_INVALID;
     uint32_t *tmp = nullptr;
     int *d_slot = nullptr;
-    if (hipMalloc(&tmp, (size_t)L.dstride[0] * L.h[0] * 4) != hipSuccess) return HV_ERR_NOMEM;
+    if (hipMalloc(&tmp, (size_t)L.dstride[lv] * L.h[lv] * 4) != hipSuccess) return HV_ERR_NOMEM;
     if (hipMalloc(&d_slot, sizeof(int)) != hipSuccess) { (void)hipFree(tmp); return HV_ERR_NOMEM; }
     int rc = HV_OK;
     PyrLevelArgs a{};
     a.src_base = src; a.src_step = 0; a.src_stride = stride; a.src_by_slot = 0;
     a.slots = d_slot; a.slab = c->slab; a.slot_bytes = L.slot_bytes;
-    a.grad_out = tmp; a.write_grad = 1; a.dstride = L.dstride[0];
-    a.w = L.w[0]; a.h = L.h[0];
+    a.grad_out = tmp; a.write_grad = 1; a.dstride = L.dstride[lv];
+    a.w = L.w[lv]; a.h = L.h[lv];
     a.tiles_x = (a.w + TW - 1) / TW; a.tiles_y = (a.h + TH - 1) / TH;
     if (hipMemcpy(d_slot, &slot, sizeof(int), hipMemcpyHostToDevice) != hipSuccess) rc = HV_ERR_HIP;
     if (rc == HV_OK) {
         hipLaunchKernelGGL(pyr_level_kernel<false>, dim3((unsigned)(a.tiles_x * a.tiles_y)), dim3(256), 0, c->stream, a);
         if (hipGetLastError() != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess) rc = HV_ERR_HIP;
     }
-    if (rc == HV_OK && hipMemcpy2D(grad, (size_t)L.w[0] * 4, tmp, (size_t)L.dstride[0] * 4, (size_t)L.w[0] * 4, L.h[0],
+    if (rc == HV_OK && hipMemcpy2D(grad, (size_t)L.w[lv] * 4, tmp, (size_t)L.dstride[lv] * 4, (size_t)L.w[lv] * 4, L.h[lv],
                                    hipMemcpyDeviceToHost) != hipSuccess) rc = HV_ERR_HIP;
     (void)hipFree(tmp); (void)hipFree(d_slot);
     return rc;
@@ -687,17 +689,17 @@ int launch_pyramid_levels(Ctx *c, int n, const int *slots_dev, const uint8_t *sr
         a.slots = slots_dev;
         a.slab = c->slab; a.slot_bytes = L.slot_bytes;
         a.doff = L.doff[l]; a.dstride = L.dstride[l];
-        a.write_grad = (l > 0 || L.l0_grad) ? 1 : 0;
+        a.write_grad = l >= L.grad_from ? 1 : 0;
         a.w = L.w[l]; a.h = L.h[l];
         const bool down = l + 1 < L.levels;
         if (down) { a.goff_next = L.goff[l + 1]; a.gstride_next = L.gstride[l + 1]; a.wn = L.w[l + 1]; a.hn = L.h[l + 1]; }
         a.tiles_x = (a.w + TW - 1) / TW; a.tiles_y = (a.h + TH - 1) / TH;
         const unsigned grid = (unsigned)(a.tiles_x * a.tiles_y * n);
         ScopedKernelTime tm(c, l == 0 ? HV_K_PYR_L0 : HV_K_PYR_LN);
-        // level 0 without a stored gradient plane is a pure down-sample: the direct kernel, when the 16-byte row loads are legal
+        // a level without a stored gradient plane is a pure down-sample: the direct kernel, when the 16-byte row loads are legal
         static const bool no_direct = [] { const char *e = getenv("HV_PYR_L0_TILED"); return e && atoi(e) != 0; }();
-        if (l == 0 && down && !a.write_grad && !no_direct && a.w >= 24 &&
-            ((reinterpret_cast<uintptr_t>(src_base) | (uintptr_t)src_stride | (uintptr_t)(src_step & 3)) & 3u) == 0) {
+        if (down && !a.write_grad && !no_direct && a.w >= 24 &&
+            ((reinterpret_cast<uintptr_t>(a.src_base) | (uintptr_t)a.src_stride | (uintptr_t)(a.src_step & 3)) & 3u) == 0) {
             DownL0Args d{};
             d.src_base = a.src_base; d.src_step = a.src_step; d.src_stride = a.src_stride; d.src_by_slot = a.src_by_slot;
             d.slots = slots_dev; d.slab = c->slab; d.slot_bytes = L.slot_bytes; d.goff_next = a.goff_next; d.gstride_next = a.gstride_next;
@@ -708,7 +710,7 @@ int launch_pyramid_levels(Ctx *c, int n, const int *slots_dev, const uint8_t *sr
             if (a.w % 8 == 0 && a.w >= 32) { d.edge_shift = 1; d.g_lo = 0; d.n_gi = d.groups; }
             d.nrp = (a.hn + 1) / 2;
             d.wgs_per_img = (d.groups * d.nrp + 255) / 256;
-            d.l0_ptr = c->d_l0_ptr; d.l0_stride = c->d_l0_stride;
+            d.l0_ptr = a.l0_ptr; d.l0_stride = a.l0_stride;
             hipLaunchKernelGGL(pyr_down_l0_kernel, dim3((unsigned)(d.wgs_per_img * n)), dim3(256), 0, c->stream, d);
             HV_HIP(c, hipGetLastError());
             continue;

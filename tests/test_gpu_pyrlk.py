@@ -349,10 +349,11 @@ def test_two_contexts_interleaved_are_independent(oracle):
 
 
 def test_level0_gradients_formed_in_the_lk_kernel_equal_the_stored_plane(oracle, seq752, monkeypatch):
-    """Default: the pyramid build does not write the level-0 gradient plane, the LK kernel forms the Scharr gradients of its
-    template window from the gray rows (klt.hip scharr_row). HV_L0_GRADIENTS=1 stores the plane as cv::buildOpticalFlowPyramid
-    does (image_pyramid.cpp:40-48). Both equal the oracle bit for bit -- windows inside the image, on every border, beyond it --
-    and the read-back of the level-0 gradients (getGradientLevel) is served in both layouts."""
+    """Default: the pyramid build does not write the gradient planes of levels 0 and 1, the LK kernel forms the Scharr gradients
+    of its template window from the gray rows (klt.hip scharr_row). HV_GRAD_FROM_LEVEL=0 stores every plane as
+    cv::buildOpticalFlowPyramid does (image_pyramid.cpp:40-48), =1 all but level 0. All equal the oracle bit for bit -- windows
+    inside the image, on every border, beyond it -- and the read-back of the gradients (getGradientLevel) is served in every
+    layout."""
     left, _, _ = seq752
     rng = np.random.default_rng(5)
     pts = np.concatenate([synth.grid_points(752, 480, 200, margin=2, seed=9),
@@ -360,12 +361,13 @@ def test_level0_gradients_formed_in_the_lk_kernel_equal_the_stored_plane(oracle,
                           np.array([[0.5, 0.5], [1, 1], [16, 16], [735, 463], [736.2, 464.7], [750.5, 478.5], [17.3, 240], [734.9, 3]], np.float32)])
     r0, r2 = oracle.Pyramid(left[0]), oracle.Pyramid(left[2])
     out = {}
-    for stored in ("0", "1"):
-        monkeypatch.setenv("HV_L0_GRADIENTS", stored)
+    for stored in ("0", "1", "2"):
+        monkeypatch.setenv("HV_GRAD_FROM_LEVEL", stored)
         with _ctx(752, 480) as ctx:
             s0, s2 = ctx.acquire(), ctx.acquire()
             ctx.build(s0, left[0]); ctx.build(s2, left[2])
             _check_pyramid(ctx, oracle, left[0], s0)
             out[stored] = _compare_klt(ctx, oracle, r0, r2, s0, s2, pts)
-    np.testing.assert_array_equal(out["0"][0], out["1"][0])
-    np.testing.assert_array_equal(out["0"][1], out["1"][1])
+    for k in ("1", "2"):
+        np.testing.assert_array_equal(out["0"][0], out[k][0])
+        np.testing.assert_array_equal(out["0"][1], out[k][1])
