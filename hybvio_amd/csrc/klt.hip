@@ -45,7 +45,7 @@ constexpr int GRAY_SHIFT = 7;          // gray samples are pre-scaled by 128 (<=
 // dot2 chain starts from 0. Gradients are stored as 4*d + 2 for the same reason (pyramid.hip).
 constexpr uint32_t ROUND_PAIR = 0x00020002u;
 constexpr int W_BITS = 14;
-constexpr int KLT_TILE_DEFAULT = 1;   // 5 (96 VGPRs) spills 3 dwords to scratch: after a kernel with a large scratch frame ran on the queue (vu_prepare) it lost 35 % (bench r02)
+constexpr int KLT_TILE_DEFAULT = 5;   // 40 x 36 tile at 5 waves per SIMD (96 VGPRs, 7 dwords of loop-invariant lane constants in scratch, reloaded once per level): -4 % against the 4-wave build of the same tile (bench r02, C2 and C3 legs)
 
 struct KltArgs {
     PyrLayout L;
@@ -195,9 +195,10 @@ __global__ __launch_bounds__(64, WPS) void klt_kernel(KltArgs a)
     const int st_loff = st_lr * TSX + 4 * st_c;
     const float half_win = (float)(WIN - 1) * 0.5f;
     const float FLT_SCALE = 1.f / (float)(1 << 20);
-    const float eps_lo = (float)(a.epsilon * (1.0 - 1e-5)), eps_hi = (float)(a.epsilon * (1.0 + 1e-5));
-    // pixel (cx, half*16 + k) exists for k < 16 (half 0) / k < 15 (half 1) and cx < 31
-    const uint32_t last_ok = (col_ok && !half) ? 1u : 0u;
+    // uniform: pinned to SGPRs (the f64 -> f32 conversions are VALU instructions; left alone their results occupy two VGPRs for the
+    // whole kernel, and the 5-waves-per-SIMD build has none to spare)
+    const float eps_lo = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint((float)(a.epsilon * (1.0 - 1e-5)))));
+    const float eps_hi = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint((float)(a.epsilon * (1.0 + 1e-5)))));
     int st = 1;
     float errv = 0.f;
     float nx = 0.f, ny = 0.f;
@@ -644,7 +645,13 @@ __global__ __launch_bounds__(64, WPS) void klt_kernel(KltArgs a)
                 const uint32_t *jrow = jt + (iny - toy + half * HALF_ROWS) * TSX + (inx - tox + cx);
                 uint32_t jp = jrow[0];
                 int sabs = 0;
-                const uint32_t ones = col_ok ? 0x00010001u : 0u;
+                // pixel (cx, half*16 + k) exists for k < 16 (half 0) / k < 15 (half 1) and cx < 31. Derived here from an opaque copy
+                // of the lane id: hoisted to the kernel prologue these masks stay live across the whole level loop
+                int ln = lane;
+                asm volatile("" : "+v"(ln));
+                const bool ok_e = (ln & 31) < WIN;
+                const uint32_t ones = ok_e ? 0x00010001u : 0u;
+                const uint32_t last_ok = (ok_e && ln < 32) ? 1u : 0u;
 #pragma unroll
                 for (int m = 0; m < HALF_ROWS / 2; ++m) {
                     const uint32_t r1 = jrow[(2 * m + 1) * TSX], r2 = jrow[(2 * m + 2) * TSX];
