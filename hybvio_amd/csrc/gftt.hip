@@ -31,6 +31,7 @@ struct GfttArgs {
     int w, h, nbx, nby;
     float k0, k1, min_response;
     float *kp;                        // [n_images][nby * nbx][3] = x, y, response
+    int n_images;
 };
 
 // total order of the reference's raster scan with strict '>': higher response wins, ties -> lower index
@@ -177,6 +178,144 @@ __global__ __launch_bounds__(256) void gftt_block_kernel(GfttArgs a)
     }
 }
 
+#ifndef GFTT_MARCH_UNROLL
+#define GFTT_MARCH_UNROLL 2
+#endif
+
+// ---- r02: the same arithmetic without LDS or barriers. A thread owns a strip of 4 columns of one arg-max block and marches
+// down its BS + 2 product rows: the horizontal Sobel pieces (difference d, smoothed value s) of a gray row are formed once
+// and slide through a 3-row register window, the row sums of the three product images slide through a second one, so every
+// gray row is loaded once per strip (8 bytes, next row requested one step ahead) and every intermediate is computed once
+// (the tiled kernel above re-forms the horizontal pieces three times and moves 72 bytes of LDS per pixel: 105 VALU
+// instructions per pixel measured, and it is VALU-issue bound). The NS = BS / 4 strips of a block are consecutive lanes: the
+// block arg-max is a 3-step lane exchange. Blocks on the first / last image rows evaluate each product row at its mirrored
+// centre with three fresh gray rows (no sliding); columns outside the image mirror inside the strip, as above.
+template <int BS>
+__global__ __launch_bounds__(256) void gftt_march_kernel(GfttArgs a)
+{
+    constexpr int NS = BS / 4;
+    const int blocks = a.nbx * a.nby;
+    const unsigned wg = xcd_remap(blockIdx.x, gridDim.x);
+    const long long gid = (long long)wg * 256 + threadIdx.x;
+    const long long total = (long long)a.n_images * blocks * NS;
+    const bool live = gid < total;
+    const long long gidc = live ? gid : total - 1;
+    const int sx = (int)(gidc % NS);
+    const long long bg = gidc / NS;
+    const int img = (int)(bg / blocks), bi = (int)(bg - (long long)img * blocks);
+    const int yb = bi / a.nbx, xb = bi - yb * a.nbx;
+    const int x0 = xb * BS, y0 = yb * BS, w = a.w, h = a.h;
+    const int slot = a.slots ? a.slots[img] : a.slot0;
+    const uint8_t *src = a.l0_ptr[slot];
+    const int stride = a.l0_stride[slot];
+    const float k0 = a.k0, k1 = a.k1;
+
+    const int xs = x0 - 2 + 4 * sx;                                   // image column of byte 0 of this strip's 8-byte row segment
+    const bool col_in = xs >= 0 && xs + 8 <= w;
+    int cxr[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) cxr[k] = reflect101(xs + k, w);
+    auto load_row = [&](int gr) -> uint2 {                            // gray row gr (inside the image), columns xs .. xs + 7
+        const uint8_t *row = src + (size_t)gr * stride;
+        uint2 v;
+        if (col_in) {
+            __builtin_memcpy(&v, row + xs, 8);
+        } else {
+            v.x = v.y = 0;
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                v.x |= (uint32_t)row[cxr[k]] << (8 * k);
+                v.y |= (uint32_t)row[cxr[4 + k]] << (8 * k);
+            }
+        }
+        return v;
+    };
+    struct HRow { float d[6], s[6]; };
+    auto hrow = [&](uint2 v) -> HRow {
+        float g[8];
+#pragma unroll
+        for (int k = 0; k < 4; k++) { g[k] = (float)((v.x >> (8 * k)) & 0xFFu); g[4 + k] = (float)((v.y >> (8 * k)) & 0xFFu); }
+        HRow o;
+#pragma unroll
+        for (int k = 0; k < 6; k++) {
+            o.d[k] = g[k + 2] - g[k];
+            o.s[k] = k0 * g[k + 1] + k1 * (g[k] + g[k + 2]);
+        }
+        return o;
+    };
+
+    // rows y0 - 2 .. y0 + BS + 1 all exist: consecutive centres, the window slides
+    const bool slide = y0 >= 2 && y0 + BS + 1 <= h - 1;
+    const bool mirror_l = sx == 0 && x0 == 0, mirror_r = sx == NS - 1 && x0 + BS == w;
+    HRow up, mid, dn;
+    float4v rsA[3], rsB[3];                                          // row sums of product rows ry - 2, ry - 1
+    float best_r = -1e10f;
+    int best_i = 0;
+    uint2 nxt = make_uint2(0, 0);
+    if (slide) {
+        up = hrow(load_row(y0 - 2));
+        mid = hrow(load_row(y0 - 1));
+        nxt = load_row(y0);
+    }
+#pragma unroll GFTT_MARCH_UNROLL
+    for (int ry = -1; ry <= BS; ++ry) {
+        if (slide) {
+            if (ry > -1) { up = mid; mid = dn; }
+            dn = hrow(nxt);
+            if (ry < BS) nxt = load_row(y0 + ry + 2);                 // the row the next step appends
+        } else {
+            const int cy = reflect101(y0 + ry, h);
+            const uint2 ru = load_row(reflect101(cy - 1, h)), rm = load_row(cy), rd = load_row(reflect101(cy + 1, h));
+            up = hrow(ru); mid = hrow(rm); dn = hrow(rd);
+        }
+        float c0[6], c1[6], c2[6];
+#pragma unroll
+        for (int k = 0; k < 6; k++) {
+            const float vx = k0 * mid.d[k] + k1 * (up.d[k] + dn.d[k]);
+            const float vy = dn.s[k] - up.s[k];
+            c0[k] = vx * vx; c1[k] = vx * vy; c2[k] = vy * vy;
+        }
+        if (mirror_l) { c0[0] = c0[2]; c1[0] = c1[2]; c2[0] = c2[2]; }
+        if (mirror_r) { c0[5] = c0[3]; c1[5] = c1[3]; c2[5] = c2[3]; }
+        float4v r[3];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            r[0][k] = (c0[k] + c0[k + 1]) + c0[k + 2];
+            r[1][k] = (c1[k] + c1[k + 1]) + c1[k + 2];
+            r[2][k] = (c2[k] + c2[k + 1]) + c2[k + 2];
+        }
+        if (ry >= 1) {
+            const int y = ry - 1;
+            float4v sm[3];
+#pragma unroll
+            for (int ch = 0; ch < 3; ch++) sm[ch] = (rsA[ch] + rsB[ch]) + r[ch];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const float aa = sm[0][k] * 0.5f, bb = sm[1][k], cc = sm[2][k] * 0.5f, amc = aa - cc;
+                const float resp = (aa + cc) - sqrtf(amc * amc + bb * bb);
+                const float r16 = resp * 16.0f;                          // CpuCornerResponse::GAIN
+                if (r16 > best_r && r16 > a.min_response) { best_r = r16; best_i = y * BS + 4 * sx + k; }
+            }
+        }
+#pragma unroll
+        for (int ch = 0; ch < 3; ch++) { rsA[ch] = rsB[ch]; rsB[ch] = r[ch]; }
+    }
+    // the NS strips of a block are NS consecutive lanes (NS divides 64): butterfly over them
+#pragma unroll
+    for (int o = 1; o < NS; o <<= 1) {
+        const float ro = __shfl_xor(best_r, o);
+        const int io = __shfl_xor(best_i, o);
+        if (better(ro, io, best_r, best_i)) { best_r = ro; best_i = io; }
+    }
+    if (live && sx == 0) {
+        const bool found = best_r > -1e10f;
+        float *o = a.kp + ((size_t)img * blocks + bi) * 3;
+        o[0] = found ? (float)(x0 + best_i % BS) : 0.f;
+        o[1] = found ? (float)(y0 + best_i / BS) : 0.f;
+        o[2] = best_r;
+    }
+}
+
 int launch(Ctx *c, int n_images, const int *slots_dev, int slot0, int bs, float min_response, int block_size, float *kp_dev)
 {
     if (block_size != 3) return HV_ERR_UNSUPPORTED;             // the reference default (gfttBlockSize 3); other box sizes: oracle only
@@ -189,7 +328,20 @@ int launch(Ctx *c, int n_images, const int *slots_dev, int slot0, int bs, float 
     a.min_response = min_response; a.kp = kp_dev;
     const unsigned grid = (unsigned)(a.nbx * a.nby * n_images);
     if (grid == 0) return HV_OK;
+    a.n_images = n_images;
     ScopedKernelTime tm(c, HV_K_GFTT);
+    // HV_GFTT_TILED (environment, experiments only): 1 = the LDS-tiled r01 kernel (one workgroup per block)
+    static const bool tiled = [] { const char *e = getenv("HV_GFTT_TILED"); return e && atoi(e) != 0; }();
+    if (!tiled && a.w >= 8 && a.h >= 3) {
+        const long long threads = (long long)grid * (bs / 4);
+        const unsigned wgs = (unsigned)((threads + 255) / 256);
+        if (bs == 32)      hipLaunchKernelGGL(gftt_march_kernel<32>, dim3(wgs), dim3(256), 0, c->stream, a);
+        else if (bs == 16) hipLaunchKernelGGL(gftt_march_kernel<16>, dim3(wgs), dim3(256), 0, c->stream, a);
+        else if (bs == 8)  hipLaunchKernelGGL(gftt_march_kernel<8>, dim3(wgs), dim3(256), 0, c->stream, a);
+        else return HV_ERR_INVALID;
+        HV_HIP(c, hipGetLastError());
+        return HV_OK;
+    }
     if (bs == 32)      hipLaunchKernelGGL(gftt_block_kernel<32>, dim3(grid), dim3(256), 0, c->stream, a);
     else if (bs == 16) hipLaunchKernelGGL(gftt_block_kernel<16>, dim3(grid), dim3(256), 0, c->stream, a);
     else if (bs == 8)  hipLaunchKernelGGL(gftt_block_kernel<8>, dim3(grid), dim3(256), 0, c->stream, a);
