@@ -179,7 +179,7 @@ __global__ __launch_bounds__(256) void gftt_block_kernel(GfttArgs a)
 }
 
 #ifndef GFTT_MARCH_UNROLL
-#define GFTT_MARCH_UNROLL 2
+#define GFTT_MARCH_UNROLL 2   // 6 removes the window moves but needs 147 VGPRs (3 waves per SIMD): 0.93 ms against 0.84
 #endif
 
 // ---- r02: the same arithmetic without LDS or barriers. A thread owns a strip of 4 columns of one arg-max block and marches
