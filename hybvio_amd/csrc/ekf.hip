@@ -149,6 +149,7 @@ __global__ __launch_bounds__(256) void ekf_predict_kernel(PredictArgs a)
 {
     __shared__ double F[INER * INER], Lm[INER * QD], Qs[QD * QD], LQ[INER * QD], P00[INER * INER], FP[INER * INER];
     __shared__ double Phi[INER * INER], PhiN[INER * INER];
+    __shared__ double ms[INER], sh[112];           // the inertial part of the mean; stage values of the mean / F / L section
     const int b = blockIdx.x, t = threadIdx.x, n = a.n;
     double *m = a.m + (size_t)b * n, *P = a.P + (size_t)b * n * n, *Q = a.Q + (size_t)b * QD * QD;
     // nsteps IMU samples in one launch: the mean / Jacobian chain and the 20 x 20 block recursion
@@ -183,6 +184,7 @@ __global__ __launch_bounds__(256) void ekf_predict_kernel(PredictArgs a)
     }
     for (int i = t; i < INER * INER; i += 256) { Phi[i] = (i % (INER + 1) == 0) ? 1.0 : 0.0; P00[i] = P[(size_t)(i / INER) * n + (i % INER)]; }
     for (int i = t; i < QD * QD; i += 256) Qs[i] = Q[i];
+    if (t < INER) ms[t] = m[t];
 
     double exp_dt = -1.0, e_baa2 = 1.0, e_bga2 = 1.0, e_baa1 = 1.0, e_bga1 = 1.0;     // thread 0 only
     for (int step = 0; step < a.nsteps; step++) {
@@ -194,9 +196,15 @@ __global__ __launch_bounds__(256) void ekf_predict_kernel(PredictArgs a)
     for (int i = t; i < INER * QD; i += 256) Lm[i] = 0.0;
     __syncthreads();
 
+    // ---- mean, F and L of this sample (ekf.cpp:370-503). r01 ran this section on thread 0 (~1.5 k dependent f64 instructions,
+    // half of a sample's time); here every ELEMENT is still evaluated by one lane with the reference's expression and summation
+    // order -- results are unchanged -- but the elements of a stage are spread over the lanes of the workgroup, with a barrier
+    // where a stage reads what the previous one wrote. Stage scalars and small matrices live in `sh`.
+    double *const sA = sh, *const sSrow = sh + 16, *const sqn = sh + 32, *const sprevQ = sh + 36, *const sR = sh + 40,
+           *const sdR = sh + 49, *const sTxab = sh + 85, *const sT34 = sh + 88, *const sxa = sh + 100, *const ssc = sh + 103;
     if (t == 0) {
-        double xg[3], xa[3];
-        for (int i = 0; i < 3; i++) { xg[i] = a.gyro ? a.gyro[3 * sb + i] : a.g0[i]; xa[i] = a.acc ? a.acc[3 * sb + i] : a.a0[i]; }
+        double xg[3];
+        for (int i = 0; i < 3; i++) { xg[i] = a.gyro ? a.gyro[3 * sb + i] : a.g0[i]; sxa[i] = a.acc ? a.acc[3 * sb + i] : a.a0[i]; }
         // the four exponentials of a sample depend on dt only: evaluated when dt changes (IMU samples are equally spaced as a
         // rule, so once per launch), the same values as the per-sample evaluation
         if (dt != exp_dt) {
@@ -205,6 +213,7 @@ __global__ __launch_bounds__(256) void ekf_predict_kernel(PredictArgs a)
             e_bga2 = a.bga_rev > 0.0 ? (1 - exp(-2 * dt * a.bga_rev)) / (2 * a.bga_rev) : 1.0;
             e_baa1 = exp(-dt * a.baa_rev); e_bga1 = exp(-dt * a.bga_rev);
         }
+        ssc[2] = e_baa1; ssc[3] = e_bga1;
         if (a.baa > 0.0) {                          // ekf.cpp:397-404
             double v = a.noise_scale * a.baa * a.baa;
             if (a.baa_rev > 0.0) v *= e_baa2;
@@ -216,47 +225,110 @@ __global__ __launch_bounds__(256) void ekf_predict_kernel(PredictArgs a)
             for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) Qs[(Q_BGA_DRIFT + j) * QD + Q_BGA_DRIFT + i] = (i == j) ? v : 0.0;
         }
         // A = exp(-dt/2 Omega(w)) = cos(th) I + sin(th)/th S, th = |w| dt/2   (ekf.cpp:415-425)
-        const double w[3] = { xg[0] - m[BGA], xg[1] - m[BGA + 1], xg[2] - m[BGA + 2] };
+        const double w[3] = { xg[0] - ms[BGA], xg[1] - ms[BGA + 1], xg[2] - ms[BGA + 2] };
         const double Srow[16] = { 0, -w[0], -w[1], -w[2],  w[0], 0, -w[2], w[1],  w[1], w[2], 0, -w[0],  w[2], -w[1], w[0], 0 };
-        double A[16];                               // column-major 4x4
-        {
-            const double th = sqrt(w[0]*w[0] + w[1]*w[1] + w[2]*w[2]) * dt / 2;
-            const double c = cos(th), sc = th > 1e-8 ? sin(th) / th : 1.0 - th * th / 6.0;
-            for (int i = 0; i < 4; i++) for (int j = 0; j < 4; j++) A[4 * j + i] = sc * Srow[4 * i + j] * (-dt / 2) + (i == j ? c : 0.0);
+#pragma unroll
+        for (int i = 0; i < 16; i++) sSrow[i] = Srow[i];
+        const double th = sqrt(w[0]*w[0] + w[1]*w[1] + w[2]*w[2]) * dt / 2;
+        ssc[0] = cos(th); ssc[1] = th > 1e-8 ? sin(th) / th : 1.0 - th * th / 6.0;
+    }
+    __syncthreads();
+    {   // stage B: A (column-major 4x4), the previous quaternion, T xa - ba, the position
+        const double c = ssc[0], sc = ssc[1];
+        if (t < 16) { const int i = t & 3, j = t >> 2; sA[4 * j + i] = sc * sSrow[4 * i + j] * (-dt / 2) + (i == j ? c : 0.0); }
+        else if (t < 20) sprevQ[t - 16] = ms[ORI + t - 16];
+        else if (t >= 32 && t < 35) { const int i = t - 32; sTxab[i] = ms[BAT + i] * sxa[i] - ms[BAA + i]; }
+        else if (t >= 40 && t < 43) { const int i = t - 40; ms[POS + i] += ms[VEL + i] * dt; }
+    }
+    __syncthreads();
+    if (t < 4) { double s_ = 0; for (int j = 0; j < 4; j++) s_ += sA[4 * j + t] * sprevQ[j]; sqn[t] = s_; }
+    __syncthreads();
+    {   // stage D: R(q) and dR/dq (util.cpp:10-47, column-major): one element per lane
+        const double q0 = sqn[0], q1 = sqn[1], q2 = sqn[2], q3 = sqn[3];
+        if (t < 9) {
+            const int i = t / 3, j = t - 3 * i;                 // Rr[3 i + j] -> R[3 j + i]
+            double v;
+            switch (t) {
+                case 0: v = q0*q0+q1*q1-q2*q2-q3*q3; break;
+                case 1: v = 2*q1*q2 - 2*q0*q3; break;
+                case 2: v = 2*q1*q3 + 2*q0*q2; break;
+                case 3: v = 2*q1*q2 + 2*q0*q3; break;
+                case 4: v = q0*q0-q1*q1+q2*q2-q3*q3; break;
+                case 5: v = 2*q2*q3 - 2*q0*q1; break;
+                case 6: v = 2*q1*q3 - 2*q0*q2; break;
+                case 7: v = 2*q2*q3 + 2*q0*q1; break;
+                default: v = q0*q0-q1*q1-q2*q2+q3*q3; break;
+            }
+            sR[3 * j + i] = v;
+        } else if (t >= 64 && t < 100) {
+            // rows[k][3 i + j] = sign * 2 q[idx]: two bits of index and one of sign per entry
+            const int e = t - 64, k = e / 9, ij = e - 9 * k, i = ij / 3, j = ij - 3 * i;
+            constexpr unsigned char IDX[4][9] = { {0,3,2, 3,0,1, 2,1,0}, {1,2,3, 2,1,0, 3,0,1}, {2,1,0, 1,2,3, 0,3,2}, {3,0,1, 0,3,2, 1,2,3} };
+            constexpr signed char SGN[4][9] = { {1,-1,1, 1,1,-1, -1,1,1}, {1,1,1, 1,-1,-1, 1,1,-1}, {-1,1,1, 1,1,1, -1,1,-1}, {-1,-1,1, 1,-1,1, 1,1,1} };
+            const int id = IDX[k][ij];
+            const double qv = id == 0 ? q0 : id == 1 ? q1 : id == 2 ? q2 : q3;
+            sdR[9 * k + 3 * j + i] = SGN[k][ij] > 0 ? 2 * qv : -2 * qv;
         }
-        double qn[4], R[9], dR[36], prevQ[4];
-        for (int i = 0; i < 4; i++) { double s = 0; for (int j = 0; j < 4; j++) s += A[4 * j + i] * m[ORI + j]; qn[i] = s; prevQ[i] = m[ORI + i]; }
-        quat2rmat_d(qn, R, dR);
-        double Txab[3];
-        for (int i = 0; i < 3; i++) Txab[i] = m[BAT + i] * xa[i] - m[BAA + i];
-        for (int i = 0; i < 3; i++) m[POS + i] += m[VEL + i] * dt;
-        const double grav[3] = { 0.0, 0.0, -a.gravity };
-        for (int i = 0; i < 3; i++) { double s = 0; for (int j = 0; j < 3; j++) s += R[3 * i + j] * Txab[j]; m[VEL + i] += (s + grav[i]) * dt; }
-        for (int i = 0; i < 4; i++) m[ORI + i] = qn[i];
-        if (a.baa > 0.0) { const double f = e_baa1; for (int i = 0; i < 3; i++) m[BAA + i] *= f; }
-        if (a.bga > 0.0) { const double f = e_bga1; for (int i = 0; i < 3; i++) m[BGA + i] *= f; }
-
-        for (int i = 0; i < 3; i++) F_(POS + i, VEL + i) = dt;
-        double T34[12];
-        for (int k = 0; k < 4; k++) for (int i = 0; i < 3; i++) { double s = 0; for (int j = 0; j < 3; j++) s += dR[9 * k + 3 * i + j] * Txab[j]; T34[3 * k + i] = s * dt; }
-        for (int i = 0; i < 3; i++) for (int j = 0; j < 4; j++) { double s = 0; for (int k = 0; k < 4; k++) s += T34[3 * k + i] * A[4 * j + k]; F_(VEL + i, ORI + j) = s; }
-        for (int i = 0; i < 4; i++) for (int j = 0; j < 4; j++) F_(ORI + i, ORI + j) = A[4 * j + i];
-        for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) L_(VEL + i, Q_ACC + j) = R[3 * i + j] * dt;
-        const double h = dt / 2;
-        const double dS[3][16] = {
-            { 0, h, 0, 0,  -h, 0, 0, 0,  0, 0, 0, h,  0, 0, -h, 0 },
-            { 0, 0, h, 0,  0, 0, 0, -h,  -h, 0, 0, 0,  0, h, 0, 0 },
-            { 0, 0, 0, h,  0, 0, h, 0,  0, -h, 0, 0,  -h, 0, 0, 0 } };
-        for (int g = 0; g < 3; g++) {
+    }
+    __syncthreads();
+    {   // stage E: the rest of the mean; the entries of F and L that depend on R, dR, A only
+        if (t < 3) {
+            const int i = t;
+            const double grav = i == 2 ? -a.gravity : 0.0;
+            double s_ = 0; for (int j = 0; j < 3; j++) s_ += sR[3 * i + j] * sTxab[j];
+            ms[VEL + i] += (s_ + grav) * dt;
+            F_(POS + i, VEL + i) = dt;
+            L_(BGA + i, Q_BGA_DRIFT + i) = 1.0; L_(BAA + i, Q_BAA_DRIFT + i) = 1.0;
+        } else if (t >= 4 && t < 8) ms[ORI + t - 4] = sqn[t - 4];
+        else if (t >= 8 && t < 11) { if (a.baa > 0.0) ms[BAA + t - 8] *= ssc[2]; }
+        else if (t >= 12 && t < 15) { if (a.bga > 0.0) ms[BGA + t - 12] *= ssc[3]; }
+        else if (t >= 16 && t < 28) {
+            const int e = t - 16, k = e / 3, i = e - 3 * k;
+            double s_ = 0; for (int j = 0; j < 3; j++) s_ += sdR[9 * k + 3 * i + j] * sTxab[j];
+            sT34[3 * k + i] = s_ * dt;
+        } else if (t >= 32 && t < 44) {
+            const int e = t - 32, g = e >> 2, i = e & 3;
+            const double h = dt / 2;
+            const double dS[3][16] = {
+                { 0, h, 0, 0,  -h, 0, 0, 0,  0, 0, 0, h,  0, 0, -h, 0 },
+                { 0, 0, h, 0,  0, 0, 0, -h,  -h, 0, 0, 0,  0, h, 0, 0 },
+                { 0, 0, 0, h,  0, 0, h, 0,  0, -h, 0, 0,  -h, 0, 0, 0 } };
             double t1[4];
-            for (int i = 0; i < 4; i++) { double s = 0; for (int j = 0; j < 4; j++) s += dS[g][4 * i + j] * prevQ[j]; t1[i] = s; }
-            for (int i = 0; i < 4; i++) { double s = 0; for (int j = 0; j < 4; j++) s += A[4 * j + i] * t1[j]; L_(ORI + i, Q_GYRO + g) = s; }
+#pragma unroll
+            for (int ii = 0; ii < 4; ii++) {
+                double s_ = 0;
+#pragma unroll
+                for (int j = 0; j < 4; j++) { const double d = g == 0 ? dS[0][4 * ii + j] : g == 1 ? dS[1][4 * ii + j] : dS[2][4 * ii + j]; s_ += d * sprevQ[j]; }
+                t1[ii] = s_;
+            }
+            double s_ = 0;
+#pragma unroll
+            for (int j = 0; j < 4; j++) s_ += sA[4 * j + i] * t1[j];
+            L_(ORI + i, Q_GYRO + g) = s_;
+        } else if (t >= 48 && t < 57) {
+            const int e = t - 48, i = e / 3, j = e - 3 * i;
+            L_(VEL + i, Q_ACC + j) = sR[3 * i + j] * dt;
+            F_(VEL + i, BAA + j) = -sR[3 * i + j] * dt; F_(VEL + i, BAT + j) = sR[3 * i + j] * sxa[j] * dt;
+        } else if (t >= 64 && t < 80) {
+            const int e = t - 64, i = e & 3, j = e >> 2;
+            F_(ORI + i, ORI + j) = sA[4 * j + i];
         }
-        for (int i = 0; i < 3; i++) { L_(BGA + i, Q_BGA_DRIFT + i) = 1.0; L_(BAA + i, Q_BAA_DRIFT + i) = 1.0; }
-        for (int i = 0; i < 3; i++) for (int g = 0; g < 3; g++) { double s = 0; for (int k = 0; k < 4; k++) s += F_(VEL + i, ORI + k) * L_(ORI + k, Q_GYRO + g); L_(VEL + i, Q_GYRO + g) = s; }
-        for (int i = 0; i < 3; i++) for (int g = 0; g < 3; g++) F_(VEL + i, BGA + g) = -L_(VEL + i, Q_GYRO + g);
-        for (int i = 0; i < 4; i++) for (int g = 0; g < 3; g++) F_(ORI + i, BGA + g) = -L_(ORI + i, Q_GYRO + g);
-        for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) { F_(VEL + i, BAA + j) = -R[3 * i + j] * dt; F_(VEL + i, BAT + j) = R[3 * i + j] * xa[j] * dt; }
+    }
+    __syncthreads();
+    if (t < 12) {
+        const int i = t / 4, j = t - 4 * i;
+        double s_ = 0; for (int k = 0; k < 4; k++) s_ += sT34[3 * k + i] * sA[4 * j + k];
+        F_(VEL + i, ORI + j) = s_;
+    }
+    __syncthreads();
+    if (t < 9) {
+        const int i = t / 3, g = t - 3 * i;
+        double s_ = 0; for (int k = 0; k < 4; k++) s_ += F_(VEL + i, ORI + k) * L_(ORI + k, Q_GYRO + g);
+        L_(VEL + i, Q_GYRO + g) = s_;
+        F_(VEL + i, BGA + g) = -s_;
+    } else if (t >= 16 && t < 28) {
+        const int e = t - 16, i = e / 3, g = e - 3 * i;
+        F_(ORI + i, BGA + g) = -L_(ORI + i, Q_GYRO + g);
     }
     __syncthreads();
 
@@ -286,6 +358,7 @@ __global__ __launch_bounds__(256) void ekf_predict_kernel(PredictArgs a)
     __syncthreads();
     for (int i = t; i < INER * INER; i += 256) { P[(size_t)(i / INER) * n + (i % INER)] = P00[i]; a.dydx[(size_t)b * INER * INER + i] = F[i]; }
     for (int i = t; i < QD * QD; i += 256) Q[i] = Qs[i];
+    if (t < INER) m[t] = ms[t];
     PHASE_STAMP(14);
     {
         // F operand (the product Phi of the steps' F), shared by every item: lane (kq, cl) holds Phi(cl + 16 tt, 4 s + kq). It is the A operand
