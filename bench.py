@@ -58,7 +58,7 @@ def algorithmic_bytes(w=None, h=None, npts=None):
     pyr_l0 = pyr_l0_ref if L0_GRADIENTS_STORED else px[0] + (px[1] if len(px) > 1 else 0)
     klt_point_level = 32 * 32 * 1 + 32 * 32 * 4 + 32 * 32 * 1     # I + dI + J windows, first touch
     klt_call = npts * len(ls) * klt_point_level
-    return dict(pyr_image=pyr_image, pyr_l0=pyr_l0, pyr_ln=pyr_image - pyr_l0_ref, klt_call=klt_call,
+    return dict(pyr_image=pyr_image, pyr_l0=pyr_l0, pyr_l0_ref=pyr_l0_ref, pyr_ln=pyr_image - pyr_l0_ref, klt_call=klt_call,
                 stereo_frame=2 * pyr_image + 2 * klt_call)
 
 

@@ -330,8 +330,12 @@ int launch(Ctx *c, int n_images, const int *slots_dev, int slot0, int bs, float 
     if (grid == 0) return HV_OK;
     a.n_images = n_images;
     ScopedKernelTime tm(c, HV_K_GFTT);
-    // HV_GFTT_TILED (environment, experiments only): 1 = the LDS-tiled r01 kernel (one workgroup per block)
-    static const bool tiled = [] { const char *e = getenv("HV_GFTT_TILED"); return e && atoi(e) != 0; }();
+    // The marching kernel is the throughput design (a thread walks 34 dependent steps); for a handful of images the LDS-tiled
+    // kernel (one workgroup per block, 256 threads side by side) finishes sooner -- 25 us per frame in the bench latency leg.
+    // HV_GFTT_TILED (environment, experiments only): 1 / 0 forces the tiled / the marching kernel.
+    const char *env_tiled = getenv("HV_GFTT_TILED");                 // read per call: the tests switch it
+    const int force_tiled = env_tiled ? atoi(env_tiled) : -1;
+    const bool tiled = force_tiled >= 0 ? force_tiled != 0 : n_images < 128;
     if (!tiled && a.w >= 8 && a.h >= 3) {
         const long long threads = (long long)grid * (bs / 4);
         const unsigned wgs = (unsigned)((threads + 255) / 256);

@@ -42,6 +42,8 @@ def test_algorithmic_byte_accounting():
     ab = bench.algorithmic_bytes()
     # SURVEY.md section 8(d)
     assert ab["pyr_image"] == 2_397_000 and ab["klt_call"] == 4_915_200 and ab["stereo_frame"] == 14_624_400
-    assert ab["pyr_l0"] + ab["pyr_ln"] == ab["pyr_image"]
+    assert ab["pyr_l0_ref"] + ab["pyr_ln"] == ab["pyr_image"]
+    # the level-0 launch's own bytes: the level-0 gradient plane is not stored by default (the LK kernel forms it)
+    assert ab["pyr_l0"] == (360_960 + 90_240 if not bench.L0_GRADIENTS_STORED else ab["pyr_l0_ref"])
     big = bench.algorithmic_bytes(1280, 720, 400)
     assert big["pyr_image"] == 6_120_000 and big["stereo_frame"] == 31_900_800

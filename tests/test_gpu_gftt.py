@@ -24,9 +24,13 @@ def _device_keypoints(ctx, slots, params=None):
     return kp.cpu().numpy()[:, :nk]
 
 
+@pytest.mark.parametrize("kernel", ["marching", "tiled"])
 @pytest.mark.parametrize("shape", [(480, 752), (720, 1280), (479, 641), (97, 130), (70, 101), (64, 64)])
 @pytest.mark.parametrize("min_distance", [50.0, 20.0, 8.0])
-def test_keypoints_bit_exact(oracle, shape, min_distance):
+def test_keypoints_bit_exact(oracle, shape, min_distance, kernel, monkeypatch):
+    # two kernels serve the detector: the register-marching one (many images) and the LDS-tiled one (a few); the library
+    # picks by image count, the test forces each
+    monkeypatch.setenv("HV_GFTT_TILED", "1" if kernel == "tiled" else "0")
     rng = np.random.default_rng(shape[0] + int(min_distance))
     imgs = [rng.integers(0, 256, shape, dtype=np.uint8),
             synth.stereo_sequence(3, shape[1], shape[0], 1)[0][0],

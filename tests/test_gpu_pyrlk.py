@@ -30,8 +30,11 @@ def _check_pyramid(ctx, oracle, img, slot):
     return ref
 
 
+@pytest.mark.parametrize("tail", ["fused", "per_level"])
 @pytest.mark.parametrize("shape", [(480, 752), (720, 1280), (479, 641), (70, 101), (33, 65), (97, 64), (256, 260)])
-def test_pyramid_bit_exact(oracle, shape):
+def test_pyramid_bit_exact(oracle, shape, tail, monkeypatch):
+    # levels >= 2 are built by one LDS-resident launch for large batches and by per-level launches otherwise: force each
+    monkeypatch.setenv("HV_PYR_TAIL", "1" if tail == "fused" else "0")
     rng = np.random.default_rng(shape[0] * 7 + shape[1])
     img = rng.integers(0, 256, shape, dtype=np.uint8)
     with _ctx(shape[1], shape[0]) as ctx:
