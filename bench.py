@@ -1118,8 +1118,11 @@ def main():
         torch.cuda.synchronize()
         lat3 = (time.perf_counter() - t0) / n_lat
         out["latency_mode"] = {"sequences": 1, "ms_per_frame": lat3 * 1e3, "frames_per_s": 1.0 / lat3, "launch": "eager",
-                               "launches_per_frame": 5 + 2 + 2 + 2 + 3 * (QUOTA + 1) + 3,
-                               "visual_update_loop": "speculative (hv_ekf_visual_frame_dev with few sequences): <= quota + 1 passes of prepare-all / gate-all / apply-first-inlier"}
+                               # pyramid 4 (L0, L1, L2, L3 + border as one: per-level launches below 64 images) + 2 LK + RANSAC + detector,
+                               # visual update 2 x (quota + 1), symmetrise + augmentation + predicts
+                               "launches_per_frame": 5 + 2 + 1 + 1 + 2 * (QUOTA + 1) + 3,
+                               "visual_update_loop": "speculative (hv_ekf_visual_frame_dev with few sequences): <= quota + 1 passes of prepare-all + one "
+                                                     "launch that gates every pending track and lets the first inlier in visit order apply itself"}
         # The whole frame captured in HIP graphs: period N_CYCLE (camera path, RANSAC draws, GFTT every 2nd frame, the augmentation's
         # discard pattern and the covariance ping-pong all repeat with it), replayed in order
         try:

@@ -505,10 +505,41 @@ struct UpdateArgs {
     // speculative frame loop (small batches, hv_ekf_visual_frame_dev): inputs / outputs are [n_tracks][batch] records
     //   spec 1: grid (batch, n_tracks), chi2 gate of EVERY pending track (index >= cursor[filter]) against the current (m, P)
     //   spec 2: grid (batch): the first pending track whose gate said INLIER is applied (mode 1), cursor moves behind it
+    //   spec 3: spec 1 and spec 2 in ONE launch (mode 3, grid (batch, n_tracks)): every pending track is gated; an inlier then waits
+    //           for the gate results of the pending tracks in front of it (they belong to workgroups with a smaller linear index:
+    //           dispatched earlier, so the wait cannot deadlock) and, if none of them is an inlier, carries on into the update with
+    //           the H P it already holds. The workgroup of the last track closes the pass when nobody applied anything.
     int spec, n_tracks, max_successful;
     int *cursor;                      // [batch] first track of the filter that is not final yet
     const int *gate_in;               // spec 2: [n_tracks][batch] gate results of spec 1 (a.status stays free for this launch's own output)
+    int *cursor_out;                  // spec 3: the cursor after this pass (ping-pong: late workgroups still read the old one)
+    int *pub;                         // spec 3: [n_tracks][batch] published gate decisions, pass_id * 4 + {1 not applicable, 2 inlier}
+    int pass_id;                      // spec 3: > 0, distinct per pass of a frame (pub is zeroed per frame)
 };
+
+// spec 3 hand-shake between the workgroups of one filter (agent scope: they run on different CUs)
+__device__ __forceinline__ void spec_publish(const UpdateArgs &a, int rec, int code)
+{
+    __hip_atomic_store(a.pub + rec, a.pass_id * 4 + code, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+}
+// decision of record `rec` in this pass; bounded spin (0.2 s): a decision that never arrives is reported as -1
+__device__ __forceinline__ int spec_wait(const UpdateArgs &a, int rec)
+{
+    for (int spin = 0; spin < (1 << 20); ++spin) {
+        const int v = __hip_atomic_load(a.pub + rec, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+        if ((v >> 2) == a.pass_id) return v & 3;
+        __builtin_amdgcn_s_sleep(8);
+    }
+    return -1;
+}
+// thread 0 of the workgroup of the LAST track, when that workgroup applies nothing: if no pending track of the filter was an
+// inlier, nobody else moves the cursor -- every pending status is final (or the pass did not run: quota used up)
+__device__ __forceinline__ void spec_close(const UpdateArgs &a, int b, int c0, bool pass_ran)
+{
+    bool any = false;
+    for (int jj = c0; jj < a.n_tracks - 1 && !any; ++jj) any = spec_wait(a, jj * (int)gridDim.x + b) == 2;
+    if (!any) a.cursor_out[b] = pass_ran ? a.n_tracks : c0;
+}
 
 constexpr int UPD_THREADS = 512;   // 8 waves = 2 per SIMD: 256 VGPRs each (whole column blocks of P stay in registers)
 
@@ -543,6 +574,20 @@ __global__ __launch_bounds__(UPD_THREADS) void ekf_update_kernel(UpdateArgs a)
             return;
         }
         e = sel * (int)gridDim.x + b;
+    }
+    int c0_spec = 0;
+    if (a.spec == 3) {
+        const int j = blockIdx.y;
+        c0_spec = a.cursor[b];
+        e = j * (int)gridDim.x + b;
+        const bool pass_runs = c0_spec < a.n_tracks && a.success_counter[b] < a.max_successful;
+        if (!pass_runs || j < c0_spec || !a.active[e]) {      // nothing to gate here: still publish, and close the pass if last
+            if (threadIdx.x == 0) {
+                spec_publish(a, e, 1);
+                if (j == a.n_tracks - 1) spec_close(a, b, c0_spec, pass_runs);
+            }
+            return;
+        }
     }
     if (a.active && !a.active[e]) return;
     if (a.require_inlier && a.require_inlier[b] != 0) return;
@@ -841,6 +886,18 @@ __global__ __launch_bounds__(UPD_THREADS) void ekf_update_kernel(UpdateArgs a)
                 if (a.status) a.status[e] = outlier ? 3 /*CHI2*/ : 0 /*INLIER*/;
             }
             *s_stop = (a.mode == 0) || broken || ((a.mode == 2 || (two_r && pass == 0)) && outlier);
+            if (a.spec == 3 && pass == 0) {
+                const int j = blockIdx.y;
+                spec_publish(a, e, outlier ? 1 : 2);
+                if (!outlier) {                               // first inlier in visit order applies; the others are re-examined next pass
+                    bool lose = false;
+                    for (int jj = c0_spec; jj < j && !lose; ++jj) lose = spec_wait(a, jj * (int)gridDim.x + b) != 1;
+                    if (lose) *s_stop = 1;
+                }
+                if (*s_stop && j == a.n_tracks - 1 && outlier) spec_close(a, b, c0_spec, true);
+            }
+            // the applying workgroup met a non-positive pivot in the second factorisation: nothing is applied, the track is final
+            if (a.spec == 3 && pass == 1 && *s_stop) a.cursor_out[b] = (int)blockIdx.y + 1;
         }
         __syncthreads();
         if (*s_stop) return;
@@ -942,6 +999,7 @@ __global__ __launch_bounds__(UPD_THREADS) void ekf_update_kernel(UpdateArgs a)
     if (t < nq) normalize4(m + (t == 0 ? ORI : CAM + POSE * (t - 1) + 3));
     if (a.success_counter && t == 0) a.success_counter[b] += 1;
     if (a.spec == 2 && t == 0) a.cursor[b] = sel + 1;      // the tracks up to the applied one are final, the rest is re-examined
+    if (a.spec == 3 && t == 0) a.cursor_out[b] = (int)blockIdx.y + 1;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1436,6 +1494,7 @@ struct Ekf {
     double *spH = nullptr, *spv = nullptr, *sppf = nullptr;
     unsigned char *spactive = nullptr;
     int *spcursor = nullptr, *spepoch = nullptr;
+    int *spcursor2 = nullptr, *sppub = nullptr;           // fused gate + apply passes: second cursor (ping-pong), published decisions
     size_t sp_records = 0; int sp_rows = 0;
     // device staging of the host-pointer entry hv_ekf_visual_track: idx | features | velocities | y | status | gate | chi2 | pf
     unsigned char *vustage = nullptr;
@@ -1447,7 +1506,7 @@ static int ekf_launch_update(Ekf *e, int nr, int l, const double *H_dev, const d
                              const unsigned char *active_dev, const int *require_inlier_dev = nullptr,
                              int *success_counter_dev = nullptr, double rd1 = 0.0, bool *two_r_done = nullptr,
                              int spec = 0, int n_tracks = 0, int *cursor_dev = nullptr, int max_successful = 0,
-                             const int *gate_in_dev = nullptr)
+                             const int *gate_in_dev = nullptr, int *cursor_out_dev = nullptr, int *pub_dev = nullptr, int pass_id = 0)
 {
     Ctx *c = e->c;
     if (nr < 1 || nr > e->max_rows || l < 1 || l > e->n) return HV_ERR_INVALID;
@@ -1466,6 +1525,7 @@ static int ekf_launch_update(Ekf *e, int nr, int l, const double *H_dev, const d
     a.m = e->m; a.P = e->P; a.H = H_dev; a.v = v_dev; a.rdiag = rdiag_dev; a.rd0 = rd0; a.rd1 = rd1; a.noise_scale = e->noise_scale;
     a.ws = e->ws; a.chi2 = chi2_dev; a.status = status_dev; a.active = active_dev; a.require_inlier = require_inlier_dev; a.success_counter = success_counter_dev;
     a.spec = spec; a.n_tracks = n_tracks; a.cursor = cursor_dev; a.max_successful = max_successful; a.gate_in = gate_in_dev;
+    a.cursor_out = cursor_out_dev; a.pub = pub_dev; a.pass_id = pass_id;
     size_t tall = (((size_t)a.Rs * nr + 1) & ~(size_t)1) * sizeof(double);
     const size_t small = (size_t)(256 + 544 + UPD_THREADS / 64 + 2) * sizeof(double);           // W + col (incl. dump area) + red + flag
     const int ti = (nr + 15) / 16, lbk = (l + 15) / 16;
@@ -1496,7 +1556,7 @@ static int ekf_launch_update(Ekf *e, int nr, int l, const double *H_dev, const d
         attr_set = true;
     }
     ScopedKernelTime tm(c, HV_K_EKF_UPDATE);
-    hipLaunchKernelGGL(kern, dim3(e->batch, spec == 1 ? n_tracks : 1), dim3(UPD_THREADS), shmem, c->stream, a);
+    hipLaunchKernelGGL(kern, dim3(e->batch, (spec == 1 || spec == 3) ? n_tracks : 1), dim3(UPD_THREADS), shmem, c->stream, a);
     HV_HIP(c, hipGetLastError());
     return HV_OK;
 }
@@ -1563,7 +1623,7 @@ void hv_ekf_destroy(hv_ekf *h)
     if (e->c && e->c->stream) (void)hipStreamSynchronize(e->c->stream);
     void *ptrs[] = { e->m, e->P, e->P1, e->m1, e->Q, e->dydx, e->ws, e->sH, e->sv, e->sr, e->schi2, e->simu,
                      e->sstatus, e->sdrop, e->sactive, e->vuH, e->vuv, e->vupf, e->vuactive, e->vustage,
-                     e->spH, e->spv, e->sppf, e->spactive, e->spcursor, e->spepoch };
+                     e->spH, e->spv, e->sppf, e->spactive, e->spcursor, e->spepoch, e->spcursor2, e->sppub };
     for (void *p : ptrs) if (p) (void)hipFree(p);
     delete h;
 }
@@ -1766,15 +1826,17 @@ int hv_ekf_visual_frame_dev(hv_ekf *h, const hv_vu_params *p, int n_tracks, int 
         const size_t rec = B * (size_t)n_tracks;
         if (e->sp_records < rec || e->sp_rows < rows) {
             HV_HIP(c, hipStreamSynchronize(c->stream));
-            void *old[] = {e->spH, e->spv, e->sppf, e->spactive, e->spcursor, e->spepoch};
+            void *old[] = {e->spH, e->spv, e->sppf, e->spactive, e->spcursor, e->spepoch, e->spcursor2, e->sppub};
             for (void *q : old) if (q) (void)hipFree(q);
-            e->spH = e->spv = e->sppf = nullptr; e->spactive = nullptr; e->spcursor = e->spepoch = nullptr; e->sp_records = 0;
+            e->spH = e->spv = e->sppf = nullptr; e->spactive = nullptr; e->spcursor = e->spepoch = e->spcursor2 = e->sppub = nullptr; e->sp_records = 0;
             HV_HIP(c, hipMalloc(reinterpret_cast<void **>(&e->spH), sizeof(double) * rec * rows * e->n));
             HV_HIP(c, hipMalloc(reinterpret_cast<void **>(&e->spv), sizeof(double) * rec * rows));
             HV_HIP(c, hipMalloc(reinterpret_cast<void **>(&e->sppf), sizeof(double) * rec * 3));
             HV_HIP(c, hipMalloc(reinterpret_cast<void **>(&e->spactive), rec));
             HV_HIP(c, hipMalloc(reinterpret_cast<void **>(&e->spcursor), sizeof(int) * B));
             HV_HIP(c, hipMalloc(reinterpret_cast<void **>(&e->spepoch), sizeof(int) * rec));
+            HV_HIP(c, hipMalloc(reinterpret_cast<void **>(&e->spcursor2), sizeof(int) * B));
+            HV_HIP(c, hipMalloc(reinterpret_cast<void **>(&e->sppub), sizeof(int) * rec));
             e->sp_records = rec; e->sp_rows = rows;
         }
         HV_HIP(c, hipMemsetAsync(e->spcursor, 0, sizeof(int) * B, c->stream));
@@ -1785,14 +1847,30 @@ int hv_ekf_visual_frame_dev(hv_ekf *h, const hv_vu_params *p, int n_tracks, int 
         a.H = e->spH; a.v = e->spv; a.f = nullptr; a.pf = pf_dev ? pf_dev : e->sppf; a.status = status_dev; a.active = e->spactive;
         a.gate_status = gate_status_dev; a.success_counter = success_counter_dev; a.max_successful = max_successful;
         a.spec_tracks = n_tracks; a.cursor = e->spcursor; a.epoch = e->spepoch;
+        // HV_EKF_SPEC_SPLIT=1 (environment, experiments only): gate-all and apply-first-inlier as two launches per pass (the first
+        // r02 form); default: one launch, the workgroups of a filter settle the visit order among themselves (UpdateArgs spec 3)
+        const char *env_split = getenv("HV_EKF_SPEC_SPLIT");
+        const bool split = env_split && atoi(env_split) != 0;
+        if (!split) HV_HIP(c, hipMemsetAsync(e->sppub, 0, sizeof(int) * rec, c->stream));
+        int *cur = e->spcursor, *nxt = e->spcursor2;
         for (int pass = 0; pass <= max_successful; ++pass) {
+            a.cursor = cur;
             rc = hv::launch_vu_prepare(c, a);
             if (rc != HV_OK) return rc;
+            if (!split) {
+                bool fused = false;
+                rc = hv::ekf_launch_update(e, rows, e->n, e->spH, e->spv, nullptr, r_gate * r_gate * e->noise_scale, 3, 0, 1, chi2_dev,
+                                           gate_status_dev, e->spactive, nullptr, success_counter_dev, r_update * r_update * e->noise_scale, &fused,
+                                           3, n_tracks, cur, max_successful, nullptr, nxt, e->sppub, pass + 1);
+                if (rc != HV_OK) return rc;
+                if (fused) { int *sw = cur; cur = nxt; nxt = sw; continue; }
+                // (mode 3 not available for this shape: the two launches below, on the same cursor)
+            }
             rc = hv::ekf_launch_update(e, rows, e->n, e->spH, e->spv, nullptr, r_gate * r_gate * e->noise_scale, 0, 0, 0, chi2_dev,
-                                       gate_status_dev, e->spactive, nullptr, success_counter_dev, 0.0, nullptr, 1, n_tracks, e->spcursor, max_successful);
+                                       gate_status_dev, e->spactive, nullptr, success_counter_dev, 0.0, nullptr, 1, n_tracks, cur, max_successful);
             if (rc != HV_OK) return rc;
             rc = hv::ekf_launch_update(e, rows, e->n, e->spH, e->spv, nullptr, r_update * r_update * e->noise_scale, 1, 0, 1, nullptr,
-                                       nullptr, e->spactive, nullptr, success_counter_dev, 0.0, nullptr, 2, n_tracks, e->spcursor, max_successful,
+                                       nullptr, e->spactive, nullptr, success_counter_dev, 0.0, nullptr, 2, n_tracks, cur, max_successful,
                                        gate_status_dev);
             if (rc != HV_OK) return rc;
         }
