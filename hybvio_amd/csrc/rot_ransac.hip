@@ -19,7 +19,8 @@
 namespace hv {
 namespace {
 
-constexpr int RT = 256;
+constexpr int RT_MANY = 256;           // workgroup size with many frames in flight (8 frames per CU)
+constexpr int RT_FEW = 1024;           // a handful of frames: the 20 000 (point, hypothesis) tests of ONE frame spread 4x wider (91 -> ~30 us)
 constexpr int MAX_PTS = 1024;
 constexpr int HYP = 100;              // ROT_RANSAC_MAX_ITERS (rot_ransac.cpp:6)
 
@@ -255,6 +256,7 @@ __device__ bool inlier(const float *R, const float *p1, float c2x, float c2y, co
     return dx * dx + dy * dy <= thr;
 }
 
+template <int RT>
 __global__ __launch_bounds__(RT) void rot_ransac_kernel(RansacArgs a)
 {
     __shared__ float s_p1[MAX_PTS * 3], s_p2[MAX_PTS * 3], s_c2[MAX_PTS * 2];
@@ -477,7 +479,8 @@ int hv_rot_ransac_batch_dev(hv_ctx *h, int n_sets, int max_points, const int *n_
     a.threshold_pow2 = threshold_pow2; a.status = status_dev; a.R = R_dev; a.summary = summary_dev;
     a.cam1 = *cam1; a.cam2 = *cam2;
     hv::ScopedKernelTime tm(c, HV_K_ROT_RANSAC);
-    hipLaunchKernelGGL(hv::rot_ransac_kernel, dim3((unsigned)n_sets), dim3(hv::RT), 0, c->stream, a);
+    if (n_sets <= 64) hipLaunchKernelGGL(hv::rot_ransac_kernel<hv::RT_FEW>, dim3((unsigned)n_sets), dim3(hv::RT_FEW), 0, c->stream, a);
+    else              hipLaunchKernelGGL(hv::rot_ransac_kernel<hv::RT_MANY>, dim3((unsigned)n_sets), dim3(hv::RT_MANY), 0, c->stream, a);
     HV_HIP(c, hipGetLastError());
     return HV_OK;
 }
@@ -498,7 +501,8 @@ int hv_rot_ransac_lk_batch_dev(hv_ctx *h, int n_sets, int max_points, const int 
     a.threshold_pow2 = threshold_pow2; a.status = status_dev; a.R = R_dev; a.summary = summary_dev;
     a.cam1 = *cam1; a.cam2 = *cam2;
     hv::ScopedKernelTime tm(c, HV_K_ROT_RANSAC);
-    hipLaunchKernelGGL(hv::rot_ransac_kernel, dim3((unsigned)n_sets), dim3(hv::RT), 0, c->stream, a);
+    if (n_sets <= 64) hipLaunchKernelGGL(hv::rot_ransac_kernel<hv::RT_FEW>, dim3((unsigned)n_sets), dim3(hv::RT_FEW), 0, c->stream, a);
+    else              hipLaunchKernelGGL(hv::rot_ransac_kernel<hv::RT_MANY>, dim3((unsigned)n_sets), dim3(hv::RT_MANY), 0, c->stream, a);
     HV_HIP(c, hipGetLastError());
     return HV_OK;
 }
