@@ -26,11 +26,21 @@ for i in range(1, 5):
         continue
     with open(path) as f:
         for r in csv.DictReader(f):
-            val[(r["kernel"], int(r["grid"]), r["counter"])] = float(r["mean_per_dispatch"])
-            disp[(r["kernel"], int(r["grid"]))] = int(r["dispatches"])
+            name = r["kernel"]
+            for short in ("pyr_down_l0_kernel", "pyr_tail_kernel", "gftt_march_kernel"):      # summaries written with an older name pattern
+                if short in name:
+                    name = short
+            val[(name, int(r["grid"]), r["counter"])] = float(r["mean_per_dispatch"])
+            disp[(name, int(r["grid"]))] = int(r["dispatches"])
 alg = bench.algorithmic_bytes()
 tiles_l0 = ((bench.W + 127) // 128) * ((bench.H + 31) // 32)
-GRID = {"klt_kernel": B * NPTS * 64, "pyr_level_kernel<true>": 2 * B * tiles_l0 * 256, "ekf_update_kernel": B * 512}
+W1, H1 = (bench.W + 1) // 2, (bench.H + 1) // 2
+wgs_l0 = (((W1 + 3) // 4) * ((H1 + 1) // 2) + 255) // 256          # pyr_down_l0_kernel: work items of one image / 256
+if bench.L0_GRADIENTS_STORED:
+    L0K, L0GRID = "pyr_level_kernel<true>", 2 * B * tiles_l0 * 256
+else:
+    L0K, L0GRID = "pyr_down_l0_kernel", 2 * B * wgs_l0 * 256
+GRID = {"klt_kernel": B * NPTS * 64, L0K: L0GRID, "ekf_update_kernel": B * 512, "pyr_tail_kernel": 2 * B * 512}
 
 
 def g(k, c):
@@ -62,15 +72,21 @@ out = {
         "lds_insts_per_feature": frac(g("klt_kernel", "SQ_INSTS_LDS"), B * NPTS),
     },
     "pyr_level_kernel_L0": {
-        "fetch_kb_raw": g("pyr_level_kernel<true>", "FETCH_SIZE"), "write_kb": g("pyr_level_kernel<true>", "WRITE_SIZE"),
-        "hbm_bytes_per_launch": hbm("pyr_level_kernel<true>"), "algorithmic_bytes_per_launch": alg["pyr_l0"] * 2 * B,
-        "how": f"the level-0 launch is the pyr_level_kernel<true> dispatch with grid 2B x {tiles_l0} tiles x 256 threads",
+        "kernel": L0K,
+        "fetch_kb_raw": g(L0K, "FETCH_SIZE"), "write_kb": g(L0K, "WRITE_SIZE"),
+        "hbm_bytes_per_launch": hbm(L0K), "algorithmic_bytes_per_launch": alg["pyr_l0"] * 2 * B,
+        "how": f"the level-0 launch is the {L0K} dispatch with grid {L0GRID} threads (2B images)",
+    },
+    "pyr_tail_kernel": {
+        "fetch_kb_raw": g("pyr_tail_kernel", "FETCH_SIZE"), "write_kb": g("pyr_tail_kernel", "WRITE_SIZE"),
+        "hbm_bytes_per_launch": hbm("pyr_tail_kernel"),
+        "how": "levels 2.. of 2B images: reads the level-2 gray interior, writes gradients of levels 2.., the next gray levels and the physical borders",
     },
     "ekf_update_kernel": {
         "hbm_bytes_per_launch": hbm("ekf_update_kernel"),
         "algorithmic_bytes_per_launch_gate": B * (160 * 160 + 40 * 160) * 8,
         "algorithmic_bytes_per_launch_update": B * (2 * 160 * 160 + 40 * 160) * 8,
-        "mix": "15 chi2 gates + 5 fused gate+update launches per frame",
+        "mix": "20 mode-3 launches per frame (gate, + update where it passes: 5 of them)",
         "mfma_busy_frac": frac(g("ekf_update_kernel", "SQ_VALU_MFMA_BUSY_CYCLES"), 32.0 * (g("ekf_update_kernel", "SQ_BUSY_CYCLES") or 0)),
         "mfma_insts_per_filter": frac(g("ekf_update_kernel", "SQ_INSTS_MFMA"), B),
     },
