@@ -952,8 +952,10 @@ def main():
             "algorithmic_bytes_per_launch": gbytes, "achieved_GBs": gbytes / (ms / n * 1e-3) / 1e9,
             "frac_of_8TBs": gbytes / (ms / n * 1e-3) / 1e9 / HBM_PEAK_GBS,
             "blocks_with_a_corner": found,
-            "note": "one workgroup per block: ~90 binary32 ops per pixel on 1 byte of HBM traffic, i.e. VALU/LDS bound by construction "
-                    "(the reference materialises 6 float images = 24 B per pixel instead)"}
+            "note": "a thread marches a 4-column strip of one arg-max block through sliding register windows (gftt_march_kernel; the "
+                    "LDS-tiled kernel serves < 128 images): ~70 binary32 instructions per pixel on 1 byte of HBM traffic, VALU-issue bound "
+                    "by construction (the chip issues 614 G wave-instructions/s: 0.6 ms floor for 1024 images; the reference materialises "
+                    "6 float images = 24 B per pixel instead)"}
         if not args.no_cpu_baseline:
             from oracle import orc
             img = tb.frames[0, 0, 0].cpu().numpy()
