@@ -69,9 +69,11 @@ int hv_synchronize(hv_ctx *ctx);
  * Replaces tracker::ImagePyramid::Factory::compute (src/tracker/image_pyramid.hpp:35-41,
  * image_pyramid.cpp:40-48 -> cv::buildOpticalFlowPyramid(img, pyr, Size(win,win), maxLevel)).
  * A slot is one image's pyramid: gray levels 1..L-1 (u8, 5x5 binomial, (s+128)>>8) and Scharr
- * gradients 0..L-1 (int16 [dx,dy] interleaved, scale 1/32: image_pyramid.hpp:19-26).
- * Device layout is compact (no 31-px border); borders are applied virtually by the tracker:
- * BORDER_REFLECT_101 for gray, 0 for gradients, exactly as OpenCV pads.
+ * gradients (int16 [dx,dy] interleaved, scale 1/32: image_pyramid.hpp:19-26). Only the coarse levels (>= 2) keep
+ * their gradient plane in memory; those of levels 0 and 1 are formed inside the tracker kernel from the gray
+ * rows -- hv_pyramid_download still returns every level's gradients (computed on demand).
+ * Levels 0 and 1 are stored without a border (applied virtually by the tracker: BORDER_REFLECT_101 for gray,
+ * 0 for gradients, exactly as OpenCV pads); levels >= 2 carry OpenCV's border physically.
  * Slots are pooled like util::Allocator (src/util/allocator.hpp:55-67): acquire when an Image
  * first needs its pyramid (image.cpp:209-214), release when the Image dies. Like the reference's
  * allocator the pool grows on demand: when every slot is in use hv_pyramid_acquire doubles the slab
