@@ -178,6 +178,95 @@ __global__ __launch_bounds__(256) void gftt_block_kernel(GfttArgs a)
     }
 }
 
+
+// ---- gfttBlockSize 5 / 7 (feature_detector.cpp:279-315 passes it to cv::cornerMinEigenVal as the box size; the default is 3 and
+// the two kernels above are built for it). A plain three-pass kernel, one workgroup per arg-max block: product images of the
+// (BS + 2 hb)^2 neighbourhood, each product evaluated at its BORDER_REFLECT_101 mirrored centre (= box-filtering the reflected
+// product images, as cv::boxFilter does); row sums left to right; column sums top to bottom; response; arg-max. The oracle's float
+// order (oracle/gftt_oracle.c). Not tuned: non-default configurations only.
+template <int BS>
+__global__ __launch_bounds__(256) void gftt_box_kernel(GfttArgs a, int hb)
+{
+    constexpr int HBMAX = 3, GWMAX = BS + 2 * (HBMAX + 1), NPMAX = BS + 2 * HBMAX;
+    __shared__ float gray[GWMAX * GWMAX];
+    __shared__ float prod[3][NPMAX * NPMAX];
+    __shared__ float rsum[3][NPMAX * BS];
+    __shared__ float red_r[4];
+    __shared__ int red_i[4];
+    const int t = threadIdx.x;
+    const int blocks = a.nbx * a.nby;
+    const unsigned lb = xcd_remap(blockIdx.x, gridDim.x);
+    const int img = lb / blocks, bi = lb - img * blocks;
+    const int yb = bi / a.nbx, xb = bi - yb * a.nbx;
+    const int x0 = xb * BS, y0 = yb * BS, w = a.w, h = a.h;
+    const int slot = a.slots ? a.slots[img] : a.slot0;
+    const uint8_t *src = a.l0_ptr[slot];
+    const int stride = a.l0_stride[slot];
+    const int G = hb + 1, GW = BS + 2 * G, NP = BS + 2 * hb;
+    for (int i = t; i < GW * GW; i += 256) {
+        const int r = i / GW, c = i - r * GW;
+        gray[i] = (float)src[(size_t)reflect101(y0 - G + r, h) * stride + reflect101(x0 - G + c, w)];
+    }
+    __syncthreads();
+    const float k0 = a.k0, k1 = a.k1;
+    for (int i = t; i < NP * NP; i += 256) {
+        const int pr = i / NP, pc = i - pr * NP;
+        // centre of product position (y0 - hb + pr, x0 - hb + pc), mirrored into the image, in tile coordinates
+        const int cy = reflect101(y0 - hb + pr, h) - y0 + G, cx = reflect101(x0 - hb + pc, w) - x0 + G;
+        const float *g = gray + cy * GW + cx;
+        const float dt = g[-GW + 1] - g[-GW - 1], dm = g[1] - g[-1], db = g[GW + 1] - g[GW - 1];
+        const float vx = k0 * dm + k1 * (dt + db);
+        const float st = k0 * g[-GW] + k1 * (g[-GW - 1] + g[-GW + 1]);
+        const float sb = k0 * g[GW] + k1 * (g[GW - 1] + g[GW + 1]);
+        const float vy = sb - st;
+        prod[0][i] = vx * vx; prod[1][i] = vx * vy; prod[2][i] = vy * vy;
+    }
+    __syncthreads();
+    for (int i = t; i < NP * BS; i += 256) {
+        const int pr = i / BS, x = i - pr * BS;
+#pragma unroll
+        for (int ch = 0; ch < 3; ch++) {
+            const float *p = prod[ch] + pr * NP + x;          // product columns x - hb .. x + hb  <->  indices x .. x + 2 hb
+            float s_ = p[0];
+            for (int k = 1; k <= 2 * hb; k++) s_ = s_ + p[k];
+            rsum[ch][i] = s_;
+        }
+    }
+    __syncthreads();
+    float best_r = -1e10f;
+    int best_i = 0;
+    for (int i = t; i < BS * BS; i += 256) {
+        const int y = i / BS, x = i - y * BS;
+        float sm[3];
+#pragma unroll
+        for (int ch = 0; ch < 3; ch++) {
+            const float *p = rsum[ch] + y * BS + x;           // product rows y - hb .. y + hb  <->  rsum rows y .. y + 2 hb
+            float s_ = p[0];
+            for (int k = 1; k <= 2 * hb; k++) s_ = s_ + p[k * BS];
+            sm[ch] = s_;
+        }
+        const float aa = sm[0] * 0.5f, bb = sm[1], cc = sm[2] * 0.5f, amc = aa - cc;
+        const float resp = (aa + cc) - sqrtf(amc * amc + bb * bb);
+        const float r16 = resp * 16.0f;                          // CpuCornerResponse::GAIN
+        if (r16 > best_r && r16 > a.min_response) { best_r = r16; best_i = i; }
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ro = __shfl_down(best_r, o);
+        const int io = __shfl_down(best_i, o);
+        if (better(ro, io, best_r, best_i)) { best_r = ro; best_i = io; }
+    }
+    if ((t & 63) == 0) { red_r[t >> 6] = best_r; red_i[t >> 6] = best_i; }
+    __syncthreads();
+    if (t == 0) {
+        for (int k = 1; k < 4; k++) if (better(red_r[k], red_i[k], best_r, best_i)) { best_r = red_r[k]; best_i = red_i[k]; }
+        const bool found = best_r > -1e10f;
+        float *o = a.kp + ((size_t)img * blocks + bi) * 3;
+        o[0] = found ? (float)(x0 + best_i % BS) : 0.f;
+        o[1] = found ? (float)(y0 + best_i / BS) : 0.f;
+        o[2] = best_r;
+    }
+}
+
 #ifndef GFTT_MARCH_UNROLL
 #define GFTT_MARCH_UNROLL 2   // 6 removes the window moves but needs 147 VGPRs (3 waves per SIMD): 0.93 ms against 0.84
 #endif
@@ -318,7 +407,7 @@ __global__ __launch_bounds__(256) void gftt_march_kernel(GfttArgs a)
 
 int launch(Ctx *c, int n_images, const int *slots_dev, int slot0, int bs, float min_response, int block_size, float *kp_dev)
 {
-    if (block_size != 3) return HV_ERR_UNSUPPORTED;             // the reference default (gfttBlockSize 3); other box sizes: oracle only
+    if (block_size != 3 && block_size != 5 && block_size != 7) return HV_ERR_UNSUPPORTED;   // odd box sizes up to 7 (default 3)
     GfttArgs a{};
     a.l0_ptr = c->d_l0_ptr; a.l0_stride = c->d_l0_stride; a.slots = slots_dev; a.slot0 = slot0;
     a.w = c->L.w[0]; a.h = c->L.h[0];
@@ -330,6 +419,14 @@ int launch(Ctx *c, int n_images, const int *slots_dev, int slot0, int bs, float 
     if (grid == 0) return HV_OK;
     a.n_images = n_images;
     ScopedKernelTime tm(c, HV_K_GFTT);
+    if (block_size != 3) {                                       // non-default box size: the plain kernel
+        if (bs == 32)      hipLaunchKernelGGL(gftt_box_kernel<32>, dim3(grid), dim3(256), 0, c->stream, a, block_size / 2);
+        else if (bs == 16) hipLaunchKernelGGL(gftt_box_kernel<16>, dim3(grid), dim3(256), 0, c->stream, a, block_size / 2);
+        else if (bs == 8)  hipLaunchKernelGGL(gftt_box_kernel<8>, dim3(grid), dim3(256), 0, c->stream, a, block_size / 2);
+        else return HV_ERR_INVALID;
+        HV_HIP(c, hipGetLastError());
+        return HV_OK;
+    }
     // The marching kernel is the throughput design (a thread walks 34 dependent steps); for a handful of images the LDS-tiled
     // kernel (one workgroup per block, 256 threads side by side) finishes sooner -- 25 us per frame in the bench latency leg.
     // HV_GFTT_TILED (environment, experiments only): 1 / 0 forces the tiled / the marching kernel.

@@ -285,7 +285,7 @@ int hv_ekf_transform(hv_ekf *ekf, int filter, const double *pChange3x3, const do
  * detect(); src/tracker/feature_detector_legacy.cpp:177-213 applyMinDistance). Field names are the
  * reference's parameters (codegen/parameter_definitions.c:262,317-324). */
 typedef struct hv_gftt_params {
-    int    gfttBlockSize;      /* box filter of the structure matrix; 3 (the only size on the device path) */
+    int    gfttBlockSize;      /* box filter of the structure matrix: 3 (default; tuned kernels), 5 or 7 (plain kernel) */
     double gfttMinDistance;    /* selects the arg-max block edge: >= 32 -> 32, >= 16 -> 16, else 8          */
     float  gfttMinResponse;    /* key points need 16 * minEigenVal > this                                   */
     int    maxTracks;          /* applyMinDistance stops after this many corners                            */

@@ -49,6 +49,25 @@ def test_keypoints_bit_exact(oracle, shape, min_distance, kernel, monkeypatch):
             assert np.array_equal(kp[i], ref), (i, np.nonzero((kp[i] != ref).any(1))[0][:5])
 
 
+@pytest.mark.parametrize("block_size", [5, 7])
+@pytest.mark.parametrize("shape,min_distance", [((480, 752), 50.0), ((97, 130), 20.0), ((70, 101), 8.0), ((64, 64), 50.0), ((67, 35), 8.0)])
+def test_keypoints_bit_exact_with_other_box_sizes(oracle, shape, min_distance, block_size):
+    """gfttBlockSize 5 / 7 (parameter_definitions.c: odometry gfttBlockSize, cv::cornerMinEigenVal's blockSize): the plain box kernel
+    against the oracle, incl. images whose ragged right / bottom strip is narrower than the box (products mirrored at the border)."""
+    rng = np.random.default_rng(shape[0] + block_size)
+    imgs = [rng.integers(0, 256, shape, dtype=np.uint8), synth.stereo_sequence(5, shape[1], shape[0], 1)[0][0]]
+    gp = capi.gftt_default_params(gfttMinDistance=min_distance, gfttBlockSize=block_size)
+    bs = oracle.gftt_block_size(min_distance)
+    with _ctx(shape[1], shape[0], pool_size=2) as ctx:
+        slots = []
+        for im in imgs:
+            s = ctx.acquire(); ctx.build(s, im); slots.append(s)
+        kp = _device_keypoints(ctx, slots, gp)
+        for i, im in enumerate(imgs):
+            ref = oracle.gftt_collect_max(oracle.corner_min_eigen_val(im, block_size), bs, 1e-3)
+            assert np.array_equal(kp[i], ref), (i, np.nonzero((kp[i] != ref).any(1))[0][:5])
+
+
 def test_detect_matches_reference_flow_incl_zero_prefix_and_mask(oracle):
     left = synth.stereo_sequence(21, 752, 480, 2)[0]
     with _ctx(752, 480) as ctx:
@@ -83,8 +102,8 @@ def test_detector_on_the_batched_device_path_and_errors(oracle, seq752):
         for i in range(B):
             ref = oracle.gftt_collect_max(oracle.corner_min_eigen_val(frames[i].cpu().numpy()), 32, 1e-3)
             assert np.array_equal(kp[i], ref)
-        # gfttBlockSize other than 3 is oracle-only
-        gp = capi.gftt_default_params(gfttBlockSize=5)
+        # box sizes beyond 7 (and even ones) are not served
+        gp = capi.gftt_default_params(gfttBlockSize=9)
         out = np.zeros((2 * ctx.gftt_keypoint_count(), 2), np.float32)
         n = capi.C.c_int(0)
         rc = capi.lib().hv_gftt_detect(ctx._h, capi.C.byref(gp), slots[0], None, 0, 0, out.ctypes.data_as(capi.f32p), len(out), capi.C.byref(n))
