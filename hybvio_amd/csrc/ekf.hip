@@ -333,26 +333,34 @@ __global__ __launch_bounds__(256) void ekf_predict_kernel(PredictArgs a)
     __syncthreads();
 
     PHASE_STAMP(13);
-    // P00 = F P00 F' + L Q L' (ekf.cpp:504-505) in LDS; Phi <- F Phi
-    for (int e = t; e < INER * QD; e += 256) {
-        const int i = e % INER, j = e / INER;
-        double s = 0; for (int k = 0; k < QD; k++) s += L_(i, k) * Qs[j * QD + k];
-        LQ[e] = s;
-    }
-    for (int e = t; e < INER * INER; e += 256) {
-        const int i = e % INER, j = e / INER;
-        double s = 0, ph = 0;
-        for (int k = 0; k < INER; k++) { s += F_(i, k) * P00[j * INER + k]; ph += F_(i, k) * Phi[j * INER + k]; }
-        FP[e] = s; PhiN[e] = ph;
-    }
-    __syncthreads();
-    for (int e = t; e < INER * INER; e += 256) {
-        const int i = e % INER, j = e / INER;
-        double s = 0;
-        for (int k = 0; k < INER; k++) s += FP[k * INER + i] * F_(j, k);
-        for (int k = 0; k < QD; k++) s += LQ[k * INER + i] * L_(j, k);
-        P00[e] = s;
-        Phi[e] = PhiN[e];
+    // P00 = F P00 F' + L Q L' (ekf.cpp:504-505) in LDS; Phi <- F Phi. The 20 x 20 results are four 16 x 16 MFMA tiles, one per
+    // wavefront (f64 16x16x4, 5 k-steps): a chain of 5 MFMAs per product where the r01 loops spent 20-32 dependent LDS round trips per
+    // element (a sample's products 3 x ~1.3 us -> well under 1 us; the summation order inside a product changes, ~1e-16 relative)
+    {
+        const int ti = wave & 1, tj = wave >> 1;                 // output rows 16 ti .., columns 16 tj ..
+        const int mi = ti ? INER - 16 : 16, nj = tj ? INER - 16 : 16;
+        // A(i, k) = F_(16 ti + i, k) = F[k INER + 16 ti + i];  B(k, j) = P00(k, 16 tj + j) = P00[(16 tj + j) INER + k]
+        const double4v fp = mfma_tile(F + 16 * ti, 1, INER, mi, P00 + 16 * tj * INER, 1, INER, nj, INER);
+        const double4v ph = mfma_tile(F + 16 * ti, 1, INER, mi, Phi + 16 * tj * INER, 1, INER, nj, INER);
+        // L Q (20 x 12): row tiles on wavefronts 0 and 1. LQ(i, j) = sum_k L(i, k) Qs(j, k): B(k, j) = Qs[j QD + k]
+        double4v lq = {0.0, 0.0, 0.0, 0.0};
+        if (wave < 2) lq = mfma_tile(Lm + 16 * wave, 1, INER, wave ? INER - 16 : 16, Qs, 1, QD, QD, QD);
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int r = kq + 4 * q;
+            if (r < mi && cl < nj) { FP[(16 * tj + cl) * INER + 16 * ti + r] = fp[q]; PhiN[(16 * tj + cl) * INER + 16 * ti + r] = ph[q]; }
+            if (wave < 2 && r < (wave ? INER - 16 : 16) && cl < QD) LQ[cl * INER + 16 * wave + r] = lq[q];
+        }
+        __syncthreads();
+        // P00(i, j) = sum_k FP(i, k) F_(j, k) + sum_k LQ(i, k) L_(j, k): B(k, j) = F[k INER + 16 tj + j] resp. Lm[k INER + 16 tj + j]
+        const double4v p1 = mfma_tile(FP + 16 * ti, 1, INER, mi, F + 16 * tj, INER, 1, nj, INER);
+        const double4v p2 = mfma_tile(LQ + 16 * ti, 1, INER, mi, Lm + 16 * tj, INER, 1, nj, QD);
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int r = kq + 4 * q;
+            if (r < mi && cl < nj) P00[(16 * tj + cl) * INER + 16 * ti + r] = p1[q] + p2[q];
+        }
+        for (int e = t; e < INER * INER; e += 256) Phi[e] = PhiN[e];
     }
     }
     __syncthreads();
