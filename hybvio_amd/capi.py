@@ -417,7 +417,8 @@ class VuParams(C.Structure):
                 ("triangulationRcondThreshold", C.c_double), ("triangulationGaussNewtonIterations", C.c_uint),
                 ("triangulationMinDist", C.c_double), ("triangulationMaxDist", C.c_double),
                 ("estimateImuCameraTimeShift", C.c_int), ("useStereo", C.c_int),
-                ("imuToCamera", C.c_double * 16), ("secondImuToCamera", C.c_double * 16)]
+                ("imuToCamera", C.c_double * 16), ("secondImuToCamera", C.c_double * 16),
+                ("useLinearTriangulation", C.c_int)]
 
 
 def vu_default_params(imu_to_camera=None, second_imu_to_camera=None, **over) -> VuParams:

@@ -1725,6 +1725,7 @@ static int vu_fill_args(Ekf *e, const hv_vu_params *p, int np, const int *idx, c
     a.conv_threshold = p->triangulationConvergenceThreshold; a.conv_r = p->triangulationConvergenceR;
     a.rcond_threshold = p->triangulationRcondThreshold; a.min_dist = p->triangulationMinDist; a.max_dist = p->triangulationMaxDist;
     a.gn_iters = (int)p->triangulationGaussNewtonIterations; a.est_shift = p->estimateImuCameraTimeShift ? 1 : 0;
+    a.linear = p->useLinearTriangulation ? 1 : 0;
     return HV_OK;
 }
 

@@ -112,6 +112,7 @@ struct VuPrepareArgs {
     double imu_to_cam[2][12];          // per camera the top 3 x 4 of imuToCamera, row-major
     double conv_threshold, conv_r, rcond_threshold, min_dist, max_dist;
     int gn_iters, est_shift;
+    int linear;                        // useLinearTriangulation: the closed-form branch instead of two-camera + Gauss-Newton
     double *H, *v, *f, *pf;            // [batch][rows * n] column-major, [batch][rows], optional [batch][rows], [batch][3]
     int *status;                       // [batch][2]: TriangulatorStatus, PrepareVuStatus
     unsigned char *active;             // optional [batch]: 1 where both are OK

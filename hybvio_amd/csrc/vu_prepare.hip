@@ -299,6 +299,97 @@ __device__ __forceinline__ void vu_prepare_body(const VuPrepareArgs &a)
     for (int i = tid; i < 3 * ncol; i += VT) s_dpfi[i] = 0.0;
     __syncthreads();
     VU_STAMP(1);
+    const double *p0 = s_trail;
+    if (a.linear) {
+        // ---- useLinearTriangulation (triangulation.cpp:146-152, triangulateLinear :820-895): the point closest to every camera
+        // ray in closed form, pf = S0^-1 S1 with S0 = sum_i A_i, S1 = sum_i A_i p_i, A_i = I - vn_i vn_i', vn_i the normalised
+        // world ray R_i' (ip_i, 1); derivatives d pf / d p_i = S0^-1 A_i, d pf / d q_i through vn_i, d pf / d t through the
+        // feature velocities. World frame from the start: no inverse-depth map, no iteration, statuses OK / BEHIND only. ----
+        double *Sinv = s_small + 40;                          // the slot the iterative branch uses for M
+        if (tid < nt) {
+            const double *pose = s_trail + tid * POSE_WORDS;
+            double *o = s_it + tid * ITER_WORDS;              // vn[3] |v| A[9] (A p)[3], later the time-shift contribution in [16..18]
+            const double ipv[3] = {s_feat[4 * tid], s_feat[4 * tid + 1], 1.0};
+            double v[3], A[9], Ap[3];
+            mTv3(pose + 3, ipv, v);
+            const double nn = sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+            const double vn[3] = {v[0] / nn, v[1] / nn, v[2] / nn};
+#pragma unroll
+            for (int r = 0; r < 3; ++r)
+#pragma unroll
+                for (int c = 0; c < 3; ++c) A[3 * r + c] = (r == c ? 1.0 : 0.0) - vn[r] * vn[c];
+            mv3(A, pose, Ap);
+#pragma unroll
+            for (int k = 0; k < 3; ++k) { o[k] = vn[k]; o[13 + k] = Ap[k]; }
+            o[3] = nn;
+#pragma unroll
+            for (int k = 0; k < 9; ++k) o[4 + k] = A[k];
+        }
+        __syncthreads();
+        if (tid == 0) {
+            double S0[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, S1[3] = {0, 0, 0};
+            for (int i = 0; i < nt; ++i) {
+                const double *o = s_it + i * ITER_WORDS;
+#pragma unroll
+                for (int k = 0; k < 9; ++k) S0[k] += o[4 + k];
+#pragma unroll
+                for (int k = 0; k < 3; ++k) S1[k] += o[13 + k];
+            }
+            // 3 x 3 inverse through the cofactors of the first column (what Eigen's fixed-size inverse does)
+            const double c0 = S0[4] * S0[8] - S0[5] * S0[7], c1 = S0[2] * S0[7] - S0[1] * S0[8], c2 = S0[1] * S0[5] - S0[2] * S0[4];
+            const double invdet = 1.0 / (c0 * S0[0] + c1 * S0[3] + c2 * S0[6]);
+            const double inv[9] = { c0 * invdet, c1 * invdet, c2 * invdet,
+                                    (S0[5] * S0[6] - S0[3] * S0[8]) * invdet, (S0[0] * S0[8] - S0[2] * S0[6]) * invdet, (S0[2] * S0[3] - S0[0] * S0[5]) * invdet,
+                                    (S0[3] * S0[7] - S0[4] * S0[6]) * invdet, (S0[1] * S0[6] - S0[0] * S0[7]) * invdet, (S0[0] * S0[4] - S0[1] * S0[3]) * invdet };
+            double pf[3];
+            mv3(inv, S1, pf);
+#pragma unroll
+            for (int k = 0; k < 9; ++k) Sinv[k] = inv[k];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) pfw[k] = pf[k];
+        }
+        __syncthreads();
+        // item (pose i, c): c < 3 column c of S0^-1 A_i; c = 3..6 the quaternion components; c = 7 the pose's share of d pf / d t
+        for (int w = tid; w < nt * 8; w += VT) {
+            const int i = w >> 3, c = w & 7;
+            const double *pose = s_trail + i * POSE_WORDS;
+            double *o = s_it + i * ITER_WORDS;
+            double col[3];
+            if (c < 3) {
+#pragma unroll
+                for (int r = 0; r < 3; ++r) col[r] = Sinv[3 * r] * o[4 + c] + Sinv[3 * r + 1] * o[4 + 3 + c] + Sinv[3 * r + 2] * o[4 + 6 + c];
+            } else {
+                // dv: the change of the un-normalised ray; g = d vn = A dv / |v|; d pf = S0^-1 (sum_k g_k Q_k) (pf - p_i) with
+                // Q_k x = e_k (vn . x) + vn x_k, i.e. (sum_k g_k Q_k) x = g (vn . x) + vn (g . x)
+                double dv[3];
+                if (c < 7) { const double ipv[3] = {s_feat[4 * i], s_feat[4 * i + 1], 1.0}; mTv3(pose + 12 + 9 * (c - 3), ipv, dv); }
+                else { const double vel[3] = {s_feat[4 * i + 2], s_feat[4 * i + 3], 0.0}; mTv3(pose + 3, vel, dv); }
+                double g[3];
+                mv3(o + 4, dv, g);
+#pragma unroll
+                for (int k = 0; k < 3; ++k) g[k] /= o[3];
+                const double x[3] = {pfw[0] - pose[0], pfw[1] - pose[1], pfw[2] - pose[2]};
+                const double vx = o[0] * x[0] + o[1] * x[1] + o[2] * x[2], gx = g[0] * x[0] + g[1] * x[1] + g[2] * x[2];
+                const double u[3] = {g[0] * vx + o[0] * gx, g[1] * vx + o[1] * gx, g[2] * vx + o[2] * gx};
+                mv3(Sinv, u, col);
+            }
+            if (c < 7) {
+#pragma unroll
+                for (int r = 0; r < 3; ++r) s_dpfi[r * ncol + 7 * i + c] = col[r];
+            } else {
+#pragma unroll
+                for (int r = 0; r < 3; ++r) o[16 + r] = col[r];
+            }
+        }
+        __syncthreads();
+        if (tid < 3 && a.est_shift) {                         // d pf / d t: the poses' shares in pose order
+            double t_ = 0.0;
+            for (int i = 0; i < nt; ++i) t_ += s_it[i * ITER_WORDS + 16 + tid];
+            s_dpfi[tid * ncol + dDim] = t_;
+        }
+        if (tid == 0) s_flag[0] = 1;
+        __syncthreads();
+    } else {
     // ---- triangulateWithTwoCameras between pose 0 and pose ind1 (triangulation.cpp:154-173, 612-716): thread j < 15
     // owns derivative column j (p0 q0 p1 q1 t); every one of them recomputes the small shared part ----
     const int ind1 = a.stereo ? nt / 2 - 1 : nt - 1;
@@ -384,7 +475,6 @@ __device__ __forceinline__ void vu_prepare_body(const VuPrepareArgs &a)
     }
     __syncthreads();
     // ---- Gauss-Newton with derivatives (triangulation.cpp:206-343) ----
-    const double *p0 = s_trail;
     // Lanes of the derivative-column phase. Every (pose i, column j) pair contributes through d(pfi)/dx_j (the plain
     // part); a pair also moves C and t of the pose when j belongs to pose i or to pose 0 (the motion part, ~2.5x the
     // flops). Both parts are linear in their inputs, so they are summed separately:
@@ -572,15 +662,17 @@ __device__ __forceinline__ void vu_prepare_body(const VuPrepareArgs &a)
         __syncthreads();
         if (s_flag[0]) break;
     }
+    }   // iterative branch
     VU_STAMP(27);
     // ---- status, back to world coordinates (:345-392) ----
     int *st_out = a.status + 2 * rec;
     double *M = s_small + 40, *pf0 = s_small + 49;           // R0T * dpf0_dpfi, the point in the frame of pose 0
     if (tid == 0) {
         int status = HV_TRI_OK;
-        if (!s_flag[0]) status = HV_TRI_NO_CONVERGENCE;
+        if (a.linear) { /* pfw and the world-frame derivative columns are in place */ }
+        else if (!s_flag[0]) status = HV_TRI_NO_CONVERGENCE;
         else if (scal[1] < a.rcond_threshold) status = HV_TRI_BAD_COND;
-        if (status == HV_TRI_OK) {
+        if (status == HV_TRI_OK && !a.linear) {
             double d[9], q[3], w[3], Ml[9];
             inverse_depth(pfi, q, d);
             mv3(R0T, q, w);
@@ -597,7 +689,7 @@ __device__ __forceinline__ void vu_prepare_body(const VuPrepareArgs &a)
     __syncthreads();
     int status = s_flag[1];
     if (status == HV_TRI_OK) {
-        if (tid < ncol) {
+        if (tid < ncol && !a.linear) {
             const int j = tid;
             double u[3] = {0, 0, 0}, v[3];
             if (j >= 3 && j < 7) mTv3(s_trail + 12 + 9 * (j - 3), pf0, u);                // dR0T * pf0

@@ -202,6 +202,8 @@ typedef struct hv_vu_params {
     int estimateImuCameraTimeShift;
     int useStereo;
     double imuToCamera[16], secondImuToCamera[16];     /* 4 x 4 homogeneous, row-major (Parameters::imuToCamera) */
+    int useLinearTriangulation;                         /* parameter_definitions.c:31 (default false): triangulateLinear instead of the
+                                                          iterative PIVO method (triangulation.cpp:146-152, 820-895) */
 } hv_vu_params;
 void hv_vu_default_params(hv_vu_params *p);
 /* odometry::TriangulatorStatus (output.hpp:21-29) and PrepareVuStatus (output.hpp:15-19) */

@@ -492,7 +492,7 @@ class TriParams(C.Structure):
     _fields_ = [("triangulationConvergenceThreshold", C.c_double), ("triangulationConvergenceR", C.c_double),
                 ("triangulationRcondThreshold", C.c_double), ("triangulationGaussNewtonIterations", C.c_uint),
                 ("triangulationMinDist", C.c_double), ("triangulationMaxDist", C.c_double),
-                ("estimateImuCameraTimeShift", C.c_int)]
+                ("estimateImuCameraTimeShift", C.c_int), ("useLinearTriangulation", C.c_int)]
 
 
 class CamPose(C.Structure):      # 3x3 matrices row-major

@@ -9,6 +9,9 @@
  *   extractCameraPoseTrail        src/odometry/triangulation.cpp:65-103
  *   Triangulator::triangulate     src/odometry/triangulation.cpp:120-407   (iterative PIVO method, the default:
  *                                 useLinearTriangulation = false, useIndependentStereoTriangulation = false)
+ *   triangulateLinear             src/odometry/triangulation.cpp:820-895   (useLinearTriangulation = true, :146-152; the
+ *                                 reference's own test leaves this case as a TODO, test/triangulation.cpp:107: it is pinned here
+ *                                 the way that test pins the default, by the numeric-vs-analytic derivative check on its data)
  *   triangulateWithTwoCameras     src/odometry/triangulation.cpp:612-716, dpinv :31-52, pinv :1000-1002
  *   inverseDepth                  src/odometry/triangulation.cpp:1004-1029
  *   prepareVisualUpdate           src/odometry/triangulation.cpp:897-987, getPosOriIndices :989-998
@@ -46,6 +49,7 @@ typedef struct orc_tri_params {            /* codegen/parameter_definitions.c:37
     unsigned triangulationGaussNewtonIterations;   /* 10 */
     double triangulationMinDist, triangulationMaxDist;   /* 0, 1e300 */
     int estimateImuCameraTimeShift;                /* true */
+    int useLinearTriangulation;                    /* false (parameter_definitions.c:31) */
 } orc_tri_params;
 
 void orc_tri_default_params(orc_tri_params *p)
@@ -53,6 +57,7 @@ void orc_tri_default_params(orc_tri_params *p)
     p->triangulationConvergenceThreshold = 1e-2; p->triangulationConvergenceR = 11.0;
     p->triangulationRcondThreshold = 1e-8; p->triangulationGaussNewtonIterations = 10;
     p->triangulationMinDist = 0; p->triangulationMaxDist = 1e300; p->estimateImuCameraTimeShift = 1;
+    p->useLinearTriangulation = 0;
 }
 
 /* ---- small dense helpers (row-major) ---- */
@@ -236,6 +241,82 @@ static double norm1_3(const double *M)
     return best;
 }
 
+
+/* 3x3 inverse through the cofactors of the first column (Eigen's fixed-size Matrix3d::inverse()) */
+static void inv3(const double *M, double *inv)
+{
+    const double c0 = M[4] * M[8] - M[5] * M[7], c1 = M[2] * M[7] - M[1] * M[8], c2 = M[1] * M[5] - M[2] * M[4];
+    const double invdet = 1.0 / (c0 * M[0] + c1 * M[3] + c2 * M[6]);
+    inv[0] = c0 * invdet; inv[1] = c1 * invdet; inv[2] = c2 * invdet;
+    inv[3] = (M[5] * M[6] - M[3] * M[8]) * invdet; inv[4] = (M[0] * M[8] - M[2] * M[6]) * invdet; inv[5] = (M[2] * M[3] - M[0] * M[5]) * invdet;
+    inv[6] = (M[3] * M[7] - M[4] * M[6]) * invdet; inv[7] = (M[1] * M[6] - M[0] * M[7]) * invdet; inv[8] = (M[0] * M[4] - M[1] * M[3]) * invdet;
+}
+
+/* triangulateLinear (triangulation.cpp:820-895): the point closest to all camera rays, in closed form */
+static int triangulate_linear(const orc_tri_params *par, int pose_count, const orc_campose *trail, const double *image_features,
+                              const double *feature_velocities, int calc_derivatives, int derivative_test, double time_shift,
+                              double *pf, double *dpfdp, double *dpfdq, double *dpfdt)
+{
+    double S0[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, S1[3] = {0, 0, 0}, S0inv[9];
+    for (int i = 0; i < pose_count; ++i) {                                         /* :830-842 */
+        double ip[3] = {image_features[2 * i], image_features[2 * i + 1], 1.0}, v[3], A[9], Ap[3];
+        if (derivative_test) { ip[0] += time_shift * feature_velocities[2 * i]; ip[1] += time_shift * feature_velocities[2 * i + 1]; }
+        mTv3(trail[i].R, ip, v);
+        const double n = sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+        const double vn[3] = {v[0] / n, v[1] / n, v[2] / n};
+        for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) A[3 * r + c] = (r == c ? 1.0 : 0.0) - vn[r] * vn[c];
+        mv3(A, trail[i].p, Ap);
+        for (int k = 0; k < 9; ++k) S0[k] += A[k];
+        for (int k = 0; k < 3; ++k) S1[k] += Ap[k];
+    }
+    inv3(S0, S0inv);
+    mv3(S0inv, S1, pf);
+    if (calc_derivatives) {                                                        /* :846-890 */
+        dpfdt[0] = dpfdt[1] = dpfdt[2] = 0.0;
+        for (int i = 0; i < pose_count; ++i) {
+            double ip[3] = {image_features[2 * i], image_features[2 * i + 1], 1.0}, v[3], A[9];
+            if (derivative_test) { ip[0] += time_shift * feature_velocities[2 * i]; ip[1] += time_shift * feature_velocities[2 * i + 1]; }
+            mTv3(trail[i].R, ip, v);
+            const double n = sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+            const double vn[3] = {v[0] / n, v[1] / n, v[2] / n};
+            for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) A[3 * r + c] = (r == c ? 1.0 : 0.0) - vn[r] * vn[c];
+            mm3(S0inv, A, dpfdp + 9 * i);                                          /* dpfdp = S0inv * A */
+            double dvdq[12];                                                       /* 3 x 4 row-major: column k = dR[k]^T ip */
+            for (int k = 0; k < 4; ++k) { double t[3]; mTv3(trail[i].dR[k], ip, t); for (int r = 0; r < 3; ++r) dvdq[4 * r + k] = t[r]; }
+            double dvndv[9];
+            for (int k = 0; k < 9; ++k) dvndv[k] = A[k] / n;
+            double dpfdvn[9];                                                      /* column k = S0inv Q S0inv S1 - S0inv Q p */
+            for (int k = 0; k < 3; ++k) {
+                double Q[9], SQ[9], t0[3], t1[3], t2[3];
+                for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) Q[3 * r + c] = (r == k ? vn[c] : 0.0) + (c == k ? vn[r] : 0.0);
+                mm3(S0inv, Q, SQ);
+                mv3(S0inv, S1, t0);
+                mv3(SQ, t0, t1);
+                mv3(SQ, trail[i].p, t2);
+                for (int r = 0; r < 3; ++r) dpfdvn[3 * r + k] = t1[r] - t2[r];
+            }
+            double G[9];
+            mm3(dpfdvn, dvndv, G);
+            for (int r = 0; r < 3; ++r) for (int k = 0; k < 4; ++k)
+                dpfdq[12 * i + 4 * r + k] = G[3 * r] * dvdq[k] + G[3 * r + 1] * dvdq[4 + k] + G[3 * r + 2] * dvdq[8 + k];
+            if (par->estimateImuCameraTimeShift) {
+                const double vel[3] = {feature_velocities[2 * i], feature_velocities[2 * i + 1], 0.0};
+                double dvdt[3], t[3];
+                mTv3(trail[i].R, vel, dvdt);
+                mv3(G, dvdt, t);
+                for (int r = 0; r < 3; ++r) dpfdt[r] += t[r];
+            }
+        }
+    }
+    for (int i = 0; i < pose_count; ++i) {                                          /* isBehind, :54-60 */
+        double dd[3], a[3];
+        for (int k = 0; k < 3; ++k) dd[k] = pf[k] - trail[i].p[k];
+        mv3(trail[i].R, dd, a);
+        if (a[2] < 0) return TRI_BEHIND;
+    }
+    return TRI_OK;
+}
+
 /* Triangulator::triangulate, iterative branch (triangulation.cpp:120-407).
  * image_features / feature_velocities: [pose_count][2]; outputs dpfdp [pose_count][9], dpfdq [pose_count][12] (3x4
  * row-major), dpfdt[3] are written when calc_derivatives and the status is not an early return. */
@@ -243,6 +324,9 @@ int orc_triangulate(const orc_tri_params *par, int pose_count, const orc_campose
                     const double *feature_velocities, int stereo, int calc_derivatives, int derivative_test, double time_shift,
                     double *pf, double *dpfdp, double *dpfdq, double *dpfdt)
 {
+    if (par->useLinearTriangulation)                                               /* :146-152 */
+        return triangulate_linear(par, pose_count, trail, image_features, feature_velocities, calc_derivatives, derivative_test,
+                                  time_shift, pf, dpfdp, dpfdq, dpfdt);
     const int est = par->estimateImuCameraTimeShift;
     const int ind1 = stereo ? pose_count / 2 - 1 : pose_count - 1;
     double dpf2[45];

@@ -152,6 +152,37 @@ def test_random_tracks_match_the_oracle(oracle, trail_len, npose, stereo):
     assert "OK" in seen and len(seen) >= 2, seen
 
 
+@pytest.mark.parametrize("trail_len,npose,stereo", [(20, 10, True), (20, 21, True), (20, 5, False), (12, 2, True), (20, 21, False)])
+def test_linear_triangulation_branch_matches_the_oracle(oracle, trail_len, npose, stereo):
+    """odometry.useLinearTriangulation (parameter_definitions.c:31; Triangulator::triangulate :146-152 -> triangulateLinear :820-895):
+    closed-form point and derivatives, statuses OK / BEHIND (/ BAD_DEPTH from the caller's window), the same prepareVisualUpdate."""
+    rng = np.random.default_rng(900 + 100 * trail_len + npose + (7 if stereo else 0))
+    B = 48
+    T1, T2, means, idx, feat, vel = _random_tracks(oracle, rng, B, trail_len, npose, stereo)
+    kw = dict(useLinearTriangulation=1, triangulationMaxDist=60.0)
+    vp = capi.vu_default_params(imu_to_camera=T1, second_imu_to_camera=T2, **kw) if stereo else capi.vu_default_params(imu_to_camera=T1, **kw)
+    y = feat.reshape(B, -1) - 2e-3
+    with capi.Context(width=64, height=64) as ctx:
+        H, v, f, pf, st, act = _device_prepare(ctx, trail_len, means, vp, idx, feat, vel, y=y)
+        vp0 = capi.vu_default_params(imu_to_camera=T1, second_imu_to_camera=T2) if stereo else capi.vu_default_params(imu_to_camera=T1)
+        H0, _, _, pf0, st0, _ = _device_prepare(ctx, trail_len, means, vp0, idx, feat, vel, y=y)
+    par = oracle.tri_default_params(**kw)
+    seen, n_ok = set(), 0
+    for b in range(B):
+        ost, ops, opf, oH, of = oracle.visual_track_prepare(par, means[b], idx[b], T1, T2, feat[b], vel[b])
+        assert st[b].tolist() == [ost, ops], (b, st[b], ost, ops)
+        assert act[b] == (1 if (ost, ops) == (0, 0) else 0)
+        seen.add(oracle.TRI_STATUS[ost])
+        if ost == 0 and ops == 0:
+            n_ok += 1
+            assert _rel(pf[b], opf) < TOL and _rel(H[b], oH) < TOL and _rel(f[b], of) < TOL, (b, _rel(H[b], oH))
+            assert np.abs(v[b] - (y[b] - of)).max() < 1e-9
+            if st0[b].tolist() == [0, 0]:                     # a different estimator: the parameter did switch branches
+                assert not np.array_equal(H[b], H0[b])
+    assert "OK" in seen and n_ok >= B // 3, (seen, n_ok)
+    assert seen <= {"OK", "BEHIND", "BAD_DEPTH"}, seen      # the closed form has no convergence / conditioning statuses
+
+
 def test_parameters_reach_the_kernel(oracle):
     """Depth window, iteration limit and the time-shift switch change the result exactly as in the oracle."""
     rng = np.random.default_rng(5)

@@ -124,6 +124,58 @@ def test_visual_triangulate_matlab_point_and_derivatives(oracle, fx):
     assert D.max() < 1e-3
 
 
+def test_linear_triangulation_derivatives_on_the_reference_fixtures(oracle, fx):
+    """useLinearTriangulation = true: test/triangulation.cpp:107 leaves this case as a TODO ("Make a new test case for this?") and
+    skips the Matlab point for it (:166-168). Pinned here the way SECTION "triangulate" pins the default branch: status OK and the
+    numeric-vs-analytic derivative check of triangulateLinear (:820-895) on the same inline data, mono and stereo; the closed-form
+    point lies within a few per cent of the depth of the iterative one."""
+    m, T, uv, vel, par0, idx = _visual_setup(oracle, fx)
+    par = oracle.tri_default_params(useLinearTriangulation=1)
+    trail = oracle.extract_camera_pose_trail(m, idx, T)
+    st, pf, dp, dq, dt = oracle.triangulate(par, trail, uv, vel, stereo=False, derivative_test=True, time_shift=0.0)
+    assert st == 0
+    depth = np.linalg.norm(fx["visual_pf_matlab"] - np.array(trail[0].p))
+    assert np.linalg.norm(pf - fx["visual_pf_matlab"]) < 0.2 * depth
+
+    def run(x):
+        tr = oracle.extract_camera_pose_trail(x_to_state(m, x, 10, True), idx, T)
+        s, pf, dp, dq, dt = oracle.triangulate(par, tr, uv, vel, stereo=False, derivative_test=True, time_shift=x[-1])
+        assert s == 0
+        return pf, out_to_dpf(dp, dq, dt)
+    D = der_check(state_to_x(m, 10, True), lambda x: run(x)[0], lambda x: run(x)[1])
+    assert D.max() < 1e-3
+
+    # Stereo: triangulateLinear differentiates the ray direction with respect to the quaternion but not the camera position, which
+    # also moves with the quaternion when imuToCamera has a translation (p_cam = p_imu - R' t, triangulation.cpp:86-100). That is the
+    # reference's code (restated as is); the check therefore covers every column with the extrinsic translations set to zero, and
+    # the position / time-shift columns with the fixture's real extrinsics.
+    m, T1, T2, uv, vel, _, idx = _stereo_setup(oracle, fx)
+    pos_t = [7 * i + c for i in range(10) for c in range(3)] + [70]
+    for zero_baseline in (True, False):
+        A1, A2 = T1.copy(), T2.copy()
+        if zero_baseline:
+            A1[:3, 3] = 0; A2[:3, 3] = 0
+
+        def run2(x):
+            tr = oracle.extract_camera_pose_trail(x_to_state(m, x, 10, False), idx, A1, A2)
+            s, pf, dp, dq, dt = oracle.triangulate(par, tr, uv, vel, stereo=True, derivative_test=True, time_shift=x[-1])
+            assert s == 0
+            return pf, out_to_dpf(*_sum_stereo(dp, dq), dt)
+        D = der_check(state_to_x(m, 10, False), lambda x: run2(x)[0], lambda x: run2(x)[1])
+        assert (D if zero_baseline else D[:, pos_t]).max() < 1e-3
+
+        def run3(x):          # through prepareVisualUpdate: the 40 x 71 Jacobian of the stereo track
+            tr = oracle.extract_camera_pose_trail(x_to_state(m, x, 10, False), idx, A1, A2)
+            s, pf, dp, dq, dt = oracle.triangulate(par, tr, uv, vel, stereo=True, derivative_test=True, time_shift=x[-1])
+            dp, dq = _sum_stereo(dp, dq)
+            ps, H, f = oracle.prepare_visual_update(pf, dp, dq, dt, vel, tr, idx, len(m), derivative_test=True, time_shift=x[-1])
+            assert s == 0 and ps == 0
+            cols = list(range(POS, POS + 3)) + list(range(ORI, ORI + 4)) + list(range(CAM, CAM + 7 * 9)) + [SFT]
+            return f, H[:, cols]
+        D = der_check(state_to_x(m, 10, False), lambda x: run3(x)[0], lambda x: run3(x)[1])
+        assert D.shape == (40, 71) and (D if zero_baseline else D[:, pos_t]).max() < 1e-4
+
+
 def test_visual_prepare_visual_update_jacobian(oracle, fx):
     """test/triangulation.cpp:199-245 SECTION "prepareVisualUpdateCheckJacobian": H vs d f / d x < 1e-6."""
     m, T, uv, vel, par, idx = _visual_setup(oracle, fx)
