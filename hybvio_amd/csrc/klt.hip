@@ -586,7 +586,8 @@ __global__ __launch_bounds__(64, WPS) void klt_kernel(KltArgs a)
             uint32_t wA, wB;
             bilinear_weights(cxn - (float)inx, cyn - (float)iny, wA, wB);
 
-            const uint32_t *jrow = jt + (iny - toy + half * HALF_ROWS) * TSX + (inx - tox + cx);
+            // (rows < 64: the 24-bit multiply is full rate, the v_mul_lo_u32 hipcc picks for a 32-bit product a quarter)
+            const uint32_t *jrow = jt + __umul24((unsigned)(iny - toy + half * HALF_ROWS), (unsigned)TSX) + (unsigned)(inx - tox + cx);
             uint32_t jp = jrow[0];
             int sb1 = 0, sb2 = 0;
 #pragma unroll
@@ -642,7 +643,8 @@ __global__ __launch_bounds__(64, WPS) void klt_kernel(KltArgs a)
                 ensure_tile(inx, iny);
                 uint32_t wA, wB;
                 bilinear_weights(ex - (float)inx, ey - (float)iny, wA, wB);
-                const uint32_t *jrow = jt + (iny - toy + half * HALF_ROWS) * TSX + (inx - tox + cx);
+                // (rows < 64: the 24-bit multiply is full rate, the v_mul_lo_u32 hipcc picks for a 32-bit product a quarter)
+            const uint32_t *jrow = jt + __umul24((unsigned)(iny - toy + half * HALF_ROWS), (unsigned)TSX) + (unsigned)(inx - tox + cx);
                 uint32_t jp = jrow[0];
                 int sabs = 0;
                 // pixel (cx, half*16 + k) exists for k < 16 (half 0) / k < 15 (half 1) and cx < 31. Derived here from an opaque copy
