@@ -520,6 +520,7 @@ struct UpdateArgs {
     int spec, n_tracks, max_successful;
     int *cursor;                      // [batch] first track of the filter that is not final yet
     const int *gate_in;               // spec 2: [n_tracks][batch] gate results of spec 1 (a.status stays free for this launch's own output)
+    const int *nr_rec;                // ragged batches: rows of every record (<= nr, which is then the record stride of H and v; 0: none)
     int *cursor_out;                  // spec 3: the cursor after this pass (ping-pong: late workgroups still read the old one)
     int *pub;                         // spec 3: [n_tracks][batch] published gate decisions, pass_id * 4 + {1 not applicable, 2 inlier}
     int pass_id;                      // spec 3: > 0, distinct per pass of a frame (pub is zeroed per frame)
@@ -602,9 +603,16 @@ __global__ __launch_bounds__(UPD_THREADS) void ekf_update_kernel(UpdateArgs a)
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);     // wave-uniform: tile indices and their addresses stay on the scalar unit
     constexpr int nwaves = UPD_THREADS / 64;
-    const int n = a.n, nr = a.nr, l = a.l, R = a.Rs;       // R is the column STRIDE of T below; a.R rows are used
+    const int n = a.n, l = a.l;
+    int nr = a.nr, R = a.Rs, Rfull = a.R;                   // R is the column STRIDE of T below; Rfull rows are used
+    if (a.nr_rec) {                                        // ragged batch: this record's own row count (uniform per workgroup)
+        nr = a.nr_rec[e];
+        if (nr < 1 || nr > a.nr) return;                   // no track (the prepare launch also cleared `active`)
+        Rfull = nr + n + 1; R = Rfull;
+        if (USE_LDS) while ((R & 31) != 15 && (R & 31) != 17) R++;
+    }
     double *m = a.m + (size_t)b * n, *P = a.P + (size_t)b * n * n;
-    const double *H = a.H + (size_t)e * nr * l;
+    const double *H = a.H + (size_t)e * a.nr * l;          // record stride: the launch's row count; leading dimension: nr
     const double rd = a.rdiag ? a.rdiag[b] : a.rd0;
     // Tall matrix T (a.R rows x nr columns, column-major with stride R >= a.R: T(r, c) = T[c * R + r]; in LDS
     // the stride is padded to 15 or 17 mod 32 doubles, see ekf_launch_update):
@@ -615,7 +623,7 @@ __global__ __launch_bounds__(UPD_THREADS) void ekf_update_kernel(UpdateArgs a)
     // only needs rows 0 .. nr. All LDS comes from the dynamic region (keeps the base 16-byte aligned):
     // [T] W[256] col[320] red[16] flag. USE_LDS is a template parameter so that the common case compiles to
     // ds_read / ds_write (a run-time select would turn every access into a flat load).
-    double *T = USE_LDS ? smem : a.ws + (size_t)b * R * nr;
+    double *T = USE_LDS ? smem : a.ws + (size_t)b * a.Rs * a.nr;
     double *W = USE_LDS ? smem + (((size_t)R * nr + 1) & ~(size_t)1) : smem;   // inverse of the current diagonal block
     double *col = W + 256;                                                      // column broadcast buffer of the diagonal factor
     double *red = col + 544;                                                    // col[256 .. 527] is the dump area of factor_diag_block's branch-free stores
@@ -628,7 +636,7 @@ __global__ __launch_bounds__(UPD_THREADS) void ekf_update_kernel(UpdateArgs a)
     // R = rd1 on the SAME H P: S (without R) and v are parked in the H staging area after phase B, the gate runs the
     // Cholesky on the measurement rows only, and an inlier restores S + rd1 I and v and runs the full factorisation.
     const bool two_r = MODE == 2 && a.mode == 3;
-    int Rlim = (gate_only || two_r) ? nr + 1 : a.R;
+    int Rlim = (gate_only || two_r) ? nr + 1 : Rfull;
 
     PHASE_STAMP(0);
     const int kq = lane >> 4, cl = lane & 15;      // MFMA lane coordinates: k sub-step / output row group, column
@@ -760,7 +768,7 @@ __global__ __launch_bounds__(UPD_THREADS) void ekf_update_kernel(UpdateArgs a)
         }
     }
     for (int i = t; i < nr; i += UPD_THREADS) {
-        double r = a.v[(size_t)e * nr + i];
+        double r = a.v[(size_t)e * a.nr + i];
         if (a.generic) { double s = 0; for (int k = 0; k < l; k++) s += H[(size_t)k * nr + i] * m[k]; r -= s; }
         T[(size_t)i * R + rv] = r;
     }
@@ -917,7 +925,7 @@ __global__ __launch_bounds__(UPD_THREADS) void ekf_update_kernel(UpdateArgs a)
                 const int c = e / (nr + 1), i = e - c * (nr + 1);
                 T[(size_t)c * R + i] = Hs[256 + e] + (i == c ? shift : 0.0);
             }
-            Rlim = a.R;
+            Rlim = Rfull;
             __syncthreads();
         }
     }
@@ -1497,6 +1505,8 @@ struct Ekf {
     // buffers of hv_ekf_visual_track_dev (row f3), sized on first use
     double *vuH = nullptr, *vuv = nullptr, *vupf = nullptr;
     unsigned char *vuactive = nullptr;
+    int *vurows = nullptr;                                // ragged batches: per-filter rows of the current visit (written by vu_prepare)
+    int *sprows = nullptr;                                // ... and per (track, filter) record of the speculative loop
     int vu_rows = 0;
     // speculative frame loop: per (track, filter) records + per-filter cursor and the update count each record was prepared at
     double *spH = nullptr, *spv = nullptr, *sppf = nullptr;
@@ -1514,7 +1524,8 @@ static int ekf_launch_update(Ekf *e, int nr, int l, const double *H_dev, const d
                              const unsigned char *active_dev, const int *require_inlier_dev = nullptr,
                              int *success_counter_dev = nullptr, double rd1 = 0.0, bool *two_r_done = nullptr,
                              int spec = 0, int n_tracks = 0, int *cursor_dev = nullptr, int max_successful = 0,
-                             const int *gate_in_dev = nullptr, int *cursor_out_dev = nullptr, int *pub_dev = nullptr, int pass_id = 0)
+                             const int *gate_in_dev = nullptr, int *cursor_out_dev = nullptr, int *pub_dev = nullptr, int pass_id = 0,
+                             const int *nr_rec_dev = nullptr)
 {
     Ctx *c = e->c;
     if (nr < 1 || nr > e->max_rows || l < 1 || l > e->n) return HV_ERR_INVALID;
@@ -1533,7 +1544,7 @@ static int ekf_launch_update(Ekf *e, int nr, int l, const double *H_dev, const d
     a.m = e->m; a.P = e->P; a.H = H_dev; a.v = v_dev; a.rdiag = rdiag_dev; a.rd0 = rd0; a.rd1 = rd1; a.noise_scale = e->noise_scale;
     a.ws = e->ws; a.chi2 = chi2_dev; a.status = status_dev; a.active = active_dev; a.require_inlier = require_inlier_dev; a.success_counter = success_counter_dev;
     a.spec = spec; a.n_tracks = n_tracks; a.cursor = cursor_dev; a.max_successful = max_successful; a.gate_in = gate_in_dev;
-    a.cursor_out = cursor_out_dev; a.pub = pub_dev; a.pass_id = pass_id;
+    a.cursor_out = cursor_out_dev; a.pub = pub_dev; a.pass_id = pass_id; a.nr_rec = nr_rec_dev;
     size_t tall = (((size_t)a.Rs * nr + 1) & ~(size_t)1) * sizeof(double);
     const size_t small = (size_t)(256 + 544 + UPD_THREADS / 64 + 2) * sizeof(double);           // W + col (incl. dump area) + red + flag
     const int ti = (nr + 15) / 16, lbk = (l + 15) / 16;
@@ -1631,7 +1642,7 @@ void hv_ekf_destroy(hv_ekf *h)
     if (e->c && e->c->stream) (void)hipStreamSynchronize(e->c->stream);
     void *ptrs[] = { e->m, e->P, e->P1, e->m1, e->Q, e->dydx, e->ws, e->sH, e->sv, e->sr, e->schi2, e->simu,
                      e->sstatus, e->sdrop, e->sactive, e->vuH, e->vuv, e->vupf, e->vuactive, e->vustage,
-                     e->spH, e->spv, e->sppf, e->spactive, e->spcursor, e->spepoch, e->spcursor2, e->sppub };
+                     e->spH, e->spv, e->sppf, e->spactive, e->spcursor, e->spepoch, e->spcursor2, e->sppub, e->vurows, e->sprows };
     for (void *p : ptrs) if (p) (void)hipFree(p);
     delete h;
 }
@@ -1744,7 +1755,8 @@ int hv_ekf_visual_prepare_dev(hv_ekf *h, const hv_vu_params *p, int np, const in
 
 static int visual_track_dev_impl(hv_ekf *h, const hv_vu_params *p, int np, const int *idx, const double *feat, const double *vel,
                                  const double *y, double r_gate, double r_update, int *status_dev, int *gate_status_dev,
-                                 double *chi2_dev, double *pf_dev, int *success_counter_dev, int max_successful);
+                                 double *chi2_dev, double *pf_dev, int *success_counter_dev, int max_successful,
+                                 const int *np_rec_dev = nullptr);
 
 int hv_ekf_visual_track_dev(hv_ekf *h, const hv_vu_params *p, int np, const int *idx, const double *feat, const double *vel,
                             const double *y, double r_gate, double r_update, int *status_dev, int *gate_status_dev,
@@ -1764,7 +1776,8 @@ int hv_ekf_visual_track_limited_dev(hv_ekf *h, const hv_vu_params *p, int np, co
 
 static int visual_track_dev_impl(hv_ekf *h, const hv_vu_params *p, int np, const int *idx, const double *feat, const double *vel,
                                  const double *y, double r_gate, double r_update, int *status_dev, int *gate_status_dev,
-                                 double *chi2_dev, double *pf_dev, int *success_counter_dev, int max_successful)
+                                 double *chi2_dev, double *pf_dev, int *success_counter_dev, int max_successful,
+                                 const int *np_rec_dev)
 {
     if (!h || !status_dev || !gate_status_dev || !y) return HV_ERR_INVALID;
     Ekf *e = &h->e; Ctx *c = e->c;
@@ -1784,6 +1797,13 @@ static int visual_track_dev_impl(hv_ekf *h, const hv_vu_params *p, int np, const
         if (!e->vuactive) HV_HIP(c, hipMalloc(reinterpret_cast<void **>(&e->vuactive), e->batch));
         e->vu_rows = rows;
     }
+    // ragged batch (filters with tracks of different lengths, or none, in one visit): np is the longest track = the record stride;
+    // the prepare launch writes every filter's row count for the gate / update launch
+    const int *nr_rec = nullptr;
+    if (np_rec_dev) {
+        if (!e->vurows) HV_HIP(c, hipMalloc(reinterpret_cast<void **>(&e->vurows), sizeof(int) * e->batch));
+        a.np_rec = np_rec_dev; a.rows_out = e->vurows; nr_rec = e->vurows;
+    }
     a.H = e->vuH; a.v = e->vuv; a.f = nullptr; a.pf = pf_dev ? pf_dev : e->vupf; a.status = status_dev; a.active = e->vuactive;
     a.gate_status = gate_status_dev;                       // preset to NOT_COMPUTED; the gate overwrites it where it runs
     a.success_counter = success_counter_dev; a.max_successful = max_successful;
@@ -1796,7 +1816,7 @@ static int visual_track_dev_impl(hv_ekf *h, const hv_vu_params *p, int np, const
     // fused launch's 0.130, an accepted one 0.110 + 0.21 instead of 0.23 -- a loss as soon as a quarter of the visits are inliers,
     // so the fused launch stays the default here; the streaming kernel serves the gate-ONLY entry points (hv_ekf_visual_dev mode 0).
     static const int stream_gate = [] { const char *s_ = getenv("HV_EKF_STREAM_GATE"); return s_ ? atoi(s_) : -1; }();
-    if (stream_gate == 1) {
+    if (stream_gate == 1 && !nr_rec) {
         bool done = false;
         rc = hv::ekf_launch_gate_stream(e, rows, e->n, e->vuH, e->vuv, r_gate * r_gate * e->noise_scale, chi2_dev, gate_status_dev, e->vuactive,
                                         success_counter_dev, max_successful, &done);
@@ -1807,16 +1827,19 @@ static int visual_track_dev_impl(hv_ekf *h, const hv_vu_params *p, int np, const
     }
     bool fused = false;
     rc = hv::ekf_launch_update(e, rows, e->n, e->vuH, e->vuv, nullptr, r_gate * r_gate * e->noise_scale, 3, 0, 1, chi2_dev,
-                               gate_status_dev, e->vuactive, nullptr, success_counter_dev, r_update * r_update * e->noise_scale, &fused);
+                               gate_status_dev, e->vuactive, nullptr, success_counter_dev, r_update * r_update * e->noise_scale, &fused,
+                               0, 0, nullptr, 0, nullptr, nullptr, nullptr, 0, nr_rec);
     if (rc != HV_OK || fused) return rc;
     rc = hv::ekf_launch_update(e, rows, e->n, e->vuH, e->vuv, nullptr, r_gate * r_gate * e->noise_scale, 0, 0, 0, chi2_dev,
-                               gate_status_dev, e->vuactive);
+                               gate_status_dev, e->vuactive, nullptr, nullptr, 0.0, nullptr, 0, 0, nullptr, 0, nullptr, nullptr, nullptr, 0, nr_rec);
     if (rc != HV_OK) return rc;
     return hv::ekf_launch_update(e, rows, e->n, e->vuH, e->vuv, nullptr, r_update * r_update * e->noise_scale, 1, 0, 1, nullptr,
-                                 nullptr, e->vuactive, gate_status_dev, success_counter_dev);
+                                 nullptr, e->vuactive, gate_status_dev, success_counter_dev, 0.0, nullptr, 0, 0, nullptr, 0, nullptr, nullptr,
+                                 nullptr, 0, nr_rec);
 }
 
-int hv_ekf_visual_frame_dev(hv_ekf *h, const hv_vu_params *p, int n_tracks, int np, const int *idx, const double *feat, const double *vel,
+static int visual_frame_dev_impl(hv_ekf *h, const hv_vu_params *p, int n_tracks, int np, const int *np_rec_dev, const int *idx,
+                                 const double *feat, const double *vel,
                             const double *y, double r_gate, double r_update, int *status_dev, int *gate_status_dev, double *chi2_dev,
                             double *pf_dev, int *success_counter_dev, int max_successful)
 {
@@ -1846,6 +1869,8 @@ int hv_ekf_visual_frame_dev(hv_ekf *h, const hv_vu_params *p, int n_tracks, int 
             HV_HIP(c, hipMalloc(reinterpret_cast<void **>(&e->spepoch), sizeof(int) * rec));
             HV_HIP(c, hipMalloc(reinterpret_cast<void **>(&e->spcursor2), sizeof(int) * B));
             HV_HIP(c, hipMalloc(reinterpret_cast<void **>(&e->sppub), sizeof(int) * rec));
+            if (e->sprows) { (void)hipFree(e->sprows); e->sprows = nullptr; }
+            HV_HIP(c, hipMalloc(reinterpret_cast<void **>(&e->sprows), sizeof(int) * rec));
             e->sp_records = rec; e->sp_rows = rows;
         }
         HV_HIP(c, hipMemsetAsync(e->spcursor, 0, sizeof(int) * B, c->stream));
@@ -1856,6 +1881,8 @@ int hv_ekf_visual_frame_dev(hv_ekf *h, const hv_vu_params *p, int n_tracks, int 
         a.H = e->spH; a.v = e->spv; a.f = nullptr; a.pf = pf_dev ? pf_dev : e->sppf; a.status = status_dev; a.active = e->spactive;
         a.gate_status = gate_status_dev; a.success_counter = success_counter_dev; a.max_successful = max_successful;
         a.spec_tracks = n_tracks; a.cursor = e->spcursor; a.epoch = e->spepoch;
+        const int *nr_rec = nullptr;                                  // ragged: per-record rows, written by the prepare launches
+        if (np_rec_dev) { a.np_rec = np_rec_dev; a.rows_out = e->sprows; nr_rec = e->sprows; }
         // HV_EKF_SPEC_SPLIT=1 (environment, experiments only): gate-all and apply-first-inlier as two launches per pass (the first
         // r02 form); default: one launch, the workgroups of a filter settle the visit order among themselves (UpdateArgs spec 3)
         const char *env_split = getenv("HV_EKF_SPEC_SPLIT");
@@ -1870,17 +1897,18 @@ int hv_ekf_visual_frame_dev(hv_ekf *h, const hv_vu_params *p, int n_tracks, int 
                 bool fused = false;
                 rc = hv::ekf_launch_update(e, rows, e->n, e->spH, e->spv, nullptr, r_gate * r_gate * e->noise_scale, 3, 0, 1, chi2_dev,
                                            gate_status_dev, e->spactive, nullptr, success_counter_dev, r_update * r_update * e->noise_scale, &fused,
-                                           3, n_tracks, cur, max_successful, nullptr, nxt, e->sppub, pass + 1);
+                                           3, n_tracks, cur, max_successful, nullptr, nxt, e->sppub, pass + 1, nr_rec);
                 if (rc != HV_OK) return rc;
                 if (fused) { int *sw = cur; cur = nxt; nxt = sw; continue; }
                 // (mode 3 not available for this shape: the two launches below, on the same cursor)
             }
             rc = hv::ekf_launch_update(e, rows, e->n, e->spH, e->spv, nullptr, r_gate * r_gate * e->noise_scale, 0, 0, 0, chi2_dev,
-                                       gate_status_dev, e->spactive, nullptr, success_counter_dev, 0.0, nullptr, 1, n_tracks, cur, max_successful);
+                                       gate_status_dev, e->spactive, nullptr, success_counter_dev, 0.0, nullptr, 1, n_tracks, cur, max_successful,
+                                       nullptr, nullptr, nullptr, 0, nr_rec);
             if (rc != HV_OK) return rc;
             rc = hv::ekf_launch_update(e, rows, e->n, e->spH, e->spv, nullptr, r_update * r_update * e->noise_scale, 1, 0, 1, nullptr,
                                        nullptr, e->spactive, nullptr, success_counter_dev, 0.0, nullptr, 2, n_tracks, cur, max_successful,
-                                       gate_status_dev);
+                                       gate_status_dev, nullptr, nullptr, 0, nr_rec);
             if (rc != HV_OK) return rc;
         }
         return HV_OK;
@@ -1889,10 +1917,29 @@ int hv_ekf_visual_frame_dev(hv_ekf *h, const hv_vu_params *p, int n_tracks, int 
         const int rc = visual_track_dev_impl(h, p, np, idx + (size_t)k * B * np, feat + (size_t)k * B * nt * 2, vel + (size_t)k * B * nt * 2,
                                              y + (size_t)k * B * nt * 2, r_gate, r_update, status_dev + (size_t)k * B * 2,
                                              gate_status_dev + (size_t)k * B, chi2_dev ? chi2_dev + (size_t)k * B : nullptr,
-                                             pf_dev ? pf_dev + (size_t)k * B * 3 : nullptr, success_counter_dev, max_successful);
+                                             pf_dev ? pf_dev + (size_t)k * B * 3 : nullptr, success_counter_dev, max_successful,
+                                             np_rec_dev ? np_rec_dev + (size_t)k * B : nullptr);
         if (rc != HV_OK) return rc;
     }
     return HV_OK;
+}
+
+int hv_ekf_visual_frame_dev(hv_ekf *h, const hv_vu_params *p, int n_tracks, int np, const int *idx, const double *feat, const double *vel,
+                            const double *y, double r_gate, double r_update, int *status_dev, int *gate_status_dev, double *chi2_dev,
+                            double *pf_dev, int *success_counter_dev, int max_successful)
+{
+    return visual_frame_dev_impl(h, p, n_tracks, np, nullptr, idx, feat, vel, y, r_gate, r_update, status_dev, gate_status_dev, chi2_dev,
+                                 pf_dev, success_counter_dev, max_successful);
+}
+
+int hv_ekf_visual_frame_ragged_dev(hv_ekf *h, const hv_vu_params *p, int n_tracks, int np_max, const int *n_poses_dev, const int *idx,
+                                   const double *feat, const double *vel, const double *y, double r_gate, double r_update,
+                                   int *status_dev, int *gate_status_dev, double *chi2_dev, double *pf_dev, int *success_counter_dev,
+                                   int max_successful)
+{
+    if (!n_poses_dev) return HV_ERR_INVALID;
+    return visual_frame_dev_impl(h, p, n_tracks, np_max, n_poses_dev, idx, feat, vel, y, r_gate, r_update, status_dev, gate_status_dev,
+                                 chi2_dev, pf_dev, success_counter_dev, max_successful);
 }
 
 int hv_ekf_visual_track(hv_ekf *h, const hv_vu_params *p, int np, const int *idx, const double *feat, const double *vel,
@@ -1932,7 +1979,8 @@ int hv_ekf_visual_track(hv_ekf *h, const hv_vu_params *p, int np, const int *idx
     return HV_OK;
 }
 
-int hv_ekf_visual_frame(hv_ekf *h, const hv_vu_params *p, int n_tracks, int np, const int *idx, const double *feat, const double *vel,
+static int visual_frame_host_impl(hv_ekf *h, const hv_vu_params *p, int n_tracks, int np, const int *n_poses, const int *idx,
+                                  const double *feat, const double *vel,
                         const double *y, double r_gate, double r_update, int *status, int *gate_status, double *chi2, double *pf,
                         int *success_count, int max_successful)
 {
@@ -1943,7 +1991,8 @@ int hv_ekf_visual_frame(hv_ekf *h, const hv_vu_params *p, int n_tracks, int np, 
     const size_t o_idx = 0, o_feat = up(o_idx + B * np * sizeof(int)), o_vel = up(o_feat + B * nt * 2 * sizeof(double));
     const size_t o_y = up(o_vel + B * nt * 2 * sizeof(double)), o_st = up(o_y + B * nt * 2 * sizeof(double));
     const size_t o_gs = up(o_st + B * 2 * sizeof(int)), o_chi = up(o_gs + B * sizeof(int)), o_pf = up(o_chi + B * sizeof(double));
-    const size_t o_cnt = up(o_pf + B * 3 * sizeof(double)), total = up(o_cnt + (size_t)e->batch * sizeof(int));
+    const size_t o_cnt = up(o_pf + B * 3 * sizeof(double)), o_np = up(o_cnt + (size_t)e->batch * sizeof(int));
+    const size_t total = up(o_np + B * sizeof(int));
     if (e->vustage_bytes < total) {
         HV_HIP(c, hipStreamSynchronize(c->stream));
         if (e->vustage) (void)hipFree(e->vustage);
@@ -1956,7 +2005,9 @@ int hv_ekf_visual_frame(hv_ekf *h, const hv_vu_params *p, int n_tracks, int np, 
     HV_HIP(c, hipMemcpyAsync(d + o_feat, feat, B * nt * 2 * sizeof(double), hipMemcpyHostToDevice, c->stream));
     HV_HIP(c, hipMemcpyAsync(d + o_vel, vel, B * nt * 2 * sizeof(double), hipMemcpyHostToDevice, c->stream));
     HV_HIP(c, hipMemcpyAsync(d + o_y, y, B * nt * 2 * sizeof(double), hipMemcpyHostToDevice, c->stream));
-    const int rc = hv_ekf_visual_frame_dev(h, p, n_tracks, np, reinterpret_cast<const int *>(d + o_idx), reinterpret_cast<const double *>(d + o_feat),
+    if (n_poses) HV_HIP(c, hipMemcpyAsync(d + o_np, n_poses, B * sizeof(int), hipMemcpyHostToDevice, c->stream));
+    const int rc = visual_frame_dev_impl(h, p, n_tracks, np, n_poses ? reinterpret_cast<const int *>(d + o_np) : nullptr,
+                                           reinterpret_cast<const int *>(d + o_idx), reinterpret_cast<const double *>(d + o_feat),
                                            reinterpret_cast<const double *>(d + o_vel), reinterpret_cast<const double *>(d + o_y), r_gate, r_update,
                                            reinterpret_cast<int *>(d + o_st), reinterpret_cast<int *>(d + o_gs), reinterpret_cast<double *>(d + o_chi),
                                            reinterpret_cast<double *>(d + o_pf), reinterpret_cast<int *>(d + o_cnt), max_successful);
@@ -1968,6 +2019,23 @@ int hv_ekf_visual_frame(hv_ekf *h, const hv_vu_params *p, int n_tracks, int np, 
     if (success_count) HV_HIP(c, hipMemcpyAsync(success_count, d + o_cnt, (size_t)e->batch * sizeof(int), hipMemcpyDeviceToHost, c->stream));
     HV_HIP(c, hipStreamSynchronize(c->stream));
     return HV_OK;
+}
+
+int hv_ekf_visual_frame(hv_ekf *h, const hv_vu_params *p, int n_tracks, int np, const int *idx, const double *feat, const double *vel,
+                        const double *y, double r_gate, double r_update, int *status, int *gate_status, double *chi2, double *pf,
+                        int *success_count, int max_successful)
+{
+    return visual_frame_host_impl(h, p, n_tracks, np, nullptr, idx, feat, vel, y, r_gate, r_update, status, gate_status, chi2, pf,
+                                  success_count, max_successful);
+}
+
+int hv_ekf_visual_frame_ragged(hv_ekf *h, const hv_vu_params *p, int n_tracks, int np_max, const int *n_poses, const int *idx,
+                               const double *feat, const double *vel, const double *y, double r_gate, double r_update, int *status,
+                               int *gate_status, double *chi2, double *pf, int *success_count, int max_successful)
+{
+    if (!n_poses) return HV_ERR_INVALID;
+    return visual_frame_host_impl(h, p, n_tracks, np_max, n_poses, idx, feat, vel, y, r_gate, r_update, status, gate_status, chi2, pf,
+                                  success_count, max_successful);
 }
 
 /* developer aid (not in the public header): phase time stamps of the last update kernel */

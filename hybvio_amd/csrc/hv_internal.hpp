@@ -113,6 +113,10 @@ struct VuPrepareArgs {
     double conv_threshold, conv_r, rcond_threshold, min_dist, max_dist;
     int gn_iters, est_shift;
     int linear;                        // useLinearTriangulation: the closed-form branch instead of two-camera + Gauss-Newton
+    // ragged batches: per-record pose counts (np above is then the record stride = the longest track; < 2: no track for this
+    // record) and, as an output for the gate / update launch, the per-record row counts 2 * cameras * poses (0: none)
+    const int *np_rec;
+    int *rows_out;
     double *H, *v, *f, *pf;            // [batch][rows * n] column-major, [batch][rows], optional [batch][rows], [batch][3]
     int *status;                       // [batch][2]: TriangulatorStatus, PrepareVuStatus
     unsigned char *active;             // optional [batch]: 1 where both are OK

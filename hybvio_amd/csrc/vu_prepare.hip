@@ -240,7 +240,12 @@ __device__ __forceinline__ void vu_prepare_body(const VuPrepareArgs &a)
     int *s_idx = reinterpret_cast<int *>(vu_lds + Lay::INTS);      // [MAXNP + 3]
     int *s_flag = s_idx + MAXNP + 3;                               // [4]
     const int b = blockIdx.x, tid = threadIdx.x;
-    const int n = a.np, ncam = a.stereo ? 2 : 1, nt = n * ncam, N = a.n;
+    // rec is computed below; a.np is the record STRIDE (the longest track of the launch) when per-record lengths are given
+    const size_t rec_ = a.spec_tracks > 0 ? (size_t)blockIdx.y * gridDim.x + blockIdx.x : (size_t)blockIdx.x;
+    const int np_rec = a.np_rec ? a.np_rec[rec_] : a.np;
+    const bool no_track = np_rec < 2 || np_rec > a.np;              // ragged batches: this filter has no (valid) track in this launch
+    const int n = no_track ? a.np : np_rec, ncam = a.stereo ? 2 : 1, nt = n * ncam, N = a.n;
+    const int nt_max = a.np * ncam, rows_max = 2 * nt_max;
     const int dDim = nt * 7, ncol = dDim + 1;
     const double *m = a.m + (size_t)b * N;
     double *pfi = s_small, *pfw = s_small + 3, *X = s_small + 6, *step = s_small + 15, *R0T = s_small + 18;
@@ -262,12 +267,23 @@ __device__ __forceinline__ void vu_prepare_body(const VuPrepareArgs &a)
         }
         return;
     }
-    if (tid < n) s_idx[tid] = a.pose_index[rec * n + tid];
+    if (no_track) {
+        if (tid == 0) {
+            a.status[2 * rec] = HV_TRI_NOT_VISITED; a.status[2 * rec + 1] = HV_TRI_NOT_VISITED;
+            if (a.active) a.active[rec] = 0;
+            if (a.gate_status) a.gate_status[rec] = 1;
+            if (a.rows_out) a.rows_out[rec] = 0;
+            if (a.spec_tracks > 0) a.epoch[rec] = a.success_counter[b];
+        }
+        return;
+    }
+    if (tid == 0 && a.rows_out) a.rows_out[rec] = 2 * nt;
+    if (tid < n) s_idx[tid] = a.pose_index[rec * a.np + tid];
     if (tid < nt) {
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
-            s_feat[4 * tid + k] = a.features[(rec * nt + tid) * 2 + k];
-            s_feat[4 * tid + 2 + k] = a.velocities[(rec * nt + tid) * 2 + k];
+            s_feat[4 * tid + k] = a.features[(rec * nt_max + tid) * 2 + k];
+            s_feat[4 * tid + 2 + k] = a.velocities[(rec * nt_max + tid) * 2 + k];
         }
     }
     __syncthreads();
@@ -749,7 +765,7 @@ __device__ __forceinline__ void vu_prepare_body(const VuPrepareArgs &a)
     __syncthreads();
     VU_STAMP(29);
     const int rows = 2 * nt;
-    double *H = a.H + rec * rows * N;
+    double *H = a.H + rec * rows_max * N;                                    // record stride: the longest track; leading dimension: this track's rows
     // which pose of the track (if any) owns state column c, and which of its 7 components: once per column
     int *s_colmap = reinterpret_cast<int *>(s_p0);                          // s_p0 is free after the Gauss-Newton loop
     for (int c = tid; c < N; c += VT) {
@@ -793,7 +809,7 @@ __device__ __forceinline__ void vu_prepare_body(const VuPrepareArgs &a)
         const double *o = s_it + tid * ITER_WORDS;
 #pragma unroll
         for (int r = 0; r < 2; ++r) {
-            const size_t e = rec * rows + 2 * tid + r;
+            const size_t e = rec * rows_max + 2 * tid + r;
             if (a.f) a.f[e] = o[14 + r];
             a.v[e] = (a.y ? a.y[e] : 0.0) - o[14 + r];
         }

@@ -289,20 +289,27 @@ struct HipEKF : public EKF {
                                                int *updateSuccessCount) final {
         std::vector<VisualTrackResult> out(tracks.size());
         if (tracks.empty()) return out;
-        const size_t K = tracks.size(), n = tracks[0].poseTrailIndex.size(), nt = n * (parameters.useStereo ? 2 : 1);
-        std::vector<int> idx(K * n), status(2 * K), gate(K);
-        std::vector<double> feat(K * 2 * nt), vel(K * 2 * nt), y(K * 2 * nt), pf(3 * K);
+        // tracks of a frame differ in length: records are padded to the longest one, the device gets every track's own pose count
+        const size_t K = tracks.size(), ncam = parameters.useStereo ? 2 : 1;
+        size_t n = 0;
+        for (const VisualFrameTrack &t : tracks) n = std::max(n, t.poseTrailIndex.size());
+        const size_t nt = n * ncam;
+        std::vector<int> idx(K * n, 0), status(2 * K), gate(K), lens(K);
+        std::vector<double> feat(K * 2 * nt, 0.0), vel(K * 2 * nt, 0.0), y(K * 2 * nt, 0.0), pf(3 * K);
         for (size_t k = 0; k < K; ++k) {
             const VisualFrameTrack &t = tracks[k];
-            assert(t.poseTrailIndex.size() == n && t.imageFeatures.size() == 2 * nt && t.featureVelocities.size() == 2 * nt && t.y.size() == 2 * nt);
+            const size_t nk = t.poseTrailIndex.size(), ntk = nk * ncam;
+            assert(t.imageFeatures.size() == 2 * ntk && t.featureVelocities.size() == 2 * ntk && t.y.size() == 2 * ntk);
+            lens[k] = (int)nk;
             std::copy(t.poseTrailIndex.begin(), t.poseTrailIndex.end(), idx.begin() + k * n);
             std::copy(t.imageFeatures.begin(), t.imageFeatures.end(), feat.begin() + k * 2 * nt);
             std::copy(t.featureVelocities.begin(), t.featureVelocities.end(), vel.begin() + k * 2 * nt);
             std::copy(t.y.begin(), t.y.end(), y.begin() + k * 2 * nt);
         }
         int applied = 0;
-        check(hv_ekf_visual_frame(dev(), &parameters, (int)K, (int)n, idx.data(), feat.data(), vel.data(), y.data(), chiOutlierR, visualR,
-                                  status.data(), gate.data(), nullptr, pf.data(), &applied, maxSuccessfulVisualUpdates));
+        check(hv_ekf_visual_frame_ragged(dev(), &parameters, (int)K, (int)n, lens.data(), idx.data(), feat.data(), vel.data(), y.data(),
+                                         chiOutlierR, visualR, status.data(), gate.data(), nullptr, pf.data(), &applied,
+                                         maxSuccessfulVisualUpdates));
         for (size_t k = 0; k < K; ++k) {
             out[k].triangulateStatus = status[2 * k]; out[k].prepareVuStatus = status[2 * k + 1];
             out[k].outlierStatus = gate[k] == 0 ? VuOutlierStatus::INLIER : gate[k] == 3 ? VuOutlierStatus::CHI2 : VuOutlierStatus::NOT_COMPUTED;

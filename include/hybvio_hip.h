@@ -259,9 +259,22 @@ int hv_ekf_visual_frame_dev(hv_ekf *ekf, const hv_vu_params *p, int n_tracks, in
                             int *success_counter_dev, int max_successful);
 /* Host-pointer form (arrays track-major as above): what a single session calls once per frame instead of n_tracks round trips
  * through hv_ekf_visual_track. chi2, pf and success_count may be NULL. Synchronous. */
+/* The same loop over RAGGED tracks: the sequences of a batch do not share track lengths (nor the number of candidate tracks).
+ * n_poses_dev [n_tracks][batch]: poses of every (visit, filter) track, 2 .. n_poses_max; anything else (0) = this filter has no
+ * track at this visit (its statuses read HV_TRI_NOT_VISITED, nothing is gated). Every other array keeps the layout of
+ * hv_ekf_visual_frame_dev with n_poses_max as the record size: a track's poses (first camera's, then the second's) sit at the
+ * start of its record, the rest is padding. */
+int hv_ekf_visual_frame_ragged_dev(hv_ekf *ekf, const hv_vu_params *p, int n_tracks, int n_poses_max, const int *n_poses_dev,
+                                   const int *pose_index_dev, const double *features_dev, const double *velocities_dev,
+                                   const double *y_dev, double r_gate, double r_update, int *status_dev, int *gate_status_dev,
+                                   double *chi2_dev, double *pf_dev, int *success_counter_dev, int max_successful);
 int hv_ekf_visual_frame(hv_ekf *ekf, const hv_vu_params *p, int n_tracks, int n_poses, const int *pose_index, const double *features,
                         const double *velocities, const double *y, double r_gate, double r_update, int *status, int *gate_status,
                         double *chi2, double *pf, int *success_count, int max_successful);
+/* host-pointer form of hv_ekf_visual_frame_ragged_dev (n_poses [n_tracks][batch] in host memory); synchronous */
+int hv_ekf_visual_frame_ragged(hv_ekf *ekf, const hv_vu_params *p, int n_tracks, int n_poses_max, const int *n_poses, const int *pose_index,
+                               const double *features, const double *velocities, const double *y, double r_gate, double r_update,
+                               int *status, int *gate_status, double *chi2, double *pf, int *success_count, int max_successful);
 /* Host-pointer form of hv_ekf_visual_track_dev (arrays [batch][...] as above): about 1 KB per track goes to the device
  * and 40 bytes come back, instead of the mean coming back and a (2 * ncam * n_poses) x stateDim Jacobian going up.
  * chi2 / pf may be NULL. Synchronous. */

@@ -327,6 +327,15 @@ static void test_visual_frame(Session &s, const std::string &dir)
         t.y = VectorXd(uv.begin(), uv.end());
         if (k == 1) for (auto &x : t.imageFeatures) x = -x;              // nothing explains it: never reaches the gate
         if (k >= 3) for (size_t i = 0; i < t.y.size(); i++) t.y[i] += 1e-4 * ((i + k) % 3);
+        // the tracks of a frame differ in length: the adapter pads them to the longest one (hv_ekf_visual_frame_ragged)
+        const int first = k == 4 ? 2 : 0, count = k == 2 ? 6 : k == 4 ? 8 : 10;
+        if (count < 10) {
+            t.poseTrailIndex.assign(t.poseTrailIndex.begin() + first, t.poseTrailIndex.begin() + first + count);
+            t.imageFeatures.assign(t.imageFeatures.begin() + 2 * first, t.imageFeatures.begin() + 2 * (first + count));
+            t.featureVelocities.assign(2 * count, 0.1);
+            VectorXd yy(t.y.begin() + 2 * first, t.y.begin() + 2 * (first + count));
+            t.y = yy;
+        }
     }
     int applied = -1;
     const auto res = a->visualFrame(vp, tracks, 1.5, 0.05, 2, &applied);

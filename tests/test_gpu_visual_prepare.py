@@ -394,6 +394,79 @@ def test_whole_frame_loop_in_one_call(oracle, B, speculative):
         g.close()
 
 
+@pytest.mark.parametrize("B,speculative,stereo", [(10, True, True), (48, False, True), (9, True, False)])
+def test_whole_frame_loop_with_ragged_track_lengths(oracle, B, speculative, stereo):
+    """hv_ekf_visual_frame_ragged_dev: the sequences of a batch do not share track lengths -- every (visit, filter) record has its own
+    pose count (2 .. n_poses_max, 0 = this filter has no candidate at this visit), padded to the longest. Result = the reference's
+    sequential loop run per filter over its own tracks."""
+    import torch
+    rng = np.random.default_rng(77 + B)
+    trail_len, np_max, K, quota = 20, 10, 8, 3
+    assert (B * K <= 256) == speculative
+    T1, T2, means, _, _, _ = _random_tracks(oracle, rng, B, trail_len, 6, stereo, bad_fraction=0.0)
+    ncam = 2 if stereo else 1
+    lens = rng.integers(2, np_max + 1, (K, B)).astype(np.int32)
+    lens[rng.uniform(size=(K, B)) < 0.15] = 0                                             # no track for this filter at this visit
+    lens[0, 0], lens[1, 1 % B] = np_max, 2
+    idx = np.zeros((K, B, np_max), np.int32); feat = np.zeros((K, B, ncam * np_max, 2)); vel = np.zeros_like(feat)
+    ys = np.zeros((K, B, 2 * ncam * np_max))
+    per = {}
+    for k in range(K):
+        for n in sorted(set(lens[k].tolist()) - {0}):
+            sel = np.nonzero(lens[k] == n)[0]
+            _, _, _, i_, f_, v_ = _random_tracks(oracle, rng, len(sel), trail_len, n, stereo, bad_fraction=0.25, given_means=means[sel])
+            for j, b in enumerate(sel):
+                yy = f_[j].reshape(-1) + 2e-3 * rng.normal(size=f_[j].size) + (3.0 if (k + b) % 3 == 0 else 0.0)
+                idx[k, b, :n] = i_[j]; feat[k, b, :ncam * n] = f_[j]; vel[k, b, :ncam * n] = v_[j]; ys[k, b, :2 * ncam * n] = yy
+                per[(k, b)] = (i_[j], f_[j], v_[j], yy)
+    vp = capi.vu_default_params(imu_to_camera=T1, second_imu_to_camera=T2) if stereo else capi.vu_default_params(imu_to_camera=T1)
+    par = oracle.tri_default_params()
+    r_gate, r_update = 1.5, 0.05
+    with capi.Context(width=64, height=64) as ctx:
+        g = capi.EkfBatch(ctx, capi.ekf_default_params(cameraTrailLength=trail_len), B)
+        filters = []
+        for b in range(B):
+            o = oracle.Ekf(oracle.ekf_default_params(cameraTrailLength=trail_len))
+            P = o.P.copy() * 1e-6 + np.eye(o.n) * 1e-4
+            o.set_state(means[b]); o.set_cov(P)
+            g.set_state(b, means[b], P)
+            filters.append(o)
+        dev = lambda a, dt: torch.from_numpy(np.array(a, dt, order="C")).cuda()
+        d = [dev(lens, np.int32), dev(idx, np.int32), dev(feat, np.float64), dev(vel, np.float64), dev(ys, np.float64)]
+        st = torch.full((K, B, 2), -9, dtype=torch.int32, device="cuda"); gs = torch.full((K, B), -9, dtype=torch.int32, device="cuda")
+        counter = torch.full((B,), 77, dtype=torch.int32, device="cuda")
+        ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+        g.visual_frame_ragged_dev(vp, K, np_max, d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(), d[3].data_ptr(), d[4].data_ptr(),
+                                  r_gate, r_update, st.data_ptr(), gs.data_ptr(), counter.data_ptr(), quota)
+        torch.cuda.synchronize()
+        st, gs, counts = st.cpu().numpy(), gs.cpu().numpy(), counter.cpu().numpy()
+        applied, rejected, lengths_applied = 0, 0, set()
+        for b, o in enumerate(filters):
+            done = 0
+            for k in range(K):
+                if done >= quota or lens[k, b] == 0:
+                    assert st[k, b].tolist() == [-1, -1] and gs[k, b] == 1, (b, k)         # not visited / no track
+                    continue
+                i_, f_, v_, yy = per[(k, b)]
+                ost, ops, opf, oH, of = oracle.visual_track_prepare(par, o.m.copy(), i_, T1, T2 if stereo else None, f_, v_)
+                assert st[k, b].tolist() == [ost, ops], (b, k, lens[k, b])
+                if (ost, ops) != (0, 0):
+                    assert gs[k, b] == 1
+                    continue
+                status, _ = o.visual_track_outlier_check(oH, of, yy, r_gate)
+                assert gs[k, b] == status, (b, k, lens[k, b])
+                if status == 0:
+                    o.update_visual_track(oH, of, yy, r_update); done += 1; lengths_applied.add(int(lens[k, b]))
+                else:
+                    rejected += 1
+            assert counts[b] == done
+            applied += done
+            mg, Pg = g.get_state(b)
+            assert _rel(mg, o.m) < 1e-8 and _rel(Pg, o.P) < 1e-7, (b, _rel(mg, o.m), _rel(Pg, o.P))
+        assert applied > B // 2 and rejected > 0 and len(lengths_applied) >= 3, (applied, rejected, lengths_applied)
+        g.close()
+
+
 def test_long_trail_track_is_rejected_not_corrupted():
     """cameraTrailLength > 20 is a valid filter size, but the prepare kernel's LDS arrays hold 21 poses per camera:
     a 22-pose mono track must come back as HV_ERR_UNSUPPORTED (r01 advisor: it used to overrun s_dpf / s_idx silently);
