@@ -85,6 +85,8 @@ PROTOTYPES = {
     "hv_optical_flow_compute": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, f32p, f32p, i32p, C.c_int, C.c_int]),
     "hv_klt_track_batch_dev": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
                                          C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int]),
+    "hv_klt_track_batch_ragged_dev": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
+                                                C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int]),
     "hv_ekf_default_params": (None, [C.POINTER(EkfParams)]),
     "hv_ekf_create": (C.c_int, [C.c_void_p, C.POINTER(EkfParams), C.c_int, C.POINTER(C.c_void_p)]),
     "hv_ekf_destroy": (None, [C.c_void_p]),
@@ -324,6 +326,13 @@ class Context:
                                                C.c_void_p(next_xy_dev), C.c_void_p(status_dev),
                                                C.c_void_p(err_dev), int(use_initial_flow), max_iter_override),
                   "hv_klt_track_batch_dev")
+
+    def klt_track_batch_ragged_dev(self, n_pairs, prev_slots_dev, next_slots_dev, pts_per_pair, pts_in_pair_dev, prev_xy_dev,
+                                   next_xy_dev, status_dev, err_dev, use_initial_flow=True, max_iter_override=-1):
+        self._chk(lib().hv_klt_track_batch_ragged_dev(self._h, n_pairs, C.c_void_p(prev_slots_dev), C.c_void_p(next_slots_dev),
+                                                      pts_per_pair, C.c_void_p(pts_in_pair_dev), C.c_void_p(prev_xy_dev),
+                                                      C.c_void_p(next_xy_dev), C.c_void_p(status_dev), C.c_void_p(err_dev),
+                                                      int(use_initial_flow), max_iter_override), "hv_klt_track_batch_ragged_dev")
 
     # -- GFTT feature detector --
     def gftt_detect(self, slot: int, prev=(), mask_radius: int = 0, params: "GfttParams" = None):

@@ -444,6 +444,19 @@ int hv_klt_track_batch_dev(hv_ctx *h, int n_pairs, const int *prev_slots_dev, co
                           prev_xy_dev, next_xy_dev, status_dev, err_dev, use_initial_flow, iters);
 }
 
+int hv_klt_track_batch_ragged_dev(hv_ctx *h, int n_pairs, const int *prev_slots_dev, const int *next_slots_dev,
+                                  int pts_per_pair, const int *pts_in_pair_dev, const float *prev_xy_dev, float *next_xy_dev,
+                                  uint8_t *status_dev, float *err_dev, int use_initial_flow, int max_iter_override)
+{
+    if (!h || n_pairs < 0 || pts_per_pair < 0) return HV_ERR_INVALID;
+    if (n_pairs == 0 || pts_per_pair == 0) return HV_OK;
+    if (!prev_slots_dev || !next_slots_dev || !prev_xy_dev || !next_xy_dev || !status_dev || !pts_in_pair_dev) return HV_ERR_INVALID;
+    Ctx *c = &h->c;
+    const int iters = max_iter_override > 0 ? max_iter_override : c->p.max_iter;
+    return hv::launch_klt(c, n_pairs, prev_slots_dev, next_slots_dev, pts_per_pair, n_pairs * pts_per_pair,
+                          prev_xy_dev, next_xy_dev, status_dev, err_dev, use_initial_flow, iters, pts_in_pair_dev);
+}
+
 /* ---- timers ---- */
 
 int hv_profile_enable(hv_ctx *h, int on)

@@ -135,7 +135,7 @@ int build_levels_of_slot(Ctx *c, int slot);
 // klt.hip
 int launch_klt(Ctx *c, int n_pairs, const int *prev_slots_dev, const int *next_slots_dev,
                int pts_per_pair, int n_points, const float *prev_xy, float *next_xy,
-               uint8_t *status, float *err, int use_initial_flow, int max_iter);
+               uint8_t *status, float *err, int use_initial_flow, int max_iter, const int *pts_in_pair_dev = nullptr);
 
 // XCD-aware block remap (MI355X: 8 XCDs, block b is dispatched to XCD b % 8): gives every XCD a
 // contiguous range of logical tiles so neighbouring tiles share that XCD's L2. Bijective for

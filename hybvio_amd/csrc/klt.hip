@@ -54,6 +54,7 @@ struct KltArgs {
     const int *l0_stride;
     const int *prev_slots, *next_slots;
     int pts_per_pair, n_points;
+    const int *pts_in_pair;            // optional [n_pairs]: points of pair p that exist (<= pts_per_pair); the rest of its record is padding
     const float2 *prev_xy;
     float2 *next_xy;
     uint8_t *status;
@@ -180,6 +181,10 @@ __global__ __launch_bounds__(64, WPS) void klt_kernel(KltArgs a)
     const PyrLayout &L = a.L;
 
     const int pair = pt / a.pts_per_pair;
+    if (a.pts_in_pair && pt - pair * a.pts_per_pair >= a.pts_in_pair[pair]) {          // padding of a ragged batch (wave-uniform)
+        if (lane == 0) { a.status[pt] = 0; if (a.err != nullptr) a.err[pt] = 0.f; }
+        return;
+    }
     const int sp = a.prev_slots[pair], sn = a.next_slots[pair];
     const uint8_t *prev_base = a.slab + (long long)sp * L.slot_bytes;
     const uint8_t *next_base = a.slab + (long long)sn * L.slot_bytes;
@@ -682,7 +687,7 @@ __global__ __launch_bounds__(64, WPS) void klt_kernel(KltArgs a)
 
 int launch_klt(Ctx *c, int n_pairs, const int *prev_slots_dev, const int *next_slots_dev,
                int pts_per_pair, int n_points, const float *prev_xy, float *next_xy,
-               uint8_t *status, float *err, int use_initial_flow, int max_iter)
+               uint8_t *status, float *err, int use_initial_flow, int max_iter, const int *pts_in_pair_dev)
 {
     (void)n_pairs;
     if (n_points <= 0) return HV_OK;
@@ -691,7 +696,7 @@ int launch_klt(Ctx *c, int n_pairs, const int *prev_slots_dev, const int *next_s
     a.slab = c->slab;
     a.l0_ptr = c->d_l0_ptr; a.l0_stride = c->d_l0_stride;
     a.prev_slots = prev_slots_dev; a.next_slots = next_slots_dev;
-    a.pts_per_pair = pts_per_pair; a.n_points = n_points;
+    a.pts_per_pair = pts_per_pair; a.n_points = n_points; a.pts_in_pair = pts_in_pair_dev;
     a.prev_xy = reinterpret_cast<const float2 *>(prev_xy);
     a.next_xy = reinterpret_cast<float2 *>(next_xy);
     a.status = status; a.err = err;

@@ -218,6 +218,22 @@ def test_klt_batch_dev_equals_single_calls(oracle, seq752):
             np.testing.assert_array_equal(S[k], o_st)
             np.testing.assert_array_equal(N[k], o_xy)
             np.testing.assert_array_equal(E[k], o_err)
+        # ragged: the pairs of a batch do not hold the same number of points; the padding behind a pair's points is skipped
+        counts = [200, 0, 37, 64, 1]
+        d_counts = torch.tensor(counts, dtype=torch.int32, device="cuda")
+        N2 = torch.full_like(P, -5.0)
+        S2 = torch.full((len(pairs) * 200,), 9, dtype=torch.uint8, device="cuda")
+        ctx.klt_track_batch_ragged_dev(len(pairs), prev.data_ptr(), nxt.data_ptr(), 200, d_counts.data_ptr(), P.data_ptr(), N2.data_ptr(),
+                                       S2.data_ptr(), 0, use_initial_flow=False)
+        torch.cuda.synchronize()
+        N2, S2 = N2.cpu().numpy().reshape(len(pairs), 200, 2), S2.cpu().numpy().reshape(-1, 200)
+        for k, (a, b) in enumerate(pairs):
+            n = counts[k]
+            if n:
+                o_xy, o_st, _ = oracle.klt_track(refs[a], refs[b], pts[:n])
+                np.testing.assert_array_equal(S2[k, :n], o_st)
+                np.testing.assert_array_equal(N2[k, :n], o_xy)
+            assert not S2[k, n:].any() and (N2[k, n:] == -5.0).all()
 
 
 def test_golden_fixture_on_gpu():
