@@ -166,7 +166,7 @@ __device__ __forceinline__ void bilinear_weights(float a, float b, uint32_t &wA,
     wB = lo16_pair(f10, i11);    // bottom row weights (iw10, iw11)
 }
 
-template <int TSX, int TSY, int MX, int MY, int WPS>
+template <int TSX, int TSY, int MX, int MY, int WPS, bool RAGGED = false>
 __global__ __launch_bounds__(64, WPS) void klt_kernel(KltArgs a)
 {
     static_assert(TSX % 4 == 0 && TSX + 4 <= RW && TSX >= 32 + MX + 3 && TSY >= 32 + MY, "tile must hold the window at any alignment");
@@ -181,15 +181,17 @@ __global__ __launch_bounds__(64, WPS) void klt_kernel(KltArgs a)
     const PyrLayout &L = a.L;
 
     const int pair = pt / a.pts_per_pair;
-    if (a.pts_in_pair && pt - pair * a.pts_per_pair >= a.pts_in_pair[pair]) {          // padding of a ragged batch (wave-uniform)
-        if (lane == 0) { a.status[pt] = 0; if (a.err != nullptr) a.err[pt] = 0.f; }
-        return;
-    }
     const int sp = a.prev_slots[pair], sn = a.next_slots[pair];
     const uint8_t *prev_base = a.slab + (long long)sp * L.slot_bytes;
     const uint8_t *next_base = a.slab + (long long)sn * L.slot_bytes;
 
-    const float2 pp = a.prev_xy[pt];
+    float2 pp = a.prev_xy[pt];
+    // ragged batch (its own instance of the kernel: even this one select costs the 5-wave build 3 more spilled registers, +2.7 %
+    // time, which the uniform batches should not pay): the padding behind a pair's points is given a position no level contains,
+    // so it falls through every level (status 0)
+    if constexpr (RAGGED) {
+        if (pt - pair * a.pts_per_pair >= a.pts_in_pair[pair]) pp = make_float2(-1.0e6f, -1.0e6f);
+    }
     float2 guess = make_float2(0.f, 0.f);
     if (a.use_init) guess = a.next_xy[pt];
 
@@ -710,7 +712,8 @@ int launch_klt(Ctx *c, int n_pairs, const int *prev_slots_dev, const int *next_s
     // HV_KLT_TILE (environment, experiments only): tile columns x rows / slack on the low side: 0 = 44 x 40 / 6, 4 (8 staging
     // passes of 5 rows), 1 = 40 x 36 / 2, 1 (6 passes of 6 rows), 2 = 40 x 42 / 2, 4 (7 passes), 5 = shape 1 compiled for 5 waves per SIMD (96 VGPRs; its 7.6 KB of LDS allow 20 waves per CU)
     static const int tile_variant = [] { const char *e = getenv("HV_KLT_TILE"); return e ? atoi(e) : KLT_TILE_DEFAULT; }();
-    if (tile_variant == 1)      hipLaunchKernelGGL((klt_kernel<40, 36, 2, 1, 4>), dim3((unsigned)n_points), dim3(64), 0, c->stream, a);
+    if (pts_in_pair_dev)        hipLaunchKernelGGL((klt_kernel<40, 36, 2, 1, 5, true>), dim3((unsigned)n_points), dim3(64), 0, c->stream, a);
+    else if (tile_variant == 1) hipLaunchKernelGGL((klt_kernel<40, 36, 2, 1, 4>), dim3((unsigned)n_points), dim3(64), 0, c->stream, a);
     else if (tile_variant == 2) hipLaunchKernelGGL((klt_kernel<40, 42, 2, 4, 4>), dim3((unsigned)n_points), dim3(64), 0, c->stream, a);
     else if (tile_variant == 5) hipLaunchKernelGGL((klt_kernel<40, 36, 2, 1, 5>), dim3((unsigned)n_points), dim3(64), 0, c->stream, a);
     else                        hipLaunchKernelGGL((klt_kernel<44, 40, 6, 4, 4>), dim3((unsigned)n_points), dim3(64), 0, c->stream, a);

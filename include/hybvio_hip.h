@@ -118,8 +118,8 @@ int hv_klt_track_batch_dev(hv_ctx *ctx, int n_pairs, const int *prev_slots_dev,
                            float *next_xy_dev, uint8_t *status_dev, float *err_dev,
                            int use_initial_flow, int max_iter_override);
 /* The same for pairs with different point counts (sequences of a batch do not track the same number of features): pair p
- * holds pts_in_pair_dev[p] <= pts_per_pair points at the start of its record; the padding behind them costs nothing (status 0,
- * next_xy untouched). */
+ * holds pts_in_pair_dev[p] <= pts_per_pair points at the start of its record; the padding behind them falls through at once
+ * (status 0, next_xy unspecified). */
 int hv_klt_track_batch_ragged_dev(hv_ctx *ctx, int n_pairs, const int *prev_slots_dev, const int *next_slots_dev,
                                   int pts_per_pair, const int *pts_in_pair_dev, const float *prev_xy_dev, float *next_xy_dev,
                                   uint8_t *status_dev, float *err_dev, int use_initial_flow, int max_iter_override);
