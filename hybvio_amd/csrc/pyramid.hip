@@ -337,7 +337,10 @@ struct TailArgs {
     int first;                 // first level handled here
     int buf1;                  // dword offset of the second level buffer
 };
-constexpr int TAIL_THREADS = 512;
+#ifndef HV_TAIL_THREADS
+#define HV_TAIL_THREADS 512
+#endif
+constexpr int TAIL_THREADS = HV_TAIL_THREADS;
 
 // i / d for 0 <= i < 2^22, d > 0 given rcp = 1.f / d: the float quotient is off by at most one (a hardware integer division is ~30
 // instructions and every work item of the tail kernel starts with one or two)
@@ -480,10 +483,16 @@ __global__ __launch_bounds__(TAIL_THREADS) void pyr_tail_kernel(TailArgs a)
                     y = r;
                     x = g < gl ? 4 * g - pd : wq + 4 * (g - gl);
                 }
-                const int rb = (reflect101(y, h) + 2) * lwd * 4 + 4;
-                uint32_t v = 0;
+                const int rr = reflect101(y, h) + 2;
+                uint32_t v;
+                if (x >= 0 && x + 4 <= w) {                          // above / below the image, inside its columns: one aligned LDS dword
+                    v = cur[rr * lwd + 1 + (x >> 2)];
+                } else {
+                    const int rb = rr * lwd * 4 + 4;
+                    v = 0;
 #pragma unroll
-                for (int i = 0; i < 4; ++i) v |= (uint32_t)b[rb + reflect101(x + i, w)] << (8 * i);
+                    for (int i = 0; i < 4; ++i) v |= (uint32_t)b[rb + reflect101(x + i, w)] << (8 * i);
+                }
                 uint8_t *dst = img + (long long)y * gs + x;
                 if (x + 4 <= w + pd) {
                     *reinterpret_cast<uint32_t *>(dst) = v;
