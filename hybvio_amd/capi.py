@@ -67,6 +67,9 @@ PROTOTYPES = {
     "hv_default_params": (None, [C.POINTER(Params)]),
     "hv_abi_version": (C.c_int, []),
     "hv_status_string": (C.c_char_p, [C.c_int]),
+    "hv_debug_set_knob": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int]),
+    "hv_debug_get_knob": (C.c_int, [C.c_void_p, C.c_char_p, C.POINTER(C.c_int)]),
+    "hv_ekf_frame_error": (C.c_int, [C.c_void_p, C.POINTER(C.c_int)]),
     "hv_create": (C.c_int, [C.POINTER(Params), C.POINTER(C.c_void_p)]),
     "hv_destroy": (None, [C.c_void_p]),
     "hv_last_error": (C.c_char_p, [C.c_void_p]),
@@ -209,6 +212,15 @@ class Context:
             raise HvError(f"{what}: {msg}")
 
     # -- plumbing --
+    def set_knob(self, name: str, value: int):
+        """Force a kernel variant (tests / measurements; include/hybvio_hip.h hv_debug_set_knob)."""
+        self._chk(self._L.hv_debug_set_knob(self._h, name.encode(), int(value)), f"hv_debug_set_knob({name})")
+
+    def get_knob(self, name: str) -> int:
+        v = C.c_int()
+        self._chk(self._L.hv_debug_get_knob(self._h, name.encode(), C.byref(v)), f"hv_debug_get_knob({name})")
+        return v.value
+
     def set_stream(self, stream_ptr: int):
         self._chk(lib().hv_set_stream(self._h, C.c_void_p(stream_ptr)), "hv_set_stream")
 
@@ -473,6 +485,12 @@ class EkfBatch:
 
     def _chk(self, rc, what):
         self.ctx._chk(rc, what)
+
+    def frame_error(self) -> int:
+        """Reads and clears the device error word of the batch (hv_ekf_frame_error)."""
+        v = C.c_int()
+        self._chk(lib().hv_ekf_frame_error(self._h, C.byref(v)), "hv_ekf_frame_error")
+        return v.value
 
     def set_state(self, b, m=None, P=None):
         mm = _f(m) if m is not None else None

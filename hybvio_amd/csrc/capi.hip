@@ -10,6 +10,46 @@
 
 namespace hv {
 
+namespace {
+struct KnobEntry { const char *name; int Knobs::*field; };
+const KnobEntry KNOB_TABLE[] = {
+    {"pyr_tail", &Knobs::pyr_tail}, {"pyr_l0_tiled", &Knobs::pyr_l0_tiled}, {"gftt_tiled", &Knobs::gftt_tiled},
+    {"klt_tile", &Knobs::klt_tile}, {"vu_threads", &Knobs::vu_threads}, {"ekf_spec_split", &Knobs::ekf_spec_split},
+    {"ekf_no_speculation", &Knobs::ekf_no_speculation}, {"ekf_stream_gate", &Knobs::ekf_stream_gate},
+    {"ekf_gate_kmode", &Knobs::ekf_gate_kmode}, {"ingest_gather", &Knobs::ingest_gather},
+    {"ekf_fused_gate", &Knobs::ekf_fused_gate}, {"ekf_spec_mode", &Knobs::ekf_spec_mode},
+    {"rot_ransac_threads", &Knobs::rot_ransac_threads},
+};
+}  // namespace
+
+int knob_set(Knobs &k, const char *name, int value)
+{
+    if (!name) return HV_ERR_INVALID;
+    for (const KnobEntry &e : KNOB_TABLE)
+        if (strcmp(e.name, name) == 0) { k.*(e.field) = value; return HV_OK; }
+    return HV_ERR_INVALID;
+}
+
+int knob_get(const Knobs &k, const char *name, int *value)
+{
+    if (!name || !value) return HV_ERR_INVALID;
+    for (const KnobEntry &e : KNOB_TABLE)
+        if (strcmp(e.name, name) == 0) { *value = k.*(e.field); return HV_OK; }
+    return HV_ERR_INVALID;
+}
+
+// hv_create only: the environment spelling of knob "abc_def" is HV_ABC_DEF
+void knobs_from_env(Knobs &k)
+{
+    for (const KnobEntry &e : KNOB_TABLE) {
+        char var[64] = "HV_";
+        size_t i = 3;
+        for (const char *q = e.name; *q && i + 1 < sizeof var; ++q, ++i) var[i] = (*q >= 'a' && *q <= 'z') ? (char)(*q - 32) : *q;
+        var[i] = 0;
+        if (const char *v = getenv(var)) k.*(e.field) = atoi(v);
+    }
+}
+
 int hip_fail(Ctx *c, hipError_t e, const char *what)
 {
     if (c) {
@@ -188,6 +228,18 @@ void hv_default_params(hv_params *p)
 
 int hv_abi_version(void) { return HV_ABI_VERSION; }
 
+int hv_debug_set_knob(hv_ctx *h, const char *name, int value)
+{
+    Ctx *c = hv::ctx_of(h);
+    return c ? hv::knob_set(c->knob, name, value) : HV_ERR_INVALID;
+}
+
+int hv_debug_get_knob(hv_ctx *h, const char *name, int *value)
+{
+    Ctx *c = hv::ctx_of(h);
+    return c ? hv::knob_get(c->knob, name, value) : HV_ERR_INVALID;
+}
+
 const char *hv_status_string(int s)
 {
     switch (s) {
@@ -198,6 +250,7 @@ const char *hv_status_string(int s)
         case HV_ERR_HIP: return "HIP runtime error";
         case HV_ERR_POOL: return "pyramid pool exhausted or bad slot";
         case HV_ERR_NOMEM: return "out of memory";
+        case HV_ERR_TIMEOUT: return "device hand-shake timed out (result discarded)";
         default: return "unknown status";
     }
 }
@@ -220,6 +273,7 @@ int hv_create(const hv_params *params, hv_ctx **out)
     Ctx *c = &h->c;
     c->p = p;
     if (c->p.max_pairs < 1) c->p.max_pairs = 1;
+    hv::knobs_from_env(c->knob);
     hv::compute_layout(p, c->L);
     int rc = HV_OK;
     do {

@@ -28,10 +28,9 @@
 
 #include <utility>
 
-#include "chi2inv95.h"
 #include <stdlib.h>
 
-#include "hv_internal.hpp"
+#include "ekf_device.hpp"
 
 // The library is built with -ffp-contract=off for the tracker's bit-exact binary32 sequence; the
 // EKF is judged against a relative tolerance, and a fused multiply-add is one rounding fewer and
@@ -42,12 +41,6 @@ namespace hv {
 
 namespace {
 
-enum { POS = 0, VEL = 3, ORI = 6, BGA = 10, BAA = 13, BAT = 16, SFT = 19, CAM = 20, INER = 20, POSE = 7, QD = 12 };
-enum { Q_ACC = 0, Q_GYRO = 3, Q_BGA_DRIFT = 6, Q_BAA_DRIFT = 9 };
-
-typedef double double4v __attribute__((ext_vector_type(4)));
-
-__device__ const double d_chi2inv95[HV_CHI2INV95_N] = { HV_CHI2INV95_VALUES };
 
 // developer aid: s_memtime stamps of the kernels' phases (block 0, thread 0), read back through
 // hv_debug_ekf_phase_stamps. Compiled in only with -DHV_EKF_PHASE_STAMPS (HV_EKF_PHASE_STAMPS=1 in the
@@ -61,51 +54,6 @@ namespace {
 #define PHASE_STAMP(i) do { } while (0)
 #endif
 
-// One wavefront: acc(16x16) = A(16 x K) * B(K x 16) with A(i, k) = Ap[i*sai + k*sak] and
-// B(k, j) = Bp[k*sbk + j*sbj]. f64 MFMA operand layout: lane l carries A[l & 15][l >> 4] and
-// B[l >> 4][l & 15]; result register q of lane l is C[(l >> 4) + 4 q][l & 15].
-// Branch-free on purpose: rows i >= mi / columns j >= nj are clamped to the last valid one (they
-// only produce output rows / columns that the caller never stores), the K tail is zeroed with a
-// select, and the next U k-steps are prefetched while the current U MFMAs issue (U = 8 where an
-// operand streams from HBM: ~2k cycles of latency against 64 cycles per MFMA and 4 waves per SIMD). (Bounds-checked
-// lambdas made hipcc emit one exec-masked branch + 64-bit address chain per operand load.)
-template <int U = 4>
-__device__ __forceinline__ double4v mfma_tile(const double *Ap, int sai, int sak, int mi,
-                                              const double *Bp, int sbk, int sbj, int nj, int K)
-{
-    const int lane = threadIdx.x & 63, r = lane & 15, q = lane >> 4;
-    const double *pa = Ap + min(r, mi - 1) * sai + q * sak;
-    const double *pb = Bp + q * sbk + min(r, nj - 1) * sbj;
-    const int da = 4 * sak, db = 4 * sbk;
-    double4v acc = {0.0, 0.0, 0.0, 0.0};
-    const int kfull = (K / (4 * U)) * (4 * U);
-    int k0 = 0;
-    if (kfull > 0) {
-        double a0[U], b0[U];
-#pragma unroll
-        for (int u = 0; u < U; u++) { a0[u] = pa[u * da]; b0[u] = pb[u * db]; }
-        for (k0 = 4 * U; k0 < kfull; k0 += 4 * U) {
-            pa += U * da; pb += U * db;
-            double a1[U], b1[U];
-#pragma unroll
-            for (int u = 0; u < U; u++) { a1[u] = pa[u * da]; b1[u] = pb[u * db]; }
-#pragma unroll
-            for (int u = 0; u < U; u++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[u], b0[u], acc, 0, 0, 0);
-#pragma unroll
-            for (int u = 0; u < U; u++) { a0[u] = a1[u]; b0[u] = b1[u]; }
-        }
-#pragma unroll
-        for (int u = 0; u < U; u++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[u], b0[u], acc, 0, 0, 0);
-        pa += U * da; pb += U * db;
-    }
-    for (k0 = kfull; k0 < K; k0 += 4) {          // tail: clamp the address, zero the value
-        const int k = k0 + q, back = max(k - (K - 1), 0);
-        const double av = pa[-back * sak], bv = pb[-back * sbk];
-        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(k < K ? av : 0.0, k < K ? bv : 0.0, acc, 0, 0, 0);
-        pa += da; pb += db;
-    }
-    return acc;
-}
 
 __device__ __forceinline__ void normalize4(double *q)
 {
@@ -423,74 +371,6 @@ __global__ __launch_bounds__(256) void ekf_predict_kernel(PredictArgs a)
     PHASE_STAMP(15);
 }
 
-// Cholesky factor of one 16 x 16 diagonal block AND the inverse of that factor, in one wavefront
-// without LDS traffic or barriers on the dependency chain. Lane r < 16 holds row r of the block,
-// lane 16 + i holds row i of the identity: running the same right-looking column steps over the
-// stacked matrix [D; I] turns it into [L; L^-T] (the tall-matrix identity T L^-T applied to I).
-// Pivot values travel through v_readlane (wave-uniform SGPRs), every array index is a constant.
-// Rows / columns >= w (ragged last block) are padded with the identity.
-__device__ __forceinline__ double lane_bcast(double v, int src_lane)
-{
-    const int lo = __builtin_amdgcn_readlane(__double2loint(v), src_lane);
-    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src_lane);
-    return __hiloint2double(hi, lo);
-}
-
-// NW = 16, or 8 for a ragged last block of at most 8 columns: only NW column steps are run (the padding
-// columns are identity and every update they would receive is zero), W is still written 16 x 16.
-template <int NW>
-__device__ __forceinline__ void factor_diag_block(double *T, double *W, double *col, int R, int j0, int w, int lane)
-{
-    const int r = lane & 15;
-    const bool ident = (lane & 16) != 0;                    // lanes 32..63 mirror 0..31 (results unused)
-    double tr[NW];
-#pragma unroll
-    for (int c = 0; c < NW; c++) {
-        const double x = T[(size_t)(j0 + min(c, w - 1)) * R + j0 + min(r, w - 1)];
-        const bool from_t = !ident && c <= r && r < w;      // lower triangle of the block; r < w implies c < w
-        tr[c] = from_t ? x : (c == r ? 1.0 : 0.0);
-    }
-    // Right-looking column steps. The dependency chain of step k -> k+1 is
-    //   pivot d (readlane) -> rsqrt -> scale column k -> update column k+1 (readlane of L(k+1, k)),
-    // all in registers. The updates of columns k+2.. are off that chain: their multipliers L(c, k)
-    // are broadcast through LDS (one ds_write of the column, (15-k)/2 ds_read_b128 of uniform pairs)
-    // instead of two v_readlane each, and they are applied one step LATE, after the chain work of
-    // step k+1 has been issued: a wavefront issues in order, so a wait for the LDS round trip in
-    // step k would stall the chain behind it.
-    double mprev[NW], lprev = 0.0;
-    double *col_dst = lane < 16 ? col + r : col + 256 + lane;   // col[256 .. 527]: dump area (an exec-masked store makes
-                                                                  // hipcc wait for the store itself before the next use of LDS data)
-#pragma unroll
-    for (int k = 0; k < NW; k++) {
-        const double d = lane_bcast(tr[k], k);
-        if (k >= 1) {                                          // step k-1's updates of columns k+1..: fill the rsqrt latency
-#pragma unroll
-            for (int c = k + 1; c < NW; c++) tr[c] -= lprev * mprev[c];
-        }
-        const double inv = rsqrt(d);                          // one rsqrt instead of sqrt + divide
-        const double lk = tr[k] * inv;                        // lane k: d * rsqrt(d) = sqrt(d)
-        tr[k] = lk;
-        if (k + 1 < NW) {
-            if (k + 2 < NW) col_dst[k * 16] = lk;            // branch-free: lanes >= 16 write to a dump row
-            tr[k + 1] -= lk * lane_bcast(lk, k + 1);          // lane c < 16 holds L(c, k)
-        }
-#pragma unroll
-        for (int c = k + 2; c < NW; c++) mprev[c] = col[k * 16 + c];         // requested now, used in step k+1
-        lprev = lk;
-        // pin the updates to this step: left alone, hipcc sinks each one to the last use of tr[c]
-        // and keeps every multiplier read so far alive
-#pragma unroll
-        for (int c = k + 1; c < NW; c++) asm volatile("" : "+v"(tr[c]));
-    }
-    if (lane < 16) {
-#pragma unroll
-        for (int c = 0; c < NW; c++)
-            if (c <= r && r < w) T[(size_t)(j0 + c) * R + j0 + r] = tr[c];
-    } else if (lane < 32) {
-#pragma unroll
-        for (int c = 0; c < 16; c++) W[r * 16 + c] = c < NW ? tr[c < NW ? c : 0] : (c == r ? 1.0 : 0.0);   // W[i][c] = Linv(c, i)
-    }
-}
 
 // ---------------------------------------------------------------------------------------------
 // update / gate (ekf.cpp:57-82, 760-844)
@@ -524,6 +404,12 @@ struct UpdateArgs {
     int *cursor_out;                  // spec 3: the cursor after this pass (ping-pong: late workgroups still read the old one)
     int *pub;                         // spec 3: [n_tracks][batch] published gate decisions, pass_id * 4 + {1 not applicable, 2 inlier}
     int pass_id;                      // spec 3: > 0, distinct per pass of a frame (pub is zeroed per frame)
+    int *err;                         // spec 3: device error word of the filter batch (bit 0: a hand-shake wait timed out)
+    // compact Jacobian written by the fused prepare + gate kernel (VuPrepareArgs::fused): column u of a record is state column
+    // acol[u]; the record holds na = 7 * (rows / (2 ncam)) + 1 columns with the record's row count as leading dimension. MODE 2 only.
+    const int *acol;                  // [records][na_max] or null (dense H)
+    int na_max, ncam;
+    size_t h_stride;                  // doubles between the H records
 };
 
 // spec 3 hand-shake between the workgroups of one filter (agent scope: they run on different CUs)
@@ -539,6 +425,8 @@ __device__ __forceinline__ int spec_wait(const UpdateArgs &a, int rec)
         if ((v >> 2) == a.pass_id) return v & 3;
         __builtin_amdgcn_s_sleep(8);
     }
+    // never silently: the frame's result is then NOT the sequential loop's (a.err is read by hv_ekf_frame_error / the host-pointer entry points)
+    if (a.err) atomicOr(a.err, 1);
     return -1;
 }
 // thread 0 of the workgroup of the LAST track, when that workgroup applies nothing: if no pending track of the filter was an
@@ -612,7 +500,7 @@ __global__ __launch_bounds__(UPD_THREADS) void ekf_update_kernel(UpdateArgs a)
         if (USE_LDS) while ((R & 31) != 15 && (R & 31) != 17) R++;
     }
     double *m = a.m + (size_t)b * n, *P = a.P + (size_t)b * n * n;
-    const double *H = a.H + (size_t)e * a.nr * l;          // record stride: the launch's row count; leading dimension: nr
+    const double *H = a.H + (size_t)e * a.h_stride;        // record stride: the launch's row count x columns; leading dimension: nr
     const double rd = a.rdiag ? a.rdiag[b] : a.rd0;
     // Tall matrix T (a.R rows x nr columns, column-major with stride R >= a.R: T(r, c) = T[c * R + r]; in LDS
     // the stride is padded to 15 or 17 mod 32 doubles, see ekf_launch_update):
@@ -654,6 +542,7 @@ __global__ __launch_bounds__(UPD_THREADS) void ekf_update_kernel(UpdateArgs a)
     const int hs = (tiles_j + 1) >> 1;
     const int J1 = 8 + (wave & 1), kb0_1 = (wave & 2) ? hs : 0, kb1_1 = (wave & 2) ? tiles_j : hs;
     const bool have0 = MODE == 2 && wave < tiles_j, have1 = MODE == 2 && wave < 4 && J1 < tiles_j;
+    unsigned kbmask = 0xFFFFFFFFu;                  // K blocks of H P with matrix work (compact H: those that hold a non-zero column)
     if constexpr (MODE == 2) {
         // ---- A: HP = H * P[0:l, :] accumulated into rows ry.. of T (the two K halves of blocks 8, 9
         // meet through ds_add_f64 on the zeroed tile: two addends commute, the sum is reproducible) ----
@@ -670,13 +559,36 @@ __global__ __launch_bounds__(UPD_THREADS) void ekf_update_kernel(UpdateArgs a)
         // arrived, and the HBM stream no longer overlaps the matrix work.
         constexpr int HREG = (48 * 160 + UPD_THREADS - 1) / UPD_THREADS, DEPTH = 4;
         double hreg[HREG];
+        if (a.acol) {
+            // compact H (fused prepare + gate): the P tiles are requested first, they do not depend on H; then the map state column ->
+            // compact column (-1: the column of H is zero) is built in LDS (the col scratch is free until the Cholesky) and H is
+            // gathered through it. kbmask: the 16-row K blocks of H P that hold a non-zero column of H at all.
 #pragma unroll
-        for (int u = 0; u < HREG; u++) {
-            const int i = t + u * UPD_THREADS, k = i / nrp, r = i - k * nrp;
-            hreg[u] = (i < nrp * 16 * lb && k < l && r < nr) ? H[(size_t)k * nr + r] : 0.0;
+            for (int bi = 0; bi < DEPTH; bi++) if (have0) fetch_blk(pres0, bi, wave, bi, tiles_j);
+            int *inv = reinterpret_cast<int *>(col);
+            const int na = 7 * (nr / (2 * a.ncam)) + 1;
+            const int *acol = a.acol + (size_t)e * a.na_max;
+            const int my_col = t < na ? acol[t] : -1;
+            for (int i = t; i < n + 1; i += UPD_THREADS) inv[i] = i < n ? -1 : 0;
+            __syncthreads();
+            if (t < na) { inv[my_col] = t; atomicOr(&inv[n], 1 << (my_col >> 4)); }
+            __syncthreads();
+            kbmask = (unsigned)inv[n];
+#pragma unroll
+            for (int u = 0; u < HREG; u++) {
+                const int i = t + u * UPD_THREADS, k = i / nrp, r = i - k * nrp;
+                const int ck = (i < nrp * 16 * lb && k < l && r < nr) ? inv[k] : -1;
+                hreg[u] = ck >= 0 ? H[(size_t)ck * nr + r] : 0.0;
+            }
+        } else {
+#pragma unroll
+            for (int u = 0; u < HREG; u++) {
+                const int i = t + u * UPD_THREADS, k = i / nrp, r = i - k * nrp;
+                hreg[u] = (i < nrp * 16 * lb && k < l && r < nr) ? H[(size_t)k * nr + r] : 0.0;
+            }
+#pragma unroll
+            for (int bi = 0; bi < DEPTH; bi++) if (have0) fetch_blk(pres0, bi, wave, bi, tiles_j);
         }
-#pragma unroll
-        for (int bi = 0; bi < DEPTH; bi++) if (have0) fetch_blk(pres0, bi, wave, bi, tiles_j);
         PHASE_STAMP(8);
         for (int i = t; i < R * nr; i += UPD_THREADS) T[i] = 0.0;
 #pragma unroll
@@ -726,7 +638,7 @@ __global__ __launch_bounds__(UPD_THREADS) void ekf_update_kernel(UpdateArgs a)
                 else if (bi + DEPTH - NBK < NBH) { if (have1) fetch_blk(pres1, bi + DEPTH - NBK, J1, kb0_1 + bi + DEPTH - NBK, kb1_1); }
                 if (bi < nv) {
                     if (bi + 1 < nv) load_h(bi + 1, av[(bi + 1) & 1]);
-                    mfma_blk(pres0, bi, av[bi & 1], acc);
+                    if ((kbmask >> bi) & 1) mfma_blk(pres0, bi, av[bi & 1], acc);
                 }
             }
             if (have0) flush(wave, acc);
@@ -744,7 +656,7 @@ __global__ __launch_bounds__(UPD_THREADS) void ekf_update_kernel(UpdateArgs a)
                 if (bi + DEPTH < NBH) { if (have1) fetch_blk(pres1, bi + DEPTH, J1, kb0_1 + bi + DEPTH, kb1_1); }
                 if (bi < nv) {
                     if (bi + 1 < nv) load_h(kb0_1 + bi + 1, av[(bi + 1) & 1]);
-                    mfma_blk(pres1, bi, av[bi & 1], acc);
+                    if ((kbmask >> (kb0_1 + bi)) & 1) mfma_blk(pres1, bi, av[bi & 1], acc);
                 }
             }
             if (have1) flush(J1, acc);
@@ -1517,7 +1429,13 @@ struct Ekf {
     // device staging of the host-pointer entry hv_ekf_visual_track: idx | features | velocities | y | status | gate | chi2 | pf
     unsigned char *vustage = nullptr;
     size_t vustage_bytes = 0;
+    // fused prepare + gate (compact Jacobians live in vuH / spH): the active-column lists of the records
+    int *vuacol = nullptr, *spacol = nullptr;
+    int *err_dev = nullptr;                               // device error word (UpdateArgs::err)
 };
+
+// compact-H description handed to ekf_launch_update (null acol: dense H of l columns)
+struct CompactH { const int *acol = nullptr; int na_max = 0, ncam = 1; };
 
 static int ekf_launch_update(Ekf *e, int nr, int l, const double *H_dev, const double *v_dev, const double *rdiag_dev,
                              double rd0, int mode, int generic, int normalize_all, double *chi2_dev, int *status_dev,
@@ -1525,7 +1443,7 @@ static int ekf_launch_update(Ekf *e, int nr, int l, const double *H_dev, const d
                              int *success_counter_dev = nullptr, double rd1 = 0.0, bool *two_r_done = nullptr,
                              int spec = 0, int n_tracks = 0, int *cursor_dev = nullptr, int max_successful = 0,
                              const int *gate_in_dev = nullptr, int *cursor_out_dev = nullptr, int *pub_dev = nullptr, int pass_id = 0,
-                             const int *nr_rec_dev = nullptr)
+                             const int *nr_rec_dev = nullptr, const CompactH *compact = nullptr)
 {
     Ctx *c = e->c;
     if (nr < 1 || nr > e->max_rows || l < 1 || l > e->n) return HV_ERR_INVALID;
@@ -1544,7 +1462,9 @@ static int ekf_launch_update(Ekf *e, int nr, int l, const double *H_dev, const d
     a.m = e->m; a.P = e->P; a.H = H_dev; a.v = v_dev; a.rdiag = rdiag_dev; a.rd0 = rd0; a.rd1 = rd1; a.noise_scale = e->noise_scale;
     a.ws = e->ws; a.chi2 = chi2_dev; a.status = status_dev; a.active = active_dev; a.require_inlier = require_inlier_dev; a.success_counter = success_counter_dev;
     a.spec = spec; a.n_tracks = n_tracks; a.cursor = cursor_dev; a.max_successful = max_successful; a.gate_in = gate_in_dev;
-    a.cursor_out = cursor_out_dev; a.pub = pub_dev; a.pass_id = pass_id; a.nr_rec = nr_rec_dev;
+    a.cursor_out = cursor_out_dev; a.pub = pub_dev; a.pass_id = pass_id; a.nr_rec = nr_rec_dev; a.err = e->err_dev;
+    a.h_stride = (size_t)nr * l;
+    if (compact && compact->acol) { a.acol = compact->acol; a.na_max = compact->na_max; a.ncam = compact->ncam; a.h_stride = (size_t)nr * compact->na_max; }
     size_t tall = (((size_t)a.Rs * nr + 1) & ~(size_t)1) * sizeof(double);
     const size_t small = (size_t)(256 + 544 + UPD_THREADS / 64 + 2) * sizeof(double);           // W + col (incl. dump area) + red + flag
     const int ti = (nr + 15) / 16, lbk = (l + 15) / 16;
@@ -1554,8 +1474,8 @@ static int ekf_launch_update(Ekf *e, int nr, int l, const double *H_dev, const d
     if (!a.use_lds) { a.Rs = a.R; tall = (((size_t)a.R * nr + 1) & ~(size_t)1) * sizeof(double); }   // global workspace: no padding
     int kmode = !a.use_lds ? 0 : (e->n <= 160 && nr <= 48 && tall + small + hbytes <= lds_cap) ? 2 : 1;
     // HV_EKF_GATE_KMODE (environment, experiments only): kernel variant for gate-only launches (1 = H streamed from L2, 2 WGs / CU)
-    static const int gate_kmode = [] { const char *s_ = getenv("HV_EKF_GATE_KMODE"); return s_ ? atoi(s_) : -1; }();
-    if (gate_kmode == 1 && mode == 0 && !spec && kmode == 2) kmode = 1;
+    if (c->knob.ekf_gate_kmode == 1 && mode == 0 && !spec && kmode == 2) kmode = 1;
+    if (a.acol && kmode != 2) return HV_ERR_UNSUPPORTED; // compact H is staged by the LDS-resident kernel only (vu_fused_supported)
     if (mode == 3) {                                     // gate (rd0) + update (rd1) in one launch: MODE 2 kernels only
         const bool can = kmode == 2 && ((size_t)(nr + 1) * nr + 256) * sizeof(double) <= hbytes;
         if (two_r_done) *two_r_done = can;
@@ -1642,7 +1562,8 @@ void hv_ekf_destroy(hv_ekf *h)
     if (e->c && e->c->stream) (void)hipStreamSynchronize(e->c->stream);
     void *ptrs[] = { e->m, e->P, e->P1, e->m1, e->Q, e->dydx, e->ws, e->sH, e->sv, e->sr, e->schi2, e->simu,
                      e->sstatus, e->sdrop, e->sactive, e->vuH, e->vuv, e->vupf, e->vuactive, e->vustage,
-                     e->spH, e->spv, e->sppf, e->spactive, e->spcursor, e->spepoch, e->spcursor2, e->sppub, e->vurows, e->sprows };
+                     e->spH, e->spv, e->sppf, e->spactive, e->spcursor, e->spepoch, e->spcursor2, e->sppub, e->vurows, e->sprows,
+                     e->vuacol, e->spacol, e->err_dev };
     for (void *p : ptrs) if (p) (void)hipFree(p);
     delete h;
 }
@@ -1671,6 +1592,8 @@ int hv_ekf_create(hv_ctx *ctx, const hv_ekf_params *par, int batch, hv_ekf **out
     alloc(e->sH, sizeof(double) * e->sH_cap); alloc(e->sv, sizeof(double) * n * batch); alloc(e->sr, sizeof(double) * batch);
     alloc(e->schi2, sizeof(double) * batch); alloc(e->simu, sizeof(double) * 7 * HV_EKF_MAX_PREDICT_SAMPLES * batch);
     alloc(e->sstatus, sizeof(int) * batch); alloc(e->sdrop, sizeof(int) * batch); alloc(e->sactive, batch);
+    alloc(e->err_dev, sizeof(int));
+    if (ok && hipMemset(e->err_dev, 0, sizeof(int)) != hipSuccess) ok = false;
     if (!ok) { hv_ekf_destroy(h); return HV_ERR_NOMEM; }
 
     // initial state and covariance: EKFImplementation ctor, ekf.cpp:153-296
@@ -1795,6 +1718,7 @@ static int visual_track_dev_impl(hv_ekf *h, const hv_vu_params *p, int np, const
         HV_HIP(c, hipMalloc(reinterpret_cast<void **>(&e->vuv), sizeof(double) * (size_t)rows * e->batch));
         if (!e->vupf) HV_HIP(c, hipMalloc(reinterpret_cast<void **>(&e->vupf), sizeof(double) * 3 * e->batch));
         if (!e->vuactive) HV_HIP(c, hipMalloc(reinterpret_cast<void **>(&e->vuactive), e->batch));
+        if (!e->vuacol) HV_HIP(c, hipMalloc(reinterpret_cast<void **>(&e->vuacol), sizeof(int) * (size_t)e->n * e->batch));
         e->vu_rows = rows;
     }
     // ragged batch (filters with tracks of different lengths, or none, in one visit): np is the longest track = the record stride;
@@ -1807,33 +1731,46 @@ static int visual_track_dev_impl(hv_ekf *h, const hv_vu_params *p, int np, const
     a.H = e->vuH; a.v = e->vuv; a.f = nullptr; a.pf = pf_dev ? pf_dev : e->vupf; a.status = status_dev; a.active = e->vuactive;
     a.gate_status = gate_status_dev;                       // preset to NOT_COMPUTED; the gate overwrites it where it runs
     a.success_counter = success_counter_dev; a.max_successful = max_successful;
+    const double ns = e->noise_scale;
+    // r03 default: visualTrackOutlierCheck runs INSIDE the prepare launch on the active columns of H (vu_gate kernels: the Jacobian
+    // of a rejected track never leaves LDS and only P(a, a) is read); updateVisualTrack then runs where the gate said INLIER, staging the
+    // compact Jacobian through its column map (7 of 20 visits at most -- backend.cpp:1233-1238 -- pay the full H P + downdate).
+    if (hv::vu_fused_supported(c, e->n, np, a.stereo, e->batch)) {
+        a.fused = 1; a.H = nullptr; a.Hc = e->vuH; a.acol = e->vuacol; a.na_max = 7 * np + 1; a.P = e->P;
+        a.rd_gate = r_gate * r_gate * ns; a.noise_scale = ns; a.chi2 = chi2_dev;
+        rc = hv::launch_vu_prepare(c, a);
+        if (rc != HV_OK) return rc;
+        const hv::CompactH ch{e->vuacol, a.na_max, a.stereo ? 2 : 1};
+        return hv::ekf_launch_update(e, rows, e->n, e->vuH, e->vuv, nullptr, r_update * r_update * ns, 1, 0, 1, nullptr, nullptr,
+                                     e->vuactive, gate_status_dev, success_counter_dev, 0.0, nullptr, 0, 0, nullptr, 0, nullptr, nullptr,
+                                     nullptr, 0, nr_rec, &ch);
+    }
     rc = hv::launch_vu_prepare(c, a);
     if (rc != HV_OK) return rc;
-    // visualTrackOutlierCheck with chiOutlierR, then updateVisualTrack with visualR where everything passed: one launch when
-    // the shape runs on the register-resident kernel (mode 3), otherwise a gate launch and an update launch
-    // HV_EKF_STREAM_GATE = 1 (environment, experiment): the streaming gate kernel (two filters per CU) for everybody, then the
+    // Dense path (tracks of more than 48 rows, filters wider than 160, knob ekf_fused_gate = 0): visualTrackOutlierCheck with chiOutlierR,
+    // then updateVisualTrack with visualR where everything passed: one launch when the shape runs on the register-resident kernel
+    // (mode 3), otherwise a gate launch and an update launch.
+    // knob ekf_stream_gate = 1 (experiment): the streaming gate kernel (two filters per CU) for everybody, then the
     // register-resident update where the gate passed. Measured at 1024 filters (r02): a rejected track costs 0.110 ms instead of the
-    // fused launch's 0.130, an accepted one 0.110 + 0.21 instead of 0.23 -- a loss as soon as a quarter of the visits are inliers,
-    // so the fused launch stays the default here; the streaming kernel serves the gate-ONLY entry points (hv_ekf_visual_dev mode 0).
-    static const int stream_gate = [] { const char *s_ = getenv("HV_EKF_STREAM_GATE"); return s_ ? atoi(s_) : -1; }();
-    if (stream_gate == 1 && !nr_rec) {
+    // fused launch's 0.130, an accepted one 0.110 + 0.21 instead of 0.23.
+    if (c->knob.ekf_stream_gate == 1 && !nr_rec) {
         bool done = false;
-        rc = hv::ekf_launch_gate_stream(e, rows, e->n, e->vuH, e->vuv, r_gate * r_gate * e->noise_scale, chi2_dev, gate_status_dev, e->vuactive,
+        rc = hv::ekf_launch_gate_stream(e, rows, e->n, e->vuH, e->vuv, r_gate * r_gate * ns, chi2_dev, gate_status_dev, e->vuactive,
                                         success_counter_dev, max_successful, &done);
         if (rc != HV_OK) return rc;
         if (done)
-            return hv::ekf_launch_update(e, rows, e->n, e->vuH, e->vuv, nullptr, r_update * r_update * e->noise_scale, 1, 0, 1, nullptr,
+            return hv::ekf_launch_update(e, rows, e->n, e->vuH, e->vuv, nullptr, r_update * r_update * ns, 1, 0, 1, nullptr,
                                          nullptr, e->vuactive, gate_status_dev, success_counter_dev);
     }
     bool fused = false;
-    rc = hv::ekf_launch_update(e, rows, e->n, e->vuH, e->vuv, nullptr, r_gate * r_gate * e->noise_scale, 3, 0, 1, chi2_dev,
-                               gate_status_dev, e->vuactive, nullptr, success_counter_dev, r_update * r_update * e->noise_scale, &fused,
+    rc = hv::ekf_launch_update(e, rows, e->n, e->vuH, e->vuv, nullptr, r_gate * r_gate * ns, 3, 0, 1, chi2_dev,
+                               gate_status_dev, e->vuactive, nullptr, success_counter_dev, r_update * r_update * ns, &fused,
                                0, 0, nullptr, 0, nullptr, nullptr, nullptr, 0, nr_rec);
     if (rc != HV_OK || fused) return rc;
-    rc = hv::ekf_launch_update(e, rows, e->n, e->vuH, e->vuv, nullptr, r_gate * r_gate * e->noise_scale, 0, 0, 0, chi2_dev,
+    rc = hv::ekf_launch_update(e, rows, e->n, e->vuH, e->vuv, nullptr, r_gate * r_gate * ns, 0, 0, 0, chi2_dev,
                                gate_status_dev, e->vuactive, nullptr, nullptr, 0.0, nullptr, 0, 0, nullptr, 0, nullptr, nullptr, nullptr, 0, nr_rec);
     if (rc != HV_OK) return rc;
-    return hv::ekf_launch_update(e, rows, e->n, e->vuH, e->vuv, nullptr, r_update * r_update * e->noise_scale, 1, 0, 1, nullptr,
+    return hv::ekf_launch_update(e, rows, e->n, e->vuH, e->vuv, nullptr, r_update * r_update * ns, 1, 0, 1, nullptr,
                                  nullptr, e->vuactive, gate_status_dev, success_counter_dev, 0.0, nullptr, 0, 0, nullptr, 0, nullptr, nullptr,
                                  nullptr, 0, nr_rec);
 }
@@ -1843,24 +1780,26 @@ static int visual_frame_dev_impl(hv_ekf *h, const hv_vu_params *p, int n_tracks,
                             const double *y, double r_gate, double r_update, int *status_dev, int *gate_status_dev, double *chi2_dev,
                             double *pf_dev, int *success_counter_dev, int max_successful)
 {
-    if (!h || n_tracks < 0 || !success_counter_dev || max_successful < 1) return HV_ERR_INVALID;
+    if (!h || n_tracks < 0 || !success_counter_dev) return HV_ERR_INVALID;
     Ekf *e = &h->e; Ctx *c = e->c;
+    // maxSuccessfulVisualUpdates <= 0 is the reference's "no limit" (backend.cpp:1233: the test is `> 0 && count >= max`): every track
+    // is visited, which a quota of n_tracks expresses exactly (r02 advisor)
+    if (max_successful <= 0 || max_successful > n_tracks) max_successful = n_tracks > 0 ? n_tracks : 1;
     const size_t B = (size_t)e->batch, nt = (size_t)np * (p && p->useStereo ? 2 : 1);
     HV_HIP(c, hipMemsetAsync(success_counter_dev, 0, sizeof(int) * B, c->stream));          // updateSuccessCount = 0 (backend.cpp:1017)
     // Few sequences (one, for the reference's `main`): the frame is latency bound -- 20 dependent visits of a ~26 us prepare and a
     // ~34 us gate. While the GPU has idle CUs the loop is run SPECULATIVELY instead: a pass prepares and gates
     // EVERY pending track of a filter against the current (m, P) in parallel, applies the first inlier in visit order, and only the
-    // tracks behind it are re-examined: <= max_successful + 1 passes of 3 launches, the same statuses and the same filter as the
+    // tracks behind it are re-examined: <= min(max_successful, n_tracks) + 1 passes, the same statuses and the same filter as the
     // sequential loop (tracks in front of the first inlier saw the state they would have seen anyway).
-    static const int spec_off = [] { const char *e_ = getenv("HV_EKF_NO_SPECULATION"); return e_ ? atoi(e_) : 0; }();
     const int rows = 2 * (int)nt;
-    if (!spec_off && n_tracks >= 2 && B * (size_t)n_tracks <= 256 && e->n <= 160 && rows <= 48 && p && idx && feat && vel && y) {
+    if (!c->knob.ekf_no_speculation && n_tracks >= 2 && B * (size_t)n_tracks <= 256 && e->n <= 160 && rows <= 48 && p && idx && feat && vel && y) {
         const size_t rec = B * (size_t)n_tracks;
         if (e->sp_records < rec || e->sp_rows < rows) {
             HV_HIP(c, hipStreamSynchronize(c->stream));
-            void *old[] = {e->spH, e->spv, e->sppf, e->spactive, e->spcursor, e->spepoch, e->spcursor2, e->sppub};
+            void *old[] = {e->spH, e->spv, e->sppf, e->spactive, e->spcursor, e->spepoch, e->spcursor2, e->sppub, e->spacol};
             for (void *q : old) if (q) (void)hipFree(q);
-            e->spH = e->spv = e->sppf = nullptr; e->spactive = nullptr; e->spcursor = e->spepoch = e->spcursor2 = e->sppub = nullptr; e->sp_records = 0;
+            e->spH = e->spv = e->sppf = nullptr; e->spactive = nullptr; e->spcursor = e->spepoch = e->spcursor2 = e->sppub = e->spacol = nullptr; e->sp_records = 0;
             HV_HIP(c, hipMalloc(reinterpret_cast<void **>(&e->spH), sizeof(double) * rec * rows * e->n));
             HV_HIP(c, hipMalloc(reinterpret_cast<void **>(&e->spv), sizeof(double) * rec * rows));
             HV_HIP(c, hipMalloc(reinterpret_cast<void **>(&e->sppf), sizeof(double) * rec * 3));
@@ -1869,11 +1808,13 @@ static int visual_frame_dev_impl(hv_ekf *h, const hv_vu_params *p, int n_tracks,
             HV_HIP(c, hipMalloc(reinterpret_cast<void **>(&e->spepoch), sizeof(int) * rec));
             HV_HIP(c, hipMalloc(reinterpret_cast<void **>(&e->spcursor2), sizeof(int) * B));
             HV_HIP(c, hipMalloc(reinterpret_cast<void **>(&e->sppub), sizeof(int) * rec));
+            HV_HIP(c, hipMalloc(reinterpret_cast<void **>(&e->spacol), sizeof(int) * rec * e->n));
             if (e->sprows) { (void)hipFree(e->sprows); e->sprows = nullptr; }
             HV_HIP(c, hipMalloc(reinterpret_cast<void **>(&e->sprows), sizeof(int) * rec));
             e->sp_records = rec; e->sp_rows = rows;
         }
         HV_HIP(c, hipMemsetAsync(e->spcursor, 0, sizeof(int) * B, c->stream));
+        HV_HIP(c, hipMemsetAsync(e->spcursor2, 0, sizeof(int) * B, c->stream));                   // (ping-pong partner: never read uninitialised)
         HV_HIP(c, hipMemsetAsync(e->spepoch, 0xFF, sizeof(int) * rec, c->stream));               // -1: nothing prepared yet
         hv::VuPrepareArgs a;
         int rc = vu_fill_args(e, p, np, idx, feat, vel, y, a);
@@ -1883,30 +1824,51 @@ static int visual_frame_dev_impl(hv_ekf *h, const hv_vu_params *p, int n_tracks,
         a.spec_tracks = n_tracks; a.cursor = e->spcursor; a.epoch = e->spepoch;
         const int *nr_rec = nullptr;                                  // ragged: per-record rows, written by the prepare launches
         if (np_rec_dev) { a.np_rec = np_rec_dev; a.rows_out = e->sprows; nr_rec = e->sprows; }
-        // HV_EKF_SPEC_SPLIT=1 (environment, experiments only): gate-all and apply-first-inlier as two launches per pass (the first
-        // r02 form); default: one launch, the workgroups of a filter settle the visit order among themselves (UpdateArgs spec 3)
-        const char *env_split = getenv("HV_EKF_SPEC_SPLIT");
-        const bool split = env_split && atoi(env_split) != 0;
+        const double ns = e->noise_scale;
+        const int n_pass = (max_successful < n_tracks ? max_successful : n_tracks) + 1;
+        // Pass forms (knob ekf_spec_mode; -1 = auto):
+        //   2  (r03 default where the fused gate serves the shape) launch A: every pending track prepared AND gated on its active columns
+        //      (vu_gate kernel, grid (filters, tracks)); launch B: per filter the first pending inlier is applied, the cursor moves behind it.
+        //      No hand-shake between workgroups: what a pass computes does not depend on how the dispatcher places them.
+        //   3  (r02) dense prepare, then ONE launch that gates every pending track and lets the first inlier apply itself after a spin-wait
+        //      on the decisions in front of it. A wait that times out raises the filter batch's error word (hv_ekf_frame_error).
+        //   knob ekf_spec_split = 1: dense prepare + dense gate-all + apply (the first r02 form).
+        const int spec_mode = c->knob.ekf_spec_mode;
+        const bool split = c->knob.ekf_spec_split != 0;
+        if (!split && spec_mode != 3 && hv::vu_fused_supported(c, e->n, np, a.stereo, e->batch)) {
+            a.fused = 1; a.H = nullptr; a.Hc = e->spH; a.acol = e->spacol; a.na_max = 7 * np + 1; a.P = e->P;
+            a.rd_gate = r_gate * r_gate * ns; a.noise_scale = ns; a.chi2 = chi2_dev;
+            const hv::CompactH ch{e->spacol, a.na_max, a.stereo ? 2 : 1};
+            for (int pass = 0; pass < n_pass; ++pass) {
+                rc = hv::launch_vu_prepare(c, a);
+                if (rc != HV_OK) return rc;
+                rc = hv::ekf_launch_update(e, rows, e->n, e->spH, e->spv, nullptr, r_update * r_update * ns, 1, 0, 1, nullptr,
+                                           nullptr, e->spactive, nullptr, success_counter_dev, 0.0, nullptr, 2, n_tracks, e->spcursor, max_successful,
+                                           gate_status_dev, nullptr, nullptr, 0, nr_rec, &ch);
+                if (rc != HV_OK) return rc;
+            }
+            return HV_OK;
+        }
         if (!split) HV_HIP(c, hipMemsetAsync(e->sppub, 0, sizeof(int) * rec, c->stream));
         int *cur = e->spcursor, *nxt = e->spcursor2;
-        for (int pass = 0; pass <= max_successful; ++pass) {
+        for (int pass = 0; pass < n_pass; ++pass) {
             a.cursor = cur;
             rc = hv::launch_vu_prepare(c, a);
             if (rc != HV_OK) return rc;
             if (!split) {
                 bool fused = false;
-                rc = hv::ekf_launch_update(e, rows, e->n, e->spH, e->spv, nullptr, r_gate * r_gate * e->noise_scale, 3, 0, 1, chi2_dev,
-                                           gate_status_dev, e->spactive, nullptr, success_counter_dev, r_update * r_update * e->noise_scale, &fused,
+                rc = hv::ekf_launch_update(e, rows, e->n, e->spH, e->spv, nullptr, r_gate * r_gate * ns, 3, 0, 1, chi2_dev,
+                                           gate_status_dev, e->spactive, nullptr, success_counter_dev, r_update * r_update * ns, &fused,
                                            3, n_tracks, cur, max_successful, nullptr, nxt, e->sppub, pass + 1, nr_rec);
                 if (rc != HV_OK) return rc;
                 if (fused) { int *sw = cur; cur = nxt; nxt = sw; continue; }
                 // (mode 3 not available for this shape: the two launches below, on the same cursor)
             }
-            rc = hv::ekf_launch_update(e, rows, e->n, e->spH, e->spv, nullptr, r_gate * r_gate * e->noise_scale, 0, 0, 0, chi2_dev,
+            rc = hv::ekf_launch_update(e, rows, e->n, e->spH, e->spv, nullptr, r_gate * r_gate * ns, 0, 0, 0, chi2_dev,
                                        gate_status_dev, e->spactive, nullptr, success_counter_dev, 0.0, nullptr, 1, n_tracks, cur, max_successful,
                                        nullptr, nullptr, nullptr, 0, nr_rec);
             if (rc != HV_OK) return rc;
-            rc = hv::ekf_launch_update(e, rows, e->n, e->spH, e->spv, nullptr, r_update * r_update * e->noise_scale, 1, 0, 1, nullptr,
+            rc = hv::ekf_launch_update(e, rows, e->n, e->spH, e->spv, nullptr, r_update * r_update * ns, 1, 0, 1, nullptr,
                                        nullptr, e->spactive, nullptr, success_counter_dev, 0.0, nullptr, 2, n_tracks, cur, max_successful,
                                        gate_status_dev, nullptr, nullptr, 0, nr_rec);
             if (rc != HV_OK) return rc;
@@ -1984,7 +1946,7 @@ static int visual_frame_host_impl(hv_ekf *h, const hv_vu_params *p, int n_tracks
                         const double *y, double r_gate, double r_update, int *status, int *gate_status, double *chi2, double *pf,
                         int *success_count, int max_successful)
 {
-    if (!h || !p || !idx || !feat || !vel || !y || !status || !gate_status || np < 2 || n_tracks < 1 || max_successful < 1) return HV_ERR_INVALID;
+    if (!h || !p || !idx || !feat || !vel || !y || !status || !gate_status || np < 2 || n_tracks < 1) return HV_ERR_INVALID;
     Ekf *e = &h->e; Ctx *c = e->c;
     const size_t B = (size_t)e->batch * n_tracks, nt = (size_t)np * (p->useStereo ? 2 : 1);
     auto up = [](size_t v) { return (v + 15) & ~(size_t)15; };
@@ -2018,7 +1980,10 @@ static int visual_frame_host_impl(hv_ekf *h, const hv_vu_params *p, int n_tracks
     if (pf) HV_HIP(c, hipMemcpyAsync(pf, d + o_pf, B * 3 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     if (success_count) HV_HIP(c, hipMemcpyAsync(success_count, d + o_cnt, (size_t)e->batch * sizeof(int), hipMemcpyDeviceToHost, c->stream));
     HV_HIP(c, hipStreamSynchronize(c->stream));
-    return HV_OK;
+    int flags = 0;
+    const int rc2 = hv_ekf_frame_error(h, &flags);                // the hand-shake form of the speculative pass never fails silently
+    if (rc2 != HV_OK) return rc2;
+    return flags ? HV_ERR_TIMEOUT : HV_OK;
 }
 
 int hv_ekf_visual_frame(hv_ekf *h, const hv_vu_params *p, int n_tracks, int np, const int *idx, const double *feat, const double *vel,
@@ -2036,6 +2001,16 @@ int hv_ekf_visual_frame_ragged(hv_ekf *h, const hv_vu_params *p, int n_tracks, i
     if (!n_poses) return HV_ERR_INVALID;
     return visual_frame_host_impl(h, p, n_tracks, np_max, n_poses, idx, feat, vel, y, r_gate, r_update, status, gate_status, chi2, pf,
                                   success_count, max_successful);
+}
+
+int hv_ekf_frame_error(hv_ekf *h, int *flags)
+{
+    if (!h || !flags) return HV_ERR_INVALID;
+    Ekf *e = &h->e; Ctx *c = e->c;
+    HV_HIP(c, hipMemcpyAsync(flags, e->err_dev, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HV_HIP(c, hipStreamSynchronize(c->stream));
+    if (*flags) HV_HIP(c, hipMemsetAsync(e->err_dev, 0, sizeof(int), c->stream));
+    return HV_OK;
 }
 
 /* developer aid (not in the public header): phase time stamps of the last update kernel */
@@ -2224,7 +2199,7 @@ int hv_ekf_visual_dev(hv_ekf *h, int nr, int l, const double *H_dev, const doubl
 {
     if (!h || !H_dev || !v_dev || mode < 0 || mode > 2) return HV_ERR_INVALID;
     Ekf *e = &h->e;
-    static const int stream_gate = [] { const char *s_ = getenv("HV_EKF_STREAM_GATE"); return s_ ? atoi(s_) : -1; }();
+    const int stream_gate = e->c->knob.ekf_stream_gate;
     if (mode == 0 && (stream_gate == 1 || (stream_gate < 0 && e->batch > 256))) {      // gate only, many filters: two per CU
         bool done = false;
         const int rc = hv::ekf_launch_gate_stream(e, nr, l, H_dev, v_dev, r * r * e->noise_scale, chi2_dev, status_dev, nullptr, nullptr, 0, &done);

@@ -1,0 +1,269 @@
+// Device building blocks shared by the EKF kernels (ekf.hip) and the fused prepare + chi2-gate kernel (vu_prepare.hip):
+// state layout constants, the f64 MFMA tile product, the in-register 16 x 16 Cholesky block factor and the chi2 table.
+// Everything lives in an anonymous namespace (force-inlined per translation unit).
+#pragma once
+#include "chi2inv95.h"
+#include "hv_internal.hpp"
+
+// (both including translation units select fused multiply-adds for their f64 algebra; see ekf.hip)
+#pragma clang fp contract(fast)
+
+namespace hv {
+namespace {
+
+enum { POS = 0, VEL = 3, ORI = 6, BGA = 10, BAA = 13, BAT = 16, SFT = 19, CAM = 20, INER = 20, POSE = 7, QD = 12 };
+enum { Q_ACC = 0, Q_GYRO = 3, Q_BGA_DRIFT = 6, Q_BAA_DRIFT = 9 };
+
+typedef double double4v __attribute__((ext_vector_type(4)));
+
+__device__ const double d_chi2inv95[HV_CHI2INV95_N] = { HV_CHI2INV95_VALUES };
+
+// One wavefront: acc(16x16) = A(16 x K) * B(K x 16) with A(i, k) = Ap[i*sai + k*sak] and
+// B(k, j) = Bp[k*sbk + j*sbj]. f64 MFMA operand layout: lane l carries A[l & 15][l >> 4] and
+// B[l >> 4][l & 15]; result register q of lane l is C[(l >> 4) + 4 q][l & 15].
+// Branch-free on purpose: rows i >= mi / columns j >= nj are clamped to the last valid one (they
+// only produce output rows / columns that the caller never stores), the K tail is zeroed with a
+// select, and the next U k-steps are prefetched while the current U MFMAs issue (U = 8 where an
+// operand streams from HBM: ~2k cycles of latency against 64 cycles per MFMA and 4 waves per SIMD). (Bounds-checked
+// lambdas made hipcc emit one exec-masked branch + 64-bit address chain per operand load.)
+template <int U = 4>
+__device__ __forceinline__ double4v mfma_tile(const double *Ap, int sai, int sak, int mi,
+                                              const double *Bp, int sbk, int sbj, int nj, int K)
+{
+    const int lane = threadIdx.x & 63, r = lane & 15, q = lane >> 4;
+    const double *pa = Ap + min(r, mi - 1) * sai + q * sak;
+    const double *pb = Bp + q * sbk + min(r, nj - 1) * sbj;
+    const int da = 4 * sak, db = 4 * sbk;
+    double4v acc = {0.0, 0.0, 0.0, 0.0};
+    const int kfull = (K / (4 * U)) * (4 * U);
+    int k0 = 0;
+    if (kfull > 0) {
+        double a0[U], b0[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) { a0[u] = pa[u * da]; b0[u] = pb[u * db]; }
+        for (k0 = 4 * U; k0 < kfull; k0 += 4 * U) {
+            pa += U * da; pb += U * db;
+            double a1[U], b1[U];
+#pragma unroll
+            for (int u = 0; u < U; u++) { a1[u] = pa[u * da]; b1[u] = pb[u * db]; }
+#pragma unroll
+            for (int u = 0; u < U; u++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[u], b0[u], acc, 0, 0, 0);
+#pragma unroll
+            for (int u = 0; u < U; u++) { a0[u] = a1[u]; b0[u] = b1[u]; }
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[u], b0[u], acc, 0, 0, 0);
+        pa += U * da; pb += U * db;
+    }
+    for (k0 = kfull; k0 < K; k0 += 4) {          // tail: clamp the address, zero the value
+        const int k = k0 + q, back = max(k - (K - 1), 0);
+        const double av = pa[-back * sak], bv = pb[-back * sbk];
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(k < K ? av : 0.0, k < K ? bv : 0.0, acc, 0, 0, 0);
+        pa += da; pb += db;
+    }
+    return acc;
+}
+
+// Cholesky factor of one 16 x 16 diagonal block AND the inverse of that factor, in one wavefront
+// without LDS traffic or barriers on the dependency chain. Lane r < 16 holds row r of the block,
+// lane 16 + i holds row i of the identity: running the same right-looking column steps over the
+// stacked matrix [D; I] turns it into [L; L^-T] (the tall-matrix identity T L^-T applied to I).
+// Pivot values travel through v_readlane (wave-uniform SGPRs), every array index is a constant.
+// Rows / columns >= w (ragged last block) are padded with the identity.
+__device__ __forceinline__ double lane_bcast(double v, int src_lane)
+{
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), src_lane);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src_lane);
+    return __hiloint2double(hi, lo);
+}
+
+// NW = 16, or 8 for a ragged last block of at most 8 columns: only NW column steps are run (the padding
+// columns are identity and every update they would receive is zero), W is still written 16 x 16.
+template <int NW>
+__device__ __forceinline__ void factor_diag_block(double *T, double *W, double *col, int R, int j0, int w, int lane)
+{
+    const int r = lane & 15;
+    const bool ident = (lane & 16) != 0;                    // lanes 32..63 mirror 0..31 (results unused)
+    double tr[NW];
+#pragma unroll
+    for (int c = 0; c < NW; c++) {
+        const double x = T[(size_t)(j0 + min(c, w - 1)) * R + j0 + min(r, w - 1)];
+        const bool from_t = !ident && c <= r && r < w;      // lower triangle of the block; r < w implies c < w
+        tr[c] = from_t ? x : (c == r ? 1.0 : 0.0);
+    }
+    // Right-looking column steps. The dependency chain of step k -> k+1 is
+    //   pivot d (readlane) -> rsqrt -> scale column k -> update column k+1 (readlane of L(k+1, k)),
+    // all in registers. The updates of columns k+2.. are off that chain: their multipliers L(c, k)
+    // are broadcast through LDS (one ds_write of the column, (15-k)/2 ds_read_b128 of uniform pairs)
+    // instead of two v_readlane each, and they are applied one step LATE, after the chain work of
+    // step k+1 has been issued: a wavefront issues in order, so a wait for the LDS round trip in
+    // step k would stall the chain behind it.
+    double mprev[NW], lprev = 0.0;
+    double *col_dst = lane < 16 ? col + r : col + 256 + lane;   // col[256 .. 527]: dump area (an exec-masked store makes
+                                                                  // hipcc wait for the store itself before the next use of LDS data)
+#pragma unroll
+    for (int k = 0; k < NW; k++) {
+        const double d = lane_bcast(tr[k], k);
+        if (k >= 1) {                                          // step k-1's updates of columns k+1..: fill the rsqrt latency
+#pragma unroll
+            for (int c = k + 1; c < NW; c++) tr[c] -= lprev * mprev[c];
+        }
+        const double inv = rsqrt(d);                          // one rsqrt instead of sqrt + divide
+        const double lk = tr[k] * inv;                        // lane k: d * rsqrt(d) = sqrt(d)
+        tr[k] = lk;
+        if (k + 1 < NW) {
+            if (k + 2 < NW) col_dst[k * 16] = lk;            // branch-free: lanes >= 16 write to a dump row
+            tr[k + 1] -= lk * lane_bcast(lk, k + 1);          // lane c < 16 holds L(c, k)
+        }
+#pragma unroll
+        for (int c = k + 2; c < NW; c++) mprev[c] = col[k * 16 + c];         // requested now, used in step k+1
+        lprev = lk;
+        // pin the updates to this step: left alone, hipcc sinks each one to the last use of tr[c]
+        // and keeps every multiplier read so far alive
+#pragma unroll
+        for (int c = k + 1; c < NW; c++) asm volatile("" : "+v"(tr[c]));
+    }
+    if (lane < 16) {
+#pragma unroll
+        for (int c = 0; c < NW; c++)
+            if (c <= r && r < w) T[(size_t)(j0 + c) * R + j0 + r] = tr[c];
+    } else if (lane < 32) {
+#pragma unroll
+        for (int c = 0; c < 16; c++) W[r * 16 + c] = c < NW ? tr[c < NW ? c : 0] : (c == r ? 1.0 : 0.0);   // W[i][c] = Linv(c, i)
+    }
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// Column-sparse chi2 gate of ONE track by one workgroup of NT threads: visualTrackOutlierCheck (ekf.cpp:787-819) on the active
+// columns only. prepareVisualUpdate fills H in the 7 columns of every pose of the track and in the time-shift column and nowhere
+// else (triangulation.cpp:908-921,958-980): with a = that column list (na = 7 poses + 1 entries) and Hc = H(:, a),
+//     S = H P[0:l, 0:l] H' + R = Hc P(a, a) Hc' + R        -- the skipped terms are exact zeros, only the summation order differs.
+// A 10-pose stereo track touches 71 of 160 columns: 40 KB of P and 0.6 MFLOP instead of 205 KB and 2.6 MFLOP.
+// A wavefront owns 16-row blocks J of P(a, a) and chains two MFMA products through its accumulators (ekf_gate_stream_kernel's scheme):
+//     G_J = P(a_J, a) Hc'   (A = P gathered from HBM / L2: lane (kq, cl) reads P[acol[4 s + kq] * n + acol[16 J + cl]], 7-double runs;
+//                            B = Hc' from LDS)
+//     S  += Hc(:, J) G_J    (A = Hc from LDS, B = the accumulator tile of the first product)
+// so neither H P nor P(a, a) is ever stored. Then the blocked Cholesky of [S; v'] and chi2 = noise_scale z'z.
+// LDS inputs: acol[na]; Hs = Hc k-major [4 ceil(na / 4)][16 TI], zero in rows >= nr and columns >= na; T = (nr + 1) x nr column-major
+// with stride Rs, ZEROED except row nr = v'. work: >= 816 + NT / 64 doubles of scratch (may alias Hs: it is used after the products).
+// Every thread returns the same chi2; a non-positive pivot leaves inf / NaN in it (the caller reports CHI2, as ekf_update_kernel does).
+// ---------------------------------------------------------------------------------------------
+template <int TI, int NT>
+__device__ __forceinline__ double sparse_gate(const double *P, int n, const int *acol, int na, const double *Hs, double *T, int Rs, int nr,
+                                              double rd, double noise_scale, double *work)
+{
+    const int t = threadIdx.x, lane = t & 63, kq = lane >> 4, cl = lane & 15;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    constexpr int nwaves = NT / 64, nrp = 16 * TI, NS = TI * (TI + 1) / 2, U = 4;
+    const int nJ = (na + 15) >> 4, nk = (na + 3) >> 2, na4 = 4 * nk;
+    for (int J = wave; J < nJ; J += nwaves) {
+        const double *pj = P + acol[min(16 * J + cl, na - 1)];                 // row a_j of P(a, a): P(a_j, a_k) = P[a_k * n + a_j]
+        double4v accG[TI];
+#pragma unroll
+        for (int ct = 0; ct < TI; ct++) accG[ct] = double4v{0.0, 0.0, 0.0, 0.0};
+        // k-steps s = 0 .. nk-1 in chunks of U, the next chunk's P values requested before this chunk's MFMAs; steps beyond nk
+        // (tail of the last chunk) read a clamped address and contribute zero
+        auto load_a = [&](double (&av)[U], int s0) {
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const int s = s0 + u;
+                const double x = pj[(size_t)acol[min(4 * s + kq, na - 1)] * n];
+                av[u] = s < nk ? x : 0.0;
+            }
+        };
+        double a0[U], a1[U];
+        load_a(a0, 0);
+        for (int s0 = 0; s0 < nk; s0 += U) {
+            load_a(a1, min(s0 + U, nk));                                       // (past the end: all zeros, never used)
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const int s = min(s0 + u, nk - 1);
+                double hb[TI];
+#pragma unroll
+                for (int ct = 0; ct < TI; ct++) hb[ct] = Hs[(size_t)(4 * s + kq) * nrp + 16 * ct + cl];      // B(k, c) = Hc(c, k)
+#pragma unroll
+                for (int ct = 0; ct < TI; ct++) accG[ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[u], hb[ct], accG[ct], 0, 0, 0);
+            }
+#pragma unroll
+            for (int u = 0; u < U; u++) a0[u] = a1[u];
+        }
+        // S(rt, ct) += Hc(16 rt + i, a-index 16 J + k) G_J(k, 16 ct + c), lower tiles; k-step v: A = Hc(.., 16 J + 4 v + kq), B = accG[ct][v]
+        // (rows j >= na of G_J repeat row na - 1: they meet the zero columns of Hs, or the select below beyond na4)
+        double4v accS[NS];                                                   // (per block: S tiles and G tiles are never live during the gather loop)
+#pragma unroll
+        for (int u = 0; u < NS; u++) accS[u] = double4v{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int v = 0; v < 4; v++) {
+            const int idx = 16 * J + 4 * v + kq;
+            double ha[TI];
+#pragma unroll
+            for (int rt = 0; rt < TI; rt++) {
+                const double x = Hs[(size_t)min(idx, na4 - 1) * nrp + 16 * rt + cl];
+                ha[rt] = idx < na4 ? x : 0.0;
+            }
+            int u = 0;
+#pragma unroll
+            for (int ct = 0; ct < TI; ct++)
+#pragma unroll
+                for (int rt = ct; rt < TI; rt++, u++)
+                    accS[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(ha[rt], accG[ct][v], accS[u], 0, 0, 0);
+        }
+        // the blocks' partial S meet in LDS (ds_add_f64 on the zeroed matrix; the order in which the waves arrive is not fixed: < 1 ulp of S)
+        int u = 0;
+#pragma unroll
+        for (int ct = 0; ct < TI; ct++)
+#pragma unroll
+            for (int rt = ct; rt < TI; rt++, u++)
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const int i = 16 * rt + kq + 4 * q, c = 16 * ct + cl;
+                    if (i < nr && c < nr && i >= c) unsafeAtomicAdd(&T[(size_t)c * Rs + i], accS[u][q]);
+                }
+    }
+    __syncthreads();
+    for (int i = t; i < nr; i += NT) T[(size_t)i * Rs + i] += rd;
+    double *W = work, *col = work + 256, *red = work + 256 + 544;
+    __syncthreads();
+    // blocked Cholesky of [S; v'] (ekf_update_kernel phase C restricted to the measurement rows)
+    const int Rlim = nr + 1;
+    for (int j0 = 0; j0 < nr; j0 += 16) {
+        const int w = min(16, nr - j0);
+        const int ntile = (Rlim - j0 + 15) / 16;
+        if (j0 > 0) {
+            for (int tile = wave; tile < ntile; tile += nwaves) {
+                const int i0 = j0 + 16 * tile, mi = Rlim - i0;
+                const double4v acc = mfma_tile(T + i0, 1, Rs, mi, T + j0, Rs, 1, w, j0);
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const int i = kq + 4 * q;
+                    if (i < mi && cl < w) T[(size_t)(j0 + cl) * Rs + i0 + i] -= acc[q];
+                }
+            }
+            __syncthreads();
+        }
+        if (wave == 0) { if (w <= 8) factor_diag_block<8>(T, W, col, Rs, j0, w, lane); else factor_diag_block<16>(T, W, col, Rs, j0, w, lane); }
+        __syncthreads();
+        for (int i0 = j0 + w + 16 * wave; i0 < Rlim; i0 += 16 * nwaves) {
+            const int mi = Rlim - i0;
+            const double4v acc = mfma_tile(T + (size_t)j0 * Rs + i0, 1, Rs, mi, W, 16, 1, 16, w);
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const int i = kq + 4 * q;
+                if (i < mi && cl < w) T[(size_t)(j0 + cl) * Rs + i0 + i] = acc[q];
+            }
+        }
+        __syncthreads();
+    }
+    double sz = 0;
+    for (int c = t; c < nr; c += NT) { const double z = T[(size_t)c * Rs + nr]; sz += z * z; }
+    for (int o = 32; o > 0; o >>= 1) sz += __shfl_down(sz, o);
+    if (lane == 0) red[wave] = sz;
+    __syncthreads();
+    double tot = 0;
+#pragma unroll
+    for (int w2 = 0; w2 < nwaves; w2++) tot += red[w2];
+    return tot * noise_scale;
+}
+}  // namespace
+}  // namespace hv

@@ -429,9 +429,8 @@ int launch(Ctx *c, int n_images, const int *slots_dev, int slot0, int bs, float 
     }
     // The marching kernel is the throughput design (a thread walks 34 dependent steps); for a handful of images the LDS-tiled
     // kernel (one workgroup per block, 256 threads side by side) finishes sooner -- 25 us per frame in the bench latency leg.
-    // HV_GFTT_TILED (environment, experiments only): 1 / 0 forces the tiled / the marching kernel.
-    const char *env_tiled = getenv("HV_GFTT_TILED");                 // read per call: the tests switch it
-    const int force_tiled = env_tiled ? atoi(env_tiled) : -1;
+    // knob gftt_tiled (tests / experiments only): 1 / 0 forces the tiled / the marching kernel.
+    const int force_tiled = c->knob.gftt_tiled;
     const bool tiled = force_tiled >= 0 ? force_tiled != 0 : n_images < 128;
     if (!tiled && a.w >= 8 && a.h >= 3) {
         const long long threads = (long long)grid * (bs / 4);

@@ -49,8 +49,32 @@ struct KernelTimer {
     long long launches = 0;
 };
 
+// Kernel-variant selectors ("knobs"). Production code never needs them: every default picks the variant by shape / batch size.
+// They exist so that tests and A/B measurements can FORCE each variant at any batch size. Read from the environment ONCE, in
+// hv_create (variable = "HV_" + upper-case name), and changed afterwards only through hv_debug_set_knob: the hot path never calls
+// getenv (r02 advisor), and a HIP graph embeds whatever was selected when it was captured.
+struct Knobs {
+    int pyr_tail = -1;            // HV_PYR_TAIL: -1 auto (levels >= 2 in one launch from 64 images up), 0 off, 1 on
+    int pyr_l0_tiled = 0;         // HV_PYR_L0_TILED: 1 = pure down-sample levels through the LDS-tile kernel
+    int gftt_tiled = -1;          // HV_GFTT_TILED: -1 auto (marching kernel from 128 images up), 1 tiled, 0 marching
+    int klt_tile = 5;             // HV_KLT_TILE: staged J tile / occupancy of the LK kernel (klt.hip)
+    int vu_threads = 0;           // HV_VU_THREADS: 0 auto, 384 / 768 force the two-per-CU / the latency build of vu_prepare
+    int ekf_spec_split = 0;       // HV_EKF_SPEC_SPLIT: legacy two-launch form of a speculative pass on the DENSE kernels
+    int ekf_no_speculation = 0;   // HV_EKF_NO_SPECULATION: 1 = always the sequential visit loop
+    int ekf_stream_gate = -1;     // HV_EKF_STREAM_GATE: -1 auto, 0 never, 1 also inside the visit loop
+    int ekf_gate_kmode = -1;      // HV_EKF_GATE_KMODE: 1 = gate-only launches on the H-from-L2 update kernel
+    int ingest_gather = 0;        // HV_INGEST_GATHER: 1 = plain gather kernel for the remap
+    int ekf_fused_gate = -1;      // HV_EKF_FUSED_GATE: -1 auto (column-sparse chi2 gate inside the prepare kernel where the shape allows), 0 off
+    int ekf_spec_mode = -1;       // HV_EKF_SPEC_MODE: speculative pass form: -1 auto, 2 = gate launch + apply launch, 3 = one launch with hand-shake
+    int rot_ransac_threads = 0;   // HV_ROT_RANSAC_THREADS: 0 auto (1024 threads up to 64 sets), 256 / 1024 force
+};
+int knob_set(Knobs &k, const char *name, int value);   // HV_ERR_INVALID for an unknown name
+int knob_get(const Knobs &k, const char *name, int *value);
+void knobs_from_env(Knobs &k);
+
 struct Ctx {
     hv_params p{};
+    Knobs knob{};
     PyrLayout L{};
     hipStream_t stream = nullptr;
     bool own_stream = false;
@@ -128,8 +152,20 @@ struct VuPrepareArgs {
     int spec_tracks;
     const int *cursor;                 // [batch]
     int *epoch;                        // [spec_tracks][batch]
+    // fused column-sparse chi2 gate (vu_gate kernels, r03): H is non-zero only in the 7 columns of each pose of the track and in the
+    // time-shift column (triangulation.cpp:908-921,958-980), so the kernel keeps the COMPACT Jacobian Hc (rows x na, na = 7 poses + 1)
+    // in LDS, gathers P_aa = P(acol, acol) and evaluates visualTrackOutlierCheck (ekf.cpp:787-819) right there: S = Hc P_aa Hc' + R,
+    // blocked Cholesky, chi2. The dense H is not written; Hc and acol go to HBM for the update of an inlier.
+    int fused;
+    double *Hc;                        // [records][rows_max * na_max], column u of a record = state column acol[u], leading dimension = the record's rows
+    int *acol;                         // [records][na_max]
+    int na_max;                        // 7 * np + 1
+    const double *P;                   // [batch][n][n]
+    double rd_gate, noise_scale;       // R = rd_gate I (already scaled by noiseScale), chi2 = noise_scale z'z
+    double *chi2;                      // optional [records]
 };
 int launch_vu_prepare(Ctx *c, const VuPrepareArgs &a);
+bool vu_fused_supported(const Ctx *c, int n_state, int np, int stereo, int batch);   // shapes the fused gate serves (else: dense path)
 // capi.hip
 int build_levels_of_slot(Ctx *c, int slot);
 // klt.hip

@@ -298,12 +298,8 @@ __global__ __launch_bounds__(256) void remap_tile_kernel(IngestArgs a)
     }
 }
 
-// HV_INGEST_GATHER=1 selects the plain gather kernel for the remap (kept for A/B measurements)
-bool gather_remap()
-{
-    static const bool on = [] { const char *e = getenv("HV_INGEST_GATHER"); return e && e[0] == '1'; }();
-    return on;
-}
+// knob ingest_gather = 1 (HV_INGEST_GATHER at hv_create) selects the plain gather kernel for the remap (kept for A/B measurements)
+bool gather_remap(const Ctx *c) { return c->knob.ingest_gather == 1; }
 
 template <int CH>
 void launch_ch(Ctx *c, const IngestArgs &a, bool remap, unsigned grid)
@@ -325,7 +321,7 @@ int launch_ingest(Ctx *c, int n, const int *slots_dev, int slot0, const uint8_t 
     a.w = L.w[0]; a.h = L.h[0]; a.wq = (a.w + 3) / 4;
     a.groups = (unsigned)a.wq * (unsigned)a.h;
     a.blocks_per_image = (a.groups + 255u) / 256u;
-    const bool tiled = camera >= 0 && !gather_remap() && c->map_tiled[camera];
+    const bool tiled = camera >= 0 && !gather_remap(c) && c->map_tiled[camera];
     if (tiled) {
         a.tile_box = reinterpret_cast<const int4 *>(c->d_tile_box[camera]);
         a.tiles_x = (a.w + RT_W - 1) / RT_W;

@@ -709,9 +709,9 @@ int launch_klt(Ctx *c, int n_pairs, const int *prev_slots_dev, const int *next_s
     a.epsilon = e * e;
     a.min_eig = (float)c->p.min_eig;
     ScopedKernelTime tm(c, HV_K_KLT);
-    // HV_KLT_TILE (environment, experiments only): tile columns x rows / slack on the low side: 0 = 44 x 40 / 6, 4 (8 staging
+    // knob klt_tile (HV_KLT_TILE at hv_create; experiments only): tile columns x rows / slack on the low side: 0 = 44 x 40 / 6, 4 (8 staging
     // passes of 5 rows), 1 = 40 x 36 / 2, 1 (6 passes of 6 rows), 2 = 40 x 42 / 2, 4 (7 passes), 5 = shape 1 compiled for 5 waves per SIMD (96 VGPRs; its 7.6 KB of LDS allow 20 waves per CU)
-    static const int tile_variant = [] { const char *e = getenv("HV_KLT_TILE"); return e ? atoi(e) : KLT_TILE_DEFAULT; }();
+    const int tile_variant = c->knob.klt_tile;
     if (pts_in_pair_dev)        hipLaunchKernelGGL((klt_kernel<40, 36, 2, 1, 5, true>), dim3((unsigned)n_points), dim3(64), 0, c->stream, a);
     else if (tile_variant == 1) hipLaunchKernelGGL((klt_kernel<40, 36, 2, 1, 4>), dim3((unsigned)n_points), dim3(64), 0, c->stream, a);
     else if (tile_variant == 2) hipLaunchKernelGGL((klt_kernel<40, 42, 2, 4, 4>), dim3((unsigned)n_points), dim3(64), 0, c->stream, a);

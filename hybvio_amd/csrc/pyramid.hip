@@ -667,11 +667,10 @@ int download_unstored_gradient(Ctx *c, int slot, int lv, int16_t *grad)
 
 // levels >= 2 in one launch (pyr_tail_kernel) when they fit LDS and no finer level is padded. One workgroup walks a whole
 // image through its phases (~60 us): a throughput design -- with few images (one sequence: 2) the per-level launches finish
-// sooner (bench latency leg: 11 us per frame), so it is used from 64 images up. HV_PYR_TAIL=0 / 1 forces it off / on.
-static int tail_first_level(const PyrLayout &L, int n_images, size_t *shmem, int *buf1)
+// sooner (bench latency leg: 11 us per frame), so it is used from 64 images up. Knob pyr_tail = 0 / 1 forces it off / on.
+static int tail_first_level(const Ctx *c, const PyrLayout &L, int n_images, size_t *shmem, int *buf1)
 {
-    const char *env_tail = getenv("HV_PYR_TAIL");                    // read per call: the tests switch it
-    const int force = env_tail ? atoi(env_tail) : -1;
+    const int force = c->knob.pyr_tail;                                // tests / experiments switch it through hv_debug_set_knob
     const int first = 2;
     if (force == 0 || (force < 0 && n_images < 64) || L.levels <= first || first_padded_level(L) < first) return L.levels;
     auto dwords = [&](int l) { return (size_t)((L.w[l] + 8 + 3) >> 2) * (4 * ((L.h[l] + 3) >> 2) + 4) + 8; };
@@ -687,7 +686,7 @@ int launch_pyramid_levels(Ctx *c, int n, const int *slots_dev, const uint8_t *sr
     const PyrLayout &L = c->L;
     size_t tail_shmem = 0;
     int tail_buf1 = 0;
-    const int tail_first = tail_first_level(L, n, &tail_shmem, &tail_buf1);
+    const int tail_first = tail_first_level(c, L, n, &tail_shmem, &tail_buf1);
     for (int l = 0; l < tail_first && l < L.levels; ++l) {
         PyrLevelArgs a{};
         if (l == 0) {
@@ -709,8 +708,7 @@ int launch_pyramid_levels(Ctx *c, int n, const int *slots_dev, const uint8_t *sr
         const unsigned grid = (unsigned)(a.tiles_x * a.tiles_y * n);
         ScopedKernelTime tm(c, l == 0 ? HV_K_PYR_L0 : HV_K_PYR_LN);
         // a level without a stored gradient plane is a pure down-sample: the direct kernel, when the 16-byte row loads are legal
-        const char *env_l0t = getenv("HV_PYR_L0_TILED");
-        const bool no_direct = env_l0t && atoi(env_l0t) != 0;
+        const bool no_direct = c->knob.pyr_l0_tiled != 0;
         if (down && !a.write_grad && !no_direct && a.w >= 24 &&
             ((reinterpret_cast<uintptr_t>(a.src_base) | (uintptr_t)a.src_stride | (uintptr_t)(a.src_step & 3)) & 3u) == 0) {
             DownL0Args d{};

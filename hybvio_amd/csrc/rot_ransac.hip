@@ -479,7 +479,10 @@ int hv_rot_ransac_batch_dev(hv_ctx *h, int n_sets, int max_points, const int *n_
     a.threshold_pow2 = threshold_pow2; a.status = status_dev; a.R = R_dev; a.summary = summary_dev;
     a.cam1 = *cam1; a.cam2 = *cam2;
     hv::ScopedKernelTime tm(c, HV_K_ROT_RANSAC);
-    if (n_sets <= 64) hipLaunchKernelGGL(hv::rot_ransac_kernel<hv::RT_FEW>, dim3((unsigned)n_sets), dim3(hv::RT_FEW), 0, c->stream, a);
+    // knob rot_ransac_threads (tests only): 256 / 1024 force the many-frames / the few-frames instantiation at any batch size
+    const int rt_forced = c->knob.rot_ransac_threads;
+    if (rt_forced == hv::RT_FEW || (rt_forced != hv::RT_MANY && n_sets <= 64))
+        hipLaunchKernelGGL(hv::rot_ransac_kernel<hv::RT_FEW>, dim3((unsigned)n_sets), dim3(hv::RT_FEW), 0, c->stream, a);
     else              hipLaunchKernelGGL(hv::rot_ransac_kernel<hv::RT_MANY>, dim3((unsigned)n_sets), dim3(hv::RT_MANY), 0, c->stream, a);
     HV_HIP(c, hipGetLastError());
     return HV_OK;
@@ -501,7 +504,10 @@ int hv_rot_ransac_lk_batch_dev(hv_ctx *h, int n_sets, int max_points, const int 
     a.threshold_pow2 = threshold_pow2; a.status = status_dev; a.R = R_dev; a.summary = summary_dev;
     a.cam1 = *cam1; a.cam2 = *cam2;
     hv::ScopedKernelTime tm(c, HV_K_ROT_RANSAC);
-    if (n_sets <= 64) hipLaunchKernelGGL(hv::rot_ransac_kernel<hv::RT_FEW>, dim3((unsigned)n_sets), dim3(hv::RT_FEW), 0, c->stream, a);
+    // knob rot_ransac_threads (tests only): 256 / 1024 force the many-frames / the few-frames instantiation at any batch size
+    const int rt_forced = c->knob.rot_ransac_threads;
+    if (rt_forced == hv::RT_FEW || (rt_forced != hv::RT_MANY && n_sets <= 64))
+        hipLaunchKernelGGL(hv::rot_ransac_kernel<hv::RT_FEW>, dim3((unsigned)n_sets), dim3(hv::RT_FEW), 0, c->stream, a);
     else              hipLaunchKernelGGL(hv::rot_ransac_kernel<hv::RT_MANY>, dim3((unsigned)n_sets), dim3(hv::RT_MANY), 0, c->stream, a);
     HV_HIP(c, hipGetLastError());
     return HV_OK;

@@ -12,7 +12,7 @@
 // column and walks the poses, whose per-iteration quantities (C, t, h, E, error) are shared through LDS.
 #include <stdlib.h>
 
-#include "hv_internal.hpp"
+#include "ekf_device.hpp"
 
 #pragma clang fp contract(fast)
 
@@ -211,7 +211,10 @@ struct VuLds {
     static constexpr int TRAIL = 0, IT = TRAIL + MAXP * POSE_WORDS, DPFI = IT + MAXP * ITER_WORDS, FEAT = DPFI + 3 * MAXC,
                          SMALL = FEAT + MAXP * 4, DPF = SMALL + 64, P0 = DPF + MAXNP * 21, MOT = P0 + 7 * MAXP * 9 + 7 * 9,
                          OWN = MOT + MAXPAIRS * MOT_STRIDE, LIN = OWN + MAXC * 9, INTS = LIN + 3 * MAXP * 9 + 32,
-                         TOTAL = INTS + (MAXNP + 3 + 4 + 1) / 2 + 1;
+                         TOTAL = INTS + (MAXNP + 3 + 4 + MAXC + 1) / 2 + 1;       // s_idx, s_flag, s_acol (fused gate)
+    // fused gate (FUSED builds): once H exists the Gauss-Newton work arrays are dead -- the compact Jacobian is staged in [P0, INTS),
+    // the (rows + 1) x rows matrix [S; v'] in [0, P0)
+    static constexpr int HS_DOUBLES = INTS - P0, T_DOUBLES = P0;
     static constexpr size_t BYTES = sizeof(double) * TOTAL;
 };
 
@@ -219,7 +222,9 @@ struct VuLds {
 // one workgroup per CU); <384, 22> holds the common sizes in 75 KB and 6 waves of 138 VGPRs, so TWO filters share a CU and one's
 // serial sections (pose records, 3 x 3 solves, barriers: most of the kernel since r02 took the column work off the critical path)
 // overlap the other's.
-template <int VT, int MAXP>
+// FUSED: the chi2 gate runs in this kernel on the compact Jacobian (VuPrepareArgs::fused, ekf_device.hpp sparse_gate): the dense H is
+// never written, only Hc / acol / v for the update of an inlier.
+template <int VT, int MAXP, bool FUSED>
 __device__ __forceinline__ void vu_prepare_body(const VuPrepareArgs &a)
 {
     // All LDS comes from the dynamic region (carved below): with static arrays the compiler derives the occupancy from their size
@@ -264,6 +269,11 @@ __device__ __forceinline__ void vu_prepare_body(const VuPrepareArgs &a)
             a.status[2 * rec] = HV_TRI_NOT_VISITED; a.status[2 * rec + 1] = HV_TRI_NOT_VISITED;
             if (a.active) a.active[rec] = 0;
             if (a.gate_status) a.gate_status[rec] = 1;
+            // a speculative pass may have left a gate result of an earlier (m, P) here: the sequential loop never visits this track
+            if (a.spec_tracks > 0) {
+                if (a.chi2) a.chi2[rec] = 0.0;
+                a.pf[3 * rec] = 0.0; a.pf[3 * rec + 1] = 0.0; a.pf[3 * rec + 2] = 0.0;
+            }
         }
         return;
     }
@@ -765,6 +775,98 @@ __device__ __forceinline__ void vu_prepare_body(const VuPrepareArgs &a)
     __syncthreads();
     VU_STAMP(29);
     const int rows = 2 * nt;
+    if constexpr (FUSED) {
+        // ---- prepareVisualUpdate in compact form + visualTrackOutlierCheck on the active columns (see VuPrepareArgs::fused) ----
+        int prep = 0;
+        for (int i = 0; i < nt && prep == 0; ++i) prep = (int)s_it[i * ITER_WORDS + 16];   // first failing pose decides (:920-927); uniform
+        const double pf_out[3] = {pfw[0], pfw[1], pfw[2]};
+        if (!(status == HV_TRI_OK && prep == 0)) {               // nothing to gate (uniform): the track is final
+            if (tid == 0) {
+                st_out[0] = status; st_out[1] = prep;
+                if (a.active) a.active[rec] = 0;
+                if (a.gate_status) a.gate_status[rec] = 1;        // VuOutlierStatus::NOT_COMPUTED
+                if (a.chi2) a.chi2[rec] = 0.0;
+                if (a.spec_tracks > 0) a.epoch[rec] = a.success_counter[b];
+#pragma unroll
+                for (int k = 0; k < 3; ++k) a.pf[3 * rec + k] = pf_out[k];
+            }
+            return;
+        }
+        const int na = 7 * n + 1, na4 = (na + 3) & ~3, ti = (rows + 15) >> 4, nrp = 16 * ti;
+        double *Hs = vu_lds + Lay::P0;
+        int *s_acol = s_flag + 4;
+        for (int i = tid; i < na4 * nrp; i += VT) Hs[i] = 0.0;
+        if (tid < na) {                                           // compact column u -> state column: pose q's position / orientation, then SFT
+            int col = SFT;
+            if (tid < 7 * n) {
+                const int q = tid / 7, comp = tid - 7 * q;
+                int ip, io;
+                pos_ori(s_idx[q], ip, io);
+                col = comp < 3 ? ip + comp : io + comp - 3;
+            }
+            s_acol[tid] = col;
+            a.acol[rec * a.na_max + tid] = col;
+        }
+        __syncthreads();
+        double *Hc = a.Hc + rec * (size_t)rows_max * a.na_max;    // record stride: the longest track; leading dimension: this track's rows
+        const unsigned inv_nt_c = (unsigned)((0x100000000ull + (unsigned)nt - 1) / (unsigned)nt);
+        for (int w = tid; w < na * nt; w += VT) {                 // work item = (compact column u, camera pose i), i fastest
+            const int u = (int)__umulhi((unsigned)w, inv_nt_c), i = w - u * nt;
+            const double *o = s_it + i * ITER_WORDS;
+            double h0 = 0.0, h1 = 0.0;
+            if (u < 7 * n) {
+                const int k = u / 7, comp = u - 7 * k;
+                if (k == i % n) {                                                          // own pose: :946-953
+                    if (comp < 3) { h0 = -o[comp]; h1 = -o[3 + comp]; }
+                    else { h0 = o[6 + comp - 3]; h1 = o[10 + comp - 3]; }
+                }
+                const double *dp = s_dpf + 21 * k + comp;                                  // :955-964
+                h0 += o[0] * dp[0] + o[1] * dp[7] + o[2] * dp[14];
+                h1 += o[3] * dp[0] + o[4] * dp[7] + o[5] * dp[14];
+            } else if (a.est_shift) {                                                      // :965-967
+                const double t0 = s_dpfi[dDim], t1 = s_dpfi[ncol + dDim], t2 = s_dpfi[2 * ncol + dDim];
+                h0 = o[0] * t0 + o[1] * t1 + o[2] * t2 - s_feat[4 * i + 2];
+                h1 = o[3] * t0 + o[4] * t1 + o[5] * t2 - s_feat[4 * i + 3];
+            }
+            *reinterpret_cast<double2 *>(Hs + (size_t)u * nrp + 2 * i) = double2{h0, h1};
+            *reinterpret_cast<double2 *>(Hc + (size_t)u * rows + 2 * i) = double2{h0, h1};
+        }
+        double vres[2] = {0.0, 0.0};
+        if (tid < nt) {
+            const double *o = s_it + tid * ITER_WORDS;
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                const size_t e = rec * rows_max + 2 * tid + r;
+                if (a.f) a.f[e] = o[14 + r];
+                vres[r] = (a.y ? a.y[e] : 0.0) - o[14 + r];
+                a.v[e] = vres[r];
+            }
+        }
+        __syncthreads();                                          // everything but Hs / s_acol is dead from here on
+        double *T = vu_lds;
+        int Rs = rows + 1;
+        while ((Rs & 31) != 15 && (Rs & 31) != 17) Rs++;
+        for (int i = tid; i < Rs * rows; i += VT) T[i] = 0.0;
+        __syncthreads();
+        if (tid < nt) { T[(size_t)(2 * tid) * Rs + rows] = vres[0]; T[(size_t)(2 * tid + 1) * Rs + rows] = vres[1]; }
+        const double *Pb = a.P + (size_t)b * N * N;
+        double chi;
+        if (ti == 1)      chi = sparse_gate<1, VT>(Pb, N, s_acol, na, Hs, T, Rs, rows, a.rd_gate, a.noise_scale, Hs);
+        else if (ti == 2) chi = sparse_gate<2, VT>(Pb, N, s_acol, na, Hs, T, Rs, rows, a.rd_gate, a.noise_scale, Hs);
+        else              chi = sparse_gate<3, VT>(Pb, N, s_acol, na, Hs, T, Rs, rows, a.rd_gate, a.noise_scale, Hs);
+        if (tid == 0) {
+            const bool broken = !(chi < 1e300);                   // non-positive pivot: reported as CHI2 (ekf_update_kernel phase D)
+            const int outlier = broken || ((rows < HV_CHI2INV95_N) ? (chi > d_chi2inv95[rows]) : 0);
+            st_out[0] = HV_TRI_OK; st_out[1] = 0;
+            if (a.active) a.active[rec] = 1;
+            if (a.gate_status) a.gate_status[rec] = outlier ? 3 /*CHI2*/ : 0 /*INLIER*/;
+            if (a.chi2) a.chi2[rec] = chi;
+            if (a.spec_tracks > 0) a.epoch[rec] = a.success_counter[b];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) a.pf[3 * rec + k] = pf_out[k];
+        }
+        return;
+    }
     double *H = a.H + rec * rows_max * N;                                    // record stride: the longest track; leading dimension: this track's rows
     // which pose of the track (if any) owns state column c, and which of its 7 components: once per column
     int *s_colmap = reinterpret_cast<int *>(s_p0);                          // s_p0 is free after the Gauss-Newton loop
@@ -827,14 +929,42 @@ __device__ __forceinline__ void vu_prepare_body(const VuPrepareArgs &a)
     }
 }
 
-__global__ __launch_bounds__(VT_LATENCY, 3) void vu_prepare_kernel(VuPrepareArgs a) { vu_prepare_body<VT_LATENCY, MAXP_ALL>(a); }
+__global__ __launch_bounds__(VT_LATENCY, 3) void vu_prepare_kernel(VuPrepareArgs a) { vu_prepare_body<VT_LATENCY, MAXP_ALL, false>(a); }
 // 4 waves per SIMD = 128 VGPRs: two workgroups of 6 waves may put 4 waves on one SIMD (512 VGPRs per lane there)
 __global__ __launch_bounds__(VT_THROUGHPUT, 4) void vu_prepare_kernel_2percu(VuPrepareArgs a)
 {
-    vu_prepare_body<VT_THROUGHPUT, MAXP_SMALL>(a);
+    vu_prepare_body<VT_THROUGHPUT, MAXP_SMALL, false>(a);
+}
+// the same two builds with the column-sparse chi2 gate fused in (VuPrepareArgs::fused)
+__global__ __launch_bounds__(VT_LATENCY, 3) void vu_gate_kernel(VuPrepareArgs a) { vu_prepare_body<VT_LATENCY, MAXP_ALL, true>(a); }
+__global__ __launch_bounds__(VT_THROUGHPUT, 4) void vu_gate_kernel_2percu(VuPrepareArgs a)
+{
+    vu_prepare_body<VT_THROUGHPUT, MAXP_SMALL, true>(a);
 }
 
 }  // namespace
+
+// The fused gate serves tracks of up to 48 rows (the 16 TI <= 48 MFMA tile template; 12 stereo / 24 mono poses) whose staged
+// matrices fit the LDS regions the Gauss-Newton arrays leave free; everything else keeps the dense path.
+static bool vu_small_build(const Ctx *c, int nt, int batch)
+{
+    const int forced = c->knob.vu_threads;
+    // two filters per CU pay off once the launch holds more filters than the GPU has CUs; below that the big build's latency wins
+    return nt <= MAXP_SMALL && (forced == VT_THROUGHPUT || (forced != VT_LATENCY && batch > 256));
+}
+
+bool vu_fused_supported(const Ctx *c, int n_state, int np, int stereo, int batch)
+{
+    if (c->knob.ekf_fused_gate == 0) return false;
+    const int nt = np * (stereo ? 2 : 1), rows = 2 * nt, na4 = (7 * np + 1 + 3) & ~3, nrp = 16 * ((rows + 15) / 16);
+    if (np < 2 || np > MAXNP || nt > MAXP_ALL || rows > 48 || rows >= HV_CHI2INV95_N || n_state < 1 || n_state > 160) return false;
+    int Rs = rows + 1;
+    while ((Rs & 31) != 15 && (Rs & 31) != 17) Rs++;
+    const bool small = vu_small_build(c, nt, batch);
+    const int hs_cap = small ? VuLds<MAXP_SMALL>::HS_DOUBLES : VuLds<MAXP_ALL>::HS_DOUBLES;
+    const int t_cap = small ? VuLds<MAXP_SMALL>::T_DOUBLES : VuLds<MAXP_ALL>::T_DOUBLES;
+    return na4 * nrp <= hs_cap && 816 + VT_LATENCY / 64 <= hs_cap && Rs * rows <= t_cap;
+}
 
 int launch_vu_prepare(Ctx *c, const VuPrepareArgs &a)
 {
@@ -844,21 +974,26 @@ int launch_vu_prepare(Ctx *c, const VuPrepareArgs &a)
     if (a.np > MAXNP || a.np * (a.stereo ? 2 : 1) > MAXP_ALL) return HV_ERR_UNSUPPORTED;
     ScopedKernelTime tm(c, HV_K_VU_PREPARE);
     const int nt = a.np * (a.stereo ? 2 : 1);
-    // HV_VU_THREADS (environment, experiments only): 384 / 768 forces a variant where it applies
-    static const int forced = [] { const char *e = getenv("HV_VU_THREADS"); return e ? atoi(e) : 0; }();
-    const bool small_ok = nt <= MAXP_SMALL;
-    // two filters per CU pay off once the launch holds more filters than the GPU has CUs; below that the big build's latency wins
-    const bool small = small_ok && (forced == VT_THROUGHPUT || (forced == 0 && a.batch > 256));
-    static bool attr_set_dev[64] = {};                       // per device: both kernels need more than the default 64 KB of dynamic LDS
+    // knob vu_threads (tests / experiments): 384 / 768 forces a build where it applies
+    const bool small = vu_small_build(c, nt, a.batch);
+    if (a.fused && (!vu_fused_supported(c, a.n, a.np, a.stereo, a.batch) || !a.Hc || !a.acol || !a.P || a.na_max < 7 * a.np + 1)) return HV_ERR_INVALID;
+    static bool attr_set_dev[64] = {};                       // per device: the kernels need more than the default 64 KB of dynamic LDS
     bool &attr_set = attr_set_dev[c->p.device & 63];
     if (!attr_set) {
         HV_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void *>(vu_prepare_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)VuLds<MAXP_ALL>::BYTES));
         HV_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void *>(vu_prepare_kernel_2percu), hipFuncAttributeMaxDynamicSharedMemorySize, (int)VuLds<MAXP_SMALL>::BYTES));
+        HV_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void *>(vu_gate_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)VuLds<MAXP_ALL>::BYTES));
+        HV_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void *>(vu_gate_kernel_2percu), hipFuncAttributeMaxDynamicSharedMemorySize, (int)VuLds<MAXP_SMALL>::BYTES));
         attr_set = true;
     }
     const dim3 grid((unsigned)a.batch, (unsigned)(a.spec_tracks > 0 ? a.spec_tracks : 1));
-    if (small) hipLaunchKernelGGL(vu_prepare_kernel_2percu, grid, dim3(VT_THROUGHPUT), VuLds<MAXP_SMALL>::BYTES, c->stream, a);
-    else       hipLaunchKernelGGL(vu_prepare_kernel, grid, dim3(VT_LATENCY), VuLds<MAXP_ALL>::BYTES, c->stream, a);
+    if (a.fused) {
+        if (small) hipLaunchKernelGGL(vu_gate_kernel_2percu, grid, dim3(VT_THROUGHPUT), VuLds<MAXP_SMALL>::BYTES, c->stream, a);
+        else       hipLaunchKernelGGL(vu_gate_kernel, grid, dim3(VT_LATENCY), VuLds<MAXP_ALL>::BYTES, c->stream, a);
+    } else {
+        if (small) hipLaunchKernelGGL(vu_prepare_kernel_2percu, grid, dim3(VT_THROUGHPUT), VuLds<MAXP_SMALL>::BYTES, c->stream, a);
+        else       hipLaunchKernelGGL(vu_prepare_kernel, grid, dim3(VT_LATENCY), VuLds<MAXP_ALL>::BYTES, c->stream, a);
+    }
     HV_HIP(c, hipGetLastError());
     return HV_OK;
 }

@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define HV_ABI_VERSION 1
+#define HV_ABI_VERSION 2   /* 2 (r03): hv_debug_*_knob, hv_ekf_frame_error, HV_ERR_TIMEOUT; maxSuccessfulVisualUpdates <= 0 = no limit */
 #define HV_MAX_LEVELS 6
 
 typedef enum hv_status {
@@ -34,7 +34,8 @@ typedef enum hv_status {
     HV_ERR_NO_DEVICE = -3,    /* no HIP device / HIP runtime failed to start    */
     HV_ERR_HIP = -4,          /* a HIP call failed; see hv_last_error()         */
     HV_ERR_POOL = -5,         /* pyramid pool exhausted / bad slot              */
-    HV_ERR_NOMEM = -6
+    HV_ERR_NOMEM = -6,
+    HV_ERR_TIMEOUT = -7       /* a device-side wait gave up; the call's result must not be used */
 } hv_status;
 
 typedef struct hv_ctx hv_ctx;
@@ -57,6 +58,12 @@ typedef struct hv_params {
 void hv_default_params(hv_params *p);                 /* fills the defaults listed above */
 int hv_abi_version(void);
 const char *hv_status_string(int status);
+/* Test / measurement hooks: force a kernel variant that production code selects by shape or batch size (names: the fields of
+ * hv::Knobs in csrc/hv_internal.hpp, e.g. "vu_threads" 384 / 768, "pyr_tail" 0 / 1, "rot_ransac_threads" 256 / 1024, "ekf_fused_gate"
+ * 0). The same names in upper case with an HV_ prefix are read from the environment ONCE, by hv_create; nothing on the hot path
+ * calls getenv. HV_ERR_INVALID for an unknown name. Not needed by an integration. */
+int hv_debug_set_knob(hv_ctx *ctx, const char *name, int value);
+int hv_debug_get_knob(hv_ctx *ctx, const char *name, int *value);
 
 /* ---- context ---------------------------------------------------------------------------- */
 int hv_create(const hv_params *params, hv_ctx **out);
@@ -256,9 +263,12 @@ int hv_ekf_visual_track_limited_dev(hv_ekf *ekf, const hv_vu_params *p, int n_po
  * Nothing crosses the host between the visits; the call is asynchronous and HIP-graph capturable once it has run once
  * (its work buffers are allocated on first use). r_gate stays constant over the frame, i.e. the reference's default
  * trackOutlierThresholdGrowthFactor = 1 (backend.cpp:1192); other factors need the per-visit entry points.
+ * max_successful <= 0 means "no limit" (the reference's maxSuccessfulVisualUpdates <= 0, backend.cpp:1233).
  * With few sequences (batch * n_tracks <= 256, n_rows <= 48) the loop runs speculatively: each pass prepares and gates every
  * pending track of a filter in parallel against the current (m, P), applies the first inlier in visit order and re-examines only
- * the tracks behind it -- at most max_successful + 1 passes, the same statuses and the same filter as the sequential loop. */
+ * the tracks behind it -- at most min(max_successful, n_tracks) + 1 passes, the same statuses and the same filter as the sequential
+ * loop. chi2_dev / pf_dev entries of tracks the loop never visits (status HV_TRI_NOT_VISITED) are 0.
+ * hv_vu_params: always start from hv_vu_default_params() -- fields added in later ABI versions then hold their defaults. */
 int hv_ekf_visual_frame_dev(hv_ekf *ekf, const hv_vu_params *p, int n_tracks, int n_poses, const int *pose_index_dev,
                             const double *features_dev, const double *velocities_dev, const double *y_dev, double r_gate,
                             double r_update, int *status_dev, int *gate_status_dev, double *chi2_dev, double *pf_dev /* [n_tracks][batch][3] or NULL */,
@@ -274,6 +284,10 @@ int hv_ekf_visual_frame_ragged_dev(hv_ekf *ekf, const hv_vu_params *p, int n_tra
                                    const int *pose_index_dev, const double *features_dev, const double *velocities_dev,
                                    const double *y_dev, double r_gate, double r_update, int *status_dev, int *gate_status_dev,
                                    double *chi2_dev, double *pf_dev, int *success_counter_dev, int max_successful);
+/* Reads (and clears) the error word of the filter batch: non-zero when a device-side wait of an asynchronous frame call gave up
+ * (only the experimental hand-shake form of the speculative pass, knob ekf_spec_mode = 3, can raise it); the host-pointer entry
+ * points check it themselves and return HV_ERR_TIMEOUT. Synchronous. */
+int hv_ekf_frame_error(hv_ekf *ekf, int *flags);
 int hv_ekf_visual_frame(hv_ekf *ekf, const hv_vu_params *p, int n_tracks, int n_poses, const int *pose_index, const double *features,
                         const double *velocities, const double *y, double r_gate, double r_update, int *status, int *gate_status,
                         double *chi2, double *pf, int *success_count, int max_successful);

@@ -10,6 +10,29 @@ import pytest
 from hybvio_amd import capi, synth
 
 pytestmark = pytest.mark.gpu
+
+# Kernel variants the library selects by shape / batch size, forced here so that EVERY instantiation the benchmark runs is
+# parity-tested at test-sized batches too: the two-per-CU / latency builds of the prepare kernel
+# (vu_prepare_kernel_2percu is what B = 1024 runs), the fused column-sparse gate (r03 default) against the dense
+# gate + update kernels, and the three forms of a speculative pass.
+VARIANTS = {
+    "default": {},
+    "vu384": {"vu_threads": 384},
+    "vu768": {"vu_threads": 768},
+    "dense": {"ekf_fused_gate": 0},
+    "dense_vu384": {"ekf_fused_gate": 0, "vu_threads": 384},
+    "spec3": {"ekf_spec_mode": 3},
+    "split": {"ekf_spec_split": 1},
+    "spec2_vu384": {"vu_threads": 384},
+}
+
+
+def _apply(ctx, variant):
+    for k, v in VARIANTS[variant].items():
+        ctx.set_knob(k, v)
+        assert ctx.get_knob(k) == v
+
+
 FX = os.path.join(os.path.dirname(__file__), "golden", "triangulation_reference_fixtures.npz")
 POS, ORI, SFT, CAM = 0, 6, 19, 20
 TOL = 1e-9
@@ -130,13 +153,15 @@ def _random_tracks(oracle, rng, B, trail_len, npose, stereo, bad_fraction=0.25, 
 
 @pytest.mark.parametrize("trail_len,npose,stereo", [(20, 10, True), (20, 21, True), (20, 4, False), (20, 21, False), (12, 2, True),
                                                     (20, 7, True), (5, 6, False)])
-def test_random_tracks_match_the_oracle(oracle, trail_len, npose, stereo):
+@pytest.mark.parametrize("variant", ["vu768", "vu384"])
+def test_random_tracks_match_the_oracle(oracle, trail_len, npose, stereo, variant):
     rng = np.random.default_rng(100 * trail_len + npose + (7 if stereo else 0))
     B = 48
     T1, T2, means, idx, feat, vel = _random_tracks(oracle, rng, B, trail_len, npose, stereo)
     vp = capi.vu_default_params(imu_to_camera=T1, second_imu_to_camera=T2) if stereo else capi.vu_default_params(imu_to_camera=T1)
     y = feat.reshape(B, -1) + 1e-3
     with capi.Context(width=64, height=64) as ctx:
+        _apply(ctx, variant)
         H, v, f, pf, st, act = _device_prepare(ctx, trail_len, means, vp, idx, feat, vel, y=y)
     par = oracle.tri_default_params()
     seen = set()
@@ -209,7 +234,8 @@ def test_parameters_reach_the_kernel(oracle):
             assert 5 in statuses                                                        # BAD_DEPTH
 
 
-def test_visual_track_dev_prepare_gate_update_equals_the_reference_sequence(oracle):
+@pytest.mark.parametrize("variant", ["default", "vu384", "dense", "dense_vu384"])
+def test_visual_track_dev_prepare_gate_update_equals_the_reference_sequence(oracle, variant):
     """hv_ekf_visual_track_dev = backend.cpp:1063-1185 for one track per filter: prepare from the device mean, gate with
     trackChiTestOutlierR, update with visualR only where triangulation, prepare and gate pass. Filters that fail stay
     bit-identical; the others match the oracle's EKF to 1e-9 relative."""
@@ -223,6 +249,7 @@ def test_visual_track_dev_prepare_gate_update_equals_the_reference_sequence(orac
     par = oracle.tri_default_params()
     r_gate, r_update = 1.5, 0.05                                                         # parameter_definitions.c:23,91
     with capi.Context(width=64, height=64) as ctx:
+        _apply(ctx, variant)
         g = capi.EkfBatch(ctx, capi.ekf_default_params(cameraTrailLength=trail_len), B)
         filters = []
         for b in range(B):
@@ -268,7 +295,8 @@ def test_visual_track_dev_prepare_gate_update_equals_the_reference_sequence(orac
         g.close()
 
 
-def test_frame_loop_with_the_successful_update_quota(oracle):
+@pytest.mark.parametrize("variant", ["default", "vu384", "dense"])
+def test_frame_loop_with_the_successful_update_quota(oracle, variant):
     """A frame's visual-update loop for a batch (backend.cpp:1012-1240): K tracks per filter, visited in order, each seeing the
     mean the previous one left; a filter stops being visited once maxSuccessfulVisualUpdates updates were applied."""
     import torch
@@ -283,6 +311,7 @@ def test_frame_loop_with_the_successful_update_quota(oracle):
     par = oracle.tri_default_params()
     r_gate, r_update = 1.5, 0.05
     with capi.Context(width=64, height=64) as ctx:
+        _apply(ctx, variant)
         g = capi.EkfBatch(ctx, capi.ekf_default_params(cameraTrailLength=trail_len), B)
         filters = []
         for b in range(B):
@@ -331,8 +360,9 @@ def test_frame_loop_with_the_successful_update_quota(oracle):
         g.close()
 
 
-@pytest.mark.parametrize("B,speculative", [(12, True), (40, False)])
-def test_whole_frame_loop_in_one_call(oracle, B, speculative):
+@pytest.mark.parametrize("B,speculative,variant", [(12, True, "default"), (12, True, "spec2_vu384"), (12, True, "spec3"), (12, True, "split"),
+                                                   (40, False, "default"), (40, False, "vu384"), (40, False, "dense"), (40, False, "dense_vu384")])
+def test_whole_frame_loop_in_one_call(oracle, B, speculative, variant):
     """hv_ekf_visual_frame_dev = the frame's visit loop in ONE call. For few sequences (B * K <= 256) it runs speculatively: every
     pending track prepared and gated in parallel, the first inlier applied, the rest re-examined (<= quota + 1 passes); for more it
     is the sequential per-visit loop. Both must give the reference's sequential result: statuses per visit, the quota, the filter."""
@@ -349,6 +379,7 @@ def test_whole_frame_loop_in_one_call(oracle, B, speculative):
     par = oracle.tri_default_params()
     r_gate, r_update = 1.5, 0.05
     with capi.Context(width=64, height=64) as ctx:
+        _apply(ctx, variant)
         g = capi.EkfBatch(ctx, capi.ekf_default_params(cameraTrailLength=trail_len), B)
         filters = []
         for b in range(B):
@@ -394,8 +425,10 @@ def test_whole_frame_loop_in_one_call(oracle, B, speculative):
         g.close()
 
 
-@pytest.mark.parametrize("B,speculative,stereo", [(10, True, True), (48, False, True), (9, True, False)])
-def test_whole_frame_loop_with_ragged_track_lengths(oracle, B, speculative, stereo):
+@pytest.mark.parametrize("B,speculative,stereo,variant", [(10, True, True, "default"), (48, False, True, "default"), (9, True, False, "default"),
+                                                          (10, True, True, "spec3"), (48, False, True, "vu384"), (48, False, True, "dense"),
+                                                          (9, True, False, "spec2_vu384"), (48, False, False, "vu384")])
+def test_whole_frame_loop_with_ragged_track_lengths(oracle, B, speculative, stereo, variant):
     """hv_ekf_visual_frame_ragged_dev: the sequences of a batch do not share track lengths -- every (visit, filter) record has its own
     pose count (2 .. n_poses_max, 0 = this filter has no candidate at this visit), padded to the longest. Result = the reference's
     sequential loop run per filter over its own tracks."""
@@ -423,6 +456,7 @@ def test_whole_frame_loop_with_ragged_track_lengths(oracle, B, speculative, ster
     par = oracle.tri_default_params()
     r_gate, r_update = 1.5, 0.05
     with capi.Context(width=64, height=64) as ctx:
+        _apply(ctx, variant)
         g = capi.EkfBatch(ctx, capi.ekf_default_params(cameraTrailLength=trail_len), B)
         filters = []
         for b in range(B):
