@@ -29,7 +29,7 @@ f32p = C.POINTER(C.c_float)
 f64p = C.POINTER(C.c_double)
 
 HV_MAX_LEVELS = 6
-K_PYR_L0, K_PYR_LN, K_KLT, K_EKF_PREDICT, K_EKF_UPDATE, K_EKF_AUGMENT, K_GFTT, K_INGEST, K_VU_PREPARE, K_ROT_RANSAC = range(10)
+K_PYR_L0, K_PYR_LN, K_KLT, K_EKF_PREDICT, K_EKF_UPDATE, K_EKF_AUGMENT, K_GFTT, K_INGEST, K_VU_PREPARE, K_ROT_RANSAC, K_EKF_GATE = range(11)
 
 # tracker::Feature::Status (src/tracker/track.hpp:9-21)
 ST_TRACKED, ST_NEW, ST_FAILED_FLOW, ST_RANSAC_OUTLIER, ST_FLOW_OUT_OF_RANGE = 0, 1, 2, 3, 4
@@ -214,11 +214,11 @@ class Context:
     # -- plumbing --
     def set_knob(self, name: str, value: int):
         """Force a kernel variant (tests / measurements; include/hybvio_hip.h hv_debug_set_knob)."""
-        self._chk(self._L.hv_debug_set_knob(self._h, name.encode(), int(value)), f"hv_debug_set_knob({name})")
+        self._chk(lib().hv_debug_set_knob(self._h, name.encode(), int(value)), f"hv_debug_set_knob({name})")
 
     def get_knob(self, name: str) -> int:
         v = C.c_int()
-        self._chk(self._L.hv_debug_get_knob(self._h, name.encode(), C.byref(v)), f"hv_debug_get_knob({name})")
+        self._chk(lib().hv_debug_get_knob(self._h, name.encode(), C.byref(v)), f"hv_debug_get_knob({name})")
         return v.value
 
     def set_stream(self, stream_ptr: int):

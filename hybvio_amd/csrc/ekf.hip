@@ -1094,6 +1094,81 @@ __global__ __launch_bounds__(GATE_THREADS, 2) void ekf_gate_stream_kernel(GateAr
 }
 
 // ---------------------------------------------------------------------------------------------
+// Column-sparse chi2 gate as its own launch (many filters): visualTrackOutlierCheck on the compact Jacobians the prepare launch left
+// in HBM (VuPrepareArgs::fused == 2). One 4-wave workgroup per filter -- four waves sit one per SIMD, so the (J, ct) items of
+// sparse_gate spread evenly over the matrix pipes --, LDS = Hc (28 KB at 10 stereo poses) + [S; v'] (15 KB): three workgroups per CU,
+// whose single-wave Cholesky chains (40 dependent pivots, ~10 us) run under each other's products. The same chain inside the
+// prepare kernel (two 80 KB workgroups per CU, both latency chains themselves) cost 60 us per 1024 filters (r03 measurements).
+// ---------------------------------------------------------------------------------------------
+struct SparseGateArgs {
+    int n, nr, ncam, na_max;          // state dimension; rows of the longest record (= record stride of v); cameras; columns per Hc record
+    const double *P;                  // [batch][n][n]
+    const double *Hc, *v;             // [batch][nr * na_max] compact Jacobians (leading dimension: the record's rows), [batch][nr]
+    const int *acol;                  // [batch][na_max]
+    const int *nr_rec;                // ragged batches: rows of every record, or null
+    const unsigned char *active;      // [batch]: 1 where triangulation and prepareVisualUpdate passed (written by the prepare launch)
+    double rd, noise_scale;
+    double *chi2; int *status;        // chi2 optional
+    int hs_doubles;                   // LDS carve: doubles reserved for the staged Hc (>= 816 + 4: it is the Cholesky scratch afterwards)
+};
+
+constexpr int SGATE_THREADS = 256;
+
+__global__ __launch_bounds__(SGATE_THREADS, 3) void ekf_sparse_gate_kernel(SparseGateArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const int b = blockIdx.x, t = threadIdx.x;
+    if (!a.active[b]) return;                                  // status stays NOT_COMPUTED (preset by the prepare launch)
+    int nr = a.nr_rec ? a.nr_rec[b] : a.nr;
+    nr = __builtin_amdgcn_readfirstlane(nr);
+    if (nr < 2 || nr > a.nr) return;
+    const int n = a.n, npose = nr / (2 * a.ncam), na = 7 * npose + 1, na4 = (na + 3) & ~3;
+    const int ti = (nr + 15) >> 4, nrp = 16 * ti;
+    int Rs = nr + 1;
+    while ((Rs & 31) != 15 && (Rs & 31) != 17) Rs++;
+    double *Hs = smem, *T = smem + a.hs_doubles;
+    int *s_acol = reinterpret_cast<int *>(T + (size_t)Rs * nr);
+    const double *Hc = a.Hc + (size_t)b * a.nr * a.na_max;
+    // stage Hc k-major with zero padding (rows >= nr, columns >= na), [S; v'] zeroed with the residual row in place
+    // (8 elements per thread in flight: a load -> LDS store loop without unrolling waits one HBM / L2 round trip per iteration -- 14 of
+    // them at 10 stereo poses, which made this staging half of the kernel)
+    const int my_acol = t < na ? a.acol[(size_t)b * a.na_max + t] : 0;
+    const double my_v = t < nr ? a.v[(size_t)b * a.nr + t] : 0.0;
+    const int total = na4 * nrp;
+    const unsigned inv_nrp = (unsigned)((0x100000000ull + (unsigned)nrp - 1) / (unsigned)nrp);       // i / nrp = umulhi(i, ceil(2^32 / nrp))
+    for (int base = 0; base < total; base += 8 * SGATE_THREADS) {
+        double hv_[8];
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+            const int i = base + q * SGATE_THREADS + t, u = (int)__umulhi((unsigned)i, inv_nrp), r = i - u * nrp;
+            const bool live = i < total && u < na && r < nr;
+            hv_[q] = live ? Hc[(size_t)(live ? u : 0) * nr + (live ? r : 0)] : 0.0;
+        }
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+            const int i = base + q * SGATE_THREADS + t;
+            if (i < total) Hs[i] = hv_[q];
+        }
+    }
+    for (int i = t; i < Rs * nr; i += SGATE_THREADS) T[i] = 0.0;             // (row nr of column c is rewritten below by thread c: same thread order
+    if (t < na) s_acol[t] = my_acol;                                           //  is not guaranteed, so the barrier comes first)
+    __syncthreads();
+    if (t < nr) T[(size_t)t * Rs + nr] = my_v;
+    __syncthreads();
+    const double *Pb = a.P + (size_t)b * n * n;
+    double chi;
+    if (ti == 1)      chi = sparse_gate<1, SGATE_THREADS, true>(Pb, n, s_acol, na, Hs, T, Rs, nr, a.rd, a.noise_scale, Hs);
+    else if (ti == 2) chi = sparse_gate<2, SGATE_THREADS, true>(Pb, n, s_acol, na, Hs, T, Rs, nr, a.rd, a.noise_scale, Hs);
+    else              chi = sparse_gate<3, SGATE_THREADS, true>(Pb, n, s_acol, na, Hs, T, Rs, nr, a.rd, a.noise_scale, Hs);
+    if (t == 0) {
+        const bool broken = !(chi < 1e300);                    // non-positive pivot: reported as CHI2 (ekf_update_kernel phase D)
+        const int outlier = broken || ((nr < HV_CHI2INV95_N) ? (chi > d_chi2inv95[nr]) : 0);
+        a.status[b] = outlier ? 3 /*CHI2*/ : 0 /*INLIER*/;
+        if (a.chi2) a.chi2[b] = chi;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // pose augmentation / undo (ekf.cpp:848-903) and housekeeping
 // ---------------------------------------------------------------------------------------------
 struct AugmentArgs {
@@ -1534,6 +1609,33 @@ static int ekf_launch_gate_stream(Ekf *e, int nr, int l, const double *H_dev, co
     return HV_OK;
 }
 
+// ekf_sparse_gate_kernel over the compact records of a prepare launch (np = poses of the longest record)
+static int ekf_launch_sparse_gate(Ekf *e, int np, int ncam, const double *Hc_dev, const double *v_dev, const int *acol_dev, const int *nr_rec_dev,
+                                  const unsigned char *active_dev, double rd, double *chi2_dev, int *status_dev)
+{
+    Ctx *c = e->c;
+    const int nr = 2 * np * ncam, na_max = 7 * np + 1, na4 = (na_max + 3) & ~3, nrp = 16 * ((nr + 15) / 16);
+    if (nr < 2 || nr > 48 || !active_dev || !status_dev) return HV_ERR_INVALID;
+    SparseGateArgs a{};
+    a.n = e->n; a.nr = nr; a.ncam = ncam; a.na_max = na_max; a.P = e->P; a.Hc = Hc_dev; a.v = v_dev; a.acol = acol_dev; a.nr_rec = nr_rec_dev;
+    a.active = active_dev; a.rd = rd; a.noise_scale = e->noise_scale; a.chi2 = chi2_dev; a.status = status_dev;
+    int Rs = nr + 1;
+    while ((Rs & 31) != 15 && (Rs & 31) != 17) Rs++;
+    a.hs_doubles = na4 * nrp < 824 ? 824 : na4 * nrp;
+    const size_t shmem = sizeof(double) * ((size_t)a.hs_doubles + (size_t)Rs * nr) + sizeof(int) * (size_t)(na_max + 2);
+    if (shmem > 96 * 1024) return HV_ERR_UNSUPPORTED;
+    static bool attr_set_dev[64] = {};
+    bool &attr_set = attr_set_dev[c->p.device & 63];
+    if (!attr_set) {
+        HV_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void *>(ekf_sparse_gate_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+        attr_set = true;
+    }
+    ScopedKernelTime tm(c, HV_K_EKF_GATE);
+    hipLaunchKernelGGL(ekf_sparse_gate_kernel, dim3(e->batch), dim3(SGATE_THREADS), shmem, c->stream, a);
+    HV_HIP(c, hipGetLastError());
+    return HV_OK;
+}
+
 }  // namespace hv
 
 using hv::Ctx;
@@ -1736,10 +1838,21 @@ static int visual_track_dev_impl(hv_ekf *h, const hv_vu_params *p, int np, const
     // of a rejected track never leaves LDS and only P(a, a) is read); updateVisualTrack then runs where the gate said INLIER, staging the
     // compact Jacobian through its column map (7 of 20 visits at most -- backend.cpp:1233-1238 -- pay the full H P + downdate).
     if (hv::vu_fused_supported(c, e->n, np, a.stereo, e->batch)) {
-        a.fused = 1; a.H = nullptr; a.Hc = e->vuH; a.acol = e->vuacol; a.na_max = 7 * np + 1; a.P = e->P;
+        // knob ekf_fused_gate: -1 auto / 1 = the gate inside the prepare launch (vu_gate kernels); 2 = its own launch (vu_compact kernels +
+        // ekf_sparse_gate_kernel, three 43 KB workgroups per CU). Measured at 1024 filters x 10 stereo poses (r03, scripts/vu_microbench.py):
+        // 156 us against 84 + 67 us per visit, and 9.0 against 9.25 ms for the chained C3 step -- the gate costs ~17 us of a CU per filter
+        // in either form (a 40-pivot Cholesky chain on one wave + 430 MFMAs at low occupancy), so the form with one launch and no round trip
+        // of Hc through HBM stays the default at every batch size.
+        const int fg = c->knob.ekf_fused_gate;
+        const bool split_gate = fg == 2;
+        a.fused = split_gate ? 2 : 1; a.H = nullptr; a.Hc = e->vuH; a.acol = e->vuacol; a.na_max = 7 * np + 1; a.P = e->P;
         a.rd_gate = r_gate * r_gate * ns; a.noise_scale = ns; a.chi2 = chi2_dev;
         rc = hv::launch_vu_prepare(c, a);
         if (rc != HV_OK) return rc;
+        if (split_gate) {
+            rc = hv::ekf_launch_sparse_gate(e, np, a.stereo ? 2 : 1, e->vuH, e->vuv, e->vuacol, nr_rec, e->vuactive, a.rd_gate, chi2_dev, gate_status_dev);
+            if (rc != HV_OK) return rc;
+        }
         const hv::CompactH ch{e->vuacol, a.na_max, a.stereo ? 2 : 1};
         return hv::ekf_launch_update(e, rows, e->n, e->vuH, e->vuv, nullptr, r_update * r_update * ns, 1, 0, 1, nullptr, nullptr,
                                      e->vuactive, gate_status_dev, success_counter_dev, 0.0, nullptr, 0, 0, nullptr, 0, nullptr, nullptr,

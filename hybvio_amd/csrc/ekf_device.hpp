@@ -149,50 +149,37 @@ __device__ __forceinline__ void factor_diag_block(double *T, double *W, double *
 // with stride Rs, ZEROED except row nr = v'. work: >= 816 + NT / 64 doubles of scratch (may alias Hs: it is used after the products).
 // Every thread returns the same chi2; a non-positive pivot leaves inf / NaN in it (the caller reports CHI2, as ekf_update_kernel does).
 // ---------------------------------------------------------------------------------------------
-template <int TI, int NT>
+// PIPE: the P values of an item rotate through one register buffer with the NEXT item's loads issued behind each MFMA (standalone gate
+// kernel, ~110 VGPRs); !PIPE: chunks of 10 k-steps, double buffered (the fused prepare + gate kernel, which lives on 128 VGPRs).
+template <int TI, int NT, bool PIPE>
 __device__ __forceinline__ double sparse_gate(const double *P, int n, const int *acol, int na, const double *Hs, double *T, int Rs, int nr,
-                                              double rd, double noise_scale, double *work)
+                                              double rd, double noise_scale, double *work, long long *stamps = nullptr)
 {
+#ifdef HV_EKF_PHASE_STAMPS
+#define GATE_STAMP(i) do { if (stamps && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) stamps[i] = (long long)__builtin_readcyclecounter(); } while (0)
+#else
+#define GATE_STAMP(i) do { (void)stamps; } while (0)
+#endif
     const int t = threadIdx.x, lane = t & 63, kq = lane >> 4, cl = lane & 15;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
-    constexpr int nwaves = NT / 64, nrp = 16 * TI, NS = TI * (TI + 1) / 2, U = 4;
+    constexpr int nwaves = NT / 64, nrp = 16 * TI;
+    // the shape is the same for every lane: keep it on the scalar unit (the callers' values come out of per-lane loads)
+    n = __builtin_amdgcn_readfirstlane(n); na = __builtin_amdgcn_readfirstlane(na); nr = __builtin_amdgcn_readfirstlane(nr);
+    Rs = __builtin_amdgcn_readfirstlane(Rs);
     const int nJ = (na + 15) >> 4, nk = (na + 3) >> 2, na4 = 4 * nk;
-    for (int J = wave; J < nJ; J += nwaves) {
-        const double *pj = P + acol[min(16 * J + cl, na - 1)];                 // row a_j of P(a, a): P(a_j, a_k) = P[a_k * n + a_j]
-        double4v accG[TI];
+    // Work items (J, ct): the 16-row block J of P(a, a) against the 16-column tile ct of Hc' -- nk + 4 (TI - ct) MFMAs (64 cycles each on a
+    // SIMD's matrix pipe), item = ct * nJ + J (the dearer tiles first). They are dealt to the waves BY SIMD (wave w runs on SIMD w % 4): a
+    // 6-wave workgroup has two waves on SIMDs 0 and 1, so a plain round-robin over the waves would give those SIMDs twice the matrix work.
+    // Slots for 6 waves: 0 1 2 3 4 5 2 3 (SIMDs 0 1 2 3 0 1 2 3), i.e. waves 2 and 3 take every 4th item, the others every 8th.
+    const int n_items = nJ * TI, stride = nwaves == 6 ? ((wave == 2 || wave == 3) ? 4 : 8) : nwaves;
+    // second product + LDS accumulation of one item, given G = P(a_J, a) Hc(tile ct)' in the accumulator layout
+    auto finish_item = [&](int J, int ct, const double4v &accG) {
+        // S(rt, ct) += Hc(16 rt + i, a-index 16 J + k) G(k, 16 ct + c) for the lower tiles rt >= ct; k-step v: A = Hc(.., 16 J + 4 v + kq),
+        // B = accG[v] -- the accumulator tile of the first product IS the B-operand layout (lane (kq, c) holds rows 4 v + kq).
+        // (rows j >= na of G repeat row na - 1: they meet the zero columns of Hs, or the select below beyond na4)
+        double4v accS[TI];
 #pragma unroll
-        for (int ct = 0; ct < TI; ct++) accG[ct] = double4v{0.0, 0.0, 0.0, 0.0};
-        // k-steps s = 0 .. nk-1 in chunks of U, the next chunk's P values requested before this chunk's MFMAs; steps beyond nk
-        // (tail of the last chunk) read a clamped address and contribute zero
-        auto load_a = [&](double (&av)[U], int s0) {
-#pragma unroll
-            for (int u = 0; u < U; u++) {
-                const int s = s0 + u;
-                const double x = pj[(size_t)acol[min(4 * s + kq, na - 1)] * n];
-                av[u] = s < nk ? x : 0.0;
-            }
-        };
-        double a0[U], a1[U];
-        load_a(a0, 0);
-        for (int s0 = 0; s0 < nk; s0 += U) {
-            load_a(a1, min(s0 + U, nk));                                       // (past the end: all zeros, never used)
-#pragma unroll
-            for (int u = 0; u < U; u++) {
-                const int s = min(s0 + u, nk - 1);
-                double hb[TI];
-#pragma unroll
-                for (int ct = 0; ct < TI; ct++) hb[ct] = Hs[(size_t)(4 * s + kq) * nrp + 16 * ct + cl];      // B(k, c) = Hc(c, k)
-#pragma unroll
-                for (int ct = 0; ct < TI; ct++) accG[ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[u], hb[ct], accG[ct], 0, 0, 0);
-            }
-#pragma unroll
-            for (int u = 0; u < U; u++) a0[u] = a1[u];
-        }
-        // S(rt, ct) += Hc(16 rt + i, a-index 16 J + k) G_J(k, 16 ct + c), lower tiles; k-step v: A = Hc(.., 16 J + 4 v + kq), B = accG[ct][v]
-        // (rows j >= na of G_J repeat row na - 1: they meet the zero columns of Hs, or the select below beyond na4)
-        double4v accS[NS];                                                   // (per block: S tiles and G tiles are never live during the gather loop)
-#pragma unroll
-        for (int u = 0; u < NS; u++) accS[u] = double4v{0.0, 0.0, 0.0, 0.0};
+        for (int rt = 0; rt < TI; rt++) accS[rt] = double4v{0.0, 0.0, 0.0, 0.0};
 #pragma unroll
         for (int v = 0; v < 4; v++) {
             const int idx = 16 * J + 4 * v + kq;
@@ -202,30 +189,116 @@ __device__ __forceinline__ double sparse_gate(const double *P, int n, const int 
                 const double x = Hs[(size_t)min(idx, na4 - 1) * nrp + 16 * rt + cl];
                 ha[rt] = idx < na4 ? x : 0.0;
             }
-            int u = 0;
 #pragma unroll
-            for (int ct = 0; ct < TI; ct++)
-#pragma unroll
-                for (int rt = ct; rt < TI; rt++, u++)
-                    accS[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(ha[rt], accG[ct][v], accS[u], 0, 0, 0);
+            for (int rt = 0; rt < TI; rt++)
+                if (rt >= ct) accS[rt] = __builtin_amdgcn_mfma_f64_16x16x4f64(ha[rt], accG[v], accS[rt], 0, 0, 0);     // (ct is wave-uniform)
         }
-        // the blocks' partial S meet in LDS (ds_add_f64 on the zeroed matrix; the order in which the waves arrive is not fixed: < 1 ulp of S)
-        int u = 0;
+        // the items' partial S meet in LDS (ds_add_f64 on the zeroed matrix; the order in which the waves arrive is not fixed: < 1 ulp of S)
 #pragma unroll
-        for (int ct = 0; ct < TI; ct++)
-#pragma unroll
-            for (int rt = ct; rt < TI; rt++, u++)
+        for (int rt = 0; rt < TI; rt++)
+            if (rt >= ct) {
 #pragma unroll
                 for (int q = 0; q < 4; q++) {
                     const int i = 16 * rt + kq + 4 * q, c = 16 * ct + cl;
-                    if (i < nr && c < nr && i >= c) unsafeAtomicAdd(&T[(size_t)c * Rs + i], accS[u][q]);
+                    if (i < nr && c < nr && i >= c) unsafeAtomicAdd(&T[(size_t)c * Rs + i], accS[rt][q]);
                 }
+            }
+    };
+    if constexpr (PIPE) {
+        constexpr int U = 20;
+        // element offsets of the K steps of THIS lane (they do not depend on the item): column a_k of P, k = 4 u + kq
+        int koff[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) koff[u] = acol[min(4 * u + kq, na - 1)] * n;
+        // The P values of an item's first U k-steps rotate through ONE register buffer: as soon as the MFMA of step u has read cur[u], the
+        // load of the NEXT item's step u is issued into it, so its HBM / L2 round trip hides behind the rest of this item (the remaining
+        // k-steps, the second product, the LDS atomics). Loaded item by item, every item exposed one full round trip.
+        double cur[U];
+        int it = wave;
+        if (it < n_items) {
+            const int aj = acol[min(16 * (it % nJ) + cl, na - 1)];             // row a_j of P(a, a): P(a_j, a_k) = P[a_k * n + a_j]
+#pragma unroll
+            for (int u = 0; u < U; u++) cur[u] = P[koff[u] + aj];              // (uniform base + 32-bit lane offset)
+        }
+        for (; it < n_items; it += stride) {
+            const int ct = it / nJ, J = it - ct * nJ;
+            const int itn = it + stride;
+            const bool has_next = itn < n_items;                               // (wave-uniform)
+            const int aj_next = acol[min(16 * ((has_next ? itn : it) % nJ) + cl, na - 1)];
+            const double *hb_base = Hs + (size_t)kq * nrp + 16 * ct + cl;      // B(k, c) = Hc(16 ct + c, k)
+            double4v accG = {0.0, 0.0, 0.0, 0.0};
+            // (branch-free bodies: k-steps beyond nk multiply by a zero B operand; one uniform branch picks the body with the prefetch)
+            if (has_next) {
+#pragma unroll
+                for (int u = 0; u < U; u++) {
+                    const double hb = hb_base[(size_t)(4 * min(u, nk - 1)) * nrp];
+                    accG = __builtin_amdgcn_mfma_f64_16x16x4f64(cur[u], u < nk ? hb : 0.0, accG, 0, 0, 0);
+                    cur[u] = P[koff[u] + aj_next];
+                }
+            } else {
+#pragma unroll
+                for (int u = 0; u < U; u++) {
+                    const double hb = hb_base[(size_t)(4 * min(u, nk - 1)) * nrp];
+                    accG = __builtin_amdgcn_mfma_f64_16x16x4f64(cur[u], u < nk ? hb : 0.0, accG, 0, 0, 0);
+                }
+            }
+            if (nk > U) {                                                      // long mono tracks: the remaining k-steps, loaded in line
+                const int aj = acol[min(16 * J + cl, na - 1)];
+                for (int s0 = U; s0 < nk; s0 += 8) {
+                    double av[8];
+#pragma unroll
+                    for (int u = 0; u < 8; u++) {
+                        const int s = s0 + u;
+                        const double x = P[acol[min(4 * s + kq, na - 1)] * n + aj];
+                        av[u] = s < nk ? x : 0.0;
+                    }
+#pragma unroll
+                    for (int u = 0; u < 8; u++)
+                        accG = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u], hb_base[(size_t)(4 * min(s0 + u, nk - 1)) * nrp], accG, 0, 0, 0);
+                }
+            }
+            finish_item(J, ct, accG);
+        }
+    } else {
+        constexpr int U = 10;
+        for (int it = wave; it < n_items; it += stride) {
+            const int ct = it / nJ, J = it - ct * nJ;
+            const int aj = acol[min(16 * J + cl, na - 1)];                     // row a_j of P(a, a): P(a_j, a_k) = P[a_k * n + a_j]
+            const double *hb_base = Hs + (size_t)kq * nrp + 16 * ct + cl;      // B(k, c) = Hc(16 ct + c, k)
+            double4v accG = {0.0, 0.0, 0.0, 0.0};
+            // k-steps in chunks of U, the next chunk's P values requested before this chunk's MFMAs; steps beyond nk read a clamped
+            // address and contribute zero
+            auto load_a = [&](double (&av)[U], int s0) {
+#pragma unroll
+                for (int u = 0; u < U; u++) {
+                    const int s = s0 + u;
+                    const double x = P[acol[min(4 * s + kq, na - 1)] * n + aj];
+                    av[u] = s < nk ? x : 0.0;
+                }
+            };
+            double a0[U], a1[U];
+            load_a(a0, 0);
+            for (int s0 = 0; s0 < nk; s0 += U) {
+                load_a(a1, min(s0 + U, nk));                                   // (past the end: zeros, never used)
+#pragma unroll
+                for (int u = 0; u < U; u++)
+                    accG = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[u], hb_base[(size_t)(4 * min(s0 + u, nk - 1)) * nrp], accG, 0, 0, 0);
+#pragma unroll
+                for (int u = 0; u < U; u++) a0[u] = a1[u];
+            }
+            finish_item(J, ct, accG);
+        }
     }
     __syncthreads();
+    GATE_STAMP(0);
     for (int i = t; i < nr; i += NT) T[(size_t)i * Rs + i] += rd;
     double *W = work, *col = work + 256, *red = work + 256 + 544;
     __syncthreads();
-    // blocked Cholesky of [S; v'] (ekf_update_kernel phase C restricted to the measurement rows)
+    // blocked Cholesky of [S; v'] (ekf_update_kernel phase C restricted to the measurement rows). The diagonal blocks are factored by ONE
+    // wave (a ~340-cycle dependent chain per pivot that keeps its SIMD's issue port about half busy): the workgroups that share a CU use
+    // different waves for it (wave w sits on SIMD w % 4; workgroups 256 apart in the grid land on the same CU in the first rounds), or
+    // their chains queue up on SIMD 0 while the other three idle.
+    const int chol_wave = __builtin_amdgcn_readfirstlane((int)((blockIdx.x >> 8) & 3u));
     const int Rlim = nr + 1;
     for (int j0 = 0; j0 < nr; j0 += 16) {
         const int w = min(16, nr - j0);
@@ -242,7 +315,7 @@ __device__ __forceinline__ double sparse_gate(const double *P, int n, const int 
             }
             __syncthreads();
         }
-        if (wave == 0) { if (w <= 8) factor_diag_block<8>(T, W, col, Rs, j0, w, lane); else factor_diag_block<16>(T, W, col, Rs, j0, w, lane); }
+        if (wave == chol_wave) { if (w <= 8) factor_diag_block<8>(T, W, col, Rs, j0, w, lane); else factor_diag_block<16>(T, W, col, Rs, j0, w, lane); }
         __syncthreads();
         for (int i0 = j0 + w + 16 * wave; i0 < Rlim; i0 += 16 * nwaves) {
             const int mi = Rlim - i0;
@@ -255,6 +328,7 @@ __device__ __forceinline__ double sparse_gate(const double *P, int n, const int 
         }
         __syncthreads();
     }
+    GATE_STAMP(1);
     double sz = 0;
     for (int c = t; c < nr; c += NT) { const double z = T[(size_t)c * Rs + nr]; sz += z * z; }
     for (int o = 32; o > 0; o >>= 1) sz += __shfl_down(sz, o);
@@ -263,7 +337,9 @@ __device__ __forceinline__ double sparse_gate(const double *P, int n, const int 
     double tot = 0;
 #pragma unroll
     for (int w2 = 0; w2 < nwaves; w2++) tot += red[w2];
+    GATE_STAMP(2);
     return tot * noise_scale;
+#undef GATE_STAMP
 }
 }  // namespace
 }  // namespace hv

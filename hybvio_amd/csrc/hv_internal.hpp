@@ -64,7 +64,7 @@ struct Knobs {
     int ekf_stream_gate = -1;     // HV_EKF_STREAM_GATE: -1 auto, 0 never, 1 also inside the visit loop
     int ekf_gate_kmode = -1;      // HV_EKF_GATE_KMODE: 1 = gate-only launches on the H-from-L2 update kernel
     int ingest_gather = 0;        // HV_INGEST_GATHER: 1 = plain gather kernel for the remap
-    int ekf_fused_gate = -1;      // HV_EKF_FUSED_GATE: -1 auto (column-sparse chi2 gate inside the prepare kernel where the shape allows), 0 off
+    int ekf_fused_gate = -1;      // HV_EKF_FUSED_GATE: column-sparse chi2 gate: -1 auto = 1 inside the prepare kernel, 2 own launch (ekf_sparse_gate_kernel), 0 off (dense kernels)
     int ekf_spec_mode = -1;       // HV_EKF_SPEC_MODE: speculative pass form: -1 auto, 2 = gate launch + apply launch, 3 = one launch with hand-shake
     int rot_ransac_threads = 0;   // HV_ROT_RANSAC_THREADS: 0 auto (1024 threads up to 64 sets), 256 / 1024 force
 };

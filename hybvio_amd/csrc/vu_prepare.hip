@@ -18,7 +18,7 @@
 
 namespace hv {
 // developer aid: s_memtime stamps of workgroup 0 at the phase boundaries (only with -DHV_EKF_PHASE_STAMPS)
-__device__ long long g_vu_stamp[32];
+__device__ long long g_vu_stamp[40];
 #ifdef HV_EKF_PHASE_STAMPS
 #define VU_STAMP(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_vu_stamp[i] = (long long)__builtin_readcyclecounter(); } while (0)
 #else
@@ -222,9 +222,11 @@ struct VuLds {
 // one workgroup per CU); <384, 22> holds the common sizes in 75 KB and 6 waves of 138 VGPRs, so TWO filters share a CU and one's
 // serial sections (pose records, 3 x 3 solves, barriers: most of the kernel since r02 took the column work off the critical path)
 // overlap the other's.
-// FUSED: the chi2 gate runs in this kernel on the compact Jacobian (VuPrepareArgs::fused, ekf_device.hpp sparse_gate): the dense H is
-// never written, only Hc / acol / v for the update of an inlier.
-template <int VT, int MAXP, bool FUSED>
+// FUSED (VuPrepareArgs::fused): 0 = the dense H of the public prepare entry point; 1 = compact Jacobian + the chi2 gate in this kernel
+// (ekf_device.hpp sparse_gate; few filters: one launch per visit / speculative pass); 2 = compact Jacobian only, the gate follows as
+// ekf_sparse_gate_kernel (many filters: three small workgroups per CU hide its Cholesky chain, which two of these cannot). In 1 and 2
+// the dense H is never written, only Hc / acol / v.
+template <int VT, int MAXP, int FUSED>
 __device__ __forceinline__ void vu_prepare_body(const VuPrepareArgs &a)
 {
     // All LDS comes from the dynamic region (carved below): with static arrays the compiler derives the occupancy from their size
@@ -775,7 +777,7 @@ __device__ __forceinline__ void vu_prepare_body(const VuPrepareArgs &a)
     __syncthreads();
     VU_STAMP(29);
     const int rows = 2 * nt;
-    if constexpr (FUSED) {
+    if constexpr (FUSED != 0) {
         // ---- prepareVisualUpdate in compact form + visualTrackOutlierCheck on the active columns (see VuPrepareArgs::fused) ----
         int prep = 0;
         for (int i = 0; i < nt && prep == 0; ++i) prep = (int)s_it[i * ITER_WORDS + 16];   // first failing pose decides (:920-927); uniform
@@ -792,10 +794,15 @@ __device__ __forceinline__ void vu_prepare_body(const VuPrepareArgs &a)
             }
             return;
         }
+        if (tid == 0) {                                           // what does not depend on the gate leaves now (nothing to keep in registers)
+            st_out[0] = HV_TRI_OK; st_out[1] = 0;
+            if (a.active) a.active[rec] = 1;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) a.pf[3 * rec + k] = pf_out[k];
+        }
         const int na = 7 * n + 1, na4 = (na + 3) & ~3, ti = (rows + 15) >> 4, nrp = 16 * ti;
         double *Hs = vu_lds + Lay::P0;
         int *s_acol = s_flag + 4;
-        for (int i = tid; i < na4 * nrp; i += VT) Hs[i] = 0.0;
         if (tid < na) {                                           // compact column u -> state column: pose q's position / orientation, then SFT
             int col = SFT;
             if (tid < 7 * n) {
@@ -804,32 +811,35 @@ __device__ __forceinline__ void vu_prepare_body(const VuPrepareArgs &a)
                 pos_ori(s_idx[q], ip, io);
                 col = comp < 3 ? ip + comp : io + comp - 3;
             }
-            s_acol[tid] = col;
+            s_acol[tid] = col;                                    // (read by the gate, after the barriers below)
             a.acol[rec * a.na_max + tid] = col;
         }
-        __syncthreads();
         double *Hc = a.Hc + rec * (size_t)rows_max * a.na_max;    // record stride: the longest track; leading dimension: this track's rows
-        const unsigned inv_nt_c = (unsigned)((0x100000000ull + (unsigned)nt - 1) / (unsigned)nt);
-        for (int w = tid; w < na * nt; w += VT) {                 // work item = (compact column u, camera pose i), i fastest
-            const int u = (int)__umulhi((unsigned)w, inv_nt_c), i = w - u * nt;
-            const double *o = s_it + i * ITER_WORDS;
+        // work item = (compact column u < na4, row pair i < nrp / 2), i fastest: every element of the staged Hs is written exactly once
+        // (zero padding in rows >= 2 nt and columns >= na), the real ones also go to HBM for the update of an inlier
+        const int hp = nrp >> 1, hp_shift = hp == 8 ? 3 : hp == 16 ? 4 : 0;       // nrp / 2 = 8, 16 or 24
+        for (int w = tid; w < na4 * hp; w += VT) {
+            const int u = hp_shift ? w >> hp_shift : w / 24, i = w - u * hp;
             double h0 = 0.0, h1 = 0.0;
-            if (u < 7 * n) {
-                const int k = u / 7, comp = u - 7 * k;
-                if (k == i % n) {                                                          // own pose: :946-953
-                    if (comp < 3) { h0 = -o[comp]; h1 = -o[3 + comp]; }
-                    else { h0 = o[6 + comp - 3]; h1 = o[10 + comp - 3]; }
+            if (u < na && i < nt) {
+                const double *o = s_it + i * ITER_WORDS;
+                if (u < 7 * n) {
+                    const int k = u / 7, comp = u - 7 * k;
+                    if (k == (i >= n ? i - n : i)) {                                       // own pose: :946-953
+                        if (comp < 3) { h0 = -o[comp]; h1 = -o[3 + comp]; }
+                        else { h0 = o[6 + comp - 3]; h1 = o[10 + comp - 3]; }
+                    }
+                    const double *dp = s_dpf + 21 * k + comp;                              // :955-964
+                    h0 += o[0] * dp[0] + o[1] * dp[7] + o[2] * dp[14];
+                    h1 += o[3] * dp[0] + o[4] * dp[7] + o[5] * dp[14];
+                } else if (a.est_shift) {                                                  // :965-967
+                    const double sft_t0 = s_dpfi[dDim], sft_t1 = s_dpfi[ncol + dDim], sft_t2 = s_dpfi[2 * ncol + dDim];
+                    h0 = o[0] * sft_t0 + o[1] * sft_t1 + o[2] * sft_t2 - s_feat[4 * i + 2];
+                    h1 = o[3] * sft_t0 + o[4] * sft_t1 + o[5] * sft_t2 - s_feat[4 * i + 3];
                 }
-                const double *dp = s_dpf + 21 * k + comp;                                  // :955-964
-                h0 += o[0] * dp[0] + o[1] * dp[7] + o[2] * dp[14];
-                h1 += o[3] * dp[0] + o[4] * dp[7] + o[5] * dp[14];
-            } else if (a.est_shift) {                                                      // :965-967
-                const double t0 = s_dpfi[dDim], t1 = s_dpfi[ncol + dDim], t2 = s_dpfi[2 * ncol + dDim];
-                h0 = o[0] * t0 + o[1] * t1 + o[2] * t2 - s_feat[4 * i + 2];
-                h1 = o[3] * t0 + o[4] * t1 + o[5] * t2 - s_feat[4 * i + 3];
+                *reinterpret_cast<double2 *>(Hc + (size_t)u * rows + 2 * i) = double2{h0, h1};
             }
-            *reinterpret_cast<double2 *>(Hs + (size_t)u * nrp + 2 * i) = double2{h0, h1};
-            *reinterpret_cast<double2 *>(Hc + (size_t)u * rows + 2 * i) = double2{h0, h1};
+            if constexpr (FUSED == 1) *reinterpret_cast<double2 *>(Hs + (size_t)u * nrp + 2 * i) = double2{h0, h1};
         }
         double vres[2] = {0.0, 0.0};
         if (tid < nt) {
@@ -842,28 +852,33 @@ __device__ __forceinline__ void vu_prepare_body(const VuPrepareArgs &a)
                 a.v[e] = vres[r];
             }
         }
+        if constexpr (FUSED == 2) {                               // the gate is the next launch: this track is "prepared, not gated yet"
+            if (tid == 0) {
+                if (a.gate_status) a.gate_status[rec] = 1;        // VuOutlierStatus::NOT_COMPUTED until ekf_sparse_gate_kernel has run
+                if (a.spec_tracks > 0) a.epoch[rec] = a.success_counter[b];
+            }
+            return;
+        }
         __syncthreads();                                          // everything but Hs / s_acol is dead from here on
+        VU_STAMP(31);
         double *T = vu_lds;
         int Rs = rows + 1;
         while ((Rs & 31) != 15 && (Rs & 31) != 17) Rs++;
         for (int i = tid; i < Rs * rows; i += VT) T[i] = 0.0;
         __syncthreads();
         if (tid < nt) { T[(size_t)(2 * tid) * Rs + rows] = vres[0]; T[(size_t)(2 * tid + 1) * Rs + rows] = vres[1]; }
+        VU_STAMP(32);
         const double *Pb = a.P + (size_t)b * N * N;
         double chi;
-        if (ti == 1)      chi = sparse_gate<1, VT>(Pb, N, s_acol, na, Hs, T, Rs, rows, a.rd_gate, a.noise_scale, Hs);
-        else if (ti == 2) chi = sparse_gate<2, VT>(Pb, N, s_acol, na, Hs, T, Rs, rows, a.rd_gate, a.noise_scale, Hs);
-        else              chi = sparse_gate<3, VT>(Pb, N, s_acol, na, Hs, T, Rs, rows, a.rd_gate, a.noise_scale, Hs);
+        if (ti == 1)      chi = sparse_gate<1, VT, false>(Pb, N, s_acol, na, Hs, T, Rs, rows, a.rd_gate, a.noise_scale, Hs, g_vu_stamp + 33);
+        else if (ti == 2) chi = sparse_gate<2, VT, false>(Pb, N, s_acol, na, Hs, T, Rs, rows, a.rd_gate, a.noise_scale, Hs, g_vu_stamp + 33);
+        else              chi = sparse_gate<3, VT, false>(Pb, N, s_acol, na, Hs, T, Rs, rows, a.rd_gate, a.noise_scale, Hs, g_vu_stamp + 33);
         if (tid == 0) {
             const bool broken = !(chi < 1e300);                   // non-positive pivot: reported as CHI2 (ekf_update_kernel phase D)
             const int outlier = broken || ((rows < HV_CHI2INV95_N) ? (chi > d_chi2inv95[rows]) : 0);
-            st_out[0] = HV_TRI_OK; st_out[1] = 0;
-            if (a.active) a.active[rec] = 1;
             if (a.gate_status) a.gate_status[rec] = outlier ? 3 /*CHI2*/ : 0 /*INLIER*/;
             if (a.chi2) a.chi2[rec] = chi;
             if (a.spec_tracks > 0) a.epoch[rec] = a.success_counter[b];
-#pragma unroll
-            for (int k = 0; k < 3; ++k) a.pf[3 * rec + k] = pf_out[k];
         }
         return;
     }
@@ -929,17 +944,23 @@ __device__ __forceinline__ void vu_prepare_body(const VuPrepareArgs &a)
     }
 }
 
-__global__ __launch_bounds__(VT_LATENCY, 3) void vu_prepare_kernel(VuPrepareArgs a) { vu_prepare_body<VT_LATENCY, MAXP_ALL, false>(a); }
+__global__ __launch_bounds__(VT_LATENCY, 3) void vu_prepare_kernel(VuPrepareArgs a) { vu_prepare_body<VT_LATENCY, MAXP_ALL, 0>(a); }
 // 4 waves per SIMD = 128 VGPRs: two workgroups of 6 waves may put 4 waves on one SIMD (512 VGPRs per lane there)
 __global__ __launch_bounds__(VT_THROUGHPUT, 4) void vu_prepare_kernel_2percu(VuPrepareArgs a)
 {
-    vu_prepare_body<VT_THROUGHPUT, MAXP_SMALL, false>(a);
+    vu_prepare_body<VT_THROUGHPUT, MAXP_SMALL, 0>(a);
 }
 // the same two builds with the column-sparse chi2 gate fused in (VuPrepareArgs::fused)
-__global__ __launch_bounds__(VT_LATENCY, 3) void vu_gate_kernel(VuPrepareArgs a) { vu_prepare_body<VT_LATENCY, MAXP_ALL, true>(a); }
+__global__ __launch_bounds__(VT_LATENCY, 3) void vu_gate_kernel(VuPrepareArgs a) { vu_prepare_body<VT_LATENCY, MAXP_ALL, 1>(a); }
 __global__ __launch_bounds__(VT_THROUGHPUT, 4) void vu_gate_kernel_2percu(VuPrepareArgs a)
 {
-    vu_prepare_body<VT_THROUGHPUT, MAXP_SMALL, true>(a);
+    vu_prepare_body<VT_THROUGHPUT, MAXP_SMALL, 1>(a);
+}
+// ... and with the compact Jacobian only (the gate runs as its own launch)
+__global__ __launch_bounds__(VT_LATENCY, 3) void vu_compact_kernel(VuPrepareArgs a) { vu_prepare_body<VT_LATENCY, MAXP_ALL, 2>(a); }
+__global__ __launch_bounds__(VT_THROUGHPUT, 4) void vu_compact_kernel_2percu(VuPrepareArgs a)
+{
+    vu_prepare_body<VT_THROUGHPUT, MAXP_SMALL, 2>(a);
 }
 
 }  // namespace
@@ -976,7 +997,7 @@ int launch_vu_prepare(Ctx *c, const VuPrepareArgs &a)
     const int nt = a.np * (a.stereo ? 2 : 1);
     // knob vu_threads (tests / experiments): 384 / 768 forces a build where it applies
     const bool small = vu_small_build(c, nt, a.batch);
-    if (a.fused && (!vu_fused_supported(c, a.n, a.np, a.stereo, a.batch) || !a.Hc || !a.acol || !a.P || a.na_max < 7 * a.np + 1)) return HV_ERR_INVALID;
+    if (a.fused && (!vu_fused_supported(c, a.n, a.np, a.stereo, a.batch) || !a.Hc || !a.acol || (a.fused == 1 && !a.P) || a.na_max < 7 * a.np + 1)) return HV_ERR_INVALID;
     static bool attr_set_dev[64] = {};                       // per device: the kernels need more than the default 64 KB of dynamic LDS
     bool &attr_set = attr_set_dev[c->p.device & 63];
     if (!attr_set) {
@@ -984,10 +1005,15 @@ int launch_vu_prepare(Ctx *c, const VuPrepareArgs &a)
         HV_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void *>(vu_prepare_kernel_2percu), hipFuncAttributeMaxDynamicSharedMemorySize, (int)VuLds<MAXP_SMALL>::BYTES));
         HV_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void *>(vu_gate_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)VuLds<MAXP_ALL>::BYTES));
         HV_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void *>(vu_gate_kernel_2percu), hipFuncAttributeMaxDynamicSharedMemorySize, (int)VuLds<MAXP_SMALL>::BYTES));
+        HV_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void *>(vu_compact_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)VuLds<MAXP_ALL>::BYTES));
+        HV_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void *>(vu_compact_kernel_2percu), hipFuncAttributeMaxDynamicSharedMemorySize, (int)VuLds<MAXP_SMALL>::BYTES));
         attr_set = true;
     }
     const dim3 grid((unsigned)a.batch, (unsigned)(a.spec_tracks > 0 ? a.spec_tracks : 1));
-    if (a.fused) {
+    if (a.fused == 2) {
+        if (small) hipLaunchKernelGGL(vu_compact_kernel_2percu, grid, dim3(VT_THROUGHPUT), VuLds<MAXP_SMALL>::BYTES, c->stream, a);
+        else       hipLaunchKernelGGL(vu_compact_kernel, grid, dim3(VT_LATENCY), VuLds<MAXP_ALL>::BYTES, c->stream, a);
+    } else if (a.fused) {
         if (small) hipLaunchKernelGGL(vu_gate_kernel_2percu, grid, dim3(VT_THROUGHPUT), VuLds<MAXP_SMALL>::BYTES, c->stream, a);
         else       hipLaunchKernelGGL(vu_gate_kernel, grid, dim3(VT_LATENCY), VuLds<MAXP_ALL>::BYTES, c->stream, a);
     } else {
@@ -1000,11 +1026,11 @@ int launch_vu_prepare(Ctx *c, const VuPrepareArgs &a)
 
 }  // namespace hv
 
-extern "C" int hv_debug_vu_phase_stamps(hv_ctx *ctx, long long *out32)
+extern "C" int hv_debug_vu_phase_stamps(hv_ctx *ctx, long long *out32 /* [40] */)
 {
     hv::Ctx *c = hv::ctx_of(ctx);
     if (!c || !out32) return HV_ERR_INVALID;
     HV_HIP(c, hipStreamSynchronize(c->stream));
-    HV_HIP(c, hipMemcpyFromSymbol(out32, HIP_SYMBOL(hv::g_vu_stamp), sizeof(long long) * 32));
+    HV_HIP(c, hipMemcpyFromSymbol(out32, HIP_SYMBOL(hv::g_vu_stamp), sizeof(long long) * 40));
     return HV_OK;
 }

@@ -13,7 +13,7 @@ for path in glob.glob(sys.argv[1] + "/**/*counter_collection.csv", recursive=Tru
     with open(path) as f:
         for r in csv.DictReader(f):
             name = r["Kernel_Name"]
-            m = re.search(r"(klt_kernel|pyr_level_kernel<\w+>|pyr_down_l0_kernel|pyr_tail_kernel|pyr_border_kernel|ekf_\w+?_kernel|vu_prepare_kernel|gftt_\w+?_kernel|rot_ransac_kernel)", name)
+            m = re.search(r"(klt_kernel|pyr_level_kernel<\w+>|pyr_down_l0_kernel|pyr_tail_kernel|pyr_border_kernel|ekf_\w+?_kernel|vu_\w+?_kernel(?:_2percu)?|gftt_\w+?_kernel|rot_ransac_kernel)", name)
             grid = r.get("Grid_Size", r.get("Grid_Size_X", "?"))
             k = (m.group(1) if m else name[:48].replace(",", ";"), grid, r["Counter_Name"])
             acc[k][0] += float(r["Counter_Value"])

@@ -53,7 +53,7 @@ def main():
               f"({ms / cnt / B * 1e6:.1f} ns per track at this batch), {ok}/{B} tracks OK")
         if os.environ.get("HV_EKF_PHASE_STAMPS") == "1":
             import ctypes as C
-            st32 = (C.c_longlong * 32)()
+            st32 = (C.c_longlong * 40)()
             capi.lib().hv_debug_vu_phase_stamps.argtypes = [C.c_void_p, C.POINTER(C.c_longlong)]
             capi.lib().hv_debug_vu_phase_stamps(ctx._h, st32)
             s_ = list(st32)
@@ -61,13 +61,31 @@ def main():
                   "iters [pose, (wait), columns, update]:", [[s_[4 + 4 * k] - s_[3 + 4 * k], s_[5 + 4 * k] - s_[4 + 4 * k], s_[6 + 4 * k] - s_[5 + 4 * k],
                                                              (s_[7 + 4 * k] if k < 5 else s_[27]) - s_[6 + 4 * k]] for k in range(6) if s_[6 + 4 * k] > s_[3 + 4 * k] > 0],
                   "final", s_[28] - s_[27], "prep-pose", s_[29] - s_[28], "H", s_[30] - s_[29], "total", s_[30] - s_[0])
-        torch.cuda.synchronize(); t0 = time.perf_counter()
-        for _ in range(20):
-            g.visual_track_dev(vp, npose, d_idx.data_ptr(), d_feat.data_ptr(), d_vel.data_ptr(), d_y.data_ptr(), 1.5, 0.05,
-                               st.data_ptr(), gs.data_ptr(), 0, pf.data_ptr())
-        torch.cuda.synchronize()
-        print(f"visual_track_dev (prepare + gate + update): {(time.perf_counter() - t0) / 20 * 1e6:.1f} us per call, "
-              f"gate inliers {int((gs.cpu().numpy() == 0).sum())}/{B}")
+        # the fused prepare + column-sparse gate kernel and the update of the inliers (r03 default); y_out rejects every track, so the
+        # update launch is a skip launch and the vu_prepare timer class shows the fused kernel alone
+        for name, yy in (("all rejected", dev(y + 3.0, np.float64)), ("all inliers", d_y)):
+            for _ in range(3):
+                g.visual_track_dev(vp, npose, d_idx.data_ptr(), d_feat.data_ptr(), d_vel.data_ptr(), yy.data_ptr(), 1.5, 0.05,
+                                   st.data_ptr(), gs.data_ptr(), 0, pf.data_ptr())
+            ctx.profile_enable(True); ctx.profile_reset()
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            for _ in range(20):
+                g.visual_track_dev(vp, npose, d_idx.data_ptr(), d_feat.data_ptr(), d_vel.data_ptr(), yy.data_ptr(), 1.5, 0.05,
+                                   st.data_ptr(), gs.data_ptr(), 0, pf.data_ptr())
+            torch.cuda.synchronize()
+            wall = (time.perf_counter() - t0) / 20 * 1e6
+            ms1, c1 = ctx.profile_read(capi.K_VU_PREPARE); ms2, c2 = ctx.profile_read(capi.K_EKF_UPDATE); ms3, c3 = ctx.profile_read(capi.K_EKF_GATE)
+            ctx.profile_enable(False)
+            print(f"visual_track_dev ({name}): {wall:.1f} us per call; prepare(+gate) kernel {ms1 / c1 * 1e3:.1f} us, sparse gate kernel {ms3 / max(c3, 1) * 1e3:.1f} us, update launch {ms2 / c2 * 1e3:.1f} us; "
+                  f"gate inliers {int((gs.cpu().numpy() == 0).sum())}/{B}")
+            if os.environ.get("HV_EKF_PHASE_STAMPS") == "1" and name == "all rejected":
+                import ctypes as C
+                st40 = (C.c_longlong * 40)()
+                capi.lib().hv_debug_vu_phase_stamps.argtypes = [C.c_void_p, C.POINTER(C.c_longlong)]
+                capi.lib().hv_debug_vu_phase_stamps(ctx._h, st40)
+                s_ = list(st40)
+                print("fused kernel phase cycles: up to prepare-pose", s_[29] - s_[0], "compact H + v", s_[31] - s_[29], "zero T", s_[32] - s_[31],
+                      "gather + products", s_[33] - s_[32], "Cholesky", s_[34] - s_[33], "chi2", s_[35] - s_[34], "total", s_[35] - s_[0])
         g.close()
 
 

@@ -20,6 +20,9 @@ VARIANTS = {
     "vu384": {"vu_threads": 384},
     "vu768": {"vu_threads": 768},
     "dense": {"ekf_fused_gate": 0},
+    "gate_in_prepare": {"ekf_fused_gate": 1, "vu_threads": 384},     # vu_gate_kernel_2percu (what more than 256 filters run by default)
+    "gate_own_launch": {"ekf_fused_gate": 2},                        # vu_compact_kernel + ekf_sparse_gate_kernel
+    "gate_own_launch_vu384": {"ekf_fused_gate": 2, "vu_threads": 384},
     "dense_vu384": {"ekf_fused_gate": 0, "vu_threads": 384},
     "spec3": {"ekf_spec_mode": 3},
     "split": {"ekf_spec_split": 1},
@@ -234,7 +237,7 @@ def test_parameters_reach_the_kernel(oracle):
             assert 5 in statuses                                                        # BAD_DEPTH
 
 
-@pytest.mark.parametrize("variant", ["default", "vu384", "dense", "dense_vu384"])
+@pytest.mark.parametrize("variant", ["default", "vu384", "dense", "dense_vu384", "gate_in_prepare", "gate_own_launch", "gate_own_launch_vu384"])
 def test_visual_track_dev_prepare_gate_update_equals_the_reference_sequence(oracle, variant):
     """hv_ekf_visual_track_dev = backend.cpp:1063-1185 for one track per filter: prepare from the device mean, gate with
     trackChiTestOutlierR, update with visualR only where triangulation, prepare and gate pass. Filters that fail stay
@@ -295,7 +298,7 @@ def test_visual_track_dev_prepare_gate_update_equals_the_reference_sequence(orac
         g.close()
 
 
-@pytest.mark.parametrize("variant", ["default", "vu384", "dense"])
+@pytest.mark.parametrize("variant", ["default", "vu384", "dense", "gate_own_launch_vu384"])
 def test_frame_loop_with_the_successful_update_quota(oracle, variant):
     """A frame's visual-update loop for a batch (backend.cpp:1012-1240): K tracks per filter, visited in order, each seeing the
     mean the previous one left; a filter stops being visited once maxSuccessfulVisualUpdates updates were applied."""
@@ -361,7 +364,8 @@ def test_frame_loop_with_the_successful_update_quota(oracle, variant):
 
 
 @pytest.mark.parametrize("B,speculative,variant", [(12, True, "default"), (12, True, "spec2_vu384"), (12, True, "spec3"), (12, True, "split"),
-                                                   (40, False, "default"), (40, False, "vu384"), (40, False, "dense"), (40, False, "dense_vu384")])
+                                                   (40, False, "default"), (40, False, "vu384"), (40, False, "dense"), (40, False, "dense_vu384"),
+                                                   (40, False, "gate_own_launch"), (40, False, "gate_own_launch_vu384"), (40, False, "gate_in_prepare")])
 def test_whole_frame_loop_in_one_call(oracle, B, speculative, variant):
     """hv_ekf_visual_frame_dev = the frame's visit loop in ONE call. For few sequences (B * K <= 256) it runs speculatively: every
     pending track prepared and gated in parallel, the first inlier applied, the rest re-examined (<= quota + 1 passes); for more it
@@ -427,7 +431,8 @@ def test_whole_frame_loop_in_one_call(oracle, B, speculative, variant):
 
 @pytest.mark.parametrize("B,speculative,stereo,variant", [(10, True, True, "default"), (48, False, True, "default"), (9, True, False, "default"),
                                                           (10, True, True, "spec3"), (48, False, True, "vu384"), (48, False, True, "dense"),
-                                                          (9, True, False, "spec2_vu384"), (48, False, False, "vu384")])
+                                                          (9, True, False, "spec2_vu384"), (48, False, False, "vu384"),
+                                                          (48, False, True, "gate_own_launch_vu384"), (48, False, False, "gate_own_launch")])
 def test_whole_frame_loop_with_ragged_track_lengths(oracle, B, speculative, stereo, variant):
     """hv_ekf_visual_frame_ragged_dev: the sequences of a batch do not share track lengths -- every (visit, filter) record has its own
     pose count (2 .. n_poses_max, 0 = this filter has no candidate at this visit), padded to the longest. Result = the reference's
