@@ -71,7 +71,7 @@ def crop_offsets(B, seed, M=32):
 class TrackerBench:
     """B sequences x (2 pyramid builds + 2 LK calls) per step, everything device resident."""
 
-    def __init__(self, B, device, seed=0, chain=False):
+    def __init__(self, B, device, seed=0, chain=False, predicted_flow=True):
         import torch
         from hybvio_amd import capi, synth
         self.torch, self.B, self.chain = torch, B, chain
@@ -113,6 +113,11 @@ class TrackerBench:
         self.err = torch.zeros(B * NPTS, dtype=torch.float32, device=dev)
         self.k = 0
         self.tracked = torch.ones(B * NPTS, dtype=torch.bool, device=dev)
+        # predictOpticalFlow (parameter_definitions.c:207, tracker.cpp:58-61): the temporal call starts every track at a PREDICTED position
+        # (OPTFLOW_USE_INITIAL_FLOW). The reference predicts from the odometry poses; the stand-in is the track's flow of the previous frame
+        # (zero for a re-seeded track). predicted_flow=False keeps r02's zero-flow start (c3_uniform).
+        self.predicted_flow = predicted_flow
+        self.flow = torch.zeros((B * NPTS, 2), dtype=torch.float32, device=dev)
         if chain:
             self.enable_chain(seed)
         self._build(0)                                                          # frame 0 primes "prev"
@@ -150,6 +155,9 @@ class TrackerBench:
         if self.chain:
             ok = ok & (self.rst.reshape(-1) != 3)                                # RANSAC_OUTLIER (rot_ransac.cpp:110-118)
         self.tracked = ok
+        if self.predicted_flow:
+            t.sub(self.cur_left, self.pts_left, out=self.flow)
+            self.flow.mul_(ok[:, None])
         t.where(ok[:, None], self.cur_left, self.grid, out=self.pts_left)
         t.where(ok, self.cur_left[:, 0] - self.cur_right[:, 0], self.disp0, out=self.dispvec[:, 0])
 
@@ -171,9 +179,10 @@ class TrackerBench:
         if self.pending and self.overlap:
             main.wait_event(self.ev_book)
         prev, cur = self.L[(k - 1) % 2], self.L[k % 2]
-        # zero-flow prediction: use_initial_flow = 0 starts every track at its previous position
+        if self.predicted_flow:
+            t.add(self.pts_left, self.flow, out=self.cur_left)                   # in / out: the initial guess of every track
         self.ctx.klt_track_batch_dev(B, prev.data_ptr(), cur.data_ptr(), NPTS, self.pts_left.data_ptr(),
-                                     self.cur_left.data_ptr(), self.st1.data_ptr(), 0, False)   # err unused, as in HybVIO
+                                     self.cur_left.data_ptr(), self.st1.data_ptr(), 0, self.predicted_flow)   # err unused, as in HybVIO
         if self.chain:
             self.rst.zero_()
             self.ctx.rot_ransac_lk_batch_dev(B, NPTS, self.npts_dev.data_ptr(), self.pts_left.data_ptr(), self.cur_left.data_ptr(),
@@ -281,6 +290,48 @@ def make_visual_frame(rng, B, distinct=32):
     return (T1, T2, np.concatenate([means] * rep)[:B], tile(np.stack(idx)), tile(np.stack(feat)), tile(np.stack(vel)), tile(np.stack(y)))
 
 
+def sample_track_lengths(rng, size):
+    """Poses of a VISITED track in the reference's steady state, derived from its own selection logic (no dataset is available here):
+    every frame adds one unused observation to each of the ~200 tracks; Session::trackerVisualUpdate only considers the half of the
+    tracks with the higher score = more unused poses (scoreVisualUpdateTracks, backend.cpp:976-992,1021-1025, trackMinFrames 4) and
+    visits at most maxVisualUpdates = 20 of them per frame in shuffled order (:960-963,1233-1238); a visited track leaves the pool --
+    all its observations marked used after a success (ekf_state_index.cpp:161-169), deleted after a failure (blacklistTracks,
+    backend.cpp:1194-1206) -- and ~20 fresh ones enter at age 0. Equilibrium: ~20 tracks per age up to the median age of 5, above it
+    20 of ~100 eligible tracks are picked per frame, i.e. the cohorts shrink by 0.8 per frame: unused poses = 5 + Geometric(0.2),
+    capped by the trail (cameraTrailLength + 1 = 21): mean 8.9 poses, 21 % of the visits see more than 11 poses (> 44 rows in
+    stereo), 3 % the full trail. TrackSampling::GAP adds the oldest pose that holds the track (ekf_state_index.cpp:98-115): the
+    returned count includes it."""
+    return np.minimum(5 + rng.geometric(0.2, size) - 1, 21).astype(np.int32)
+
+
+def make_visual_frame_realistic(rng, B, distinct=64, p_inlier=0.25):
+    """Like make_visual_frame, but with what the judge of r02 asked for: every (visit, filter) track has its own
+    length drawn from sample_track_lengths (stereo: 20 .. 84 rows), uses the pose set GAP sampling returns (the newest poses + an older
+    one), and every (visit, filter) pair is an inlier with probability p_inlier independently -- so the filters of one launch are a mix
+    of gate rejections, updates and filters that already used up their quota of 5. Padded to the longest track for the ragged API
+    (hv_ekf_visual_frame_ragged_dev). Returns (T1, T2, means, lens [V][B], idx, feat, vel, y)."""
+    from hybvio_amd import synth
+    d, np_max = min(B, distinct), 21
+    T1, T2, means, _, _ = synth.visual_tracks(rng, d, 20, NPOSE, True, noise=1e-4)
+    lens = sample_track_lengths(rng, (VISITS, d))
+    idx = np.zeros((VISITS, d, np_max), np.int32); feat = np.zeros((VISITS, d, 2 * np_max, 2)); vel = np.zeros_like(feat)
+    y = np.zeros((VISITS, d, 4 * np_max))
+    inlier = rng.uniform(size=(VISITS, d)) < p_inlier
+    for k in range(VISITS):
+        for n in sorted(set(lens[k].tolist())):
+            sel = np.nonzero(lens[k] == n)[0]
+            _, _, _, i_, f_ = synth.visual_tracks(rng, len(sel), 20, n, True, given_means=means[sel], noise=1e-4, recent=True)
+            for j, b in enumerate(sel):
+                yy = f_[j].reshape(-1) + 1e-4 * rng.normal(size=f_[j].size)
+                if not inlier[k, b]:
+                    yy = yy + 0.05 * rng.choice([-1.0, 1.0], size=yy.shape)       # gross error (~23 px): rejected by the chi2 gate
+                idx[k, b, :n] = i_[j]; feat[k, b, :2 * n] = f_[j]; vel[k, b, :2 * n] = rng.normal(size=f_[j].shape) * 0.1
+                y[k, b, :4 * n] = yy
+    rep = (B + d - 1) // d
+    tile = lambda a: np.concatenate([a] * rep, axis=1)[:, :B]
+    return T1, T2, np.concatenate([means] * rep)[:B], tile(lens), tile(idx), tile(feat), tile(vel), tile(y)
+
+
 class _DevView:                                     # zero-copy torch view of the library's device buffers
     def __init__(self, ptr, shape):
         self.__cuda_array_interface__ = {"shape": shape, "typestr": "<f8", "data": (ptr, False), "version": 2}
@@ -293,13 +344,20 @@ class VisualEkfBench:
     The filters are put back to the same trail state at the start of every step (device copy, inside the timed region) so that
     the synthetic tracks stay geometrically consistent with the means frame after frame."""
 
-    def __init__(self, ctx, B, device, seed=0):
+    def __init__(self, ctx, B, device, seed=0, realistic=True):
         import torch
         from hybvio_amd import capi
         self.torch, self.B, self.ctx = torch, B, ctx
         dev = torch.device("cuda", device)
         rng = np.random.default_rng(300 + seed)
-        T1, T2, means, idx, feat, vel, y = make_visual_frame(rng, B)
+        self.realistic, self.lens = realistic, None
+        if realistic:
+            T1, T2, means, lens, idx, feat, vel, y = make_visual_frame_realistic(rng, B)
+            self.lens_host = lens
+            self.lens = torch.from_numpy(np.ascontiguousarray(lens)).to(dev)
+        else:
+            T1, T2, means, idx, feat, vel, y = make_visual_frame(rng, B)
+        self.host_inputs = (T1, T2, means, idx, feat, vel, y)
         self.vp = capi.vu_default_params(imu_to_camera=T1, second_imu_to_camera=T2)
         self.ekf = capi.EkfBatch(ctx, capi.ekf_default_params(cameraTrailLength=20), B)
         _, P = self.ekf.get_state(0)
@@ -312,8 +370,10 @@ class VisualEkfBench:
         self.gs = torch.zeros((VISITS, B), dtype=torch.int32, device=dev)
         self.counter = torch.zeros((B,), dtype=torch.int32, device=dev)
         self.dtn = torch.full((EKF_PREDICTS, B), 0.005, dtype=torch.float64, device=dev)
-        self.gyro = torch.from_numpy(rng.normal(0, 0.05, (EKF_PREDICTS, B, 3))).to(dev)
-        self.acc = torch.from_numpy(rng.normal(0, 0.05, (EKF_PREDICTS, B, 3)) + [0.0, 0.0, 9.819]).to(dev)
+        self.gyro_host = rng.normal(0, 0.05, (EKF_PREDICTS, B, 3))
+        self.acc_host = rng.normal(0, 0.05, (EKF_PREDICTS, B, 3)) + [0.0, 0.0, 9.819]
+        self.gyro, self.acc = torch.from_numpy(self.gyro_host).to(dev), torch.from_numpy(self.acc_host).to(dev)
+        self.P0_host = P
         self.drop = [torch.full((B,), h, dtype=torch.int32, device=dev) for h in HANOI]
         self.views = {}
         self.k = 0
@@ -333,13 +393,111 @@ class VisualEkfBench:
         mv, Pv = self._views()
         mv.copy_(self.m0); Pv.copy_(self.P0)
         e = self.ekf
-        e.visual_frame_dev(self.vp, VISITS, NPOSE, self.idx.data_ptr(), self.feat.data_ptr(), self.vel.data_ptr(), self.y.data_ptr(),
-                           R_GATE, R_UPDATE, self.st.data_ptr(), self.gs.data_ptr(), self.counter.data_ptr(), QUOTA)
+        if self.realistic:
+            e.visual_frame_ragged_dev(self.vp, VISITS, 21, self.lens.data_ptr(), self.idx.data_ptr(), self.feat.data_ptr(), self.vel.data_ptr(),
+                                      self.y.data_ptr(), R_GATE, R_UPDATE, self.st.data_ptr(), self.gs.data_ptr(), self.counter.data_ptr(), QUOTA)
+        else:
+            e.visual_frame_dev(self.vp, VISITS, NPOSE, self.idx.data_ptr(), self.feat.data_ptr(), self.vel.data_ptr(), self.y.data_ptr(),
+                               R_GATE, R_UPDATE, self.st.data_ptr(), self.gs.data_ptr(), self.counter.data_ptr(), QUOTA)
         self.applied += self.counter.sum()
         e.symmetrize()
+        self.last_drop = HANOI[self.k % len(HANOI)]
         e.augment_dev(self.drop[self.k % len(HANOI)].data_ptr())
         e.predict_n_dev(EKF_PREDICTS, self.dtn.data_ptr(), self.gyro.data_ptr(), self.acc.data_ptr())
         self.k += 1
+
+
+def verify_c3(tb, eb, n_check, seed=0):
+    """Parity of the benchmarked configuration itself, OUTSIDE the timed region: one more C3 step is run, then
+    n_check of the B resident sequences are re-computed by the CPU oracle from the same inputs (the oracle is the checker here, never
+    the thing measured): the tracker half must be bit-identical (LK statuses and positions, RANSAC statuses and rotation, GFTT key
+    points), the EKF half must give the same visit statuses and (m, P) within the north-star tolerance after the whole frame
+    (20 ragged visits from the device mean, symmetrise, augmentation, 10 predicts). Reference chain: optical_flow.cpp:46-49,
+    rot_ransac.cpp:41-120, feature_detector.cpp:279-315, backend.cpp:1012-1252, ekf.cpp:320-514,787-885."""
+    import torch
+    from oracle import orc
+    t = torch
+    tb.step(); eb.step()
+    t.cuda.synchronize()
+    B, k = tb.B, tb.k - 1
+    rng = np.random.default_rng(seed)
+    pick = sorted(rng.choice(B, size=min(n_check, B), replace=False).tolist())
+    res = {"parity_checked_sequences": len(pick), "sequences": pick, "frame": k,
+           "lk_status_mismatches": 0, "lk_max_abs_dxy_px": 0.0, "lk_points_compared": 0, "ransac_status_mismatches": 0, "ransac_R_bit_mismatches": 0,
+           "gftt_keypoint_mismatches": 0 if k % 2 == 0 else None, "ekf_visit_status_mismatches": 0, "ekf_visits_compared": 0,
+           "ekf_rel_err_m": 0.0, "ekf_rel_err_P": 0.0, "ekf_updates_applied": 0, "ekf_gate_rejections": 0}
+    fr_prev, fr_cur = tb.frames[(k - 1) % N_CYCLE], tb.frames[k % N_CYCLE]
+    pts = tb.pts_left.reshape(B, NPTS, 2); cur = tb.cur_left.reshape(B, NPTS, 2); curR = tb.cur_right.reshape(B, NPTS, 2)
+    flow = tb.flow.reshape(B, NPTS, 2); disp = tb.dispvec.reshape(B, NPTS, 2)
+    st1, st2 = tb.st1.reshape(B, NPTS), tb.st2.reshape(B, NPTS)
+    ocam = orc.Camera("pinhole", 458.654, 457.296, 367.215, 248.375, coeffs=[-0.28340811, 0.07395907, 0.0])
+    T1, T2, means, idx, feat, vel, y = eb.host_inputs
+    par = orc.tri_default_params()
+    for s_ in pick:
+        # ---- tracker half ----
+        lp, lc, rc = (orc.Pyramid(fr_prev[0, s_].cpu().numpy()), orc.Pyramid(fr_cur[0, s_].cpu().numpy()), orc.Pyramid(fr_cur[1, s_].cpu().numpy()))
+        p0 = pts[s_].cpu().numpy()
+        guess = (pts[s_] + flow[s_]).cpu().numpy() if tb.predicted_flow else None
+        oxy, ost, _ = orc.klt_track(lp, lc, p0, next_pts=guess)
+        g_xy, g_st = cur[s_].cpu().numpy(), st1[s_].cpu().numpy()
+        res["lk_status_mismatches"] += int((g_st != ost).sum())
+        keep = (ost == 1) & (g_st == 1)
+        res["lk_points_compared"] += int(keep.sum())
+        if keep.any():
+            res["lk_max_abs_dxy_px"] = max(res["lk_max_abs_dxy_px"], float(np.abs(g_xy[keep] - oxy[keep]).max()))
+        trk = np.flatnonzero(g_st == 1)
+        if len(trk) >= 2:
+            draws = tb.draws[k % N_CYCLE][s_].cpu().numpy().view(np.uint32)
+            rs, oR, _, _ = orc.rot_ransac_fit(p0[trk], g_xy[trk], ocam, ocam, draws, tb.ransac_thr)
+            res["ransac_status_mismatches"] += int((tb.rst[s_].cpu().numpy()[trk] != rs).sum())
+            res["ransac_R_bit_mismatches"] += int((tb.rR[s_].cpu().numpy().view(np.uint32) != oR.reshape(-1).view(np.uint32)).sum())
+        g2 = (cur[s_] - disp[s_]).cpu().numpy()
+        oxr, ost2, _ = orc.klt_track(lc, rc, g_xy, next_pts=g2)
+        gr_xy, g_st2 = curR[s_].cpu().numpy(), st2[s_].cpu().numpy()
+        res["lk_status_mismatches"] += int((g_st2 != ost2).sum())
+        keep = (ost2 == 1) & (g_st2 == 1)
+        res["lk_points_compared"] += int(keep.sum())
+        if keep.any():
+            res["lk_max_abs_dxy_px"] = max(res["lk_max_abs_dxy_px"], float(np.abs(gr_xy[keep] - oxr[keep]).max()))
+        if k % 2 == 0:
+            okp = orc.gftt_collect_max(orc.corner_min_eigen_val(fr_cur[0, s_].cpu().numpy()), 32, 1e-3)
+            res["gftt_keypoint_mismatches"] += int((tb.kp[s_].cpu().numpy() != okp).any(axis=1).sum())
+        # ---- EKF half ----
+        o = orc.Ekf(orc.ekf_default_params(cameraTrailLength=20))
+        o.set_state(means[s_]); o.set_cov(eb.P0_host); o.set_first_sample_time(0.0)
+        gst, ggs = eb.st[:, s_].cpu().numpy(), eb.gs[:, s_].cpu().numpy()
+        done = 0
+        for v in range(VISITS):
+            n = int(eb.lens_host[v, s_]) if eb.realistic else NPOSE
+            res["ekf_visits_compared"] += 1
+            if done >= QUOTA:
+                res["ekf_visit_status_mismatches"] += int(gst[v].tolist() != [-1, -1] or ggs[v] != 1)
+                continue
+            ots, ops, _, oH, of = orc.visual_track_prepare(par, o.m.copy(), idx[v, s_, :n], T1, T2, feat[v, s_, :2 * n], vel[v, s_, :2 * n])
+            bad = gst[v].tolist() != [ots, ops]
+            if (ots, ops) == (0, 0):
+                status, _ = o.visual_track_outlier_check(oH, of, y[v, s_, :4 * n], R_GATE)
+                bad = bad or ggs[v] != status
+                if status == 0:
+                    o.update_visual_track(oH, of, y[v, s_, :4 * n], R_UPDATE); done += 1
+                else:
+                    res["ekf_gate_rejections"] += 1
+            else:
+                bad = bad or ggs[v] != 1
+            res["ekf_visit_status_mismatches"] += int(bad)
+        res["ekf_updates_applied"] += done
+        o.maintain_psd()
+        o.update_visual_pose_augmentation(eb.last_drop)
+        for j in range(EKF_PREDICTS):
+            o.predict(0.005 * (j + 1), eb.gyro_host[j, s_], eb.acc_host[j, s_])
+        mg, Pg = eb.ekf.get_state(s_)
+        res["ekf_rel_err_m"] = max(res["ekf_rel_err_m"], float(np.linalg.norm(mg - o.m) / np.linalg.norm(o.m)))
+        res["ekf_rel_err_P"] = max(res["ekf_rel_err_P"], float(np.linalg.norm(Pg - o.P) / np.linalg.norm(o.P)))
+    res["ok"] = bool(res["lk_status_mismatches"] == 0 and res["lk_max_abs_dxy_px"] <= 1e-3 and res["ransac_status_mismatches"] == 0
+                     and res["ransac_R_bit_mismatches"] == 0 and not res["gftt_keypoint_mismatches"] and res["ekf_visit_status_mismatches"] == 0
+                     and res["ekf_rel_err_m"] <= 1e-5 and res["ekf_rel_err_P"] <= 1e-5)
+    res["bars"] = "LK status / RANSAC / GFTT bit-exact, |dxy| <= 1e-3 px, EKF rel-err <= 1e-5 (north star); checker: oracle/, outside the timed region"
+    return res
 
 
 def cpu_baseline_ekf(budget_s=8.0):
@@ -538,6 +696,8 @@ class DistEnv:
             kw = {"device_id": torch.device("cuda", self.local_rank)} if backend == "nccl" else {}
             dist.init_process_group(backend, **kw)
             self.dist = dist
+            dist.barrier()                                     # absorbs the start-up skew of the ranks (imports, first CUDA context): the
+                                                               # waits measured below are those of the timed regions only
 
     def _pin(self):
         if not hasattr(os, "sched_setaffinity"):
@@ -897,6 +1057,9 @@ def main():
     ap.add_argument("--no-ransac", action="store_true", help="skip the f4 (2-point rotation RANSAC kernel) measurement")
     ap.add_argument("--no-pcie", action="store_true", help="skip the PCIe-inclusive measurement (frames handed over as host buffers)")
     ap.add_argument("--only-headline", action="store_true", help="C2 + C3 legs only (what the rocprofv3 collection runs)")
+    ap.add_argument("--verify", type=int, default=4, help="sequences of the C3 batch re-computed by the CPU oracle after the timed region (0 = off)")
+    ap.add_argument("--repeats", type=int, default=5, help="repeats of the K-step timed region of the headline; `value` is the median repeat")
+    ap.add_argument("--one-sequence-leg", action="store_true", help="add the literal north-star configuration (ONE sequence per GPU) at N > 1 too")
     ap.add_argument("--cpu-baseline-child", type=float, default=None, help=argparse.SUPPRESS)
     args = ap.parse_args()
 
@@ -977,51 +1140,98 @@ def main():
     if solo and not args.no_ransac:
         out["f4_rot_ransac"] = bench_rot_ransac(tb.ctx, min(B, 1024), local_rank, not args.no_cpu_baseline)
 
-    # ---- C3 (configs[2], the headline): the whole frame chained on one stream -- tracker (pyramids, temporal LK, rotation RANSAC on
-    # its output, stereo LK, GFTT on every second frame, bookkeeping) and the HIP EKF driven from the DEVICE mean (f3): 20 track
-    # visits of which 5 update, symmetrise, augmentation, 10 predicts ----
-    tb.enable_chain(rank)
-    eb = VisualEkfBench(tb.ctx, B, local_rank, seed=rank)
-    for _ in range(args.warmup):
-        tb.step(); eb.step()
-    eb.applied.zero_()
-    tb.ctx.profile_enable(True)
-    tb.ctx.profile_reset()
-    el3 = env.timed(lambda: (tb.step(), eb.step()), args.steps)
+    # ---- C3 (configs[2], the headline): the whole frame chained on one stream -- tracker (pyramids, temporal LK from predicted positions,
+    # rotation RANSAC on its output, stereo LK, GFTT on every second frame, bookkeeping) and the HIP EKF driven from the DEVICE mean (f3):
+    # 20 track visits with the reference's track-length distribution (ragged: 5 .. 21 stereo poses = 20 .. 84 rows), per-filter
+    # independent inlier patterns, quota 5, symmetrise, augmentation, 10 predicts ----
     names = (("pyr_l0", capi.K_PYR_L0), ("pyr_ln", capi.K_PYR_LN), ("klt", capi.K_KLT), ("rot_ransac", capi.K_ROT_RANSAC), ("gftt", capi.K_GFTT),
              ("ekf_predict", capi.K_EKF_PREDICT), ("vu_prepare", capi.K_VU_PREPARE), ("ekf_update_gate", capi.K_EKF_UPDATE),
-             ("ekf_augment", capi.K_EKF_AUGMENT))
-    prof3 = {name: tb.ctx.profile_read(kid) for name, kid in names}
-    tb.ctx.profile_enable(False)
-    applied = float(eb.applied.item()) / (B * args.steps)
+             ("ekf_gate", capi.K_EKF_GATE), ("ekf_augment", capi.K_EKF_AUGMENT))
+
+    def c3_leg(realistic, repeats):
+        """One C3 leg under the timing contract: `repeats` timed regions of exactly args.steps steps each (barrier + sync on both sides,
+        MAX over ranks); per-kernel hipEvent times are taken over all of them. Returns the bench objects, the sorted region times and
+        the per-kernel table."""
+        tb.enable_chain(rank)
+        tb.predicted_flow = realistic
+        eb_ = VisualEkfBench(tb.ctx, B, local_rank, seed=rank, realistic=realistic)
+        for _ in range(args.warmup):
+            tb.step(); eb_.step()
+        eb_.applied.zero_()
+        tb.ctx.profile_enable(True)
+        tb.ctx.profile_reset()
+        times = [env.timed(lambda: (tb.step(), eb_.step()), args.steps) for _ in range(max(1, repeats))]
+        prof = {name: tb.ctx.profile_read(kid) for name, kid in names}
+        tb.ctx.profile_enable(False)
+        nsteps = args.steps * len(times)
+        kern = {k: {"avg_ms": ms / n, "launches": n, "total_ms": ms, "ms_per_step": ms / nsteps} for k, (ms, n) in prof.items() if n}
+        return eb_, times, kern, float(eb_.applied.item()) / (B * nsteps)
+
+    eb, times3, k3, applied = c3_leg(True, args.repeats)
+    el3 = sorted(times3)[len(times3) // 2]                      # the median repeat is the reported timed region
     gate_hist = [int((eb.gs[k] == 0).sum().item()) for k in range(VISITS)]
+    verify = verify_c3(tb, eb, args.verify, seed=rank) if (args.verify > 0 and rank == 0) else None
+    tracked3 = tb.tracked_fraction()
+    lens_mean = float(eb.lens_host.mean()); long_share = float((eb.lens_host > 11).mean())
     eb.ekf.close()
     del eb
     n_state = 160
     p_bytes = n_state * n_state * 8
     ab = algorithmic_bytes()
-    k3 = {k: {"avg_ms": ms / n, "launches": n, "total_ms": ms, "ms_per_step": ms / args.steps} for k, (ms, n) in prof3.items() if n}
-    # algorithmic bytes per launch of the kernel classes that can dominate the step (SURVEY.md 8(d) / DESIGN.md 3):
-    #   klt: B x 200 points x 4 levels x 6144 B; pyr_l0: 2B x 1 895 040 B; fused gate(+update): B x P read once (+ written by the 1 in 4
-    #   launches that update) + the 40 x 160 Jacobian; vu_prepare: B x (mean in, Jacobian out); augment / predict: P read + written
-    h_bytes = 4 * NPOSE * n_state * 8
-    alg = {"klt": B * ab["klt_call"], "pyr_l0": 2 * B * ab["pyr_l0"], "pyr_ln": 2 * B * ab["pyr_ln"] * args.steps / max(1, prof3["pyr_ln"][1]),
-           "ekf_update_gate": B * (p_bytes * (1.0 + QUOTA / VISITS) + h_bytes), "vu_prepare": B * (n_state * 8 + h_bytes),
+    # algorithmic bytes per launch of the kernel classes that can dominate the step (SURVEY.md 8(d) / DESIGN.md 3), at the workload's MEAN
+    # track (8.9 stereo poses: 35.5 rows, 63 active columns): klt: B x 200 points x 4 levels x 6144 B; pyr_l0: 2B x its own bytes;
+    # vu_prepare (fused prepare + sparse gate): mean in, track in, P(a, a) read, compact Jacobian + residual out; update: P read + written
+    # (+ the compact Jacobian); augment / predict: P read + written
+    rows_mean, na_mean = 4 * lens_mean, 7 * lens_mean + 1
+    hc_bytes = rows_mean * na_mean * 8
+    alg = {"klt": B * ab["klt_call"], "pyr_l0": 2 * B * ab["pyr_l0"], "pyr_ln": 2 * B * ab["pyr_ln"] * args.steps * len(times3) / max(1, k3.get("pyr_ln", {}).get("launches", 1)),
+           "vu_prepare": B * (n_state * 8 + 12 * 8 * 2 * lens_mean + na_mean * na_mean * 8 + hc_bytes),
+           "ekf_update_gate": B * (QUOTA / VISITS) * (2 * p_bytes + hc_bytes), "ekf_gate": B * (na_mean * na_mean * 8 + hc_bytes),
            "ekf_augment": B * p_bytes * 2, "ekf_predict": B * p_bytes * 2, "rot_ransac": B * NPTS * 20, "gftt": B * W * H}
     for k in k3:
         k3[k]["algorithmic_bytes_per_launch"] = alg[k]
         k3[k]["achieved_GBs"] = alg[k] / (k3[k]["avg_ms"] * 1e-3) / 1e9
     dom = max(k3, key=lambda k: k3[k]["total_ms"])
     prof_t = profiled_traffic() if rank == 0 else None
-    traffic, traffic_note = None, None
-    if prof_t is not None:
-        key = {"klt": "klt_kernel", "pyr_l0": "pyr_level_kernel_L0", "ekf_update_gate": "ekf_update_kernel", "vu_prepare": "vu_prepare_kernel"}.get(dom)
-        if key in prof_t and prof_t[key].get("hbm_bytes_per_launch") is not None:
-            traffic = prof_t[key]["hbm_bytes_per_launch"] * B / float(prof_t.get("sequences_per_gpu", B))
-            traffic_note = (f"rocprofv3 FETCH_SIZE x2 + WRITE_SIZE per launch from {prof_t['_file']} "
-                            f"(collected at B={prof_t.get('sequences_per_gpu')}, scaled to B={B})")
+    pmc_key = {"klt": "klt_kernel", "pyr_l0": "pyr_down_l0_kernel", "ekf_update_gate": "ekf_update_kernel", "vu_prepare": "vu_gate_kernel_2percu",
+               "pyr_ln": "pyr_tail_kernel", "ekf_gate": "ekf_sparse_gate_kernel"}
+
+    def pmc(kname, field):
+        e_ = (prof_t or {}).get(pmc_key.get(kname, ""), None)
+        if not isinstance(e_, dict) or e_.get(field) is None:
+            return None
+        v = e_[field]
+        return v * B / float(prof_t.get("sequences_per_gpu", B)) if field == "hbm_bytes_per_launch" else v
+    traffic = pmc(dom, "hbm_bytes_per_launch")
+    traffic_note = (f"rocprofv3 FETCH_SIZE x2 + WRITE_SIZE per launch from {prof_t['_file']} (collected at B={prof_t.get('sequences_per_gpu')}, scaled to B={B})"
+                    if traffic is not None else None)
+    # the stage the north star asks about, twice (VERDICT r02 item 5 ii): on the agreed SURVEY 8(d) bytes, and on the bytes the kernels
+    # really move (PMC; levels 0-1 store no gradient planes, LK windows are cache hits) -- the second is the true HBM utilisation
     stage_ms = sum(k3[k]["ms_per_step"] for k in ("pyr_l0", "pyr_ln", "klt") if k in k3)
     stage_gbs = B * ab["stereo_frame"] / (stage_ms * 1e-3) / 1e9
+    stage_actual = None
+    if prof_t is not None and all(pmc(k, "hbm_bytes_per_launch") is not None for k in ("klt", "pyr_l0")):
+        per_step = {k: k3[k]["launches"] / (args.steps * len(times3)) for k in ("klt", "pyr_l0", "pyr_ln") if k in k3}
+        stage_actual = sum(pmc(k, "hbm_bytes_per_launch") * per_step[k] for k in ("klt", "pyr_l0")) + \
+            sum((prof_t.get(kk, {}) or {}).get("hbm_bytes_per_launch", 0.0) * B / float(prof_t.get("sequences_per_gpu", B))
+                for kk in ("pyr_down_l0_kernel_L1", "pyr_tail_kernel"))
+    stage = {"ms_per_step": stage_ms, "achieved_GBs": stage_gbs, "frac_of_8TBs": stage_gbs / HBM_PEAK_GBS,
+             "frac_of_measured_copy_ceiling": stage_gbs / HBM_COPY_CEILING_GBS, "algorithmic_bytes_per_stereo_frame": ab["stereo_frame"],
+             "stage_actual_bytes_per_step": stage_actual,
+             "frac_actual": (stage_actual / (stage_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if stage_actual else None,
+             "bound": "valu", "valu_busy_frac_klt": pmc("klt", "valu_busy_frac"),
+             "note": "frac_of_8TBs prices the AGREED bytes of SURVEY 8(d) (gradient planes of every level written, windows read once); the kernels "
+                     "move stage_actual_bytes (levels 0-1 keep no gradient plane, LK windows are cache hits): frac_actual is the real HBM "
+                     "utilisation; the limiter of the stage is klt_kernel's integer VALU issue rate"}
+    # limiter of the dominant kernel class, stated for what it is (item 5 iii): the EKF kernels are f64 matrix / latency structured
+    f64_peak_tflops = 78.6                                        # MI355X f64 vector = matrix peak (MI355X_MICROARCH.md)
+    flops_vu = B * (1.1e6 * lens_mean / 10.0 + 2 * rows_mean * na_mean * na_mean + 2 * rows_mean * rows_mean * na_mean + rows_mean ** 3 / 3)
+    limiter = {"klt": "VALU issue (integer): klt_kernel issues VALU instructions > 90 % of the time; HBM traffic is a quarter of the agreed bytes",
+               "vu_prepare": "per-workgroup latency: the fused triangulation + prepareVisualUpdate + column-sparse chi2 gate kernel is a chain of ~50 "
+                             "barrier-separated f64 phases (two 80 KB workgroups per CU, waves parked 70 % of the time, VALU busy ~25 %, MFMA busy ~10 %); "
+                             "neither HBM nor the matrix pipe bounds it",
+               "ekf_update_gate": "f64 MFMA + per-workgroup latency: one 512-thread workgroup per CU keeps P in registers (read once, written once); "
+                                  "MFMA busy ~35 %"}.get(dom)
     if rank == 0:
         head = {
             "metric": "VIO frames/sec at 752x480 stereo, 200 KLT features; pyramid+KLT HBM GB/s",
@@ -1029,34 +1239,55 @@ def main():
             "ms_per_step": el3 / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u8/int16 pixels, int32/int64 sums, f32 solve (tracker); f64 (EKF)", "data": "synthetic",
             "smoke_all_ranks_on_one_device": forced_dev is not None or None,
-            "config": {"workload": "C3: 752x480 stereo, 200 pts -- the whole frame chained on one stream per sequence: 2 pyramid builds, temporal LK, "
-                                   "2-point rotation RANSAC on its output, stereo LK, GFTT key points every 2nd frame (HIP tracker), then the HIP EKF "
-                                   "from the device mean: 20 track visits (triangulation + prepareVisualUpdate, 10 stereo poses = 40 x 160 Jacobian, "
-                                   "chi2 gate) of which 5 update, symmetrise, 1 Joseph-form augmentation, 10 predicts in one launch; state dim 160",
+            "repeats_ms_per_step": [t_ / args.steps * 1e3 for t_ in times3], "value_is": "median of the repeats (each an exact K-step timed region)",
+            "stage_pyramid_klt_frac_of_8TBs": stage["frac_of_8TBs"], "stage_pyramid_klt_frac_actual": stage["frac_actual"],
+            "parity_checked_sequences": verify["parity_checked_sequences"] if verify else 0, "parity_ok": verify["ok"] if verify else None,
+            "config": {"workload": "C3: 752x480 stereo, 200 pts -- the whole frame chained on one stream per sequence: 2 pyramid builds, temporal LK from "
+                                   "predicted positions, 2-point rotation RANSAC on its output, stereo LK, GFTT key points every 2nd frame (HIP tracker), "
+                                   "then the HIP EKF from the device mean: 20 track visits (triangulation + prepareVisualUpdate + chi2 gate; track lengths "
+                                   "5 + Geometric(0.2) <= 21 stereo poses = 20 .. 84 rows, per-filter independent inliers p = 0.25, quota 5 updates), "
+                                   "symmetrise, 1 Joseph-form augmentation, 10 predicts in one launch; state dim 160",
                        "sequences_per_gpu": B, "frames_per_step": world * B, "parallelism": f"replicas x{world} (no collective)",
+                       "track_poses_mean": lens_mean, "tracks_longer_than_11_poses": long_share,
                        "timing_process_group": args.dist_backend if world > 1 else None, "host_cores_per_rank": env.cores},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": k3[dom]["achieved_GBs"], "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": k3[dom]["achieved_GBs"] / HBM_PEAK_GBS, "traffic": traffic,
                          "algorithmic_bytes_per_launch": alg[dom], "avg_launch_ms": k3[dom]["avg_ms"], "traffic_source": traffic_note,
-                         "limiter": ("klt_kernel is VALU-issue bound (rocprof: VALU busy > 80 %, HBM traffic < algorithmic bytes); "
-                                     "the HBM-bound kernel of the path is pyr_l0, see kernels / measured_ceilings") if dom == "klt" else None},
+                         "true_bound": {"klt": "valu", "vu_prepare": "f64-valu+mfma/latency", "ekf_update_gate": "f64-mfma/latency"}.get(dom, "hbm"),
+                         "limiter": limiter,
+                         "f64_flop_frac": (flops_vu / (k3[dom]["avg_ms"] * 1e-3) / 1e12 / f64_peak_tflops) if dom == "vu_prepare" else None,
+                         "mfma_busy_frac": pmc(dom, "mfma_busy_frac"), "valu_busy_frac": pmc(dom, "valu_busy_frac"),
+                         "stage_pyramid_klt": stage},
             "measured_ceilings_GBs": (prof_t or {}).get("measured_hbm_ceilings_GBs"),
             "kernels": k3,
             # the reference's own `-timer` keys -> device ms per step of B frames
             "timers_ms_per_step": {"pyramid": sum(k3[k]["ms_per_step"] for k in ("pyr_l0", "pyr_ln") if k in k3),
                                    "computeOpticalFlow": k3.get("klt", {}).get("ms_per_step"),
                                    "KF predict": k3.get("ekf_predict", {}).get("ms_per_step"),
-                                   "trackerVisualUpdate": sum(k3[k]["ms_per_step"] for k in ("vu_prepare", "ekf_update_gate") if k in k3),
+                                   "trackerVisualUpdate": sum(k3[k]["ms_per_step"] for k in ("vu_prepare", "ekf_update_gate", "ekf_gate") if k in k3),
                                    "augmentation": k3.get("ekf_augment", {}).get("ms_per_step")},
-            "stage_pyramid_klt": {"ms_per_step": stage_ms, "achieved_GBs": stage_gbs, "frac_of_8TBs": stage_gbs / HBM_PEAK_GBS,
-                                  "frac_of_measured_copy_ceiling": stage_gbs / HBM_COPY_CEILING_GBS,
-                                  "algorithmic_bytes_per_stereo_frame": ab["stereo_frame"]},
+            "stage_pyramid_klt": stage,
             "visual_updates_applied_per_frame": applied, "inlier_gates_per_visit_last_step": gate_hist,
-            "tracked_fraction": c2["tracked_fraction"],
+            "tracked_fraction": tracked3,
+            "verify": verify,
             "c2": c2,
         }
         head.update(out)
         out = head
+    # ---- r02's C3 workload (every track 10 stereo poses, all filters share the inlier pattern 3, 7, 11, 15, 19, zero-flow LK start):
+    # kept for round-over-round comparison ----
+    if not args.only_headline or os.environ.get("HV_BENCH_C3_UNIFORM") == "1":
+        ebu, timesu, ku, appliedu = c3_leg(False, 1)
+        ebu.ekf.close()
+        del ebu
+        tb.predicted_flow = True
+        if rank == 0:
+            out["c3_uniform"] = {"workload": "r02's C3: as the headline but every track 10 stereo poses (40 x 160 Jacobian), one inlier pattern for all filters, "
+                                             "temporal LK without initial flow",
+                                 "value": aggregate_value(B, world, args.steps, timesu[0]), "unit": "frames/s", "ms_per_step": timesu[0] / args.steps * 1e3,
+                                 "visual_updates_applied_per_frame": appliedu,
+                                 "kernels": {k: {"avg_ms": v["avg_ms"], "launches": v["launches"], "ms_per_step": v["ms_per_step"]} for k, v in ku.items()},
+                                 "r02_value": 103900.0}
     # ---- the r01 definition of the EKF leg (dense random 40 x 160 Jacobians handed to the gate, no triangulation): kept for
     # round-over-round comparison, not the headline ----
     if not args.only_headline:
@@ -1076,6 +1307,23 @@ def main():
                                  "value": aggregate_value(B, world, args.steps, eld), "unit": "frames/s", "ms_per_step": eld / args.steps * 1e3,
                                  "kernels": {k: {"avg_ms": ms / n, "launches": n, "ms_per_step": ms / args.steps} for k, (ms, n) in profd.items() if n}}
     del tb
+
+    # ---- the north star's literal configuration: ONE sequence per GPU (each rank its own), the whole chained frame, eager launches. At
+    # N = 1 this is `latency_mode` below; at N > 1 it is reported here under the same barrier / MAX contract ----
+    if world > 1 or args.one_sequence_leg:
+        t1 = TrackerBench(1, local_rank, seed=777 + rank, chain=True)
+        e1 = VisualEkfBench(t1.ctx, 1, local_rank, seed=777 + rank)
+        for _ in range(N_CYCLE):
+            t1.step(); e1.step()
+        n1 = 100
+        el1 = env.timed(lambda: (t1.step(), e1.step()), n1)
+        if rank == 0:
+            out["one_sequence_per_gpu"] = {"sequences_per_gpu": 1, "n_gpus": world, "value": aggregate_value(1, world, n1, el1), "unit": "frames/s",
+                                           "ms_per_frame": el1 / n1 * 1e3, "launch": "eager",
+                                           "note": "north_star: 'the 8 GPUs of one node each run an independent benchmark sequence'; the batched "
+                                                   "headline keeps `sequences_per_gpu` independent sequences resident per GPU instead"}
+        e1.ekf.close()
+        del e1, t1
 
     # ---- frames handed over as HOST buffers (the reference's boundary): every rank feeds its own GPU from pinned memory ----
     if not args.no_pcie:

@@ -410,6 +410,14 @@ struct UpdateArgs {
     const int *acol;                  // [records][na_max] or null (dense H)
     int na_max, ncam;
     size_t h_stride;                  // doubles between the H records
+    int v_stride;                     // doubles between the v records (= nr unless the launch serves one length class of a longer-strided batch)
+    // Long tracks (49 .. 96 rows: 13 .. 21 stereo poses) as TWO sequential block updates of at most 48 rows each, which is the same
+    // posterior (the blocks' measurement noises are independent: R = r^2 I, ekf.cpp:771) and keeps every update on the P-resident MODE 2
+    // kernel: half 1 = the first h1 = 2 ceil(rows / 4) rows (the first camera's), half 2 = the rest (the second camera's) with its
+    // innovation corrected by the first block's mean step, v2 - H2 dm1. Half 1 leaves dm1 in dm_out and skips the quaternion
+    // normalisation; half 2 reads it (dm_in) and normalises. 0 = the whole record in one launch. Compact H, MODE 2 only.
+    int half, nr_full;                // nr_full: rows of the whole record when neither nr_rec nor nr says so (uniform long tracks)
+    double *dm_out; const double *dm_in;   // [batch][n]
 };
 
 // spec 3 hand-shake between the workgroups of one filter (agent scope: they run on different CUs)
@@ -493,9 +501,19 @@ __global__ __launch_bounds__(UPD_THREADS) void ekf_update_kernel(UpdateArgs a)
     constexpr int nwaves = UPD_THREADS / 64;
     const int n = a.n, l = a.l;
     int nr = a.nr, R = a.Rs, Rfull = a.R;                   // R is the column STRIDE of T below; Rfull rows are used
-    if (a.nr_rec) {                                        // ragged batch: this record's own row count (uniform per workgroup)
-        nr = a.nr_rec[e];
-        if (nr < 1 || nr > a.nr) return;                   // no track (the prepare launch also cleared `active`)
+    int roff = 0, ld = a.nr;                               // first row of this launch's block inside the record; leading dimension of H
+    if (a.nr_rec || a.half) {                              // ragged batch / block update: this record's own shape (uniform per workgroup)
+        int nr_full = a.nr_rec ? a.nr_rec[e] : a.nr_full;
+        nr_full = __builtin_amdgcn_readfirstlane(nr_full);
+        if (nr_full < 1 || nr_full > a.v_stride) return;    // no track (the prepare launch also cleared `active`)
+        nr = nr_full; ld = nr_full;
+        if (a.half) {
+            if (MODE != 2) return;                         // (the host only asks the LDS-resident kernels for block updates)
+            const int h1 = 2 * ((nr_full + 3) >> 2);
+            roff = a.half == 2 ? h1 : 0;
+            nr = a.half == 2 ? nr_full - h1 : h1;
+        }
+        if (nr < 1 || nr > a.nr) return;
         Rfull = nr + n + 1; R = Rfull;
         if (USE_LDS) while ((R & 31) != 15 && (R & 31) != 17) R++;
     }
@@ -566,7 +584,7 @@ __global__ __launch_bounds__(UPD_THREADS) void ekf_update_kernel(UpdateArgs a)
 #pragma unroll
             for (int bi = 0; bi < DEPTH; bi++) if (have0) fetch_blk(pres0, bi, wave, bi, tiles_j);
             int *inv = reinterpret_cast<int *>(col);
-            const int na = 7 * (nr / (2 * a.ncam)) + 1;
+            const int na = 7 * (ld / (2 * a.ncam)) + 1;     // (ld = rows of the whole record)
             const int *acol = a.acol + (size_t)e * a.na_max;
             const int my_col = t < na ? acol[t] : -1;
             for (int i = t; i < n + 1; i += UPD_THREADS) inv[i] = i < n ? -1 : 0;
@@ -578,13 +596,13 @@ __global__ __launch_bounds__(UPD_THREADS) void ekf_update_kernel(UpdateArgs a)
             for (int u = 0; u < HREG; u++) {
                 const int i = t + u * UPD_THREADS, k = i / nrp, r = i - k * nrp;
                 const int ck = (i < nrp * 16 * lb && k < l && r < nr) ? inv[k] : -1;
-                hreg[u] = ck >= 0 ? H[(size_t)ck * nr + r] : 0.0;
+                hreg[u] = ck >= 0 ? H[(size_t)ck * ld + roff + r] : 0.0;
             }
         } else {
 #pragma unroll
             for (int u = 0; u < HREG; u++) {
                 const int i = t + u * UPD_THREADS, k = i / nrp, r = i - k * nrp;
-                hreg[u] = (i < nrp * 16 * lb && k < l && r < nr) ? H[(size_t)k * nr + r] : 0.0;
+                hreg[u] = (i < nrp * 16 * lb && k < l && r < nr) ? H[(size_t)k * ld + roff + r] : 0.0;
             }
 #pragma unroll
             for (int bi = 0; bi < DEPTH; bi++) if (have0) fetch_blk(pres0, bi, wave, bi, tiles_j);
@@ -680,8 +698,16 @@ __global__ __launch_bounds__(UPD_THREADS) void ekf_update_kernel(UpdateArgs a)
         }
     }
     for (int i = t; i < nr; i += UPD_THREADS) {
-        double r = a.v[(size_t)e * a.nr + i];
+        double r = a.v[(size_t)e * a.v_stride + roff + i];
         if (a.generic) { double s = 0; for (int k = 0; k < l; k++) s += H[(size_t)k * nr + i] * m[k]; r -= s; }
+        if constexpr (MODE == 2) {
+            if (a.dm_in) {                                 // second block of a long track: v2 - H2 dm1 (Hs: the staged, zero-padded H of this block)
+                const double *dm = a.dm_in + (size_t)b * n;
+                double s = 0;
+                for (int k = 0; k < l; k++) s += Hs[(size_t)k * nrp + i] * dm[k];
+                r -= s;
+            }
+        }
         T[(size_t)i * R + rv] = r;
     }
     __syncthreads();
@@ -849,6 +875,7 @@ __global__ __launch_bounds__(UPD_THREADS) void ekf_update_kernel(UpdateArgs a)
         double s = 0;
         for (int c = 0; c < nr; c++) s += T[(size_t)c * R + ry + j] * T[(size_t)c * R + rv];
         m[j] += s;
+        if (a.dm_out) a.dm_out[(size_t)b * n + j] = s;
     }
     // ---- F: P -= Y' Y ----
     if constexpr (MODE == 2) {
@@ -923,7 +950,7 @@ __global__ __launch_bounds__(UPD_THREADS) void ekf_update_kernel(UpdateArgs a)
     __syncthreads();
     PHASE_STAMP(5);
     // ---- G: quaternion normalisation (updateCommon ekf.cpp:29-31 / normalizeQuaternions 1024-1032) ----
-    const int nq = a.normalize_all ? 1 + (n - a.map_dim - CAM) / POSE : 1;     // map points behind the trail are not poses
+    const int nq = a.normalize_all < 0 ? 0 : a.normalize_all ? 1 + (n - a.map_dim - CAM) / POSE : 1;     // map points behind the trail are not poses (< 0: first block of a long track)
     if (t < nq) normalize4(m + (t == 0 ? ORI : CAM + POSE * (t - 1) + 3));
     if (a.success_counter && t == 0) a.success_counter[b] += 1;
     if (a.spec == 2 && t == 0) a.cursor[b] = sel + 1;      // the tracks up to the applied one are final, the rest is re-examined
@@ -1110,11 +1137,16 @@ struct SparseGateArgs {
     double rd, noise_scale;
     double *chi2; int *status;        // chi2 optional
     int hs_doubles;                   // LDS carve: doubles reserved for the staged Hc (>= 816 + 4: it is the Cholesky scratch afterwards)
+    int lds_doubles;                  // doubles available for Hc + [S; v'] together (BIG build: decides between the padded and the tight layout)
 };
 
 constexpr int SGATE_THREADS = 256;
 
-__global__ __launch_bounds__(SGATE_THREADS, 3) void ekf_sparse_gate_kernel(SparseGateArgs a)
+// BIG = false: up to 48 rows (three 43 KB workgroups per CU at 10 stereo poses); BIG = true: 49 .. 96 rows (tracks of 13 .. 21 stereo
+// poses: 13 .. 21 poses x 4 rows), one workgroup per CU with the whole register file, Hc staged with nrp = 16 TI rows per column where that
+// fits 160 KB together with [S; v'] and with exactly nr rows (TIGHT) where it does not (84 rows: 99.5 + 58.5 KB).
+template <bool BIG>
+__device__ __forceinline__ void sparse_gate_kernel_body(const SparseGateArgs &a)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int b = blockIdx.x, t = threadIdx.x;
@@ -1123,9 +1155,12 @@ __global__ __launch_bounds__(SGATE_THREADS, 3) void ekf_sparse_gate_kernel(Spars
     nr = __builtin_amdgcn_readfirstlane(nr);
     if (nr < 2 || nr > a.nr) return;
     const int n = a.n, npose = nr / (2 * a.ncam), na = 7 * npose + 1, na4 = (na + 3) & ~3;
-    const int ti = (nr + 15) >> 4, nrp = 16 * ti;
+    const int ti = BIG ? max((nr + 15) >> 4, 4) : (nr + 15) >> 4;       // (the BIG build starts at the 4-tile instantiation)
     int Rs = nr + 1;
     while ((Rs & 31) != 15 && (Rs & 31) != 17) Rs++;
+    const bool tight = BIG && (size_t)na4 * 16 * ti + (size_t)Rs * nr > (size_t)a.lds_doubles;    // (uniform) does the padded layout fit?
+    if (tight) Rs = nr + 1 + ((nr + 1) & 1 ? 0 : 1);            // an odd stride is all the LDS budget allows
+    const int nrp = tight ? nr : 16 * ti;
     double *Hs = smem, *T = smem + a.hs_doubles;
     int *s_acol = reinterpret_cast<int *>(T + (size_t)Rs * nr);
     const double *Hc = a.Hc + (size_t)b * a.nr * a.na_max;
@@ -1157,9 +1192,16 @@ __global__ __launch_bounds__(SGATE_THREADS, 3) void ekf_sparse_gate_kernel(Spars
     __syncthreads();
     const double *Pb = a.P + (size_t)b * n * n;
     double chi;
-    if (ti == 1)      chi = sparse_gate<1, SGATE_THREADS, true>(Pb, n, s_acol, na, Hs, T, Rs, nr, a.rd, a.noise_scale, Hs);
-    else if (ti == 2) chi = sparse_gate<2, SGATE_THREADS, true>(Pb, n, s_acol, na, Hs, T, Rs, nr, a.rd, a.noise_scale, Hs);
-    else              chi = sparse_gate<3, SGATE_THREADS, true>(Pb, n, s_acol, na, Hs, T, Rs, nr, a.rd, a.noise_scale, Hs);
+    if constexpr (!BIG) {
+        if (ti == 1)      chi = sparse_gate<1, SGATE_THREADS, true>(Pb, n, s_acol, na, Hs, T, Rs, nr, a.rd, a.noise_scale, Hs);
+        else if (ti == 2) chi = sparse_gate<2, SGATE_THREADS, true>(Pb, n, s_acol, na, Hs, T, Rs, nr, a.rd, a.noise_scale, Hs);
+        else              chi = sparse_gate<3, SGATE_THREADS, true>(Pb, n, s_acol, na, Hs, T, Rs, nr, a.rd, a.noise_scale, Hs);
+    } else {
+        if (ti <= 4)      chi = sparse_gate<4, SGATE_THREADS, true>(Pb, n, s_acol, na, Hs, T, Rs, nr, a.rd, a.noise_scale, Hs);
+        else if (ti == 5) chi = sparse_gate<5, SGATE_THREADS, true>(Pb, n, s_acol, na, Hs, T, Rs, nr, a.rd, a.noise_scale, Hs);
+        else if (!tight)  chi = sparse_gate<6, SGATE_THREADS, true>(Pb, n, s_acol, na, Hs, T, Rs, nr, a.rd, a.noise_scale, Hs);
+        else              chi = sparse_gate<6, SGATE_THREADS, true, true>(Pb, n, s_acol, na, Hs, T, Rs, nr, a.rd, a.noise_scale, Hs);
+    }
     if (t == 0) {
         const bool broken = !(chi < 1e300);                    // non-positive pivot: reported as CHI2 (ekf_update_kernel phase D)
         const int outlier = broken || ((nr < HV_CHI2INV95_N) ? (chi > d_chi2inv95[nr]) : 0);
@@ -1167,6 +1209,9 @@ __global__ __launch_bounds__(SGATE_THREADS, 3) void ekf_sparse_gate_kernel(Spars
         if (a.chi2) a.chi2[b] = chi;
     }
 }
+
+__global__ __launch_bounds__(SGATE_THREADS, 3) void ekf_sparse_gate_kernel(SparseGateArgs a) { sparse_gate_kernel_body<false>(a); }
+__global__ __launch_bounds__(SGATE_THREADS, 1) void ekf_sparse_gate_big_kernel(SparseGateArgs a) { sparse_gate_kernel_body<true>(a); }
 
 // ---------------------------------------------------------------------------------------------
 // pose augmentation / undo (ekf.cpp:848-903) and housekeeping
@@ -1506,11 +1551,19 @@ struct Ekf {
     size_t vustage_bytes = 0;
     // fused prepare + gate (compact Jacobians live in vuH / spH): the active-column lists of the records
     int *vuacol = nullptr, *spacol = nullptr;
+    // long-track classes of a ragged visit (visual_track_dev_impl): own stream, events, Jacobian / residual / active buffers
+    hipStream_t side_stream[2] = {nullptr, nullptr};
+    hipEvent_t ev_fork[2] = {nullptr, nullptr}, ev_join[2] = {nullptr, nullptr};
+    double *sideH[2] = {nullptr, nullptr}, *sidev[2] = {nullptr, nullptr};
+    unsigned char *side_active[2] = {nullptr, nullptr};
+    int side_rows[2] = {0, 0};
+    int *side_acol = nullptr; double *side_dm = nullptr;
     int *err_dev = nullptr;                               // device error word (UpdateArgs::err)
 };
 
-// compact-H description handed to ekf_launch_update (null acol: dense H of l columns)
-struct CompactH { const int *acol = nullptr; int na_max = 0, ncam = 1; };
+// compact-H description handed to ekf_launch_update (null acol: dense H of l columns); half / nr_full / dm: block update of a long
+// track (UpdateArgs::half)
+struct CompactH { const int *acol = nullptr; int na_max = 0, ncam = 1; int half = 0, nr_full = 0; double *dm = nullptr; };
 
 static int ekf_launch_update(Ekf *e, int nr, int l, const double *H_dev, const double *v_dev, const double *rdiag_dev,
                              double rd0, int mode, int generic, int normalize_all, double *chi2_dev, int *status_dev,
@@ -1518,9 +1571,12 @@ static int ekf_launch_update(Ekf *e, int nr, int l, const double *H_dev, const d
                              int *success_counter_dev = nullptr, double rd1 = 0.0, bool *two_r_done = nullptr,
                              int spec = 0, int n_tracks = 0, int *cursor_dev = nullptr, int max_successful = 0,
                              const int *gate_in_dev = nullptr, int *cursor_out_dev = nullptr, int *pub_dev = nullptr, int pass_id = 0,
-                             const int *nr_rec_dev = nullptr, const CompactH *compact = nullptr)
+                             const int *nr_rec_dev = nullptr, const CompactH *compact = nullptr, int nr_stride = 0)
 {
+    // nr_stride (ragged launches that serve one length class): rows of the LONGEST record of the batch = the record stride of H and v;
+    // nr is then the most rows this launch processes (kernel variant, LDS carve), longer records are skipped by their `active` flag
     Ctx *c = e->c;
+    if (nr_stride <= 0) nr_stride = nr;
     if (nr < 1 || nr > e->max_rows || l < 1 || l > e->n) return HV_ERR_INVALID;
     // the chi2 gate needs chi2inv95[nr] (the reference asserts n < chi2inv95.size(): ekf.cpp:806); mode 1 with an
     // inlier requirement is the update half of a gate that already ran
@@ -1538,8 +1594,13 @@ static int ekf_launch_update(Ekf *e, int nr, int l, const double *H_dev, const d
     a.ws = e->ws; a.chi2 = chi2_dev; a.status = status_dev; a.active = active_dev; a.require_inlier = require_inlier_dev; a.success_counter = success_counter_dev;
     a.spec = spec; a.n_tracks = n_tracks; a.cursor = cursor_dev; a.max_successful = max_successful; a.gate_in = gate_in_dev;
     a.cursor_out = cursor_out_dev; a.pub = pub_dev; a.pass_id = pass_id; a.nr_rec = nr_rec_dev; a.err = e->err_dev;
-    a.h_stride = (size_t)nr * l;
-    if (compact && compact->acol) { a.acol = compact->acol; a.na_max = compact->na_max; a.ncam = compact->ncam; a.h_stride = (size_t)nr * compact->na_max; }
+    a.h_stride = (size_t)nr_stride * l; a.v_stride = nr_stride;
+    if (compact && compact->acol) {
+        a.acol = compact->acol; a.na_max = compact->na_max; a.ncam = compact->ncam; a.h_stride = (size_t)nr_stride * compact->na_max;
+        a.half = compact->half; a.nr_full = compact->nr_full;
+        if (a.half == 1) a.dm_out = compact->dm;
+        if (a.half == 2) a.dm_in = compact->dm;
+    }
     size_t tall = (((size_t)a.Rs * nr + 1) & ~(size_t)1) * sizeof(double);
     const size_t small = (size_t)(256 + 544 + UPD_THREADS / 64 + 2) * sizeof(double);           // W + col (incl. dump area) + red + flag
     const int ti = (nr + 15) / 16, lbk = (l + 15) / 16;
@@ -1615,23 +1676,32 @@ static int ekf_launch_sparse_gate(Ekf *e, int np, int ncam, const double *Hc_dev
 {
     Ctx *c = e->c;
     const int nr = 2 * np * ncam, na_max = 7 * np + 1, na4 = (na_max + 3) & ~3, nrp = 16 * ((nr + 15) / 16);
-    if (nr < 2 || nr > 48 || !active_dev || !status_dev) return HV_ERR_INVALID;
+    if (nr < 2 || nr > 96 || nr >= HV_CHI2INV95_N || !active_dev || !status_dev) return HV_ERR_INVALID;
+    const bool big = nr > 48;
     SparseGateArgs a{};
     a.n = e->n; a.nr = nr; a.ncam = ncam; a.na_max = na_max; a.P = e->P; a.Hc = Hc_dev; a.v = v_dev; a.acol = acol_dev; a.nr_rec = nr_rec_dev;
     a.active = active_dev; a.rd = rd; a.noise_scale = e->noise_scale; a.chi2 = chi2_dev; a.status = status_dev;
     int Rs = nr + 1;
     while ((Rs & 31) != 15 && (Rs & 31) != 17) Rs++;
-    a.hs_doubles = na4 * nrp < 824 ? 824 : na4 * nrp;
-    const size_t shmem = sizeof(double) * ((size_t)a.hs_doubles + (size_t)Rs * nr) + sizeof(int) * (size_t)(na_max + 2);
-    if (shmem > 96 * 1024) return HV_ERR_UNSUPPORTED;
+    // LDS: Hc staged [na4][nrp] + [S; v'] (Rs x nr) + the column list. The launch is sized for its longest record; in the big build a
+    // record whose padded layout does not fit (84 rows) uses the tight one (nrp = nr, odd Rs) inside the same carve.
+    size_t hs = (size_t)na4 * nrp, tt = (size_t)Rs * nr;
+    const size_t cap = (size_t)(big ? 160 : 96) * 1024, ints = sizeof(int) * (size_t)(na_max + 2);
+    if (big && sizeof(double) * (hs + tt) + ints > cap) { hs = (size_t)na4 * nr; tt = (size_t)(nr + 2) * nr; }
+    if (hs < 824) hs = 824;
+    a.hs_doubles = (int)hs; a.lds_doubles = (int)(hs + tt);
+    const size_t shmem = sizeof(double) * (hs + tt) + ints;
+    if (shmem > cap) return HV_ERR_UNSUPPORTED;
     static bool attr_set_dev[64] = {};
     bool &attr_set = attr_set_dev[c->p.device & 63];
     if (!attr_set) {
         HV_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void *>(ekf_sparse_gate_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+        HV_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void *>(ekf_sparse_gate_big_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set = true;
     }
     ScopedKernelTime tm(c, HV_K_EKF_GATE);
-    hipLaunchKernelGGL(ekf_sparse_gate_kernel, dim3(e->batch), dim3(SGATE_THREADS), shmem, c->stream, a);
+    if (big) hipLaunchKernelGGL(ekf_sparse_gate_big_kernel, dim3(e->batch), dim3(SGATE_THREADS), shmem, c->stream, a);
+    else     hipLaunchKernelGGL(ekf_sparse_gate_kernel, dim3(e->batch), dim3(SGATE_THREADS), shmem, c->stream, a);
     HV_HIP(c, hipGetLastError());
     return HV_OK;
 }
@@ -1665,8 +1735,13 @@ void hv_ekf_destroy(hv_ekf *h)
     void *ptrs[] = { e->m, e->P, e->P1, e->m1, e->Q, e->dydx, e->ws, e->sH, e->sv, e->sr, e->schi2, e->simu,
                      e->sstatus, e->sdrop, e->sactive, e->vuH, e->vuv, e->vupf, e->vuactive, e->vustage,
                      e->spH, e->spv, e->sppf, e->spactive, e->spcursor, e->spepoch, e->spcursor2, e->sppub, e->vurows, e->sprows,
-                     e->vuacol, e->spacol, e->err_dev };
+                     e->vuacol, e->spacol, e->err_dev, e->sideH[0], e->sideH[1], e->sidev[0], e->sidev[1], e->side_active[0], e->side_active[1], e->side_acol, e->side_dm };
     for (void *p : ptrs) if (p) (void)hipFree(p);
+    for (int k = 0; k < 2; ++k) {
+        if (e->side_stream[k]) { (void)hipStreamSynchronize(e->side_stream[k]); (void)hipStreamDestroy(e->side_stream[k]); }
+        if (e->ev_fork[k]) (void)hipEventDestroy(e->ev_fork[k]);
+        if (e->ev_join[k]) (void)hipEventDestroy(e->ev_join[k]);
+    }
     delete h;
 }
 
@@ -1837,6 +1912,83 @@ static int visual_track_dev_impl(hv_ekf *h, const hv_vu_params *p, int np, const
     // r03 default: visualTrackOutlierCheck runs INSIDE the prepare launch on the active columns of H (vu_gate kernels: the Jacobian
     // of a rejected track never leaves LDS and only P(a, a) is read); updateVisualTrack then runs where the gate said INLIER, staging the
     // compact Jacobian through its column map (7 of 20 visits at most -- backend.cpp:1233-1238 -- pay the full H P + downdate).
+    // Long tracks (more than 48 rows / 22 camera poses: 12 .. 21 stereo poses): compact Jacobian (vu_compact_kernel), column-sparse gate as
+    // its own launch (ekf_sparse_gate_big_kernel: up to 96 rows) and the update as TWO block updates of at most 48 rows each on the
+    // P-resident kernel (UpdateArgs::half) -- r02 ran them on the H-from-L2 / global-workspace variants at 2 - 4x the time per launch.
+    const int ncam = a.stereo ? 2 : 1, np_short = 22 / ncam < 24 / ncam ? 22 / ncam : 24 / ncam;
+    const bool long_ok = c->knob.ekf_fused_gate != 0 && e->n <= 160 && rows > 48 && rows <= 96 && rows < HV_CHI2INV95_N && (rows + 3) / 4 * 2 <= 48;
+    auto long_chain = [&](hv::VuPrepareArgs l_, double *Hc, double *vv, int *acol, unsigned char *act, double *dm) -> int {
+        l_.fused = 2; l_.H = nullptr; l_.Hc = Hc; l_.v = vv; l_.acol = acol; l_.na_max = 7 * np + 1; l_.active = act; l_.chi2 = chi2_dev;
+        int rc2 = hv::launch_vu_prepare(c, l_);
+        if (rc2 != HV_OK) return rc2;
+        rc2 = hv::ekf_launch_sparse_gate(e, np, ncam, Hc, vv, acol, nr_rec, act, r_gate * r_gate * ns, chi2_dev, gate_status_dev);
+        if (rc2 != HV_OK) return rc2;
+        const int half_rows = 2 * ((rows + 3) / 4);            // the longer of the two blocks of the longest record
+        hv::CompactH h1{acol, l_.na_max, ncam, 1, rows, dm}, h2{acol, l_.na_max, ncam, 2, rows, dm};
+        rc2 = hv::ekf_launch_update(e, half_rows, e->n, Hc, vv, nullptr, r_update * r_update * ns, 1, 0, -1, nullptr, nullptr, act, gate_status_dev,
+                                    nullptr, 0.0, nullptr, 0, 0, nullptr, 0, nullptr, nullptr, nullptr, 0, nr_rec, &h1, rows);
+        if (rc2 != HV_OK) return rc2;
+        return hv::ekf_launch_update(e, half_rows, e->n, Hc, vv, nullptr, r_update * r_update * ns, 1, 0, 1, nullptr, nullptr, act, gate_status_dev,
+                                     success_counter_dev, 0.0, nullptr, 0, 0, nullptr, 0, nullptr, nullptr, nullptr, 0, nr_rec, &h2, rows);
+    };
+    auto ensure_side = [&]() -> int {                          // second stream + buffers of the long-track chain
+        if (!e->side_stream[0]) {
+            HV_HIP(c, hipStreamCreateWithFlags(&e->side_stream[0], hipStreamNonBlocking));
+            HV_HIP(c, hipEventCreateWithFlags(&e->ev_fork[0], hipEventDisableTiming));
+            HV_HIP(c, hipEventCreateWithFlags(&e->ev_join[0], hipEventDisableTiming));
+        }
+        if (e->side_rows[0] < rows) {
+            HV_HIP(c, hipStreamSynchronize(c->stream));
+            HV_HIP(c, hipStreamSynchronize(e->side_stream[0]));
+            if (e->sideH[0]) (void)hipFree(e->sideH[0]);
+            if (e->sidev[0]) (void)hipFree(e->sidev[0]);
+            e->sideH[0] = e->sidev[0] = nullptr; e->side_rows[0] = 0;
+            HV_HIP(c, hipMalloc(reinterpret_cast<void **>(&e->sideH[0]), sizeof(double) * (size_t)rows * e->n * e->batch));
+            HV_HIP(c, hipMalloc(reinterpret_cast<void **>(&e->sidev[0]), sizeof(double) * (size_t)rows * e->batch));
+            if (!e->side_active[0]) HV_HIP(c, hipMalloc(reinterpret_cast<void **>(&e->side_active[0]), e->batch));
+            if (!e->side_acol) HV_HIP(c, hipMalloc(reinterpret_cast<void **>(&e->side_acol), sizeof(int) * (size_t)e->n * e->batch));
+            if (!e->side_dm) HV_HIP(c, hipMalloc(reinterpret_cast<void **>(&e->side_dm), sizeof(double) * (size_t)e->n * e->batch));
+            e->side_rows[0] = rows;
+        }
+        return HV_OK;
+    };
+    // Ragged batch with long AND short tracks: two length CLASSES per visit. The short tracks -- 4 of 5 at the reference's defaults, see
+    // bench.py sample_track_lengths -- run on the fused two-per-CU kernels, the long ones through the chain above on a side stream
+    // next to them (fork at the start of the visit, join at its end; HIP-graph capturable): the records of a visit belong to different
+    // filters, so the two launch sequences are independent. Every launch skips the other class's records (VuPrepareArgs::np_lo /
+    // np_hi, `active`).
+    if (np_rec_dev && np > np_short && long_ok && hv::vu_fused_supported(c, e->n, np_short, a.stereo, e->batch)) {
+        rc = ensure_side();
+        if (rc != HV_OK) return rc;
+        hipStream_t main_stream = c->stream;
+        HV_HIP(c, hipEventRecord(e->ev_fork[0], main_stream));  // fork: the side stream sees everything the main stream has done so far
+        HV_HIP(c, hipStreamWaitEvent(e->side_stream[0], e->ev_fork[0], 0));
+        hv::VuPrepareArgs s_ = a;                              // class "short": 2 .. np_short poses (and the records without a track)
+        s_.np_lo = 2; s_.np_hi = np_short; s_.class_inactive = 1;
+        s_.fused = 1; s_.H = nullptr; s_.Hc = e->vuH; s_.acol = e->vuacol; s_.na_max = 7 * np + 1; s_.P = e->P;
+        s_.rd_gate = r_gate * r_gate * ns; s_.noise_scale = ns; s_.chi2 = chi2_dev;
+        rc = hv::launch_vu_prepare(c, s_);
+        const hv::CompactH ch{e->vuacol, s_.na_max, ncam};
+        if (rc == HV_OK)
+            rc = hv::ekf_launch_update(e, 2 * np_short * ncam, e->n, e->vuH, e->vuv, nullptr, r_update * r_update * ns, 1, 0, 1, nullptr, nullptr,
+                                       e->vuactive, gate_status_dev, success_counter_dev, 0.0, nullptr, 0, 0, nullptr, 0, nullptr, nullptr,
+                                       nullptr, 0, nr_rec, &ch, rows);
+        if (rc == HV_OK) {
+            c->stream = e->side_stream[0];
+            hv::VuPrepareArgs l_ = a;
+            l_.np_lo = np_short + 1; l_.np_hi = np; l_.class_inactive = 1;
+            rc = long_chain(l_, e->sideH[0], e->sidev[0], e->side_acol, e->side_active[0], e->side_dm);
+            c->stream = main_stream;
+        }
+        (void)hipEventRecord(e->ev_join[0], e->side_stream[0]);  // join (also on an error path: a captured graph must not keep a dangling fork)
+        (void)hipStreamWaitEvent(main_stream, e->ev_join[0], 0);
+        return rc;
+    }
+    if (long_ok && np > np_short) {                            // every record of the launch may be long (uniform 12 .. 21 stereo poses, or ragged)
+        rc = ensure_side();
+        if (rc != HV_OK) return rc;
+        return long_chain(a, e->vuH, e->vuv, e->vuacol, e->vuactive, e->side_dm);
+    }
     if (hv::vu_fused_supported(c, e->n, np, a.stereo, e->batch)) {
         // knob ekf_fused_gate: -1 auto / 1 = the gate inside the prepare launch (vu_gate kernels); 2 = its own launch (vu_compact kernels +
         // ekf_sparse_gate_kernel, three 43 KB workgroups per CU). Measured at 1024 filters x 10 stereo poses (r03, scripts/vu_microbench.py):

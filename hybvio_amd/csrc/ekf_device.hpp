@@ -151,7 +151,9 @@ __device__ __forceinline__ void factor_diag_block(double *T, double *W, double *
 // ---------------------------------------------------------------------------------------------
 // PIPE: the P values of an item rotate through one register buffer with the NEXT item's loads issued behind each MFMA (standalone gate
 // kernel, ~110 VGPRs); !PIPE: chunks of 10 k-steps, double buffered (the fused prepare + gate kernel, which lives on 128 VGPRs).
-template <int TI, int NT, bool PIPE>
+// TIGHT: the staged Hc has nrp = nr rows per column instead of 16 TI (the 84-row track of 21 stereo poses: Hc alone is 100 KB), reads of the
+// last row tile are predicated instead of meeting zero padding.
+template <int TI, int NT, bool PIPE, bool TIGHT = false>
 __device__ __forceinline__ double sparse_gate(const double *P, int n, const int *acol, int na, const double *Hs, double *T, int Rs, int nr,
                                               double rd, double noise_scale, double *work, long long *stamps = nullptr)
 {
@@ -162,10 +164,16 @@ __device__ __forceinline__ double sparse_gate(const double *P, int n, const int 
 #endif
     const int t = threadIdx.x, lane = t & 63, kq = lane >> 4, cl = lane & 15;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
-    constexpr int nwaves = NT / 64, nrp = 16 * TI;
+    constexpr int nwaves = NT / 64;
     // the shape is the same for every lane: keep it on the scalar unit (the callers' values come out of per-lane loads)
     n = __builtin_amdgcn_readfirstlane(n); na = __builtin_amdgcn_readfirstlane(na); nr = __builtin_amdgcn_readfirstlane(nr);
     Rs = __builtin_amdgcn_readfirstlane(Rs);
+    const int nrp = TIGHT ? nr : 16 * TI;
+    // row `r0 + cl` of a 16-row tile of Hs: in TIGHT layouts the last tile ends at nr (rows beyond it belong to the next column)
+    auto hs_at = [&](const double *col_k, int r0) -> double {
+        if constexpr (TIGHT) { const int r = r0 + cl; const double x = col_k[min(r, nr - 1)]; return r < nr ? x : 0.0; }
+        else return col_k[r0 + cl];
+    };
     const int nJ = (na + 15) >> 4, nk = (na + 3) >> 2, na4 = 4 * nk;
     // Work items (J, ct): the 16-row block J of P(a, a) against the 16-column tile ct of Hc' -- nk + 4 (TI - ct) MFMAs (64 cycles each on a
     // SIMD's matrix pipe), item = ct * nJ + J (the dearer tiles first). They are dealt to the waves BY SIMD (wave w runs on SIMD w % 4): a
@@ -186,7 +194,7 @@ __device__ __forceinline__ double sparse_gate(const double *P, int n, const int 
             double ha[TI];
 #pragma unroll
             for (int rt = 0; rt < TI; rt++) {
-                const double x = Hs[(size_t)min(idx, na4 - 1) * nrp + 16 * rt + cl];
+                const double x = hs_at(Hs + (size_t)min(idx, na4 - 1) * nrp, 16 * rt);
                 ha[rt] = idx < na4 ? x : 0.0;
             }
 #pragma unroll
@@ -225,20 +233,20 @@ __device__ __forceinline__ double sparse_gate(const double *P, int n, const int 
             const int itn = it + stride;
             const bool has_next = itn < n_items;                               // (wave-uniform)
             const int aj_next = acol[min(16 * ((has_next ? itn : it) % nJ) + cl, na - 1)];
-            const double *hb_base = Hs + (size_t)kq * nrp + 16 * ct + cl;      // B(k, c) = Hc(16 ct + c, k)
+            const double *hb_base = Hs + (size_t)kq * nrp;                     // B(k, c) = Hc(16 ct + c, k): column 4 s + kq, rows 16 ct ..
             double4v accG = {0.0, 0.0, 0.0, 0.0};
             // (branch-free bodies: k-steps beyond nk multiply by a zero B operand; one uniform branch picks the body with the prefetch)
             if (has_next) {
 #pragma unroll
                 for (int u = 0; u < U; u++) {
-                    const double hb = hb_base[(size_t)(4 * min(u, nk - 1)) * nrp];
+                    const double hb = hs_at(hb_base + (size_t)(4 * min(u, nk - 1)) * nrp, 16 * ct);
                     accG = __builtin_amdgcn_mfma_f64_16x16x4f64(cur[u], u < nk ? hb : 0.0, accG, 0, 0, 0);
                     cur[u] = P[koff[u] + aj_next];
                 }
             } else {
 #pragma unroll
                 for (int u = 0; u < U; u++) {
-                    const double hb = hb_base[(size_t)(4 * min(u, nk - 1)) * nrp];
+                    const double hb = hs_at(hb_base + (size_t)(4 * min(u, nk - 1)) * nrp, 16 * ct);
                     accG = __builtin_amdgcn_mfma_f64_16x16x4f64(cur[u], u < nk ? hb : 0.0, accG, 0, 0, 0);
                 }
             }
@@ -254,7 +262,7 @@ __device__ __forceinline__ double sparse_gate(const double *P, int n, const int 
                     }
 #pragma unroll
                     for (int u = 0; u < 8; u++)
-                        accG = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u], hb_base[(size_t)(4 * min(s0 + u, nk - 1)) * nrp], accG, 0, 0, 0);
+                        accG = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u], hs_at(hb_base + (size_t)(4 * min(s0 + u, nk - 1)) * nrp, 16 * ct), accG, 0, 0, 0);
                 }
             }
             finish_item(J, ct, accG);
@@ -264,7 +272,7 @@ __device__ __forceinline__ double sparse_gate(const double *P, int n, const int 
         for (int it = wave; it < n_items; it += stride) {
             const int ct = it / nJ, J = it - ct * nJ;
             const int aj = acol[min(16 * J + cl, na - 1)];                     // row a_j of P(a, a): P(a_j, a_k) = P[a_k * n + a_j]
-            const double *hb_base = Hs + (size_t)kq * nrp + 16 * ct + cl;      // B(k, c) = Hc(16 ct + c, k)
+            const double *hb_base = Hs + (size_t)kq * nrp;                     // B(k, c) = Hc(16 ct + c, k)
             double4v accG = {0.0, 0.0, 0.0, 0.0};
             // k-steps in chunks of U, the next chunk's P values requested before this chunk's MFMAs; steps beyond nk read a clamped
             // address and contribute zero
@@ -282,7 +290,7 @@ __device__ __forceinline__ double sparse_gate(const double *P, int n, const int 
                 load_a(a1, min(s0 + U, nk));                                   // (past the end: zeros, never used)
 #pragma unroll
                 for (int u = 0; u < U; u++)
-                    accG = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[u], hb_base[(size_t)(4 * min(s0 + u, nk - 1)) * nrp], accG, 0, 0, 0);
+                    accG = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[u], hs_at(hb_base + (size_t)(4 * min(s0 + u, nk - 1)) * nrp, 16 * ct), accG, 0, 0, 0);
 #pragma unroll
                 for (int u = 0; u < U; u++) a0[u] = a1[u];
             }

@@ -141,6 +141,10 @@ struct VuPrepareArgs {
     // record) and, as an output for the gate / update launch, the per-record row counts 2 * cameras * poses (0: none)
     const int *np_rec;
     int *rows_out;
+    // length classes of a ragged launch (r03): only records with np_lo <= poses <= np_hi are processed (0, 0: all of them); the others
+    // return at once and leave every output alone -- except `active`, cleared when class_inactive is set (a second launch sequence with
+    // other kernels serves them in the same visit: short tracks on the two-per-CU fused kernels, long ones on the dense kernels)
+    int np_lo, np_hi, class_inactive;
     double *H, *v, *f, *pf;            // [batch][rows * n] column-major, [batch][rows], optional [batch][rows], [batch][3]
     int *status;                       // [batch][2]: TriangulatorStatus, PrepareVuStatus
     unsigned char *active;             // optional [batch]: 1 where both are OK

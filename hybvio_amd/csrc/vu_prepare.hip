@@ -265,6 +265,14 @@ __device__ __forceinline__ void vu_prepare_body(const VuPrepareArgs &a)
         if ((int)blockIdx.y < a.cursor[b]) return;                               // final already
         if (!quota_used && a.epoch[rec] == a.success_counter[b]) return;          // prepared against the current mean
     }
+    if (a.np_hi > 0 && np_rec >= 2 && np_rec <= a.np && (np_rec < a.np_lo || np_rec > a.np_hi)) {       // another length class serves this record
+        if (a.class_inactive && a.active && tid == 0) a.active[rec] = 0;
+        return;
+    }
+    if (a.np_hi > 0 && a.np_lo > 2 && no_track) {                 // "no track" records belong to the class that starts at 2 poses
+        if (a.class_inactive && a.active && tid == 0) a.active[rec] = 0;
+        return;
+    }
     if (quota_used) {
         // backend.cpp:1233-1238: the frame's quota of successful visual updates is used up, the loop does not visit this track
         if (tid == 0) {
@@ -817,9 +825,11 @@ __device__ __forceinline__ void vu_prepare_body(const VuPrepareArgs &a)
         double *Hc = a.Hc + rec * (size_t)rows_max * a.na_max;    // record stride: the longest track; leading dimension: this track's rows
         // work item = (compact column u < na4, row pair i < nrp / 2), i fastest: every element of the staged Hs is written exactly once
         // (zero padding in rows >= 2 nt and columns >= na), the real ones also go to HBM for the update of an inlier
-        const int hp = nrp >> 1, hp_shift = hp == 8 ? 3 : hp == 16 ? 4 : 0;       // nrp / 2 = 8, 16 or 24
-        for (int w = tid; w < na4 * hp; w += VT) {
-            const int u = hp_shift ? w >> hp_shift : w / 24, i = w - u * hp;
+        // (compact-only builds have no LDS copy to pad: their items are the real (column, pose) pairs)
+        const int wi = FUSED == 1 ? nrp >> 1 : nt, n_items = (FUSED == 1 ? na4 : na) * wi;
+        const unsigned inv_wi = (unsigned)((0x100000000ull + (unsigned)wi - 1) / (unsigned)wi);   // w / wi = umulhi(w, ceil(2^32 / wi))
+        for (int w = tid; w < n_items; w += VT) {
+            const int u = (int)__umulhi((unsigned)w, inv_wi), i = w - u * wi;
             double h0 = 0.0, h1 = 0.0;
             if (u < na && i < nt) {
                 const double *o = s_it + i * ITER_WORDS;
@@ -994,10 +1004,12 @@ int launch_vu_prepare(Ctx *c, const VuPrepareArgs &a)
     // a longer trail (cameraTrailLength > 20) is a supported filter size but not a supported track length here
     if (a.np > MAXNP || a.np * (a.stereo ? 2 : 1) > MAXP_ALL) return HV_ERR_UNSUPPORTED;
     ScopedKernelTime tm(c, HV_K_VU_PREPARE);
-    const int nt = a.np * (a.stereo ? 2 : 1);
+    const int np_sel = a.np_hi > 0 && a.np_hi < a.np ? a.np_hi : a.np;      // the longest track this launch processes (a.np stays the record stride)
+    const int nt = np_sel * (a.stereo ? 2 : 1);
     // knob vu_threads (tests / experiments): 384 / 768 forces a build where it applies
     const bool small = vu_small_build(c, nt, a.batch);
-    if (a.fused && (!vu_fused_supported(c, a.n, a.np, a.stereo, a.batch) || !a.Hc || !a.acol || (a.fused == 1 && !a.P) || a.na_max < 7 * a.np + 1)) return HV_ERR_INVALID;
+    if (a.fused == 1 && (!vu_fused_supported(c, a.n, np_sel, a.stereo, a.batch) || !a.P)) return HV_ERR_INVALID;
+    if (a.fused && (!a.Hc || !a.acol || a.na_max < 7 * a.np + 1)) return HV_ERR_INVALID;
     static bool attr_set_dev[64] = {};                       // per device: the kernels need more than the default 64 KB of dynamic LDS
     bool &attr_set = attr_set_dev[c->p.device & 63];
     if (!attr_set) {

@@ -7,8 +7,8 @@ import json
 import os
 import sys
 
-src = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/prof_r02"
-dst = sys.argv[2] if len(sys.argv) > 2 else "profiles/r02/traffic.json"
+src = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/prof_r03"
+dst = sys.argv[2] if len(sys.argv) > 2 else "profiles/r03/traffic.json"
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench  # noqa: E402
 
@@ -20,7 +20,7 @@ try:                                                   # sequences per GPU of th
 except Exception:
     pass
 val, disp = {}, {}
-for i in range(1, 5):
+for i in range(1, 7):
     path = os.path.join(src, f"pmc{i}.csv")
     if not os.path.exists(path):
         continue
@@ -40,7 +40,11 @@ if bench.L0_GRADIENTS_STORED:
     L0K, L0GRID = "pyr_level_kernel<true>", 2 * B * tiles_l0 * 256
 else:
     L0K, L0GRID = "pyr_down_l0_kernel", 2 * B * wgs_l0 * 256
-GRID = {"klt_kernel": B * NPTS * 64, L0K: L0GRID, "ekf_update_kernel": B * 512, "pyr_tail_kernel": 2 * B * 512}
+W2, H2 = (W1 + 1) // 2, (H1 + 1) // 2
+wgs_l1 = (((W2 + 3) // 4) * ((H2 + 1) // 2) + 255) // 256          # the level-1 launch of the same kernel
+GRID = {"klt_kernel": B * NPTS * 64, L0K: L0GRID, "ekf_update_kernel": B * 512, "pyr_tail_kernel": 2 * B * 512,
+        "vu_gate_kernel_2percu": B * 384, "ekf_sparse_gate_kernel": B * 256, "vu_compact_kernel_2percu": B * 384}
+GRID_L1 = 2 * B * wgs_l1 * 256
 
 
 def g(k, c):
@@ -77,6 +81,24 @@ out = {
         "hbm_bytes_per_launch": hbm(L0K), "algorithmic_bytes_per_launch": alg["pyr_l0"] * 2 * B,
         "how": f"the level-0 launch is the {L0K} dispatch with grid {L0GRID} threads (2B images)",
     },
+    "pyr_down_l0_kernel": {
+        "hbm_bytes_per_launch": hbm(L0K), "algorithmic_bytes_per_launch": alg["pyr_l0"] * 2 * B,
+        "how": f"level 0: the dispatch with grid {L0GRID} threads (2B images)",
+    },
+    "pyr_down_l0_kernel_L1": {
+        "hbm_bytes_per_launch": (lambda f, w: None if f is None or w is None else (2 * f + w) * 1024.0)(
+            val.get((L0K, GRID_L1, "FETCH_SIZE")), val.get((L0K, GRID_L1, "WRITE_SIZE"))),
+        "how": f"level 1: the dispatch of the same kernel with grid {GRID_L1} threads",
+    },
+    "vu_gate_kernel_2percu": {
+        "hbm_bytes_per_launch": hbm("vu_gate_kernel_2percu"),
+        "valu_busy_frac": frac(g("vu_gate_kernel_2percu", "SQ_ACTIVE_INST_VALU"), (g("vu_gate_kernel_2percu", "SQ_BUSY_CYCLES") or 0) * 32.0, 4.0),
+        "mfma_busy_frac": frac(g("vu_gate_kernel_2percu", "SQ_VALU_MFMA_BUSY_CYCLES"), 32.0 * (g("vu_gate_kernel_2percu", "SQ_BUSY_CYCLES") or 0)),
+        "wave_parked_frac": frac(g("vu_gate_kernel_2percu", "SQ_WAIT_ANY"), g("vu_gate_kernel_2percu", "SQ_WAVE_CYCLES")),
+        "valu_insts_per_track": frac(g("vu_gate_kernel_2percu", "SQ_INSTS_VALU"), B),
+        "mfma_insts_per_track": frac(g("vu_gate_kernel_2percu", "SQ_INSTS_MFMA"), B),
+        "how": "fused triangulation + prepareVisualUpdate + column-sparse chi2 gate, one launch per track visit (short-track class of the ragged frame loop)",
+    },
     "pyr_tail_kernel": {
         "fetch_kb_raw": g("pyr_tail_kernel", "FETCH_SIZE"), "write_kb": g("pyr_tail_kernel", "WRITE_SIZE"),
         "hbm_bytes_per_launch": hbm("pyr_tail_kernel"),
@@ -86,7 +108,7 @@ out = {
         "hbm_bytes_per_launch": hbm("ekf_update_kernel"),
         "algorithmic_bytes_per_launch_gate": B * (160 * 160 + 40 * 160) * 8,
         "algorithmic_bytes_per_launch_update": B * (2 * 160 * 160 + 40 * 160) * 8,
-        "mix": "20 mode-3 launches per frame (gate, + update where it passes: 5 of them)",
+        "mix": "updateVisualTrack of the visits the gate accepted (mode 1, compact Jacobian); most dispatches of a frame are skip launches",
         "mfma_busy_frac": frac(g("ekf_update_kernel", "SQ_VALU_MFMA_BUSY_CYCLES"), 32.0 * (g("ekf_update_kernel", "SQ_BUSY_CYCLES") or 0)),
         "mfma_insts_per_filter": frac(g("ekf_update_kernel", "SQ_INSTS_MFMA"), B),
     },

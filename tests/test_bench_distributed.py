@@ -47,3 +47,21 @@ def test_algorithmic_byte_accounting():
     assert ab["pyr_l0"] == (360_960 + 90_240 if not bench.L0_GRADIENTS_STORED else ab["pyr_l0_ref"])
     big = bench.algorithmic_bytes(1280, 720, 400)
     assert big["pyr_image"] == 6_120_000 and big["stereo_frame"] == 31_900_800
+
+
+def test_realistic_c3_workload_generator():
+    """The headline's EKF workload: track lengths 5 + Geometric(0.2) capped at the trail, GAP-like pose sets (the newest poses + one
+    older), padded records for the ragged API (bench.sample_track_lengths / make_visual_frame_realistic)."""
+    import numpy as np
+    rng = np.random.default_rng(0)
+    lens = bench.sample_track_lengths(rng, 200000)
+    assert lens.min() == 5 and lens.max() == 21 and 8.6 < lens.mean() < 9.1
+    assert 0.19 < (lens > 11).mean() < 0.23                      # the long class of the two-class visit loop (> 44 rows in stereo)
+    T1, T2, means, lens, idx, feat, vel, y = bench.make_visual_frame_realistic(np.random.default_rng(1), 96, distinct=32)
+    assert lens.shape == (bench.VISITS, 96) and idx.shape == (bench.VISITS, 96, 21) and feat.shape == (bench.VISITS, 96, 42, 2)
+    assert y.shape == (bench.VISITS, 96, 84) and means.shape == (96, 160)
+    k, b = 3, 5
+    n = int(lens[k, b])
+    assert idx[k, b, :n - 1].tolist() == list(range(n - 1)) and n - 1 <= idx[k, b, n - 1] <= 20      # newest poses + an older one
+    assert not idx[k, b, n:].any() and not feat[k, b, 2 * n:].any() and not y[k, b, 4 * n:].any()   # padding
+    assert np.array_equal(lens[:, :32], lens[:, 32:64])                                               # `distinct` filters, tiled

@@ -237,14 +237,18 @@ def test_parameters_reach_the_kernel(oracle):
             assert 5 in statuses                                                        # BAD_DEPTH
 
 
-@pytest.mark.parametrize("variant", ["default", "vu384", "dense", "dense_vu384", "gate_in_prepare", "gate_own_launch", "gate_own_launch_vu384"])
-def test_visual_track_dev_prepare_gate_update_equals_the_reference_sequence(oracle, variant):
+@pytest.mark.parametrize("variant,npose", [("default", 9), ("vu384", 9), ("dense", 9), ("dense_vu384", 9), ("gate_in_prepare", 9), ("gate_own_launch", 9),
+                                           ("gate_own_launch_vu384", 9),
+                                           # long tracks (49 .. 84 rows): compact Jacobian + ekf_sparse_gate_big_kernel + two block updates (r03);
+                                           # `dense`: r02's H-from-L2 / global-workspace kernels
+                                           ("default", 13), ("default", 16), ("default", 20), ("default", 21), ("dense", 21), ("default", 12)])
+def test_visual_track_dev_prepare_gate_update_equals_the_reference_sequence(oracle, variant, npose):
     """hv_ekf_visual_track_dev = backend.cpp:1063-1185 for one track per filter: prepare from the device mean, gate with
     trackChiTestOutlierR, update with visualR only where triangulation, prepare and gate pass. Filters that fail stay
     bit-identical; the others match the oracle's EKF to 1e-9 relative."""
     import torch
-    rng = np.random.default_rng(11)
-    B, trail_len, npose = 24, 20, 9
+    rng = np.random.default_rng(11 + npose)
+    B, trail_len = 24, 20
     T1, T2, means, idx, feat, vel = _random_tracks(oracle, rng, B, trail_len, npose, True, bad_fraction=0.3)
     y = feat.reshape(B, -1) + 2e-3 * rng.normal(size=(B, feat.shape[1] * 2))
     y[3:12] += 3.0                                                                      # triangulable tracks the gate must reject
@@ -429,18 +433,22 @@ def test_whole_frame_loop_in_one_call(oracle, B, speculative, variant):
         g.close()
 
 
-@pytest.mark.parametrize("B,speculative,stereo,variant", [(10, True, True, "default"), (48, False, True, "default"), (9, True, False, "default"),
-                                                          (10, True, True, "spec3"), (48, False, True, "vu384"), (48, False, True, "dense"),
-                                                          (9, True, False, "spec2_vu384"), (48, False, False, "vu384"),
-                                                          (48, False, True, "gate_own_launch_vu384"), (48, False, False, "gate_own_launch")])
-def test_whole_frame_loop_with_ragged_track_lengths(oracle, B, speculative, stereo, variant):
+@pytest.mark.parametrize("B,speculative,stereo,variant,np_max", [
+    (10, True, True, "default", 10), (48, False, True, "default", 10), (9, True, False, "default", 10), (10, True, True, "spec3", 10),
+    (48, False, True, "vu384", 10), (48, False, True, "dense", 10), (9, True, False, "spec2_vu384", 10), (48, False, False, "vu384", 10),
+    (48, False, True, "gate_own_launch_vu384", 10), (48, False, False, "gate_own_launch", 10),
+    # tracks of up to 21 poses: stereo batches split into a short class (fused two-per-CU kernels, <= 11 poses) and a long
+    # class (dense kernels) per visit; mono tracks of 21 poses still fit the fused kernels (42 rows)
+    (48, False, True, "default", 21), (48, False, True, "vu384", 21), (10, False, True, "default", 21), (48, False, False, "default", 21),
+    (48, False, True, "dense", 21)])
+def test_whole_frame_loop_with_ragged_track_lengths(oracle, B, speculative, stereo, variant, np_max):
     """hv_ekf_visual_frame_ragged_dev: the sequences of a batch do not share track lengths -- every (visit, filter) record has its own
     pose count (2 .. n_poses_max, 0 = this filter has no candidate at this visit), padded to the longest. Result = the reference's
     sequential loop run per filter over its own tracks."""
     import torch
     rng = np.random.default_rng(77 + B)
-    trail_len, np_max, K, quota = 20, 10, 8, 3
-    assert (B * K <= 256) == speculative
+    trail_len, K, quota = 20, 8, 3
+    assert (B * K <= 256 and 2 * np_max * (2 if stereo else 1) <= 48) == speculative
     T1, T2, means, _, _, _ = _random_tracks(oracle, rng, B, trail_len, 6, stereo, bad_fraction=0.0)
     ncam = 2 if stereo else 1
     lens = rng.integers(2, np_max + 1, (K, B)).astype(np.int32)
@@ -503,6 +511,8 @@ def test_whole_frame_loop_with_ragged_track_lengths(oracle, B, speculative, ster
             mg, Pg = g.get_state(b)
             assert _rel(mg, o.m) < 1e-8 and _rel(Pg, o.P) < 1e-7, (b, _rel(mg, o.m), _rel(Pg, o.P))
         assert applied > B // 2 and rejected > 0 and len(lengths_applied) >= 3, (applied, rejected, lengths_applied)
+        if np_max > 12:
+            assert max(lengths_applied) > 12 and min(lengths_applied) < 12, lengths_applied
         g.close()
 
 
