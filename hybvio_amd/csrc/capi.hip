@@ -18,7 +18,7 @@ const KnobEntry KNOB_TABLE[] = {
     {"ekf_no_speculation", &Knobs::ekf_no_speculation}, {"ekf_stream_gate", &Knobs::ekf_stream_gate},
     {"ekf_gate_kmode", &Knobs::ekf_gate_kmode}, {"ingest_gather", &Knobs::ingest_gather},
     {"ekf_fused_gate", &Knobs::ekf_fused_gate}, {"ekf_spec_mode", &Knobs::ekf_spec_mode},
-    {"rot_ransac_threads", &Knobs::rot_ransac_threads},
+    {"rot_ransac_threads", &Knobs::rot_ransac_threads}, {"ekf_persistent", &Knobs::ekf_persistent}, {"ekf_side_stream", &Knobs::ekf_side_stream},
 };
 }  // namespace
 
@@ -278,6 +278,7 @@ int hv_create(const hv_params *params, hv_ctx **out)
     int rc = HV_OK;
     do {
         if (hipSetDevice(p.device) != hipSuccess) { rc = HV_ERR_NO_DEVICE; break; }
+        { hipDeviceProp_t prop; if (hipGetDeviceProperties(&prop, p.device) == hipSuccess && prop.multiProcessorCount > 0) c->num_cus = prop.multiProcessorCount; }
         if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { rc = HV_ERR_HIP; break; }
         c->own_stream = true;
         const size_t slab_bytes = (size_t)c->L.slot_bytes * p.pool_size + hv::SLAB_SLACK;

@@ -418,6 +418,9 @@ struct UpdateArgs {
     // normalisation; half 2 reads it (dm_in) and normalises. 0 = the whole record in one launch. Compact H, MODE 2 only.
     int half, nr_full;                // nr_full: rows of the whole record when neither nr_rec nor nr says so (uniform long tracks)
     double *dm_out; const double *dm_in;   // [batch][n]
+    int persistent, batch;            // persistent launch: grid = CUs, the workgroups pull filters from `queue` (HV_QUEUE_LOOP)
+    int *queue; int q_off;
+    const int *rec_count, *rec_list;  // compaction list (VuPrepareArgs): workgroup i updates filter rec_list[i], i < *rec_count; the others exit
 };
 
 // spec 3 hand-shake between the workgroups of one filter (agent scope: they run on different CUs)
@@ -454,11 +457,10 @@ constexpr int UPD_THREADS = 512;   // 8 waves = 2 per SIMD: 256 VGPRs each (whol
 // TI (MODE 2 only): 16-row tiles of H, nr <= 16 TI: a compile-time count keeps the MFMA loops free of
 // branches (a uniform branch per tile made hipcc wait for each LDS operand right before its MFMA).
 template <int MODE, int TI>
-__global__ __launch_bounds__(UPD_THREADS) void ekf_update_kernel(UpdateArgs a)
+__device__ __forceinline__ void ekf_update_body(const UpdateArgs &a, const int b /* filter: blockIdx.x, or the loop variable of a persistent launch */)
 {
     constexpr bool USE_LDS = MODE >= 1;
     extern __shared__ __attribute__((aligned(16))) double smem[];
-    const int b = blockIdx.x;
     int e = b;                                             // record of this workgroup's H, v, active, chi2, status
     int sel = -1;
     if (a.spec == 1) {
@@ -957,6 +959,17 @@ __global__ __launch_bounds__(UPD_THREADS) void ekf_update_kernel(UpdateArgs a)
     if (a.spec == 3 && t == 0) a.cursor_out[b] = (int)blockIdx.y + 1;
 }
 
+template <int MODE, int TI>
+__global__ __launch_bounds__(UPD_THREADS) void ekf_update_kernel(UpdateArgs a)
+{
+    // persistent form (launches that skip most filters: block updates of the long class, updates of the few inliers of a visit): one
+    // workgroup per CU walks the batch instead of 4 x as many workgroups queueing for a CU-sized LDS slot just to find out they have no work
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    if (a.persistent) HV_QUEUE_LOOP(a.queue, a.batch, reinterpret_cast<int *>(reinterpret_cast<char *>(smem) + a.q_off), (ekf_update_body<MODE, TI>(a, b_)));
+    else if (a.rec_list) { if ((int)blockIdx.x < *a.rec_count) ekf_update_body<MODE, TI>(a, a.rec_list[blockIdx.x]); }
+    else ekf_update_body<MODE, TI>(a, blockIdx.x);
+}
+
 // ---------------------------------------------------------------------------------------------
 // chi2 gate for MANY filters at once (throughput launches): S = H P H' + R without ever holding H P.
 //
@@ -1138,6 +1151,10 @@ struct SparseGateArgs {
     double *chi2; int *status;        // chi2 optional
     int hs_doubles;                   // LDS carve: doubles reserved for the staged Hc (>= 816 + 4: it is the Cholesky scratch afterwards)
     int lds_doubles;                  // doubles available for Hc + [S; v'] together (BIG build: decides between the padded and the tight layout)
+    int persistent, batch;
+    int *queue; int q_off;
+    const int *rec_count, *rec_list;  // this launch's records (compaction list of the long class), or null
+    int *inl_count, *inl_list;        // appended: records whose gate said INLIER
 };
 
 constexpr int SGATE_THREADS = 256;
@@ -1146,10 +1163,10 @@ constexpr int SGATE_THREADS = 256;
 // poses: 13 .. 21 poses x 4 rows), one workgroup per CU with the whole register file, Hc staged with nrp = 16 TI rows per column where that
 // fits 160 KB together with [S; v'] and with exactly nr rows (TIGHT) where it does not (84 rows: 99.5 + 58.5 KB).
 template <bool BIG>
-__device__ __forceinline__ void sparse_gate_kernel_body(const SparseGateArgs &a)
+__device__ __forceinline__ void sparse_gate_kernel_body(const SparseGateArgs &a, const int b)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
-    const int b = blockIdx.x, t = threadIdx.x;
+    const int t = threadIdx.x;
     if (!a.active[b]) return;                                  // status stays NOT_COMPUTED (preset by the prepare launch)
     int nr = a.nr_rec ? a.nr_rec[b] : a.nr;
     nr = __builtin_amdgcn_readfirstlane(nr);
@@ -1206,12 +1223,19 @@ __device__ __forceinline__ void sparse_gate_kernel_body(const SparseGateArgs &a)
         const bool broken = !(chi < 1e300);                    // non-positive pivot: reported as CHI2 (ekf_update_kernel phase D)
         const int outlier = broken || ((nr < HV_CHI2INV95_N) ? (chi > d_chi2inv95[nr]) : 0);
         a.status[b] = outlier ? 3 /*CHI2*/ : 0 /*INLIER*/;
+        if (!outlier && a.inl_list) a.inl_list[atomicAdd(a.inl_count, 1)] = b;
         if (a.chi2) a.chi2[b] = chi;
     }
 }
 
-__global__ __launch_bounds__(SGATE_THREADS, 3) void ekf_sparse_gate_kernel(SparseGateArgs a) { sparse_gate_kernel_body<false>(a); }
-__global__ __launch_bounds__(SGATE_THREADS, 1) void ekf_sparse_gate_big_kernel(SparseGateArgs a) { sparse_gate_kernel_body<true>(a); }
+__global__ __launch_bounds__(SGATE_THREADS, 3) void ekf_sparse_gate_kernel(SparseGateArgs a) { sparse_gate_kernel_body<false>(a, blockIdx.x); }
+__global__ __launch_bounds__(SGATE_THREADS, 1) void ekf_sparse_gate_big_kernel(SparseGateArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    if (a.persistent) HV_QUEUE_LOOP(a.queue, a.batch, reinterpret_cast<int *>(reinterpret_cast<char *>(smem) + a.q_off), (sparse_gate_kernel_body<true>(a, b_)));     // (see ekf_update_kernel)
+    else if (a.rec_list) { if ((int)blockIdx.x < *a.rec_count) sparse_gate_kernel_body<true>(a, a.rec_list[blockIdx.x]); }
+    else sparse_gate_kernel_body<true>(a, blockIdx.x);
+}
 
 // ---------------------------------------------------------------------------------------------
 // pose augmentation / undo (ekf.cpp:848-903) and housekeeping
@@ -1559,11 +1583,13 @@ struct Ekf {
     int side_rows[2] = {0, 0};
     int *side_acol = nullptr; double *side_dm = nullptr;
     int *err_dev = nullptr;                               // device error word (UpdateArgs::err)
+    int *queue_dev = nullptr;                             // work queue of the persistent launches (HV_QUEUE_LOOP), zero between launches
+    int *visit_counts = nullptr, *visit_lists = nullptr;  // compaction lists of a visit: counts {inliers short, long records, inliers long}, lists 3 x [batch]
 };
 
 // compact-H description handed to ekf_launch_update (null acol: dense H of l columns); half / nr_full / dm: block update of a long
 // track (UpdateArgs::half)
-struct CompactH { const int *acol = nullptr; int na_max = 0, ncam = 1; int half = 0, nr_full = 0; double *dm = nullptr; };
+struct CompactH { const int *acol = nullptr; int na_max = 0, ncam = 1; int half = 0, nr_full = 0; double *dm = nullptr; const int *rec_count = nullptr, *rec_list = nullptr; };
 
 static int ekf_launch_update(Ekf *e, int nr, int l, const double *H_dev, const double *v_dev, const double *rdiag_dev,
                              double rd0, int mode, int generic, int normalize_all, double *chi2_dev, int *status_dev,
@@ -1600,6 +1626,7 @@ static int ekf_launch_update(Ekf *e, int nr, int l, const double *H_dev, const d
         a.half = compact->half; a.nr_full = compact->nr_full;
         if (a.half == 1) a.dm_out = compact->dm;
         if (a.half == 2) a.dm_in = compact->dm;
+        a.rec_count = compact->rec_count; a.rec_list = compact->rec_list;
     }
     size_t tall = (((size_t)a.Rs * nr + 1) & ~(size_t)1) * sizeof(double);
     const size_t small = (size_t)(256 + 544 + UPD_THREADS / 64 + 2) * sizeof(double);           // W + col (incl. dump area) + red + flag
@@ -1631,7 +1658,12 @@ static int ekf_launch_update(Ekf *e, int nr, int l, const double *H_dev, const d
         attr_set = true;
     }
     ScopedKernelTime tm(c, HV_K_EKF_UPDATE);
-    hipLaunchKernelGGL(kern, dim3(e->batch, (spec == 1 || spec == 3) ? n_tracks : 1), dim3(UPD_THREADS), shmem, c->stream, a);
+    a.batch = e->batch;
+    a.queue = e->queue_dev;
+    a.persistent = (c->knob.ekf_persistent == 1 && !a.rec_list && !spec && kmode == 2 && (active_dev || require_inlier_dev) && e->batch > c->num_cus) ? 1 : 0;
+    if (a.persistent && shmem + 16 > 160 * 1024) a.persistent = 0;
+    if (a.persistent) { a.q_off = (int)((shmem + 15) & ~(size_t)15); hipLaunchKernelGGL(kern, dim3((unsigned)c->num_cus), dim3(UPD_THREADS), (size_t)a.q_off + 16, c->stream, a); }
+    else hipLaunchKernelGGL(kern, dim3(e->batch, (spec == 1 || spec == 3) ? n_tracks : 1), dim3(UPD_THREADS), shmem, c->stream, a);
     HV_HIP(c, hipGetLastError());
     return HV_OK;
 }
@@ -1672,7 +1704,8 @@ static int ekf_launch_gate_stream(Ekf *e, int nr, int l, const double *H_dev, co
 
 // ekf_sparse_gate_kernel over the compact records of a prepare launch (np = poses of the longest record)
 static int ekf_launch_sparse_gate(Ekf *e, int np, int ncam, const double *Hc_dev, const double *v_dev, const int *acol_dev, const int *nr_rec_dev,
-                                  const unsigned char *active_dev, double rd, double *chi2_dev, int *status_dev)
+                                  const unsigned char *active_dev, double rd, double *chi2_dev, int *status_dev,
+                                  const int *rec_count = nullptr, const int *rec_list = nullptr, int *inl_count = nullptr, int *inl_list = nullptr)
 {
     Ctx *c = e->c;
     const int nr = 2 * np * ncam, na_max = 7 * np + 1, na4 = (na_max + 3) & ~3, nrp = 16 * ((nr + 15) / 16);
@@ -1700,7 +1733,11 @@ static int ekf_launch_sparse_gate(Ekf *e, int np, int ncam, const double *Hc_dev
         attr_set = true;
     }
     ScopedKernelTime tm(c, HV_K_EKF_GATE);
-    if (big) hipLaunchKernelGGL(ekf_sparse_gate_big_kernel, dim3(e->batch), dim3(SGATE_THREADS), shmem, c->stream, a);
+    a.rec_count = rec_count; a.rec_list = rec_list; a.inl_count = inl_count; a.inl_list = inl_list;
+    a.batch = e->batch; a.queue = e->queue_dev; a.persistent = c->knob.ekf_persistent == 1 && !rec_list && big && e->batch > c->num_cus && shmem + 32 <= cap ? 1 : 0;
+    a.q_off = (int)((shmem + 15) & ~(size_t)15);
+    if (big) hipLaunchKernelGGL(ekf_sparse_gate_big_kernel, dim3((unsigned)(a.persistent ? c->num_cus : e->batch)), dim3(SGATE_THREADS),
+                                a.persistent ? (size_t)a.q_off + 16 : shmem, c->stream, a);
     else     hipLaunchKernelGGL(ekf_sparse_gate_kernel, dim3(e->batch), dim3(SGATE_THREADS), shmem, c->stream, a);
     HV_HIP(c, hipGetLastError());
     return HV_OK;
@@ -1735,7 +1772,7 @@ void hv_ekf_destroy(hv_ekf *h)
     void *ptrs[] = { e->m, e->P, e->P1, e->m1, e->Q, e->dydx, e->ws, e->sH, e->sv, e->sr, e->schi2, e->simu,
                      e->sstatus, e->sdrop, e->sactive, e->vuH, e->vuv, e->vupf, e->vuactive, e->vustage,
                      e->spH, e->spv, e->sppf, e->spactive, e->spcursor, e->spepoch, e->spcursor2, e->sppub, e->vurows, e->sprows,
-                     e->vuacol, e->spacol, e->err_dev, e->sideH[0], e->sideH[1], e->sidev[0], e->sidev[1], e->side_active[0], e->side_active[1], e->side_acol, e->side_dm };
+                     e->vuacol, e->spacol, e->err_dev, e->sideH[0], e->sideH[1], e->sidev[0], e->sidev[1], e->side_active[0], e->side_active[1], e->side_acol, e->side_dm, e->queue_dev, e->visit_counts, e->visit_lists };
     for (void *p : ptrs) if (p) (void)hipFree(p);
     for (int k = 0; k < 2; ++k) {
         if (e->side_stream[k]) { (void)hipStreamSynchronize(e->side_stream[k]); (void)hipStreamDestroy(e->side_stream[k]); }
@@ -1769,8 +1806,10 @@ int hv_ekf_create(hv_ctx *ctx, const hv_ekf_params *par, int batch, hv_ekf **out
     alloc(e->sH, sizeof(double) * e->sH_cap); alloc(e->sv, sizeof(double) * n * batch); alloc(e->sr, sizeof(double) * batch);
     alloc(e->schi2, sizeof(double) * batch); alloc(e->simu, sizeof(double) * 7 * HV_EKF_MAX_PREDICT_SAMPLES * batch);
     alloc(e->sstatus, sizeof(int) * batch); alloc(e->sdrop, sizeof(int) * batch); alloc(e->sactive, batch);
-    alloc(e->err_dev, sizeof(int));
+    alloc(e->err_dev, sizeof(int)); alloc(e->queue_dev, 2 * sizeof(int));
+    alloc(e->visit_counts, 4 * sizeof(int)); alloc(e->visit_lists, 3 * sizeof(int) * (size_t)batch);
     if (ok && hipMemset(e->err_dev, 0, sizeof(int)) != hipSuccess) ok = false;
+    if (ok && hipMemset(e->queue_dev, 0, 2 * sizeof(int)) != hipSuccess) ok = false;
     if (!ok) { hv_ekf_destroy(h); return HV_ERR_NOMEM; }
 
     // initial state and covariance: EKFImplementation ctor, ekf.cpp:153-296
@@ -1917,14 +1956,20 @@ static int visual_track_dev_impl(hv_ekf *h, const hv_vu_params *p, int np, const
     // P-resident kernel (UpdateArgs::half) -- r02 ran them on the H-from-L2 / global-workspace variants at 2 - 4x the time per launch.
     const int ncam = a.stereo ? 2 : 1, np_short = 22 / ncam < 24 / ncam ? 22 / ncam : 24 / ncam;
     const bool long_ok = c->knob.ekf_fused_gate != 0 && e->n <= 160 && rows > 48 && rows <= 96 && rows < HV_CHI2INV95_N && (rows + 3) / 4 * 2 <= 48;
-    auto long_chain = [&](hv::VuPrepareArgs l_, double *Hc, double *vv, int *acol, unsigned char *act, double *dm) -> int {
+    // compaction lists of this visit (VuPrepareArgs): zeroed here, filled by the kernels, consumed by the launches behind them
+    int *cnt_inl = e->visit_counts, *cnt_long = e->visit_counts + 1, *cnt_inl_long = e->visit_counts + 2;
+    int *list_inl = e->visit_lists, *list_long = e->visit_lists + e->batch, *list_inl_long = e->visit_lists + 2 * (size_t)e->batch;
+    HV_HIP(c, hipMemsetAsync(e->visit_counts, 0, 4 * sizeof(int), c->stream));
+    auto long_chain = [&](hv::VuPrepareArgs l_, double *Hc, double *vv, int *acol, unsigned char *act, double *dm, bool listed) -> int {
         l_.fused = 2; l_.H = nullptr; l_.Hc = Hc; l_.v = vv; l_.acol = acol; l_.na_max = 7 * np + 1; l_.active = act; l_.chi2 = chi2_dev;
+        if (listed) { l_.rec_count = cnt_long; l_.rec_list = list_long; }
         int rc2 = hv::launch_vu_prepare(c, l_);
         if (rc2 != HV_OK) return rc2;
-        rc2 = hv::ekf_launch_sparse_gate(e, np, ncam, Hc, vv, acol, nr_rec, act, r_gate * r_gate * ns, chi2_dev, gate_status_dev);
+        rc2 = hv::ekf_launch_sparse_gate(e, np, ncam, Hc, vv, acol, nr_rec, act, r_gate * r_gate * ns, chi2_dev, gate_status_dev,
+                                         listed ? cnt_long : nullptr, listed ? list_long : nullptr, cnt_inl_long, list_inl_long);
         if (rc2 != HV_OK) return rc2;
         const int half_rows = 2 * ((rows + 3) / 4);            // the longer of the two blocks of the longest record
-        hv::CompactH h1{acol, l_.na_max, ncam, 1, rows, dm}, h2{acol, l_.na_max, ncam, 2, rows, dm};
+        hv::CompactH h1{acol, l_.na_max, ncam, 1, rows, dm, cnt_inl_long, list_inl_long}, h2{acol, l_.na_max, ncam, 2, rows, dm, cnt_inl_long, list_inl_long};
         rc2 = hv::ekf_launch_update(e, half_rows, e->n, Hc, vv, nullptr, r_update * r_update * ns, 1, 0, -1, nullptr, nullptr, act, gate_status_dev,
                                     nullptr, 0.0, nullptr, 0, 0, nullptr, 0, nullptr, nullptr, nullptr, 0, nr_rec, &h1, rows);
         if (rc2 != HV_OK) return rc2;
@@ -1960,34 +2005,44 @@ static int visual_track_dev_impl(hv_ekf *h, const hv_vu_params *p, int np, const
     if (np_rec_dev && np > np_short && long_ok && hv::vu_fused_supported(c, e->n, np_short, a.stereo, e->batch)) {
         rc = ensure_side();
         if (rc != HV_OK) return rc;
+        // knob ekf_side_stream = 1: the long chain on a second stream next to the short one. Measured (r03, 1024 filters, rocprofv3
+        // kernel trace): the two sequences do NOT overlap usefully -- every kernel of the long chain needs a whole CU's LDS, the short
+        // chain's fused kernel fills all of it (2 x 80 KB), so their workgroups queue for each other's CUs and a visit took 700 - 900 us
+        // against ~550 us back to back. Default: one stream, short chain first.
+        const bool fork = c->knob.ekf_side_stream == 1;
         hipStream_t main_stream = c->stream;
-        HV_HIP(c, hipEventRecord(e->ev_fork[0], main_stream));  // fork: the side stream sees everything the main stream has done so far
-        HV_HIP(c, hipStreamWaitEvent(e->side_stream[0], e->ev_fork[0], 0));
+        if (fork) {
+            HV_HIP(c, hipEventRecord(e->ev_fork[0], main_stream));
+            HV_HIP(c, hipStreamWaitEvent(e->side_stream[0], e->ev_fork[0], 0));
+        }
         hv::VuPrepareArgs s_ = a;                              // class "short": 2 .. np_short poses (and the records without a track)
         s_.np_lo = 2; s_.np_hi = np_short; s_.class_inactive = 1;
         s_.fused = 1; s_.H = nullptr; s_.Hc = e->vuH; s_.acol = e->vuacol; s_.na_max = 7 * np + 1; s_.P = e->P;
         s_.rd_gate = r_gate * r_gate * ns; s_.noise_scale = ns; s_.chi2 = chi2_dev;
+        s_.inl_count = cnt_inl; s_.inl_list = list_inl; s_.long_count = cnt_long; s_.long_list = list_long;
         rc = hv::launch_vu_prepare(c, s_);
-        const hv::CompactH ch{e->vuacol, s_.na_max, ncam};
+        const hv::CompactH ch{e->vuacol, s_.na_max, ncam, 0, 0, nullptr, cnt_inl, list_inl};
         if (rc == HV_OK)
             rc = hv::ekf_launch_update(e, 2 * np_short * ncam, e->n, e->vuH, e->vuv, nullptr, r_update * r_update * ns, 1, 0, 1, nullptr, nullptr,
                                        e->vuactive, gate_status_dev, success_counter_dev, 0.0, nullptr, 0, 0, nullptr, 0, nullptr, nullptr,
                                        nullptr, 0, nr_rec, &ch, rows);
         if (rc == HV_OK) {
-            c->stream = e->side_stream[0];
+            if (fork) c->stream = e->side_stream[0];
             hv::VuPrepareArgs l_ = a;
-            l_.np_lo = np_short + 1; l_.np_hi = np; l_.class_inactive = 1;
-            rc = long_chain(l_, e->sideH[0], e->sidev[0], e->side_acol, e->side_active[0], e->side_dm);
+            l_.np_lo = np_short + 1; l_.np_hi = np; l_.class_inactive = 1; l_.persistent = c->knob.ekf_persistent == 1 ? 1 : 0; l_.queue = e->queue_dev;
+            rc = long_chain(l_, e->sideH[0], e->sidev[0], e->side_acol, e->side_active[0], e->side_dm, true);
             c->stream = main_stream;
         }
-        (void)hipEventRecord(e->ev_join[0], e->side_stream[0]);  // join (also on an error path: a captured graph must not keep a dangling fork)
-        (void)hipStreamWaitEvent(main_stream, e->ev_join[0], 0);
+        if (fork) {
+            (void)hipEventRecord(e->ev_join[0], e->side_stream[0]);  // join (also on an error path: a captured graph must not keep a dangling fork)
+            (void)hipStreamWaitEvent(main_stream, e->ev_join[0], 0);
+        }
         return rc;
     }
     if (long_ok && np > np_short) {                            // every record of the launch may be long (uniform 12 .. 21 stereo poses, or ragged)
         rc = ensure_side();
         if (rc != HV_OK) return rc;
-        return long_chain(a, e->vuH, e->vuv, e->vuacol, e->vuactive, e->side_dm);
+        return long_chain(a, e->vuH, e->vuv, e->vuacol, e->vuactive, e->side_dm, false);
     }
     if (hv::vu_fused_supported(c, e->n, np, a.stereo, e->batch)) {
         // knob ekf_fused_gate: -1 auto / 1 = the gate inside the prepare launch (vu_gate kernels); 2 = its own launch (vu_compact kernels +
@@ -1999,13 +2054,15 @@ static int visual_track_dev_impl(hv_ekf *h, const hv_vu_params *p, int np, const
         const bool split_gate = fg == 2;
         a.fused = split_gate ? 2 : 1; a.H = nullptr; a.Hc = e->vuH; a.acol = e->vuacol; a.na_max = 7 * np + 1; a.P = e->P;
         a.rd_gate = r_gate * r_gate * ns; a.noise_scale = ns; a.chi2 = chi2_dev;
+        if (!split_gate) { a.inl_count = cnt_inl; a.inl_list = list_inl; }
         rc = hv::launch_vu_prepare(c, a);
         if (rc != HV_OK) return rc;
         if (split_gate) {
-            rc = hv::ekf_launch_sparse_gate(e, np, a.stereo ? 2 : 1, e->vuH, e->vuv, e->vuacol, nr_rec, e->vuactive, a.rd_gate, chi2_dev, gate_status_dev);
+            rc = hv::ekf_launch_sparse_gate(e, np, a.stereo ? 2 : 1, e->vuH, e->vuv, e->vuacol, nr_rec, e->vuactive, a.rd_gate, chi2_dev, gate_status_dev,
+                                            nullptr, nullptr, cnt_inl, list_inl);
             if (rc != HV_OK) return rc;
         }
-        const hv::CompactH ch{e->vuacol, a.na_max, a.stereo ? 2 : 1};
+        const hv::CompactH ch{e->vuacol, a.na_max, a.stereo ? 2 : 1, 0, 0, nullptr, cnt_inl, list_inl};
         return hv::ekf_launch_update(e, rows, e->n, e->vuH, e->vuv, nullptr, r_update * r_update * ns, 1, 0, 1, nullptr, nullptr,
                                      e->vuactive, gate_status_dev, success_counter_dev, 0.0, nullptr, 0, 0, nullptr, 0, nullptr, nullptr,
                                      nullptr, 0, nr_rec, &ch);

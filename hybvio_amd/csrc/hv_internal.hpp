@@ -66,6 +66,8 @@ struct Knobs {
     int ingest_gather = 0;        // HV_INGEST_GATHER: 1 = plain gather kernel for the remap
     int ekf_fused_gate = -1;      // HV_EKF_FUSED_GATE: column-sparse chi2 gate: -1 auto = 1 inside the prepare kernel, 2 own launch (ekf_sparse_gate_kernel), 0 off (dense kernels)
     int ekf_spec_mode = -1;       // HV_EKF_SPEC_MODE: speculative pass form: -1 auto, 2 = gate launch + apply launch, 3 = one launch with hand-shake
+    int ekf_persistent = 0;       // HV_EKF_PERSISTENT: 1 = the masked one-workgroup-per-CU launches run as num_cus workgroups pulling records from a device queue instead of using the compaction lists (measured slower: the update body inside a loop runs 2.4x longer per record, r03)
+    int ekf_side_stream = 0;      // HV_EKF_SIDE_STREAM: 1 = the long-track chain of a ragged visit on a second stream (measured slower: LDS-slot contention)
     int rot_ransac_threads = 0;   // HV_ROT_RANSAC_THREADS: 0 auto (1024 threads up to 64 sets), 256 / 1024 force
 };
 int knob_set(Knobs &k, const char *name, int value);   // HV_ERR_INVALID for an unknown name
@@ -78,6 +80,7 @@ struct Ctx {
     PyrLayout L{};
     hipStream_t stream = nullptr;
     bool own_stream = false;
+    int num_cus = 256;                    // multiProcessorCount of the device (grid of the persistent launches)
     uint8_t *slab = nullptr;              // pool_size * slot_bytes
     const uint8_t **d_l0_ptr = nullptr;   // [pool_size]
     int *d_l0_stride = nullptr;           // [pool_size]
@@ -145,6 +148,15 @@ struct VuPrepareArgs {
     // return at once and leave every output alone -- except `active`, cleared when class_inactive is set (a second launch sequence with
     // other kernels serves them in the same visit: short tracks on the two-per-CU fused kernels, long ones on the dense kernels)
     int np_lo, np_hi, class_inactive;
+    // compaction lists of a visit (r03): a masked launch of big-LDS workgroups loses half its time to the inactive ones queueing for CU
+    // slots, so the kernels that find out which records need the NEXT launch append them to a list; that launch maps workgroup i to
+    // list[i] and the rest exit at once. counts are zeroed per visit by the host entry (one memset node).
+    int *inl_count, *inl_list;         // appended by the fused gate: records whose gate said INLIER (-> update launch)
+    int *long_count, *long_list;       // appended by the short class's launch: records of the long class (-> its prepare / gate launches)
+    const int *rec_count, *rec_list;   // this launch's own records (long-class prepare): workgroup i handles rec_list[i], i < *rec_count
+    int persistent;                    // one workgroup per CU pulls records from a device queue (launches that skip most records: the long class of a ragged visit)
+    int *queue;                        // persistent launches: {next record, finished workgroups}, zero between launches (the last workgroup resets it)
+    int q_off;                         // byte offset of the queue slot inside the dynamic LDS (behind everything the body uses)
     double *H, *v, *f, *pf;            // [batch][rows * n] column-major, [batch][rows], optional [batch][rows], [batch][3]
     int *status;                       // [batch][2]: TriangulatorStatus, PrepareVuStatus
     unsigned char *active;             // optional [batch]: 1 where both are OK
@@ -187,6 +199,28 @@ __device__ __forceinline__ unsigned xcd_remap(unsigned bid, unsigned nwg)
     const unsigned base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
     return base + idx;
 }
+
+// Work queue of a persistent launch: workgroups pull record numbers until the batch is exhausted; the last workgroup to leave puts the
+// two counters back to zero, so the next launch on the stream (kernels of one stream do not overlap) finds them clean -- no host-side
+// reset, HIP-graph replay safe. Dynamic on purpose: a static split (record b to workgroup b % grid) left some CUs with three long records
+// and others with none (r03: 33.8 against 20.1 ms per step).
+#define HV_QUEUE_LOOP(queue, batch, slot, body_call)   /* slot: an int in LDS outside what the body uses (the kernels' dynamic LDS may be the whole 160 KB, so a static variable is out) */ \
+    do {                                                                                              \
+        volatile int *hv_q_next = (slot);                                                             \
+        for (;;) {                                                                                    \
+            if (threadIdx.x == 0) *hv_q_next = atomicAdd(&(queue)[0], 1);                             \
+            __syncthreads();                                                                          \
+            const int b_ = *hv_q_next;                                                                \
+            __syncthreads();                                                                          \
+            if (b_ >= (batch)) break;                                                                 \
+            body_call;                                                                                \
+            __syncthreads();                                                                          \
+        }                                                                                             \
+        if (threadIdx.x == 0) {                                                                       \
+            __threadfence();                                                                          \
+            if (atomicAdd(&(queue)[1], 1) == (int)gridDim.x - 1) { (queue)[0] = 0; (queue)[1] = 0; __threadfence(); }   \
+        }                                                                                             \
+    } while (0)
 
 __device__ __forceinline__ int reflect101(int p, int len)
 {

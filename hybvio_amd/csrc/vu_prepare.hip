@@ -227,7 +227,7 @@ struct VuLds {
 // ekf_sparse_gate_kernel (many filters: three small workgroups per CU hide its Cholesky chain, which two of these cannot). In 1 and 2
 // the dense H is never written, only Hc / acol / v.
 template <int VT, int MAXP, int FUSED>
-__device__ __forceinline__ void vu_prepare_body(const VuPrepareArgs &a)
+__device__ __forceinline__ void vu_prepare_body(const VuPrepareArgs &a, const int bx /* filter: blockIdx.x, or the loop variable of a persistent launch */)
 {
     // All LDS comes from the dynamic region (carved below): with static arrays the compiler derives the occupancy from their size
     // and stops honouring the register cap that lets two of the small workgroups share a CU.
@@ -246,9 +246,9 @@ __device__ __forceinline__ void vu_prepare_body(const VuPrepareArgs &a)
     double *s_lin = vu_lds + Lay::LIN;           // plain part: per (pose, unit vector) 3 + 6 numbers, then L[3][9] and c_t[3]
     int *s_idx = reinterpret_cast<int *>(vu_lds + Lay::INTS);      // [MAXNP + 3]
     int *s_flag = s_idx + MAXNP + 3;                               // [4]
-    const int b = blockIdx.x, tid = threadIdx.x;
+    const int b = bx, tid = threadIdx.x;
     // rec is computed below; a.np is the record STRIDE (the longest track of the launch) when per-record lengths are given
-    const size_t rec_ = a.spec_tracks > 0 ? (size_t)blockIdx.y * gridDim.x + blockIdx.x : (size_t)blockIdx.x;
+    const size_t rec_ = a.spec_tracks > 0 ? (size_t)blockIdx.y * a.batch + bx : (size_t)bx;
     const int np_rec = a.np_rec ? a.np_rec[rec_] : a.np;
     const bool no_track = np_rec < 2 || np_rec > a.np;              // ragged batches: this filter has no (valid) track in this launch
     const int n = no_track ? a.np : np_rec, ncam = a.stereo ? 2 : 1, nt = n * ncam, N = a.n;
@@ -259,14 +259,17 @@ __device__ __forceinline__ void vu_prepare_body(const VuPrepareArgs &a)
     double *scal = s_small + 36;                 // [0] error2, [1] rcond, [2] Jprev
     VU_STAMP(0);
     // rec: the (track, filter) record this workgroup reads its inputs from and writes its outputs to (the filter itself without speculation)
-    const size_t rec = a.spec_tracks > 0 ? (size_t)blockIdx.y * gridDim.x + b : (size_t)b;
+    const size_t rec = a.spec_tracks > 0 ? (size_t)blockIdx.y * a.batch + b : (size_t)b;
     const bool quota_used = a.success_counter && a.success_counter[b] >= a.max_successful;
     if (a.spec_tracks > 0) {
         if ((int)blockIdx.y < a.cursor[b]) return;                               // final already
         if (!quota_used && a.epoch[rec] == a.success_counter[b]) return;          // prepared against the current mean
     }
     if (a.np_hi > 0 && np_rec >= 2 && np_rec <= a.np && (np_rec < a.np_lo || np_rec > a.np_hi)) {       // another length class serves this record
-        if (a.class_inactive && a.active && tid == 0) a.active[rec] = 0;
+        if (tid == 0) {
+            if (a.class_inactive && a.active) a.active[rec] = 0;
+            if (a.long_list && np_rec > a.np_hi) a.long_list[atomicAdd(a.long_count, 1)] = (int)rec;
+        }
         return;
     }
     if (a.np_hi > 0 && a.np_lo > 2 && no_track) {                 // "no track" records belong to the class that starts at 2 poses
@@ -887,6 +890,7 @@ __device__ __forceinline__ void vu_prepare_body(const VuPrepareArgs &a)
             const bool broken = !(chi < 1e300);                   // non-positive pivot: reported as CHI2 (ekf_update_kernel phase D)
             const int outlier = broken || ((rows < HV_CHI2INV95_N) ? (chi > d_chi2inv95[rows]) : 0);
             if (a.gate_status) a.gate_status[rec] = outlier ? 3 /*CHI2*/ : 0 /*INLIER*/;
+            if (!outlier && a.inl_list) a.inl_list[atomicAdd(a.inl_count, 1)] = (int)rec;
             if (a.chi2) a.chi2[rec] = chi;
             if (a.spec_tracks > 0) a.epoch[rec] = a.success_counter[b];
         }
@@ -954,23 +958,31 @@ __device__ __forceinline__ void vu_prepare_body(const VuPrepareArgs &a)
     }
 }
 
-__global__ __launch_bounds__(VT_LATENCY, 3) void vu_prepare_kernel(VuPrepareArgs a) { vu_prepare_body<VT_LATENCY, MAXP_ALL, 0>(a); }
+__global__ __launch_bounds__(VT_LATENCY, 3) void vu_prepare_kernel(VuPrepareArgs a) { vu_prepare_body<VT_LATENCY, MAXP_ALL, 0>(a, blockIdx.x); }
 // 4 waves per SIMD = 128 VGPRs: two workgroups of 6 waves may put 4 waves on one SIMD (512 VGPRs per lane there)
 __global__ __launch_bounds__(VT_THROUGHPUT, 4) void vu_prepare_kernel_2percu(VuPrepareArgs a)
 {
-    vu_prepare_body<VT_THROUGHPUT, MAXP_SMALL, 0>(a);
+    vu_prepare_body<VT_THROUGHPUT, MAXP_SMALL, 0>(a, blockIdx.x);
 }
 // the same two builds with the column-sparse chi2 gate fused in (VuPrepareArgs::fused)
-__global__ __launch_bounds__(VT_LATENCY, 3) void vu_gate_kernel(VuPrepareArgs a) { vu_prepare_body<VT_LATENCY, MAXP_ALL, 1>(a); }
+__global__ __launch_bounds__(VT_LATENCY, 3) void vu_gate_kernel(VuPrepareArgs a) { vu_prepare_body<VT_LATENCY, MAXP_ALL, 1>(a, blockIdx.x); }
 __global__ __launch_bounds__(VT_THROUGHPUT, 4) void vu_gate_kernel_2percu(VuPrepareArgs a)
 {
-    vu_prepare_body<VT_THROUGHPUT, MAXP_SMALL, 1>(a);
+    vu_prepare_body<VT_THROUGHPUT, MAXP_SMALL, 1>(a, blockIdx.x);
 }
 // ... and with the compact Jacobian only (the gate runs as its own launch)
-__global__ __launch_bounds__(VT_LATENCY, 3) void vu_compact_kernel(VuPrepareArgs a) { vu_prepare_body<VT_LATENCY, MAXP_ALL, 2>(a); }
+__global__ __launch_bounds__(VT_LATENCY, 3) void vu_compact_kernel(VuPrepareArgs a)
+{
+    // persistent form (one workgroup per CU walks the batch): the launches that serve one length class of a ragged visit -- most of their
+    // records belong to the other class, and a 150 KB workgroup that only finds that out occupies a whole CU's LDS slot for it
+    extern __shared__ __attribute__((aligned(16))) double vu_lds[];
+    if (a.persistent) HV_QUEUE_LOOP(a.queue, a.batch, reinterpret_cast<int *>(reinterpret_cast<char *>(vu_lds) + a.q_off), (vu_prepare_body<VT_LATENCY, MAXP_ALL, 2>(a, b_)));
+    else if (a.rec_list) { if ((int)blockIdx.x < *a.rec_count) vu_prepare_body<VT_LATENCY, MAXP_ALL, 2>(a, a.rec_list[blockIdx.x]); }
+    else vu_prepare_body<VT_LATENCY, MAXP_ALL, 2>(a, blockIdx.x);
+}
 __global__ __launch_bounds__(VT_THROUGHPUT, 4) void vu_compact_kernel_2percu(VuPrepareArgs a)
 {
-    vu_prepare_body<VT_THROUGHPUT, MAXP_SMALL, 2>(a);
+    vu_prepare_body<VT_THROUGHPUT, MAXP_SMALL, 2>(a, blockIdx.x);
 }
 
 }  // namespace
@@ -1017,14 +1029,16 @@ int launch_vu_prepare(Ctx *c, const VuPrepareArgs &a)
         HV_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void *>(vu_prepare_kernel_2percu), hipFuncAttributeMaxDynamicSharedMemorySize, (int)VuLds<MAXP_SMALL>::BYTES));
         HV_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void *>(vu_gate_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)VuLds<MAXP_ALL>::BYTES));
         HV_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void *>(vu_gate_kernel_2percu), hipFuncAttributeMaxDynamicSharedMemorySize, (int)VuLds<MAXP_SMALL>::BYTES));
-        HV_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void *>(vu_compact_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)VuLds<MAXP_ALL>::BYTES));
+        HV_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void *>(vu_compact_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)VuLds<MAXP_ALL>::BYTES + 16));
         HV_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void *>(vu_compact_kernel_2percu), hipFuncAttributeMaxDynamicSharedMemorySize, (int)VuLds<MAXP_SMALL>::BYTES));
         attr_set = true;
     }
     const dim3 grid((unsigned)a.batch, (unsigned)(a.spec_tracks > 0 ? a.spec_tracks : 1));
     if (a.fused == 2) {
         if (small) hipLaunchKernelGGL(vu_compact_kernel_2percu, grid, dim3(VT_THROUGHPUT), VuLds<MAXP_SMALL>::BYTES, c->stream, a);
-        else       hipLaunchKernelGGL(vu_compact_kernel, grid, dim3(VT_LATENCY), VuLds<MAXP_ALL>::BYTES, c->stream, a);
+        else if (a.persistent && a.queue && a.spec_tracks == 0 && a.batch > c->num_cus)
+        { VuPrepareArgs a1 = a; a1.q_off = (int)VuLds<MAXP_ALL>::BYTES; hipLaunchKernelGGL(vu_compact_kernel, dim3((unsigned)c->num_cus), dim3(VT_LATENCY), VuLds<MAXP_ALL>::BYTES + 16, c->stream, a1); }
+        else { VuPrepareArgs a1 = a; a1.persistent = 0; hipLaunchKernelGGL(vu_compact_kernel, grid, dim3(VT_LATENCY), VuLds<MAXP_ALL>::BYTES, c->stream, a1); }
     } else if (a.fused) {
         if (small) hipLaunchKernelGGL(vu_gate_kernel_2percu, grid, dim3(VT_THROUGHPUT), VuLds<MAXP_SMALL>::BYTES, c->stream, a);
         else       hipLaunchKernelGGL(vu_gate_kernel, grid, dim3(VT_LATENCY), VuLds<MAXP_ALL>::BYTES, c->stream, a);

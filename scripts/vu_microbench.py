@@ -63,7 +63,9 @@ def main():
                   "final", s_[28] - s_[27], "prep-pose", s_[29] - s_[28], "H", s_[30] - s_[29], "total", s_[30] - s_[0])
         # the fused prepare + column-sparse gate kernel and the update of the inliers (r03 default); y_out rejects every track, so the
         # update launch is a skip launch and the vu_prepare timer class shows the fused kernel alone
-        for name, yy in (("all rejected", dev(y + 3.0, np.float64)), ("all inliers", d_y)):
+        frac = float(sys.argv[4]) if len(sys.argv) > 4 else 0.25
+        y_mix = y.copy(); y_mix[rng.uniform(size=B) >= frac] += 3.0
+        for name, yy in (("all rejected", dev(y + 3.0, np.float64)), ("all inliers", d_y), (f"{frac:.2f} inliers", dev(y_mix, np.float64))):
             for _ in range(3):
                 g.visual_track_dev(vp, npose, d_idx.data_ptr(), d_feat.data_ptr(), d_vel.data_ptr(), yy.data_ptr(), 1.5, 0.05,
                                    st.data_ptr(), gs.data_ptr(), 0, pf.data_ptr())
