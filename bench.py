@@ -1059,6 +1059,7 @@ def main():
     ap.add_argument("--only-headline", action="store_true", help="C2 + C3 legs only (what the rocprofv3 collection runs)")
     ap.add_argument("--verify", type=int, default=4, help="sequences of the C3 batch re-computed by the CPU oracle after the timed region (0 = off)")
     ap.add_argument("--repeats", type=int, default=5, help="repeats of the K-step timed region of the headline; `value` is the median repeat")
+    ap.add_argument("--no-graph", action="store_true", help="time the headline with eager launches instead of HIP-graph replay of the captured steps")
     ap.add_argument("--one-sequence-leg", action="store_true", help="add the literal north-star configuration (ONE sequence per GPU) at N > 1 too")
     ap.add_argument("--cpu-baseline-child", type=float, default=None, help=argparse.SUPPRESS)
     args = ap.parse_args()
@@ -1148,7 +1149,7 @@ def main():
              ("ekf_predict", capi.K_EKF_PREDICT), ("vu_prepare", capi.K_VU_PREPARE), ("ekf_update_gate", capi.K_EKF_UPDATE),
              ("ekf_gate", capi.K_EKF_GATE), ("ekf_augment", capi.K_EKF_AUGMENT))
 
-    def c3_leg(realistic, repeats):
+    def c3_leg(realistic, repeats, graph):
         """One C3 leg under the timing contract: `repeats` timed regions of exactly args.steps steps each (barrier + sync on both sides,
         MAX over ranks); per-kernel hipEvent times are taken over all of them. Returns the bench objects, the sorted region times and
         the per-kernel table."""
@@ -1160,14 +1161,59 @@ def main():
         eb_.applied.zero_()
         tb.ctx.profile_enable(True)
         tb.ctx.profile_reset()
-        times = [env.timed(lambda: (tb.step(), eb_.step()), args.steps) for _ in range(max(1, repeats))]
+        eager = [env.timed(lambda: (tb.step(), eb_.step()), args.steps) for _ in range(1 if graph else max(1, repeats))]
         prof = {name: tb.ctx.profile_read(kid) for name, kid in names}
         tb.ctx.profile_enable(False)
-        nsteps = args.steps * len(times)
+        nsteps = args.steps * len(eager)
         kern = {k: {"avg_ms": ms / n, "launches": n, "total_ms": ms, "ms_per_step": ms / nsteps} for k, (ms, n) in prof.items() if n}
-        return eb_, times, kern, float(eb_.applied.item()) / (B * nsteps)
+        applied_ = float(eb_.applied.item()) / (B * nsteps)
+        times, launch = eager, "eager"
+        if graph:
+            # The step is a fixed launch sequence with period N_CYCLE (camera path, RANSAC draws, GFTT every 2nd frame, the augmentation's
+            # discard pattern, the pyramid-slot and covariance ping-pongs): captured once into N_CYCLE HIP graphs and replayed -- the same
+            # kernels on the same data, without ~150 eager launch gaps of 10 - 15 us per step (rocprofv3 kernel trace, r03). A timed region
+            # is still exactly args.steps steps = args.steps graph launches, bracketed as the contract says.
+            try:
+                main = torch.cuda.current_stream()
+                side = torch.cuda.Stream()
+                tb.overlap = False                               # one capture stream: the bookkeeping runs in line
+                tb.tracked_fraction()                            # (folds the pending frame in on the main stream)
+                torch.cuda.synchronize()
+                tb.ctx.set_stream(side.cuda_stream)
+                graphs = []
+                with torch.cuda.stream(side):
+                    for _ in range(N_CYCLE):
+                        tb.step(); eb_.step()
+                    side.synchronize()
+                    for _ in range(N_CYCLE):
+                        g_ = torch.cuda.CUDAGraph()
+                        with torch.cuda.graph(g_, stream=side):
+                            tb.step(); eb_.step()
+                        graphs.append(g_)
+                    side.synchronize()
+                    cnt = [0]
 
-    eb, times3, k3, applied = c3_leg(True, args.repeats)
+                    def replay():
+                        graphs[cnt[0] % N_CYCLE].replay(); cnt[0] += 1
+                    for _ in range(N_CYCLE):
+                        replay()
+                    side.synchronize()
+                    times = [env.timed(replay, args.steps) for _ in range(max(1, repeats))]
+                    while cnt[0] % N_CYCLE:                      # back to a cycle boundary: the host-side counters (frame number, discard
+                        replay()                                 # pattern) match the device state again for the eager steps that follow
+                    side.synchronize()
+                tb.ctx.set_stream(main.cuda_stream)
+                torch.cuda.synchronize()
+                launch = "hipGraph replay"
+                keep_graphs.append(graphs)                       # (destroyed with the process: the captured kernels hold the library's buffers)
+            except Exception as ex:                              # pragma: no cover
+                tb.ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+                launch = "eager (graph capture failed: " + repr(ex)[:120] + ")"
+                times = eager
+        return eb_, times, kern, applied_, launch, eager, nsteps
+
+    keep_graphs = []
+    eb, times3, k3, applied, launch3, eager3, nprof3 = c3_leg(True, args.repeats, not args.no_graph)
     el3 = sorted(times3)[len(times3) // 2]                      # the median repeat is the reported timed region
     gate_hist = [int((eb.gs[k] == 0).sum().item()) for k in range(VISITS)]
     verify = verify_c3(tb, eb, args.verify, seed=rank) if (args.verify > 0 and rank == 0) else None
@@ -1184,7 +1230,7 @@ def main():
     # (+ the compact Jacobian); augment / predict: P read + written
     rows_mean, na_mean = 4 * lens_mean, 7 * lens_mean + 1
     hc_bytes = rows_mean * na_mean * 8
-    alg = {"klt": B * ab["klt_call"], "pyr_l0": 2 * B * ab["pyr_l0"], "pyr_ln": 2 * B * ab["pyr_ln"] * args.steps * len(times3) / max(1, k3.get("pyr_ln", {}).get("launches", 1)),
+    alg = {"klt": B * ab["klt_call"], "pyr_l0": 2 * B * ab["pyr_l0"], "pyr_ln": 2 * B * ab["pyr_ln"] * nprof3 / max(1, k3.get("pyr_ln", {}).get("launches", 1)),
            "vu_prepare": B * (n_state * 8 + 12 * 8 * 2 * lens_mean + na_mean * na_mean * 8 + hc_bytes),
            "ekf_update_gate": B * (QUOTA / VISITS) * (2 * p_bytes + hc_bytes), "ekf_gate": B * (na_mean * na_mean * 8 + hc_bytes),
            "ekf_augment": B * p_bytes * 2, "ekf_predict": B * p_bytes * 2, "rot_ransac": B * NPTS * 20, "gftt": B * W * H}
@@ -1211,7 +1257,7 @@ def main():
     stage_gbs = B * ab["stereo_frame"] / (stage_ms * 1e-3) / 1e9
     stage_actual = None
     if prof_t is not None and all(pmc(k, "hbm_bytes_per_launch") is not None for k in ("klt", "pyr_l0")):
-        per_step = {k: k3[k]["launches"] / (args.steps * len(times3)) for k in ("klt", "pyr_l0", "pyr_ln") if k in k3}
+        per_step = {k: k3[k]["launches"] / nprof3 for k in ("klt", "pyr_l0", "pyr_ln") if k in k3}
         stage_actual = sum(pmc(k, "hbm_bytes_per_launch") * per_step[k] for k in ("klt", "pyr_l0")) + \
             sum((prof_t.get(kk, {}) or {}).get("hbm_bytes_per_launch", 0.0) * B / float(prof_t.get("sequences_per_gpu", B))
                 for kk in ("pyr_down_l0_kernel_L1", "pyr_tail_kernel"))
@@ -1240,6 +1286,7 @@ def main():
             "dtype": "u8/int16 pixels, int32/int64 sums, f32 solve (tracker); f64 (EKF)", "data": "synthetic",
             "smoke_all_ranks_on_one_device": forced_dev is not None or None,
             "repeats_ms_per_step": [t_ / args.steps * 1e3 for t_ in times3], "value_is": "median of the repeats (each an exact K-step timed region)",
+            "launch": launch3, "eager_ms_per_step": eager3[0] / args.steps * 1e3,
             "stage_pyramid_klt_frac_of_8TBs": stage["frac_of_8TBs"], "stage_pyramid_klt_frac_actual": stage["frac_actual"],
             "parity_checked_sequences": verify["parity_checked_sequences"] if verify else 0, "parity_ok": verify["ok"] if verify else None,
             "config": {"workload": "C3: 752x480 stereo, 200 pts -- the whole frame chained on one stream per sequence: 2 pyramid builds, temporal LK from "
@@ -1277,14 +1324,14 @@ def main():
     # ---- r02's C3 workload (every track 10 stereo poses, all filters share the inlier pattern 3, 7, 11, 15, 19, zero-flow LK start):
     # kept for round-over-round comparison ----
     if not args.only_headline or os.environ.get("HV_BENCH_C3_UNIFORM") == "1":
-        ebu, timesu, ku, appliedu = c3_leg(False, 1)
+        ebu, timesu, ku, appliedu, launchu, _, _ = c3_leg(False, 1, not args.no_graph)
         ebu.ekf.close()
         del ebu
         tb.predicted_flow = True
         if rank == 0:
             out["c3_uniform"] = {"workload": "r02's C3: as the headline but every track 10 stereo poses (40 x 160 Jacobian), one inlier pattern for all filters, "
                                              "temporal LK without initial flow",
-                                 "value": aggregate_value(B, world, args.steps, timesu[0]), "unit": "frames/s", "ms_per_step": timesu[0] / args.steps * 1e3,
+                                 "value": aggregate_value(B, world, args.steps, timesu[0]), "unit": "frames/s", "ms_per_step": timesu[0] / args.steps * 1e3, "launch": launchu,
                                  "visual_updates_applied_per_frame": appliedu,
                                  "kernels": {k: {"avg_ms": v["avg_ms"], "launches": v["launches"], "ms_per_step": v["ms_per_step"]} for k, v in ku.items()},
                                  "r02_value": 103900.0}

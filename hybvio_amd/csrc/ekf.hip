@@ -418,8 +418,7 @@ struct UpdateArgs {
     // normalisation; half 2 reads it (dm_in) and normalises. 0 = the whole record in one launch. Compact H, MODE 2 only.
     int half, nr_full;                // nr_full: rows of the whole record when neither nr_rec nor nr says so (uniform long tracks)
     double *dm_out; const double *dm_in;   // [batch][n]
-    int persistent, batch;            // persistent launch: grid = CUs, the workgroups pull filters from `queue` (HV_QUEUE_LOOP)
-    int *queue; int q_off;
+    int batch;
     const int *rec_count, *rec_list;  // compaction list (VuPrepareArgs): workgroup i updates filter rec_list[i], i < *rec_count; the others exit
 };
 
@@ -962,12 +961,12 @@ __device__ __forceinline__ void ekf_update_body(const UpdateArgs &a, const int b
 template <int MODE, int TI>
 __global__ __launch_bounds__(UPD_THREADS) void ekf_update_kernel(UpdateArgs a)
 {
-    // persistent form (launches that skip most filters: block updates of the long class, updates of the few inliers of a visit): one
-    // workgroup per CU walks the batch instead of 4 x as many workgroups queueing for a CU-sized LDS slot just to find out they have no work
-    extern __shared__ __attribute__((aligned(16))) double smem[];
-    if (a.persistent) HV_QUEUE_LOOP(a.queue, a.batch, reinterpret_cast<int *>(reinterpret_cast<char *>(smem) + a.q_off), (ekf_update_body<MODE, TI>(a, b_)));
-    else if (a.rec_list) { if ((int)blockIdx.x < *a.rec_count) ekf_update_body<MODE, TI>(a, a.rec_list[blockIdx.x]); }
-    else ekf_update_body<MODE, TI>(a, blockIdx.x);
+    // (r03 also tried one workgroup per CU pulling filters from a device queue: inside a loop the body lost its register allocation --
+    // ~480 spilled VGPRs, 2.4x the time per filter -- and keeping P in the registers across the two blocks of a long track in ONE launch
+    // -- 250 - 450 spilled VGPRs --, so masked launches use the compaction list and long tracks take two launches)
+    int b = blockIdx.x;
+    if (a.rec_list) { if ((int)blockIdx.x >= *a.rec_count) return; b = a.rec_list[blockIdx.x]; }
+    ekf_update_body<MODE, TI>(a, b);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1659,11 +1658,7 @@ static int ekf_launch_update(Ekf *e, int nr, int l, const double *H_dev, const d
     }
     ScopedKernelTime tm(c, HV_K_EKF_UPDATE);
     a.batch = e->batch;
-    a.queue = e->queue_dev;
-    a.persistent = (c->knob.ekf_persistent == 1 && !a.rec_list && !spec && kmode == 2 && (active_dev || require_inlier_dev) && e->batch > c->num_cus) ? 1 : 0;
-    if (a.persistent && shmem + 16 > 160 * 1024) a.persistent = 0;
-    if (a.persistent) { a.q_off = (int)((shmem + 15) & ~(size_t)15); hipLaunchKernelGGL(kern, dim3((unsigned)c->num_cus), dim3(UPD_THREADS), (size_t)a.q_off + 16, c->stream, a); }
-    else hipLaunchKernelGGL(kern, dim3(e->batch, (spec == 1 || spec == 3) ? n_tracks : 1), dim3(UPD_THREADS), shmem, c->stream, a);
+    hipLaunchKernelGGL(kern, dim3(e->batch, (spec == 1 || spec == 3) ? n_tracks : 1), dim3(UPD_THREADS), shmem, c->stream, a);
     HV_HIP(c, hipGetLastError());
     return HV_OK;
 }

@@ -66,7 +66,7 @@ struct Knobs {
     int ingest_gather = 0;        // HV_INGEST_GATHER: 1 = plain gather kernel for the remap
     int ekf_fused_gate = -1;      // HV_EKF_FUSED_GATE: column-sparse chi2 gate: -1 auto = 1 inside the prepare kernel, 2 own launch (ekf_sparse_gate_kernel), 0 off (dense kernels)
     int ekf_spec_mode = -1;       // HV_EKF_SPEC_MODE: speculative pass form: -1 auto, 2 = gate launch + apply launch, 3 = one launch with hand-shake
-    int ekf_persistent = 0;       // HV_EKF_PERSISTENT: 1 = the masked one-workgroup-per-CU launches run as num_cus workgroups pulling records from a device queue instead of using the compaction lists (measured slower: the update body inside a loop runs 2.4x longer per record, r03)
+    int ekf_persistent = 0;       // HV_EKF_PERSISTENT: 1 = the masked one-workgroup-per-CU launches run as num_cus workgroups pulling records from a device queue instead of using the compaction lists: the long class's prepare and gate launches only (experiment; the update kernel lost its register allocation inside such a loop, r03)
     int ekf_side_stream = 0;      // HV_EKF_SIDE_STREAM: 1 = the long-track chain of a ragged visit on a second stream (measured slower: LDS-slot contention)
     int rot_ransac_threads = 0;   // HV_ROT_RANSAC_THREADS: 0 auto (1024 threads up to 64 sets), 256 / 1024 force
 };

@@ -17,7 +17,9 @@ sel = [r for r in rows if "hv::" in r["Kernel_Name"]][-420:]
 t0 = int(sel[0]["Start_Timestamp"])
 with open(sys.argv[2], "w") as f:
     for r in sel:
-        name = r["Kernel_Name"].split("(")[0].replace("hv::(anonymous namespace)::", "").replace("void ", "")[:40]
+        import re
+        m_ = re.search(r"(\w+_kernel\w*)", r["Kernel_Name"])
+        name = m_.group(1) if m_ else r["Kernel_Name"][:40]
         s_, e_ = int(r["Start_Timestamp"]) - t0, int(r["End_Timestamp"]) - t0
         f.write(f"{s_/1e3:10.1f} {e_/1e3:10.1f} {(e_-s_)/1e3:8.1f} q{r.get('Queue_Id','?')} {name} grid={r.get('Grid_Size','?')}\n")
 PY
