@@ -599,12 +599,13 @@ def cpu_baseline(budget_s=10.0):
 
 
 def cpu_baseline_visual_chain(budget_s=8.0):
-    """The EKF half of the chained frame on the CPU oracle, one thread as the reference runs it: per frame 20 x (triangulate +
-    prepareVisualUpdate from the current mean, chi2 gate, update for the 5 inliers), maintainPSD, augmentation, 10 predicts; the
-    filter is reset to the same trail state per frame exactly as VisualEkfBench does."""
+    """The EKF half of the chained frame on the CPU oracle, one thread as the reference runs it: per frame up to 20 x (triangulate +
+    prepareVisualUpdate from the current mean, chi2 gate, update of the inliers until the quota of 5) over the headline's ragged
+    tracks (make_visual_frame_realistic), maintainPSD, augmentation, 10 predicts; the filter is reset to the same trail state per
+    frame exactly as VisualEkfBench does."""
     from oracle import orc
     rng = np.random.default_rng(300)
-    T1, T2, means, idx, feat, vel, y = make_visual_frame(rng, 1, distinct=1)
+    T1, T2, means, lens, idx, feat, vel, y = make_visual_frame_realistic(rng, 4, distinct=4)      # the headline's workload: 4 filters' frames in turn
     par = orc.tri_default_params()
     e = orc.Ekf()
     P0 = e.P.copy() * 1e-6 + np.eye(e.n) * 1e-4
@@ -614,17 +615,19 @@ def cpu_baseline_visual_chain(budget_s=8.0):
     t = 0.0
     while True:
         ta = time.perf_counter()
-        e.set_state(means[0]); e.set_cov(P0)
+        b_ = frames % means.shape[0]
+        e.set_state(means[b_]); e.set_cov(P0)
         ok = 0
         for k in range(VISITS):
             if ok >= QUOTA:
                 break
-            ts, ps, pf, Hm, f = orc.visual_track_prepare(par, e.m, idx[k, 0], T1, T2, feat[k, 0], vel[k, 0])
+            n_ = int(lens[k, b_])
+            ts, ps, pf, Hm, f = orc.visual_track_prepare(par, e.m, idx[k, b_, :n_], T1, T2, feat[k, b_, :2 * n_], vel[k, b_, :2 * n_])
             if ts != 0 or ps != 0:
                 continue
-            st, _ = e.visual_track_outlier_check(Hm, f, y[k, 0], R_GATE)
+            st, _ = e.visual_track_outlier_check(Hm, f, y[k, b_, :4 * n_], R_GATE)
             if st == 0:
-                e.update_visual_track(Hm, f, y[k, 0], R_UPDATE); ok += 1
+                e.update_visual_track(Hm, f, y[k, b_, :4 * n_], R_UPDATE); ok += 1
         applied += ok
         tb_ = time.perf_counter()
         e.maintain_psd()
@@ -1418,8 +1421,25 @@ def main():
                                # pyramid 4 (L0, L1, L2, L3 + border as one: per-level launches below 64 images) + 2 LK + RANSAC + detector,
                                # visual update 2 x (quota + 1), symmetrise + augmentation + predicts
                                "launches_per_frame": 5 + 2 + 1 + 1 + 2 * (QUOTA + 1) + 3,
-                               "visual_update_loop": "speculative (hv_ekf_visual_frame_dev with few sequences): <= quota + 1 passes of prepare-all + one "
-                                                     "launch that gates every pending track and lets the first inlier in visit order apply itself"}
+                               "visual_update_loop": "sequential, two length classes per visit (the headline's ragged tracks reach 84 rows; the speculative "
+                                                     "loop serves <= 48 rows: latency_mode_uniform)"}
+        # the same with r02's uniform 10-pose tracks (40 rows: the speculative visit loop applies), for round-over-round comparison
+        try:
+            e1u = VisualEkfBench(t1.ctx, 1, local_rank, seed=12345, realistic=False)
+            for _ in range(N_CYCLE):
+                t1.step(); e1u.step()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(n_lat):
+                t1.step(); e1u.step()
+            torch.cuda.synchronize()
+            out["latency_mode_uniform"] = {"sequences": 1, "ms_per_frame": (time.perf_counter() - t0) / n_lat * 1e3, "launch": "eager",
+                                           "visual_update_loop": "speculative: <= quota + 1 passes of (fused prepare + gate of every pending track) + (apply the "
+                                                                 "first inlier); r02: 0.72 ms eager with the one-launch hand-shake pass"}
+            e1u.ekf.close()
+            del e1u
+        except Exception as ex:                               # pragma: no cover
+            out["latency_mode_uniform"] = {"error": repr(ex)[:200]}
         # The whole frame captured in HIP graphs: period N_CYCLE (camera path, RANSAC draws, GFTT every 2nd frame, the augmentation's
         # discard pattern and the covariance ping-pong all repeat with it), replayed in order
         try:

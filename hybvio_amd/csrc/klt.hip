@@ -8,19 +8,23 @@
 //   * lane (half, cx) owns window column cx and rows half*16 .. half*16+15 of the 31x31 window;
 //     its 16 template samples (I, Ix, Iy; int16 range) live in VGPRs as packed pairs for the
 //     whole level, so an iteration reads only the J window;
-//   * the J window comes from a 48x48 tile of the next image staged in LDS with coalesced row
-//     loads and re-staged only when the window leaves it (8 px margin). The tile is stored as one
+//   * the J window comes from a tile of the next image staged in LDS (default 40 x 36 pixels, template parameters TSX x TSY; r01
+//     used 44 x 44 and before that 48 x 48) with coalesced row loads, requested together with the template rows of the level and
+//     re-staged only when the window leaves it. The tile is stored as one
 //     dword per pixel holding the packed pair (J[x], J[x+1]) << 7, so one ds_read_b32 per window
 //     row feeds v_dot2_i32_i16 directly and the rounding shift ">> 9" becomes "take the high
 //     half" (128*t + 32768 >> 16 == t + 256 >> 9). Gradients are stored x4 in the pyramid for
 //     the same reason (4*s + 32768 >> 16 == s + 8192 >> 14). The kernel is VALU-issue bound
-//     (rocprof: 90 % VALU busy), so the design minimises integer instructions per pixel;
+//     (rocprof: 93 % VALU busy), so the design minimises integer instructions per pixel;
+//   * levels 0 and 1 have NO stored gradient plane (PyrLayout::grad_from, r02): the lane forms the Scharr gradients of its template
+//     columns from the gray rows it loads anyway (scharr_row below), in the pre-scaled 4 d + 2 form the pyramid stores for levels >= 2;
 //   * the 2x2 normal equations are accumulated as exact integers per lane and reduced across the
 //     wavefront with DPP row operations + v_readlane (no LDS, no atomics): one 32-bit chain when
 //     a ballot proves the total fits, else an exact 2-chain 64-bit path. Integer sums are
 //     order independent, so status / positions are bit-reproducible against the CPU oracle;
-//   * image borders are virtual: BORDER_REFLECT_101 index math for gray, zero for gradients
-//     (OpenCV pads the pyramid by the window size instead).
+//   * image borders: levels 0 and 1 keep VIRTUAL borders (BORDER_REFLECT_101 index math for gray, zero for gradients); levels >= 2
+//     carry OpenCV's 31 (+1) pixel border PHYSICALLY in the slot (PyrLayout::pad, r02), so the coarse levels -- where most windows
+//     cross the image edge -- run the border-free code paths.
 // The per-point float sequence (weights, 2x2 solve, termination tests) is evaluated redundantly
 // by all lanes in IEEE binary32 without FMA contraction (-ffp-contract=off).
 #include <float.h>

@@ -1,13 +1,18 @@
-// Image pyramid for the LK tracker: fused Scharr-gradient + 5x5 binomial down-sample stencils.
+// Image pyramid for the LK tracker: 5x5 binomial down-sample and Scharr-gradient stencils.
 //
 // Replaces cv::buildOpticalFlowPyramid as called by CpuImagePyramidFactory::compute
-// (reference: src/tracker/image_pyramid.cpp:40-48). One launch per pyramid level over a whole
-// batch of images: every workgroup stages one 128x32 source tile (+halo) in LDS with coalesced
-// row loads, then writes (a) the level's Scharr gradients (int16 dx|dy per pixel, 16 B per lane,
-// 512 B contiguous per half-wave) and (b) the next level's gray tile (u8, (s+128)>>8).
-// The source level is read from HBM exactly once; nothing else is written, so HBM traffic equals
-// the algorithmic bytes of SURVEY.md section 8(d). Integer arithmetic throughout: results are
-// bit-identical to the OpenCV algorithm restated in oracle/pyrlk_oracle.c.
+// (reference: src/tracker/image_pyramid.cpp:40-48). Three kernels (r02 layout):
+//   * pyr_down_l0_kernel  levels without a stored gradient plane (0 and 1 by default: the LK kernel forms those gradients itself):
+//                          a pure 5x5 down-sample straight from 16-byte row loads, no LDS, no barrier;
+//   * pyr_tail_kernel     levels >= 2 of one image in ONE workgroup, LDS resident: gradients, the physical 32-pixel border of the
+//                          padded levels, the next gray level (used from 64 images up);
+//   * pyr_level_kernel    the general tile kernel (128x32 source tile + halo staged in LDS, Scharr gradients as int16 dx|dy per pixel
+//                          + the next level's gray tile): stored-gradient levels of the experiment layouts, few images, unaligned
+//                          caller buffers, and the on-demand gradient read-back of hv_pyramid_download.
+// A source level is read from HBM once per launch. HBM traffic equals each launch's OWN bytes (PMC: 1.00 - 1.03x); it is NOT the
+// "algorithmic bytes" of SURVEY.md 8(d) any more -- those count gradient planes of levels 0 and 1 that are never written (bench.py
+// reports the stage both ways). Integer arithmetic throughout: results are bit-identical to the OpenCV algorithm restated in
+// oracle/pyrlk_oracle.c.
 #include "hv_internal.hpp"
 
 namespace hv {

@@ -8,7 +8,7 @@ OUT=$R/gpurun_out/${PROF_DIR:-prof_r03}
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 ulimit -c 0
-B="python $R/bench.py --steps 10 --warmup 2 --only-headline --repeats 1 --verify 0 ${BENCH_EXTRA:-}"
+B="python $R/bench.py --steps 10 --warmup 2 --only-headline --repeats 1 --verify 0 --no-graph ${BENCH_EXTRA:-}"
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pf_kt -o kt -- $B > $OUT/bench_under_kernel_trace.log 2>&1
 find /tmp/pf_kt -name "*kernel_stats.csv" -exec cp {} $OUT/kernel_stats.csv \;
 i=0

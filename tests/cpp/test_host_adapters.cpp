@@ -355,6 +355,17 @@ static void test_visual_frame(Session &s, const std::string &dir)
     double diff = 0, norm = 0;
     for (size_t i = 0; i < ma.size(); i++) { diff += std::fabs(ma[i] - mb[i]); norm += std::fabs(mb[i]); }
     REQUIRE(diff <= 1e-9 * norm);
+    // maxSuccessfulVisualUpdates <= 0 is the reference's "no limit" (backend.cpp:1233): every track is visited (r02 advisor: used to throw)
+    auto c = b->clone(), d = b->clone();
+    int applied_all = -1;
+    const auto all = c->visualFrame(vp, tracks, 1.5, 0.05, 0, &applied_all);
+    int done_all = 0;
+    for (size_t k = 0; k < tracks.size(); k++) {
+        const auto one = d->visualTrack(vp, tracks[k].poseTrailIndex, tracks[k].imageFeatures, tracks[k].featureVelocities, tracks[k].y, 1.5, 0.05);
+        REQUIRE(all[k].triangulateStatus == one.triangulateStatus && all[k].outlierStatus == one.outlierStatus);
+        done_all += one.outlierStatus == odometry::VuOutlierStatus::INLIER;
+    }
+    REQUIRE(applied_all == done_all && done_all >= 1);
 }
 
 // RotRansac::fit as doRansac2 calls it (ransac_pipeline.cpp:197-216): two consecutive frames share ONE std::mt19937, so
