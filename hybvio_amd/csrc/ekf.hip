@@ -1156,16 +1156,22 @@ struct SparseGateArgs {
     int *inl_count, *inl_list;        // appended: records whose gate said INLIER
 };
 
-constexpr int SGATE_THREADS = 256;
+constexpr int SGATE_THREADS = 256;         // small build: four waves, one per SIMD, three workgroups per CU
+constexpr int SGATE_BIG_THREADS = 512;     // big build (one workgroup per CU by its LDS): two waves per SIMD for the 60 (J, ct) items of an 84-row track
 
 // BIG = false: up to 48 rows (three 43 KB workgroups per CU at 10 stereo poses); BIG = true: 49 .. 96 rows (tracks of 13 .. 21 stereo
 // poses: 13 .. 21 poses x 4 rows), one workgroup per CU with the whole register file, Hc staged with nrp = 16 TI rows per column where that
-// fits 160 KB together with [S; v'] and with exactly nr rows (TIGHT) where it does not (84 rows: 99.5 + 58.5 KB).
+// fits 160 KB together with [S; v'] and with 84 rows (TIGHT) where it does not (84 rows: 99.5 + 58.5 KB).
 template <bool BIG>
-__device__ __forceinline__ void sparse_gate_kernel_body(const SparseGateArgs &a, const int b)
+__device__ __forceinline__ void sparse_gate_kernel_body(const SparseGateArgs &a, const int b_in)
 {
+    // (the record index may come out of a compaction list, i.e. a per-lane load: on the scalar unit every base address below is
+    //  uniform and the P gather becomes scalar base + 32-bit lane offset)
+    const int b = __builtin_amdgcn_readfirstlane(b_in);
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int t = threadIdx.x;
+    constexpr int NTH = BIG ? SGATE_BIG_THREADS : SGATE_THREADS;
+    PHASE_STAMP(12);
     if (!a.active[b]) return;                                  // status stays NOT_COMPUTED (preset by the prepare launch)
     int nr = a.nr_rec ? a.nr_rec[b] : a.nr;
     nr = __builtin_amdgcn_readfirstlane(nr);
@@ -1176,7 +1182,8 @@ __device__ __forceinline__ void sparse_gate_kernel_body(const SparseGateArgs &a,
     while ((Rs & 31) != 15 && (Rs & 31) != 17) Rs++;
     const bool tight = BIG && (size_t)na4 * 16 * ti + (size_t)Rs * nr > (size_t)a.lds_doubles;    // (uniform) does the padded layout fit?
     if (tight) Rs = nr + 1 + ((nr + 1) & 1 ? 0 : 1);            // an odd stride is all the LDS budget allows
-    const int nrp = tight ? nr : 16 * ti;
+    if (tight && nr > HV_GATE_TIGHT_ROWS) return;              // (the launcher sizes LDS for <= 84 rows: never taken)
+    const int nrp = tight ? HV_GATE_TIGHT_ROWS : 16 * ti;
     double *Hs = smem, *T = smem + a.hs_doubles;
     int *s_acol = reinterpret_cast<int *>(T + (size_t)Rs * nr);
     const double *Hc = a.Hc + (size_t)b * a.nr * a.na_max;
@@ -1187,36 +1194,37 @@ __device__ __forceinline__ void sparse_gate_kernel_body(const SparseGateArgs &a,
     const double my_v = t < nr ? a.v[(size_t)b * a.nr + t] : 0.0;
     const int total = na4 * nrp;
     const unsigned inv_nrp = (unsigned)((0x100000000ull + (unsigned)nrp - 1) / (unsigned)nrp);       // i / nrp = umulhi(i, ceil(2^32 / nrp))
-    for (int base = 0; base < total; base += 8 * SGATE_THREADS) {
+    for (int base = 0; base < total; base += 8 * NTH) {
         double hv_[8];
 #pragma unroll
         for (int q = 0; q < 8; q++) {
-            const int i = base + q * SGATE_THREADS + t, u = (int)__umulhi((unsigned)i, inv_nrp), r = i - u * nrp;
+            const int i = base + q * NTH + t, u = (int)__umulhi((unsigned)i, inv_nrp), r = i - u * nrp;
             const bool live = i < total && u < na && r < nr;
             hv_[q] = live ? Hc[(size_t)(live ? u : 0) * nr + (live ? r : 0)] : 0.0;
         }
 #pragma unroll
         for (int q = 0; q < 8; q++) {
-            const int i = base + q * SGATE_THREADS + t;
+            const int i = base + q * NTH + t;
             if (i < total) Hs[i] = hv_[q];
         }
     }
-    for (int i = t; i < Rs * nr; i += SGATE_THREADS) T[i] = 0.0;             // (row nr of column c is rewritten below by thread c: same thread order
+    for (int i = t; i < Rs * nr; i += NTH) T[i] = 0.0;             // (row nr of column c is rewritten below by thread c: same thread order
     if (t < na) s_acol[t] = my_acol;                                           //  is not guaranteed, so the barrier comes first)
     __syncthreads();
     if (t < nr) T[(size_t)t * Rs + nr] = my_v;
     __syncthreads();
+    PHASE_STAMP(13);
     const double *Pb = a.P + (size_t)b * n * n;
     double chi;
     if constexpr (!BIG) {
-        if (ti == 1)      chi = sparse_gate<1, SGATE_THREADS, true>(Pb, n, s_acol, na, Hs, T, Rs, nr, a.rd, a.noise_scale, Hs);
-        else if (ti == 2) chi = sparse_gate<2, SGATE_THREADS, true>(Pb, n, s_acol, na, Hs, T, Rs, nr, a.rd, a.noise_scale, Hs);
-        else              chi = sparse_gate<3, SGATE_THREADS, true>(Pb, n, s_acol, na, Hs, T, Rs, nr, a.rd, a.noise_scale, Hs);
+        if (ti == 1)      chi = sparse_gate<1, NTH, true>(Pb, n, s_acol, na, Hs, T, Rs, nr, a.rd, a.noise_scale, Hs, BIG ? g_phase_stamp : nullptr);
+        else if (ti == 2) chi = sparse_gate<2, NTH, true>(Pb, n, s_acol, na, Hs, T, Rs, nr, a.rd, a.noise_scale, Hs, BIG ? g_phase_stamp : nullptr);
+        else              chi = sparse_gate<3, NTH, true>(Pb, n, s_acol, na, Hs, T, Rs, nr, a.rd, a.noise_scale, Hs, BIG ? g_phase_stamp : nullptr);
     } else {
-        if (ti <= 4)      chi = sparse_gate<4, SGATE_THREADS, true>(Pb, n, s_acol, na, Hs, T, Rs, nr, a.rd, a.noise_scale, Hs);
-        else if (ti == 5) chi = sparse_gate<5, SGATE_THREADS, true>(Pb, n, s_acol, na, Hs, T, Rs, nr, a.rd, a.noise_scale, Hs);
-        else if (!tight)  chi = sparse_gate<6, SGATE_THREADS, true>(Pb, n, s_acol, na, Hs, T, Rs, nr, a.rd, a.noise_scale, Hs);
-        else              chi = sparse_gate<6, SGATE_THREADS, true, true>(Pb, n, s_acol, na, Hs, T, Rs, nr, a.rd, a.noise_scale, Hs);
+        if (ti <= 4)      chi = sparse_gate<4, NTH, true>(Pb, n, s_acol, na, Hs, T, Rs, nr, a.rd, a.noise_scale, Hs, BIG ? g_phase_stamp : nullptr);
+        else if (ti == 5) chi = sparse_gate<5, NTH, true>(Pb, n, s_acol, na, Hs, T, Rs, nr, a.rd, a.noise_scale, Hs, BIG ? g_phase_stamp : nullptr);
+        else if (!tight)  chi = sparse_gate<6, NTH, true>(Pb, n, s_acol, na, Hs, T, Rs, nr, a.rd, a.noise_scale, Hs, BIG ? g_phase_stamp : nullptr);
+        else              chi = sparse_gate<6, NTH, true, true>(Pb, n, s_acol, na, Hs, T, Rs, nr, a.rd, a.noise_scale, Hs, BIG ? g_phase_stamp : nullptr);
     }
     if (t == 0) {
         const bool broken = !(chi < 1e300);                    // non-positive pivot: reported as CHI2 (ekf_update_kernel phase D)
@@ -1228,7 +1236,7 @@ __device__ __forceinline__ void sparse_gate_kernel_body(const SparseGateArgs &a,
 }
 
 __global__ __launch_bounds__(SGATE_THREADS, 3) void ekf_sparse_gate_kernel(SparseGateArgs a) { sparse_gate_kernel_body<false>(a, blockIdx.x); }
-__global__ __launch_bounds__(SGATE_THREADS, 1) void ekf_sparse_gate_big_kernel(SparseGateArgs a)
+__global__ __launch_bounds__(SGATE_BIG_THREADS, 1) void ekf_sparse_gate_big_kernel(SparseGateArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     if (a.persistent) HV_QUEUE_LOOP(a.queue, a.batch, reinterpret_cast<int *>(reinterpret_cast<char *>(smem) + a.q_off), (sparse_gate_kernel_body<true>(a, b_)));     // (see ekf_update_kernel)
@@ -1712,10 +1720,13 @@ static int ekf_launch_sparse_gate(Ekf *e, int np, int ncam, const double *Hc_dev
     int Rs = nr + 1;
     while ((Rs & 31) != 15 && (Rs & 31) != 17) Rs++;
     // LDS: Hc staged [na4][nrp] + [S; v'] (Rs x nr) + the column list. The launch is sized for its longest record; in the big build a
-    // record whose padded layout does not fit (84 rows) uses the tight one (nrp = nr, odd Rs) inside the same carve.
+    // record whose padded layout does not fit (84 rows) uses the tight one (nrp = 84, odd Rs) inside the same carve.
     size_t hs = (size_t)na4 * nrp, tt = (size_t)Rs * nr;
     const size_t cap = (size_t)(big ? 160 : 96) * 1024, ints = sizeof(int) * (size_t)(na_max + 2);
-    if (big && sizeof(double) * (hs + tt) + ints > cap) { hs = (size_t)na4 * nr; tt = (size_t)(nr + 2) * nr; }
+    if (big && sizeof(double) * (hs + tt) + ints > cap) {
+        if (nr > HV_GATE_TIGHT_ROWS) return HV_ERR_UNSUPPORTED;
+        hs = (size_t)na4 * HV_GATE_TIGHT_ROWS; tt = (size_t)(nr + 2) * nr;
+    }
     if (hs < 824) hs = 824;
     a.hs_doubles = (int)hs; a.lds_doubles = (int)(hs + tt);
     const size_t shmem = sizeof(double) * (hs + tt) + ints;
@@ -1731,7 +1742,7 @@ static int ekf_launch_sparse_gate(Ekf *e, int np, int ncam, const double *Hc_dev
     a.rec_count = rec_count; a.rec_list = rec_list; a.inl_count = inl_count; a.inl_list = inl_list;
     a.batch = e->batch; a.queue = e->queue_dev; a.persistent = c->knob.ekf_persistent == 1 && !rec_list && big && e->batch > c->num_cus && shmem + 32 <= cap ? 1 : 0;
     a.q_off = (int)((shmem + 15) & ~(size_t)15);
-    if (big) hipLaunchKernelGGL(ekf_sparse_gate_big_kernel, dim3((unsigned)(a.persistent ? c->num_cus : e->batch)), dim3(SGATE_THREADS),
+    if (big) hipLaunchKernelGGL(ekf_sparse_gate_big_kernel, dim3((unsigned)(a.persistent ? c->num_cus : e->batch)), dim3(SGATE_BIG_THREADS),
                                 a.persistent ? (size_t)a.q_off + 16 : shmem, c->stream, a);
     else     hipLaunchKernelGGL(ekf_sparse_gate_kernel, dim3(e->batch), dim3(SGATE_THREADS), shmem, c->stream, a);
     HV_HIP(c, hipGetLastError());

@@ -2,6 +2,7 @@
 // state layout constants, the f64 MFMA tile product, the in-register 16 x 16 Cholesky block factor and the chi2 table.
 // Everything lives in an anonymous namespace (force-inlined per translation unit).
 #pragma once
+#include <type_traits>
 #include "chi2inv95.h"
 #include "hv_internal.hpp"
 
@@ -151,8 +152,9 @@ __device__ __forceinline__ void factor_diag_block(double *T, double *W, double *
 // ---------------------------------------------------------------------------------------------
 // PIPE: the P values of an item rotate through one register buffer with the NEXT item's loads issued behind each MFMA (standalone gate
 // kernel, ~110 VGPRs); !PIPE: chunks of 10 k-steps, double buffered (the fused prepare + gate kernel, which lives on 128 VGPRs).
-// TIGHT: the staged Hc has nrp = nr rows per column instead of 16 TI (the 84-row track of 21 stereo poses: Hc alone is 100 KB), reads of the
-// last row tile are predicated instead of meeting zero padding.
+// TIGHT: the staged Hc has nrp = 84 rows per column instead of 16 TI = 96 (the 84-row track of 21 stereo poses: Hc alone is 100 KB; rows
+// nr .. 83 zero); the last row tile reads on into the next column instead of meeting zero padding.
+constexpr int HV_GATE_TIGHT_ROWS = 84;     // rows per staged column of the TIGHT layout: 21 stereo poses, the longest track there is
 template <int TI, int NT, bool PIPE, bool TIGHT = false>
 __device__ __forceinline__ double sparse_gate(const double *P, int n, const int *acol, int na, const double *Hs, double *T, int Rs, int nr,
                                               double rd, double noise_scale, double *work, long long *stamps = nullptr)
@@ -168,101 +170,129 @@ __device__ __forceinline__ double sparse_gate(const double *P, int n, const int 
     // the shape is the same for every lane: keep it on the scalar unit (the callers' values come out of per-lane loads)
     n = __builtin_amdgcn_readfirstlane(n); na = __builtin_amdgcn_readfirstlane(na); nr = __builtin_amdgcn_readfirstlane(nr);
     Rs = __builtin_amdgcn_readfirstlane(Rs);
-    const int nrp = TIGHT ? nr : 16 * TI;
-    // row `r0 + cl` of a 16-row tile of Hs: in TIGHT layouts the last tile ends at nr (rows beyond it belong to the next column)
-    auto hs_at = [&](const double *col_k, int r0) -> double {
-        if constexpr (TIGHT) { const int r = r0 + cl; const double x = col_k[min(r, nr - 1)]; return r < nr ? x : 0.0; }
-        else return col_k[r0 + cl];
-    };
+    // rows per staged column of Hc: a compile-time constant, so that the LDS addresses of the k-steps are immediates off one lane base
+    // (as run-time scalars the compiler hoisted one per k-step out of the item loop and spilled a thousand SGPRs)
+    constexpr int nrp = TIGHT ? HV_GATE_TIGHT_ROWS : 16 * TI;
+    // fewest k-steps a track that needs TI row tiles can have (<= 4 rows per pose: 4 (TI - 1) + 1 poses, 7 columns each + the SFT column):
+    // the k-steps below it are live in every call and take no select
+    constexpr int NK_MIN = (7 * (4 * (TI - 1) + 1) + 1 + 3) / 4;
+    // row `r0 + cl` of a 16-row tile of Hs. In TIGHT layouts the last tile runs past row nrp into the next column (after the last column:
+    // into whatever follows Hs in LDS): those values only reach rows / columns >= nr of G and S, which are never stored -- a garbage row i
+    // of an MFMA's A operand stays in output row i, a garbage column c of its B operand in output column c -- so no predication is needed.
+    // The same holds for k-steps beyond nk and columns beyond na4, read unclamped (somewhere inside the workgroup's LDS) and replaced by
+    // zero in a register.
+    auto hs_at = [&](const double *col_k, int r0) -> double { return col_k[r0 + cl]; };
     const int nJ = (na + 15) >> 4, nk = (na + 3) >> 2, na4 = 4 * nk;
     // Work items (J, ct): the 16-row block J of P(a, a) against the 16-column tile ct of Hc' -- nk + 4 (TI - ct) MFMAs (64 cycles each on a
     // SIMD's matrix pipe), item = ct * nJ + J (the dearer tiles first). They are dealt to the waves BY SIMD (wave w runs on SIMD w % 4): a
     // 6-wave workgroup has two waves on SIMDs 0 and 1, so a plain round-robin over the waves would give those SIMDs twice the matrix work.
     // Slots for 6 waves: 0 1 2 3 4 5 2 3 (SIMDs 0 1 2 3 0 1 2 3), i.e. waves 2 and 3 take every 4th item, the others every 8th.
     const int n_items = nJ * TI, stride = nwaves == 6 ? ((wave == 2 || wave == 3) ? 4 : 8) : nwaves;
-    // second product + LDS accumulation of one item, given G = P(a_J, a) Hc(tile ct)' in the accumulator layout
-    auto finish_item = [&](int J, int ct, const double4v &accG) {
+    // second product + LDS accumulation of one item, given G = P(a_J, a) Hc(tile ct)' in the accumulator layout. CT is a compile-time
+    // copy of ct: with `if (rt >= ct)` around every MFMA each tile was its own basic block -- LDS read, full wait, MFMA, branch --
+    // and the matrix pipe idled through one LDS round trip per instruction (r03 ISA reading of the 84-row build)
+    auto finish_tiles = [&](auto ctc, int J, const double4v &accG) {
+        constexpr int CT = decltype(ctc)::value;
         // S(rt, ct) += Hc(16 rt + i, a-index 16 J + k) G(k, 16 ct + c) for the lower tiles rt >= ct; k-step v: A = Hc(.., 16 J + 4 v + kq),
         // B = accG[v] -- the accumulator tile of the first product IS the B-operand layout (lane (kq, c) holds rows 4 v + kq).
         // (rows j >= na of G repeat row na - 1: they meet the zero columns of Hs, or the select below beyond na4)
-        double4v accS[TI];
-#pragma unroll
-        for (int rt = 0; rt < TI; rt++) accS[rt] = double4v{0.0, 0.0, 0.0, 0.0};
+        constexpr int NR = TI - CT;
+        double ha[4][NR];
 #pragma unroll
         for (int v = 0; v < 4; v++) {
             const int idx = 16 * J + 4 * v + kq;
-            double ha[TI];
+            const bool live = 16 * J + 4 * v < na4;                            // (wave-uniform: na4 is a multiple of 4)
+            const double *col_k = Hs + idx * nrp + cl;
 #pragma unroll
-            for (int rt = 0; rt < TI; rt++) {
-                const double x = hs_at(Hs + (size_t)min(idx, na4 - 1) * nrp, 16 * rt);
-                ha[rt] = idx < na4 ? x : 0.0;
-            }
-#pragma unroll
-            for (int rt = 0; rt < TI; rt++)
-                if (rt >= ct) accS[rt] = __builtin_amdgcn_mfma_f64_16x16x4f64(ha[rt], accG[v], accS[rt], 0, 0, 0);     // (ct is wave-uniform)
+            for (int r = 0; r < NR; r++) { const double x = col_k[16 * (CT + r)]; ha[v][r] = live ? x : 0.0; }
         }
+        double4v accS[NR];
+#pragma unroll
+        for (int r = 0; r < NR; r++) accS[r] = double4v{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int v = 0; v < 4; v++)
+#pragma unroll
+            for (int r = 0; r < NR; r++) accS[r] = __builtin_amdgcn_mfma_f64_16x16x4f64(ha[v][r], accG[v], accS[r], 0, 0, 0);
         // the items' partial S meet in LDS (ds_add_f64 on the zeroed matrix; the order in which the waves arrive is not fixed: < 1 ulp of S)
 #pragma unroll
-        for (int rt = 0; rt < TI; rt++)
-            if (rt >= ct) {
+        for (int r = 0; r < NR; r++) {
 #pragma unroll
-                for (int q = 0; q < 4; q++) {
-                    const int i = 16 * rt + kq + 4 * q, c = 16 * ct + cl;
-                    if (i < nr && c < nr && i >= c) unsafeAtomicAdd(&T[(size_t)c * Rs + i], accS[rt][q]);
-                }
+            for (int q = 0; q < 4; q++) {
+                const int i = 16 * (CT + r) + kq + 4 * q, c = 16 * CT + cl;
+                if (i < nr && c < nr && i >= c) unsafeAtomicAdd(&T[(size_t)c * Rs + i], accS[r][q]);
             }
+        }
+    };
+    auto finish_item = [&](int J, int ct, const double4v &accG) {               // (ct is wave-uniform)
+        if (ct == 0) finish_tiles(std::integral_constant<int, 0>{}, J, accG);
+        if constexpr (TI > 1) { if (ct == 1) finish_tiles(std::integral_constant<int, 1>{}, J, accG); }
+        if constexpr (TI > 2) { if (ct == 2) finish_tiles(std::integral_constant<int, 2>{}, J, accG); }
+        if constexpr (TI > 3) { if (ct == 3) finish_tiles(std::integral_constant<int, 3>{}, J, accG); }
+        if constexpr (TI > 4) { if (ct == 4) finish_tiles(std::integral_constant<int, 4>{}, J, accG); }
+        if constexpr (TI > 5) { if (ct == 5) finish_tiles(std::integral_constant<int, 5>{}, J, accG); }
+        static_assert(TI <= 6, "finish_item dispatches up to six column tiles");
     };
     if constexpr (PIPE) {
-        constexpr int U = 20;
+        // U k-steps of an item live in the rotating buffer: 20 cover 80 active columns (<= 11 poses); the big build (one 8-wave workgroup
+        // per CU, 256 VGPRs per wave) holds all 37 k-steps of a 21-pose track -- an in-line remainder exposed one HBM round trip per item
+        constexpr int G = 8, U = TI > 3 ? 40 : 24, NG = U / G;
         // element offsets of the K steps of THIS lane (they do not depend on the item): column a_k of P, k = 4 u + kq
-        int koff[U];
+        // (BYTE offsets, unsigned: scalar base + 32-bit lane offset is one global_load; a 64-bit lane address cost two adds and a VGPR pair)
+        unsigned koff[U];
 #pragma unroll
-        for (int u = 0; u < U; u++) koff[u] = acol[min(4 * u + kq, na - 1)] * n;
-        // The P values of an item's first U k-steps rotate through ONE register buffer: as soon as the MFMA of step u has read cur[u], the
+        for (int u = 0; u < U; u++) koff[u] = (unsigned)(acol[min(4 * u + kq, na - 1)] * n) * 8u;
+        auto p_at = [&](unsigned byte_off) -> double { return *reinterpret_cast<const double *>(reinterpret_cast<const char *>(P) + byte_off); };
+        // The P values of an item's k-steps rotate through ONE register buffer: as soon as the MFMA of step u has read cur[u], the
         // load of the NEXT item's step u is issued into it, so its HBM / L2 round trip hides behind the rest of this item (the remaining
         // k-steps, the second product, the LDS atomics). Loaded item by item, every item exposed one full round trip.
         double cur[U];
         int it = wave;
         if (it < n_items) {
-            const int aj = acol[min(16 * (it % nJ) + cl, na - 1)];             // row a_j of P(a, a): P(a_j, a_k) = P[a_k * n + a_j]
+            const unsigned aj = 8u * (unsigned)acol[min(16 * (it % nJ) + cl, na - 1)];   // row a_j of P(a, a): P(a_j, a_k) = P[a_k * n + a_j]
 #pragma unroll
-            for (int u = 0; u < U; u++) cur[u] = P[koff[u] + aj];              // (uniform base + 32-bit lane offset)
+            for (int u = 0; u < U; u++) cur[u] = p_at(koff[u] + aj);
         }
         for (; it < n_items; it += stride) {
             const int ct = it / nJ, J = it - ct * nJ;
             const int itn = it + stride;
-            const bool has_next = itn < n_items;                               // (wave-uniform)
-            const int aj_next = acol[min(16 * ((has_next ? itn : it) % nJ) + cl, na - 1)];
-            const double *hb_base = Hs + (size_t)kq * nrp;                     // B(k, c) = Hc(16 ct + c, k): column 4 s + kq, rows 16 ct ..
+            // (the last item of a wave re-requests its own values: cheaper than a second copy of the loop body without the prefetch)
+            const unsigned aj_next = 8u * (unsigned)acol[min(16 * ((itn < n_items ? itn : it) % nJ) + cl, na - 1)];
+            const double *hb_base = Hs + (size_t)kq * nrp + 16 * ct + cl;      // B(k, c) = Hc(16 ct + c, k): column 4 s + kq, rows 16 ct ..
             double4v accG = {0.0, 0.0, 0.0, 0.0};
-            // (branch-free bodies: k-steps beyond nk multiply by a zero B operand; one uniform branch picks the body with the prefetch)
-            if (has_next) {
+            // The Hc' operands come from LDS one GROUP of G k-steps ahead of the MFMAs that use them (read one by one in front of each MFMA,
+            // every k-step waited for an LDS round trip); groups beyond nk are skipped by one uniform branch each, k-steps beyond nk
+            // inside the last live group multiply by a zero B operand.
+            double hq[2][G];
+            auto load_hb = [&](double (&h)[G], int g) {
 #pragma unroll
-                for (int u = 0; u < U; u++) {
-                    const double hb = hs_at(hb_base + (size_t)(4 * min(u, nk - 1)) * nrp, 16 * ct);
-                    accG = __builtin_amdgcn_mfma_f64_16x16x4f64(cur[u], u < nk ? hb : 0.0, accG, 0, 0, 0);
-                    cur[u] = P[koff[u] + aj_next];
-                }
-            } else {
+                for (int j = 0; j < G; j++) h[j] = hb_base[4 * (g * G + j) * nrp];
+            };
+            load_hb(hq[0], 0);
 #pragma unroll
-                for (int u = 0; u < U; u++) {
-                    const double hb = hs_at(hb_base + (size_t)(4 * min(u, nk - 1)) * nrp, 16 * ct);
-                    accG = __builtin_amdgcn_mfma_f64_16x16x4f64(cur[u], u < nk ? hb : 0.0, accG, 0, 0, 0);
+            for (int g = 0; g < NG; g++) {
+                if (g * G < nk) {
+                    if (g + 1 < NG) load_hb(hq[(g + 1) & 1], g + 1);
+#pragma unroll
+                    for (int j = 0; j < G; j++) {
+                        const int u = g * G + j;
+                        accG = __builtin_amdgcn_mfma_f64_16x16x4f64(cur[u], (u < NK_MIN || u < nk) ? hq[g & 1][j] : 0.0, accG, 0, 0, 0);
+                        cur[u] = p_at(koff[u] + aj_next);
+                    }
                 }
             }
             if (nk > U) {                                                      // long mono tracks: the remaining k-steps, loaded in line
                 const int aj = acol[min(16 * J + cl, na - 1)];
                 for (int s0 = U; s0 < nk; s0 += 8) {
-                    double av[8];
+                    double av[8], hv8[8];
 #pragma unroll
                     for (int u = 0; u < 8; u++) {
                         const int s = s0 + u;
                         const double x = P[acol[min(4 * s + kq, na - 1)] * n + aj];
                         av[u] = s < nk ? x : 0.0;
+                        hv8[u] = hb_base[(size_t)(4 * min(s, nk - 1)) * nrp];
                     }
 #pragma unroll
-                    for (int u = 0; u < 8; u++)
-                        accG = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u], hs_at(hb_base + (size_t)(4 * min(s0 + u, nk - 1)) * nrp, 16 * ct), accG, 0, 0, 0);
+                    for (int u = 0; u < 8; u++) accG = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u], hv8[u], accG, 0, 0, 0);
                 }
             }
             finish_item(J, ct, accG);
@@ -288,9 +318,11 @@ __device__ __forceinline__ double sparse_gate(const double *P, int n, const int 
             load_a(a0, 0);
             for (int s0 = 0; s0 < nk; s0 += U) {
                 load_a(a1, min(s0 + U, nk));                                   // (past the end: zeros, never used)
+                double hb[U];                                                  // (all of the chunk's LDS operands before its first MFMA)
 #pragma unroll
-                for (int u = 0; u < U; u++)
-                    accG = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[u], hs_at(hb_base + (size_t)(4 * min(s0 + u, nk - 1)) * nrp, 16 * ct), accG, 0, 0, 0);
+                for (int u = 0; u < U; u++) hb[u] = hs_at(hb_base + 4 * min(s0 + u, nk - 1) * nrp, 16 * ct);
+#pragma unroll
+                for (int u = 0; u < U; u++) accG = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[u], hb[u], accG, 0, 0, 0);
 #pragma unroll
                 for (int u = 0; u < U; u++) a0[u] = a1[u];
             }

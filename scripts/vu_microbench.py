@@ -80,6 +80,13 @@ def main():
             ctx.profile_enable(False)
             print(f"visual_track_dev ({name}): {wall:.1f} us per call; prepare(+gate) kernel {ms1 / c1 * 1e3:.1f} us, sparse gate kernel {ms3 / max(c3, 1) * 1e3:.1f} us, update launch {ms2 / c2 * 1e3:.1f} us; "
                   f"gate inliers {int((gs.cpu().numpy() == 0).sum())}/{B}")
+            if os.environ.get("HV_EKF_PHASE_STAMPS") == "1" and name == "all rejected" and ms3 > 0:
+                import ctypes as C
+                st16 = (C.c_longlong * 16)()
+                capi.lib().hv_debug_ekf_phase_stamps.argtypes = [C.c_void_p, C.POINTER(C.c_longlong)]
+                capi.lib().hv_debug_ekf_phase_stamps(g._h, st16)
+                q_ = list(st16)
+                print("big sparse gate phase cycles: staging", q_[13] - q_[12], "gather + products", q_[0] - q_[13], "Cholesky", q_[1] - q_[0], "chi2", q_[2] - q_[1])
             if os.environ.get("HV_EKF_PHASE_STAMPS") == "1" and name == "all rejected":
                 import ctypes as C
                 st40 = (C.c_longlong * 40)()
