@@ -24,6 +24,7 @@
 //     matrix A P A' + Q, which is a gather of P and never materialised; mirrored tile pairs meet
 //     through an in-wave LDS transpose for the fused (P+P')/2, and the result goes to the second of
 //     two ping-pong buffers: one read and one write of P per augmentation.
+#include <functional>
 #include <math.h>
 
 #include <utility>
@@ -969,6 +970,21 @@ __global__ __launch_bounds__(UPD_THREADS) void ekf_update_kernel(UpdateArgs a)
     ekf_update_body<MODE, TI>(a, b);
 }
 
+// Two masked update launches in ONE grid (ragged visits: the inliers of the short class and the first block of the long class's
+// inliers are different filters, ~200 + ~50 of 1024 at the reference's track mix -- one workgroup each on a CU of its own, so two
+// launches were two latency chains back to back on a mostly idle chip): workgroup i < *a0.rec_count serves a0's list, the next
+// *a1.rec_count workgroups serve a1's. The argument block is chosen by a uniform select; the body is instantiated once.
+template <int MODE, int TI>
+__global__ __launch_bounds__(UPD_THREADS) void ekf_update_dual_kernel(UpdateArgs a0, UpdateArgs a1)
+{
+    const int n0 = *a0.rec_count, i = (int)blockIdx.x;
+    const bool first = i < n0;
+    const UpdateArgs &a = first ? a0 : a1;
+    const int j = first ? i : i - n0;
+    if (j >= *a.rec_count) return;
+    ekf_update_body<MODE, TI>(a, a.rec_list[j]);
+}
+
 // ---------------------------------------------------------------------------------------------
 // chi2 gate for MANY filters at once (throughput launches): S = H P H' + R without ever holding H P.
 //
@@ -1598,13 +1614,16 @@ struct Ekf {
 // track (UpdateArgs::half)
 struct CompactH { const int *acol = nullptr; int na_max = 0, ncam = 1; int half = 0, nr_full = 0; double *dm = nullptr; const int *rec_count = nullptr, *rec_list = nullptr; };
 
+// an update launch prepared but not issued (ekf_launch_update's `defer`): two of them can share one grid (ekf_launch_update_dual)
+struct UpdateLaunch { UpdateArgs a; size_t base_bytes = 0; int kmode = -1, ti = 0, lbk = 0; };
+
 static int ekf_launch_update(Ekf *e, int nr, int l, const double *H_dev, const double *v_dev, const double *rdiag_dev,
                              double rd0, int mode, int generic, int normalize_all, double *chi2_dev, int *status_dev,
                              const unsigned char *active_dev, const int *require_inlier_dev = nullptr,
                              int *success_counter_dev = nullptr, double rd1 = 0.0, bool *two_r_done = nullptr,
                              int spec = 0, int n_tracks = 0, int *cursor_dev = nullptr, int max_successful = 0,
                              const int *gate_in_dev = nullptr, int *cursor_out_dev = nullptr, int *pub_dev = nullptr, int pass_id = 0,
-                             const int *nr_rec_dev = nullptr, const CompactH *compact = nullptr, int nr_stride = 0)
+                             const int *nr_rec_dev = nullptr, const CompactH *compact = nullptr, int nr_stride = 0, UpdateLaunch *defer = nullptr)
 {
     // nr_stride (ragged launches that serve one length class): rows of the LONGEST record of the batch = the record stride of H and v;
     // nr is then the most rows this launch processes (kernel variant, LDS carve), longer records are skipped by their `active` flag
@@ -1653,6 +1672,12 @@ static int ekf_launch_update(Ekf *e, int nr, int l, const double *H_dev, const d
     }
     if (spec && kmode != 2) return HV_ERR_UNSUPPORTED;   // the speculative loop keeps every record in the LDS-resident kernel
     const size_t shmem = kmode == 2 ? tall + small + hbytes : kmode == 1 ? tall + small : small;
+    a.batch = e->batch;
+    if (defer) {
+        if (mode == 3 || spec) return HV_ERR_INVALID;
+        defer->a = a; defer->base_bytes = tall + small; defer->kmode = kmode; defer->ti = ti; defer->lbk = lbk;
+        return HV_OK;
+    }
     using Kern = void (*)(UpdateArgs);
     const Kern kern = kmode == 0 ? (Kern)ekf_update_kernel<0, 0> : kmode == 1 ? (Kern)ekf_update_kernel<1, 0>
                     : ti == 1 ? (Kern)ekf_update_kernel<2, 1> : ti == 2 ? (Kern)ekf_update_kernel<2, 2> : (Kern)ekf_update_kernel<2, 3>;
@@ -1665,9 +1690,33 @@ static int ekf_launch_update(Ekf *e, int nr, int l, const double *H_dev, const d
         attr_set = true;
     }
     ScopedKernelTime tm(c, HV_K_EKF_UPDATE);
-    a.batch = e->batch;
     hipLaunchKernelGGL(kern, dim3(e->batch, (spec == 1 || spec == 3) ? n_tracks : 1), dim3(UPD_THREADS), shmem, c->stream, a);
     HV_HIP(c, hipGetLastError());
+    return HV_OK;
+}
+
+// two deferred masked MODE 2 launches over disjoint filters as one grid; *done = false when their shapes do not allow it (the caller
+// then issues them one after the other)
+static int ekf_launch_update_dual(Ekf *e, const UpdateLaunch &A, const UpdateLaunch &B, bool *done)
+{
+    Ctx *c = e->c;
+    *done = false;
+    if (A.kmode != 2 || B.kmode != 2 || !A.a.rec_list || !B.a.rec_list || !A.a.rec_count || !B.a.rec_count) return HV_OK;
+    const int ti = A.ti > B.ti ? A.ti : B.ti;
+    if (ti != 3) return HV_OK;                                     // (the only pairing the visit loop produces: 44 + 42 rows)
+    const size_t sa = A.base_bytes + (size_t)(16 * ti) * (16 * A.lbk) * sizeof(double), sb = B.base_bytes + (size_t)(16 * ti) * (16 * B.lbk) * sizeof(double);
+    const size_t shmem = sa > sb ? sa : sb;
+    if (shmem > 160 * 1024) return HV_OK;
+    static bool attr_set_dev[64] = {};
+    bool &attr_set = attr_set_dev[c->p.device & 63];
+    if (!attr_set) {
+        HV_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void *>(ekf_update_dual_kernel<2, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_set = true;
+    }
+    ScopedKernelTime tm(c, HV_K_EKF_UPDATE);
+    hipLaunchKernelGGL((ekf_update_dual_kernel<2, 3>), dim3(e->batch), dim3(UPD_THREADS), shmem, c->stream, A.a, B.a);
+    HV_HIP(c, hipGetLastError());
+    *done = true;
     return HV_OK;
 }
 
@@ -1966,7 +2015,11 @@ static int visual_track_dev_impl(hv_ekf *h, const hv_vu_params *p, int np, const
     int *cnt_inl = e->visit_counts, *cnt_long = e->visit_counts + 1, *cnt_inl_long = e->visit_counts + 2;
     int *list_inl = e->visit_lists, *list_long = e->visit_lists + e->batch, *list_inl_long = e->visit_lists + 2 * (size_t)e->batch;
     HV_HIP(c, hipMemsetAsync(e->visit_counts, 0, 4 * sizeof(int), c->stream));
-    auto long_chain = [&](hv::VuPrepareArgs l_, double *Hc, double *vv, int *acol, unsigned char *act, double *dm, bool listed) -> int {
+    // short_upd (ragged two-class visits): issues the short class's update, or only prepares it (non-null argument) so that it shares
+    // a grid with the first block update of the long class
+    using ShortUpd = std::function<int(hv::UpdateLaunch *)>;
+    auto long_chain = [&](hv::VuPrepareArgs l_, double *Hc, double *vv, int *acol, unsigned char *act, double *dm, bool listed,
+                          const ShortUpd *short_upd = nullptr) -> int {
         l_.fused = 2; l_.H = nullptr; l_.Hc = Hc; l_.v = vv; l_.acol = acol; l_.na_max = 7 * np + 1; l_.active = act; l_.chi2 = chi2_dev;
         if (listed) { l_.rec_count = cnt_long; l_.rec_list = list_long; }
         int rc2 = hv::launch_vu_prepare(c, l_);
@@ -1976,8 +2029,18 @@ static int visual_track_dev_impl(hv_ekf *h, const hv_vu_params *p, int np, const
         if (rc2 != HV_OK) return rc2;
         const int half_rows = 2 * ((rows + 3) / 4);            // the longer of the two blocks of the longest record
         hv::CompactH h1{acol, l_.na_max, ncam, 1, rows, dm, cnt_inl_long, list_inl_long}, h2{acol, l_.na_max, ncam, 2, rows, dm, cnt_inl_long, list_inl_long};
-        rc2 = hv::ekf_launch_update(e, half_rows, e->n, Hc, vv, nullptr, r_update * r_update * ns, 1, 0, -1, nullptr, nullptr, act, gate_status_dev,
-                                    nullptr, 0.0, nullptr, 0, 0, nullptr, 0, nullptr, nullptr, nullptr, 0, nr_rec, &h1, rows);
+        auto block1 = [&](hv::UpdateLaunch *defer) -> int {
+            return hv::ekf_launch_update(e, half_rows, e->n, Hc, vv, nullptr, r_update * r_update * ns, 1, 0, -1, nullptr, nullptr, act, gate_status_dev,
+                                         nullptr, 0.0, nullptr, 0, 0, nullptr, 0, nullptr, nullptr, nullptr, 0, nr_rec, &h1, rows, defer);
+        };
+        if (short_upd) {
+            hv::UpdateLaunch us, u1;
+            bool dual = false;
+            rc2 = (*short_upd)(&us);
+            if (rc2 == HV_OK) rc2 = block1(&u1);
+            if (rc2 == HV_OK) rc2 = hv::ekf_launch_update_dual(e, us, u1, &dual);
+            if (rc2 == HV_OK && !dual) { rc2 = (*short_upd)(nullptr); if (rc2 == HV_OK) rc2 = block1(nullptr); }
+        } else rc2 = block1(nullptr);
         if (rc2 != HV_OK) return rc2;
         return hv::ekf_launch_update(e, half_rows, e->n, Hc, vv, nullptr, r_update * r_update * ns, 1, 0, 1, nullptr, nullptr, act, gate_status_dev,
                                      success_counter_dev, 0.0, nullptr, 0, 0, nullptr, 0, nullptr, nullptr, nullptr, 0, nr_rec, &h2, rows);
@@ -2028,15 +2091,20 @@ static int visual_track_dev_impl(hv_ekf *h, const hv_vu_params *p, int np, const
         s_.inl_count = cnt_inl; s_.inl_list = list_inl; s_.long_count = cnt_long; s_.long_list = list_long;
         rc = hv::launch_vu_prepare(c, s_);
         const hv::CompactH ch{e->vuacol, s_.na_max, ncam, 0, 0, nullptr, cnt_inl, list_inl};
-        if (rc == HV_OK)
-            rc = hv::ekf_launch_update(e, 2 * np_short * ncam, e->n, e->vuH, e->vuv, nullptr, r_update * r_update * ns, 1, 0, 1, nullptr, nullptr,
-                                       e->vuactive, gate_status_dev, success_counter_dev, 0.0, nullptr, 0, 0, nullptr, 0, nullptr, nullptr,
-                                       nullptr, 0, nr_rec, &ch, rows);
+        const ShortUpd short_upd = [&](hv::UpdateLaunch *defer) -> int {
+            return hv::ekf_launch_update(e, 2 * np_short * ncam, e->n, e->vuH, e->vuv, nullptr, r_update * r_update * ns, 1, 0, 1, nullptr, nullptr,
+                                         e->vuactive, gate_status_dev, success_counter_dev, 0.0, nullptr, 0, 0, nullptr, 0, nullptr, nullptr,
+                                         nullptr, 0, nr_rec, &ch, rows, defer);
+        };
+        // knob ekf_dual_update (default 1): the short class's update waits for the long class's prepare + gate launches and then shares
+        // a grid with the first block update of the long class (the two serve different filters)
+        const bool pair = c->knob.ekf_dual_update != 0 && !fork;
+        if (rc == HV_OK && !pair) rc = short_upd(nullptr);
         if (rc == HV_OK) {
             if (fork) c->stream = e->side_stream[0];
             hv::VuPrepareArgs l_ = a;
             l_.np_lo = np_short + 1; l_.np_hi = np; l_.class_inactive = 1; l_.persistent = c->knob.ekf_persistent == 1 ? 1 : 0; l_.queue = e->queue_dev;
-            rc = long_chain(l_, e->sideH[0], e->sidev[0], e->side_acol, e->side_active[0], e->side_dm, true);
+            rc = long_chain(l_, e->sideH[0], e->sidev[0], e->side_acol, e->side_active[0], e->side_dm, true, pair ? &short_upd : nullptr);
             c->stream = main_stream;
         }
         if (fork) {
