@@ -972,16 +972,22 @@ __global__ __launch_bounds__(UPD_THREADS) void ekf_update_kernel(UpdateArgs a)
 
 // Two masked update launches in ONE grid (ragged visits: the inliers of the short class and the first block of the long class's
 // inliers are different filters, ~200 + ~50 of 1024 at the reference's track mix -- one workgroup each on a CU of its own, so two
-// launches were two latency chains back to back on a mostly idle chip): workgroup i < *a0.rec_count serves a0's list, the next
-// *a1.rec_count workgroups serve a1's. The argument block is chosen by a uniform select; the body is instantiated once.
+// launches were two latency chains back to back on a mostly idle chip): the first workgroups serve a1's list, the next ones a0's.
+// The argument block is chosen by a uniform select; the body is instantiated once.
+// Every workgroup needs a CU of its own, so a grid of more than num_cus live workgroups takes a second round. The long class follows
+// with a second launch anyway (its second block update): `part` 0 = all of a1 + the entries of a0's list that fit beside them on the
+// chip (cap = num_cus - *a1.rec_count), `part` 1 = all of a1 + the REST of a0's list -- the visit loop issues (a0 = short class, a1 =
+// long block 1, part 0) and then (a0 = short class, a1 = long block 2, part 1); `part` < 0: all of both lists.
 template <int MODE, int TI>
-__global__ __launch_bounds__(UPD_THREADS) void ekf_update_dual_kernel(UpdateArgs a0, UpdateArgs a1)
+__global__ __launch_bounds__(UPD_THREADS) void ekf_update_dual_kernel(UpdateArgs a0, UpdateArgs a1, int part, int num_cus)
 {
-    const int n0 = *a0.rec_count, i = (int)blockIdx.x;
-    const bool first = i < n0;
-    const UpdateArgs &a = first ? a0 : a1;
-    const int j = first ? i : i - n0;
-    if (j >= *a.rec_count) return;
+    const int n0 = *a0.rec_count, n1 = *a1.rec_count, i = (int)blockIdx.x;
+    const int cap = min(n0, max(num_cus - n1, 0));
+    const int lo = part == 1 ? cap : 0, hi = part == 0 ? cap : n0;          // a0's share of this launch
+    const bool second = i < n1;
+    const UpdateArgs &a = second ? a1 : a0;
+    const int j = second ? i : i - n1 + lo;
+    if (!second && j >= hi) return;
     ekf_update_body<MODE, TI>(a, a.rec_list[j]);
 }
 
@@ -1237,10 +1243,10 @@ __device__ __forceinline__ void sparse_gate_kernel_body(const SparseGateArgs &a,
         else if (ti == 2) chi = sparse_gate<2, NTH, true>(Pb, n, s_acol, na, Hs, T, Rs, nr, a.rd, a.noise_scale, Hs, BIG ? g_phase_stamp : nullptr);
         else              chi = sparse_gate<3, NTH, true>(Pb, n, s_acol, na, Hs, T, Rs, nr, a.rd, a.noise_scale, Hs, BIG ? g_phase_stamp : nullptr);
     } else {
-        if (ti <= 4)      chi = sparse_gate<4, NTH, true>(Pb, n, s_acol, na, Hs, T, Rs, nr, a.rd, a.noise_scale, Hs, BIG ? g_phase_stamp : nullptr);
-        else if (ti == 5) chi = sparse_gate<5, NTH, true>(Pb, n, s_acol, na, Hs, T, Rs, nr, a.rd, a.noise_scale, Hs, BIG ? g_phase_stamp : nullptr);
-        else if (!tight)  chi = sparse_gate<6, NTH, true>(Pb, n, s_acol, na, Hs, T, Rs, nr, a.rd, a.noise_scale, Hs, BIG ? g_phase_stamp : nullptr);
-        else              chi = sparse_gate<6, NTH, true, true>(Pb, n, s_acol, na, Hs, T, Rs, nr, a.rd, a.noise_scale, Hs, BIG ? g_phase_stamp : nullptr);
+        if (ti <= 4)      chi = sparse_gate<4, NTH, false>(Pb, n, s_acol, na, Hs, T, Rs, nr, a.rd, a.noise_scale, Hs, BIG ? g_phase_stamp : nullptr);
+        else if (ti == 5) chi = sparse_gate<5, NTH, false>(Pb, n, s_acol, na, Hs, T, Rs, nr, a.rd, a.noise_scale, Hs, BIG ? g_phase_stamp : nullptr);
+        else if (!tight)  chi = sparse_gate<6, NTH, false>(Pb, n, s_acol, na, Hs, T, Rs, nr, a.rd, a.noise_scale, Hs, BIG ? g_phase_stamp : nullptr);
+        else              chi = sparse_gate<6, NTH, false, true>(Pb, n, s_acol, na, Hs, T, Rs, nr, a.rd, a.noise_scale, Hs, BIG ? g_phase_stamp : nullptr);
     }
     if (t == 0) {
         const bool broken = !(chi < 1e300);                    // non-positive pivot: reported as CHI2 (ekf_update_kernel phase D)
@@ -1608,6 +1614,10 @@ struct Ekf {
     int *err_dev = nullptr;                               // device error word (UpdateArgs::err)
     int *queue_dev = nullptr;                             // work queue of the persistent launches (HV_QUEUE_LOOP), zero between launches
     int *visit_counts = nullptr, *visit_lists = nullptr;  // compaction lists of a visit: counts {inliers short, long records, inliers long}, lists 3 x [batch]
+    // the counts exist once per visit of a frame loop (VISIT_SLOTS x 4 ints, zeroed by ONE memset per frame; visit_slot = the running
+    // visit, set by the loop) plus one set for stand-alone visits (zeroed per call): a memset node per visit was 20 more graph nodes
+    static constexpr int VISIT_SLOTS = 64;
+    int visit_slot = -1;
 };
 
 // compact-H description handed to ekf_launch_update (null acol: dense H of l columns); half / nr_full / dm: block update of a long
@@ -1697,7 +1707,7 @@ static int ekf_launch_update(Ekf *e, int nr, int l, const double *H_dev, const d
 
 // two deferred masked MODE 2 launches over disjoint filters as one grid; *done = false when their shapes do not allow it (the caller
 // then issues them one after the other)
-static int ekf_launch_update_dual(Ekf *e, const UpdateLaunch &A, const UpdateLaunch &B, bool *done)
+static int ekf_launch_update_dual(Ekf *e, const UpdateLaunch &A, const UpdateLaunch &B, int part, bool *done)
 {
     Ctx *c = e->c;
     *done = false;
@@ -1714,7 +1724,7 @@ static int ekf_launch_update_dual(Ekf *e, const UpdateLaunch &A, const UpdateLau
         attr_set = true;
     }
     ScopedKernelTime tm(c, HV_K_EKF_UPDATE);
-    hipLaunchKernelGGL((ekf_update_dual_kernel<2, 3>), dim3(e->batch), dim3(UPD_THREADS), shmem, c->stream, A.a, B.a);
+    hipLaunchKernelGGL((ekf_update_dual_kernel<2, 3>), dim3(e->batch), dim3(UPD_THREADS), shmem, c->stream, A.a, B.a, part, c->num_cus);
     HV_HIP(c, hipGetLastError());
     *done = true;
     return HV_OK;
@@ -1862,7 +1872,7 @@ int hv_ekf_create(hv_ctx *ctx, const hv_ekf_params *par, int batch, hv_ekf **out
     alloc(e->schi2, sizeof(double) * batch); alloc(e->simu, sizeof(double) * 7 * HV_EKF_MAX_PREDICT_SAMPLES * batch);
     alloc(e->sstatus, sizeof(int) * batch); alloc(e->sdrop, sizeof(int) * batch); alloc(e->sactive, batch);
     alloc(e->err_dev, sizeof(int)); alloc(e->queue_dev, 2 * sizeof(int));
-    alloc(e->visit_counts, 4 * sizeof(int)); alloc(e->visit_lists, 3 * sizeof(int) * (size_t)batch);
+    alloc(e->visit_counts, 4 * sizeof(int) * (Ekf::VISIT_SLOTS + 1)); alloc(e->visit_lists, 3 * sizeof(int) * (size_t)batch);
     if (ok && hipMemset(e->err_dev, 0, sizeof(int)) != hipSuccess) ok = false;
     if (ok && hipMemset(e->queue_dev, 0, 2 * sizeof(int)) != hipSuccess) ok = false;
     if (!ok) { hv_ekf_destroy(h); return HV_ERR_NOMEM; }
@@ -2012,9 +2022,11 @@ static int visual_track_dev_impl(hv_ekf *h, const hv_vu_params *p, int np, const
     const int ncam = a.stereo ? 2 : 1, np_short = 22 / ncam < 24 / ncam ? 22 / ncam : 24 / ncam;
     const bool long_ok = c->knob.ekf_fused_gate != 0 && e->n <= 160 && rows > 48 && rows <= 96 && rows < HV_CHI2INV95_N && (rows + 3) / 4 * 2 <= 48;
     // compaction lists of this visit (VuPrepareArgs): zeroed here, filled by the kernels, consumed by the launches behind them
-    int *cnt_inl = e->visit_counts, *cnt_long = e->visit_counts + 1, *cnt_inl_long = e->visit_counts + 2;
+    const bool own_counts = e->visit_slot < 0 || e->visit_slot >= Ekf::VISIT_SLOTS;
+    int *counts = e->visit_counts + 4 * (own_counts ? Ekf::VISIT_SLOTS : e->visit_slot);
+    int *cnt_inl = counts, *cnt_long = counts + 1, *cnt_inl_long = counts + 2;
     int *list_inl = e->visit_lists, *list_long = e->visit_lists + e->batch, *list_inl_long = e->visit_lists + 2 * (size_t)e->batch;
-    HV_HIP(c, hipMemsetAsync(e->visit_counts, 0, 4 * sizeof(int), c->stream));
+    if (own_counts) HV_HIP(c, hipMemsetAsync(counts, 0, 4 * sizeof(int), c->stream));
     // short_upd (ragged two-class visits): issues the short class's update, or only prepares it (non-null argument) so that it shares
     // a grid with the first block update of the long class
     using ShortUpd = std::function<int(hv::UpdateLaunch *)>;
@@ -2033,17 +2045,23 @@ static int visual_track_dev_impl(hv_ekf *h, const hv_vu_params *p, int np, const
             return hv::ekf_launch_update(e, half_rows, e->n, Hc, vv, nullptr, r_update * r_update * ns, 1, 0, -1, nullptr, nullptr, act, gate_status_dev,
                                          nullptr, 0.0, nullptr, 0, 0, nullptr, 0, nullptr, nullptr, nullptr, 0, nr_rec, &h1, rows, defer);
         };
+        auto block2 = [&](hv::UpdateLaunch *defer) -> int {
+            return hv::ekf_launch_update(e, half_rows, e->n, Hc, vv, nullptr, r_update * r_update * ns, 1, 0, 1, nullptr, nullptr, act, gate_status_dev,
+                                         success_counter_dev, 0.0, nullptr, 0, 0, nullptr, 0, nullptr, nullptr, nullptr, 0, nr_rec, &h2, rows, defer);
+        };
         if (short_upd) {
-            hv::UpdateLaunch us, u1;
+            // (short class beside block 1, what did not fit on the chip beside block 2: see ekf_update_dual_kernel)
+            hv::UpdateLaunch us, u1, u2;
             bool dual = false;
             rc2 = (*short_upd)(&us);
             if (rc2 == HV_OK) rc2 = block1(&u1);
-            if (rc2 == HV_OK) rc2 = hv::ekf_launch_update_dual(e, us, u1, &dual);
-            if (rc2 == HV_OK && !dual) { rc2 = (*short_upd)(nullptr); if (rc2 == HV_OK) rc2 = block1(nullptr); }
+            if (rc2 == HV_OK) rc2 = block2(&u2);
+            if (rc2 == HV_OK) rc2 = hv::ekf_launch_update_dual(e, us, u1, 0, &dual);
+            if (rc2 == HV_OK && dual) return hv::ekf_launch_update_dual(e, us, u2, 1, &dual);      // (same shapes: accepted again)
+            if (rc2 == HV_OK) { rc2 = (*short_upd)(nullptr); if (rc2 == HV_OK) rc2 = block1(nullptr); }
         } else rc2 = block1(nullptr);
         if (rc2 != HV_OK) return rc2;
-        return hv::ekf_launch_update(e, half_rows, e->n, Hc, vv, nullptr, r_update * r_update * ns, 1, 0, 1, nullptr, nullptr, act, gate_status_dev,
-                                     success_counter_dev, 0.0, nullptr, 0, 0, nullptr, 0, nullptr, nullptr, nullptr, 0, nr_rec, &h2, rows);
+        return block2(nullptr);
     };
     auto ensure_side = [&]() -> int {                          // second stream + buffers of the long-track chain
         if (!e->side_stream[0]) {
@@ -2271,12 +2289,15 @@ static int visual_frame_dev_impl(hv_ekf *h, const hv_vu_params *p, int n_tracks,
         }
         return HV_OK;
     }
+    HV_HIP(c, hipMemsetAsync(e->visit_counts, 0, 4 * sizeof(int) * Ekf::VISIT_SLOTS, c->stream));
     for (int k = 0; k < n_tracks; ++k) {
+        e->visit_slot = k;
         const int rc = visual_track_dev_impl(h, p, np, idx + (size_t)k * B * np, feat + (size_t)k * B * nt * 2, vel + (size_t)k * B * nt * 2,
                                              y + (size_t)k * B * nt * 2, r_gate, r_update, status_dev + (size_t)k * B * 2,
                                              gate_status_dev + (size_t)k * B, chi2_dev ? chi2_dev + (size_t)k * B : nullptr,
                                              pf_dev ? pf_dev + (size_t)k * B * 3 : nullptr, success_counter_dev, max_successful,
                                              np_rec_dev ? np_rec_dev + (size_t)k * B : nullptr);
+        e->visit_slot = -1;
         if (rc != HV_OK) return rc;
     }
     return HV_OK;

@@ -176,18 +176,20 @@ __device__ __forceinline__ double sparse_gate(const double *P, int n, const int 
     // fewest k-steps a track that needs TI row tiles can have (<= 4 rows per pose: 4 (TI - 1) + 1 poses, 7 columns each + the SFT column):
     // the k-steps below it are live in every call and take no select
     constexpr int NK_MIN = (7 * (4 * (TI - 1) + 1) + 1 + 3) / 4;
-    // row `r0 + cl` of a 16-row tile of Hs. In TIGHT layouts the last tile runs past row nrp into the next column (after the last column:
+    // Rows of a 16-row tile of Hs: in TIGHT layouts the last tile runs past row nrp into the next column (after the last column:
     // into whatever follows Hs in LDS): those values only reach rows / columns >= nr of G and S, which are never stored -- a garbage row i
     // of an MFMA's A operand stays in output row i, a garbage column c of its B operand in output column c -- so no predication is needed.
-    // The same holds for k-steps beyond nk and columns beyond na4, read unclamped (somewhere inside the workgroup's LDS) and replaced by
-    // zero in a register.
-    auto hs_at = [&](const double *col_k, int r0) -> double { return col_k[r0 + cl]; };
+    // Columns beyond na4 (second product) are read unclamped -- somewhere inside the workgroup's LDS -- and replaced by zero in a register.
     const int nJ = (na + 15) >> 4, nk = (na + 3) >> 2, na4 = 4 * nk;
-    // Work items (J, ct): the 16-row block J of P(a, a) against the 16-column tile ct of Hc' -- nk + 4 (TI - ct) MFMAs (64 cycles each on a
-    // SIMD's matrix pipe), item = ct * nJ + J (the dearer tiles first). They are dealt to the waves BY SIMD (wave w runs on SIMD w % 4): a
-    // 6-wave workgroup has two waves on SIMDs 0 and 1, so a plain round-robin over the waves would give those SIMDs twice the matrix work.
-    // Slots for 6 waves: 0 1 2 3 4 5 2 3 (SIMDs 0 1 2 3 0 1 2 3), i.e. waves 2 and 3 take every 4th item, the others every 8th.
-    const int n_items = nJ * TI, stride = nwaves == 6 ? ((wave == 2 || wave == 3) ? 4 : 8) : nwaves;
+    // Work items (J, g): the 16-row block J of P(a, a) against the column tiles ct of group g of Hc' (one group of all TI tiles up to 48
+    // rows, two groups of 3 / 3, 3 / 2 or 2 / 2 tiles in the big build); item = g * nJ + J. The P values of block J are the A operand of
+    // EVERY column tile: as (J, ct) items -- r03's first form -- each of them was gathered TI times, and the scattered 8-byte gather
+    // (~14 cache lines per wave-wide load), not the matrix pipe, set the pace: 52 k cycles of a 10-pose gate against 7 k of MFMA work.
+    // Items are dealt to the waves BY SIMD (wave w runs on SIMD w % 4): a 6-wave workgroup has two waves on SIMDs 0 and 1, so a plain
+    // round-robin over the waves would give those SIMDs twice the matrix work. Slots for 6 waves: 0 1 2 3 4 5 2 3 (SIMDs 0 1 2 3 0 1 2 3),
+    // i.e. waves 2 and 3 take every 4th item, the others every 8th.
+    constexpr int NCG = TI > 3 ? 2 : 1, CGS = (TI + NCG - 1) / NCG;
+    const int n_items = nJ * NCG, stride = nwaves == 6 ? ((wave == 2 || wave == 3) ? 4 : 8) : nwaves;
     // second product + LDS accumulation of one item, given G = P(a_J, a) Hc(tile ct)' in the accumulator layout. CT is a compile-time
     // copy of ct: with `if (rt >= ct)` around every MFMA each tile was its own basic block -- LDS read, full wait, MFMA, branch --
     // and the matrix pipe idled through one LDS round trip per instruction (r03 ISA reading of the 84-row build)
@@ -197,22 +199,25 @@ __device__ __forceinline__ double sparse_gate(const double *P, int n, const int 
         // B = accG[v] -- the accumulator tile of the first product IS the B-operand layout (lane (kq, c) holds rows 4 v + kq).
         // (rows j >= na of G repeat row na - 1: they meet the zero columns of Hs, or the select below beyond na4)
         constexpr int NR = TI - CT;
-        double ha[4][NR];
-#pragma unroll
-        for (int v = 0; v < 4; v++) {
+        // (the A operands of k-step v + 1 are read while the MFMAs of step v run: two buffers of NR values)
+        double ha[2][NR];
+        auto load_ha = [&](double (&h)[NR], int v) {
             const int idx = 16 * J + 4 * v + kq;
             const bool live = 16 * J + 4 * v < na4;                            // (wave-uniform: na4 is a multiple of 4)
             const double *col_k = Hs + idx * nrp + cl;
 #pragma unroll
-            for (int r = 0; r < NR; r++) { const double x = col_k[16 * (CT + r)]; ha[v][r] = live ? x : 0.0; }
-        }
+            for (int r = 0; r < NR; r++) { const double x = col_k[16 * (CT + r)]; h[r] = live ? x : 0.0; }
+        };
+        load_ha(ha[0], 0);
         double4v accS[NR];
 #pragma unroll
         for (int r = 0; r < NR; r++) accS[r] = double4v{0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-        for (int v = 0; v < 4; v++)
+        for (int v = 0; v < 4; v++) {
+            if (v < 3) load_ha(ha[(v + 1) & 1], v + 1);
 #pragma unroll
-            for (int r = 0; r < NR; r++) accS[r] = __builtin_amdgcn_mfma_f64_16x16x4f64(ha[v][r], accG[v], accS[r], 0, 0, 0);
+            for (int r = 0; r < NR; r++) accS[r] = __builtin_amdgcn_mfma_f64_16x16x4f64(ha[v & 1][r], accG[v], accS[r], 0, 0, 0);
+        }
         // the items' partial S meet in LDS (ds_add_f64 on the zeroed matrix; the order in which the waves arrive is not fixed: < 1 ulp of S)
 #pragma unroll
         for (int r = 0; r < NR; r++) {
@@ -223,110 +228,146 @@ __device__ __forceinline__ double sparse_gate(const double *P, int n, const int 
             }
         }
     };
-    auto finish_item = [&](int J, int ct, const double4v &accG) {               // (ct is wave-uniform)
-        if (ct == 0) finish_tiles(std::integral_constant<int, 0>{}, J, accG);
-        if constexpr (TI > 1) { if (ct == 1) finish_tiles(std::integral_constant<int, 1>{}, J, accG); }
-        if constexpr (TI > 2) { if (ct == 2) finish_tiles(std::integral_constant<int, 2>{}, J, accG); }
-        if constexpr (TI > 3) { if (ct == 3) finish_tiles(std::integral_constant<int, 3>{}, J, accG); }
-        if constexpr (TI > 4) { if (ct == 4) finish_tiles(std::integral_constant<int, 4>{}, J, accG); }
-        if constexpr (TI > 5) { if (ct == 5) finish_tiles(std::integral_constant<int, 5>{}, J, accG); }
-        static_assert(TI <= 6, "finish_item dispatches up to six column tiles");
+    // the second products of an item's column tiles CT0 .. CT0 + NCT - 1
+    auto finish_group = [&](auto ct0c, auto nctc, int J, const double4v *accG) {
+        constexpr int CT0 = decltype(ct0c)::value, NCT = decltype(nctc)::value;
+        finish_tiles(std::integral_constant<int, CT0>{}, J, accG[0]);
+        if constexpr (NCT > 1) finish_tiles(std::integral_constant<int, CT0 + 1>{}, J, accG[1]);
+        if constexpr (NCT > 2) finish_tiles(std::integral_constant<int, CT0 + 2>{}, J, accG[2]);
+        static_assert(NCT <= 3, "at most three column tiles per item");
     };
+    // LDS address of the B operands of k-step u: B(k, c) = Hc(16 ct + c, k), column 4 u + kq. Steps that may lie beyond nk re-read the
+    // last live column (their A operand is zero; an unclamped read could meet a NaN bit pattern elsewhere in LDS)
+    auto hb_col = [&](int u) -> const double * { return Hs + (size_t)(4 * ((u < NK_MIN) ? u : min(u, nk - 1)) + kq) * nrp + cl; };
     if constexpr (PIPE) {
-        // U k-steps of an item live in the rotating buffer: 20 cover 80 active columns (<= 11 poses); the big build (one 8-wave workgroup
+        // U k-steps of an item live in the rotating buffer: 24 cover 96 active columns (<= 13 poses); the big build (one 8-wave workgroup
         // per CU, 256 VGPRs per wave) holds all 37 k-steps of a 21-pose track -- an in-line remainder exposed one HBM round trip per item
         constexpr int G = 8, U = TI > 3 ? 40 : 24, NG = U / G;
         // element offsets of the K steps of THIS lane (they do not depend on the item): column a_k of P, k = 4 u + kq
         // (BYTE offsets, unsigned: scalar base + 32-bit lane offset is one global_load; a 64-bit lane address cost two adds and a VGPR pair)
-        unsigned koff[U];
+        // Kept in registers by the small build; the big one (40 k-steps in flight) re-reads the column list from LDS in front of each
+        // prefetch instead of holding 40 more VGPRs
+        constexpr bool KOFF_REGS = U <= 24;
+        unsigned koff_r[KOFF_REGS ? U : 1];
+        if constexpr (KOFF_REGS) {
 #pragma unroll
-        for (int u = 0; u < U; u++) koff[u] = (unsigned)(acol[min(4 * u + kq, na - 1)] * n) * 8u;
+            for (int u = 0; u < U; u++) koff_r[u] = (unsigned)(acol[min(4 * u + kq, na - 1)] * n) * 8u;
+        }
+        auto koff = [&](int u) -> unsigned {
+            if constexpr (KOFF_REGS) return koff_r[u];
+            else return (unsigned)(acol[min(4 * u + kq, na - 1)] * n) * 8u;
+        };
         auto p_at = [&](unsigned byte_off) -> double { return *reinterpret_cast<const double *>(reinterpret_cast<const char *>(P) + byte_off); };
-        // The P values of an item's k-steps rotate through ONE register buffer: as soon as the MFMA of step u has read cur[u], the
+        // The P values of an item's k-steps rotate through ONE register buffer: as soon as the MFMAs of step u have read cur[u], the
         // load of the NEXT item's step u is issued into it, so its HBM / L2 round trip hides behind the rest of this item (the remaining
-        // k-steps, the second product, the LDS atomics). Loaded item by item, every item exposed one full round trip.
+        // k-steps, the second products, the LDS atomics). Loaded item by item, every item exposed one full round trip.
         double cur[U];
+        auto aj_of = [&](int item) -> unsigned {                               // row a_j of P(a, a): P(a_j, a_k) = P[a_k * n + a_j]
+            const int J = item >= nJ ? item - nJ : item;
+            return 8u * (unsigned)acol[min(16 * J + cl, na - 1)];
+        };
         int it = wave;
         if (it < n_items) {
-            const unsigned aj = 8u * (unsigned)acol[min(16 * (it % nJ) + cl, na - 1)];   // row a_j of P(a, a): P(a_j, a_k) = P[a_k * n + a_j]
+            const unsigned aj = aj_of(it);
 #pragma unroll
-            for (int u = 0; u < U; u++) cur[u] = p_at(koff[u] + aj);
+            for (int u = 0; u < U; u++) cur[u] = p_at(koff(u) + aj);
         }
-        for (; it < n_items; it += stride) {
-            const int ct = it / nJ, J = it - ct * nJ;
-            const int itn = it + stride;
-            // (the last item of a wave re-requests its own values: cheaper than a second copy of the loop body without the prefetch)
-            const unsigned aj_next = 8u * (unsigned)acol[min(16 * ((itn < n_items ? itn : it) % nJ) + cl, na - 1)];
-            const double *hb_base = Hs + (size_t)kq * nrp + 16 * ct + cl;      // B(k, c) = Hc(16 ct + c, k): column 4 s + kq, rows 16 ct ..
-            double4v accG = {0.0, 0.0, 0.0, 0.0};
-            // The Hc' operands come from LDS one GROUP of G k-steps ahead of the MFMAs that use them (read one by one in front of each MFMA,
-            // every k-step waited for an LDS round trip); groups beyond nk are skipped by one uniform branch each, k-steps beyond nk
-            // inside the last live group multiply by a zero B operand.
-            double hq[2][G];
-            auto load_hb = [&](double (&h)[G], int g) {
+        // one item: NCT accumulator chains share every A operand; the Hc' operands of step u + 1 are read from LDS while the MFMAs of
+        // step u run (read right in front of their MFMA, every k-step waited for an LDS round trip)
+        auto pipe_item = [&](auto ct0c, auto nctc, int J, unsigned aj_next) {
+            constexpr int CT0 = decltype(ct0c)::value, NCT = decltype(nctc)::value;
+            double4v accG[NCT];
 #pragma unroll
-                for (int j = 0; j < G; j++) h[j] = hb_base[4 * (g * G + j) * nrp];
+            for (int c = 0; c < NCT; c++) accG[c] = double4v{0.0, 0.0, 0.0, 0.0};
+            double hq[2][NCT];
+            auto load_hb = [&](double (&h)[NCT], int u) {
+                const double *col = hb_col(u) + 16 * CT0;
+#pragma unroll
+                for (int c = 0; c < NCT; c++) h[c] = col[16 * c];
             };
             load_hb(hq[0], 0);
 #pragma unroll
             for (int g = 0; g < NG; g++) {
-                if (g * G < nk) {
-                    if (g + 1 < NG) load_hb(hq[(g + 1) & 1], g + 1);
+                if (g * G < nk) {                                              // (groups beyond nk: one uniform branch each)
 #pragma unroll
                     for (int j = 0; j < G; j++) {
                         const int u = g * G + j;
-                        accG = __builtin_amdgcn_mfma_f64_16x16x4f64(cur[u], (u < NK_MIN || u < nk) ? hq[g & 1][j] : 0.0, accG, 0, 0, 0);
-                        cur[u] = p_at(koff[u] + aj_next);
+                        if (u + 1 < U) load_hb(hq[(u + 1) & 1], u + 1);
+                        const double av = (u < NK_MIN || u < nk) ? cur[u] : 0.0;
+#pragma unroll
+                        for (int c = 0; c < NCT; c++) accG[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, hq[u & 1][c], accG[c], 0, 0, 0);
+                        cur[u] = p_at(koff(u) + aj_next);
                     }
                 }
             }
             if (nk > U) {                                                      // long mono tracks: the remaining k-steps, loaded in line
-                const int aj = acol[min(16 * J + cl, na - 1)];
+                const unsigned aj = 8u * (unsigned)acol[min(16 * J + cl, na - 1)];
                 for (int s0 = U; s0 < nk; s0 += 8) {
-                    double av[8], hv8[8];
+                    double av[8];
 #pragma unroll
                     for (int u = 0; u < 8; u++) {
                         const int s = s0 + u;
-                        const double x = P[acol[min(4 * s + kq, na - 1)] * n + aj];
+                        const double x = p_at((unsigned)(acol[min(4 * s + kq, na - 1)] * n) * 8u + aj);
                         av[u] = s < nk ? x : 0.0;
-                        hv8[u] = hb_base[(size_t)(4 * min(s, nk - 1)) * nrp];
                     }
 #pragma unroll
-                    for (int u = 0; u < 8; u++) accG = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u], hv8[u], accG, 0, 0, 0);
+                    for (int u = 0; u < 8; u++) {
+                        const double *col = Hs + (size_t)(4 * min(s0 + u, nk - 1) + kq) * nrp + cl + 16 * CT0;
+#pragma unroll
+                        for (int c = 0; c < NCT; c++) accG[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u], col[16 * c], accG[c], 0, 0, 0);
+                    }
                 }
             }
-            finish_item(J, ct, accG);
+            finish_group(ct0c, nctc, J, accG);
+        };
+        for (; it < n_items; it += stride) {
+            const int itn = it + stride;
+            // (the last item of a wave re-requests its own values: cheaper than a second copy of the loop body without the prefetch)
+            const unsigned aj_next = aj_of(itn < n_items ? itn : it);
+            if constexpr (NCG == 1) pipe_item(std::integral_constant<int, 0>{}, std::integral_constant<int, TI>{}, it, aj_next);
+            else if (it < nJ)       pipe_item(std::integral_constant<int, 0>{}, std::integral_constant<int, CGS>{}, it, aj_next);
+            else                    pipe_item(std::integral_constant<int, CGS>{}, std::integral_constant<int, TI - CGS>{}, it - nJ, aj_next);
         }
     } else {
-        constexpr int U = 10;
-        for (int it = wave; it < n_items; it += stride) {
-            const int ct = it / nJ, J = it - ct * nJ;
-            const int aj = acol[min(16 * J + cl, na - 1)];                     // row a_j of P(a, a): P(a_j, a_k) = P[a_k * n + a_j]
-            const double *hb_base = Hs + (size_t)kq * nrp;                     // B(k, c) = Hc(16 ct + c, k)
-            double4v accG = {0.0, 0.0, 0.0, 0.0};
+        // chunked form (the fused prepare + gate kernel on its 128 VGPRs, and the big build: with two or three column tiles per item an
+        // item is >= 7 k cycles of matrix work against one exposed load round trip, which the SIMD's other wave covers -- the rotating
+        // buffer of 40 k-steps plus three accumulator chains did not fit 256 VGPRs)
+        constexpr int U = 10;                  // (the big build with chunks of 16: 21-pose gate 88 k -> 99 k cycles, r03)
+        auto chunk_item = [&](auto ct0c, auto nctc, int J) {
+            constexpr int CT0 = decltype(ct0c)::value, NCT = decltype(nctc)::value;
+            const unsigned aj = (unsigned)acol[min(16 * J + cl, na - 1)];      // row a_j of P(a, a): P(a_j, a_k) = P[a_k * n + a_j]
+            double4v accG[NCT];
+#pragma unroll
+            for (int c = 0; c < NCT; c++) accG[c] = double4v{0.0, 0.0, 0.0, 0.0};
             // k-steps in chunks of U, the next chunk's P values requested before this chunk's MFMAs; steps beyond nk read a clamped
-            // address and contribute zero
+            // address and are replaced by zero WHERE THEY ARE USED (a select next to the load sits in the block of the uniform branch
+            // around it and made that block wait for its own loads: no prefetch at all)
             auto load_a = [&](double (&av)[U], int s0) {
 #pragma unroll
-                for (int u = 0; u < U; u++) {
-                    const int s = s0 + u;
-                    const double x = P[acol[min(4 * s + kq, na - 1)] * n + aj];
-                    av[u] = s < nk ? x : 0.0;
-                }
+                for (int u = 0; u < U; u++)                                    // (unsigned byte offset: scalar base + 32-bit lane offset)
+                    av[u] = *reinterpret_cast<const double *>(reinterpret_cast<const char *>(P) +
+                                                              ((unsigned)acol[min(4 * (s0 + u) + kq, na - 1)] * (unsigned)n + aj) * 8u);
             };
             double a0[U], a1[U];
             load_a(a0, 0);
             for (int s0 = 0; s0 < nk; s0 += U) {
-                load_a(a1, min(s0 + U, nk));                                   // (past the end: zeros, never used)
-                double hb[U];                                                  // (all of the chunk's LDS operands before its first MFMA)
+                if (s0 + U < nk) load_a(a1, s0 + U);                           // (uniform)
 #pragma unroll
-                for (int u = 0; u < U; u++) hb[u] = hs_at(hb_base + 4 * min(s0 + u, nk - 1) * nrp, 16 * ct);
+                for (int u = 0; u < U; u++) {
+                    const double *col = Hs + (size_t)(4 * min(s0 + u, nk - 1) + kq) * nrp + cl + 16 * CT0;
+                    const double av = s0 + u < nk ? a0[u] : 0.0;
 #pragma unroll
-                for (int u = 0; u < U; u++) accG = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[u], hb[u], accG, 0, 0, 0);
+                    for (int c = 0; c < NCT; c++) accG[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, col[16 * c], accG[c], 0, 0, 0);
+                }
 #pragma unroll
                 for (int u = 0; u < U; u++) a0[u] = a1[u];
             }
-            finish_item(J, ct, accG);
+            finish_group(ct0c, nctc, J, accG);
+        };
+        for (int it = wave; it < n_items; it += stride) {
+            if constexpr (NCG == 1) chunk_item(std::integral_constant<int, 0>{}, std::integral_constant<int, TI>{}, it);
+            else if (it < nJ)       chunk_item(std::integral_constant<int, 0>{}, std::integral_constant<int, CGS>{}, it);
+            else                    chunk_item(std::integral_constant<int, CGS>{}, std::integral_constant<int, TI - CGS>{}, it - nJ);
         }
     }
     __syncthreads();
