@@ -31,6 +31,7 @@ def build_hip(force: bool = False, verbose: bool = False) -> str:
     os.makedirs(LIBDIR, exist_ok=True)
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     extra = ["-DHV_EKF_PHASE_STAMPS"] if os.environ.get("HV_EKF_PHASE_STAMPS") == "1" else []
+    extra += ["-D" + d for d in os.environ.get("HV_EXTRA_DEFINES", "").split() if d]        # developer experiments
     cmd = [hipcc] + HIPCC_FLAGS + extra + ["-o", LIB] + sources()
     if verbose:
         print(" ".join(cmd))

@@ -105,11 +105,18 @@ __device__ __forceinline__ void factor_diag_block(double *T, double *W, double *
 #pragma unroll
     for (int k = 0; k < NW; k++) {
         const double d = lane_bcast(tr[k], k);
+        // one rsqrt instead of sqrt + divide: v_rsq_f64 and one third-order correction (the device library's sequence without its
+        // special-case select: a non-positive pivot gives inf / NaN either way, which the callers report as a failed gate). The
+        // empty asm ties the late updates to the v_rsq result: in source order the compiler kept two of them -- with the wait for
+        // their LDS operands -- IN FRONT of the v_rsq, i.e. inside the pivot-to-pivot chain (r03 ISA reading).
+        double y0 = __builtin_amdgcn_rsq(d);
+        asm volatile("" : "+v"(y0), "+v"(lprev));
         if (k >= 1) {                                          // step k-1's updates of columns k+1..: fill the rsqrt latency
 #pragma unroll
             for (int c = k + 1; c < NW; c++) tr[c] -= lprev * mprev[c];
         }
-        const double inv = rsqrt(d);                          // one rsqrt instead of sqrt + divide
+        const double e0 = __builtin_fma(-d * y0, y0, 1.0);
+        const double inv = __builtin_fma(y0 * e0, __builtin_fma(e0, 0.375, 0.5), y0);
         const double lk = tr[k] * inv;                        // lane k: d * rsqrt(d) = sqrt(d)
         tr[k] = lk;
         if (k + 1 < NW) {
