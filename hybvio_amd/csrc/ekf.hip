@@ -1618,6 +1618,8 @@ struct Ekf {
     // visit, set by the loop) plus one set for stand-alone visits (zeroed per call): a memset node per visit was 20 more graph nodes
     static constexpr int VISIT_SLOTS = 64;
     int visit_slot = -1;
+    int *visit_order = nullptr;                           // [VISIT_SLOTS][batch] launch_visit_order of the running frame loop, valid while visit_order_ok
+    bool visit_order_ok = false;
 };
 
 // compact-H description handed to ekf_launch_update (null acol: dense H of l columns); half / nr_full / dm: block update of a long
@@ -1837,7 +1839,7 @@ void hv_ekf_destroy(hv_ekf *h)
     void *ptrs[] = { e->m, e->P, e->P1, e->m1, e->Q, e->dydx, e->ws, e->sH, e->sv, e->sr, e->schi2, e->simu,
                      e->sstatus, e->sdrop, e->sactive, e->vuH, e->vuv, e->vupf, e->vuactive, e->vustage,
                      e->spH, e->spv, e->sppf, e->spactive, e->spcursor, e->spepoch, e->spcursor2, e->sppub, e->vurows, e->sprows,
-                     e->vuacol, e->spacol, e->err_dev, e->sideH[0], e->sideH[1], e->sidev[0], e->sidev[1], e->side_active[0], e->side_active[1], e->side_acol, e->side_dm, e->queue_dev, e->visit_counts, e->visit_lists };
+                     e->vuacol, e->spacol, e->err_dev, e->sideH[0], e->sideH[1], e->sidev[0], e->sidev[1], e->side_active[0], e->side_active[1], e->side_acol, e->side_dm, e->queue_dev, e->visit_counts, e->visit_lists, e->visit_order };
     for (void *p : ptrs) if (p) (void)hipFree(p);
     for (int k = 0; k < 2; ++k) {
         if (e->side_stream[k]) { (void)hipStreamSynchronize(e->side_stream[k]); (void)hipStreamDestroy(e->side_stream[k]); }
@@ -1872,7 +1874,7 @@ int hv_ekf_create(hv_ctx *ctx, const hv_ekf_params *par, int batch, hv_ekf **out
     alloc(e->schi2, sizeof(double) * batch); alloc(e->simu, sizeof(double) * 7 * HV_EKF_MAX_PREDICT_SAMPLES * batch);
     alloc(e->sstatus, sizeof(int) * batch); alloc(e->sdrop, sizeof(int) * batch); alloc(e->sactive, batch);
     alloc(e->err_dev, sizeof(int)); alloc(e->queue_dev, 2 * sizeof(int));
-    alloc(e->visit_counts, 4 * sizeof(int) * (Ekf::VISIT_SLOTS + 1)); alloc(e->visit_lists, 3 * sizeof(int) * (size_t)batch);
+    alloc(e->visit_counts, 4 * sizeof(int) * (Ekf::VISIT_SLOTS + 1)); alloc(e->visit_order, sizeof(int) * (size_t)Ekf::VISIT_SLOTS * batch); alloc(e->visit_lists, 3 * sizeof(int) * (size_t)batch);
     if (ok && hipMemset(e->err_dev, 0, sizeof(int)) != hipSuccess) ok = false;
     if (ok && hipMemset(e->queue_dev, 0, 2 * sizeof(int)) != hipSuccess) ok = false;
     if (!ok) { hv_ekf_destroy(h); return HV_ERR_NOMEM; }
@@ -2107,6 +2109,7 @@ static int visual_track_dev_impl(hv_ekf *h, const hv_vu_params *p, int np, const
         s_.fused = 1; s_.H = nullptr; s_.Hc = e->vuH; s_.acol = e->vuacol; s_.na_max = 7 * np + 1; s_.P = e->P;
         s_.rd_gate = r_gate * r_gate * ns; s_.noise_scale = ns; s_.chi2 = chi2_dev;
         s_.inl_count = cnt_inl; s_.inl_list = list_inl; s_.long_count = cnt_long; s_.long_list = list_long;
+        if (!own_counts && e->visit_order_ok) s_.order = e->visit_order + (size_t)e->visit_slot * e->batch;     // (frame loop: sorted once per frame)
         rc = hv::launch_vu_prepare(c, s_);
         const hv::CompactH ch{e->vuacol, s_.na_max, ncam, 0, 0, nullptr, cnt_inl, list_inl};
         const ShortUpd short_upd = [&](hv::UpdateLaunch *defer) -> int {
@@ -2290,6 +2293,16 @@ static int visual_frame_dev_impl(hv_ekf *h, const hv_vu_params *p, int n_tracks,
         return HV_OK;
     }
     HV_HIP(c, hipMemsetAsync(e->visit_counts, 0, 4 * sizeof(int) * Ekf::VISIT_SLOTS, c->stream));
+    // ragged visits with two length classes: the short class's fused launches take their records longest track first (one sort per frame)
+    e->visit_order_ok = false;
+    if (np_rec_dev && c->knob.ekf_visit_order != 0 && n_tracks <= Ekf::VISIT_SLOTS) {
+        const int ncam_ = p->useStereo ? 2 : 1, np_short_ = 22 / ncam_;
+        if (np > np_short_) {
+            const int rc = hv::launch_visit_order(c, n_tracks, B, np_rec_dev, 2, np_short_, e->visit_order);
+            if (rc != HV_OK) return rc;
+            e->visit_order_ok = true;
+        }
+    }
     for (int k = 0; k < n_tracks; ++k) {
         e->visit_slot = k;
         const int rc = visual_track_dev_impl(h, p, np, idx + (size_t)k * B * np, feat + (size_t)k * B * nt * 2, vel + (size_t)k * B * nt * 2,
@@ -2298,8 +2311,9 @@ static int visual_frame_dev_impl(hv_ekf *h, const hv_vu_params *p, int n_tracks,
                                              pf_dev ? pf_dev + (size_t)k * B * 3 : nullptr, success_counter_dev, max_successful,
                                              np_rec_dev ? np_rec_dev + (size_t)k * B : nullptr);
         e->visit_slot = -1;
-        if (rc != HV_OK) return rc;
+        if (rc != HV_OK) { e->visit_order_ok = false; return rc; }
     }
+    e->visit_order_ok = false;
     return HV_OK;
 }
 

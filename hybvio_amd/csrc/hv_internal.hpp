@@ -69,6 +69,7 @@ struct Knobs {
     int ekf_persistent = 0;       // HV_EKF_PERSISTENT: 1 = the masked one-workgroup-per-CU launches run as num_cus workgroups pulling records from a device queue instead of using the compaction lists: the long class's prepare and gate launches only (experiment; the update kernel lost its register allocation inside such a loop, r03)
     int ekf_side_stream = 0;      // HV_EKF_SIDE_STREAM: 1 = the long-track chain of a ragged visit on a second stream (measured slower: LDS-slot contention)
     int ekf_dual_update = 1;      // HV_EKF_DUAL_UPDATE: 1 = ragged visits issue the short class's update and the long class's first block update as one grid (ekf_update_dual_kernel); 0 = one after the other
+    int ekf_visit_order = 1;      // HV_EKF_VISIT_ORDER: 1 = ragged frame loops hand the fused kernel its records longest track first (one sort launch per frame); 0 = in filter order
     int rot_ransac_threads = 0;   // HV_ROT_RANSAC_THREADS: 0 auto (1024 threads up to 64 sets), 256 / 1024 force
 };
 int knob_set(Knobs &k, const char *name, int value);   // HV_ERR_INVALID for an unknown name
@@ -155,6 +156,7 @@ struct VuPrepareArgs {
     int *inl_count, *inl_list;         // appended by the fused gate: records whose gate said INLIER (-> update launch)
     int *long_count, *long_list;       // appended by the short class's launch: records of the long class (-> its prepare / gate launches)
     const int *rec_count, *rec_list;   // this launch's own records (long-class prepare): workgroup i handles rec_list[i], i < *rec_count
+    const int *order;                  // fused two-per-CU launches: workgroup i serves filter order[i] (a permutation of the batch, longest tracks first: launch_visit_order), or null
     int persistent;                    // one workgroup per CU pulls records from a device queue (launches that skip most records: the long class of a ragged visit)
     int *queue;                        // persistent launches: {next record, finished workgroups}, zero between launches (the last workgroup resets it)
     int q_off;                         // byte offset of the queue slot inside the dynamic LDS (behind everything the body uses)
@@ -182,6 +184,8 @@ struct VuPrepareArgs {
     double *chi2;                      // optional [records]
 };
 int launch_vu_prepare(Ctx *c, const VuPrepareArgs &a);
+// order[v][0 .. batch): the filters of visit v sorted by descending pose count among those with np_lo <= np_rec <= np_hi (the others last)
+int launch_visit_order(Ctx *c, int visits, int batch, const int *np_rec_dev, int np_lo, int np_hi, int *order_dev);
 bool vu_fused_supported(const Ctx *c, int n_state, int np, int stereo, int batch);   // shapes the fused gate serves (else: dense path)
 // capi.hip
 int build_levels_of_slot(Ctx *c, int slot);

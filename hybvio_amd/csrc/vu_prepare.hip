@@ -968,7 +968,26 @@ __global__ __launch_bounds__(VT_THROUGHPUT, 4) void vu_prepare_kernel_2percu(VuP
 __global__ __launch_bounds__(VT_LATENCY, 3) void vu_gate_kernel(VuPrepareArgs a) { vu_prepare_body<VT_LATENCY, MAXP_ALL, 1>(a, blockIdx.x); }
 __global__ __launch_bounds__(VT_THROUGHPUT, 4) void vu_gate_kernel_2percu(VuPrepareArgs a)
 {
-    vu_prepare_body<VT_THROUGHPUT, MAXP_SMALL, 1>(a, blockIdx.x);
+    // a.order (ragged frame loops): the records arrive longest track first. A workgroup's time grows ~2x from 4 to 11 poses and the
+    // launch is ~1.6 waves of workgroups on the chip's 512 slots: in filter order a long track that starts late sets the launch time
+    const int b = a.order ? __builtin_amdgcn_readfirstlane(a.order[blockIdx.x]) : (int)blockIdx.x;
+    vu_prepare_body<VT_THROUGHPUT, MAXP_SMALL, 1>(a, b);
+}
+
+// launch_visit_order: counting sort of one visit's filters per workgroup (keys 0 .. 63: the pose count inside the class, else 0)
+__global__ __launch_bounds__(1024) void visit_order_kernel(const int *np_rec, int batch, int np_lo, int np_hi, int *order)
+{
+    __shared__ int cnt[64], start[64];
+    const int t = threadIdx.x;
+    np_rec += (size_t)blockIdx.x * batch; order += (size_t)blockIdx.x * batch;
+    if (t < 64) cnt[t] = 0;
+    __syncthreads();
+    auto key = [&](int i) -> int { const int np = np_rec[i]; return (np >= np_lo && np <= np_hi) ? min(np, 63) : 0; };
+    for (int i = t; i < batch; i += 1024) atomicAdd(&cnt[key(i)], 1);
+    __syncthreads();
+    if (t == 0) { int s = 0; for (int k = 63; k >= 0; --k) { start[k] = s; s += cnt[k]; } }
+    __syncthreads();
+    for (int i = t; i < batch; i += 1024) order[atomicAdd(&start[key(i)], 1)] = i;
 }
 // ... and with the compact Jacobian only (the gate runs as its own launch)
 __global__ __launch_bounds__(VT_LATENCY, 3) void vu_compact_kernel(VuPrepareArgs a)
@@ -986,6 +1005,14 @@ __global__ __launch_bounds__(VT_THROUGHPUT, 4) void vu_compact_kernel_2percu(VuP
 }
 
 }  // namespace
+
+int launch_visit_order(Ctx *c, int visits, int batch, const int *np_rec_dev, int np_lo, int np_hi, int *order_dev)
+{
+    if (visits < 1 || batch < 1 || !np_rec_dev || !order_dev) return HV_ERR_INVALID;
+    hipLaunchKernelGGL(visit_order_kernel, dim3((unsigned)visits), dim3(1024), 0, c->stream, np_rec_dev, batch, np_lo, np_hi, order_dev);
+    HV_HIP(c, hipGetLastError());
+    return HV_OK;
+}
 
 // The fused gate serves tracks of up to 48 rows (the 16 TI <= 48 MFMA tile template; 12 stereo / 24 mono poses) whose staged
 // matrices fit the LDS regions the Gauss-Newton arrays leave free; everything else keeps the dense path.

@@ -28,6 +28,7 @@ VARIANTS = {
     "split": {"ekf_spec_split": 1},
     "spec2_vu384": {"vu_threads": 384},
     "updates_one_by_one": {"ekf_dual_update": 0},                    # ragged two-class visits without ekf_update_dual_kernel
+    "filter_order": {"ekf_visit_order": 0},                          # ... and without the longest-track-first permutation of the fused launches
 }
 
 
@@ -441,7 +442,7 @@ def test_whole_frame_loop_in_one_call(oracle, B, speculative, variant):
     # tracks of up to 21 poses: stereo batches split into a short class (fused two-per-CU kernels, <= 11 poses) and a long
     # class (dense kernels) per visit; mono tracks of 21 poses still fit the fused kernels (42 rows)
     (48, False, True, "default", 21), (48, False, True, "vu384", 21), (10, False, True, "default", 21), (48, False, False, "default", 21),
-    (48, False, True, "dense", 21), (48, False, True, "updates_one_by_one", 21)])
+    (48, False, True, "dense", 21), (48, False, True, "updates_one_by_one", 21), (48, False, True, "filter_order", 21)])
 def test_whole_frame_loop_with_ragged_track_lengths(oracle, B, speculative, stereo, variant, np_max):
     """hv_ekf_visual_frame_ragged_dev: the sequences of a batch do not share track lengths -- every (visit, filter) record has its own
     pose count (2 .. n_poses_max, 0 = this filter has no candidate at this visit), padded to the longest. Result = the reference's
