@@ -1619,6 +1619,7 @@ struct Ekf {
     static constexpr int VISIT_SLOTS = 64;
     int visit_slot = -1;
     int *visit_order = nullptr;                           // [VISIT_SLOTS][batch] launch_visit_order of the running frame loop, valid while visit_order_ok
+    int *visit_long = nullptr, *visit_long_count = nullptr;   // ... its long-class lists [VISIT_SLOTS][batch] and their lengths [VISIT_SLOTS]
     bool visit_order_ok = false;
 };
 
@@ -1839,7 +1840,7 @@ void hv_ekf_destroy(hv_ekf *h)
     void *ptrs[] = { e->m, e->P, e->P1, e->m1, e->Q, e->dydx, e->ws, e->sH, e->sv, e->sr, e->schi2, e->simu,
                      e->sstatus, e->sdrop, e->sactive, e->vuH, e->vuv, e->vupf, e->vuactive, e->vustage,
                      e->spH, e->spv, e->sppf, e->spactive, e->spcursor, e->spepoch, e->spcursor2, e->sppub, e->vurows, e->sprows,
-                     e->vuacol, e->spacol, e->err_dev, e->sideH[0], e->sideH[1], e->sidev[0], e->sidev[1], e->side_active[0], e->side_active[1], e->side_acol, e->side_dm, e->queue_dev, e->visit_counts, e->visit_lists, e->visit_order };
+                     e->vuacol, e->spacol, e->err_dev, e->sideH[0], e->sideH[1], e->sidev[0], e->sidev[1], e->side_active[0], e->side_active[1], e->side_acol, e->side_dm, e->queue_dev, e->visit_counts, e->visit_lists, e->visit_order, e->visit_long, e->visit_long_count };
     for (void *p : ptrs) if (p) (void)hipFree(p);
     for (int k = 0; k < 2; ++k) {
         if (e->side_stream[k]) { (void)hipStreamSynchronize(e->side_stream[k]); (void)hipStreamDestroy(e->side_stream[k]); }
@@ -1874,7 +1875,8 @@ int hv_ekf_create(hv_ctx *ctx, const hv_ekf_params *par, int batch, hv_ekf **out
     alloc(e->schi2, sizeof(double) * batch); alloc(e->simu, sizeof(double) * 7 * HV_EKF_MAX_PREDICT_SAMPLES * batch);
     alloc(e->sstatus, sizeof(int) * batch); alloc(e->sdrop, sizeof(int) * batch); alloc(e->sactive, batch);
     alloc(e->err_dev, sizeof(int)); alloc(e->queue_dev, 2 * sizeof(int));
-    alloc(e->visit_counts, 4 * sizeof(int) * (Ekf::VISIT_SLOTS + 1)); alloc(e->visit_order, sizeof(int) * (size_t)Ekf::VISIT_SLOTS * batch); alloc(e->visit_lists, 3 * sizeof(int) * (size_t)batch);
+    alloc(e->visit_counts, 4 * sizeof(int) * (Ekf::VISIT_SLOTS + 1)); alloc(e->visit_order, sizeof(int) * (size_t)Ekf::VISIT_SLOTS * batch);
+    alloc(e->visit_long, sizeof(int) * (size_t)Ekf::VISIT_SLOTS * batch); alloc(e->visit_long_count, sizeof(int) * Ekf::VISIT_SLOTS); alloc(e->visit_lists, 3 * sizeof(int) * (size_t)batch);
     if (ok && hipMemset(e->err_dev, 0, sizeof(int)) != hipSuccess) ok = false;
     if (ok && hipMemset(e->queue_dev, 0, 2 * sizeof(int)) != hipSuccess) ok = false;
     if (!ok) { hv_ekf_destroy(h); return HV_ERR_NOMEM; }
@@ -2028,19 +2030,37 @@ static int visual_track_dev_impl(hv_ekf *h, const hv_vu_params *p, int np, const
     int *counts = e->visit_counts + 4 * (own_counts ? Ekf::VISIT_SLOTS : e->visit_slot);
     int *cnt_inl = counts, *cnt_long = counts + 1, *cnt_inl_long = counts + 2;
     int *list_inl = e->visit_lists, *list_long = e->visit_lists + e->batch, *list_inl_long = e->visit_lists + 2 * (size_t)e->batch;
+    // frame loop with sorted visits (launch_visit_order): the long class's records are known -- longest first -- before the fused launch runs
+    const bool presorted = !own_counts && e->visit_order_ok;
+    if (presorted) { cnt_long = e->visit_long_count + e->visit_slot; list_long = e->visit_long + (size_t)e->visit_slot * e->batch; }
     if (own_counts) HV_HIP(c, hipMemsetAsync(counts, 0, 4 * sizeof(int), c->stream));
     // short_upd (ragged two-class visits): issues the short class's update, or only prepares it (non-null argument) so that it shares
     // a grid with the first block update of the long class
     using ShortUpd = std::function<int(hv::UpdateLaunch *)>;
+    // gate_stream (knob ekf_side_stream = 2): the long class's prepare + gate launches run on it, beside the fused launch of the short
+    // class on the context's stream; the updates follow on the context's stream behind a join
+    bool gate_joined = false;
     auto long_chain = [&](hv::VuPrepareArgs l_, double *Hc, double *vv, int *acol, unsigned char *act, double *dm, bool listed,
-                          const ShortUpd *short_upd = nullptr) -> int {
+                          const ShortUpd *short_upd = nullptr, hipStream_t gate_stream = nullptr, int stage = 0) -> int {
+        // stage 0: everything; 1: the prepare + gate launches only (the caller joins gate_stream itself); 2: the update launches only
         l_.fused = 2; l_.H = nullptr; l_.Hc = Hc; l_.v = vv; l_.acol = acol; l_.na_max = 7 * np + 1; l_.active = act; l_.chi2 = chi2_dev;
         if (listed) { l_.rec_count = cnt_long; l_.rec_list = list_long; }
-        int rc2 = hv::launch_vu_prepare(c, l_);
-        if (rc2 != HV_OK) return rc2;
-        rc2 = hv::ekf_launch_sparse_gate(e, np, ncam, Hc, vv, acol, nr_rec, act, r_gate * r_gate * ns, chi2_dev, gate_status_dev,
-                                         listed ? cnt_long : nullptr, listed ? list_long : nullptr, cnt_inl_long, list_inl_long);
-        if (rc2 != HV_OK) return rc2;
+        int rc2 = HV_OK;
+        if (stage != 2) {
+            hipStream_t ctx_stream = c->stream;
+            if (gate_stream) c->stream = gate_stream;
+            rc2 = hv::launch_vu_prepare(c, l_);
+            if (rc2 == HV_OK)
+                rc2 = hv::ekf_launch_sparse_gate(e, np, ncam, Hc, vv, acol, nr_rec, act, r_gate * r_gate * ns, chi2_dev, gate_status_dev,
+                                                 listed ? cnt_long : nullptr, listed ? list_long : nullptr, cnt_inl_long, list_inl_long);
+            c->stream = ctx_stream;
+            if (gate_stream && stage == 0) {                   // join (also on an error path: a captured graph must not keep a dangling fork)
+                (void)hipEventRecord(e->ev_join[0], gate_stream);
+                (void)hipStreamWaitEvent(ctx_stream, e->ev_join[0], 0);
+                gate_joined = true;
+            }
+        }
+        if (rc2 != HV_OK || stage == 1) return rc2;
         const int half_rows = 2 * ((rows + 3) / 4);            // the longer of the two blocks of the longest record
         hv::CompactH h1{acol, l_.na_max, ncam, 1, rows, dm, cnt_inl_long, list_inl_long}, h2{acol, l_.na_max, ncam, 2, rows, dm, cnt_inl_long, list_inl_long};
         auto block1 = [&](hv::UpdateLaunch *defer) -> int {
@@ -2099,8 +2119,12 @@ static int visual_track_dev_impl(hv_ekf *h, const hv_vu_params *p, int np, const
         // chain's fused kernel fills all of it (2 x 80 KB), so their workgroups queue for each other's CUs and a visit took 700 - 900 us
         // against ~550 us back to back. Default: one stream, short chain first.
         const bool fork = c->knob.ekf_side_stream == 1;
+        // knob ekf_side_stream = 2 (needs the sorted visits of a frame loop): only the long class's prepare + gate launches leave the
+        // stream -- they read what the fused launch reads and write their own buffers
+        const bool fork_gate = (c->knob.ekf_side_stream == 2 || c->knob.ekf_side_stream == 3) && presorted;
+        const bool gate_first = c->knob.ekf_side_stream == 3;  // (3: the long class's launches are enqueued BEFORE the fused launch)
         hipStream_t main_stream = c->stream;
-        if (fork) {
+        if (fork || fork_gate) {
             HV_HIP(c, hipEventRecord(e->ev_fork[0], main_stream));
             HV_HIP(c, hipStreamWaitEvent(e->side_stream[0], e->ev_fork[0], 0));
         }
@@ -2108,9 +2132,19 @@ static int visual_track_dev_impl(hv_ekf *h, const hv_vu_params *p, int np, const
         s_.np_lo = 2; s_.np_hi = np_short; s_.class_inactive = 1;
         s_.fused = 1; s_.H = nullptr; s_.Hc = e->vuH; s_.acol = e->vuacol; s_.na_max = 7 * np + 1; s_.P = e->P;
         s_.rd_gate = r_gate * r_gate * ns; s_.noise_scale = ns; s_.chi2 = chi2_dev;
-        s_.inl_count = cnt_inl; s_.inl_list = list_inl; s_.long_count = cnt_long; s_.long_list = list_long;
+        s_.inl_count = cnt_inl; s_.inl_list = list_inl;
+        if (!presorted) { s_.long_count = cnt_long; s_.long_list = list_long; }      // (else nothing to collect)
         if (!own_counts && e->visit_order_ok) s_.order = e->visit_order + (size_t)e->visit_slot * e->batch;     // (frame loop: sorted once per frame)
-        rc = hv::launch_vu_prepare(c, s_);
+        hv::VuPrepareArgs l_ = a;
+        l_.np_lo = np_short + 1; l_.np_hi = np; l_.class_inactive = 1; l_.persistent = c->knob.ekf_persistent == 1 ? 1 : 0; l_.queue = e->queue_dev;
+        rc = HV_OK;
+        if (fork_gate && gate_first) rc = long_chain(l_, e->sideH[0], e->sidev[0], e->side_acol, e->side_active[0], e->side_dm, true, nullptr, e->side_stream[0], 1);
+        if (rc == HV_OK) rc = hv::launch_vu_prepare(c, s_);
+        if (fork_gate && gate_first) {
+            (void)hipEventRecord(e->ev_join[0], e->side_stream[0]);
+            (void)hipStreamWaitEvent(main_stream, e->ev_join[0], 0);
+            gate_joined = true;
+        }
         const hv::CompactH ch{e->vuacol, s_.na_max, ncam, 0, 0, nullptr, cnt_inl, list_inl};
         const ShortUpd short_upd = [&](hv::UpdateLaunch *defer) -> int {
             return hv::ekf_launch_update(e, 2 * np_short * ncam, e->n, e->vuH, e->vuv, nullptr, r_update * r_update * ns, 1, 0, 1, nullptr, nullptr,
@@ -2123,12 +2157,11 @@ static int visual_track_dev_impl(hv_ekf *h, const hv_vu_params *p, int np, const
         if (rc == HV_OK && !pair) rc = short_upd(nullptr);
         if (rc == HV_OK) {
             if (fork) c->stream = e->side_stream[0];
-            hv::VuPrepareArgs l_ = a;
-            l_.np_lo = np_short + 1; l_.np_hi = np; l_.class_inactive = 1; l_.persistent = c->knob.ekf_persistent == 1 ? 1 : 0; l_.queue = e->queue_dev;
-            rc = long_chain(l_, e->sideH[0], e->sidev[0], e->side_acol, e->side_active[0], e->side_dm, true, pair ? &short_upd : nullptr);
+            rc = long_chain(l_, e->sideH[0], e->sidev[0], e->side_acol, e->side_active[0], e->side_dm, true, pair ? &short_upd : nullptr,
+                            fork_gate && !gate_first ? e->side_stream[0] : nullptr, fork_gate && gate_first ? 2 : 0);
             c->stream = main_stream;
         }
-        if (fork) {
+        if (fork || (fork_gate && !gate_joined)) {
             (void)hipEventRecord(e->ev_join[0], e->side_stream[0]);  // join (also on an error path: a captured graph must not keep a dangling fork)
             (void)hipStreamWaitEvent(main_stream, e->ev_join[0], 0);
         }
@@ -2298,7 +2331,7 @@ static int visual_frame_dev_impl(hv_ekf *h, const hv_vu_params *p, int n_tracks,
     if (np_rec_dev && c->knob.ekf_visit_order != 0 && n_tracks <= Ekf::VISIT_SLOTS) {
         const int ncam_ = p->useStereo ? 2 : 1, np_short_ = 22 / ncam_;
         if (np > np_short_) {
-            const int rc = hv::launch_visit_order(c, n_tracks, B, np_rec_dev, 2, np_short_, e->visit_order);
+            const int rc = hv::launch_visit_order(c, n_tracks, B, np_rec_dev, 2, np_short_, np, e->visit_order, e->visit_long, e->visit_long_count);
             if (rc != HV_OK) return rc;
             e->visit_order_ok = true;
         }

@@ -67,7 +67,7 @@ struct Knobs {
     int ekf_fused_gate = -1;      // HV_EKF_FUSED_GATE: column-sparse chi2 gate: -1 auto = 1 inside the prepare kernel, 2 own launch (ekf_sparse_gate_kernel), 0 off (dense kernels)
     int ekf_spec_mode = -1;       // HV_EKF_SPEC_MODE: speculative pass form: -1 auto, 2 = gate launch + apply launch, 3 = one launch with hand-shake
     int ekf_persistent = 0;       // HV_EKF_PERSISTENT: 1 = the masked one-workgroup-per-CU launches run as num_cus workgroups pulling records from a device queue instead of using the compaction lists: the long class's prepare and gate launches only (experiment; the update kernel lost its register allocation inside such a loop, r03)
-    int ekf_side_stream = 0;      // HV_EKF_SIDE_STREAM: 1 = the long-track chain of a ragged visit on a second stream (measured slower: LDS-slot contention)
+    int ekf_side_stream = 3;      // HV_EKF_SIDE_STREAM, ragged visits with two length classes: 0 = one stream; 1 = the whole long-track chain on a second stream (measured slower: its update launches and the short class's fight for whole CUs); 2 / 3 = only the long class's prepare + gate launches on the second stream, enqueued behind (2) / in front of (3, default: +6 % on the realistic C3 step) the short class's fused launch -- frame loops only (they need the per-frame sort of launch_visit_order)
     int ekf_dual_update = 1;      // HV_EKF_DUAL_UPDATE: 1 = ragged visits issue the short class's update and the long class's first block update as one grid (ekf_update_dual_kernel); 0 = one after the other
     int ekf_visit_order = 1;      // HV_EKF_VISIT_ORDER: 1 = ragged frame loops hand the fused kernel its records longest track first (one sort launch per frame); 0 = in filter order
     int rot_ransac_threads = 0;   // HV_ROT_RANSAC_THREADS: 0 auto (1024 threads up to 64 sets), 256 / 1024 force
@@ -184,8 +184,10 @@ struct VuPrepareArgs {
     double *chi2;                      // optional [records]
 };
 int launch_vu_prepare(Ctx *c, const VuPrepareArgs &a);
-// order[v][0 .. batch): the filters of visit v sorted by descending pose count among those with np_lo <= np_rec <= np_hi (the others last)
-int launch_visit_order(Ctx *c, int visits, int batch, const int *np_rec_dev, int np_lo, int np_hi, int *order_dev);
+// order[v][0 .. batch): the filters of visit v sorted by descending pose count among those with np_lo <= np_rec <= np_hi (the others last);
+// long_list[v][0 .. long_count[v]) (optional): those with np_hi < np_rec <= np_max, longest first
+int launch_visit_order(Ctx *c, int visits, int batch, const int *np_rec_dev, int np_lo, int np_hi, int np_max, int *order_dev,
+                       int *long_list_dev, int *long_count_dev);
 bool vu_fused_supported(const Ctx *c, int n_state, int np, int stereo, int batch);   // shapes the fused gate serves (else: dense path)
 // capi.hip
 int build_levels_of_slot(Ctx *c, int slot);

@@ -975,19 +975,32 @@ __global__ __launch_bounds__(VT_THROUGHPUT, 4) void vu_gate_kernel_2percu(VuPrep
 }
 
 // launch_visit_order: counting sort of one visit's filters per workgroup (keys 0 .. 63: the pose count inside the class, else 0)
-__global__ __launch_bounds__(1024) void visit_order_kernel(const int *np_rec, int batch, int np_lo, int np_hi, int *order)
+// Two sorts per visit: `order` = the whole batch, the class np_lo .. np_hi first and longest first; `long_list` / `long_count` = the
+// records above np_hi (<= np_max), longest first -- the long class's launches then need not wait for the fused launch to collect them.
+__global__ __launch_bounds__(1024) void visit_order_kernel(const int *np_rec, int batch, int np_lo, int np_hi, int np_max, int *order,
+                                                           int *long_list, int *long_count)
 {
-    __shared__ int cnt[64], start[64];
+    __shared__ int cnt[2][64], start[2][64];
     const int t = threadIdx.x;
     np_rec += (size_t)blockIdx.x * batch; order += (size_t)blockIdx.x * batch;
-    if (t < 64) cnt[t] = 0;
+    if (long_list) long_list += (size_t)blockIdx.x * batch;
+    if (t < 128) cnt[t >> 6][t & 63] = 0;
     __syncthreads();
     auto key = [&](int i) -> int { const int np = np_rec[i]; return (np >= np_lo && np <= np_hi) ? min(np, 63) : 0; };
-    for (int i = t; i < batch; i += 1024) atomicAdd(&cnt[key(i)], 1);
+    auto key_long = [&](int i) -> int { const int np = np_rec[i]; return (np > np_hi && np <= np_max) ? min(np, 63) : 0; };
+    for (int i = t; i < batch; i += 1024) { atomicAdd(&cnt[0][key(i)], 1); atomicAdd(&cnt[1][key_long(i)], 1); }
     __syncthreads();
-    if (t == 0) { int s = 0; for (int k = 63; k >= 0; --k) { start[k] = s; s += cnt[k]; } }
+    if (t < 2) {
+        int s = 0;
+        for (int k = 63; k >= 0; --k) { start[t][k] = s; s += cnt[t][k]; }
+        if (t == 1 && long_count) long_count[blockIdx.x] = batch - cnt[1][0];
+    }
     __syncthreads();
-    for (int i = t; i < batch; i += 1024) order[atomicAdd(&start[key(i)], 1)] = i;
+    for (int i = t; i < batch; i += 1024) {
+        order[atomicAdd(&start[0][key(i)], 1)] = i;
+        const int kl = key_long(i);
+        if (long_list && kl > 0) long_list[atomicAdd(&start[1][kl], 1)] = i;
+    }
 }
 // ... and with the compact Jacobian only (the gate runs as its own launch)
 __global__ __launch_bounds__(VT_LATENCY, 3) void vu_compact_kernel(VuPrepareArgs a)
@@ -1006,10 +1019,12 @@ __global__ __launch_bounds__(VT_THROUGHPUT, 4) void vu_compact_kernel_2percu(VuP
 
 }  // namespace
 
-int launch_visit_order(Ctx *c, int visits, int batch, const int *np_rec_dev, int np_lo, int np_hi, int *order_dev)
+int launch_visit_order(Ctx *c, int visits, int batch, const int *np_rec_dev, int np_lo, int np_hi, int np_max, int *order_dev,
+                       int *long_list_dev, int *long_count_dev)
 {
     if (visits < 1 || batch < 1 || !np_rec_dev || !order_dev) return HV_ERR_INVALID;
-    hipLaunchKernelGGL(visit_order_kernel, dim3((unsigned)visits), dim3(1024), 0, c->stream, np_rec_dev, batch, np_lo, np_hi, order_dev);
+    hipLaunchKernelGGL(visit_order_kernel, dim3((unsigned)visits), dim3(1024), 0, c->stream, np_rec_dev, batch, np_lo, np_hi, np_max, order_dev,
+                       long_list_dev, long_count_dev);
     HV_HIP(c, hipGetLastError());
     return HV_OK;
 }

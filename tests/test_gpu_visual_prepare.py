@@ -29,6 +29,9 @@ VARIANTS = {
     "spec2_vu384": {"vu_threads": 384},
     "updates_one_by_one": {"ekf_dual_update": 0},                    # ragged two-class visits without ekf_update_dual_kernel
     "filter_order": {"ekf_visit_order": 0},                          # ... and without the longest-track-first permutation of the fused launches
+    "one_stream": {"ekf_side_stream": 0},                            # ... with the long class's prepare + gate launches behind the fused launch
+    "gates_behind": {"ekf_side_stream": 2},                          # ... on the second stream, enqueued behind the fused launch
+    "long_chain_on_side_stream": {"ekf_side_stream": 1},
 }
 
 
@@ -442,7 +445,8 @@ def test_whole_frame_loop_in_one_call(oracle, B, speculative, variant):
     # tracks of up to 21 poses: stereo batches split into a short class (fused two-per-CU kernels, <= 11 poses) and a long
     # class (dense kernels) per visit; mono tracks of 21 poses still fit the fused kernels (42 rows)
     (48, False, True, "default", 21), (48, False, True, "vu384", 21), (10, False, True, "default", 21), (48, False, False, "default", 21),
-    (48, False, True, "dense", 21), (48, False, True, "updates_one_by_one", 21), (48, False, True, "filter_order", 21)])
+    (48, False, True, "dense", 21), (48, False, True, "updates_one_by_one", 21), (48, False, True, "filter_order", 21), (48, False, True, "one_stream", 21),
+    (48, False, True, "gates_behind", 21), (48, False, True, "long_chain_on_side_stream", 21), (300, False, True, "default", 21), (300, False, True, "one_stream", 21)])
 def test_whole_frame_loop_with_ragged_track_lengths(oracle, B, speculative, stereo, variant, np_max):
     """hv_ekf_visual_frame_ragged_dev: the sequences of a batch do not share track lengths -- every (visit, filter) record has its own
     pose count (2 .. n_poses_max, 0 = this filter has no candidate at this visit), padded to the longest. Result = the reference's
@@ -489,7 +493,7 @@ def test_whole_frame_loop_with_ragged_track_lengths(oracle, B, speculative, ster
                                   r_gate, r_update, st.data_ptr(), gs.data_ptr(), counter.data_ptr(), quota)
         torch.cuda.synchronize()
         st, gs, counts = st.cpu().numpy(), gs.cpu().numpy(), counter.cpu().numpy()
-        applied, rejected, lengths_applied = 0, 0, set()
+        applied, rejected, lengths_applied, ties = 0, 0, set(), 0
         for b, o in enumerate(filters):
             done = 0
             for k in range(K):
@@ -498,7 +502,19 @@ def test_whole_frame_loop_with_ragged_track_lengths(oracle, B, speculative, ster
                     continue
                 i_, f_, v_, yy = per[(k, b)]
                 ost, ops, opf, oH, of = oracle.visual_track_prepare(par, o.m.copy(), i_, T1, T2 if stereo else None, f_, v_)
-                assert st[k, b].tolist() == [ost, ops], (b, k, lens[k, b])
+                if st[k, b].tolist() != [ost, ops]:
+                    # A degenerate track (a quarter of them are built to fail) can send the Gauss-Newton iteration of the triangulation
+                    # through a singular normal matrix: the path then follows the last bit of every sum and WHICH failure is reported
+                    # (behind a camera / rcond / no convergence) is not a property of the input. Tolerated only as such: both statuses are
+                    # failures, and the oracle itself reaches the device's status when its input mean is moved in the 13th digit.
+                    assert ost != 0 and st[k, b, 0] != 0, (b, k, lens[k, b], st[k, b].tolist(), [ost, ops])
+                    rng_tie, seen = np.random.default_rng(1000 * k + b), set()
+                    for _ in range(48):
+                        m2 = o.m * (1.0 + 1e-13 * rng_tie.normal(size=o.m.size))
+                        o2 = oracle.visual_track_prepare(par, m2, i_, T1, T2 if stereo else None, f_, v_)
+                        seen.add((o2[0], o2[1]))
+                    assert tuple(st[k, b].tolist()) in seen, (b, k, lens[k, b], st[k, b].tolist(), [ost, ops], seen)
+                    ties += 1
                 if (ost, ops) != (0, 0):
                     assert gs[k, b] == 1
                     continue
@@ -513,6 +529,7 @@ def test_whole_frame_loop_with_ragged_track_lengths(oracle, B, speculative, ster
             mg, Pg = g.get_state(b)
             assert _rel(mg, o.m) < 1e-8 and _rel(Pg, o.P) < 1e-7, (b, _rel(mg, o.m), _rel(Pg, o.P))
         assert applied > B // 2 and rejected > 0 and len(lengths_applied) >= 3, (applied, rejected, lengths_applied)
+        assert ties <= 1 + B * K // 1000, ties
         if np_max > 12:
             assert max(lengths_applied) > 12 and min(lengths_applied) < 12, lengths_applied
         g.close()
