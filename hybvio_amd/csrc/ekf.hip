@@ -2123,8 +2123,11 @@ static int visual_track_dev_impl(hv_ekf *h, const hv_vu_params *p, int np, const
         // stream -- they read what the fused launch reads and write their own buffers
         const bool fork_gate = (c->knob.ekf_side_stream == 2 || c->knob.ekf_side_stream == 3) && presorted;
         const bool gate_first = c->knob.ekf_side_stream == 3;  // (3: the long class's launches are enqueued BEFORE the fused launch)
+        // 4: the WHOLE long chain (prepare, gate, both block updates) on the second stream, enqueued first; the short class's fused launch
+        // and its update follow on the context's stream (no shared update grid)
+        const bool chain_first = c->knob.ekf_side_stream == 4 && presorted;
         hipStream_t main_stream = c->stream;
-        if (fork || fork_gate) {
+        if (fork || fork_gate || chain_first) {
             HV_HIP(c, hipEventRecord(e->ev_fork[0], main_stream));
             HV_HIP(c, hipStreamWaitEvent(e->side_stream[0], e->ev_fork[0], 0));
         }
@@ -2139,7 +2142,16 @@ static int visual_track_dev_impl(hv_ekf *h, const hv_vu_params *p, int np, const
         l_.np_lo = np_short + 1; l_.np_hi = np; l_.class_inactive = 1; l_.persistent = c->knob.ekf_persistent == 1 ? 1 : 0; l_.queue = e->queue_dev;
         rc = HV_OK;
         if (fork_gate && gate_first) rc = long_chain(l_, e->sideH[0], e->sidev[0], e->side_acol, e->side_active[0], e->side_dm, true, nullptr, e->side_stream[0], 1);
+        if (chain_first) {
+            c->stream = e->side_stream[0];
+            rc = long_chain(l_, e->sideH[0], e->sidev[0], e->side_acol, e->side_active[0], e->side_dm, true);
+            c->stream = main_stream;
+        }
         if (rc == HV_OK) rc = hv::launch_vu_prepare(c, s_);
+        if (fork && !presorted) {                              // (the long class's list is collected by the fused launch: the second stream waits for it)
+            HV_HIP(c, hipEventRecord(e->ev_fork[0], main_stream));
+            HV_HIP(c, hipStreamWaitEvent(e->side_stream[0], e->ev_fork[0], 0));
+        }
         if (fork_gate && gate_first) {
             (void)hipEventRecord(e->ev_join[0], e->side_stream[0]);
             (void)hipStreamWaitEvent(main_stream, e->ev_join[0], 0);
@@ -2153,15 +2165,15 @@ static int visual_track_dev_impl(hv_ekf *h, const hv_vu_params *p, int np, const
         };
         // knob ekf_dual_update (default 1): the short class's update waits for the long class's prepare + gate launches and then shares
         // a grid with the first block update of the long class (the two serve different filters)
-        const bool pair = c->knob.ekf_dual_update != 0 && !fork;
+        const bool pair = c->knob.ekf_dual_update != 0 && !fork && !chain_first;
         if (rc == HV_OK && !pair) rc = short_upd(nullptr);
-        if (rc == HV_OK) {
+        if (rc == HV_OK && !chain_first) {
             if (fork) c->stream = e->side_stream[0];
             rc = long_chain(l_, e->sideH[0], e->sidev[0], e->side_acol, e->side_active[0], e->side_dm, true, pair ? &short_upd : nullptr,
                             fork_gate && !gate_first ? e->side_stream[0] : nullptr, fork_gate && gate_first ? 2 : 0);
             c->stream = main_stream;
         }
-        if (fork || (fork_gate && !gate_joined)) {
+        if (fork || chain_first || (fork_gate && !gate_joined)) {
             (void)hipEventRecord(e->ev_join[0], e->side_stream[0]);  // join (also on an error path: a captured graph must not keep a dangling fork)
             (void)hipStreamWaitEvent(main_stream, e->ev_join[0], 0);
         }
@@ -2328,7 +2340,9 @@ static int visual_frame_dev_impl(hv_ekf *h, const hv_vu_params *p, int n_tracks,
     HV_HIP(c, hipMemsetAsync(e->visit_counts, 0, 4 * sizeof(int) * Ekf::VISIT_SLOTS, c->stream));
     // ragged visits with two length classes: the short class's fused launches take their records longest track first (one sort per frame)
     e->visit_order_ok = false;
-    if (np_rec_dev && c->knob.ekf_visit_order != 0 && n_tracks <= Ekf::VISIT_SLOTS) {
+    // (many filters only: below one workgroup per CU nothing queues, and the sort, the fork and the join are pure launch overhead --
+    //  a single sequence went from 1.14 to 1.51 ms per frame with them)
+    if (np_rec_dev && c->knob.ekf_visit_order != 0 && n_tracks <= Ekf::VISIT_SLOTS && (B > c->num_cus || c->knob.ekf_visit_order == 2)) {
         const int ncam_ = p->useStereo ? 2 : 1, np_short_ = 22 / ncam_;
         if (np > np_short_) {
             const int rc = hv::launch_visit_order(c, n_tracks, B, np_rec_dev, 2, np_short_, np, e->visit_order, e->visit_long, e->visit_long_count);

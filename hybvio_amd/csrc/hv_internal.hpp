@@ -67,9 +67,9 @@ struct Knobs {
     int ekf_fused_gate = -1;      // HV_EKF_FUSED_GATE: column-sparse chi2 gate: -1 auto = 1 inside the prepare kernel, 2 own launch (ekf_sparse_gate_kernel), 0 off (dense kernels)
     int ekf_spec_mode = -1;       // HV_EKF_SPEC_MODE: speculative pass form: -1 auto, 2 = gate launch + apply launch, 3 = one launch with hand-shake
     int ekf_persistent = 0;       // HV_EKF_PERSISTENT: 1 = the masked one-workgroup-per-CU launches run as num_cus workgroups pulling records from a device queue instead of using the compaction lists: the long class's prepare and gate launches only (experiment; the update kernel lost its register allocation inside such a loop, r03)
-    int ekf_side_stream = 3;      // HV_EKF_SIDE_STREAM, ragged visits with two length classes: 0 = one stream; 1 = the whole long-track chain on a second stream (measured slower: its update launches and the short class's fight for whole CUs); 2 / 3 = only the long class's prepare + gate launches on the second stream, enqueued behind (2) / in front of (3, default: +6 % on the realistic C3 step) the short class's fused launch -- frame loops only (they need the per-frame sort of launch_visit_order)
+    int ekf_side_stream = 3;      // HV_EKF_SIDE_STREAM, ragged visits with two length classes: 0 = one stream; 1 = the whole long-track chain on a second stream (measured slower: its update launches and the short class's fight for whole CUs); 2 / 3 = only the long class's prepare + gate launches on the second stream, enqueued behind (2) / in front of (3, default: +6 % on the realistic C3 step) the short class's fused launch; 4 = the whole long chain on the second stream, enqueued first (no better than 3) -- 2 .. 4: frame loops only (they need the per-frame sort of launch_visit_order)
     int ekf_dual_update = 1;      // HV_EKF_DUAL_UPDATE: 1 = ragged visits issue the short class's update and the long class's first block update as one grid (ekf_update_dual_kernel); 0 = one after the other
-    int ekf_visit_order = 1;      // HV_EKF_VISIT_ORDER: 1 = ragged frame loops hand the fused kernel its records longest track first (one sort launch per frame); 0 = in filter order
+    int ekf_visit_order = 1;      // HV_EKF_VISIT_ORDER: 1 = ragged frame loops over more filters than the GPU has CUs hand the fused kernel its records longest track first (one sort launch per frame; the presorted long-class lists also enable ekf_side_stream 2 .. 4); 2 = at every batch size (tests); 0 = in filter order
     int rot_ransac_threads = 0;   // HV_ROT_RANSAC_THREADS: 0 auto (1024 threads up to 64 sets), 256 / 1024 force
 };
 int knob_set(Knobs &k, const char *name, int value);   // HV_ERR_INVALID for an unknown name

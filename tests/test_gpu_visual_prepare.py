@@ -30,8 +30,12 @@ VARIANTS = {
     "updates_one_by_one": {"ekf_dual_update": 0},                    # ragged two-class visits without ekf_update_dual_kernel
     "filter_order": {"ekf_visit_order": 0},                          # ... and without the longest-track-first permutation of the fused launches
     "one_stream": {"ekf_side_stream": 0},                            # ... with the long class's prepare + gate launches behind the fused launch
-    "gates_behind": {"ekf_side_stream": 2},                          # ... on the second stream, enqueued behind the fused launch
+    # (ekf_visit_order 2: the per-frame sort -- and with it the second-stream forms -- also below one filter per CU, where the default skips them)
+    "sorted_small_batch": {"ekf_visit_order": 2},                    # the many-filter default (gates on the second stream, enqueued first) on a small batch
+    "gates_behind": {"ekf_side_stream": 2, "ekf_visit_order": 2},    # ... on the second stream, enqueued behind the fused launch
     "long_chain_on_side_stream": {"ekf_side_stream": 1},
+    "long_chain_on_side_stream_sorted": {"ekf_side_stream": 1, "ekf_visit_order": 2},
+    "long_chain_first": {"ekf_side_stream": 4, "ekf_visit_order": 2},
 }
 
 
@@ -446,7 +450,8 @@ def test_whole_frame_loop_in_one_call(oracle, B, speculative, variant):
     # class (dense kernels) per visit; mono tracks of 21 poses still fit the fused kernels (42 rows)
     (48, False, True, "default", 21), (48, False, True, "vu384", 21), (10, False, True, "default", 21), (48, False, False, "default", 21),
     (48, False, True, "dense", 21), (48, False, True, "updates_one_by_one", 21), (48, False, True, "filter_order", 21), (48, False, True, "one_stream", 21),
-    (48, False, True, "gates_behind", 21), (48, False, True, "long_chain_on_side_stream", 21), (300, False, True, "default", 21), (300, False, True, "one_stream", 21)])
+    (48, False, True, "gates_behind", 21), (48, False, True, "long_chain_on_side_stream", 21), (48, False, True, "long_chain_first", 21), (48, False, True, "sorted_small_batch", 21),
+    (48, False, True, "long_chain_on_side_stream_sorted", 21), (300, False, True, "default", 21), (300, False, True, "one_stream", 21)])
 def test_whole_frame_loop_with_ragged_track_lengths(oracle, B, speculative, stereo, variant, np_max):
     """hv_ekf_visual_frame_ragged_dev: the sequences of a batch do not share track lengths -- every (visit, filter) record has its own
     pose count (2 .. n_poses_max, 0 = this filter has no candidate at this visit), padded to the longest. Result = the reference's
