@@ -1315,7 +1315,11 @@ def main():
                                    "computeOpticalFlow": k3.get("klt", {}).get("ms_per_step"),
                                    "KF predict": k3.get("ekf_predict", {}).get("ms_per_step"),
                                    "trackerVisualUpdate": sum(k3[k]["ms_per_step"] for k in ("vu_prepare", "ekf_update_gate", "ekf_gate") if k in k3),
-                                   "augmentation": k3.get("ekf_augment", {}).get("ms_per_step")},
+                                   "augmentation": k3.get("ekf_augment", {}).get("ms_per_step"),
+                                   "note": "per-class hipEvent sums over the eager profiling steps; in the realistic leg the long class's prepare + "
+                                           "gate launches run on a second stream BESIDE the short class's fused launch (DESIGN 3.3 o), so the "
+                                           "trackerVisualUpdate classes overlap and their sum exceeds the wall-clock share of the visit loop "
+                                           "(20 visits x ~245 us on the rocprofv3 timeline, profiles/r03/visit_timeline_two_streams.txt)"},
             "stage_pyramid_klt": stage,
             "visual_updates_applied_per_frame": applied, "inlier_gates_per_visit_last_step": gate_hist,
             "tracked_fraction": tracked3,

@@ -1179,7 +1179,7 @@ struct SparseGateArgs {
 };
 
 constexpr int SGATE_THREADS = 256;         // small build: four waves, one per SIMD, three workgroups per CU
-constexpr int SGATE_BIG_THREADS = 512;     // big build (one workgroup per CU by its LDS): two waves per SIMD for the 60 (J, ct) items of an 84-row track
+constexpr int SGATE_BIG_THREADS = 768;     // big build (one workgroup per CU by its LDS): three waves per SIMD for the 20 (J, group) items of an 84-row track (512 threads: 70.9 us per 256 records of 21 poses, 768: 66.7, 1024: 87 spilled VGPRs)
 
 // BIG = false: up to 48 rows (three 43 KB workgroups per CU at 10 stereo poses); BIG = true: 49 .. 96 rows (tracks of 13 .. 21 stereo
 // poses: 13 .. 21 poses x 4 rows), one workgroup per CU with the whole register file, Hc staged with nrp = 16 TI rows per column where that
