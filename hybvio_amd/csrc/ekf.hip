@@ -457,8 +457,11 @@ constexpr int UPD_THREADS = 512;   // 8 waves = 2 per SIMD: 256 VGPRs each (whol
 // TI (MODE 2 only): 16-row tiles of H, nr <= 16 TI: a compile-time count keeps the MFMA loops free of
 // branches (a uniform branch per tile made hipcc wait for each LDS operand right before its MFMA).
 template <int MODE, int TI>
-__device__ __forceinline__ void ekf_update_body(const UpdateArgs &a, const int b /* filter: blockIdx.x, or the loop variable of a persistent launch */)
+__device__ __forceinline__ void ekf_update_body(const UpdateArgs &a, const int b_in /* filter: blockIdx.x, or an entry of a compaction list */)
 {
+    // (a list entry is a per-lane load: on the scalar unit the filter's base addresses are uniform and its gathers become scalar base +
+    //  32-bit lane offset -- one VGPR and one VALU instruction per request instead of a 64-bit multiply-add pair)
+    const int b = __builtin_amdgcn_readfirstlane(b_in);
     constexpr bool USE_LDS = MODE >= 1;
     extern __shared__ __attribute__((aligned(16))) double smem[];
     int e = b;                                             // record of this workgroup's H, v, active, chi2, status
@@ -496,17 +499,24 @@ __device__ __forceinline__ void ekf_update_body(const UpdateArgs &a, const int b
             return;
         }
     }
-    if (a.active && !a.active[e]) return;
-    if (a.require_inlier && a.require_inlier[b] != 0) return;
+    // The record's flags and its shape are requested TOGETHER: as a sequence of tests each of them was
+    // a dependent HBM / L2 round trip of its own -- 15 k cycles went by before the first request for H was issued (r03 phase stamps)
     const int t = threadIdx.x, lane = t & 63;
+    const unsigned char act_v = a.active ? a.active[e] : (unsigned char)1;
+    const int req_v = a.require_inlier ? a.require_inlier[b] : 0;
+    const int nr_rec_v0 = a.nr_rec ? a.nr_rec[e] : a.nr_full;
+    int shape_pin = nr_rec_v0;
+    asm volatile("" : "+v"(shape_pin));                     // (keeps the three requests in front of the first test)
+    const int nr_rec_v = shape_pin;
+    if (!act_v) return;
+    if (req_v != 0) return;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);     // wave-uniform: tile indices and their addresses stay on the scalar unit
     constexpr int nwaves = UPD_THREADS / 64;
     const int n = a.n, l = a.l;
     int nr = a.nr, R = a.Rs, Rfull = a.R;                   // R is the column STRIDE of T below; Rfull rows are used
     int roff = 0, ld = a.nr;                               // first row of this launch's block inside the record; leading dimension of H
     if (a.nr_rec || a.half) {                              // ragged batch / block update: this record's own shape (uniform per workgroup)
-        int nr_full = a.nr_rec ? a.nr_rec[e] : a.nr_full;
-        nr_full = __builtin_amdgcn_readfirstlane(nr_full);
+        int nr_full = __builtin_amdgcn_readfirstlane(nr_rec_v);
         if (nr_full < 1 || nr_full > a.v_stride) return;    // no track (the prepare launch also cleared `active`)
         nr = nr_full; ld = nr_full;
         if (a.half) {
@@ -570,7 +580,8 @@ __device__ __forceinline__ void ekf_update_body(const UpdateArgs &a, const int b
             if (kb < kend && (kb < lb || !gate_only)) {
                 const int jc = min(J * 16 + cl, n - 1);
 #pragma unroll
-                for (int sx = 0; sx < 4; sx++) pv[bi][sx] = P[(size_t)min(kb * 16 + 4 * sx + kq, n - 1) * n + jc];
+                for (int sx = 0; sx < 4; sx++)
+                    pv[bi][sx] = *reinterpret_cast<const double *>(reinterpret_cast<const char *>(P) + (unsigned)(min(kb * 16 + 4 * sx + kq, n - 1) * n + jc) * 8u);
             }
         };
         // request order = arrival order: H first (every MFMA needs it), then the P tiles in the order
@@ -578,29 +589,56 @@ __device__ __forceinline__ void ekf_update_body(const UpdateArgs &a, const int b
         // wave that queues its whole column block up front sits in the issue queue until most of it has
         // arrived, and the HBM stream no longer overlaps the matrix work.
         constexpr int HREG = (48 * 160 + UPD_THREADS - 1) / UPD_THREADS, DEPTH = 4;
-        double hreg[HREG];
         if (a.acol) {
-            // compact H (fused prepare + gate): the P tiles are requested first, they do not depend on H; then the map state column ->
-            // compact column (-1: the column of H is zero) is built in LDS (the col scratch is free until the Cholesky) and H is
-            // gathered through it. kbmask: the 16-row K blocks of H P that hold a non-zero column of H at all.
-#pragma unroll
-            for (int bi = 0; bi < DEPTH; bi++) if (have0) fetch_blk(pres0, bi, wave, bi, tiles_j);
-            int *inv = reinterpret_cast<int *>(col);
+            // compact H (fused prepare + gate): Hs is zeroed and the record's na x nr values are gathered BY COMPACT COLUMN and scattered
+            // to their state columns -- the addresses of the gather do not depend on the column list, so Hc and the list travel
+            // together: one HBM / L2 round trip, 8 values per thread at 11 stereo poses. (r03's first form built the inverse map
+            // state column -> compact column in LDS first -- a dependent round trip and two barriers -- and walked all 48 x 160 cells
+            // with 15 registers per thread.) kbmask: the 16-row K blocks of H P that hold a non-zero column of H at all.
+            int *mask = reinterpret_cast<int *>(col);       // (the col scratch is free until the Cholesky)
             const int na = 7 * (ld / (2 * a.ncam)) + 1;     // (ld = rows of the whole record)
             const int *acol = a.acol + (size_t)e * a.na_max;
-            const int my_col = t < na ? acol[t] : -1;
-            for (int i = t; i < n + 1; i += UPD_THREADS) inv[i] = i < n ? -1 : 0;
-            __syncthreads();
-            if (t < na) { inv[my_col] = t; atomicOr(&inv[n], 1 << (my_col >> 4)); }
-            __syncthreads();
-            kbmask = (unsigned)inv[n];
+            const int total = na * nr;
+            const unsigned inv_nr = (unsigned)((0x100000000ull + (unsigned)nr - 1) / (unsigned)nr);      // i / nr = umulhi(i, ceil(2^32 / nr)), i < 2^20
+            constexpr int HC = 8;
+            double hv[HC]; int hc[HC];
+            auto request = [&](int base) {
 #pragma unroll
-            for (int u = 0; u < HREG; u++) {
-                const int i = t + u * UPD_THREADS, k = i / nrp, r = i - k * nrp;
-                const int ck = (i < nrp * 16 * lb && k < l && r < nr) ? inv[k] : -1;
-                hreg[u] = ck >= 0 ? H[(size_t)ck * ld + roff + r] : 0.0;
-            }
+                for (int u = 0; u < HC; u++) {
+                    const int i = base + t + u * UPD_THREADS, uc = (int)__umulhi((unsigned)i, inv_nr), r = i - uc * nr;
+                    const bool live = i < total;
+                    hc[u] = live ? acol[uc] : -1;
+                    hv[u] = live ? *reinterpret_cast<const double *>(reinterpret_cast<const char *>(H) + (unsigned)(uc * ld + roff + r) * 8u) : 0.0;
+                }
+            };
+            auto scatter = [&](int base) {
+#pragma unroll
+                for (int u = 0; u < HC; u++) {
+                    const int i = base + t + u * UPD_THREADS, uc = (int)__umulhi((unsigned)i, inv_nr), r = i - uc * nr;
+                    if (hc[u] >= 0 && hc[u] < l) {
+                        Hs[hc[u] * nrp + r] = hv[u];
+                        if (r == 0) atomicOr(mask, 1 << (hc[u] >> 4));
+                    }
+                }
+            };
+            request(0);
+            // The P tiles are requested BEHIND the gather, the block that is used last FIRST: the kernel sits at 255 VGPRs and the
+            // register allocator spills one value of that block right behind its load, i.e. waits for it -- and loads return in order.
+            // (r03's first form requested the tiles in front of the staging, block 0 first: the spill waited for all 16 of them,
+            // 14 k cycles before the first request for H.)
+#pragma unroll
+            for (int bi = DEPTH - 1; bi >= 0; bi--) if (have0) fetch_blk(pres0, bi, wave, bi, tiles_j);     // (LAST block first: see below)
+            PHASE_STAMP(8);
+            for (int i = t; i < nrp * 16 * lb; i += UPD_THREADS) Hs[i] = 0.0;
+            for (int i = t; i < R * nr; i += UPD_THREADS) T[i] = 0.0;
+            if (t == 0) mask[0] = 0;
+            __syncthreads();
+            scatter(0);
+            for (int base = HC * UPD_THREADS; base < total; base += HC * UPD_THREADS) { request(base); scatter(base); }     // (long mono tracks)
+            __syncthreads();
+            kbmask = (unsigned)mask[0];
         } else {
+            double hreg[HREG];
 #pragma unroll
             for (int u = 0; u < HREG; u++) {
                 const int i = t + u * UPD_THREADS, k = i / nrp, r = i - k * nrp;
@@ -608,13 +646,13 @@ __device__ __forceinline__ void ekf_update_body(const UpdateArgs &a, const int b
             }
 #pragma unroll
             for (int bi = 0; bi < DEPTH; bi++) if (have0) fetch_blk(pres0, bi, wave, bi, tiles_j);
-        }
-        PHASE_STAMP(8);
-        for (int i = t; i < R * nr; i += UPD_THREADS) T[i] = 0.0;
+            PHASE_STAMP(8);
+            for (int i = t; i < R * nr; i += UPD_THREADS) T[i] = 0.0;
 #pragma unroll
-        for (int u = 0; u < HREG; u++) {
-            const int i = t + u * UPD_THREADS;
-            if (i < nrp * 16 * lb) Hs[i] = hreg[u];
+            for (int u = 0; u < HREG; u++) {
+                const int i = t + u * UPD_THREADS;
+                if (i < nrp * 16 * lb) Hs[i] = hreg[u];
+            }
         }
         __syncthreads();
         PHASE_STAMP(9);
@@ -622,18 +660,20 @@ __device__ __forceinline__ void ekf_update_body(const UpdateArgs &a, const int b
         // H operands of a K block: 4 k-steps x TI row tiles, double-buffered across blocks (the reads of
         // block b+1 are issued before the MFMAs of block b: a wavefront that only prefetches one or two
         // ds_reads ahead issues an MFMA every ~100 cycles instead of every 64)
-        auto load_h = [&](int kb, double (&av)[4][TI]) {
+        // (in HALF blocks of two k-steps: 2 x 2 x TI operand registers instead of 2 x 4 x TI -- the kernel sits at 255 VGPRs and the
+        //  allocator took its last pair from the P prefetch, spilling a value right behind its load: a full stop in front of the staging)
+        auto load_h = [&](int kb, int hf, double (&av)[2][TI]) {
 #pragma unroll
-            for (int sx = 0; sx < 4; sx++)
+            for (int sx = 0; sx < 2; sx++)
 #pragma unroll
-                for (int mt = 0; mt < TI; mt++) av[sx][mt] = hbase[(size_t)(kb * 16 + 4 * sx) * nrp + 16 * mt];
+                for (int mt = 0; mt < TI; mt++) av[sx][mt] = hbase[(size_t)(kb * 16 + 4 * (2 * hf + sx)) * nrp + 16 * mt];
         };
-        auto mfma_blk = [&](auto &pv, int bi, const double (&av)[4][TI], double4v (&acc)[TI]) {
+        auto mfma_half = [&](auto &pv, int bi, int hf, const double (&av)[2][TI], double4v (&acc)[TI]) {
 #pragma unroll
-            for (int sx = 0; sx < 4; sx++)
+            for (int sx = 0; sx < 2; sx++)
 #pragma unroll
                 for (int mt = 0; mt < TI; mt++)
-                    acc[mt] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[sx][mt], pv[bi][sx], acc[mt], 0, 0, 0);
+                    acc[mt] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[sx][mt], pv[bi][2 * hf + sx], acc[mt], 0, 0, 0);
         };
         auto flush = [&](int J, double4v (&acc)[TI]) {
 #pragma unroll
@@ -650,15 +690,18 @@ __device__ __forceinline__ void ekf_update_body(const UpdateArgs &a, const int b
 #pragma unroll
             for (int mt = 0; mt < TI; mt++) acc[mt] = double4v{0.0, 0.0, 0.0, 0.0};
             const int nv = have0 ? min(tiles_j, lb) : 0;                   // K blocks with matrix work: 0 .. nv-1
-            double av[2][4][TI];
-            if (nv > 0) load_h(0, av[0]);
+            double av[2][2][TI];
+            if (nv > 0) load_h(0, 0, av[0]);
 #pragma unroll
             for (int bi = 0; bi < NBK; bi++) {
                 if (bi + DEPTH < NBK) { if (have0) fetch_blk(pres0, bi + DEPTH, wave, bi + DEPTH, tiles_j); }
                 else if (bi + DEPTH - NBK < NBH) { if (have1) fetch_blk(pres1, bi + DEPTH - NBK, J1, kb0_1 + bi + DEPTH - NBK, kb1_1); }
                 if (bi < nv) {
-                    if (bi + 1 < nv) load_h(bi + 1, av[(bi + 1) & 1]);
-                    if ((kbmask >> bi) & 1) mfma_blk(pres0, bi, av[bi & 1], acc);
+                    const bool work = (kbmask >> bi) & 1;
+                    load_h(bi, 1, av[1]);
+                    if (work) mfma_half(pres0, bi, 0, av[0], acc);
+                    if (bi + 1 < nv) load_h(bi + 1, 0, av[0]);
+                    if (work) mfma_half(pres0, bi, 1, av[1], acc);
                 }
             }
             if (have0) flush(wave, acc);
@@ -669,14 +712,17 @@ __device__ __forceinline__ void ekf_update_body(const UpdateArgs &a, const int b
 #pragma unroll
             for (int mt = 0; mt < TI; mt++) acc[mt] = double4v{0.0, 0.0, 0.0, 0.0};
             const int nv = have1 ? max(min(kb1_1, lb) - kb0_1, 0) : 0;     // blocks kb0_1 .. kb0_1 + nv - 1
-            double av[2][4][TI];
-            if (nv > 0) load_h(kb0_1, av[0]);
+            double av[2][2][TI];
+            if (nv > 0) load_h(kb0_1, 0, av[0]);
 #pragma unroll
             for (int bi = 0; bi < NBH; bi++) {
                 if (bi + DEPTH < NBH) { if (have1) fetch_blk(pres1, bi + DEPTH, J1, kb0_1 + bi + DEPTH, kb1_1); }
                 if (bi < nv) {
-                    if (bi + 1 < nv) load_h(kb0_1 + bi + 1, av[(bi + 1) & 1]);
-                    if ((kbmask >> (kb0_1 + bi)) & 1) mfma_blk(pres1, bi, av[bi & 1], acc);
+                    const bool work = (kbmask >> (kb0_1 + bi)) & 1;
+                    load_h(kb0_1 + bi, 1, av[1]);
+                    if (work) mfma_half(pres1, bi, 0, av[0], acc);
+                    if (bi + 1 < nv) load_h(kb0_1 + bi + 1, 0, av[0]);
+                    if (work) mfma_half(pres1, bi, 1, av[1], acc);
                 }
             }
             if (have1) flush(J1, acc);
@@ -978,14 +1024,17 @@ __global__ __launch_bounds__(UPD_THREADS) void ekf_update_kernel(UpdateArgs a)
 // with a second launch anyway (its second block update): `part` 0 = all of a1 + the entries of a0's list that fit beside them on the
 // chip (cap = num_cus - *a1.rec_count), `part` 1 = all of a1 + the REST of a0's list -- the visit loop issues (a0 = short class, a1 =
 // long block 1, part 0) and then (a0 = short class, a1 = long block 2, part 1); `part` < 0: all of both lists.
+struct UpdatePair { UpdateArgs a[2]; };
 template <int MODE, int TI>
-__global__ __launch_bounds__(UPD_THREADS) void ekf_update_dual_kernel(UpdateArgs a0, UpdateArgs a1, int part, int num_cus)
+__global__ __launch_bounds__(UPD_THREADS) void ekf_update_dual_kernel(UpdatePair p, int part, int num_cus)
 {
-    const int n0 = *a0.rec_count, n1 = *a1.rec_count, i = (int)blockIdx.x;
+    const int n0 = *p.a[0].rec_count, n1 = *p.a[1].rec_count, i = (int)blockIdx.x;
     const int cap = min(n0, max(num_cus - n1, 0));
-    const int lo = part == 1 ? cap : 0, hi = part == 0 ? cap : n0;          // a0's share of this launch
+    const int lo = part == 1 ? cap : 0, hi = part == 0 ? cap : n0;          // a[0]'s share of this launch
     const bool second = i < n1;
-    const UpdateArgs &a = second ? a1 : a0;
+    // (ONE block is read, through a run-time index into the kernel-argument segment: with two by-value blocks and a select per field
+    //  both sat in SGPRs -- 250 of them spilled into VGPR lanes, in a kernel that has no VGPR to spare)
+    const UpdateArgs &a = p.a[second ? 1 : 0];
     const int j = second ? i : i - n1 + lo;
     if (!second && j >= hi) return;
     ekf_update_body<MODE, TI>(a, a.rec_list[j]);
@@ -1194,9 +1243,14 @@ __device__ __forceinline__ void sparse_gate_kernel_body(const SparseGateArgs &a,
     const int t = threadIdx.x;
     constexpr int NTH = BIG ? SGATE_BIG_THREADS : SGATE_THREADS;
     PHASE_STAMP(12);
-    if (!a.active[b]) return;                                  // status stays NOT_COMPUTED (preset by the prepare launch)
-    int nr = a.nr_rec ? a.nr_rec[b] : a.nr;
-    nr = __builtin_amdgcn_readfirstlane(nr);
+    // (flag, shape, column list and residual requested together: one round trip instead of three dependent ones)
+    const unsigned char act_v = a.active[b];
+    const int nr_v = a.nr_rec ? a.nr_rec[b] : a.nr;
+    int my_acol_raw = a.acol[(size_t)b * a.na_max + min(t, a.na_max - 1)];
+    double my_v_raw = a.v[(size_t)b * a.nr + min(t, a.nr - 1)];
+    asm volatile("" : "+v"(my_acol_raw), "+v"(my_v_raw));
+    if (!act_v) return;                                        // status stays NOT_COMPUTED (preset by the prepare launch)
+    const int nr = __builtin_amdgcn_readfirstlane(nr_v);
     if (nr < 2 || nr > a.nr) return;
     const int n = a.n, npose = nr / (2 * a.ncam), na = 7 * npose + 1, na4 = (na + 3) & ~3;
     const int ti = BIG ? max((nr + 15) >> 4, 4) : (nr + 15) >> 4;       // (the BIG build starts at the 4-tile instantiation)
@@ -1212,8 +1266,8 @@ __device__ __forceinline__ void sparse_gate_kernel_body(const SparseGateArgs &a,
     // stage Hc k-major with zero padding (rows >= nr, columns >= na), [S; v'] zeroed with the residual row in place
     // (8 elements per thread in flight: a load -> LDS store loop without unrolling waits one HBM / L2 round trip per iteration -- 14 of
     // them at 10 stereo poses, which made this staging half of the kernel)
-    const int my_acol = t < na ? a.acol[(size_t)b * a.na_max + t] : 0;
-    const double my_v = t < nr ? a.v[(size_t)b * a.nr + t] : 0.0;
+    const int my_acol = t < na ? my_acol_raw : 0;
+    const double my_v = t < nr ? my_v_raw : 0.0;
     const int total = na4 * nrp;
     const unsigned inv_nrp = (unsigned)((0x100000000ull + (unsigned)nrp - 1) / (unsigned)nrp);       // i / nrp = umulhi(i, ceil(2^32 / nrp))
     for (int base = 0; base < total; base += 8 * NTH) {
@@ -1727,7 +1781,9 @@ static int ekf_launch_update_dual(Ekf *e, const UpdateLaunch &A, const UpdateLau
         attr_set = true;
     }
     ScopedKernelTime tm(c, HV_K_EKF_UPDATE);
-    hipLaunchKernelGGL((ekf_update_dual_kernel<2, 3>), dim3(e->batch), dim3(UPD_THREADS), shmem, c->stream, A.a, B.a, part, c->num_cus);
+    UpdatePair pair;
+    pair.a[0] = A.a; pair.a[1] = B.a;
+    hipLaunchKernelGGL((ekf_update_dual_kernel<2, 3>), dim3(e->batch), dim3(UPD_THREADS), shmem, c->stream, pair, part, c->num_cus);
     HV_HIP(c, hipGetLastError());
     *done = true;
     return HV_OK;

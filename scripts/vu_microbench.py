@@ -93,7 +93,7 @@ def main():
                 capi.lib().hv_debug_ekf_phase_stamps.argtypes = [C.c_void_p, C.POINTER(C.c_longlong)]
                 capi.lib().hv_debug_ekf_phase_stamps(g._h, st16)
                 q_ = list(st16)
-                print("update kernel phase cycles (workgroup 0): P loads issued + H staged", q_[9] - q_[0], "H P products", q_[1] - q_[9], "S", q_[2] - q_[1],
+                print("update kernel phase cycles (workgroup 0): P loads issued + H staged", q_[9] - q_[0], "(of which up to the H requests", q_[8] - q_[0], ")", "item 0 products", q_[10] - q_[9], "item 1", q_[11] - q_[10], "H P products", q_[1] - q_[9], "S", q_[2] - q_[1],
                       "Cholesky + solves", q_[3] - q_[2], "(first diagonal block", q_[7] - q_[6], ") mean step", q_[4] - q_[3], "P -= Y'Y + store", q_[5] - q_[4],
                       "total", q_[5] - q_[0])
             if os.environ.get("HV_EKF_PHASE_STAMPS") == "1" and name == "all rejected":
