@@ -2163,17 +2163,20 @@ static int visual_track_dev_impl(hv_ekf *h, const hv_vu_params *p, int np, const
         return HV_OK;
     };
     // Ragged batch with long AND short tracks: two length CLASSES per visit. The short tracks -- 4 of 5 at the reference's defaults, see
-    // bench.py sample_track_lengths -- run on the fused two-per-CU kernels, the long ones through the chain above on a side stream
-    // next to them (fork at the start of the visit, join at its end; HIP-graph capturable): the records of a visit belong to different
-    // filters, so the two launch sequences are independent. Every launch skips the other class's records (VuPrepareArgs::np_lo /
-    // np_hi, `active`).
+    // bench.py sample_track_lengths -- run on the fused two-per-CU kernels, the long ones through the chain above; the records of a visit
+    // belong to different filters, so the two launch sequences are independent up to the shared update grids. Every launch skips the
+    // other class's records (VuPrepareArgs::np_lo / np_hi, `active`). Schedule of a visit inside a frame loop over more filters than CUs
+    // (knob ekf_side_stream 3, default; HIP-graph capturable: fork at the start of the visit, join in front of the updates):
+    //     second stream:   compact prepare (long) -> big sparse gate (long)        -- enqueued FIRST: they take their CUs while all are free
+    //     context stream:  fused prepare + gate (short)  | join |  short update + long block 1  ->  rest of short + long block 2
+    // Stand-alone visits and small batches: everything on the context's stream, short class first.
     if (np_rec_dev && np > np_short && long_ok && hv::vu_fused_supported(c, e->n, np_short, a.stereo, e->batch)) {
         rc = ensure_side();
         if (rc != HV_OK) return rc;
         // knob ekf_side_stream = 1: the long chain on a second stream next to the short one. Measured (r03, 1024 filters, rocprofv3
         // kernel trace): the two sequences do NOT overlap usefully -- every kernel of the long chain needs a whole CU's LDS, the short
         // chain's fused kernel fills all of it (2 x 80 KB), so their workgroups queue for each other's CUs and a visit took 700 - 900 us
-        // against ~550 us back to back. Default: one stream, short chain first.
+        // against ~550 us back to back.
         const bool fork = c->knob.ekf_side_stream == 1;
         // knob ekf_side_stream = 2 (needs the sorted visits of a frame loop): only the long class's prepare + gate launches leave the
         // stream -- they read what the fused launch reads and write their own buffers
