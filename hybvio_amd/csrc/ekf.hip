@@ -2401,7 +2401,7 @@ static int visual_frame_dev_impl(hv_ekf *h, const hv_vu_params *p, int n_tracks,
     e->visit_order_ok = false;
     // (many filters only: below one workgroup per CU nothing queues, and the sort, the fork and the join are pure launch overhead --
     //  a single sequence went from 1.14 to 1.51 ms per frame with them)
-    if (np_rec_dev && c->knob.ekf_visit_order != 0 && n_tracks <= Ekf::VISIT_SLOTS && (B > c->num_cus || c->knob.ekf_visit_order == 2)) {
+    if (p && np_rec_dev && c->knob.ekf_visit_order != 0 && n_tracks >= 1 && n_tracks <= Ekf::VISIT_SLOTS && (B > (size_t)c->num_cus || c->knob.ekf_visit_order == 2)) {
         const int ncam_ = p->useStereo ? 2 : 1, np_short_ = 22 / ncam_;
         if (np > np_short_) {
             const int rc = hv::launch_visit_order(c, n_tracks, B, np_rec_dev, 2, np_short_, np, e->visit_order, e->visit_long, e->visit_long_count);
