@@ -442,6 +442,71 @@ def test_whole_frame_loop_in_one_call(oracle, B, speculative, variant):
         g.close()
 
 
+@pytest.mark.parametrize("variant", ["default", "spec3"])
+def test_speculative_frame_loop_under_contention(variant):
+    """the speculative visit loop while another stream keeps most of the chip busy. The default pass (a fused
+    prepare + gate launch, then an apply launch) has no inter-workgroup hand-shake, so contention can only delay it; the r02 one-launch
+    form (knob ekf_spec_mode 3) waits for the gate decisions of workgroups in front of it and must either produce the same result or
+    say so (hv_ekf_frame_error). Reference = the sequential visit loop (knob ekf_no_speculation) on the same inputs."""
+    import torch
+    rng = np.random.default_rng(2024)
+    B, trail_len, npose, K, quota = 12, 20, 6, 9, 3
+    T1, T2, means, _, _ = synth.visual_tracks(rng, B, trail_len, npose, True)
+    tracks, ys = [], []
+    for k in range(K):
+        _, _, _, i_, f_ = synth.visual_tracks(np.random.default_rng(500 + k), B, trail_len, npose, True, given_means=means)
+        tracks.append((i_, f_, np.zeros_like(f_)))
+        y = f_.reshape(B, -1) + 2e-3 * rng.normal(size=(B, f_.shape[1] * 2))
+        if k in (0, 1, 4, 6):
+            y[::2] += 3.0
+        ys.append(y)
+    vp = capi.vu_default_params(imu_to_camera=T1, second_imu_to_camera=T2)
+    r_gate, r_update = 1.5, 0.05
+    P0 = np.eye(20 + 7 * trail_len) * 1e-4
+
+    def run(knobs, busy):
+        with capi.Context(width=64, height=64) as ctx:
+            for k_, v_ in knobs.items():
+                ctx.set_knob(k_, v_)
+            g = capi.EkfBatch(ctx, capi.ekf_default_params(cameraTrailLength=trail_len), B)
+            for b in range(B):
+                g.set_state(b, means[b], P0)
+            dev = lambda a, dt: torch.from_numpy(np.array(a, dt, order="C")).cuda()
+            d = [dev(np.stack([t[0] for t in tracks]), np.int32), dev(np.stack([t[1] for t in tracks]), np.float64),
+                 dev(np.stack([t[2] for t in tracks]), np.float64), dev(np.stack(ys), np.float64)]
+            st = torch.full((K, B, 2), -9, dtype=torch.int32, device="cuda"); gs = torch.full((K, B), -9, dtype=torch.int32, device="cuda")
+            counter = torch.full((B,), 77, dtype=torch.int32, device="cuda")
+            main = torch.cuda.current_stream()
+            ctx.set_stream(main.cuda_stream)
+            if busy:                                          # ~100 ms of large matrix products on a second stream, started first
+                other = torch.cuda.Stream()
+                a_ = torch.randn(8192, 8192, device="cuda"); b_ = torch.randn(8192, 8192, device="cuda")
+                torch.cuda.synchronize()
+                with torch.cuda.stream(other):
+                    for _ in range(12):
+                        a_ = (a_ @ b_) * 1e-4
+            for _ in range(3 if busy else 1):                 # several frames while the other stream is busy
+                for b in range(B):
+                    g.set_state(b, means[b], P0)
+                g.visual_frame_dev(vp, K, npose, d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(), d[3].data_ptr(), r_gate, r_update,
+                                   st.data_ptr(), gs.data_ptr(), counter.data_ptr(), quota)
+            err = g.frame_error()
+            torch.cuda.synchronize()
+            out = (st.cpu().numpy().copy(), gs.cpu().numpy().copy(), counter.cpu().numpy().copy(), [g.get_state(b) for b in range(B)], err)
+            g.close()
+            return out
+
+    ref = run({"ekf_no_speculation": 1}, False)
+    got = run(dict(VARIANTS[variant]), True)
+    if got[4] != 0:                                           # loud failure of the hand-shake form: allowed, a silent difference is not
+        assert variant == "spec3"
+        return
+    assert (got[0] == ref[0]).all() and (got[1] == ref[1]).all() and (got[2] == ref[2]).all()
+    for (mg, Pg), (mr, Pr) in zip(got[3], ref[3]):
+        assert _rel(mg, mr) < 1e-9 and _rel(Pg, Pr) < 1e-8
+    assert ref[2].sum() > 0
+
+
 @pytest.mark.parametrize("B,speculative,stereo,variant,np_max", [
     (10, True, True, "default", 10), (48, False, True, "default", 10), (9, True, False, "default", 10), (10, True, True, "spec3", 10),
     (48, False, True, "vu384", 10), (48, False, True, "dense", 10), (9, True, False, "spec2_vu384", 10), (48, False, False, "vu384", 10),
