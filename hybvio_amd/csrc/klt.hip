@@ -101,8 +101,10 @@ __device__ __forceinline__ uint32_t scaled_pair(uint32_t lo, uint32_t hi)
 // row: the Scharr stencils of pixels x and x+1 (cv::calcSharrDeriv: smooth [3 10 3] across, difference [-1 0 1] along) are
 // separable, so a row contributes its horizontal difference d = I(x+1) - I(x-1) and smoothed value s4 = 4 (3 I(x-1) + 10 I(x)
 // + 3 I(x+1)) as packed 16-bit pairs for the two columns, and a gradient row is a vertical combination of three of those:
-//   4 dx + 2 = 12 (d[r-1] + d[r+1]) + 40 d[r] + 2        4 dy + 2 = s4[r+1] - s4[r-1] + 2
-// -- the pre-scaled form the pyramid stores (pyramid.hip). Every intermediate fits 16 bits (|.| <= 16322): v_pk_* arithmetic.
+//   4 dx = 12 (d[r-1] + d[r+1]) + 40 d[r]        4 dy = s4[r+1] - s4[r-1]
+// -- the pre-scaled form the pyramid stores (pyramid.hip) WITHOUT its + 2: the four bilinear weights sum to 2^14, so the + 2 of every
+// sample is one + 32768 of the weighted sum, and the dot2 chains of the gradients formed here start from 32768 instead (window_row's
+// ginit; r03: the OR per gradient row was 68 VALU instructions per feature). Every intermediate fits 16 bits (|.| <= 16322): v_pk_* arithmetic.
 typedef unsigned short us2v __attribute__((ext_vector_type(2)));
 struct ScharrRow { us2v d, s4; uint32_t g; };
 __device__ __forceinline__ ScharrRow scharr_row(uint32_t q)
@@ -118,11 +120,11 @@ __device__ __forceinline__ ScharrRow scharr_row(uint32_t q)
 }
 __device__ __forceinline__ uint32_t scharr_dx(const ScharrRow &a, const ScharrRow &b, const ScharrRow &c)
 {
-    return __builtin_bit_cast(uint32_t, (a.d + c.d) * us2v{12, 12} + (b.d * us2v{40, 40} + us2v{2, 2}));
+    return __builtin_bit_cast(uint32_t, (a.d + c.d) * us2v{12, 12} + b.d * us2v{40, 40});
 }
 __device__ __forceinline__ uint32_t scharr_dy(const ScharrRow &a, const ScharrRow &c)
 {
-    return __builtin_bit_cast(uint32_t, (c.s4 - a.s4) + us2v{2, 2});
+    return __builtin_bit_cast(uint32_t, c.s4 - a.s4);
 }
 
 // Wavefront sum of a small integer (|sum| < 2^31) entirely in DPP: 4 in-row steps, then
@@ -136,6 +138,22 @@ __device__ __forceinline__ int wave_sum_small(int v)
     v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xA, 0xF, false);  // row_bcast:15 -> rows 1,3
     v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xC, 0xF, false);  // row_bcast:31 -> rows 2,3
     return __builtin_amdgcn_readlane(v, 63);
+}
+
+// Two such sums in one DPP chain (gfx950 v_permlane32_swap): the upper half-wave of `a` changes places with the lower half-wave of `b`,
+// so that lanes 0 .. 31 hold a[l] + a[l + 32] and lanes 32 .. 63 b[l - 32] + b[l]; four in-row steps and one row_bcast:15 leave the
+// totals in lanes 31 and 63. 9 VALU instructions for two sums instead of 14 (integer sums: any order gives the same bits).
+__device__ __forceinline__ void wave_sum_pair_small(int a, int b, int &sum_a, int &sum_b)
+{
+    const auto r = __builtin_amdgcn_permlane32_swap((unsigned)a, (unsigned)b, false, false);
+    int v = (int)r[0] + (int)r[1];
+    v += __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, true);    // quad_perm:[1,0,3,2]
+    v += __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xF, 0xF, true);    // quad_perm:[2,3,0,1]
+    v += __builtin_amdgcn_update_dpp(0, v, 0x141, 0xF, 0xF, true);   // row_half_mirror
+    v += __builtin_amdgcn_update_dpp(0, v, 0x140, 0xF, 0xF, true);   // row_mirror
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xA, 0xF, false);  // row_bcast:15 -> rows 1,3
+    sum_a = __builtin_amdgcn_readlane(v, 31);
+    sum_b = __builtin_amdgcn_readlane(v, 63);
 }
 
 // Exact sum of per-lane int32 partials as the nearest float (== (float)(int64 sum)): the low 16
@@ -317,12 +335,13 @@ __global__ __launch_bounds__(64, WPS) void klt_kernel(KltArgs a)
             // the high half of one dot2 chain started from 0. Rows r0 .. r0 + nk of the pre-scaled packed pairs -> window rows
             // r0 .. r0 + nk - 1 (r0 even).
             int vi_prev = 0, vx_prev = 0, vy_prev = 0;
-            auto window_row = [&](int k, uint32_t g0, uint32_t g1, uint32_t dx0, uint32_t dx1, uint32_t dy0, uint32_t dy1) {
+            // ginit: 0 for gradients that carry the rounding constant (stored planes: 4 d + 2), 32768 for the ones formed here (4 d)
+            auto window_row = [&](int k, int ginit, uint32_t g0, uint32_t g1, uint32_t dx0, uint32_t dx1, uint32_t dy0, uint32_t dy1) {
                 const uint32_t wAk = (k == HALF_ROWS - 1 && half) ? 0u : wA;   // row 31 does not exist
                 const uint32_t wBk = (k == HALF_ROWS - 1 && half) ? 0u : wB;
                 const int vi = dot2(g1, wBk, dot2(g0, wAk, 0));
-                const int vx = dot2(dx1, wBk, dot2(dx0, wAk, 0));
-                const int vy = dot2(dy1, wBk, dot2(dy0, wAk, 0));
+                const int vx = dot2(dx1, wBk, dot2(dx0, wAk, ginit));       // (zero weights: 32768 -> high half 0, as before)
+                const int vy = dot2(dy1, wBk, dot2(dy0, wAk, ginit));
                 if (k & 1) {
                     const int m = k >> 1;
                     Ivp[m] = hi16_pair((uint32_t)vi_prev, (uint32_t)vi);
@@ -365,7 +384,7 @@ __global__ __launch_bounds__(64, WPS) void klt_kernel(KltArgs a)
                 for (int k = 0; k < HALF_ROWS; ++k) {
                     ra = rb; rb = rc; rc = scharr_row(q[k + 3]);
                     const uint32_t g1 = rb.g, dx1 = scharr_dx(ra, rb, rc), dy1 = scharr_dy(ra, rc);
-                    window_row(k, g0, g1, dx0, dx1, dy0, dy1);
+                    window_row(k, 32768, g0, g1, dx0, dx1, dy0, dy1);
                     g0 = g1; dx0 = dx1; dy0 = dy1;
                 }
             } else if (early) {
@@ -388,7 +407,7 @@ __global__ __launch_bounds__(64, WPS) void klt_kernel(KltArgs a)
                 for (int k = 0; k < HALF_ROWS; ++k) {
                     const uint32_t g1 = scaled_pair<0>((uint32_t)graw[k + 1], 0u);
                     const uint32_t dx1 = lo16_pair(draw[k + 1].x, draw[k + 1].y), dy1 = hi16_pair(draw[k + 1].x, draw[k + 1].y);
-                    window_row(k, g0, g1, dx0, dx1, dy0, dy1);
+                    window_row(k, 0, g0, g1, dx0, dx1, dy0, dy1);
                     g0 = g1; dx0 = dx1; dy0 = dy1;
                 }
             } else {
@@ -441,8 +460,8 @@ __global__ __launch_bounds__(64, WPS) void klt_kernel(KltArgs a)
                             const bool rin0 = (unsigned)(ipy + r0 + r) < (unsigned)h, rin1 = (unsigned)(ipy + r0 + r + HALF_ROWS) < (unsigned)h;
                             const bool rin = half ? rin1 : rin0;
                             const uint32_t keep = ((ina && rin) ? 0x0000FFFFu : 0u) | ((inb && rin) ? 0xFFFF0000u : 0u);
-                            dxp[r] = (dxp[r] & keep) | (ROUND_PAIR & ~keep);     // border value 0 is 4*0 + 2
-                            dyp[r] = (dyp[r] & keep) | (ROUND_PAIR & ~keep);
+                            dxp[r] &= keep;                                       // border value 0 (no rounding constant in this form)
+                            dyp[r] &= keep;
                         }
                     }
                 } else if (inside) {
@@ -493,15 +512,17 @@ __global__ __launch_bounds__(64, WPS) void klt_kernel(KltArgs a)
                 }
 #pragma unroll
                 for (int kk = 0; kk < HALF_ROWS / 2; ++kk)
-                    window_row(r0 + kk, gp[kk], gp[kk + 1], dxp[kk], dxp[kk + 1], dyp[kk], dyp[kk + 1]);
+                    window_row(r0 + kk, fly ? 32768 : 0, gp[kk], gp[kk + 1], dxp[kk], dxp[kk + 1], dyp[kk], dyp[kk + 1]);
             }
             }
         }
         float A11, A12, A22;
         // per-lane sums of squares are < 2^29; when all are < 2^24 one int32 chain each is exact
         if (all_small(sA11, sA12, sA22)) {
-            A11 = (float)wave_sum_small(sA11) * FLT_SCALE;
-            A12 = (float)wave_sum_small(sA12) * FLT_SCALE;
+            int t11, t12;
+            wave_sum_pair_small(sA11, sA12, t11, t12);
+            A11 = (float)t11 * FLT_SCALE;
+            A12 = (float)t12 * FLT_SCALE;
             A22 = (float)wave_sum_small(sA22) * FLT_SCALE;
         } else {
             A11 = wave_sum_wide(sA11) * FLT_SCALE;
@@ -613,8 +634,10 @@ __global__ __launch_bounds__(64, WPS) void klt_kernel(KltArgs a)
             }
             float b1, b2;
             if (all_small(sb1, sb2, 0)) {
-                b1 = (float)wave_sum_small(sb1) * FLT_SCALE;
-                b2 = (float)wave_sum_small(sb2) * FLT_SCALE;
+                int t1, t2;
+                wave_sum_pair_small(sb1, sb2, t1, t2);
+                b1 = (float)t1 * FLT_SCALE;
+                b2 = (float)t2 * FLT_SCALE;
             } else {
                 b1 = wave_sum_wide(sb1) * FLT_SCALE;
                 b2 = wave_sum_wide(sb2) * FLT_SCALE;
