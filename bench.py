@@ -1063,6 +1063,9 @@ def main():
     ap.add_argument("--verify", type=int, default=4, help="sequences of the C3 batch re-computed by the CPU oracle after the timed region (0 = off)")
     ap.add_argument("--repeats", type=int, default=5, help="repeats of the K-step timed region of the headline; `value` is the median repeat")
     ap.add_argument("--no-graph", action="store_true", help="time the headline with eager launches instead of HIP-graph replay of the captured steps")
+    ap.add_argument("--engines", type=int, default=2,
+                    help="engine instances per GPU in the realistic headline leg: each its own hv context, stream, HIP graphs and --sequences "
+                         "resident sequences; their launch chains run beside each other (1 = r03's first-half configuration)")
     ap.add_argument("--one-sequence-leg", action="store_true", help="add the literal north-star configuration (ONE sequence per GPU) at N > 1 too")
     ap.add_argument("--cpu-baseline-child", type=float, default=None, help=argparse.SUPPRESS)
     args = ap.parse_args()
@@ -1094,9 +1097,158 @@ def main():
     global W, H, NPTS
     B = args.sequences
 
+    # The headline's engine instances are created FIRST, each stream in front of its engine: ROCclr deals the HIP streams of a process
+    # onto GPU_MAX_HW_QUEUES (4) hardware queues in creation order, and kernels of streams that share a queue run one after the other.
+    # Created behind the C2 leg's objects, two engines landed on shared queues and ran 7 % slower (scripts/two_engines.py, TE_PRELOAD).
+    pre_engines = []
+    if args.engines > 1 and not args.no_graph:
+        # ... and behind two throw-away streams that have run a kernel: which hardware queue a stream gets depends on the streams used
+        # before it. Measured with two engines (scripts/two_engines.py, TE_PRELOAD=5): 0 primed streams 17.3 ms per step of 2048 frames,
+        # 1: 18.65, 2 .. 6: 15.8 - 15.95 -- with >= 2 each engine's two busy streams (its own and the library's second one, DESIGN 3.3 o)
+        # end up on queues of their own. One engine is indifferent to it (9.6 ms either way).
+        prime_ = [torch.cuda.Stream() for _ in range(2)]
+        for x_ in prime_:
+            with torch.cuda.stream(x_):
+                torch.zeros(16, device=f"cuda:{local_rank}").add_(1)
+        torch.cuda.synchronize()
+        for i_ in range(args.engines):
+            si_ = torch.cuda.Stream()
+            tbi_ = TrackerBench(B, local_rank, seed=rank + 1000 * i_)
+            tbi_.enable_chain(rank + 1000 * i_)
+            tbi_.predicted_flow = True
+            ebi_ = VisualEkfBench(tbi_.ctx, B, local_rank, seed=rank + 1000 * i_, realistic=True)
+            # ... warmed and captured here, engine by engine (the sequence scripts/two_engines.py measured)
+            tbi_.overlap = False
+            tbi_.tracked_fraction()
+            torch.cuda.synchronize()
+            tbi_.ctx.set_stream(si_.cuda_stream)
+            gl_ = []
+            with torch.cuda.stream(si_):
+                for _ in range(N_CYCLE):
+                    tbi_.step(); ebi_.step()
+                si_.synchronize()
+                for _ in range(N_CYCLE):
+                    g_ = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g_, stream=si_):
+                        tbi_.step(); ebi_.step()
+                    gl_.append(g_)
+                si_.synchronize()
+            pre_engines.append((si_, tbi_, ebi_, gl_))
+        torch.cuda.synchronize()
+
+    # ---- C3 (configs[2], the headline): the whole frame chained on one stream -- tracker (pyramids, temporal LK from predicted positions,
+    # rotation RANSAC on its output, stereo LK, GFTT on every second frame, bookkeeping) and the HIP EKF driven from the DEVICE mean (f3):
+    # 20 track visits with the reference's track-length distribution (ragged: 5 .. 21 stereo poses = 20 .. 84 rows), per-filter
+    # independent inlier patterns, quota 5, symmetrise, augmentation, 10 predicts ----
+    names = (("pyr_l0", capi.K_PYR_L0), ("pyr_ln", capi.K_PYR_LN), ("klt", capi.K_KLT), ("rot_ransac", capi.K_ROT_RANSAC), ("gftt", capi.K_GFTT),
+             ("ekf_predict", capi.K_EKF_PREDICT), ("vu_prepare", capi.K_VU_PREPARE), ("ekf_update_gate", capi.K_EKF_UPDATE),
+             ("ekf_gate", capi.K_EKF_GATE), ("ekf_augment", capi.K_EKF_AUGMENT))
+
+    def c3_leg(realistic, repeats, graph, engines=1):
+        """One C3 leg under the timing contract: `repeats` timed regions of exactly args.steps steps each (barrier + sync on both sides,
+        MAX over ranks); per-kernel hipEvent times are taken over all of them. Returns the bench objects, the sorted region times and
+        the per-kernel table.
+        engines > 1 (graph replay only): that many INDEPENDENT engine instances on this GPU -- each its own hv context, stream, B resident
+        sequences and captured graphs; a step replays one graph of every engine, i.e. is a step of engines x B frames. The visit loop of
+        one engine is a chain of dependent launches of which several fill a fraction of the chip (the long class's launches, the second
+        update launch); a second engine's chain runs in those gaps. The eager per-kernel profile is engine 0's alone."""
+        multi = graph and engines > 1 and realistic and len(pre_engines) == engines
+        if multi:
+            tb, eb_ = pre_engines[0][1], pre_engines[0][2]
+            extra = [(t_, e_) for _, t_, e_, _ in pre_engines[1:]]
+        else:
+            tb = tb_c2
+            tb.enable_chain(rank)
+            tb.predicted_flow = realistic
+            eb_ = VisualEkfBench(tb.ctx, B, local_rank, seed=rank, realistic=realistic)
+            extra = []
+        def eager_part():
+            for _ in range(args.warmup):
+                tb.step(); eb_.step()
+            eb_.applied.zero_()
+            tb.ctx.profile_enable(True)
+            tb.ctx.profile_reset()
+            eager_ = [env.timed(lambda: (tb.step(), eb_.step()), args.steps) for _ in range(1 if graph else max(1, repeats))]
+            prof = {name: tb.ctx.profile_read(kid) for name, kid in names}
+            tb.ctx.profile_enable(False)
+            nsteps_ = args.steps * len(eager_)
+            kern_ = {k: {"avg_ms": ms / n, "launches": n, "total_ms": ms, "ms_per_step": ms / nsteps_} for k, (ms, n) in prof.items() if n}
+            return eager_, nsteps_, kern_, float(eb_.applied.item()) / (B * nsteps_)
+        # (several engines: the graph region first, the eager profile of engine 0 behind it -- eager steps on the default stream in front
+        #  of the replay left the engines' streams on shared hardware queues: 18.6 instead of 15.9 ms per step, scripts/two_engines.py)
+        if not multi:
+            eager, nsteps, kern, applied_ = eager_part()
+        times, launch = None, "eager"
+        if graph:
+            # The step is a fixed launch sequence with period N_CYCLE (camera path, RANSAC draws, GFTT every 2nd frame, the augmentation's
+            # discard pattern, the pyramid-slot and covariance ping-pongs): captured once into N_CYCLE HIP graphs and replayed -- the same
+            # kernels on the same data, without ~150 eager launch gaps of 10 - 15 us per step (rocprofv3 kernel trace, r03). A timed region
+            # is still exactly args.steps steps = args.steps graph launches, bracketed as the contract says.
+            try:
+                main = torch.cuda.current_stream()
+                side = pre_engines[0][0] if multi else torch.cuda.Stream()
+                tb.overlap = False                               # one capture stream: the bookkeeping runs in line
+                tb.tracked_fraction()                            # (folds the pending frame in on the main stream)
+                torch.cuda.synchronize()
+                tb.ctx.set_stream(side.cuda_stream)
+                lanes = [(side, tb, eb_, [])]                    # (stream, tracker, EKF, graphs) of every engine
+                if multi:                                        # (captured when the engines were created)
+                    lanes = [(s_, t_, e_, list(g_)) for s_, t_, e_, g_ in pre_engines]
+                for s_, t_, e_, gl_ in (lanes if not multi else []):
+                    with torch.cuda.stream(s_):
+                        for _ in range(N_CYCLE):
+                            t_.step(); e_.step()
+                        s_.synchronize()
+                        for _ in range(N_CYCLE):
+                            g_ = torch.cuda.CUDAGraph()
+                            with torch.cuda.graph(g_, stream=s_):
+                                t_.step(); e_.step()
+                            gl_.append(g_)
+                        s_.synchronize()
+                torch.cuda.synchronize()
+                cnt = [0]
+
+                def replay():
+                    for s_, _, _, gl_ in lanes:                  # one graph of every engine, each on its own stream
+                        with torch.cuda.stream(s_):
+                            gl_[cnt[0] % N_CYCLE].replay()
+                    cnt[0] += 1
+                for _ in range(N_CYCLE):
+                    replay()
+                torch.cuda.synchronize()
+                times = [env.timed(replay, args.steps) for _ in range(max(1, repeats))]
+                while cnt[0] % N_CYCLE:                          # back to a cycle boundary: the host-side counters (frame number, discard
+                    replay()                                     # pattern) match the device state again for the eager steps that follow
+                torch.cuda.synchronize()
+                for s_, t_, _, _ in lanes:
+                    t_.ctx.set_stream(main.cuda_stream)
+                torch.cuda.synchronize()
+                launch = "hipGraph replay" if len(lanes) == 1 else f"hipGraph replay, {len(lanes)} engines x {B} sequences on {len(lanes)} streams"
+                keep_graphs.append([gl_ for _, _, _, gl_ in lanes])   # (destroyed with the process: the captured kernels hold the library's buffers)
+                keep_graphs.append(extra)
+            except Exception as ex:                              # pragma: no cover
+                tb.ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+                launch = "eager (graph capture failed: " + repr(ex)[:120] + ")"
+                times = None
+        if multi:
+            eager, nsteps, kern, applied_ = eager_part()
+        if times is None:
+            times = eager
+        n_eng[0] = 1 + len(extra) if (graph and launch.startswith("hipGraph")) else 1
+        return eb_, times, kern, applied_, launch, eager, nsteps, tb
+
+    keep_graphs, n_eng = [], [1]
+    head_early = None
+    if pre_engines:
+        # several engines: the headline region runs FIRST, before any other leg has used a stream of its own -- which hardware queue a
+        # HIP stream's kernels go through depends on the streams that were busy before it, and behind the C2 leg the engines' streams
+        # shared queues (18.6 instead of 15.9 ms per step of 2 x 1024 frames; scripts/two_engines.py TE_PRELOAD = 1, 4, 5)
+        head_early = c3_leg(True, args.repeats, True, args.engines)
+    eng_head = n_eng[0]
     # ---- C2: tracker only (configs[1]) ----
     tb, c2 = tracker_leg(env, args, B, local_rank, rank,
                          "C2: 752x480 stereo, 200 pts, HIP pyramid+KLT tracker (2 builds + 2 LK calls per frame), EKF on the host")
+    tb_c2 = tb
     out = {}
     # ---- f1..f4, PCIe: single-kernel characterisation, 1-GPU job only ----
     if solo and not args.no_gftt:
@@ -1144,79 +1296,16 @@ def main():
     if solo and not args.no_ransac:
         out["f4_rot_ransac"] = bench_rot_ransac(tb.ctx, min(B, 1024), local_rank, not args.no_cpu_baseline)
 
-    # ---- C3 (configs[2], the headline): the whole frame chained on one stream -- tracker (pyramids, temporal LK from predicted positions,
-    # rotation RANSAC on its output, stereo LK, GFTT on every second frame, bookkeeping) and the HIP EKF driven from the DEVICE mean (f3):
-    # 20 track visits with the reference's track-length distribution (ragged: 5 .. 21 stereo poses = 20 .. 84 rows), per-filter
-    # independent inlier patterns, quota 5, symmetrise, augmentation, 10 predicts ----
-    names = (("pyr_l0", capi.K_PYR_L0), ("pyr_ln", capi.K_PYR_LN), ("klt", capi.K_KLT), ("rot_ransac", capi.K_ROT_RANSAC), ("gftt", capi.K_GFTT),
-             ("ekf_predict", capi.K_EKF_PREDICT), ("vu_prepare", capi.K_VU_PREPARE), ("ekf_update_gate", capi.K_EKF_UPDATE),
-             ("ekf_gate", capi.K_EKF_GATE), ("ekf_augment", capi.K_EKF_AUGMENT))
-
-    def c3_leg(realistic, repeats, graph):
-        """One C3 leg under the timing contract: `repeats` timed regions of exactly args.steps steps each (barrier + sync on both sides,
-        MAX over ranks); per-kernel hipEvent times are taken over all of them. Returns the bench objects, the sorted region times and
-        the per-kernel table."""
-        tb.enable_chain(rank)
-        tb.predicted_flow = realistic
-        eb_ = VisualEkfBench(tb.ctx, B, local_rank, seed=rank, realistic=realistic)
-        for _ in range(args.warmup):
-            tb.step(); eb_.step()
-        eb_.applied.zero_()
-        tb.ctx.profile_enable(True)
-        tb.ctx.profile_reset()
-        eager = [env.timed(lambda: (tb.step(), eb_.step()), args.steps) for _ in range(1 if graph else max(1, repeats))]
-        prof = {name: tb.ctx.profile_read(kid) for name, kid in names}
-        tb.ctx.profile_enable(False)
-        nsteps = args.steps * len(eager)
-        kern = {k: {"avg_ms": ms / n, "launches": n, "total_ms": ms, "ms_per_step": ms / nsteps} for k, (ms, n) in prof.items() if n}
-        applied_ = float(eb_.applied.item()) / (B * nsteps)
-        times, launch = eager, "eager"
-        if graph:
-            # The step is a fixed launch sequence with period N_CYCLE (camera path, RANSAC draws, GFTT every 2nd frame, the augmentation's
-            # discard pattern, the pyramid-slot and covariance ping-pongs): captured once into N_CYCLE HIP graphs and replayed -- the same
-            # kernels on the same data, without ~150 eager launch gaps of 10 - 15 us per step (rocprofv3 kernel trace, r03). A timed region
-            # is still exactly args.steps steps = args.steps graph launches, bracketed as the contract says.
-            try:
-                main = torch.cuda.current_stream()
-                side = torch.cuda.Stream()
-                tb.overlap = False                               # one capture stream: the bookkeeping runs in line
-                tb.tracked_fraction()                            # (folds the pending frame in on the main stream)
-                torch.cuda.synchronize()
-                tb.ctx.set_stream(side.cuda_stream)
-                graphs = []
-                with torch.cuda.stream(side):
-                    for _ in range(N_CYCLE):
-                        tb.step(); eb_.step()
-                    side.synchronize()
-                    for _ in range(N_CYCLE):
-                        g_ = torch.cuda.CUDAGraph()
-                        with torch.cuda.graph(g_, stream=side):
-                            tb.step(); eb_.step()
-                        graphs.append(g_)
-                    side.synchronize()
-                    cnt = [0]
-
-                    def replay():
-                        graphs[cnt[0] % N_CYCLE].replay(); cnt[0] += 1
-                    for _ in range(N_CYCLE):
-                        replay()
-                    side.synchronize()
-                    times = [env.timed(replay, args.steps) for _ in range(max(1, repeats))]
-                    while cnt[0] % N_CYCLE:                      # back to a cycle boundary: the host-side counters (frame number, discard
-                        replay()                                 # pattern) match the device state again for the eager steps that follow
-                    side.synchronize()
-                tb.ctx.set_stream(main.cuda_stream)
-                torch.cuda.synchronize()
-                launch = "hipGraph replay"
-                keep_graphs.append(graphs)                       # (destroyed with the process: the captured kernels hold the library's buffers)
-            except Exception as ex:                              # pragma: no cover
-                tb.ctx.set_stream(torch.cuda.current_stream().cuda_stream)
-                launch = "eager (graph capture failed: " + repr(ex)[:120] + ")"
-                times = eager
-        return eb_, times, kern, applied_, launch, eager, nsteps
-
-    keep_graphs = []
-    eb, times3, k3, applied, launch3, eager3, nprof3 = c3_leg(True, args.repeats, not args.no_graph)
+    one_engine = None
+    if args.engines > 1 and not args.no_graph and not os.environ.get('HV_BENCH_SKIP_ONE_ENGINE'):
+        # the same leg with ONE engine first (r03's first-half configuration, what c3_uniform and r02's headline are comparable to)
+        eb1, t1_, _, _, l1_, _, _, _ = c3_leg(True, 1, True, 1)
+        one_engine = {"sequences_per_gpu": B, "value": aggregate_value(B, world, args.steps, t1_[0]), "unit": "frames/s",
+                      "ms_per_step": t1_[0] / args.steps * 1e3, "launch": l1_}
+        eb1.ekf.close()
+        del eb1
+    eb, times3, k3, applied, launch3, eager3, nprof3, tb = head_early if head_early is not None else c3_leg(True, args.repeats, not args.no_graph, 1)     # (tb: engine 0's tracker from here on)
+    ENG = eng_head if head_early is not None else n_eng[0]     # engines the headline region really ran
     el3 = sorted(times3)[len(times3) // 2]                      # the median repeat is the reported timed region
     gate_hist = [int((eb.gs[k] == 0).sum().item()) for k in range(VISITS)]
     verify = verify_c3(tb, eb, args.verify, seed=rank) if (args.verify > 0 and rank == 0) else None
@@ -1284,12 +1373,14 @@ def main():
     if rank == 0:
         head = {
             "metric": "VIO frames/sec at 752x480 stereo, 200 KLT features; pyramid+KLT HBM GB/s",
-            "value": aggregate_value(B, world, args.steps, el3), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "value": aggregate_value(ENG * B, world, args.steps, el3), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": el3 / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u8/int16 pixels, int32/int64 sums, f32 solve (tracker); f64 (EKF)", "data": "synthetic",
             "smoke_all_ranks_on_one_device": forced_dev is not None or None,
             "repeats_ms_per_step": [t_ / args.steps * 1e3 for t_ in times3], "value_is": "median of the repeats (each an exact K-step timed region)",
             "launch": launch3, "eager_ms_per_step": eager3[0] / args.steps * 1e3,
+            "eager_ms_per_step_is": f"ONE engine ({B} sequences) with eager launches: the region the per-kernel hipEvent profile (`kernels`, `roofline`) comes from",
+            "one_engine": one_engine,
             "stage_pyramid_klt_frac_of_8TBs": stage["frac_of_8TBs"], "stage_pyramid_klt_frac_actual": stage["frac_actual"],
             "parity_checked_sequences": verify["parity_checked_sequences"] if verify else 0, "parity_ok": verify["ok"] if verify else None,
             "config": {"workload": "C3: 752x480 stereo, 200 pts -- the whole frame chained on one stream per sequence: 2 pyramid builds, temporal LK from "
@@ -1297,7 +1388,10 @@ def main():
                                    "then the HIP EKF from the device mean: 20 track visits (triangulation + prepareVisualUpdate + chi2 gate; track lengths "
                                    "5 + Geometric(0.2) <= 21 stereo poses = 20 .. 84 rows, per-filter independent inliers p = 0.25, quota 5 updates), "
                                    "symmetrise, 1 Joseph-form augmentation, 10 predicts in one launch; state dim 160",
-                       "sequences_per_gpu": B, "frames_per_step": world * B, "parallelism": f"replicas x{world} (no collective)",
+                       "sequences_per_gpu": ENG * B, "engines_per_gpu": ENG, "sequences_per_engine": B, "frames_per_step": world * ENG * B,
+                       "engines": "independent engine instances per GPU (own hv context, stream, captured graphs, resident sequences): a step replays one "
+                                  "graph of each, their launch chains fill each other's idle CUs; `one_engine` below = the same leg with one",
+                       "parallelism": f"replicas x{world} (no collective)",
                        "track_poses_mean": lens_mean, "tracks_longer_than_11_poses": long_share,
                        "timing_process_group": args.dist_backend if world > 1 else None, "host_cores_per_rank": env.cores},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": k3[dom]["achieved_GBs"], "peak": HBM_PEAK_GBS,
@@ -1331,7 +1425,7 @@ def main():
     # ---- r02's C3 workload (every track 10 stereo poses, all filters share the inlier pattern 3, 7, 11, 15, 19, zero-flow LK start):
     # kept for round-over-round comparison ----
     if not args.only_headline or os.environ.get("HV_BENCH_C3_UNIFORM") == "1":
-        ebu, timesu, ku, appliedu, launchu, _, _ = c3_leg(False, 1, not args.no_graph)
+        ebu, timesu, ku, appliedu, launchu, _, _, _ = c3_leg(False, 1, not args.no_graph)
         ebu.ekf.close()
         del ebu
         tb.predicted_flow = True
