@@ -43,8 +43,9 @@ for i in range(E):
     s = torch.cuda.Stream()
     sd = 1000 * i
     tb = bench.TrackerBench(S, dev, seed=sd)
-    tb.enable_chain(sd); tb.predicted_flow = True; tb.overlap = False
-    eb = bench.VisualEkfBench(tb.ctx, S, dev, seed=sd, realistic=True)
+    REAL = os.environ.get('TE_UNIFORM') is None
+    tb.enable_chain(sd); tb.predicted_flow = REAL; tb.overlap = False
+    eb = bench.VisualEkfBench(tb.ctx, S, dev, seed=sd, realistic=REAL)
     tb.tracked_fraction()
     torch.cuda.synchronize()
     tb.ctx.set_stream(s.cuda_stream)
