@@ -75,6 +75,11 @@ PROTOTYPES = {
     "hv_last_error": (C.c_char_p, [C.c_void_p]),
     "hv_set_stream": (C.c_int, [C.c_void_p, C.c_void_p]),
     "hv_synchronize": (C.c_int, [C.c_void_p]),
+    "hv_get_stream": (C.c_void_p, [C.c_void_p]),
+    "hv_lanes_create": (C.c_int, [C.POINTER(Params), C.c_int, C.POINTER(C.c_void_p)]),
+    "hv_lanes_count": (C.c_int, [C.c_void_p]),
+    "hv_lanes_ctx": (C.c_void_p, [C.c_void_p, C.c_int]),
+    "hv_lanes_destroy": (None, [C.c_void_p]),
     "hv_pyramid_acquire": (C.c_int, [C.c_void_p, C.POINTER(C.c_int)]),
     "hv_pyramid_release": (C.c_int, [C.c_void_p, C.c_int]),
     "hv_pyramid_level_size": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
@@ -167,7 +172,7 @@ class Context:
     """One hv_ctx: a HIP stream, a pool of pyramid slots and the tracker parameters."""
 
     def __init__(self, width=752, height=480, levels=4, win=31, max_iter=20, eps=0.03, min_eig=1e-3,
-                 max_tracks=200, pool_size=16, max_pairs=1, device=0):
+                 max_tracks=200, pool_size=16, max_pairs=1, device=0, _adopt=None):
         L = lib()
         p = Params()
         L.hv_default_params(C.byref(p))
@@ -175,11 +180,15 @@ class Context:
         p.max_iter, p.eps, p.min_eig, p.max_tracks = max_iter, eps, min_eig, max_tracks
         p.pool_size, p.max_pairs = pool_size, max_pairs
         self.params = p
-        self._h = C.c_void_p()
-        rc = L.hv_create(C.byref(p), C.byref(self._h))
-        if rc != 0:
-            self._h = None
-            raise HvError(f"hv_create: {L.hv_status_string(rc).decode()}")
+        self._owned = _adopt is None
+        if _adopt is not None:                       # a lane of a Lanes set: the set owns the hv_ctx
+            self._h = C.c_void_p(_adopt)
+        else:
+            self._h = C.c_void_p()
+            rc = L.hv_create(C.byref(p), C.byref(self._h))
+            if rc != 0:
+                self._h = None
+                raise HvError(f"hv_create: {L.hv_status_string(rc).decode()}")
         self.levels = 0
         self.level_sizes = []
         w, h = C.c_int(), C.c_int()
@@ -191,7 +200,8 @@ class Context:
         if getattr(self, "_h", None):
             for child in list(getattr(self, "_children", [])):   # hv_ekf objects must die before their hv_ctx
                 child.close()
-            lib().hv_destroy(self._h)
+            if self._owned:
+                lib().hv_destroy(self._h)
             self._h = None
 
     def __del__(self):
@@ -223,6 +233,10 @@ class Context:
 
     def set_stream(self, stream_ptr: int):
         self._chk(lib().hv_set_stream(self._h, C.c_void_p(stream_ptr)), "hv_set_stream")
+
+    def get_stream(self) -> int:
+        """The hipStream_t the context issues on (hv_get_stream), as an integer handle."""
+        return int(lib().hv_get_stream(self._h) or 0)
 
     def synchronize(self):
         self._chk(lib().hv_synchronize(self._h), "hv_synchronize")
@@ -455,6 +469,45 @@ def vu_default_params(imu_to_camera=None, second_imu_to_camera=None, **over) -> 
     for k, v in over.items():
         setattr(p, k, v)
     return p
+
+
+class Lanes:
+    """hv_lanes: n batched contexts of one GPU whose streams come from the device's high-priority queue pool, so that their launch
+    chains run beside each other whatever the process did before (include/hybvio_hip.h). ctx[i] are Context objects the set owns."""
+
+    def __init__(self, n_lanes, **kw):
+        L = lib()
+        p = Params()
+        L.hv_default_params(C.byref(p))
+        vals = dict(width=752, height=480, levels=4, win=31, max_iter=20, eps=0.03, min_eig=1e-3, max_tracks=200, pool_size=16,
+                    max_pairs=1, device=0)
+        vals.update(kw)
+        for k, v in vals.items():
+            setattr(p, k, v)
+        self._g = C.c_void_p()
+        rc = L.hv_lanes_create(C.byref(p), int(n_lanes), C.byref(self._g))
+        if rc != 0:
+            self._g = None
+            raise HvError(f"hv_lanes_create: {L.hv_status_string(rc).decode()}")
+        n = L.hv_lanes_count(self._g)
+        kw2 = {k: getattr(p, k) for k in ("width", "height", "levels", "win", "max_iter", "eps", "min_eig", "max_tracks", "pool_size", "max_pairs", "device")}
+        self.ctx = [Context(_adopt=L.hv_lanes_ctx(self._g, i), **kw2) for i in range(n)]
+
+    def close(self):
+        if getattr(self, "_g", None):
+            for c in self.ctx:
+                c.close()                             # (closes the lanes' hv_ekf children; the contexts themselves die with the set)
+            lib().hv_lanes_destroy(self._g)
+            self._g = None
+
+    def __del__(self):
+        self.close()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
 
 
 class EkfBatch:

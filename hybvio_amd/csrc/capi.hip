@@ -18,7 +18,7 @@ const KnobEntry KNOB_TABLE[] = {
     {"ekf_no_speculation", &Knobs::ekf_no_speculation}, {"ekf_stream_gate", &Knobs::ekf_stream_gate},
     {"ekf_gate_kmode", &Knobs::ekf_gate_kmode}, {"ingest_gather", &Knobs::ingest_gather},
     {"ekf_fused_gate", &Knobs::ekf_fused_gate}, {"ekf_spec_mode", &Knobs::ekf_spec_mode},
-    {"rot_ransac_threads", &Knobs::rot_ransac_threads}, {"ekf_persistent", &Knobs::ekf_persistent}, {"ekf_side_stream", &Knobs::ekf_side_stream}, {"ekf_dual_update", &Knobs::ekf_dual_update}, {"ekf_visit_order", &Knobs::ekf_visit_order},
+    {"rot_ransac_threads", &Knobs::rot_ransac_threads}, {"ekf_side_stream", &Knobs::ekf_side_stream}, {"ekf_dual_update", &Knobs::ekf_dual_update}, {"ekf_long_fused", &Knobs::ekf_long_fused}, {"ekf_visit_order", &Knobs::ekf_visit_order},
 };
 }  // namespace
 
@@ -60,19 +60,19 @@ int hip_fail(Ctx *c, hipError_t e, const char *what)
     return HV_ERR_HIP;
 }
 
-ScopedKernelTime::ScopedKernelTime(Ctx *c_, int id_) : c(c_), id(id_)
+ScopedKernelTime::ScopedKernelTime(Ctx *c_, int id_, hipStream_t stream) : c(c_), id(id_), s(stream ? stream : c_->stream)
 {
     if (!c->profiling) return;
     KernelTimer &t = c->timers[id];
     if (!t.free_list.empty()) { a = t.free_list.back().first; b = t.free_list.back().second; t.free_list.pop_back(); }
     else { (void)hipEventCreate(&a); (void)hipEventCreate(&b); }
-    (void)hipEventRecord(a, c->stream);
+    (void)hipEventRecord(a, s);
 }
 
 ScopedKernelTime::~ScopedKernelTime()
 {
     if (!a) return;
-    (void)hipEventRecord(b, c->stream);
+    (void)hipEventRecord(b, s);
     c->timers[id].pending.emplace_back(a, b);
 }
 
@@ -255,7 +255,29 @@ const char *hv_status_string(int s)
     }
 }
 
-int hv_create(const hv_params *params, hv_ctx **out)
+// Both streams of a context come from ONE queue pool of the runtime. ROCclr keeps a pool of hardware (HSA) queues per stream priority
+// (GPU_MAX_HW_QUEUES = 4 each) and hands a new stream the queue of its priority with the fewest users. With the default priority that
+// pool is shared with everything else the process created before -- the null stream, the 32 pooled streams of a torch process, the
+// streams a HIP graph instantiates for its branches -- so whether two contexts' busy streams ended up on one hardware queue (kernels
+// of one queue run one after the other) depended on the process history (r03: 15.8 / 17.3 / 18.6 ms per step for the same two engines
+// after different warm-ups). hv_lanes_create therefore takes its streams from the HIGH-priority pool, which nothing else uses
+// unless asked to: up to four streams (two lanes) get a hardware queue each, independent of what ran before.
+static int create_streams(Ctx *c, int high_priority)
+{
+    int least = 0, greatest = 0;
+    if (high_priority && hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) high_priority = 0;
+    if (high_priority && greatest == least) high_priority = 0;                 // the device has one priority level only
+    c->stream_priority = high_priority ? 1 : 0;
+    for (hipStream_t *s : { &c->stream, &c->aux_stream }) {
+        const hipError_t e = high_priority ? hipStreamCreateWithPriority(s, hipStreamNonBlocking, greatest)
+                                           : hipStreamCreateWithFlags(s, hipStreamNonBlocking);
+        if (e != hipSuccess) return hip_fail(c, e, "hipStreamCreate");
+    }
+    c->own_stream = true;
+    return HV_OK;
+}
+
+static int create_ctx(const hv_params *params, int high_priority, hv_ctx **out)
 {
     if (!params || !out) return HV_ERR_INVALID;
     *out = nullptr;
@@ -279,14 +301,17 @@ int hv_create(const hv_params *params, hv_ctx **out)
     do {
         if (hipSetDevice(p.device) != hipSuccess) { rc = HV_ERR_NO_DEVICE; break; }
         { hipDeviceProp_t prop; if (hipGetDeviceProperties(&prop, p.device) == hipSuccess && prop.multiProcessorCount > 0) c->num_cus = prop.multiProcessorCount; }
-        if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { rc = HV_ERR_HIP; break; }
-        c->own_stream = true;
+        rc = create_streams(c, high_priority);
+        if (rc != HV_OK) break;
         const size_t slab_bytes = (size_t)c->L.slot_bytes * p.pool_size + hv::SLAB_SLACK;
         if (hipMalloc(&c->slab, slab_bytes) != hipSuccess) { rc = HV_ERR_NOMEM; break; }
         if (hipMalloc(&c->d_l0_ptr, sizeof(void *) * p.pool_size) != hipSuccess) { rc = HV_ERR_NOMEM; break; }
         if (hipMalloc(&c->d_l0_stride, sizeof(int) * p.pool_size) != hipSuccess) { rc = HV_ERR_NOMEM; break; }
         if (hipMalloc(&c->d_slots, sizeof(int) * 4) != hipSuccess) { rc = HV_ERR_NOMEM; break; }
         if (hipMemsetAsync(c->d_l0_ptr, 0, sizeof(void *) * p.pool_size, c->stream) != hipSuccess) { rc = HV_ERR_HIP; break; }
+        // (the second stream runs its first command here, not inside the first frame: a stream's hardware queue is bound when it is used)
+        if (hipMemsetAsync(c->d_slots, 0, sizeof(int) * 4, c->aux_stream) != hipSuccess) { rc = HV_ERR_HIP; break; }
+        if (hipStreamSynchronize(c->aux_stream) != hipSuccess) { rc = HV_ERR_HIP; break; }
         c->slot_used.assign(p.pool_size, 0);
         for (int s = p.pool_size - 1; s >= 0; --s) c->free_slots.push_back(s);
         rc = hv::ensure_point_staging(c, p.max_tracks);
@@ -296,6 +321,39 @@ int hv_create(const hv_params *params, hv_ctx **out)
     *out = h;
     return HV_OK;
 }
+
+int hv_create(const hv_params *params, hv_ctx **out) { return create_ctx(params, 0, out); }
+
+/* ---- lanes ---- */
+struct hv_lanes { std::vector<hv_ctx *> ctx; };
+
+int hv_lanes_create(const hv_params *params, int n_lanes, hv_lanes **out)
+{
+    if (!params || !out || n_lanes < 1 || n_lanes > HV_MAX_LANES) return HV_ERR_INVALID;
+    *out = nullptr;
+    hv_lanes *g = new (std::nothrow) hv_lanes();
+    if (!g) return HV_ERR_NOMEM;
+    for (int i = 0; i < n_lanes; ++i) {
+        hv_ctx *h = nullptr;
+        const int rc = create_ctx(params, 1, &h);
+        if (rc != HV_OK) { hv_lanes_destroy(g); return rc; }
+        g->ctx.push_back(h);
+    }
+    *out = g;
+    return HV_OK;
+}
+
+int hv_lanes_count(const hv_lanes *g) { return g ? (int)g->ctx.size() : HV_ERR_INVALID; }
+hv_ctx *hv_lanes_ctx(hv_lanes *g, int lane) { return (g && lane >= 0 && lane < (int)g->ctx.size()) ? g->ctx[lane] : nullptr; }
+
+void hv_lanes_destroy(hv_lanes *g)
+{
+    if (!g) return;
+    for (hv_ctx *h : g->ctx) hv_destroy(h);
+    delete g;
+}
+
+void *hv_get_stream(hv_ctx *h) { return h ? reinterpret_cast<void *>(h->c.stream) : nullptr; }
 
 void hv_destroy(hv_ctx *h)
 {
@@ -321,6 +379,7 @@ void hv_destroy(hv_ctx *h)
         if (c->d_tile_box[k]) (void)hipFree(c->d_tile_box[k]);
     for (int k = 0; k < HV_INGEST_CAMERAS; ++k)
         if (c->d_map_xy[k]) { (void)hipFree(c->d_map_xy[k]); (void)hipFree(c->d_map_xf[k]); (void)hipFree(c->d_map_yf[k]); }
+    if (c->aux_stream) { (void)hipStreamSynchronize(c->aux_stream); (void)hipStreamDestroy(c->aux_stream); }
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
     delete h;
 }

@@ -25,6 +25,7 @@
 //     through an in-wave LDS transpose for the fused (P+P')/2, and the result goes to the second of
 //     two ping-pong buffers: one read and one write of P per augmentation.
 #include <functional>
+#include <limits.h>
 #include <math.h>
 
 #include <utility>
@@ -419,6 +420,10 @@ struct UpdateArgs {
     // normalisation; half 2 reads it (dm_in) and normalises. 0 = the whole record in one launch. Compact H, MODE 2 only.
     int half, nr_full;                // nr_full: rows of the whole record when neither nr_rec nor nr says so (uniform long tracks)
     double *dm_out; const double *dm_in;   // [batch][n]
+    // half 1 only: the visit's gate statuses. A block 1 that meets a non-positive pivot applies nothing and turns its record's status
+    // into CHI2 -- what every other mode reports for a broken factorisation --, so that block 2 (require_inlier) skips the record
+    // instead of applying half an update on a stale dm_in (r03 advisor)
+    int *gate_rw;
     int batch;
     const int *rec_count, *rec_list;  // compaction list (VuPrepareArgs): workgroup i updates filter rec_list[i], i < *rec_count; the others exit
 };
@@ -888,6 +893,7 @@ __device__ __forceinline__ void ekf_update_body(const UpdateArgs &a, const int b
                 if (a.status) a.status[e] = outlier ? 3 /*CHI2*/ : 0 /*INLIER*/;
             }
             *s_stop = (a.mode == 0) || broken || ((a.mode == 2 || (two_r && pass == 0)) && outlier);
+            if (broken && a.gate_rw) a.gate_rw[e] = 3 /*CHI2*/;
             if (a.spec == 3 && pass == 0) {
                 const int j = blockIdx.y;
                 spec_publish(a, e, outlier ? 1 : 2);
@@ -1221,8 +1227,7 @@ struct SparseGateArgs {
     double *chi2; int *status;        // chi2 optional
     int hs_doubles;                   // LDS carve: doubles reserved for the staged Hc (>= 816 + 4: it is the Cholesky scratch afterwards)
     int lds_doubles;                  // doubles available for Hc + [S; v'] together (BIG build: decides between the padded and the tight layout)
-    int persistent, batch;
-    int *queue; int q_off;
+    int batch;
     const int *rec_count, *rec_list;  // this launch's records (compaction list of the long class), or null
     int *inl_count, *inl_list;        // appended: records whose gate said INLIER
 };
@@ -1314,10 +1319,9 @@ __device__ __forceinline__ void sparse_gate_kernel_body(const SparseGateArgs &a,
 __global__ __launch_bounds__(SGATE_THREADS, 3) void ekf_sparse_gate_kernel(SparseGateArgs a) { sparse_gate_kernel_body<false>(a, blockIdx.x); }
 __global__ __launch_bounds__(SGATE_BIG_THREADS, 1) void ekf_sparse_gate_big_kernel(SparseGateArgs a)
 {
-    extern __shared__ __attribute__((aligned(16))) double smem[];
-    if (a.persistent) HV_QUEUE_LOOP(a.queue, a.batch, reinterpret_cast<int *>(reinterpret_cast<char *>(smem) + a.q_off), (sparse_gate_kernel_body<true>(a, b_)));     // (see ekf_update_kernel)
-    else if (a.rec_list) { if ((int)blockIdx.x < *a.rec_count) sparse_gate_kernel_body<true>(a, a.rec_list[blockIdx.x]); }
-    else sparse_gate_kernel_body<true>(a, blockIdx.x);
+    int b = blockIdx.x;
+    if (a.rec_list) { if (b >= *a.rec_count) return; b = a.rec_list[b]; }
+    sparse_gate_kernel_body<true>(a, b);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1659,14 +1663,12 @@ struct Ekf {
     // fused prepare + gate (compact Jacobians live in vuH / spH): the active-column lists of the records
     int *vuacol = nullptr, *spacol = nullptr;
     // long-track classes of a ragged visit (visual_track_dev_impl): own stream, events, Jacobian / residual / active buffers
-    hipStream_t side_stream[2] = {nullptr, nullptr};
-    hipEvent_t ev_fork[2] = {nullptr, nullptr}, ev_join[2] = {nullptr, nullptr};
-    double *sideH[2] = {nullptr, nullptr}, *sidev[2] = {nullptr, nullptr};
-    unsigned char *side_active[2] = {nullptr, nullptr};
-    int side_rows[2] = {0, 0};
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;    // fork onto / join of the context's second stream (Ctx::aux_stream) inside a visit
+    double *sideH = nullptr, *sidev = nullptr;
+    unsigned char *side_active = nullptr;
+    int side_rows = 0;
     int *side_acol = nullptr; double *side_dm = nullptr;
     int *err_dev = nullptr;                               // device error word (UpdateArgs::err)
-    int *queue_dev = nullptr;                             // work queue of the persistent launches (HV_QUEUE_LOOP), zero between launches
     int *visit_counts = nullptr, *visit_lists = nullptr;  // compaction lists of a visit: counts {inliers short, long records, inliers long}, lists 3 x [batch]
     // the counts exist once per visit of a frame loop (VISIT_SLOTS x 4 ints, zeroed by ONE memset per frame; visit_slot = the running
     // visit, set by the loop) plus one set for stand-alone visits (zeroed per call): a memset node per visit was 20 more graph nodes
@@ -1679,7 +1681,7 @@ struct Ekf {
 
 // compact-H description handed to ekf_launch_update (null acol: dense H of l columns); half / nr_full / dm: block update of a long
 // track (UpdateArgs::half)
-struct CompactH { const int *acol = nullptr; int na_max = 0, ncam = 1; int half = 0, nr_full = 0; double *dm = nullptr; const int *rec_count = nullptr, *rec_list = nullptr; };
+struct CompactH { const int *acol = nullptr; int na_max = 0, ncam = 1; int half = 0, nr_full = 0; double *dm = nullptr; const int *rec_count = nullptr, *rec_list = nullptr; int *gate_rw = nullptr; };
 
 // an update launch prepared but not issued (ekf_launch_update's `defer`): two of them can share one grid (ekf_launch_update_dual)
 struct UpdateLaunch { UpdateArgs a; size_t base_bytes = 0; int kmode = -1, ti = 0, lbk = 0; };
@@ -1717,7 +1719,7 @@ static int ekf_launch_update(Ekf *e, int nr, int l, const double *H_dev, const d
     if (compact && compact->acol) {
         a.acol = compact->acol; a.na_max = compact->na_max; a.ncam = compact->ncam; a.h_stride = (size_t)nr_stride * compact->na_max;
         a.half = compact->half; a.nr_full = compact->nr_full;
-        if (a.half == 1) a.dm_out = compact->dm;
+        if (a.half == 1) { a.dm_out = compact->dm; a.gate_rw = compact->gate_rw; }
         if (a.half == 2) a.dm_in = compact->dm;
         a.rec_count = compact->rec_count; a.rec_list = compact->rec_list;
     }
@@ -1826,9 +1828,11 @@ static int ekf_launch_gate_stream(Ekf *e, int nr, int l, const double *H_dev, co
 // ekf_sparse_gate_kernel over the compact records of a prepare launch (np = poses of the longest record)
 static int ekf_launch_sparse_gate(Ekf *e, int np, int ncam, const double *Hc_dev, const double *v_dev, const int *acol_dev, const int *nr_rec_dev,
                                   const unsigned char *active_dev, double rd, double *chi2_dev, int *status_dev,
-                                  const int *rec_count = nullptr, const int *rec_list = nullptr, int *inl_count = nullptr, int *inl_list = nullptr)
+                                  const int *rec_count = nullptr, const int *rec_list = nullptr, int *inl_count = nullptr, int *inl_list = nullptr,
+                                  hipStream_t stream = nullptr)
 {
     Ctx *c = e->c;
+    if (!stream) stream = c->stream;
     const int nr = 2 * np * ncam, na_max = 7 * np + 1, na4 = (na_max + 3) & ~3, nrp = 16 * ((nr + 15) / 16);
     if (nr < 2 || nr > 96 || nr >= HV_CHI2INV95_N || !active_dev || !status_dev) return HV_ERR_INVALID;
     const bool big = nr > 48;
@@ -1856,13 +1860,11 @@ static int ekf_launch_sparse_gate(Ekf *e, int np, int ncam, const double *Hc_dev
         HV_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void *>(ekf_sparse_gate_big_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set = true;
     }
-    ScopedKernelTime tm(c, HV_K_EKF_GATE);
+    ScopedKernelTime tm(c, HV_K_EKF_GATE, stream);
     a.rec_count = rec_count; a.rec_list = rec_list; a.inl_count = inl_count; a.inl_list = inl_list;
-    a.batch = e->batch; a.queue = e->queue_dev; a.persistent = c->knob.ekf_persistent == 1 && !rec_list && big && e->batch > c->num_cus && shmem + 32 <= cap ? 1 : 0;
-    a.q_off = (int)((shmem + 15) & ~(size_t)15);
-    if (big) hipLaunchKernelGGL(ekf_sparse_gate_big_kernel, dim3((unsigned)(a.persistent ? c->num_cus : e->batch)), dim3(SGATE_BIG_THREADS),
-                                a.persistent ? (size_t)a.q_off + 16 : shmem, c->stream, a);
-    else     hipLaunchKernelGGL(ekf_sparse_gate_kernel, dim3(e->batch), dim3(SGATE_THREADS), shmem, c->stream, a);
+    a.batch = e->batch;
+    if (big) hipLaunchKernelGGL(ekf_sparse_gate_big_kernel, dim3((unsigned)e->batch), dim3(SGATE_BIG_THREADS), shmem, stream, a);
+    else     hipLaunchKernelGGL(ekf_sparse_gate_kernel, dim3(e->batch), dim3(SGATE_THREADS), shmem, stream, a);
     HV_HIP(c, hipGetLastError());
     return HV_OK;
 }
@@ -1896,13 +1898,11 @@ void hv_ekf_destroy(hv_ekf *h)
     void *ptrs[] = { e->m, e->P, e->P1, e->m1, e->Q, e->dydx, e->ws, e->sH, e->sv, e->sr, e->schi2, e->simu,
                      e->sstatus, e->sdrop, e->sactive, e->vuH, e->vuv, e->vupf, e->vuactive, e->vustage,
                      e->spH, e->spv, e->sppf, e->spactive, e->spcursor, e->spepoch, e->spcursor2, e->sppub, e->vurows, e->sprows,
-                     e->vuacol, e->spacol, e->err_dev, e->sideH[0], e->sideH[1], e->sidev[0], e->sidev[1], e->side_active[0], e->side_active[1], e->side_acol, e->side_dm, e->queue_dev, e->visit_counts, e->visit_lists, e->visit_order, e->visit_long, e->visit_long_count };
+                     e->vuacol, e->spacol, e->err_dev, e->sideH, e->sidev, e->side_active, e->side_acol, e->side_dm, e->visit_counts, e->visit_lists, e->visit_order, e->visit_long, e->visit_long_count };
     for (void *p : ptrs) if (p) (void)hipFree(p);
-    for (int k = 0; k < 2; ++k) {
-        if (e->side_stream[k]) { (void)hipStreamSynchronize(e->side_stream[k]); (void)hipStreamDestroy(e->side_stream[k]); }
-        if (e->ev_fork[k]) (void)hipEventDestroy(e->ev_fork[k]);
-        if (e->ev_join[k]) (void)hipEventDestroy(e->ev_join[k]);
-    }
+    if (e->c && e->c->aux_stream) (void)hipStreamSynchronize(e->c->aux_stream);
+    if (e->ev_fork) (void)hipEventDestroy(e->ev_fork);
+    if (e->ev_join) (void)hipEventDestroy(e->ev_join);
     delete h;
 }
 
@@ -1930,11 +1930,10 @@ int hv_ekf_create(hv_ctx *ctx, const hv_ekf_params *par, int batch, hv_ekf **out
     alloc(e->sH, sizeof(double) * e->sH_cap); alloc(e->sv, sizeof(double) * n * batch); alloc(e->sr, sizeof(double) * batch);
     alloc(e->schi2, sizeof(double) * batch); alloc(e->simu, sizeof(double) * 7 * HV_EKF_MAX_PREDICT_SAMPLES * batch);
     alloc(e->sstatus, sizeof(int) * batch); alloc(e->sdrop, sizeof(int) * batch); alloc(e->sactive, batch);
-    alloc(e->err_dev, sizeof(int)); alloc(e->queue_dev, 2 * sizeof(int));
+    alloc(e->err_dev, sizeof(int));
     alloc(e->visit_counts, 4 * sizeof(int) * (Ekf::VISIT_SLOTS + 1)); alloc(e->visit_order, sizeof(int) * (size_t)Ekf::VISIT_SLOTS * batch);
     alloc(e->visit_long, sizeof(int) * (size_t)Ekf::VISIT_SLOTS * batch); alloc(e->visit_long_count, sizeof(int) * Ekf::VISIT_SLOTS); alloc(e->visit_lists, 3 * sizeof(int) * (size_t)batch);
     if (ok && hipMemset(e->err_dev, 0, sizeof(int)) != hipSuccess) ok = false;
-    if (ok && hipMemset(e->queue_dev, 0, 2 * sizeof(int)) != hipSuccess) ok = false;
     if (!ok) { hv_ekf_destroy(h); return HV_ERR_NOMEM; }
 
     // initial state and covariance: EKFImplementation ctor, ekf.cpp:153-296
@@ -2022,6 +2021,18 @@ static int visual_track_dev_impl(hv_ekf *h, const hv_vu_params *p, int np, const
                                  double *chi2_dev, double *pf_dev, int *success_counter_dev, int max_successful,
                                  const int *np_rec_dev = nullptr);
 
+// shapes of a track visit: the longest track the short class's fused two-per-CU kernels serve, whether tracks of np poses take the
+// long-class launches (49 .. 96 rows), and whether a ragged visit of up to np poses runs as TWO length classes
+struct VisitShape { int ncam, np_short, rows; bool long_ok, two_class; };
+static VisitShape visit_shape(const Ekf *e, int np, bool stereo)
+{
+    VisitShape v{};
+    v.ncam = stereo ? 2 : 1; v.np_short = 22 / v.ncam; v.rows = 2 * np * v.ncam;
+    v.long_ok = e->c->knob.ekf_fused_gate != 0 && e->n <= 160 && v.rows > 48 && v.rows <= 96 && v.rows < HV_CHI2INV95_N && (v.rows + 3) / 4 * 2 <= 48;
+    v.two_class = np > v.np_short && v.long_ok && hv::vu_fused_supported(e->c, e->n, v.np_short, stereo, e->batch);
+    return v;
+}
+
 int hv_ekf_visual_track_dev(hv_ekf *h, const hv_vu_params *p, int np, const int *idx, const double *feat, const double *vel,
                             const double *y, double r_gate, double r_update, int *status_dev, int *gate_status_dev,
                             double *chi2_dev, double *pf_dev)
@@ -2033,7 +2044,9 @@ int hv_ekf_visual_track_limited_dev(hv_ekf *h, const hv_vu_params *p, int np, co
                                     const double *y, double r_gate, double r_update, int *status_dev, int *gate_status_dev,
                                     double *chi2_dev, double *pf_dev, int *success_counter_dev, int max_successful)
 {
-    if (!success_counter_dev || max_successful < 1) return HV_ERR_INVALID;
+    if (!success_counter_dev) return HV_ERR_INVALID;
+    // maxSuccessfulVisualUpdates <= 0 is the reference's "no limit" (backend.cpp:1233), as in the frame entry points (r03 advisor)
+    if (max_successful <= 0) max_successful = INT_MAX;
     return visual_track_dev_impl(h, p, np, idx, feat, vel, y, r_gate, r_update, status_dev, gate_status_dev, chi2_dev, pf_dev,
                                  success_counter_dev, max_successful);
 }
@@ -2073,14 +2086,16 @@ static int visual_track_dev_impl(hv_ekf *h, const hv_vu_params *p, int np, const
     a.gate_status = gate_status_dev;                       // preset to NOT_COMPUTED; the gate overwrites it where it runs
     a.success_counter = success_counter_dev; a.max_successful = max_successful;
     const double ns = e->noise_scale;
+    hipStream_t main_stream = c->stream;
     // r03 default: visualTrackOutlierCheck runs INSIDE the prepare launch on the active columns of H (vu_gate kernels: the Jacobian
     // of a rejected track never leaves LDS and only P(a, a) is read); updateVisualTrack then runs where the gate said INLIER, staging the
     // compact Jacobian through its column map (7 of 20 visits at most -- backend.cpp:1233-1238 -- pay the full H P + downdate).
-    // Long tracks (more than 48 rows / 22 camera poses: 12 .. 21 stereo poses): compact Jacobian (vu_compact_kernel), column-sparse gate as
-    // its own launch (ekf_sparse_gate_big_kernel: up to 96 rows) and the update as TWO block updates of at most 48 rows each on the
-    // P-resident kernel (UpdateArgs::half) -- r02 ran them on the H-from-L2 / global-workspace variants at 2 - 4x the time per launch.
-    const int ncam = a.stereo ? 2 : 1, np_short = 22 / ncam < 24 / ncam ? 22 / ncam : 24 / ncam;
-    const bool long_ok = c->knob.ekf_fused_gate != 0 && e->n <= 160 && rows > 48 && rows <= 96 && rows < HV_CHI2INV95_N && (rows + 3) / 4 * 2 <= 48;
+    // Long tracks (more than 48 rows / 22 camera poses: 12 .. 21 stereo poses): prepare + column-sparse gate of up to 96 rows in ONE
+    // launch (r04: vu_gate_long_kernel; r03: vu_compact_kernel + ekf_sparse_gate_big_kernel, kept behind knob ekf_long_fused = 0) and the
+    // update as TWO block updates of at most 48 rows each on the P-resident kernel (UpdateArgs::half).
+    const VisitShape shape = visit_shape(e, np, a.stereo != 0);
+    const int ncam = shape.ncam, np_short = shape.np_short;
+    const bool long_ok = shape.long_ok;
     // compaction lists of this visit (VuPrepareArgs): zeroed here, filled by the kernels, consumed by the launches behind them
     const bool own_counts = e->visit_slot < 0 || e->visit_slot >= Ekf::VISIT_SLOTS;
     int *counts = e->visit_counts + 4 * (own_counts ? Ekf::VISIT_SLOTS : e->visit_slot);
@@ -2089,36 +2104,55 @@ static int visual_track_dev_impl(hv_ekf *h, const hv_vu_params *p, int np, const
     // frame loop with sorted visits (launch_visit_order): the long class's records are known -- longest first -- before the fused launch runs
     const bool presorted = !own_counts && e->visit_order_ok;
     if (presorted) { cnt_long = e->visit_long_count + e->visit_slot; list_long = e->visit_long + (size_t)e->visit_slot * e->batch; }
-    if (own_counts) HV_HIP(c, hipMemsetAsync(counts, 0, 4 * sizeof(int), c->stream));
+    if (own_counts) HV_HIP(c, hipMemsetAsync(counts, 0, 4 * sizeof(int), main_stream));
     // short_upd (ragged two-class visits): issues the short class's update, or only prepares it (non-null argument) so that it shares
     // a grid with the first block update of the long class
     using ShortUpd = std::function<int(hv::UpdateLaunch *)>;
-    // gate_stream (knob ekf_side_stream = 2): the long class's prepare + gate launches run on it, beside the fused launch of the short
-    // class on the context's stream; the updates follow on the context's stream behind a join
-    bool gate_joined = false;
-    auto long_chain = [&](hv::VuPrepareArgs l_, double *Hc, double *vv, int *acol, unsigned char *act, double *dm, bool listed,
-                          const ShortUpd *short_upd = nullptr, hipStream_t gate_stream = nullptr, int stage = 0) -> int {
-        // stage 0: everything; 1: the prepare + gate launches only (the caller joins gate_stream itself); 2: the update launches only
-        l_.fused = 2; l_.H = nullptr; l_.Hc = Hc; l_.v = vv; l_.acol = acol; l_.na_max = 7 * np + 1; l_.active = act; l_.chi2 = chi2_dev;
-        if (listed) { l_.rec_count = cnt_long; l_.rec_list = list_long; }
-        int rc2 = HV_OK;
-        if (stage != 2) {
-            hipStream_t ctx_stream = c->stream;
-            if (gate_stream) c->stream = gate_stream;
-            rc2 = hv::launch_vu_prepare(c, l_);
-            if (rc2 == HV_OK)
-                rc2 = hv::ekf_launch_sparse_gate(e, np, ncam, Hc, vv, acol, nr_rec, act, r_gate * r_gate * ns, chi2_dev, gate_status_dev,
-                                                 listed ? cnt_long : nullptr, listed ? list_long : nullptr, cnt_inl_long, list_inl_long);
-            c->stream = ctx_stream;
-            if (gate_stream && stage == 0) {                   // join (also on an error path: a captured graph must not keep a dangling fork)
-                (void)hipEventRecord(e->ev_join[0], gate_stream);
-                (void)hipStreamWaitEvent(ctx_stream, e->ev_join[0], 0);
-                gate_joined = true;
-            }
+    // buffers of the long class: compact Jacobians, residuals, column lists, active flags, block 1's mean step; the fork / join events
+    auto ensure_long = [&]() -> int {
+        if (!e->ev_fork) {
+            HV_HIP(c, hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming));
+            HV_HIP(c, hipEventCreateWithFlags(&e->ev_join, hipEventDisableTiming));
         }
-        if (rc2 != HV_OK || stage == 1) return rc2;
+        if (e->side_rows < rows) {
+            HV_HIP(c, hipStreamSynchronize(main_stream));
+            HV_HIP(c, hipStreamSynchronize(c->aux_stream));
+            if (e->sideH) (void)hipFree(e->sideH);
+            if (e->sidev) (void)hipFree(e->sidev);
+            e->sideH = e->sidev = nullptr; e->side_rows = 0;
+            HV_HIP(c, hipMalloc(reinterpret_cast<void **>(&e->sideH), sizeof(double) * (size_t)rows * e->n * e->batch));
+            HV_HIP(c, hipMalloc(reinterpret_cast<void **>(&e->sidev), sizeof(double) * (size_t)rows * e->batch));
+            if (!e->side_active) HV_HIP(c, hipMalloc(reinterpret_cast<void **>(&e->side_active), e->batch));
+            if (!e->side_acol) HV_HIP(c, hipMalloc(reinterpret_cast<void **>(&e->side_acol), sizeof(int) * (size_t)e->n * e->batch));
+            if (!e->side_dm) {
+                HV_HIP(c, hipMalloc(reinterpret_cast<void **>(&e->side_dm), sizeof(double) * (size_t)e->n * e->batch));
+                HV_HIP(c, hipMemsetAsync(e->side_dm, 0, sizeof(double) * (size_t)e->n * e->batch, main_stream));   // (r03 advisor: never read uninitialised)
+            }
+            e->side_rows = rows;
+        }
+        return HV_OK;
+    };
+    // prepare + gate of the long class on `stream` (nothing else touches c->stream: r03 swapped the context's stream for these calls)
+    auto long_prepare_gate = [&](hv::VuPrepareArgs l_, double *Hc, double *vv, int *acol, unsigned char *act, bool listed, hipStream_t stream) -> int {
+        l_.H = nullptr; l_.Hc = Hc; l_.v = vv; l_.acol = acol; l_.na_max = 7 * np + 1; l_.active = act; l_.chi2 = chi2_dev;
+        if (listed) { l_.rec_count = cnt_long; l_.rec_list = list_long; }
+        if (c->knob.ekf_long_fused != 0) {
+            l_.fused = 3; l_.P = e->P; l_.rd_gate = r_gate * r_gate * ns; l_.noise_scale = ns;
+            l_.inl_count = cnt_inl_long; l_.inl_list = list_inl_long;
+            return hv::launch_vu_prepare(c, l_, stream);
+        }
+        l_.fused = 2;
+        const int rc2 = hv::launch_vu_prepare(c, l_, stream);
+        if (rc2 != HV_OK) return rc2;
+        return hv::ekf_launch_sparse_gate(e, np, ncam, Hc, vv, acol, nr_rec, act, r_gate * r_gate * ns, chi2_dev, gate_status_dev,
+                                          listed ? cnt_long : nullptr, listed ? list_long : nullptr, cnt_inl_long, list_inl_long, stream);
+    };
+    // the two block updates of the long class's inliers on the context stream; with short_upd the short class's update shares their grids
+    auto long_updates = [&](double *Hc, double *vv, int *acol, unsigned char *act, double *dm, const ShortUpd *short_upd) -> int {
         const int half_rows = 2 * ((rows + 3) / 4);            // the longer of the two blocks of the longest record
-        hv::CompactH h1{acol, l_.na_max, ncam, 1, rows, dm, cnt_inl_long, list_inl_long}, h2{acol, l_.na_max, ncam, 2, rows, dm, cnt_inl_long, list_inl_long};
+        const int na_max = 7 * np + 1;
+        hv::CompactH h1{acol, na_max, ncam, 1, rows, dm, cnt_inl_long, list_inl_long, gate_status_dev}, h2{acol, na_max, ncam, 2, rows, dm, cnt_inl_long, list_inl_long};
+        // (block 1 may turn a record's gate status into CHI2 when it meets a non-positive pivot: block 2 then skips it -- r03 advisor)
         auto block1 = [&](hv::UpdateLaunch *defer) -> int {
             return hv::ekf_launch_update(e, half_rows, e->n, Hc, vv, nullptr, r_update * r_update * ns, 1, 0, -1, nullptr, nullptr, act, gate_status_dev,
                                          nullptr, 0.0, nullptr, 0, 0, nullptr, 0, nullptr, nullptr, nullptr, 0, nr_rec, &h1, rows, defer);
@@ -2127,6 +2161,7 @@ static int visual_track_dev_impl(hv_ekf *h, const hv_vu_params *p, int np, const
             return hv::ekf_launch_update(e, half_rows, e->n, Hc, vv, nullptr, r_update * r_update * ns, 1, 0, 1, nullptr, nullptr, act, gate_status_dev,
                                          success_counter_dev, 0.0, nullptr, 0, 0, nullptr, 0, nullptr, nullptr, nullptr, 0, nr_rec, &h2, rows, defer);
         };
+        int rc2 = HV_OK;
         if (short_upd) {
             // (short class beside block 1, what did not fit on the chip beside block 2: see ekf_update_dual_kernel)
             hv::UpdateLaunch us, u1, u2;
@@ -2141,107 +2176,65 @@ static int visual_track_dev_impl(hv_ekf *h, const hv_vu_params *p, int np, const
         if (rc2 != HV_OK) return rc2;
         return block2(nullptr);
     };
-    auto ensure_side = [&]() -> int {                          // second stream + buffers of the long-track chain
-        if (!e->side_stream[0]) {
-            HV_HIP(c, hipStreamCreateWithFlags(&e->side_stream[0], hipStreamNonBlocking));
-            HV_HIP(c, hipEventCreateWithFlags(&e->ev_fork[0], hipEventDisableTiming));
-            HV_HIP(c, hipEventCreateWithFlags(&e->ev_join[0], hipEventDisableTiming));
-        }
-        if (e->side_rows[0] < rows) {
-            HV_HIP(c, hipStreamSynchronize(c->stream));
-            HV_HIP(c, hipStreamSynchronize(e->side_stream[0]));
-            if (e->sideH[0]) (void)hipFree(e->sideH[0]);
-            if (e->sidev[0]) (void)hipFree(e->sidev[0]);
-            e->sideH[0] = e->sidev[0] = nullptr; e->side_rows[0] = 0;
-            HV_HIP(c, hipMalloc(reinterpret_cast<void **>(&e->sideH[0]), sizeof(double) * (size_t)rows * e->n * e->batch));
-            HV_HIP(c, hipMalloc(reinterpret_cast<void **>(&e->sidev[0]), sizeof(double) * (size_t)rows * e->batch));
-            if (!e->side_active[0]) HV_HIP(c, hipMalloc(reinterpret_cast<void **>(&e->side_active[0]), e->batch));
-            if (!e->side_acol) HV_HIP(c, hipMalloc(reinterpret_cast<void **>(&e->side_acol), sizeof(int) * (size_t)e->n * e->batch));
-            if (!e->side_dm) HV_HIP(c, hipMalloc(reinterpret_cast<void **>(&e->side_dm), sizeof(double) * (size_t)e->n * e->batch));
-            e->side_rows[0] = rows;
-        }
-        return HV_OK;
-    };
     // Ragged batch with long AND short tracks: two length CLASSES per visit. The short tracks -- 4 of 5 at the reference's defaults, see
-    // bench.py sample_track_lengths -- run on the fused two-per-CU kernels, the long ones through the chain above; the records of a visit
+    // bench.py sample_track_lengths -- run on the fused two-per-CU kernels, the long ones through the launches above; the records of a visit
     // belong to different filters, so the two launch sequences are independent up to the shared update grids. Every launch skips the
     // other class's records (VuPrepareArgs::np_lo / np_hi, `active`). Schedule of a visit inside a frame loop over more filters than CUs
-    // (knob ekf_side_stream 3, default; HIP-graph capturable: fork at the start of the visit, join in front of the updates):
-    //     second stream:   compact prepare (long) -> big sparse gate (long)        -- enqueued FIRST: they take their CUs while all are free
-    //     context stream:  fused prepare + gate (short)  | join |  short update + long block 1  ->  rest of short + long block 2
-    // Stand-alone visits and small batches: everything on the context's stream, short class first.
-    if (np_rec_dev && np > np_short && long_ok && hv::vu_fused_supported(c, e->n, np_short, a.stereo, e->batch)) {
-        rc = ensure_side();
+    // (knob ekf_side_stream != 0, default; HIP-graph capturable: fork at the start of the visit, join in front of the updates):
+    //     second stream (Ctx::aux_stream):  prepare + gate (long)              -- enqueued FIRST: it takes its CUs while all are free
+    //     context stream:                   fused prepare + gate (short)  | join |  short update + long block 1  ->  rest of short + long block 2
+    // Stand-alone visits and small batches: everything on the context's stream, short class first (its launch collects the long list).
+    // (r03 also had the whole long chain on the second stream -- knob values 1 and 4 -- and the long class enqueued BEHIND the fused
+    //  launch -- 2: all measured slower, removed in r04 together with the stream swap they needed.)
+    if (np_rec_dev && shape.two_class) {
+        rc = ensure_long();
         if (rc != HV_OK) return rc;
-        // knob ekf_side_stream = 1: the long chain on a second stream next to the short one. Measured (r03, 1024 filters, rocprofv3
-        // kernel trace): the two sequences do NOT overlap usefully -- every kernel of the long chain needs a whole CU's LDS, the short
-        // chain's fused kernel fills all of it (2 x 80 KB), so their workgroups queue for each other's CUs and a visit took 700 - 900 us
-        // against ~550 us back to back.
-        const bool fork = c->knob.ekf_side_stream == 1;
-        // knob ekf_side_stream = 2 (needs the sorted visits of a frame loop): only the long class's prepare + gate launches leave the
-        // stream -- they read what the fused launch reads and write their own buffers
-        const bool fork_gate = (c->knob.ekf_side_stream == 2 || c->knob.ekf_side_stream == 3) && presorted;
-        const bool gate_first = c->knob.ekf_side_stream == 3;  // (3: the long class's launches are enqueued BEFORE the fused launch)
-        // 4: the WHOLE long chain (prepare, gate, both block updates) on the second stream, enqueued first; the short class's fused launch
-        // and its update follow on the context's stream (no shared update grid)
-        const bool chain_first = c->knob.ekf_side_stream == 4 && presorted;
-        hipStream_t main_stream = c->stream;
-        if (fork || fork_gate || chain_first) {
-            HV_HIP(c, hipEventRecord(e->ev_fork[0], main_stream));
-            HV_HIP(c, hipStreamWaitEvent(e->side_stream[0], e->ev_fork[0], 0));
-        }
+        const bool use_aux = c->knob.ekf_side_stream != 0 && presorted && c->aux_stream;
         hv::VuPrepareArgs s_ = a;                              // class "short": 2 .. np_short poses (and the records without a track)
         s_.np_lo = 2; s_.np_hi = np_short; s_.class_inactive = 1;
         s_.fused = 1; s_.H = nullptr; s_.Hc = e->vuH; s_.acol = e->vuacol; s_.na_max = 7 * np + 1; s_.P = e->P;
         s_.rd_gate = r_gate * r_gate * ns; s_.noise_scale = ns; s_.chi2 = chi2_dev;
         s_.inl_count = cnt_inl; s_.inl_list = list_inl;
         if (!presorted) { s_.long_count = cnt_long; s_.long_list = list_long; }      // (else nothing to collect)
-        if (!own_counts && e->visit_order_ok) s_.order = e->visit_order + (size_t)e->visit_slot * e->batch;     // (frame loop: sorted once per frame)
+        if (presorted) s_.order = e->visit_order + (size_t)e->visit_slot * e->batch;     // (frame loop: sorted once per frame)
         hv::VuPrepareArgs l_ = a;
-        l_.np_lo = np_short + 1; l_.np_hi = np; l_.class_inactive = 1; l_.persistent = c->knob.ekf_persistent == 1 ? 1 : 0; l_.queue = e->queue_dev;
+        l_.np_lo = np_short + 1; l_.np_hi = np; l_.class_inactive = 1;
+        // fork ... join: every exit between the two goes through the join (a HIP-graph capture must not be left with a dangling fork)
+        bool forked = false;
+        if (use_aux) {
+            hipError_t he = hipEventRecord(e->ev_fork, main_stream);
+            if (he == hipSuccess) he = hipStreamWaitEvent(c->aux_stream, e->ev_fork, 0);
+            if (he != hipSuccess) return hv::hip_fail(c, he, "fork onto the second stream");
+            forked = true;
+        }
         rc = HV_OK;
-        if (fork_gate && gate_first) rc = long_chain(l_, e->sideH[0], e->sidev[0], e->side_acol, e->side_active[0], e->side_dm, true, nullptr, e->side_stream[0], 1);
-        if (chain_first) {
-            c->stream = e->side_stream[0];
-            rc = long_chain(l_, e->sideH[0], e->sidev[0], e->side_acol, e->side_active[0], e->side_dm, true);
-            c->stream = main_stream;
+        if (presorted) rc = long_prepare_gate(l_, e->sideH, e->sidev, e->side_acol, e->side_active, true, forked ? c->aux_stream : main_stream);
+        if (rc == HV_OK) rc = hv::launch_vu_prepare(c, s_, main_stream);
+        if (rc == HV_OK && !presorted) rc = long_prepare_gate(l_, e->sideH, e->sidev, e->side_acol, e->side_active, true, main_stream);
+        if (forked) {
+            hipError_t he = hipEventRecord(e->ev_join, c->aux_stream);
+            if (he == hipSuccess) he = hipStreamWaitEvent(main_stream, e->ev_join, 0);
+            if (he != hipSuccess && rc == HV_OK) rc = hv::hip_fail(c, he, "join of the second stream");
         }
-        if (rc == HV_OK) rc = hv::launch_vu_prepare(c, s_);
-        if (fork && !presorted) {                              // (the long class's list is collected by the fused launch: the second stream waits for it)
-            HV_HIP(c, hipEventRecord(e->ev_fork[0], main_stream));
-            HV_HIP(c, hipStreamWaitEvent(e->side_stream[0], e->ev_fork[0], 0));
-        }
-        if (fork_gate && gate_first) {
-            (void)hipEventRecord(e->ev_join[0], e->side_stream[0]);
-            (void)hipStreamWaitEvent(main_stream, e->ev_join[0], 0);
-            gate_joined = true;
-        }
+        if (rc != HV_OK) return rc;
         const hv::CompactH ch{e->vuacol, s_.na_max, ncam, 0, 0, nullptr, cnt_inl, list_inl};
         const ShortUpd short_upd = [&](hv::UpdateLaunch *defer) -> int {
             return hv::ekf_launch_update(e, 2 * np_short * ncam, e->n, e->vuH, e->vuv, nullptr, r_update * r_update * ns, 1, 0, 1, nullptr, nullptr,
                                          e->vuactive, gate_status_dev, success_counter_dev, 0.0, nullptr, 0, 0, nullptr, 0, nullptr, nullptr,
                                          nullptr, 0, nr_rec, &ch, rows, defer);
         };
-        // knob ekf_dual_update (default 1): the short class's update waits for the long class's prepare + gate launches and then shares
-        // a grid with the first block update of the long class (the two serve different filters)
-        const bool pair = c->knob.ekf_dual_update != 0 && !fork && !chain_first;
-        if (rc == HV_OK && !pair) rc = short_upd(nullptr);
-        if (rc == HV_OK && !chain_first) {
-            if (fork) c->stream = e->side_stream[0];
-            rc = long_chain(l_, e->sideH[0], e->sidev[0], e->side_acol, e->side_active[0], e->side_dm, true, pair ? &short_upd : nullptr,
-                            fork_gate && !gate_first ? e->side_stream[0] : nullptr, fork_gate && gate_first ? 2 : 0);
-            c->stream = main_stream;
-        }
-        if (fork || chain_first || (fork_gate && !gate_joined)) {
-            (void)hipEventRecord(e->ev_join[0], e->side_stream[0]);  // join (also on an error path: a captured graph must not keep a dangling fork)
-            (void)hipStreamWaitEvent(main_stream, e->ev_join[0], 0);
-        }
-        return rc;
+        // knob ekf_dual_update (default 1): the short class's update shares a grid with the first block update of the long class (the two
+        // serve different filters)
+        const bool pair = c->knob.ekf_dual_update != 0;
+        if (!pair) { rc = short_upd(nullptr); if (rc != HV_OK) return rc; }
+        return long_updates(e->sideH, e->sidev, e->side_acol, e->side_active, e->side_dm, pair ? &short_upd : nullptr);
     }
     if (long_ok && np > np_short) {                            // every record of the launch may be long (uniform 12 .. 21 stereo poses, or ragged)
-        rc = ensure_side();
+        rc = ensure_long();
         if (rc != HV_OK) return rc;
-        return long_chain(a, e->vuH, e->vuv, e->vuacol, e->vuactive, e->side_dm, false);
+        rc = long_prepare_gate(a, e->vuH, e->vuv, e->vuacol, e->vuactive, false, main_stream);
+        if (rc != HV_OK) return rc;
+        return long_updates(e->vuH, e->vuv, e->vuacol, e->vuactive, e->side_dm, nullptr);
     }
     if (hv::vu_fused_supported(c, e->n, np, a.stereo, e->batch)) {
         // knob ekf_fused_gate: -1 auto / 1 = the gate inside the prepare launch (vu_gate kernels); 2 = its own launch (vu_compact kernels +
@@ -2295,6 +2288,7 @@ static int visual_track_dev_impl(hv_ekf *h, const hv_vu_params *p, int np, const
                                  nullptr, e->vuactive, gate_status_dev, success_counter_dev, 0.0, nullptr, 0, 0, nullptr, 0, nullptr, nullptr,
                                  nullptr, 0, nr_rec);
 }
+
 
 static int visual_frame_dev_impl(hv_ekf *h, const hv_vu_params *p, int n_tracks, int np, const int *np_rec_dev, const int *idx,
                                  const double *feat, const double *vel,
@@ -2402,9 +2396,10 @@ static int visual_frame_dev_impl(hv_ekf *h, const hv_vu_params *p, int n_tracks,
     // (many filters only: below one workgroup per CU nothing queues, and the sort, the fork and the join are pure launch overhead --
     //  a single sequence went from 1.14 to 1.51 ms per frame with them)
     if (p && np_rec_dev && c->knob.ekf_visit_order != 0 && n_tracks >= 1 && n_tracks <= Ekf::VISIT_SLOTS && (B > (size_t)c->num_cus || c->knob.ekf_visit_order == 2)) {
-        const int ncam_ = p->useStereo ? 2 : 1, np_short_ = 22 / ncam_;
-        if (np > np_short_) {
-            const int rc = hv::launch_visit_order(c, n_tracks, B, np_rec_dev, 2, np_short_, np, e->visit_order, e->visit_long, e->visit_long_count);
+        // (only where the visits really run as two length classes: 12 stereo poses = 48 rows still ride the short class -- r03 advisor)
+        const VisitShape shape = visit_shape(e, np, p->useStereo != 0);
+        if (shape.two_class) {
+            const int rc = hv::launch_visit_order(c, n_tracks, B, np_rec_dev, 2, shape.np_short, np, e->visit_order, e->visit_long, e->visit_long_count);
             if (rc != HV_OK) return rc;
             e->visit_order_ok = true;
         }

@@ -66,8 +66,8 @@ struct Knobs {
     int ingest_gather = 0;        // HV_INGEST_GATHER: 1 = plain gather kernel for the remap
     int ekf_fused_gate = -1;      // HV_EKF_FUSED_GATE: column-sparse chi2 gate: -1 auto = 1 inside the prepare kernel, 2 own launch (ekf_sparse_gate_kernel), 0 off (dense kernels)
     int ekf_spec_mode = -1;       // HV_EKF_SPEC_MODE: speculative pass form: -1 auto, 2 = gate launch + apply launch, 3 = one launch with hand-shake
-    int ekf_persistent = 0;       // HV_EKF_PERSISTENT: 1 = the masked one-workgroup-per-CU launches run as num_cus workgroups pulling records from a device queue instead of using the compaction lists: the long class's prepare and gate launches only (experiment; the update kernel lost its register allocation inside such a loop, r03)
-    int ekf_side_stream = 3;      // HV_EKF_SIDE_STREAM, ragged visits with two length classes: 0 = one stream; 1 = the whole long-track chain on a second stream (measured slower: its update launches and the short class's fight for whole CUs); 2 / 3 = only the long class's prepare + gate launches on the second stream, enqueued behind (2) / in front of (3, default: +6 % on the realistic C3 step) the short class's fused launch; 4 = the whole long chain on the second stream, enqueued first (no better than 3) -- 2 .. 4: frame loops only (they need the per-frame sort of launch_visit_order)
+    int ekf_side_stream = 3;      // HV_EKF_SIDE_STREAM, ragged visits with two length classes: 0 = one stream; non-zero (default 3, r03's numbering) = the long class's prepare + gate launch on the context's second stream, enqueued in front of the short class's fused launch (+6 % on the realistic C3 step); frame loops only (needs the per-frame sort of launch_visit_order). r03's other forms (1, 2, 4: whole long chain on the second stream / enqueued behind) measured slower and were removed in r04
+    int ekf_long_fused = 1;       // HV_EKF_LONG_FUSED: 1 (r04 default) = prepare + column-sparse gate of the long class (49 .. 84 rows) in ONE launch (vu_gate_long_kernel); 0 = r03's vu_compact_kernel + ekf_sparse_gate_big_kernel
     int ekf_dual_update = 1;      // HV_EKF_DUAL_UPDATE: 1 = ragged visits issue the short class's update and the long class's first block update as one grid (ekf_update_dual_kernel); 0 = one after the other
     int ekf_visit_order = 1;      // HV_EKF_VISIT_ORDER: 1 = ragged frame loops over more filters than the GPU has CUs hand the fused kernel its records longest track first (one sort launch per frame; the presorted long-class lists also enable ekf_side_stream 2 .. 4); 2 = at every batch size (tests); 0 = in filter order
     int rot_ransac_threads = 0;   // HV_ROT_RANSAC_THREADS: 0 auto (1024 threads up to 64 sets), 256 / 1024 force
@@ -82,7 +82,12 @@ struct Ctx {
     PyrLayout L{};
     hipStream_t stream = nullptr;
     bool own_stream = false;
-    int num_cus = 256;                    // multiProcessorCount of the device (grid of the persistent launches)
+    // second stream of the context, library-owned, created WITH the context (r04; r03 created it lazily inside the first ragged visit,
+    // so which hardware queue it landed on depended on what the process had done by then): the long-track class of a ragged visit
+    // runs its prepare + gate launches on it beside the short class's launch on `stream` (ekf.hip), joined again inside the visit
+    hipStream_t aux_stream = nullptr;
+    int stream_priority = 0;              // 0: default priority; 1: both streams from the device's HIGH-priority queue pool (hv_lanes_create)
+    int num_cus = 256;                    // multiProcessorCount of the device
     uint8_t *slab = nullptr;              // pool_size * slot_bytes
     const uint8_t **d_l0_ptr = nullptr;   // [pool_size]
     int *d_l0_stride = nullptr;           // [pool_size]
@@ -120,8 +125,8 @@ Ctx *ctx_of(hv_ctx *h);
 
 // RAII-ish per-launch timing helper (no-op unless profiling is on).
 struct ScopedKernelTime {
-    Ctx *c; int id; hipEvent_t a = nullptr, b = nullptr;
-    ScopedKernelTime(Ctx *c, int id);
+    Ctx *c; int id; hipEvent_t a = nullptr, b = nullptr; hipStream_t s = nullptr;
+    ScopedKernelTime(Ctx *c, int id, hipStream_t stream = nullptr);   // stream: the one the kernel is launched on (null = the context's)
     ~ScopedKernelTime();
 };
 
@@ -157,9 +162,6 @@ struct VuPrepareArgs {
     int *long_count, *long_list;       // appended by the short class's launch: records of the long class (-> its prepare / gate launches)
     const int *rec_count, *rec_list;   // this launch's own records (long-class prepare): workgroup i handles rec_list[i], i < *rec_count
     const int *order;                  // fused two-per-CU launches: workgroup i serves filter order[i] (a permutation of the batch, longest tracks first: launch_visit_order), or null
-    int persistent;                    // one workgroup per CU pulls records from a device queue (launches that skip most records: the long class of a ragged visit)
-    int *queue;                        // persistent launches: {next record, finished workgroups}, zero between launches (the last workgroup resets it)
-    int q_off;                         // byte offset of the queue slot inside the dynamic LDS (behind everything the body uses)
     double *H, *v, *f, *pf;            // [batch][rows * n] column-major, [batch][rows], optional [batch][rows], [batch][3]
     int *status;                       // [batch][2]: TriangulatorStatus, PrepareVuStatus
     unsigned char *active;             // optional [batch]: 1 where both are OK
@@ -183,7 +185,7 @@ struct VuPrepareArgs {
     double rd_gate, noise_scale;       // R = rd_gate I (already scaled by noiseScale), chi2 = noise_scale z'z
     double *chi2;                      // optional [records]
 };
-int launch_vu_prepare(Ctx *c, const VuPrepareArgs &a);
+int launch_vu_prepare(Ctx *c, const VuPrepareArgs &a, hipStream_t stream = nullptr);   // stream: null = the context's
 // order[v][0 .. batch): the filters of visit v sorted by descending pose count among those with np_lo <= np_rec <= np_hi (the others last);
 // long_list[v][0 .. long_count[v]) (optional): those with np_hi < np_rec <= np_max, longest first
 int launch_visit_order(Ctx *c, int visits, int batch, const int *np_rec_dev, int np_lo, int np_hi, int np_max, int *order_dev,
@@ -206,28 +208,6 @@ __device__ __forceinline__ unsigned xcd_remap(unsigned bid, unsigned nwg)
     const unsigned base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
     return base + idx;
 }
-
-// Work queue of a persistent launch: workgroups pull record numbers until the batch is exhausted; the last workgroup to leave puts the
-// two counters back to zero, so the next launch on the stream (kernels of one stream do not overlap) finds them clean -- no host-side
-// reset, HIP-graph replay safe. Dynamic on purpose: a static split (record b to workgroup b % grid) left some CUs with three long records
-// and others with none (r03: 33.8 against 20.1 ms per step).
-#define HV_QUEUE_LOOP(queue, batch, slot, body_call)   /* slot: an int in LDS outside what the body uses (the kernels' dynamic LDS may be the whole 160 KB, so a static variable is out) */ \
-    do {                                                                                              \
-        volatile int *hv_q_next = (slot);                                                             \
-        for (;;) {                                                                                    \
-            if (threadIdx.x == 0) *hv_q_next = atomicAdd(&(queue)[0], 1);                             \
-            __syncthreads();                                                                          \
-            const int b_ = *hv_q_next;                                                                \
-            __syncthreads();                                                                          \
-            if (b_ >= (batch)) break;                                                                 \
-            body_call;                                                                                \
-            __syncthreads();                                                                          \
-        }                                                                                             \
-        if (threadIdx.x == 0) {                                                                       \
-            __threadfence();                                                                          \
-            if (atomicAdd(&(queue)[1], 1) == (int)gridDim.x - 1) { (queue)[0] = 0; (queue)[1] = 0; __threadfence(); }   \
-        }                                                                                             \
-    } while (0)
 
 __device__ __forceinline__ int reflect101(int p, int len)
 {

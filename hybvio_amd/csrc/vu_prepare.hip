@@ -204,19 +204,28 @@ __device__ __forceinline__ void pose_motion(const double *trail, const double *R
 }
 
 // LDS layout of the kernel in doubles, for MAXP camera poses
-template <int MAXP>
+// LONG (the fused prepare + gate of the long class, FUSED = 3): the gate of a 49 .. 84-row track needs more room than the Gauss-Newton
+// arrays leave in the FUSED = 1 carve -- [S; v'] up to 86 x 84 and the staged compact Jacobian up to 148 x 84 doubles (21 stereo poses,
+// the TIGHT layout of sparse_gate). Everything the Jacobian is built FROM (pose records, dpf, dpfi, features, indices) lies below P0,
+// so the staged Hc goes to [LONG_T, LONG_T + LONG_HS) -- over the dead motion / linear-map arrays -- while it is built, [S; v'] to
+// [0, LONG_T) once the build is done, and the index arrays move behind both: 158.6 KB of the CU's 160.
+template <int MAXP, bool LONG = false>
 struct VuLds {
     static constexpr int MAXC = MAXP * 7 + 1, MOT_STRIDE = 13;
     static constexpr int MAXPAIRS = 14 * MAXP - 7;            // motion pairs: 7 nt with a pose-0 column + 7 (nt - 1) with the pose's own column
+    static constexpr int LONG_T = 7224, LONG_HS = 12432;      // doubles: (84 + 2) x 84, 148 x 84
     static constexpr int TRAIL = 0, IT = TRAIL + MAXP * POSE_WORDS, DPFI = IT + MAXP * ITER_WORDS, FEAT = DPFI + 3 * MAXC,
                          SMALL = FEAT + MAXP * 4, DPF = SMALL + 64, P0 = DPF + MAXNP * 21, MOT = P0 + 7 * MAXP * 9 + 7 * 9,
-                         OWN = MOT + MAXPAIRS * MOT_STRIDE, LIN = OWN + MAXC * 9, INTS = LIN + 3 * MAXP * 9 + 32,
+                         OWN = MOT + MAXPAIRS * MOT_STRIDE, LIN = OWN + MAXC * 9, LIN_END = LIN + 3 * MAXP * 9 + 32,
+                         INTS = (LONG && LONG_T + LONG_HS > LIN_END) ? LONG_T + LONG_HS : LIN_END,
                          TOTAL = INTS + (MAXNP + 3 + 4 + MAXC + 1) / 2 + 1;       // s_idx, s_flag, s_acol (fused gate)
-    // fused gate (FUSED builds): once H exists the Gauss-Newton work arrays are dead -- the compact Jacobian is staged in [P0, INTS),
+    static_assert(!LONG || P0 <= LONG_T, "the sources of the compact Jacobian must lie below the staged copy");
+    // fused gate (FUSED = 1 builds): once H exists the Gauss-Newton work arrays are dead -- the compact Jacobian is staged in [P0, INTS),
     // the (rows + 1) x rows matrix [S; v'] in [0, P0)
     static constexpr int HS_DOUBLES = INTS - P0, T_DOUBLES = P0;
     static constexpr size_t BYTES = sizeof(double) * TOTAL;
 };
+static_assert(VuLds<42, true>::BYTES <= 160 * 1024, "the long build must fit one CU's LDS");
 
 // MAXP (camera poses the LDS arrays are sized for) is a template parameter next to VT: <768, 42> holds every track (151 KB of LDS,
 // one workgroup per CU); <384, 22> holds the common sizes in 75 KB and 6 waves of 138 VGPRs, so TWO filters share a CU and one's
@@ -224,14 +233,16 @@ struct VuLds {
 // overlap the other's.
 // FUSED (VuPrepareArgs::fused): 0 = the dense H of the public prepare entry point; 1 = compact Jacobian + the chi2 gate in this kernel
 // (ekf_device.hpp sparse_gate; few filters: one launch per visit / speculative pass); 2 = compact Jacobian only, the gate follows as
-// ekf_sparse_gate_kernel (many filters: three small workgroups per CU hide its Cholesky chain, which two of these cannot). In 1 and 2
-// the dense H is never written, only Hc / acol / v.
+// ekf_sparse_gate_kernel (many filters: three small workgroups per CU hide its Cholesky chain, which two of these cannot); 3 = like 1
+// for the LONG class (49 .. 84 rows, VuLds<.., true>, the 4- to 6-tile instantiations of sparse_gate; r04 -- r03 ran 2 + the big gate
+// kernel: two launches and a round trip of Hc through HBM on the critical path of every visit). In 1 .. 3 the dense H is never
+// written, only Hc / acol / v.
 template <int VT, int MAXP, int FUSED>
 __device__ __forceinline__ void vu_prepare_body(const VuPrepareArgs &a, const int bx /* filter: blockIdx.x, or the loop variable of a persistent launch */)
 {
     // All LDS comes from the dynamic region (carved below): with static arrays the compiler derives the occupancy from their size
     // and stops honouring the register cap that lets two of the small workgroups share a CU.
-    using Lay = VuLds<MAXP>;
+    using Lay = VuLds<MAXP, FUSED == 3>;
     constexpr int MOT_STRIDE = Lay::MOT_STRIDE;
     extern __shared__ __attribute__((aligned(16))) double vu_lds[];
     double *s_trail = vu_lds + Lay::TRAIL;       // [MAXP][POSE_WORDS]
@@ -811,8 +822,19 @@ __device__ __forceinline__ void vu_prepare_body(const VuPrepareArgs &a, const in
 #pragma unroll
             for (int k = 0; k < 3; ++k) a.pf[3 * rec + k] = pf_out[k];
         }
-        const int na = 7 * n + 1, na4 = (na + 3) & ~3, ti = (rows + 15) >> 4, nrp = 16 * ti;
-        double *Hs = vu_lds + Lay::P0;
+        constexpr bool STAGED = FUSED == 1 || FUSED == 3;         // the compact Jacobian is also staged in LDS for the gate of this launch
+        const int na = 7 * n + 1, na4 = (na + 3) & ~3, ti = FUSED == 3 ? max((rows + 15) >> 4, 4) : (rows + 15) >> 4;
+        int Rs = rows + 1;                                        // column stride of [S; v']: 15 or 17 mod 32 doubles (bank spread)
+        while ((Rs & 31) != 15 && (Rs & 31) != 17) Rs++;
+        // long build: the padded layout (16 ti rows per staged column) where it fits the carve, else sparse_gate's TIGHT one (84 rows per
+        // column, odd stride of [S; v']) -- 21 stereo poses
+        bool tight = false;
+        if constexpr (FUSED == 3) {
+            tight = na4 * 16 * ti > Lay::LONG_HS || Rs * rows > Lay::LONG_T;
+            if (tight) Rs = rows + 1 + (((rows + 1) & 1) ? 0 : 1);
+        }
+        const int nrp = tight ? HV_GATE_TIGHT_ROWS : 16 * ti;
+        double *Hs = vu_lds + (FUSED == 3 ? Lay::LONG_T : Lay::P0);
         int *s_acol = s_flag + 4;
         if (tid < na) {                                           // compact column u -> state column: pose q's position / orientation, then SFT
             int col = SFT;
@@ -829,7 +851,7 @@ __device__ __forceinline__ void vu_prepare_body(const VuPrepareArgs &a, const in
         // work item = (compact column u < na4, row pair i < nrp / 2), i fastest: every element of the staged Hs is written exactly once
         // (zero padding in rows >= 2 nt and columns >= na), the real ones also go to HBM for the update of an inlier
         // (compact-only builds have no LDS copy to pad: their items are the real (column, pose) pairs)
-        const int wi = FUSED == 1 ? nrp >> 1 : nt, n_items = (FUSED == 1 ? na4 : na) * wi;
+        const int wi = STAGED ? nrp >> 1 : nt, n_items = (STAGED ? na4 : na) * wi;
         const unsigned inv_wi = (unsigned)((0x100000000ull + (unsigned)wi - 1) / (unsigned)wi);   // w / wi = umulhi(w, ceil(2^32 / wi))
         for (int w = tid; w < n_items; w += VT) {
             const int u = (int)__umulhi((unsigned)w, inv_wi), i = w - u * wi;
@@ -852,7 +874,7 @@ __device__ __forceinline__ void vu_prepare_body(const VuPrepareArgs &a, const in
                 }
                 *reinterpret_cast<double2 *>(Hc + (size_t)u * rows + 2 * i) = double2{h0, h1};
             }
-            if constexpr (FUSED == 1) *reinterpret_cast<double2 *>(Hs + (size_t)u * nrp + 2 * i) = double2{h0, h1};
+            if constexpr (STAGED) *reinterpret_cast<double2 *>(Hs + (size_t)u * nrp + 2 * i) = double2{h0, h1};
         }
         double vres[2] = {0.0, 0.0};
         if (tid < nt) {
@@ -875,17 +897,27 @@ __device__ __forceinline__ void vu_prepare_body(const VuPrepareArgs &a, const in
         __syncthreads();                                          // everything but Hs / s_acol is dead from here on
         VU_STAMP(31);
         double *T = vu_lds;
-        int Rs = rows + 1;
-        while ((Rs & 31) != 15 && (Rs & 31) != 17) Rs++;
+        if constexpr (FUSED == 3) {
+            if (tight && (ti != 6 || rows > HV_GATE_TIGHT_ROWS)) {     // (cannot happen: the launcher admits <= 21 stereo poses) not gated, never applied
+                if (tid == 0 && a.gate_status) a.gate_status[rec] = 1;
+                return;
+            }
+        }
         for (int i = tid; i < Rs * rows; i += VT) T[i] = 0.0;
         __syncthreads();
         if (tid < nt) { T[(size_t)(2 * tid) * Rs + rows] = vres[0]; T[(size_t)(2 * tid + 1) * Rs + rows] = vres[1]; }
         VU_STAMP(32);
         const double *Pb = a.P + (size_t)b * N * N;
         double chi;
-        if (ti == 1)      chi = sparse_gate<1, VT, false>(Pb, N, s_acol, na, Hs, T, Rs, rows, a.rd_gate, a.noise_scale, Hs, g_vu_stamp + 33);
-        else if (ti == 2) chi = sparse_gate<2, VT, false>(Pb, N, s_acol, na, Hs, T, Rs, rows, a.rd_gate, a.noise_scale, Hs, g_vu_stamp + 33);
-        else              chi = sparse_gate<3, VT, false>(Pb, N, s_acol, na, Hs, T, Rs, rows, a.rd_gate, a.noise_scale, Hs, g_vu_stamp + 33);
+        if constexpr (FUSED == 3) {
+            if (ti <= 4)      chi = sparse_gate<4, VT, false>(Pb, N, s_acol, na, Hs, T, Rs, rows, a.rd_gate, a.noise_scale, Hs, g_vu_stamp + 33);
+            else if (ti == 5) chi = sparse_gate<5, VT, false>(Pb, N, s_acol, na, Hs, T, Rs, rows, a.rd_gate, a.noise_scale, Hs, g_vu_stamp + 33);
+            else              chi = sparse_gate<6, VT, false, true>(Pb, N, s_acol, na, Hs, T, Rs, rows, a.rd_gate, a.noise_scale, Hs, g_vu_stamp + 33);
+        } else {
+            if (ti == 1)      chi = sparse_gate<1, VT, false>(Pb, N, s_acol, na, Hs, T, Rs, rows, a.rd_gate, a.noise_scale, Hs, g_vu_stamp + 33);
+            else if (ti == 2) chi = sparse_gate<2, VT, false>(Pb, N, s_acol, na, Hs, T, Rs, rows, a.rd_gate, a.noise_scale, Hs, g_vu_stamp + 33);
+            else              chi = sparse_gate<3, VT, false>(Pb, N, s_acol, na, Hs, T, Rs, rows, a.rd_gate, a.noise_scale, Hs, g_vu_stamp + 33);
+        }
         if (tid == 0) {
             const bool broken = !(chi < 1e300);                   // non-positive pivot: reported as CHI2 (ekf_update_kernel phase D)
             const int outlier = broken || ((rows < HV_CHI2INV95_N) ? (chi > d_chi2inv95[rows]) : 0);
@@ -1002,15 +1034,22 @@ __global__ __launch_bounds__(1024) void visit_order_kernel(const int *np_rec, in
         if (long_list && kl > 0) long_list[atomicAdd(&start[1][kl], 1)] = i;
     }
 }
+// the long class of a ragged visit: compact Jacobian + the 4- to 6-tile column-sparse gate in one launch (FUSED = 3), listed like vu_compact_kernel
+__global__ __launch_bounds__(VT_LATENCY, 3) void vu_gate_long_kernel(VuPrepareArgs a)
+{
+    int b = blockIdx.x;
+    if (a.rec_list) { if (b >= *a.rec_count) return; b = a.rec_list[b]; }
+    vu_prepare_body<VT_LATENCY, MAXP_ALL, 3>(a, b);
+}
 // ... and with the compact Jacobian only (the gate runs as its own launch)
 __global__ __launch_bounds__(VT_LATENCY, 3) void vu_compact_kernel(VuPrepareArgs a)
 {
-    // persistent form (one workgroup per CU walks the batch): the launches that serve one length class of a ragged visit -- most of their
-    // records belong to the other class, and a 150 KB workgroup that only finds that out occupies a whole CU's LDS slot for it
-    extern __shared__ __attribute__((aligned(16))) double vu_lds[];
-    if (a.persistent) HV_QUEUE_LOOP(a.queue, a.batch, reinterpret_cast<int *>(reinterpret_cast<char *>(vu_lds) + a.q_off), (vu_prepare_body<VT_LATENCY, MAXP_ALL, 2>(a, b_)));
-    else if (a.rec_list) { if ((int)blockIdx.x < *a.rec_count) vu_prepare_body<VT_LATENCY, MAXP_ALL, 2>(a, a.rec_list[blockIdx.x]); }
-    else vu_prepare_body<VT_LATENCY, MAXP_ALL, 2>(a, blockIdx.x);
+    // listed launches (the long class of a ragged visit): workgroup i serves rec_list[i]; the workgroups beyond the list leave at once.
+    // ONE instantiation of the body: r03 kept a queue-persistent copy and a listed copy beside the plain one, and the kernel spilled
+    // 45 VGPRs (236 B of scratch per lane) at its 168-register cap
+    int b = blockIdx.x;
+    if (a.rec_list) { if (b >= *a.rec_count) return; b = a.rec_list[b]; }
+    vu_prepare_body<VT_LATENCY, MAXP_ALL, 2>(a, b);
 }
 __global__ __launch_bounds__(VT_THROUGHPUT, 4) void vu_compact_kernel_2percu(VuPrepareArgs a)
 {
@@ -1051,19 +1090,24 @@ bool vu_fused_supported(const Ctx *c, int n_state, int np, int stereo, int batch
     return na4 * nrp <= hs_cap && 816 + VT_LATENCY / 64 <= hs_cap && Rs * rows <= t_cap;
 }
 
-int launch_vu_prepare(Ctx *c, const VuPrepareArgs &a)
+int launch_vu_prepare(Ctx *c, const VuPrepareArgs &a, hipStream_t stream)
 {
+    if (!stream) stream = c->stream;
     if (a.np < 2 || a.batch < 1) return HV_ERR_INVALID;
     // the kernel's LDS arrays hold at most MAXNP poses per camera (the reference's cameraTrailLength 20 + the current pose);
     // a longer trail (cameraTrailLength > 20) is a supported filter size but not a supported track length here
     if (a.np > MAXNP || a.np * (a.stereo ? 2 : 1) > MAXP_ALL) return HV_ERR_UNSUPPORTED;
-    ScopedKernelTime tm(c, HV_K_VU_PREPARE);
+    ScopedKernelTime tm(c, HV_K_VU_PREPARE, stream);
     const int np_sel = a.np_hi > 0 && a.np_hi < a.np ? a.np_hi : a.np;      // the longest track this launch processes (a.np stays the record stride)
     const int nt = np_sel * (a.stereo ? 2 : 1);
     // knob vu_threads (tests / experiments): 384 / 768 forces a build where it applies
     const bool small = vu_small_build(c, nt, a.batch);
     if (a.fused == 1 && (!vu_fused_supported(c, a.n, np_sel, a.stereo, a.batch) || !a.P)) return HV_ERR_INVALID;
     if (a.fused && (!a.Hc || !a.acol || a.na_max < 7 * a.np + 1)) return HV_ERR_INVALID;
+    if (a.fused == 3) {                                      // long class: 12 .. 21 stereo poses (49 .. 84 rows; 48 rows ride along), n <= 160
+        const int rows = 2 * nt;
+        if (!a.P || a.spec_tracks > 0 || a.n > 160 || rows > HV_GATE_TIGHT_ROWS || rows >= HV_CHI2INV95_N) return HV_ERR_UNSUPPORTED;
+    }
     static bool attr_set_dev[64] = {};                       // per device: the kernels need more than the default 64 KB of dynamic LDS
     bool &attr_set = attr_set_dev[c->p.device & 63];
     if (!attr_set) {
@@ -1071,22 +1115,25 @@ int launch_vu_prepare(Ctx *c, const VuPrepareArgs &a)
         HV_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void *>(vu_prepare_kernel_2percu), hipFuncAttributeMaxDynamicSharedMemorySize, (int)VuLds<MAXP_SMALL>::BYTES));
         HV_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void *>(vu_gate_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)VuLds<MAXP_ALL>::BYTES));
         HV_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void *>(vu_gate_kernel_2percu), hipFuncAttributeMaxDynamicSharedMemorySize, (int)VuLds<MAXP_SMALL>::BYTES));
-        HV_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void *>(vu_compact_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)VuLds<MAXP_ALL>::BYTES + 16));
+        HV_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void *>(vu_compact_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)VuLds<MAXP_ALL>::BYTES));
         HV_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void *>(vu_compact_kernel_2percu), hipFuncAttributeMaxDynamicSharedMemorySize, (int)VuLds<MAXP_SMALL>::BYTES));
+        constexpr int long_bytes_attr = (int)VuLds<MAXP_ALL, true>::BYTES;
+        HV_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void *>(vu_gate_long_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, long_bytes_attr));
         attr_set = true;
     }
     const dim3 grid((unsigned)a.batch, (unsigned)(a.spec_tracks > 0 ? a.spec_tracks : 1));
-    if (a.fused == 2) {
-        if (small) hipLaunchKernelGGL(vu_compact_kernel_2percu, grid, dim3(VT_THROUGHPUT), VuLds<MAXP_SMALL>::BYTES, c->stream, a);
-        else if (a.persistent && a.queue && a.spec_tracks == 0 && a.batch > c->num_cus)
-        { VuPrepareArgs a1 = a; a1.q_off = (int)VuLds<MAXP_ALL>::BYTES; hipLaunchKernelGGL(vu_compact_kernel, dim3((unsigned)c->num_cus), dim3(VT_LATENCY), VuLds<MAXP_ALL>::BYTES + 16, c->stream, a1); }
-        else { VuPrepareArgs a1 = a; a1.persistent = 0; hipLaunchKernelGGL(vu_compact_kernel, grid, dim3(VT_LATENCY), VuLds<MAXP_ALL>::BYTES, c->stream, a1); }
+    if (a.fused == 3) {
+        constexpr size_t long_bytes = VuLds<MAXP_ALL, true>::BYTES;
+        hipLaunchKernelGGL(vu_gate_long_kernel, grid, dim3(VT_LATENCY), long_bytes, stream, a);
+    } else if (a.fused == 2) {
+        if (small) hipLaunchKernelGGL(vu_compact_kernel_2percu, grid, dim3(VT_THROUGHPUT), VuLds<MAXP_SMALL>::BYTES, stream, a);
+        else       hipLaunchKernelGGL(vu_compact_kernel, grid, dim3(VT_LATENCY), VuLds<MAXP_ALL>::BYTES, stream, a);
     } else if (a.fused) {
-        if (small) hipLaunchKernelGGL(vu_gate_kernel_2percu, grid, dim3(VT_THROUGHPUT), VuLds<MAXP_SMALL>::BYTES, c->stream, a);
-        else       hipLaunchKernelGGL(vu_gate_kernel, grid, dim3(VT_LATENCY), VuLds<MAXP_ALL>::BYTES, c->stream, a);
+        if (small) hipLaunchKernelGGL(vu_gate_kernel_2percu, grid, dim3(VT_THROUGHPUT), VuLds<MAXP_SMALL>::BYTES, stream, a);
+        else       hipLaunchKernelGGL(vu_gate_kernel, grid, dim3(VT_LATENCY), VuLds<MAXP_ALL>::BYTES, stream, a);
     } else {
-        if (small) hipLaunchKernelGGL(vu_prepare_kernel_2percu, grid, dim3(VT_THROUGHPUT), VuLds<MAXP_SMALL>::BYTES, c->stream, a);
-        else       hipLaunchKernelGGL(vu_prepare_kernel, grid, dim3(VT_LATENCY), VuLds<MAXP_ALL>::BYTES, c->stream, a);
+        if (small) hipLaunchKernelGGL(vu_prepare_kernel_2percu, grid, dim3(VT_THROUGHPUT), VuLds<MAXP_SMALL>::BYTES, stream, a);
+        else       hipLaunchKernelGGL(vu_prepare_kernel, grid, dim3(VT_LATENCY), VuLds<MAXP_ALL>::BYTES, stream, a);
     }
     HV_HIP(c, hipGetLastError());
     return HV_OK;

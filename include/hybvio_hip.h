@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define HV_ABI_VERSION 2   /* 2 (r03): hv_debug_*_knob, hv_ekf_frame_error, HV_ERR_TIMEOUT; maxSuccessfulVisualUpdates <= 0 = no limit */
+#define HV_ABI_VERSION 3   /* 3 (r04): hv_lanes_*, hv_get_stream; 2 (r03): hv_debug_*_knob, hv_ekf_frame_error, HV_ERR_TIMEOUT; maxSuccessfulVisualUpdates <= 0 = no limit */
 #define HV_MAX_LEVELS 6
 
 typedef enum hv_status {
@@ -70,7 +70,27 @@ int hv_create(const hv_params *params, hv_ctx **out);
 void hv_destroy(hv_ctx *ctx);
 const char *hv_last_error(hv_ctx *ctx);               /* text of the last HV_ERR_HIP           */
 int hv_set_stream(hv_ctx *ctx, void *hip_stream);     /* run on a caller-owned hipStream_t     */
+void *hv_get_stream(hv_ctx *ctx);                     /* the hipStream_t the context issues on  */
 int hv_synchronize(hv_ctx *ctx);
+
+/* ---- lanes: several batched contexts of one process on one GPU ------------------------------
+ * The reference runs one session per process (main.cpp); a GPU serves many. One batched context advances its B resident
+ * sequences through a frame as a chain of dependent launches -- a VALU-bound tracker half, then a latency-bound EKF half whose
+ * launches fill a fraction of the chip -- so TWO contexts whose chains run beside each other deliver more frames per second
+ * than one context of twice the batch (107 k -> 129 k frames/s at 2 x 1024 sequences in r03). Whether their
+ * launches really overlap is decided by the HARDWARE QUEUE each busy stream is bound to, and for default-priority streams that
+ * depends on everything the process created before (r03 needed a particular creation order in the caller). A lane set owns that
+ * placement: hv_lanes_create creates n_lanes contexts (same parameters) whose two streams each -- the context stream and the
+ * library's second stream of the ragged visit loop -- come from the device's HIGH-priority queue pool, which holds a queue per
+ * stream for up to two lanes regardless of process history. Drive every lane from its own host thread or round-robin from one;
+ * the lanes share nothing but the device. hv_lanes_ctx returns a lane's context (owned by the set: do not hv_destroy it, do not
+ * hv_set_stream it); hv_get_stream gives the stream to enqueue caller-side work (or a HIP-graph capture) on. */
+#define HV_MAX_LANES 8
+typedef struct hv_lanes hv_lanes;
+int hv_lanes_create(const hv_params *params, int n_lanes, hv_lanes **out);
+int hv_lanes_count(const hv_lanes *lanes);
+hv_ctx *hv_lanes_ctx(hv_lanes *lanes, int lane);
+void hv_lanes_destroy(hv_lanes *lanes);
 
 /* ---- image pyramid ----------------------------------------------------------------------
  * Replaces tracker::ImagePyramid::Factory::compute (src/tracker/image_pyramid.hpp:35-41,

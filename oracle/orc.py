@@ -79,6 +79,7 @@ def lib():
                                       f64p, f64p, f64p, f64p]
         L.orc_prepare_visual_update.argtypes = [f64p, f64p, f64p, f64p, f64p, C.c_void_p, C.c_int, i32p, C.c_int, C.c_int, C.c_int,
                                                 C.c_int, C.c_int, C.c_int, C.c_double, f64p, f64p, i32p]
+        L.orc_tri_last_diag.argtypes = [f64p]
         L.orc_visual_track_prepare.argtypes = [C.c_void_p, f64p, C.c_int, i32p, C.c_int, f64p, f64p, f64p, f64p, f64p, f64p, f64p, i32p]
         u32p = C.POINTER(C.c_uint32)
         L.orc_mt19937_draws.argtypes = [C.c_uint32, C.c_int, C.c_int, u32p]
@@ -610,6 +611,13 @@ def visual_track_prepare(par, m, pose_trail_index, imu_to_cam, imu_to_cam2, imag
                                         None if b is None else _p(b, f64p), _p(_f64(image_features), f64p),
                                         _p(_f64(feature_velocities), f64p), _p(pf, f64p), _p(H, f64p), _p(f, f64p), _p(ps, i32p))
     return st, int(ps[0]), pf, H.T.copy(), f
+
+
+def tri_last_diag():
+    """(min rcond of E'E, min |h_z| / |h|, iterations, converged) of this thread's last triangulation: see orc_tri_last_diag."""
+    out = np.zeros(4)
+    lib().orc_tri_last_diag(_p(out, f64p))
+    return out
 
 
 # ---- 2-point rotation RANSAC (oracle/rot_ransac_oracle.c) ----

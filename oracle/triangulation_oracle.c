@@ -320,6 +320,14 @@ static int triangulate_linear(const orc_tri_params *par, int pose_count, const o
 /* Triangulator::triangulate, iterative branch (triangulation.cpp:120-407).
  * image_features / feature_velocities: [pose_count][2]; outputs dpfdp [pose_count][9], dpfdq [pose_count][12] (3x4
  * row-major), dpfdt[3] are written when calc_derivatives and the status is not an early return. */
+/* Test diagnostic (not part of the reference): how close the LAST orc_triangulate call of this thread came to a singular
+ * Gauss-Newton step -- the smallest rcond of E'E over the iterations, the smallest |h_z| (the projective denominator of a pose)
+ * relative to |h|, the iterations run and whether the loop converged. A track that drives either minimum to rounding level has no
+ * well-defined failure status: which of BEHIND / BAD_COND / NO_CONVERGENCE comes out follows the last bit of every sum (tests use
+ * this to say WHEN a device status may differ from the oracle's; see tests/test_gpu_visual_prepare.py). */
+static _Thread_local double g_tri_diag[4];
+void orc_tri_last_diag(double *out4) { for (int k = 0; k < 4; ++k) out4[k] = g_tri_diag[k]; }
+
 int orc_triangulate(const orc_tri_params *par, int pose_count, const orc_campose *trail, const double *image_features,
                     const double *feature_velocities, int stereo, int calc_derivatives, int derivative_test, double time_shift,
                     double *pf, double *dpfdp, double *dpfdq, double *dpfdt)
@@ -360,6 +368,7 @@ int orc_triangulate(const orc_tri_params *par, int pose_count, const orc_campose
     double rcond = 0.0, Jprev = 1e10;
     int converged = 0;
     const double *p0 = trail[0].p;
+    g_tri_diag[0] = 1e300; g_tri_diag[1] = 1e300; g_tri_diag[2] = 0; g_tri_diag[3] = 0;
     for (unsigned it = 0; it < par->triangulationGaussNewtonIterations; ++it) {
         double ETE[9] = {0}, Eerror[3] = {0}, error2 = 0;
         memset(dETE, 0, sizeof(double) * 9 * ncol);
@@ -374,6 +383,10 @@ int orc_triangulate(const orc_tri_params *par, int pose_count, const orc_campose
             mv3(C, pfiab, h);
             for (int a = 0; a < 3; ++a) h[a] += pfi[2] * t[a];
             const double ih2sq = 1.0 / (h[2] * h[2]);
+            {
+                const double hn = sqrt(h[0] * h[0] + h[1] * h[1] + h[2] * h[2]), rz = hn > 0 ? fabs(h[2]) / hn : 0.0;
+                if (!(rz >= g_tri_diag[1])) g_tri_diag[1] = rz;                  /* (NaN counts as degenerate) */
+            }
             double err[2] = {image_features[2 * i] - h[0] / h[2], image_features[2 * i + 1] - h[1] / h[2]};
             if (derivative_test && est) { err[0] += time_shift * feature_velocities[2 * i]; err[1] += time_shift * feature_velocities[2 * i + 1]; }
             double E[6];                                                          /* 2 x 3 */
@@ -449,11 +462,14 @@ int orc_triangulate(const orc_tri_params *par, int pose_count, const orc_campose
             for (int a = 0; a < 3; ++a) dpfi[a * ncol + j] += -t3[a] - (-t2[a]);
         }
         rcond = 1.0 / (norm1_3(ETE) * norm1_3(X));
+        if (!(rcond >= g_tri_diag[0])) g_tri_diag[0] = rcond;
+        g_tri_diag[2] = (double)(it + 1);
         const double Rnoise = par->triangulationConvergenceR * par->triangulationConvergenceR;
         const double J = 0.5 * error2 / Rnoise, Jd = fabs((J - Jprev) / J);
         Jprev = J;
         if (Jd < par->triangulationConvergenceThreshold) { converged = 1; break; }
     }
+    g_tri_diag[3] = (double)converged;
     int status = TRI_OK;
     if (!converged) status = TRI_NO_CONVERGENCE;
     else if (rcond < par->triangulationRcondThreshold) status = TRI_BAD_COND;

@@ -30,7 +30,7 @@ def test_header_symbols_exported_and_bound():
 
 def test_defaults_and_status_strings():
     L = capi.lib()
-    assert L.hv_abi_version() == 2
+    assert L.hv_abi_version() == 3
     p = capi.Params()
     L.hv_default_params(C.byref(p))
     # codegen/parameter_definitions.c:262,336-344
@@ -50,6 +50,24 @@ def test_create_rejects_bad_arguments_without_touching_the_device():
     assert L.hv_create(C.byref(p), C.byref(h)) == -2      # only the 31x31 window is implemented
     p.win, p.levels = 31, 9
     assert L.hv_create(C.byref(p), C.byref(h)) == -1
+
+
+def test_lanes_reject_bad_arguments_and_a_missing_device():
+    """hv_lanes_create (r04): argument checks come before any device work; without a GPU it reports HV_ERR_NO_DEVICE like hv_create."""
+    import torch
+    L = capi.lib()
+    p = capi.Params()
+    L.hv_default_params(C.byref(p))
+    h = C.c_void_p()
+    assert L.hv_lanes_create(C.byref(p), 0, C.byref(h)) == -1
+    assert L.hv_lanes_create(C.byref(p), 9, C.byref(h)) == -1
+    assert L.hv_lanes_create(None, 2, C.byref(h)) == -1
+    assert L.hv_lanes_count(None) == -1 and not L.hv_lanes_ctx(None, 0) and not L.hv_get_stream(None)
+    L.hv_lanes_destroy(None)
+    if not torch.cuda.is_available():
+        assert L.hv_lanes_create(C.byref(p), 2, C.byref(h)) == -3 and not h.value
+        with pytest.raises(capi.HvError, match="no HIP device"):
+            capi.Lanes(2)
 
 
 def test_no_silent_cpu_fallback():

@@ -32,11 +32,18 @@ VARIANTS = {
     "one_stream": {"ekf_side_stream": 0},                            # ... with the long class's prepare + gate launches behind the fused launch
     # (ekf_visit_order 2: the per-frame sort -- and with it the second-stream forms -- also below one filter per CU, where the default skips them)
     "sorted_small_batch": {"ekf_visit_order": 2},                    # the many-filter default (gates on the second stream, enqueued first) on a small batch
-    "gates_behind": {"ekf_side_stream": 2, "ekf_visit_order": 2},    # ... on the second stream, enqueued behind the fused launch
-    "long_chain_on_side_stream": {"ekf_side_stream": 1},
-    "long_chain_on_side_stream_sorted": {"ekf_side_stream": 1, "ekf_visit_order": 2},
-    "long_chain_first": {"ekf_side_stream": 4, "ekf_visit_order": 2},
+    # r04: the long class's prepare + gate is ONE launch (vu_gate_long_kernel); r03's two launches stay behind knob ekf_long_fused = 0
+    "long_two_launches": {"ekf_long_fused": 0},
+    "long_two_launches_sorted": {"ekf_long_fused": 0, "ekf_visit_order": 2},
+    "long_two_launches_one_stream": {"ekf_long_fused": 0, "ekf_side_stream": 0, "ekf_visit_order": 2},
+    "sorted_one_stream": {"ekf_side_stream": 0, "ekf_visit_order": 2},
 }
+
+
+def _well_conditioned(diag):
+    """oracle.tri_last_diag() -> the track's triangulation status is reproducible to the bit (see the ragged frame-loop test)."""
+    min_rcond, min_hz, iters, converged = diag
+    return bool(converged == 1 and iters <= 5 and min_rcond > 1e-8 and min_hz > 1e-3)
 
 
 def _apply(ctx, variant):
@@ -248,9 +255,11 @@ def test_parameters_reach_the_kernel(oracle):
 
 @pytest.mark.parametrize("variant,npose", [("default", 9), ("vu384", 9), ("dense", 9), ("dense_vu384", 9), ("gate_in_prepare", 9), ("gate_own_launch", 9),
                                            ("gate_own_launch_vu384", 9),
-                                           # long tracks (49 .. 84 rows): compact Jacobian + ekf_sparse_gate_big_kernel + two block updates (r03);
-                                           # `dense`: r02's H-from-L2 / global-workspace kernels
-                                           ("default", 13), ("default", 16), ("default", 20), ("default", 21), ("dense", 21), ("default", 12)])
+                                           # long tracks (49 .. 84 rows): prepare + big column-sparse gate in one launch (vu_gate_long_kernel, r04:
+                                           # every tile count 4 / 5 / 6-tight and the 48-row edge) + two block updates; `long_two_launches`: r03's
+                                           # vu_compact_kernel + ekf_sparse_gate_big_kernel; `dense`: r02's H-from-L2 / global-workspace kernels
+                                           ("default", 13), ("default", 16), ("default", 17), ("default", 20), ("default", 21), ("dense", 21), ("default", 12),
+                                           ("long_two_launches", 13), ("long_two_launches", 20), ("long_two_launches", 21)])
 def test_visual_track_dev_prepare_gate_update_equals_the_reference_sequence(oracle, variant, npose):
     """hv_ekf_visual_track_dev = backend.cpp:1063-1185 for one track per filter: prepare from the device mean, gate with
     trackChiTestOutlierR, update with visualR only where triangulation, prepare and gate pass. Filters that fail stay
@@ -515,8 +524,9 @@ def test_speculative_frame_loop_under_contention(variant):
     # class (dense kernels) per visit; mono tracks of 21 poses still fit the fused kernels (42 rows)
     (48, False, True, "default", 21), (48, False, True, "vu384", 21), (10, False, True, "default", 21), (48, False, False, "default", 21),
     (48, False, True, "dense", 21), (48, False, True, "updates_one_by_one", 21), (48, False, True, "filter_order", 21), (48, False, True, "one_stream", 21),
-    (48, False, True, "gates_behind", 21), (48, False, True, "long_chain_on_side_stream", 21), (48, False, True, "long_chain_first", 21), (48, False, True, "sorted_small_batch", 21),
-    (48, False, True, "long_chain_on_side_stream_sorted", 21), (300, False, True, "default", 21), (300, False, True, "one_stream", 21)])
+    (48, False, True, "long_two_launches", 21), (48, False, True, "long_two_launches_sorted", 21), (48, False, True, "long_two_launches_one_stream", 21),
+    (48, False, True, "sorted_small_batch", 21), (48, False, True, "sorted_one_stream", 21),
+    (300, False, True, "default", 21), (300, False, True, "one_stream", 21), (300, False, True, "long_two_launches", 21)])
 def test_whole_frame_loop_with_ragged_track_lengths(oracle, B, speculative, stereo, variant, np_max):
     """hv_ekf_visual_frame_ragged_dev: the sequences of a batch do not share track lengths -- every (visit, filter) record has its own
     pose count (2 .. n_poses_max, 0 = this filter has no candidate at this visit), padded to the longest. Result = the reference's
@@ -573,17 +583,17 @@ def test_whole_frame_loop_with_ragged_track_lengths(oracle, B, speculative, ster
                 i_, f_, v_, yy = per[(k, b)]
                 ost, ops, opf, oH, of = oracle.visual_track_prepare(par, o.m.copy(), i_, T1, T2 if stereo else None, f_, v_)
                 if st[k, b].tolist() != [ost, ops]:
-                    # A degenerate track (a quarter of them are built to fail) can send the Gauss-Newton iteration of the triangulation
-                    # through a singular normal matrix: the path then follows the last bit of every sum and WHICH failure is reported
-                    # (behind a camera / rcond / no convergence) is not a property of the input. Tolerated only as such: both statuses are
-                    # failures, and the oracle itself reaches the device's status when its input mean is moved in the 13th digit.
+                    # The failure status of a track is only a property of the input while the Gauss-Newton iteration is well conditioned.
+                    # Deterministic rule (r04, replaces r03's "some 1e-13 perturbation of the oracle reaches the device's status"): the
+                    # oracle reports how close ITS iteration came to a singular step (oracle.tri_last_diag: smallest rcond of E'E,
+                    # smallest |h_z| / |h| of a projection, iterations, convergence). A track that converged within 5 iterations with
+                    # rcond > 1e-8 and no projection within 1e-3 of a camera plane is WELL conditioned: the device must report exactly the
+                    # oracle's status. Any other track (a quarter of this test's tracks are nonsense on purpose) is DEGENERATE: its
+                    # iteration amplifies the last bit of every sum, BEHIND / BAD_COND / NO_CONVERGENCE are one class "triangulation
+                    # failed", and the assertion is on the class -- nothing downstream depends on which member (gate NOT_COMPUTED, filter
+                    # untouched: asserted below).
+                    assert not _well_conditioned(oracle.tri_last_diag()), (b, k, lens[k, b], st[k, b].tolist(), [ost, ops], oracle.tri_last_diag())
                     assert ost != 0 and st[k, b, 0] != 0, (b, k, lens[k, b], st[k, b].tolist(), [ost, ops])
-                    rng_tie, seen = np.random.default_rng(1000 * k + b), set()
-                    for _ in range(48):
-                        m2 = o.m * (1.0 + 1e-13 * rng_tie.normal(size=o.m.size))
-                        o2 = oracle.visual_track_prepare(par, m2, i_, T1, T2 if stereo else None, f_, v_)
-                        seen.add((o2[0], o2[1]))
-                    assert tuple(st[k, b].tolist()) in seen, (b, k, lens[k, b], st[k, b].tolist(), [ost, ops], seen)
                     ties += 1
                 if (ost, ops) != (0, 0):
                     assert gs[k, b] == 1
