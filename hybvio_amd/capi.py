@@ -205,7 +205,10 @@ class Context:
             self._h = None
 
     def __del__(self):
-        self.close()
+        try:
+            self.close()
+        except Exception:                             # interpreter shutdown: module globals may be gone already
+            pass
 
     def __enter__(self):
         return self
@@ -501,7 +504,10 @@ class Lanes:
             self._g = None
 
     def __del__(self):
-        self.close()
+        try:
+            self.close()
+        except Exception:                             # interpreter shutdown: module globals may be gone already
+            pass
 
     def __enter__(self):
         return self
@@ -534,7 +540,10 @@ class EkfBatch:
                 self.ctx._children.remove(self)
 
     def __del__(self):
-        self.close()
+        try:
+            self.close()
+        except Exception:                             # interpreter shutdown: module globals may be gone already
+            pass
 
     def _chk(self, rc, what):
         self.ctx._chk(rc, what)

@@ -295,6 +295,7 @@ static int create_ctx(const hv_params *params, int high_priority, hv_ctx **out)
     Ctx *c = &h->c;
     c->p = p;
     if (c->p.max_pairs < 1) c->p.max_pairs = 1;
+    if (high_priority) c->knob.ekf_side_stream = 5;       // lanes: the visit forks onto the second stream only outside a stream capture (ekf.hip)
     hv::knobs_from_env(c->knob);
     hv::compute_layout(p, c->L);
     int rc = HV_OK;

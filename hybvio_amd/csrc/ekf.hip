@@ -2189,7 +2189,16 @@ static int visual_track_dev_impl(hv_ekf *h, const hv_vu_params *p, int np, const
     if (np_rec_dev && shape.two_class) {
         rc = ensure_long();
         if (rc != HV_OK) return rc;
-        const bool use_aux = c->knob.ekf_side_stream != 0 && presorted && c->aux_stream;
+        bool use_aux = c->knob.ekf_side_stream != 0 && presorted && c->aux_stream;
+        if (use_aux && c->knob.ekf_side_stream == 5) {
+            // lanes (knob value 5, their default): no fork while the context stream is being CAPTURED. A captured fork does not run on
+            // the library's high-priority second stream when the graph is replayed but on a stream the graph instance creates for the
+            // branch -- default priority, bound to whichever hardware queue the process history left least used --, which is exactly the
+            // placement lottery the lanes exist to end (r04, scripts/lanes_probe.py: 2 x 1024 sequences 19.2 / 16.3 ms per step with the
+            // captured fork after two different process histories, 15.84 ms without it)
+            hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+            if (hipStreamIsCapturing(main_stream, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) use_aux = false;
+        }
         hv::VuPrepareArgs s_ = a;                              // class "short": 2 .. np_short poses (and the records without a track)
         s_.np_lo = 2; s_.np_hi = np_short; s_.class_inactive = 1;
         s_.fused = 1; s_.H = nullptr; s_.Hc = e->vuH; s_.acol = e->vuacol; s_.na_max = 7 * np + 1; s_.P = e->P;
