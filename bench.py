@@ -1149,9 +1149,11 @@ def main():
     ap.add_argument("--verify", type=int, default=4, help="sequences of the C3 batch re-computed by the CPU oracle after the timed region (0 = off)")
     ap.add_argument("--repeats", type=int, default=5, help="repeats of the K-step timed region of the headline; `value` is the median repeat")
     ap.add_argument("--no-graph", action="store_true", help="time the headline with eager launches instead of HIP-graph replay of the captured steps")
-    ap.add_argument("--engines", type=int, default=2,
-                    help="engine instances per GPU in the realistic headline leg: each its own hv context, stream, HIP graphs and --sequences "
-                         "resident sequences; their launch chains run beside each other (1 = r03's first-half configuration)")
+    ap.add_argument("--engines", type=int, default=4,
+                    help="lanes of the hv_lanes set of the realistic headline leg: each a batched context on library-owned streams with its own HIP "
+                         "graphs and --sequences resident sequences; their launch chains run beside each other (2 = r03's headline configuration, "
+                         "reported as `lanes_2` whenever more lanes run; 1 = one context on a torch stream)")
+    ap.add_argument("--verify-per-engine", type=int, default=2, help="sequences checked per lane when more than two lanes run (--verify applies up to two)")
     ap.add_argument("--one-sequence-leg", action="store_true", help="add the literal north-star configuration (ONE sequence per GPU) at N > 1 too")
     ap.add_argument("--cpu-baseline-child", type=float, default=None, help=argparse.SUPPRESS)
     args = ap.parse_args()
@@ -1298,33 +1300,48 @@ def main():
     def c3_lanes(repeats, verify_n):
         """The realistic C3 step on every lane of the hv_lanes set at once: a step replays one captured graph of EACH lane on the lane's
         own stream, i.e. is a step of lanes x B frames. The visit loop of one lane is a chain of dependent launches of which several
-        fill a fraction of the chip (the long class's launch, the second update launch) and its tracker half is VALU-bound while its EKF
-        half is latency-bound; another lane's chain runs in those gaps. After the timed regions EVERY lane is verified against the oracle
-        from the state its last replay left (the lanes' last replays ran beside each other)."""
-        cnt = [0]
+        fill a fraction of the chip (the long class's launch, the second update launch); the other lanes' chains run in those gaps (the
+        lanes' VALU-bound tracker halves gain nothing from each other: rocprofv3 timeline in profiles/r04). Timed twice: the first two
+        lanes alone (`lanes_2`: r03's configuration of 2 x B resident sequences) and all of them (the headline). After the timed regions
+        EVERY lane is verified against the oracle from the state its last replay left (the lanes' last replays ran beside each other)."""
+        cnt = [0] * len(pre_engines)
 
-        def replay():
-            for s_, _, _, gl_, _ in pre_engines:                 # one graph of every lane, each on its own stream
-                with torch.cuda.stream(s_):
-                    gl_[cnt[0] % N_CYCLE].replay()
-            cnt[0] += 1
+        def replay_on(sel):
+            def fn():
+                for i_ in sel:                                   # one graph of every selected lane, each on its own stream
+                    s_, _, _, gl_, _ = pre_engines[i_]
+                    with torch.cuda.stream(s_):
+                        gl_[cnt[i_] % N_CYCLE].replay()
+                    cnt[i_] += 1
+            return fn
+        every = list(range(len(pre_engines)))
         for _ in range(N_CYCLE):
-            replay()
+            replay_on(every)()
         torch.cuda.synchronize()
-        times = [env.timed(replay, args.steps) for _ in range(max(1, repeats))]
-        while cnt[0] % N_CYCLE:
-            replay()
+        two = None
+        if len(pre_engines) > 2:
+            t2 = sorted(env.timed(replay_on([0, 1]), args.steps) for _ in range(3))[1]
+            two = {"sequences_per_gpu": 2 * B, "value": aggregate_value(2 * B, world, args.steps, t2), "unit": "frames/s",
+                   "ms_per_step": t2 / args.steps * 1e3, "r03_value": 129538.0,
+                   "note": "two lanes of the same set replaying alone: r03's headline configuration (2 engines x 1024 sequences)"}
+        times = [env.timed(replay_on(every), args.steps) for _ in range(max(1, repeats))]
+        for i_ in every:
+            while cnt[i_] % N_CYCLE:
+                replay_on([i_])()
+        # one more full cycle of ALL lanes together, so that the state that is verified was left by concurrent replays of every lane
+        for _ in range(N_CYCLE):
+            replay_on(every)()
         torch.cuda.synchronize()
         vers = []
         if verify_n > 0 and rank == 0:
             for i_, (_, t_, e_, _, fr_) in enumerate(pre_engines):
                 vers.append(verify_c3(t_, e_, verify_n, seed=rank + 17 * i_, frame=fr_[-1]))
         gate_hist = [int((pre_engines[0][2].gs[k] == 0).sum().item()) for k in range(VISITS)]
-        return {"times": times, "verify": vers, "gate_hist": gate_hist,
+        return {"times": times, "verify": vers, "gate_hist": gate_hist, "lanes_2": two,
                 "launch": f"hipGraph replay, {len(pre_engines)} lanes (hv_lanes) x {B} sequences, one captured graph per lane and step"}
 
     keep_graphs = []
-    head_lanes = c3_lanes(args.repeats, args.verify) if pre_engines else None
+    head_lanes = c3_lanes(args.repeats, args.verify if args.engines <= 2 else min(args.verify, args.verify_per_engine)) if pre_engines else None
     # ---- C2: tracker only (configs[1]) ----
     tb, c2 = tracker_leg(env, args, B, local_rank, rank,
                          "C2: 752x480 stereo, 200 pts, HIP pyramid+KLT tracker (2 builds + 2 LK calls per frame), EKF on the host")
@@ -1483,7 +1500,7 @@ def main():
             "launch": launch3, "eager_ms_per_step": eager3[0] / args.steps * 1e3,
             "eager_ms_per_step_is": f"ONE engine ({B} sequences) with eager launches: the region the per-kernel hipEvent profile (`kernels`, `roofline`) comes from",
             "r03": {"value": 129538.0, "one_engine": 107100.0, "c3_uniform": 124600.0},
-            "one_engine": one_engine,
+            "one_engine": one_engine, "lanes_2": head_lanes["lanes_2"] if head_lanes else None,
             "stage_pyramid_klt_frac_of_8TBs": stage["frac_of_8TBs"], "stage_pyramid_klt_frac_actual": stage["frac_actual"],
             "parity_checked_sequences": verify["parity_checked_sequences"] if verify else 0, "parity_ok": verify["ok"] if verify else None,
             "config": {"workload": "C3: 752x480 stereo, 200 pts -- the whole frame chained on one stream per sequence: 2 pyramid builds, temporal LK from "
@@ -1501,7 +1518,8 @@ def main():
                        "parity_engines_checked": verify["engines_checked"] if verify else 0,
                        "stage_frac_agreed": stage["frac_of_8TBs"], "stage_frac_actual": stage["frac_actual"],
                        "one_engine_value": one_engine["value"], "one_engine_ms_per_step": one_engine["ms_per_step"],
-                       "comparable_to_r03": "value: r03 headline 129.5 k (2 engines x 1024 on torch streams created first); one_engine_value: r03 one_engine 107.1 k",
+                       "lanes_2_value": (head_lanes["lanes_2"] or {}).get("value") if head_lanes else None,
+                       "comparable_to_r03": "lanes_2_value (or value when 2 lanes run): r03 headline 129.5 k (2 engines x 1024 on torch streams created first); one_engine_value: r03 one_engine 107.1 k; value with 4 lanes has no r03 counterpart (r03 probe of 4 engines: 130 k)",
                        "timing_process_group": args.dist_backend if world > 1 else None, "host_cores_per_rank": env.cores},
             # the dominant kernel, labelled for what bounds it: klt_kernel issues integer VALU instructions > 90 % of the time. achieved /
             # peak / frac stay in the contract's units on the AGREED bytes of SURVEY 8(d) (windows read once, every gradient plane counted);

@@ -7,8 +7,8 @@ import json
 import os
 import sys
 
-src = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/prof_r03"
-dst = sys.argv[2] if len(sys.argv) > 2 else "profiles/r03/traffic.json"
+src = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/prof_r04"
+dst = sys.argv[2] if len(sys.argv) > 2 else "profiles/r04/traffic.json"
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench  # noqa: E402
 
@@ -45,7 +45,8 @@ else:
 W2, H2 = (W1 + 1) // 2, (H1 + 1) // 2
 wgs_l1 = (((W2 + 3) // 4) * ((H2 + 1) // 2) + 255) // 256          # the level-1 launch of the same kernel
 GRID = {"klt_kernel": B * NPTS * 64, L0K: L0GRID, "ekf_update_kernel": B * 512, "pyr_tail_kernel": 2 * B * 512,
-        "vu_gate_kernel_2percu": B * 384, "ekf_sparse_gate_kernel": B * 256, "vu_compact_kernel_2percu": B * 384}
+        "vu_gate_kernel_2percu": B * 384, "ekf_sparse_gate_kernel": B * 256, "vu_compact_kernel_2percu": B * 384,
+        "vu_gate_long_kernel": B * 768}
 GRID_L1 = 2 * B * wgs_l1 * 256
 
 
@@ -100,6 +101,13 @@ out = {
         "valu_insts_per_track": frac(g("vu_gate_kernel_2percu", "SQ_INSTS_VALU"), B),
         "mfma_insts_per_track": frac(g("vu_gate_kernel_2percu", "SQ_INSTS_MFMA"), B),
         "how": "fused triangulation + prepareVisualUpdate + column-sparse chi2 gate, one launch per track visit (short-track class of the ragged frame loop)",
+    },
+    "vu_gate_long_kernel": {
+        "hbm_bytes_per_launch": hbm("vu_gate_long_kernel"),
+        "valu_busy_frac": frac(g("vu_gate_long_kernel", "SQ_ACTIVE_INST_VALU"), (g("vu_gate_long_kernel", "SQ_BUSY_CYCLES") or 0) * 32.0, 4.0),
+        "mfma_busy_frac": frac(g("vu_gate_long_kernel", "SQ_VALU_MFMA_BUSY_CYCLES"), 32.0 * (g("vu_gate_long_kernel", "SQ_BUSY_CYCLES") or 0)),
+        "wave_parked_frac": frac(g("vu_gate_long_kernel", "SQ_WAIT_ANY"), g("vu_gate_long_kernel", "SQ_WAVE_CYCLES")),
+        "how": "r04: triangulation + prepareVisualUpdate + the 4- to 6-tile column-sparse gate of the long-track class (12 .. 21 stereo poses) in one launch per visit; ~21 % of the records of a launch are live",
     },
     "pyr_tail_kernel": {
         "fetch_kb_raw": g("pyr_tail_kernel", "FETCH_SIZE"), "write_kb": g("pyr_tail_kernel", "WRITE_SIZE"),
