@@ -77,7 +77,7 @@ int hv_synchronize(hv_ctx *ctx);
  * The reference runs one session per process (main.cpp); a GPU serves many. One batched context advances its B resident
  * sequences through a frame as a chain of dependent launches -- a VALU-bound tracker half, then a latency-bound EKF half whose
  * launches fill a fraction of the chip -- so TWO contexts whose chains run beside each other deliver more frames per second
- * than one context of twice the batch (107 k -> 129 k frames/s at 2 x 1024 sequences in r03). Whether their
+ * than one context alone (107 k -> 130 k frames/s at 2 x 1024 sequences, 138 k at 4 x 1024). Whether their
  * launches really overlap is decided by the HARDWARE QUEUE each busy stream is bound to, and for default-priority streams that
  * depends on everything the process created before (r03 needed a particular creation order in the caller). A lane set owns that
  * placement: hv_lanes_create creates n_lanes contexts (same parameters) whose two streams each -- the context stream and the
