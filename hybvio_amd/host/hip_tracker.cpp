@@ -15,7 +15,20 @@ Session::Session(const hv_params &params) : params_(params)
     if (rc != HV_OK) throw std::runtime_error(std::string("hv_create: ") + hv_status_string(rc));
 }
 
-Session::~Session() { hv_destroy(ctx_); }
+Session::~Session() { if (owned_) hv_destroy(ctx_); }
+
+Lanes::Lanes(const hv_params &params, int n)
+{
+    const int rc = hv_lanes_create(&params, n, &lanes_);
+    if (rc != HV_OK) throw std::runtime_error(std::string("hv_lanes_create: ") + hv_status_string(rc));
+    for (int i = 0; i < hv_lanes_count(lanes_); ++i) sessions_.emplace_back(new Session(hv_lanes_ctx(lanes_, i), params));
+}
+
+Lanes::~Lanes()
+{
+    sessions_.clear();                     // (the borrowed contexts die with the set)
+    hv_lanes_destroy(lanes_);
+}
 
 void Session::check(int rc, const char *what) const
 {

@@ -55,6 +55,8 @@ public:
     ~Session();
     Session(const Session &) = delete;
     Session &operator=(const Session &) = delete;
+    // a session on a context somebody else owns: lane i of a Lanes set (below)
+    Session(hv_ctx *borrowed, const hv_params &params) : ctx_(borrowed), params_(params), owned_(false) {}
     hv_ctx *ctx() const { return ctx_; }
     const hv_params &params() const { return params_; }
     // Every C-ABI return code of the adapters passes through here: a device failure throws DeviceError (also under
@@ -63,6 +65,25 @@ public:
 private:
     hv_ctx *ctx_ = nullptr;
     hv_params params_{};
+    bool owned_ = true;
+};
+
+// Several sessions of one process on one GPU whose launch chains are meant to run beside each other (a server multiplexing VIO
+// sessions onto a GPU; the reference runs one session per process, main.cpp): hv_lanes_create gives every lane streams from the
+// device's high-priority hardware-queue pool, so the lanes' work overlaps whatever else the process created (include/hybvio_hip.h).
+// session(i) is a Session on lane i's context; the adapters' buildHip factories take it like any other Session.
+class Lanes {
+public:
+    Lanes(const hv_params &params, int n);
+    ~Lanes();
+    Lanes(const Lanes &) = delete;
+    Lanes &operator=(const Lanes &) = delete;
+    int size() const { return (int)sessions_.size(); }
+    Session &session(int i) { return *sessions_.at((size_t)i); }
+    void *stream(int i) { return hv_get_stream(sessions_.at((size_t)i)->ctx()); }   // hipStream_t of lane i
+private:
+    hv_lanes *lanes_ = nullptr;
+    std::vector<std::unique_ptr<Session>> sessions_;
 };
 
 namespace tracker {

@@ -414,6 +414,14 @@ int main(int argc, char **argv)
     test_visual_track(session, dir);
     test_visual_frame(session, dir);
     test_rot_ransac(session, dir);
+    {   // the same EKF / tracker / visual-update tests through the lanes of an hv_lanes set (library-owned high-priority streams)
+        Lanes lanes(p, 2);
+        REQUIRE(lanes.size() == 2 && lanes.stream(0) != nullptr && lanes.stream(0) != lanes.stream(1));
+        test_chi_squared(lanes.session(0), dir);
+        test_der_predict(lanes.session(1), dir);
+        test_tracker(lanes.session(1), dir);
+        test_visual_frame(lanes.session(0), dir);
+    }
     std::printf("%s (%d failure%s)\n", failures ? "FAILED" : "all host adapter tests passed", failures, failures == 1 ? "" : "s");
     return failures ? 1 : 0;
 }
