@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """One track visit (hv_ekf_visual_track_dev: triangulation + prepareVisualUpdate + chi2 gate + update) over the track lengths a stereo
-session sees (4 .. 21 poses = 16 .. 84 rows), B filters, r03 path against r02's dense kernels (knob ekf_fused_gate = 0).
+session sees (4 .. 21 poses = 16 .. 84 rows), B filters: the default path (r04: the long class's prepare + gate in one
+launch) against r03's two-launch long class (knob ekf_long_fused = 0) and r02's dense kernels (knob ekf_fused_gate = 0).
 Prints one JSON object: {poses: {path: {case: {wall_us, prepare_us, gate_us, update_us}}}}. Run on the GPU box.
 usage: python scripts/track_length_sweep.py [B]"""
 import json
@@ -24,7 +25,7 @@ for npose in (4, 8, 10, 11, 12, 13, 16, 20, 21):
     y_in = feat.reshape(B, -1) + 1e-4 * rng.normal(size=(B, feat.shape[1] * 2))
     vp = capi.vu_default_params(imu_to_camera=T1, second_imu_to_camera=T2)
     row = {"rows": 4 * npose, "active_columns": 7 * npose + 1}
-    for path, knobs in (("r03", {}), ("r02_dense", {"ekf_fused_gate": 0})):
+    for path, knobs in (("r04", {}), ("r03_long_two_launches", {"ekf_long_fused": 0}), ("r02_dense", {"ekf_fused_gate": 0})):
         with capi.Context(width=64, height=64) as ctx:
             for k, v in knobs.items():
                 ctx.set_knob(k, v)
