@@ -458,7 +458,8 @@ class VuParams(C.Structure):
                 ("triangulationMinDist", C.c_double), ("triangulationMaxDist", C.c_double),
                 ("estimateImuCameraTimeShift", C.c_int), ("useStereo", C.c_int),
                 ("imuToCamera", C.c_double * 16), ("secondImuToCamera", C.c_double * 16),
-                ("useLinearTriangulation", C.c_int)]
+                ("useLinearTriangulation", C.c_int),
+                ("trackRmseThreshold", C.c_double), ("trackOutlierThresholdGrowthFactor", C.c_double)]
 
 
 def vu_default_params(imu_to_camera=None, second_imu_to_camera=None, **over) -> VuParams:

@@ -1568,6 +1568,12 @@ __global__ __launch_bounds__(1024) void ekf_symmetrize_kernel(int n, double *Pal
     }
 }
 
+__global__ void fill_doubles_kernel(double *dst, int n, double value)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = value;
+}
+
 __global__ void ekf_normalize_kernel(int n, int map_dim, double *mall, int only_current)
 {
     double *m = mall + (size_t)blockIdx.x * n;
@@ -1669,6 +1675,8 @@ struct Ekf {
     int side_rows = 0;
     int *side_acol = nullptr; double *side_dm = nullptr;
     int *err_dev = nullptr;                               // device error word (UpdateArgs::err)
+    double *gate_scale = nullptr;                         // [batch] per-filter multiplier of the outlier thresholds inside a frame loop (backend.cpp:1192-1193)
+    bool gate_scale_on = false;                           // set by the frame loop while its visits run with a growth factor != 1
     int *visit_counts = nullptr, *visit_lists = nullptr;  // compaction lists of a visit: counts {inliers short, long records, inliers long}, lists 3 x [batch]
     // the counts exist once per visit of a frame loop (VISIT_SLOTS x 4 ints, zeroed by ONE memset per frame; visit_slot = the running
     // visit, set by the loop) plus one set for stand-alone visits (zeroed per call): a memset node per visit was 20 more graph nodes
@@ -1898,7 +1906,7 @@ void hv_ekf_destroy(hv_ekf *h)
     void *ptrs[] = { e->m, e->P, e->P1, e->m1, e->Q, e->dydx, e->ws, e->sH, e->sv, e->sr, e->schi2, e->simu,
                      e->sstatus, e->sdrop, e->sactive, e->vuH, e->vuv, e->vupf, e->vuactive, e->vustage,
                      e->spH, e->spv, e->sppf, e->spactive, e->spcursor, e->spepoch, e->spcursor2, e->sppub, e->vurows, e->sprows,
-                     e->vuacol, e->spacol, e->err_dev, e->sideH, e->sidev, e->side_active, e->side_acol, e->side_dm, e->visit_counts, e->visit_lists, e->visit_order, e->visit_long, e->visit_long_count };
+                     e->vuacol, e->spacol, e->err_dev, e->gate_scale, e->sideH, e->sidev, e->side_active, e->side_acol, e->side_dm, e->visit_counts, e->visit_lists, e->visit_order, e->visit_long, e->visit_long_count };
     for (void *p : ptrs) if (p) (void)hipFree(p);
     if (e->c && e->c->aux_stream) (void)hipStreamSynchronize(e->c->aux_stream);
     if (e->ev_fork) (void)hipEventDestroy(e->ev_fork);
@@ -1975,6 +1983,7 @@ void hv_vu_default_params(hv_vu_params *p)
     p->triangulationRcondThreshold = 1e-8; p->triangulationGaussNewtonIterations = 10;
     p->triangulationMinDist = 0; p->triangulationMaxDist = 1e300;
     p->estimateImuCameraTimeShift = 1;                                                          // :163
+    p->trackRmseThreshold = -1.0; p->trackOutlierThresholdGrowthFactor = 1.0;                   // :21,27
     p->useStereo = 0;
     const double imu[9] = {1, 0, 0, 0, -1, 0, 0, 0, -1};                                         // :178 imuToCameraMatrix (symmetric)
     for (int r = 0; r < 4; ++r) for (int c = 0; c < 4; ++c) {
@@ -2000,6 +2009,11 @@ static int vu_fill_args(Ekf *e, const hv_vu_params *p, int np, const int *idx, c
     a.rcond_threshold = p->triangulationRcondThreshold; a.min_dist = p->triangulationMinDist; a.max_dist = p->triangulationMaxDist;
     a.gn_iters = (int)p->triangulationGaussNewtonIterations; a.est_shift = p->estimateImuCameraTimeShift ? 1 : 0;
     a.linear = p->useLinearTriangulation ? 1 : 0;
+    // adaptive outlier thresholds (ABI 3): the RMSE test applies everywhere the fused gate runs; the per-filter growth only inside a
+    // frame loop (visual_frame_dev_impl hands the multiplier array over through Ekf::gate_scale_on)
+    a.rmse_thr = p->trackRmseThreshold; a.growth = p->trackOutlierThresholdGrowthFactor;
+    a.gate_scale = e->gate_scale_on ? e->gate_scale : nullptr;
+    if (!(a.growth > 0.0)) return HV_ERR_INVALID;
     return HV_OK;
 }
 
@@ -2136,6 +2150,8 @@ static int visual_track_dev_impl(hv_ekf *h, const hv_vu_params *p, int np, const
     auto long_prepare_gate = [&](hv::VuPrepareArgs l_, double *Hc, double *vv, int *acol, unsigned char *act, bool listed, hipStream_t stream) -> int {
         l_.H = nullptr; l_.Hc = Hc; l_.v = vv; l_.acol = acol; l_.na_max = 7 * np + 1; l_.active = act; l_.chi2 = chi2_dev;
         if (listed) { l_.rec_count = cnt_long; l_.rec_list = list_long; }
+        const bool adaptive_gate = l_.rmse_thr >= 0.0 || l_.gate_scale;     // (served by the fused gates only)
+        if (c->knob.ekf_long_fused == 0 && adaptive_gate) return HV_ERR_UNSUPPORTED;
         if (c->knob.ekf_long_fused != 0) {
             l_.fused = 3; l_.P = e->P; l_.rd_gate = r_gate * r_gate * ns; l_.noise_scale = ns;
             l_.inl_count = cnt_inl_long; l_.inl_list = list_inl_long;
@@ -2253,6 +2269,7 @@ static int visual_track_dev_impl(hv_ekf *h, const hv_vu_params *p, int np, const
         // of Hc through HBM stays the default at every batch size.
         const int fg = c->knob.ekf_fused_gate;
         const bool split_gate = fg == 2;
+        if (split_gate && (a.rmse_thr >= 0.0 || a.gate_scale)) return HV_ERR_UNSUPPORTED;   // (adaptive thresholds: fused gates only)
         a.fused = split_gate ? 2 : 1; a.H = nullptr; a.Hc = e->vuH; a.acol = e->vuacol; a.na_max = 7 * np + 1; a.P = e->P;
         a.rd_gate = r_gate * r_gate * ns; a.noise_scale = ns; a.chi2 = chi2_dev;
         if (!split_gate) { a.inl_count = cnt_inl; a.inl_list = list_inl; }
@@ -2268,6 +2285,8 @@ static int visual_track_dev_impl(hv_ekf *h, const hv_vu_params *p, int np, const
                                      e->vuactive, gate_status_dev, success_counter_dev, 0.0, nullptr, 0, 0, nullptr, 0, nullptr, nullptr,
                                      nullptr, 0, nr_rec, &ch);
     }
+    // (the dense kernels below know neither the RMSE test nor the per-filter threshold growth)
+    if (a.rmse_thr >= 0.0 || a.gate_scale) return HV_ERR_UNSUPPORTED;
     rc = hv::launch_vu_prepare(c, a);
     if (rc != HV_OK) return rc;
     // Dense path (tracks of more than 48 rows, filters wider than 160, knob ekf_fused_gate = 0): visualTrackOutlierCheck with chiOutlierR,
@@ -2311,13 +2330,24 @@ static int visual_frame_dev_impl(hv_ekf *h, const hv_vu_params *p, int n_tracks,
     if (max_successful <= 0 || max_successful > n_tracks) max_successful = n_tracks > 0 ? n_tracks : 1;
     const size_t B = (size_t)e->batch, nt = (size_t)np * (p && p->useStereo ? 2 : 1);
     HV_HIP(c, hipMemsetAsync(success_counter_dev, 0, sizeof(int) * B, c->stream));          // updateSuccessCount = 0 (backend.cpp:1017)
+    // adaptive outlier thresholds (backend.cpp:994-996,1192-1193): every filter starts the frame at the base thresholds; a rejected
+    // track multiplies its filter's thresholds for the tracks behind it. Kept per filter on the device, reset here.
+    const bool adaptive = p && p->trackOutlierThresholdGrowthFactor != 1.0;
+    struct ScaleScope { Ekf *e; ~ScaleScope() { e->gate_scale_on = false; } } scale_scope{e};
+    if (adaptive) {
+        if (!e->gate_scale) HV_HIP(c, hipMalloc(reinterpret_cast<void **>(&e->gate_scale), sizeof(double) * B));
+        hipLaunchKernelGGL(hv::fill_doubles_kernel, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, c->stream, e->gate_scale, (int)B, 1.0);
+        HV_HIP(c, hipGetLastError());
+        e->gate_scale_on = true;
+    }
     // Few sequences (one, for the reference's `main`): the frame is latency bound -- 20 dependent visits of a ~26 us prepare and a
     // ~34 us gate. While the GPU has idle CUs the loop is run SPECULATIVELY instead: a pass prepares and gates
     // EVERY pending track of a filter against the current (m, P) in parallel, applies the first inlier in visit order, and only the
     // tracks behind it are re-examined: <= min(max_successful, n_tracks) + 1 passes, the same statuses and the same filter as the
     // sequential loop (tracks in front of the first inlier saw the state they would have seen anyway).
     const int rows = 2 * (int)nt;
-    if (!c->knob.ekf_no_speculation && n_tracks >= 2 && B * (size_t)n_tracks <= 256 && e->n <= 160 && rows <= 48 && p && idx && feat && vel && y) {
+    // (a growth factor != 1 makes the threshold of a track depend on the verdicts of the tracks in front of it: no parallel gating)
+    if (!c->knob.ekf_no_speculation && !adaptive && n_tracks >= 2 && B * (size_t)n_tracks <= 256 && e->n <= 160 && rows <= 48 && p && idx && feat && vel && y) {
         const size_t rec = B * (size_t)n_tracks;
         if (e->sp_records < rec || e->sp_rows < rows) {
             HV_HIP(c, hipStreamSynchronize(c->stream));
@@ -2373,6 +2403,7 @@ static int visual_frame_dev_impl(hv_ekf *h, const hv_vu_params *p, int n_tracks,
             }
             return HV_OK;
         }
+        if (a.rmse_thr >= 0.0) return HV_ERR_UNSUPPORTED;             // (the dense pass forms have no RMSE test)
         if (!split) HV_HIP(c, hipMemsetAsync(e->sppub, 0, sizeof(int) * rec, c->stream));
         int *cur = e->spcursor, *nxt = e->spcursor2;
         for (int pass = 0; pass < n_pass; ++pass) {

@@ -183,6 +183,10 @@ struct VuPrepareArgs {
     int na_max;                        // 7 * np + 1
     const double *P;                   // [batch][n][n]
     double rd_gate, noise_scale;       // R = rd_gate I (already scaled by noiseScale), chi2 = noise_scale z'z
+    // adaptive thresholds of the frame loop (backend.cpp:994-996,1192-1193; fused gates only): gate_scale[filter] multiplies
+    // trackChiTestOutlierR and trackRmseThreshold (null: 1); a filter whose track fails the RMSE or the chi2 test multiplies its entry
+    // by `growth`. rmse_thr < 0: no RMSE test (ekf.cpp:797-801)
+    double *gate_scale; double growth, rmse_thr;
     double *chi2;                      // optional [records]
 };
 int launch_vu_prepare(Ctx *c, const VuPrepareArgs &a, hipStream_t stream = nullptr);   // stream: null = the context's

@@ -908,21 +908,39 @@ __device__ __forceinline__ void vu_prepare_body(const VuPrepareArgs &a, const in
         if (tid < nt) { T[(size_t)(2 * tid) * Rs + rows] = vres[0]; T[(size_t)(2 * tid + 1) * Rs + rows] = vres[1]; }
         VU_STAMP(32);
         const double *Pb = a.P + (size_t)b * N * N;
+        // adaptive thresholds of the frame loop (backend.cpp:1192-1193): this filter's multiplier of chiOutlierR and rmseThreshold
+        const double gscale = a.gate_scale ? a.gate_scale[b] : 1.0;
+        const double rd_eff = a.rd_gate * gscale * gscale;
+        if (a.rmse_thr >= 0.0) {                                  // (uniform) visualTrackOutlierCheck's early RMSE test, ekf.cpp:797-801
+            __syncthreads();                                      // v is in row `rows` of T
+            double s2 = 0.0;
+            for (int c = 0; c < rows; ++c) { const double vc = T[(size_t)c * Rs + rows]; s2 += vc * vc; }    // every thread: same order, same value
+            if (sqrt(s2 / rows) > a.rmse_thr * gscale) {
+                if (tid == 0) {
+                    if (a.gate_status) a.gate_status[rec] = 2 /*RMSE*/;
+                    if (a.chi2) a.chi2[rec] = 0.0;
+                    if (a.gate_scale) a.gate_scale[b] = gscale * a.growth;
+                    if (a.spec_tracks > 0) a.epoch[rec] = a.success_counter[b];
+                }
+                return;
+            }
+        }
         double chi;
         if constexpr (FUSED == 3) {
-            if (ti <= 4)      chi = sparse_gate<4, VT, false>(Pb, N, s_acol, na, Hs, T, Rs, rows, a.rd_gate, a.noise_scale, Hs, g_vu_stamp + 33);
-            else if (ti == 5) chi = sparse_gate<5, VT, false>(Pb, N, s_acol, na, Hs, T, Rs, rows, a.rd_gate, a.noise_scale, Hs, g_vu_stamp + 33);
-            else              chi = sparse_gate<6, VT, false, true>(Pb, N, s_acol, na, Hs, T, Rs, rows, a.rd_gate, a.noise_scale, Hs, g_vu_stamp + 33);
+            if (ti <= 4)      chi = sparse_gate<4, VT, false>(Pb, N, s_acol, na, Hs, T, Rs, rows, rd_eff, a.noise_scale, Hs, g_vu_stamp + 33);
+            else if (ti == 5) chi = sparse_gate<5, VT, false>(Pb, N, s_acol, na, Hs, T, Rs, rows, rd_eff, a.noise_scale, Hs, g_vu_stamp + 33);
+            else              chi = sparse_gate<6, VT, false, true>(Pb, N, s_acol, na, Hs, T, Rs, rows, rd_eff, a.noise_scale, Hs, g_vu_stamp + 33);
         } else {
-            if (ti == 1)      chi = sparse_gate<1, VT, false>(Pb, N, s_acol, na, Hs, T, Rs, rows, a.rd_gate, a.noise_scale, Hs, g_vu_stamp + 33);
-            else if (ti == 2) chi = sparse_gate<2, VT, false>(Pb, N, s_acol, na, Hs, T, Rs, rows, a.rd_gate, a.noise_scale, Hs, g_vu_stamp + 33);
-            else              chi = sparse_gate<3, VT, false>(Pb, N, s_acol, na, Hs, T, Rs, rows, a.rd_gate, a.noise_scale, Hs, g_vu_stamp + 33);
+            if (ti == 1)      chi = sparse_gate<1, VT, false>(Pb, N, s_acol, na, Hs, T, Rs, rows, rd_eff, a.noise_scale, Hs, g_vu_stamp + 33);
+            else if (ti == 2) chi = sparse_gate<2, VT, false>(Pb, N, s_acol, na, Hs, T, Rs, rows, rd_eff, a.noise_scale, Hs, g_vu_stamp + 33);
+            else              chi = sparse_gate<3, VT, false>(Pb, N, s_acol, na, Hs, T, Rs, rows, rd_eff, a.noise_scale, Hs, g_vu_stamp + 33);
         }
         if (tid == 0) {
             const bool broken = !(chi < 1e300);                   // non-positive pivot: reported as CHI2 (ekf_update_kernel phase D)
             const int outlier = broken || ((rows < HV_CHI2INV95_N) ? (chi > d_chi2inv95[rows]) : 0);
             if (a.gate_status) a.gate_status[rec] = outlier ? 3 /*CHI2*/ : 0 /*INLIER*/;
             if (!outlier && a.inl_list) a.inl_list[atomicAdd(a.inl_count, 1)] = (int)rec;
+            if (outlier && a.gate_scale) a.gate_scale[b] = gscale * a.growth;
             if (a.chi2) a.chi2[rec] = chi;
             if (a.spec_tracks > 0) a.epoch[rec] = a.success_counter[b];
         }

@@ -312,8 +312,10 @@ public:
     // of ONE length in ONE device call (hv_ekf_visual_frame: a single round trip instead of one per track; with one session the
     // device runs it speculatively, see include/hybvio_hip.h). tracks[k] are in the backend's visit order; the loop stops applying
     // updates after maxSuccessfulVisualUpdates (results of unvisited tracks: triangulateStatus = -1). The backend replays its
-    // per-track side effects (blacklist, statistics, point cloud) from the returned statuses. Requires the default
-    // trackOutlierThresholdGrowthFactor = 1.
+    // per-track side effects (blacklist, statistics, point cloud) from the returned statuses. The adaptive thresholds of
+    // backend.cpp:994-996,1192-1193 travel in `parameters` (hv_vu_params::trackRmseThreshold -- already divided by the focal length, like
+    // chiOutlierR -- and trackOutlierThresholdGrowthFactor; ABI 3): outlierStatus RMSE / CHI2 come back per track, the growth is applied
+    // per frame on the device.
     struct VisualFrameTrack {
         std::vector<int> poseTrailIndex;
         std::vector<double> imageFeatures, featureVelocities;

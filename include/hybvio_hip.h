@@ -237,6 +237,13 @@ typedef struct hv_vu_params {
     double imuToCamera[16], secondImuToCamera[16];     /* 4 x 4 homogeneous, row-major (Parameters::imuToCamera) */
     int useLinearTriangulation;                         /* parameter_definitions.c:31 (default false): triangulateLinear instead of the
                                                           iterative PIVO method (triangulation.cpp:146-152, 820-895) */
+    /* ABI 3 (r04): the adaptive outlier thresholds of Session::trackerVisualUpdate (backend.cpp:994-996,1159,1192-1193), applied by the
+     * FRAME entry points (hv_ekf_visual_frame*): every track the chi2 / RMSE test rejects multiplies both thresholds of ITS filter by
+     * the growth factor for the rest of the frame. trackRmseThreshold is in the units of r_gate (the caller divides by the focal length
+     * as backend.cpp:995 does); < 0 = no RMSE test (ekf.cpp:797-801), the reference's default -1. Growth factor default 1
+     * (parameter_definitions.c:21,27). The per-visit entry points (hv_ekf_visual_track*) apply the RMSE test with the threshold as
+     * given and leave the growth to their caller. */
+    double trackRmseThreshold, trackOutlierThresholdGrowthFactor;
 } hv_vu_params;
 void hv_vu_default_params(hv_vu_params *p);
 /* odometry::TriangulatorStatus (output.hpp:21-29) and PrepareVuStatus (output.hpp:15-19) */
@@ -281,8 +288,9 @@ int hv_ekf_visual_track_limited_dev(hv_ekf *ekf, const hv_vu_params *p, int n_po
  * (may be NULL) [n_tracks][batch], pf_dev (may be NULL) the triangulated world points. success_counter_dev [batch] is zeroed here and
  * holds the applied updates on return.
  * Nothing crosses the host between the visits; the call is asynchronous and HIP-graph capturable once it has run once
- * (its work buffers are allocated on first use). r_gate stays constant over the frame, i.e. the reference's default
- * trackOutlierThresholdGrowthFactor = 1 (backend.cpp:1192); other factors need the per-visit entry points.
+ * (its work buffers are allocated on first use). The adaptive thresholds of backend.cpp:1192-1193 (hv_vu_params::
+ * trackOutlierThresholdGrowthFactor != 1, trackRmseThreshold >= 0; gate status 2 = RMSE) are kept per filter on the device; with a
+ * growth factor != 1 the loop always runs sequentially (a rejection changes the threshold of the NEXT track).
  * max_successful <= 0 means "no limit" (the reference's maxSuccessfulVisualUpdates <= 0, backend.cpp:1233).
  * With few sequences (batch * n_tracks <= 256, n_rows <= 48) the loop runs speculatively: each pass prepares and gates every
  * pending track of a filter in parallel against the current (m, P), applies the first inlier in visit order and re-examines only

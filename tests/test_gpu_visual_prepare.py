@@ -614,6 +614,124 @@ def test_whole_frame_loop_with_ragged_track_lengths(oracle, B, speculative, ster
             assert max(lengths_applied) > 12 and min(lengths_applied) < 12, lengths_applied
         g.close()
 
+@pytest.mark.parametrize("B,np_max,growth,rmse_thr,variant", [
+    (48, 21, 1.5, 2.5, "sorted_small_batch"),      # two sorted length classes: vu_gate_kernel + vu_gate_long_kernel keep the per-filter multiplier
+    (300, 21, 1.3, 2.5, "default"),                # ... more filters than CUs (two-per-CU build, second stream)
+    (48, 21, 1.5, -1.0, "default"),                # growth without the RMSE test
+    (10, 10, 1.0, 2.5, "default"),                 # few sequences: the speculative loop with the RMSE test (growth 1)
+    (10, 10, 1.5, 2.5, "default"),                 # ... a growth factor forces the sequential loop
+    (24, 10, 1.4, 2.2, "vu384")])
+def test_frame_loop_with_adaptive_outlier_thresholds(oracle, B, np_max, growth, rmse_thr, variant):
+    """backend.cpp:994-996,1159,1192-1193 inside hv_ekf_visual_frame_ragged_dev (ABI 3): visualTrackOutlierCheck's early RMSE test
+    (ekf.cpp:797-801; gate status 2) and the per-session growth of BOTH thresholds after every rejected track, kept per filter on the
+    device. Tracks carry no, a medium (2.0: passes the RMSE test, fails chi2 at trackChiTestOutlierR 1.5 when it is long enough) or a
+    gross (3.0: fails the RMSE test) measurement offset, so that one frame sees RMSE rejections, chi2 rejections, and tracks that pass
+    only because earlier rejections raised the thresholds. Reference: the oracle's loop with the same
+    rule, per filter."""
+    import torch
+    rng = np.random.default_rng(4000 + B + np_max)
+    trail_len, K, quota = 20, 8, 3
+    T1, T2, means, _, _, _ = _random_tracks(oracle, rng, B, trail_len, 6, True, bad_fraction=0.0)
+    lens = rng.integers(2, np_max + 1, (K, B)).astype(np.int32)
+    lens[rng.uniform(size=(K, B)) < 0.1] = 0
+    idx = np.zeros((K, B, np_max), np.int32); feat = np.zeros((K, B, 2 * np_max, 2)); vel = np.zeros_like(feat)
+    ys = np.zeros((K, B, 4 * np_max))
+    per = {}
+    for k in range(K):
+        for n in sorted(set(lens[k].tolist()) - {0}):
+            sel = np.nonzero(lens[k] == n)[0]
+            _, _, _, i_, f_, v_ = _random_tracks(oracle, rng, len(sel), trail_len, n, True, bad_fraction=0.0, given_means=means[sel])
+            for j, b in enumerate(sel):
+                off = rng.choice([0.0, 2.0, 3.0], p=[0.4, 0.35, 0.25])
+                yy = f_[j].reshape(-1) + 2e-3 * rng.normal(size=f_[j].size) + off
+                idx[k, b, :n] = i_[j]; feat[k, b, :2 * n] = f_[j]; vel[k, b, :2 * n] = v_[j]; ys[k, b, :4 * n] = yy
+                per[(k, b)] = (i_[j], f_[j], v_[j], yy)
+    vp = capi.vu_default_params(imu_to_camera=T1, second_imu_to_camera=T2, trackRmseThreshold=rmse_thr,
+                                trackOutlierThresholdGrowthFactor=growth)
+    par = oracle.tri_default_params()
+    r_gate, r_update = 1.5, 0.05
+    with capi.Context(width=64, height=64) as ctx:
+        _apply(ctx, variant)
+        g = capi.EkfBatch(ctx, capi.ekf_default_params(cameraTrailLength=trail_len), B)
+        filters = []
+        for b in range(B):
+            o = oracle.Ekf(oracle.ekf_default_params(cameraTrailLength=trail_len))
+            P = o.P.copy() * 1e-6 + np.eye(o.n) * 1e-4
+            o.set_state(means[b]); o.set_cov(P)
+            g.set_state(b, means[b], P)
+            filters.append(o)
+        dev = lambda a, dt: torch.from_numpy(np.array(a, dt, order="C")).cuda()
+        d = [dev(lens, np.int32), dev(idx, np.int32), dev(feat, np.float64), dev(vel, np.float64), dev(ys, np.float64)]
+        st = torch.full((K, B, 2), -9, dtype=torch.int32, device="cuda"); gs = torch.full((K, B), -9, dtype=torch.int32, device="cuda")
+        counter = torch.full((B,), 77, dtype=torch.int32, device="cuda")
+        ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+        for rep in range(2):                                   # twice from the same start: the multipliers are reset per frame
+            for b in range(B):
+                g.set_state(b, means[b], P)
+            g.visual_frame_ragged_dev(vp, K, np_max, d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(), d[3].data_ptr(), d[4].data_ptr(),
+                                      r_gate, r_update, st.data_ptr(), gs.data_ptr(), counter.data_ptr(), quota)
+            torch.cuda.synchronize()
+        st, gs, counts = st.cpu().numpy(), gs.cpu().numpy(), counter.cpu().numpy()
+        seen = {0: 0, 2: 0, 3: 0}
+        grown_inliers = 0
+        for b, o in enumerate(filters):
+            done, scale = 0, 1.0
+            for k in range(K):
+                if done >= quota or lens[k, b] == 0:
+                    assert st[k, b].tolist() == [-1, -1] and gs[k, b] == 1, (b, k)
+                    continue
+                i_, f_, v_, yy = per[(k, b)]
+                ost, ops, _, oH, of = oracle.visual_track_prepare(par, o.m.copy(), i_, T1, T2, f_, v_)
+                if st[k, b].tolist() != [ost, ops]:
+                    assert not _well_conditioned(oracle.tri_last_diag()) and ost != 0 and st[k, b, 0] != 0, (b, k)
+                if (ost, ops) != (0, 0):
+                    assert gs[k, b] == 1
+                    continue
+                status, _ = o.visual_track_outlier_check(oH, of, yy, r_gate * scale, rmse_thr * scale if rmse_thr >= 0 else -1.0)
+                assert gs[k, b] == status, (b, k, lens[k, b], gs[k, b], status, scale)
+                seen[int(status)] += 1
+                if status == 0:
+                    if scale > 1.0:
+                        base, _ = o.visual_track_outlier_check(oH, of, yy, r_gate, rmse_thr)
+                        grown_inliers += base != 0             # passes only because of the growth
+                    o.update_visual_track(oH, of, yy, r_update); done += 1
+                else:
+                    scale *= growth
+            assert counts[b] == done
+            mg, Pg = g.get_state(b)
+            assert _rel(mg, o.m) < 1e-8 and _rel(Pg, o.P) < 1e-7, (b, _rel(mg, o.m), _rel(Pg, o.P))
+        assert seen[0] > 0 and seen[3] > 0 and (rmse_thr < 0 or seen[2] > 0), seen
+        assert growth == 1.0 or grown_inliers > 0, (seen, grown_inliers)
+        g.close()
+
+
+def test_adaptive_thresholds_are_refused_where_no_kernel_serves_them(oracle):
+    """The dense gate kernels (knob ekf_fused_gate 0) and r03's two-launch long class know neither the RMSE test nor the per-filter
+    growth: the frame entry point must say so (HV_ERR_UNSUPPORTED), never ignore the parameters."""
+    import torch
+    rng = np.random.default_rng(5)
+    B, K, npose = 8, 3, 6
+    T1, T2, means, idx, feat, vel = _random_tracks(oracle, rng, B, 20, npose, True, bad_fraction=0.0)
+    for knobs, rmse, growth in (({"ekf_fused_gate": 0}, 0.3, 1.0), ({"ekf_fused_gate": 0, "ekf_no_speculation": 1}, -1.0, 1.5), ({"ekf_fused_gate": 2, "ekf_no_speculation": 1}, 0.3, 1.0)):
+        with capi.Context(width=64, height=64) as ctx:
+            for k_, v_ in knobs.items():
+                ctx.set_knob(k_, v_)
+            g = capi.EkfBatch(ctx, capi.ekf_default_params(cameraTrailLength=20), B)
+            for b in range(B):
+                g.set_state(b, means[b], np.eye(g.n) * 1e-4)
+            vp = capi.vu_default_params(imu_to_camera=T1, second_imu_to_camera=T2, trackRmseThreshold=rmse, trackOutlierThresholdGrowthFactor=growth)
+            dev = lambda a, dt: torch.from_numpy(np.array(a, dt, order="C")).cuda()
+            d = [dev(np.stack([idx] * K), np.int32), dev(np.stack([feat] * K), np.float64), dev(np.stack([vel] * K), np.float64),
+                 dev(np.stack([feat.reshape(B, -1)] * K), np.float64)]
+            st = torch.zeros((K, B, 2), dtype=torch.int32, device="cuda"); gs = torch.zeros((K, B), dtype=torch.int32, device="cuda")
+            counter = torch.zeros((B,), dtype=torch.int32, device="cuda")
+            ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+            with pytest.raises(capi.HvError, match="unsupported"):
+                g.visual_frame_dev(vp, K, npose, d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(), d[3].data_ptr(), 1.5, 0.05,
+                                   st.data_ptr(), gs.data_ptr(), counter.data_ptr(), 2)
+            torch.cuda.synchronize()
+            g.close()
+
 
 def test_long_trail_track_is_rejected_not_corrupted():
     """cameraTrailLength > 20 is a valid filter size, but the prepare kernel's LDS arrays hold 21 poses per camera:
