@@ -70,6 +70,13 @@ def test_lanes_reject_bad_arguments_and_a_missing_device():
             capi.Lanes(2)
 
 
+def test_vu_params_defaults_keep_the_adaptive_thresholds_off():
+    """ABI 3 fields of hv_vu_params: trackRmseThreshold -1 (no RMSE test), trackOutlierThresholdGrowthFactor 1 (parameter_definitions.c:21,27)."""
+    vp = capi.vu_default_params()
+    assert vp.trackRmseThreshold == -1.0 and vp.trackOutlierThresholdGrowthFactor == 1.0
+    assert vp.triangulationGaussNewtonIterations == 10 and vp.useLinearTriangulation == 0
+
+
 def test_no_silent_cpu_fallback():
     """Without a GPU the product path must fail loudly (HV_ERR_NO_DEVICE), never compute on the CPU."""
     import torch

@@ -11,7 +11,7 @@ from hybvio_amd import capi
 
 pytestmark = pytest.mark.gpu
 
-B, K, NP_MAX, QUOTA, TRAIL = 300, 6, 21, 3, 20
+B, K, NP_MAX, QUOTA, TRAIL = 300, 6, 21, 3, 20      # (B: the two-lane test; the four-lane test runs 64 filters per lane)
 R_GATE, R_UPDATE = 1.5, 0.05
 
 
@@ -19,7 +19,7 @@ def _rel(a, b):
     return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-300))
 
 
-def _problem(oracle, seed):
+def _problem(oracle, seed, B=B):
     """One lane's inputs (host arrays) and what the oracle's sequential loop makes of them."""
     from test_gpu_visual_prepare import _random_tracks, _well_conditioned
     rng = np.random.default_rng(seed)
@@ -70,7 +70,7 @@ def _problem(oracle, seed):
         o.maintain_psd()
         exp_m[b], exp_P[b] = o.m, o.P
     assert long_applied > B // 4 and short_applied > B // 4 and rejected > B, (long_applied, short_applied, rejected)
-    return dict(T1=T1, T2=T2, means=means, P0=P0, lens=lens, idx=idx, feat=feat, vel=vel, ys=ys,
+    return dict(B=B, T1=T1, T2=T2, means=means, P0=P0, lens=lens, idx=idx, feat=feat, vel=vel, ys=ys,
                 exp=(exp_st, exp_gs, exp_cnt, exp_m, exp_P), well=well)
 
 
@@ -88,6 +88,7 @@ class _Lane:
     def __init__(self, ctx, prob):
         import torch
         self.t, self.ctx, self.prob = torch, ctx, prob
+        B = self.B = prob["B"]
         self.g = capi.EkfBatch(ctx, capi.ekf_default_params(cameraTrailLength=TRAIL), B)
         dev = lambda a, dt: torch.from_numpy(np.array(a, dt, order="C")).cuda()
         self.m0, self.P0 = dev(prob["means"], np.float64), dev(prob["P0"], np.float64)
@@ -99,6 +100,7 @@ class _Lane:
         self.stream = torch.cuda.ExternalStream(ctx.get_stream())
 
     def reset(self):                                # on the torch default stream; the caller synchronises
+        B = self.B
         mp, pp = self.g.device_pointers()
         self.t.as_tensor(_DevView(mp, (B, 160)), device="cuda").copy_(self.m0)
         self.t.as_tensor(_DevView(pp, (B, 160, 160)), device="cuda").copy_(self.P0)
@@ -111,6 +113,7 @@ class _Lane:
         self.g.symmetrize()
 
     def check(self, tag):
+        B = self.B
         exp_st, exp_gs, exp_cnt, exp_m, exp_P = self.prob["exp"]
         st, gs, cnt = self.st.cpu().numpy(), self.gs.cpu().numpy(), self.counter.cpu().numpy()
         assert self.g.frame_error() == 0
@@ -172,5 +175,56 @@ def test_two_lanes_of_300_distinct_ragged_filters(problems, mode):
             del graphs
         for i, l in enumerate(L):
             l.check(f"{mode} lane {i}")
+        for l in L:
+            l.g.close()
+
+
+@pytest.fixture(scope="module")
+def problems4(oracle):
+    return [_problem(oracle, 9100 + i, B=64) for i in range(4)]
+
+
+@pytest.mark.parametrize("mode", ["concurrent_eager", "concurrent_graph_replay"])
+def test_four_lanes_of_64_distinct_ragged_filters(problems4, mode):
+    """The benchmark's default lane count: four lanes in flight at once (eager: each forks onto its own second stream; captured: one
+    stream per lane), the sorted two-class schedule forced at 64 filters per lane (knob ekf_visit_order 2), every filter vs the oracle."""
+    import torch
+    with capi.Lanes(4, width=64, height=64) as lanes:
+        assert len({c.get_stream() for c in lanes.ctx}) == 4
+        L = [_Lane(lanes.ctx[i], problems4[i]) for i in range(4)]
+        for l in L:
+            l.ctx.set_knob("ekf_visit_order", 2)
+            assert l.ctx.get_knob("ekf_side_stream") == 5
+            l.reset()
+        torch.cuda.synchronize()
+        if mode == "concurrent_eager":
+            for rep in range(2):
+                for l in L:
+                    l.reset()
+                torch.cuda.synchronize()
+                for l in L:
+                    l.frame()
+                torch.cuda.synchronize()
+        else:
+            for l in L:
+                l.frame()
+            torch.cuda.synchronize()
+            graphs = []
+            for l in L:
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, stream=l.stream):
+                    l.frame()
+                graphs.append(g)
+            for rep in range(3):
+                for l in L:
+                    l.reset()
+                torch.cuda.synchronize()
+                for l, g in zip(L, graphs):
+                    with torch.cuda.stream(l.stream):
+                        g.replay()
+                torch.cuda.synchronize()
+            del graphs
+        for i, l in enumerate(L):
+            l.check(f"{mode} lane {i} of 4")
         for l in L:
             l.g.close()
