@@ -2233,9 +2233,10 @@ static int visual_track_dev_impl(hv_ekf *h, const hv_vu_params *p, int np, const
             forked = true;
         }
         rc = HV_OK;
-        if (presorted) rc = long_prepare_gate(l_, e->sideH, e->sidev, e->side_acol, e->side_active, true, forked ? c->aux_stream : main_stream);
+        const bool long_first = presorted && (forked || c->knob.ekf_long_first != 0);
+        if (long_first) rc = long_prepare_gate(l_, e->sideH, e->sidev, e->side_acol, e->side_active, true, forked ? c->aux_stream : main_stream);
         if (rc == HV_OK) rc = hv::launch_vu_prepare(c, s_, main_stream);
-        if (rc == HV_OK && !presorted) rc = long_prepare_gate(l_, e->sideH, e->sidev, e->side_acol, e->side_active, true, main_stream);
+        if (rc == HV_OK && !long_first) rc = long_prepare_gate(l_, e->sideH, e->sidev, e->side_acol, e->side_active, true, main_stream);
         if (forked) {
             hipError_t he = hipEventRecord(e->ev_join, c->aux_stream);
             if (he == hipSuccess) he = hipStreamWaitEvent(main_stream, e->ev_join, 0);

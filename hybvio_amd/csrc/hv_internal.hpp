@@ -68,6 +68,7 @@ struct Knobs {
     int ekf_spec_mode = -1;       // HV_EKF_SPEC_MODE: speculative pass form: -1 auto, 2 = gate launch + apply launch, 3 = one launch with hand-shake
     int ekf_side_stream = 3;      // HV_EKF_SIDE_STREAM, ragged visits with two length classes: 0 = one stream; non-zero (default 3, r03's numbering) = the long class's prepare + gate launch on the context's second stream, enqueued in front of the short class's fused launch (+6 % on the realistic C3 step); frame loops only (needs the per-frame sort of launch_visit_order); 5 (default of the contexts of an hv_lanes set) = the same, but never inside a stream capture (a captured fork is replayed on a default-priority stream of the graph instance, not on the lane's own: ekf.hip). r03's other forms (1, 2, 4: whole long chain on the second stream / enqueued behind) measured slower and were removed in r04
     int ekf_long_fused = 1;       // HV_EKF_LONG_FUSED: 1 (r04 default) = prepare + column-sparse gate of the long class (49 .. 84 rows) in ONE launch (vu_gate_long_kernel); 0 = r03's vu_compact_kernel + ekf_sparse_gate_big_kernel
+    int ekf_long_first = 1;       // HV_EKF_LONG_FIRST: sorted ragged visits enqueue the long class's prepare + gate launch in front of (1) / behind (0) the short class's fused launch
     int ekf_dual_update = 1;      // HV_EKF_DUAL_UPDATE: 1 = ragged visits issue the short class's update and the long class's first block update as one grid (ekf_update_dual_kernel); 0 = one after the other
     int ekf_visit_order = 1;      // HV_EKF_VISIT_ORDER: 1 = ragged frame loops over more filters than the GPU has CUs hand the fused kernel its records longest track first (one sort launch per frame; the presorted long-class lists also enable ekf_side_stream 2 .. 4); 2 = at every batch size (tests); 0 = in filter order
     int rot_ransac_threads = 0;   // HV_ROT_RANSAC_THREADS: 0 auto (1024 threads up to 64 sets), 256 / 1024 force
