@@ -391,6 +391,7 @@ int hv_set_stream(hv_ctx *h, void *hip_stream)
 {
     if (!h) return HV_ERR_INVALID;
     Ctx *c = &h->c;
+    if (c->stream_priority != 0) return HV_ERR_INVALID;   // a lane's streams are the point of the lane set: they stay the library's
     HV_HIP(c, hipStreamSynchronize(c->stream));
     if (c->own_stream) { (void)hipStreamDestroy(c->stream); c->own_stream = false; }
     c->stream = reinterpret_cast<hipStream_t>(hip_stream);

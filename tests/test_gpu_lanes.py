@@ -138,6 +138,8 @@ def test_two_lanes_of_300_distinct_ragged_filters(problems, mode):
     import torch
     with capi.Lanes(2, width=64, height=64) as lanes:
         assert len(lanes.ctx) == 2 and lanes.ctx[0].get_stream() != lanes.ctx[1].get_stream() != 0
+        with pytest.raises(capi.HvError, match="invalid"):      # a lane keeps the library's stream
+            lanes.ctx[0].set_stream(torch.cuda.current_stream().cuda_stream)
         L = [_Lane(lanes.ctx[i], problems[i]) for i in range(2)]
         for l in L:
             l.ctx.set_knob("ekf_visit_order", 1)    # (default: the per-frame sort + second-stream schedule, B = 300 > 256 CUs)
