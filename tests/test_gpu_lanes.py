@@ -230,3 +230,39 @@ def test_four_lanes_of_64_distinct_ragged_filters(problems4, mode):
             l.check(f"{mode} lane {i} of 4")
         for l in L:
             l.g.close()
+
+
+def test_lanes_driven_from_their_own_host_threads(problems4):
+    """one driver thread per lane. Two host threads enqueue whole frames on their lanes at the same time
+    (ctypes releases the GIL inside every C-ABI call); nothing but the device is shared between lanes, so every filter must still equal
+    the oracle's sequential loop."""
+    import threading
+    import torch
+    with capi.Lanes(2, width=64, height=64) as lanes:
+        L = [_Lane(lanes.ctx[i], problems4[i]) for i in range(2)]
+        for l in L:
+            l.ctx.set_knob("ekf_visit_order", 2)
+        errors = []
+
+        def drive(l):
+            try:
+                torch.cuda.set_device(0)
+                for rep in range(3):
+                    with torch.cuda.stream(l.stream):          # the lane's own stream: resets and frames stay ordered without a device sync
+                        l.reset()
+                        l.frame()
+                l.ctx.synchronize()
+            except Exception as ex:                              # pragma: no cover
+                errors.append(repr(ex))
+        torch.cuda.synchronize()
+        threads = [threading.Thread(target=drive, args=(l,)) for l in L]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+        torch.cuda.synchronize()
+        assert not errors, errors
+        for i, l in enumerate(L):
+            l.check(f"threaded lane {i}")
+        for l in L:
+            l.g.close()
