@@ -2233,9 +2233,16 @@ static int visual_track_dev_impl(hv_ekf *h, const hv_vu_params *p, int np, const
             forked = true;
         }
         rc = HV_OK;
+        // which class runs on which stream when the visit forks: the launch that has to START first -- the long class's, which needs
+        // whole CUs and finds them only while the chip is empty -- belongs on the stream that does NOT wait for the fork event.
+        // knob 6 (r04): long class on the context stream, short class on the second stream. (3 / 5, r03's arrangement: the long
+        // class on the second stream, enqueued first -- but released by the fork event about when the short class's 810 two-per-CU
+        // workgroups are, so that it got its CUs a round late: 144 us under that load against 95 alone, profiles/r04/kernel_stats.csv)
+        const bool swap = forked && c->knob.ekf_side_stream == 6;
+        hipStream_t long_stream = forked && !swap ? c->aux_stream : main_stream, short_stream = swap ? c->aux_stream : main_stream;
         const bool long_first = presorted && (forked || c->knob.ekf_long_first != 0);
-        if (long_first) rc = long_prepare_gate(l_, e->sideH, e->sidev, e->side_acol, e->side_active, true, forked ? c->aux_stream : main_stream);
-        if (rc == HV_OK) rc = hv::launch_vu_prepare(c, s_, main_stream);
+        if (long_first) rc = long_prepare_gate(l_, e->sideH, e->sidev, e->side_acol, e->side_active, true, long_stream);
+        if (rc == HV_OK) rc = hv::launch_vu_prepare(c, s_, short_stream);
         if (rc == HV_OK && !long_first) rc = long_prepare_gate(l_, e->sideH, e->sidev, e->side_acol, e->side_active, true, main_stream);
         if (forked) {
             hipError_t he = hipEventRecord(e->ev_join, c->aux_stream);

@@ -15,6 +15,7 @@ E, S = int(sys.argv[1]), int(sys.argv[2])
 K = int(sys.argv[3]) if len(sys.argv) > 3 else 24
 MODE = os.environ.get("LP_MODE", "lanes")
 PRE = int(os.environ.get("LP_PRELOAD", "0"))
+EAGER = os.environ.get("LP_EAGER", "0") == "1"              # time eager launches instead of HIP-graph replay
 dev = 0
 torch.cuda.set_device(dev)
 keep = []
@@ -84,7 +85,10 @@ torch.cuda.synchronize()
 def step(k):
     for s, tb, eb, graphs in engines:
         with torch.cuda.stream(s):
-            graphs[k % bench.N_CYCLE].replay()
+            if EAGER:
+                tb.step(); eb.step()
+            else:
+                graphs[k % bench.N_CYCLE].replay()
 
 
 for k in range(bench.N_CYCLE):
@@ -99,4 +103,4 @@ for rep in range(3):
     res.append((time.perf_counter() - t0) / K * 1e3)
 ms = sorted(res)[1]
 knobs = {k: v for k, v in os.environ.items() if k.startswith("HV_")}
-print(f"LANES_PROBE mode={MODE} preload={PRE} engines={E}x{S} knobs={knobs}: {ms:.3f} ms per step of {E * S} frames -> {E * S / ms:.1f} k frames/s   (runs {['%.3f' % r for r in res]})")
+print(f"LANES_PROBE mode={MODE}{' eager' if EAGER else ''} preload={PRE} engines={E}x{S} knobs={knobs}: {ms:.3f} ms per step of {E * S} frames -> {E * S / ms:.1f} k frames/s   (runs {['%.3f' % r for r in res]})")
