@@ -2235,10 +2235,12 @@ static int visual_track_dev_impl(hv_ekf *h, const hv_vu_params *p, int np, const
         rc = HV_OK;
         // which class runs on which stream when the visit forks: the launch that has to START first -- the long class's, which needs
         // whole CUs and finds them only while the chip is empty -- belongs on the stream that does NOT wait for the fork event.
-        // knob 6 (r04): long class on the context stream, short class on the second stream. (3 / 5, r03's arrangement: the long
-        // class on the second stream, enqueued first -- but released by the fork event about when the short class's 810 two-per-CU
-        // workgroups are, so that it got its CUs a round late: 144 us under that load against 95 alone, profiles/r04/kernel_stats.csv)
-        const bool swap = forked && c->knob.ekf_side_stream == 6;
+        // r04 default (knob 6, and 5 = the lanes' form of it): long class on the context stream, short class on the second stream.
+        // Knob 3 = r03's arrangement: the long class on the second stream, enqueued first -- but released by the fork event about when
+        // the short class's 810 two-per-CU workgroups are, so that part of it got its CUs a round late (144 us under that load against
+        // 95 alone, profiles/r04/kernel_stats.csv). Measured, one context of 1024 sequences: eager 10.13 -> 9.82 ms per step, HIP-graph
+        // replay 9.67 -> 9.63 (profiles/r04/lanes_probe.txt, session 9).
+        const bool swap = forked && c->knob.ekf_side_stream != 3;
         hipStream_t long_stream = forked && !swap ? c->aux_stream : main_stream, short_stream = swap ? c->aux_stream : main_stream;
         const bool long_first = presorted && (forked || c->knob.ekf_long_first != 0);
         if (long_first) rc = long_prepare_gate(l_, e->sideH, e->sidev, e->side_acol, e->side_active, true, long_stream);

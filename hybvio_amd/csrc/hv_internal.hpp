@@ -66,7 +66,7 @@ struct Knobs {
     int ingest_gather = 0;        // HV_INGEST_GATHER: 1 = plain gather kernel for the remap
     int ekf_fused_gate = -1;      // HV_EKF_FUSED_GATE: column-sparse chi2 gate: -1 auto = 1 inside the prepare kernel, 2 own launch (ekf_sparse_gate_kernel), 0 off (dense kernels)
     int ekf_spec_mode = -1;       // HV_EKF_SPEC_MODE: speculative pass form: -1 auto, 2 = gate launch + apply launch, 3 = one launch with hand-shake
-    int ekf_side_stream = 3;      // HV_EKF_SIDE_STREAM, ragged visits with two length classes: 0 = one stream; non-zero (default 3, r03's numbering) = the long class's prepare + gate launch on the context's second stream, enqueued in front of the short class's fused launch (+6 % on the realistic C3 step); frame loops only (needs the per-frame sort of launch_visit_order); 6 = the fork with the roles swapped (long class on the context stream, which starts without waiting for the fork event; short class on the second stream); 5 (default of the contexts of an hv_lanes set) = like 3, but never inside a stream capture (a captured fork is replayed on a default-priority stream of the graph instance, not on the lane's own: ekf.hip). r03's other forms (1, 2, 4: whole long chain on the second stream / enqueued behind) measured slower and were removed in r04
+    int ekf_side_stream = 6;      // HV_EKF_SIDE_STREAM, ragged visits with two length classes inside a frame loop over more filters than CUs (needs the per-frame sort of launch_visit_order): 0 = one stream; 6 (default of hv_create) = the visit forks: long class's prepare + gate launch on the context stream, short class's fused launch on the context's second stream, joined in front of the update launches (+6 % on the realistic C3 step against 0); 3 = r03's arrangement of the fork (long class on the second stream, enqueued first: 3 % slower than 6 with eager launches, equal under graph replay); 5 (default of the contexts of an hv_lanes set) = 6, but never inside a stream capture (a captured fork is replayed on a default-priority stream of the graph instance, not on the lane's own: ekf.hip). r03's other forms (1, 2, 4: whole long chain on the second stream / enqueued behind) measured slower and were removed in r04
     int ekf_long_fused = 1;       // HV_EKF_LONG_FUSED: 1 (r04 default) = prepare + column-sparse gate of the long class (49 .. 84 rows) in ONE launch (vu_gate_long_kernel); 0 = r03's vu_compact_kernel + ekf_sparse_gate_big_kernel
     int ekf_long_first = 1;       // HV_EKF_LONG_FIRST: sorted ragged visits enqueue the long class's prepare + gate launch in front of (1) / behind (0) the short class's fused launch
     int ekf_dual_update = 1;      // HV_EKF_DUAL_UPDATE: 1 = ragged visits issue the short class's update and the long class's first block update as one grid (ekf_update_dual_kernel); 0 = one after the other

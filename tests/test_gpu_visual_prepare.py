@@ -37,6 +37,7 @@ VARIANTS = {
     "long_two_launches_sorted": {"ekf_long_fused": 0, "ekf_visit_order": 2},
     "long_two_launches_one_stream": {"ekf_long_fused": 0, "ekf_side_stream": 0, "ekf_visit_order": 2},
     "sorted_one_stream": {"ekf_side_stream": 0, "ekf_visit_order": 2},
+    "fork_r03_arrangement": {"ekf_side_stream": 3, "ekf_visit_order": 2},   # long class on the second stream (r04 default: on the context stream)
 }
 
 
@@ -525,7 +526,8 @@ def test_speculative_frame_loop_under_contention(variant):
     (48, False, True, "default", 21), (48, False, True, "vu384", 21), (10, False, True, "default", 21), (48, False, False, "default", 21),
     (48, False, True, "dense", 21), (48, False, True, "updates_one_by_one", 21), (48, False, True, "filter_order", 21), (48, False, True, "one_stream", 21),
     (48, False, True, "long_two_launches", 21), (48, False, True, "long_two_launches_sorted", 21), (48, False, True, "long_two_launches_one_stream", 21),
-    (48, False, True, "sorted_small_batch", 21), (48, False, True, "sorted_one_stream", 21),
+    (48, False, True, "sorted_small_batch", 21), (48, False, True, "sorted_one_stream", 21), (48, False, True, "fork_r03_arrangement", 21),
+    (300, False, True, "fork_r03_arrangement", 21),
     (300, False, True, "default", 21), (300, False, True, "one_stream", 21), (300, False, True, "long_two_launches", 21)])
 def test_whole_frame_loop_with_ragged_track_lengths(oracle, B, speculative, stereo, variant, np_max):
     """hv_ekf_visual_frame_ragged_dev: the sequences of a batch do not share track lengths -- every (visit, filter) record has its own
