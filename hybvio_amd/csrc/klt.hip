@@ -229,22 +229,13 @@ __global__ __launch_bounds__(64, WPS) void klt_kernel(KltArgs a)
     const float FLT_SCALE = 1.f / (float)(1 << 20);
     // uniform: pinned to SGPRs (the f64 -> f32 conversions are VALU instructions; left alone their results occupy two VGPRs for the
     // whole kernel, and the 5-waves-per-SIMD build has none to spare)
-#ifdef KLT_ALT
     const float eps_lo = a.eps_lo, eps_hi = a.eps_hi;
-#else
-    const float eps_lo = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint((float)(a.epsilon * (1.0 - 1e-5)))));
-    const float eps_hi = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint((float)(a.epsilon * (1.0 + 1e-5)))));
-#endif
     int st = 1;
     float errv = 0.f;
     float nx = 0.f, ny = 0.f;
 
     for (int level = L.levels - 1; level >= 0; --level) {
-#ifdef KLT_ALT
         const float lscale = __uint_as_float((127u - (unsigned)level) << 23);      // 2^-level exactly (levels < 127): no division sequence
-#else
-        const float lscale = 1.f / (float)(1 << level);
-#endif
         float px = pp.x * lscale, py = pp.y * lscale;
         if (level == L.levels - 1) {
             if (a.use_init) { nx = guess.x * lscale; ny = guess.y * lscale; }
@@ -547,16 +538,8 @@ __global__ __launch_bounds__(64, WPS) void klt_kernel(KltArgs a)
         // from the raw v_sqrt_f32 (1 ulp, no denormal fix-up, no division) unless the numerator lies within a few ulps of
         // its operands of the threshold; only then the correctly rounded sqrt and the IEEE division of the oracle run.
         const float tr = A22 + A11, disc = (A11 - A22) * (A11 - A22) + 4.f * A12 * A12;
-#ifdef KLT_ALT
         const float num_fast = tr - __builtin_amdgcn_sqrtf(disc), bound = a.eig_bound;
-#else
-        const float num_fast = tr - __builtin_amdgcn_sqrtf(disc), bound = a.min_eig * (float)(2 * WIN * WIN);
-#endif
-#ifdef KLT_ALT
         const float margin = 4e-6f * fabsf(tr) + a.eig_margin + 1e-30f;
-#else
-        const float margin = 4e-6f * fabsf(tr) + 1e-5f * bound + 1e-30f;
-#endif
         bool weak;
         if (fabsf(num_fast - bound) > margin) weak = num_fast < bound;
         else weak = (tr - sqrtf(disc)) / (float)(2 * WIN * WIN) < a.min_eig;
@@ -733,21 +716,12 @@ __global__ __launch_bounds__(64, WPS) void klt_kernel(KltArgs a)
 
 }  // namespace
 
-#ifndef KLT_ALT
-int launch_klt_alt(Ctx *c, int n_pairs, const int *prev_slots_dev, const int *next_slots_dev, int pts_per_pair, int n_points, const float *prev_xy,
-                   float *next_xy, uint8_t *status, float *err, int use_initial_flow, int max_iter, const int *pts_in_pair_dev);   // klt_alt.hip
-#endif
-
 int launch_klt(Ctx *c, int n_pairs, const int *prev_slots_dev, const int *next_slots_dev,
                int pts_per_pair, int n_points, const float *prev_xy, float *next_xy,
                uint8_t *status, float *err, int use_initial_flow, int max_iter, const int *pts_in_pair_dev)
 {
     (void)n_pairs;
     if (n_points <= 0) return HV_OK;
-#ifndef KLT_ALT
-    if (c->knob.klt_tile >= 6) return launch_klt_alt(c, n_pairs, prev_slots_dev, next_slots_dev, pts_per_pair, n_points, prev_xy, next_xy, status, err,
-                                                     use_initial_flow, max_iter, pts_in_pair_dev);   // A/B build (klt_alt.hip): 6 = tile variant 5, 7 = 1
-#endif
     KltArgs a{};
     a.L = c->L;
     a.slab = c->slab;
@@ -769,11 +743,7 @@ int launch_klt(Ctx *c, int n_pairs, const int *prev_slots_dev, const int *next_s
     ScopedKernelTime tm(c, HV_K_KLT);
     // knob klt_tile (HV_KLT_TILE at hv_create; experiments only): tile columns x rows / slack on the low side: 0 = 44 x 40 / 6, 4 (8 staging
     // passes of 5 rows), 1 = 40 x 36 / 2, 1 (6 passes of 6 rows), 2 = 40 x 42 / 2, 4 (7 passes), 5 = shape 1 compiled for 5 waves per SIMD (96 VGPRs; its 7.6 KB of LDS allow 20 waves per CU)
-#ifdef KLT_ALT
     const int tile_variant = c->knob.klt_tile == 7 ? 1 : 5;
-#else
-    const int tile_variant = c->knob.klt_tile;
-#endif
     if (pts_in_pair_dev)        hipLaunchKernelGGL((klt_kernel<40, 36, 2, 1, 5, true>), dim3((unsigned)n_points), dim3(64), 0, c->stream, a);
     else if (tile_variant == 1) hipLaunchKernelGGL((klt_kernel<40, 36, 2, 1, 4>), dim3((unsigned)n_points), dim3(64), 0, c->stream, a);
     else if (tile_variant == 2) hipLaunchKernelGGL((klt_kernel<40, 42, 2, 4, 4>), dim3((unsigned)n_points), dim3(64), 0, c->stream, a);
