@@ -274,6 +274,8 @@ class EkfBench:
 
 VISITS, QUOTA, NPOSE = 20, 5, 10       # maxVisualUpdates, maxSuccessfulVisualUpdates (parameter_definitions.c:8,10); 10 stereo poses = 40 rows
 FOCAL = 458.654                        # EuRoC cam0; the backend divides both measurement noises by it (backend.cpp:996-997)
+# HV_BENCH_SPLIT_SYM=1: the r03 sequence hv_ekf_symmetrize + hv_ekf_augment_dev instead of the one-pass entry (A/B; same values)
+FUSED_SYM_AUGMENT = os.environ.get("HV_BENCH_SPLIT_SYM", "0") != "1"
 R_GATE, R_UPDATE = 1.5 / FOCAL, 0.05 / FOCAL    # trackChiTestOutlierR, visualR (parameter_definitions.c:23,91) in normalised image units
 
 
@@ -479,9 +481,12 @@ class VisualEkfBench:
             e.visual_frame_dev(self.vp, VISITS, NPOSE, self.idx.data_ptr(), self.feat.data_ptr(), self.vel.data_ptr(), self.y.data_ptr(),
                                R_GATE, R_UPDATE, self.st.data_ptr(), self.gs.data_ptr(), self.counter.data_ptr(), QUOTA)
         self.applied += self.counter.sum()
-        e.symmetrize()
         self.last_drop = HANOI[self.k % len(HANOI)]
-        e.augment_dev(self.drop[self.k % len(HANOI)].data_ptr())
+        if FUSED_SYM_AUGMENT:
+            e.symmetrize_augment_dev(self.drop[self.k % len(HANOI)].data_ptr())   # maintainPositiveSemiDefinite + augmentation, one pass
+        else:
+            e.symmetrize()
+            e.augment_dev(self.drop[self.k % len(HANOI)].data_ptr())
         e.predict_n_dev(EKF_PREDICTS, self.dtn.data_ptr(), self.gyro.data_ptr(), self.acc.data_ptr())
         self.k += 1
 

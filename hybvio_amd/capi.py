@@ -128,6 +128,7 @@ PROTOTYPES = {
     "hv_ekf_visual_frame_ragged": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int] + [C.c_void_p] * 5 + [C.c_double, C.c_double] + [C.c_void_p] * 5 + [C.c_int]),
     "hv_ekf_visual_frame_ragged_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int] + [C.c_void_p] * 5 + [C.c_double, C.c_double] + [C.c_void_p] * 5 + [C.c_int]),
     "hv_ekf_augment_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "hv_ekf_symmetrize_augment_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "hv_ekf_visual_dev": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_double, C.c_int,
                                     C.c_void_p, C.c_void_p]),
     "hv_ekf_augment": (C.c_int, [C.c_void_p, i32p, u8p]),
@@ -676,6 +677,10 @@ class EkfBatch:
     def augment_dev(self, discarded_dev=0, active_dev=0):
         """hv_ekf_augment_dev: device arrays (or 0), asynchronous."""
         self._chk(lib().hv_ekf_augment_dev(self._h, C.c_void_p(discarded_dev), C.c_void_p(active_dev)), "hv_ekf_augment_dev")
+
+    def symmetrize_augment_dev(self, discarded_dev=0, active_dev=0):
+        """hv_ekf_symmetrize_augment_dev: symmetrize() + augment_dev() in one pass over P, asynchronous."""
+        self._chk(lib().hv_ekf_symmetrize_augment_dev(self._h, C.c_void_p(discarded_dev), C.c_void_p(active_dev)), "hv_ekf_symmetrize_augment_dev")
 
     def visual_frame_dev(self, params: VuParams, n_tracks, n_poses, pose_index_dev, features_dev, velocities_dev, y_dev, r_gate, r_update,
                          status_dev, gate_status_dev, success_counter_dev, max_successful, chi2_dev=0, pf_dev=0):

@@ -1370,6 +1370,11 @@ __device__ __forceinline__ void tri_decode(int p, int &I, int &J)
 // The kernel reads the covariance from P and writes the result to P1 (the host swaps the two
 // afterwards): the shifted matrix A P A' + Q is a gather of P and is never materialised, so the
 // covariance crosses HBM once in each direction instead of three + one times.
+// SYM (hv_ekf_symmetrize_augment_dev, r04): the covariance is read as (P + P') / 2 -- maintainPositiveSemiDefinite (ekf.cpp:1059-1067),
+// which the backend calls at the end of the visual updates (backend.cpp:1267), folded into the augmentation that follows it: the
+// mirrored element of every gathered value belongs to the tile pair the same wavefront reads anyway (L2 hits), and a separate
+// symmetrise launch is one more read and write of every covariance. Same values as the two calls in sequence, bit for bit.
+template <bool SYM>
 __global__ __launch_bounds__(AUG_THREADS) void ekf_augment_kernel(AugmentArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
@@ -1378,7 +1383,10 @@ __global__ __launch_bounds__(AUG_THREADS) void ekf_augment_kernel(AugmentArgs a)
     const double *P = a.P + (size_t)b * n * n;
     double *Pout = a.P1 + (size_t)b * n * n, *m1 = a.m1 + (size_t)b * n;
     if (a.active && !a.active[b]) {                                  // untouched filter: carry P over to the new buffer
-        for (int e = t; e < n * n; e += AUG_THREADS) Pout[e] = P[e];
+        for (int e = t; e < n * n; e += AUG_THREADS) {
+            if (SYM) { const int i = e % n, j = e / n; Pout[e] = 0.5 * (P[e] + P[(size_t)i * n + j]); }
+            else Pout[e] = P[e];
+        }
         return;
     }
     int dropped = a.dropped ? a.dropped[b] : a.dropped0;
@@ -1392,7 +1400,11 @@ __global__ __launch_bounds__(AUG_THREADS) void ekf_augment_kernel(AugmentArgs a)
     // P1 = A P A' + Q as a function (ekf.cpp:230-248, 848-871)
     auto p1 = [&](int i, int j) -> double {
         const int si = aug_src(i, dropped, n), sj = aug_src(j, dropped, n);
-        double v = (si >= 0 && sj >= 0) ? P[(size_t)sj * n + si] : 0.0;
+        double v = 0.0;
+        if (si >= 0 && sj >= 0) {
+            v = P[(size_t)sj * n + si];
+            if (SYM) v = 0.5 * (v + P[(size_t)si * n + sj]);
+        }
         if (i == j && i >= CAM && i < CAM + POSE) v += (i < CAM + 3) ? a.q_pos : a.q_ori;
         return v;
     };
@@ -2812,18 +2824,18 @@ int hv_ekf_augment(hv_ekf *h, const int *discarded, const unsigned char *active)
         static bool aug_attr_set_dev[64] = {};
         bool &aug_attr_set = aug_attr_set_dev[c->p.device & 63];
         if (!aug_attr_set) {
-            HV_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void *>(hv::ekf_augment_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024));
+            HV_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void *>(hv::ekf_augment_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024));
             aug_attr_set = true;
         }
     }
     hv::ScopedKernelTime tm(c, HV_K_EKF_AUGMENT);
-    hipLaunchKernelGGL(hv::ekf_augment_kernel, dim3(e->batch), dim3(hv::AUG_THREADS), shmem, c->stream, a);
+    hipLaunchKernelGGL(hv::ekf_augment_kernel<false>, dim3(e->batch), dim3(hv::AUG_THREADS), shmem, c->stream, a);
     HV_HIP(c, hipGetLastError());
     std::swap(e->P, e->P1);                 // the kernel wrote the new covariance to the other buffer
     return HV_OK;
 }
 
-int hv_ekf_augment_dev(hv_ekf *h, const int *discarded_dev, const unsigned char *active_dev)
+static int augment_dev_impl(hv_ekf *h, const int *discarded_dev, const unsigned char *active_dev, bool sym_input)
 {
     if (!h) return HV_ERR_INVALID;
     Ekf *e = &h->e; Ctx *c = e->c;
@@ -2837,11 +2849,15 @@ int hv_ekf_augment_dev(hv_ekf *h, const int *discarded_dev, const unsigned char 
     const size_t shmem = sizeof(double) * (3 * hv::POSE * e->n + 2 * hv::POSE * hv::POSE + hv::POSE + 1 + (hv::AUG_THREADS / 64) * 16 * 17);
     if (shmem > 64 * 1024) return HV_ERR_UNSUPPORTED;        // map-point states: use hv_ekf_augment (it raises the LDS limit)
     hv::ScopedKernelTime tm(c, HV_K_EKF_AUGMENT);
-    hipLaunchKernelGGL(hv::ekf_augment_kernel, dim3(e->batch), dim3(hv::AUG_THREADS), shmem, c->stream, a);
+    if (sym_input) hipLaunchKernelGGL(hv::ekf_augment_kernel<true>, dim3(e->batch), dim3(hv::AUG_THREADS), shmem, c->stream, a);
+    else           hipLaunchKernelGGL(hv::ekf_augment_kernel<false>, dim3(e->batch), dim3(hv::AUG_THREADS), shmem, c->stream, a);
     HV_HIP(c, hipGetLastError());
     std::swap(e->P, e->P1);
     return HV_OK;
 }
+
+int hv_ekf_augment_dev(hv_ekf *h, const int *discarded_dev, const unsigned char *active_dev) { return augment_dev_impl(h, discarded_dev, active_dev, false); }
+int hv_ekf_symmetrize_augment_dev(hv_ekf *h, const int *discarded_dev, const unsigned char *active_dev) { return augment_dev_impl(h, discarded_dev, active_dev, true); }
 
 int hv_ekf_undo_augment(hv_ekf *h, const unsigned char *active)
 {

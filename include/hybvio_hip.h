@@ -334,6 +334,11 @@ int hv_ekf_visual_track(hv_ekf *ekf, const hv_vu_params *p, int n_poses, const i
 int hv_ekf_augment(hv_ekf *ekf, const int *discarded /* [batch] or NULL */, const unsigned char *active);
 /* The same with device arrays (either may be NULL): no host copy, so a batch of sequences stays HIP-graph capturable. */
 int hv_ekf_augment_dev(hv_ekf *ekf, const int *discarded_dev, const unsigned char *active_dev);
+/* hv_ekf_symmetrize followed by hv_ekf_augment_dev in ONE pass over the covariances (ABI 3, r04): the end of a frame's visual
+ * updates (maintainPositiveSemiDefinite, backend.cpp:1267) and the pose augmentation that follows it. The augmentation reads
+ * every covariance element together with its mirror, so (P + P') / 2 is formed on the fly; results are bit-identical to the
+ * two calls in sequence (tests/test_gpu_ekf.py), inactive filters come out symmetrised and otherwise untouched. */
+int hv_ekf_symmetrize_augment_dev(hv_ekf *ekf, const int *discarded_dev, const unsigned char *active_dev);
 int hv_ekf_undo_augment(hv_ekf *ekf, const unsigned char *active);
 int hv_ekf_symmetrize(hv_ekf *ekf);                                 /* maintainPositiveSemiDefinite */
 int hv_ekf_normalize_quaternions(hv_ekf *ekf, int only_current);    /* ekf.cpp:1024-1032            */

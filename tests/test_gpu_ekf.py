@@ -266,6 +266,39 @@ def test_symmetrize_is_exact_and_undo_respects_active_mask(oracle, ctx):
         assert rel(g.get_state(0)[1], os_[0].P) < 1e-15
 
 
+def test_symmetrize_folded_into_the_augmentation_is_bit_identical(oracle, ctx):
+    """hv_ekf_symmetrize_augment_dev == hv_ekf_symmetrize then hv_ekf_augment_dev, bit for bit, on asymmetric covariances
+    (as the visual updates leave them), per-filter discard indices and an active mask: masked-out filters come out symmetrised
+    and otherwise untouched."""
+    import torch
+    rng = np.random.default_rng(11)
+    for trail in (20, 5, 1):
+        B = 5
+        _, ga = make_pair(oracle, ctx, rng, batch=B, trail=trail)
+        _, gb = make_pair(oracle, ctx, rng, batch=B, trail=trail)
+        n = ga.n
+        for b in range(B):
+            m, P = ga.get_state(b)
+            P = P + 1e-3 * np.abs(P).max() * rng.normal(size=(n, n))      # not symmetric
+            ga.set_state(b, m, P); gb.set_state(b, m, P)
+        ks = rng.integers(-1, trail, size=B).astype(np.int32)
+        for active in (None, np.array([1, 0, 1, 1, 0], np.uint8)):
+            kd = torch.from_numpy(ks).cuda()
+            ad = torch.from_numpy(active).cuda() if active is not None else None
+            ap = ad.data_ptr() if ad is not None else 0
+            ga.symmetrize(); ga.augment_dev(kd.data_ptr(), ap)
+            gb.symmetrize_augment_dev(kd.data_ptr(), ap)
+            ctx.synchronize()
+            for b in range(B):
+                ma, Pa = ga.get_state(b); mb, Pb = gb.get_state(b)
+                assert np.array_equal(ma, mb) and np.array_equal(Pa, Pb), (trail, b)
+                assert np.array_equal(Pb, Pb.T)
+            for b in range(B):                                              # asymmetric again for the masked round
+                m, P = ga.get_state(b)
+                P = P + 1e-3 * np.abs(P).max() * rng.normal(size=(n, n))
+                ga.set_state(b, m, P); gb.set_state(b, m, P)
+
+
 def test_mixed_discard_indices_and_active_mask(oracle, ctx):
     rng = np.random.default_rng(77)
     os_, g = make_pair(oracle, ctx, rng, batch=4)
