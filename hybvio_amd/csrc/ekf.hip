@@ -424,6 +424,12 @@ struct UpdateArgs {
     // into CHI2 -- what every other mode reports for a broken factorisation --, so that block 2 (require_inlier) skips the record
     // instead of applying half an update on a stale dm_in (r03 advisor)
     int *gate_rw;
+    // speculative frame loop over LONG records (spec 2 with half 1 / 2, r04): the record a filter applies is chosen by the scan of the
+    // half-1 launch; `half_auto` makes the block split a per-record decision -- a record of at most 48 rows is applied whole by the
+    // half-1 launch (normalisation, success count and cursor included) and skipped by the half-2 launch, a longer one takes both --,
+    // and sel_io [batch] carries the chosen track of a long record (-1: none) from the half-1 launch to the half-2 launch, which
+    // must not scan again: the first launch may have moved the cursor or turned the record's gate status into CHI2
+    int half_auto; int *sel_io;
     int batch;
     const int *rec_count, *rec_list;  // compaction list (VuPrepareArgs): workgroup i updates filter rec_list[i], i < *rec_count; the others exit
 };
@@ -461,7 +467,8 @@ constexpr int UPD_THREADS = 512;   // 8 waves = 2 per SIMD: 256 VGPRs each (whol
 // MODE 2: T and H in LDS (n <= 160, nr <= 48): K-split products, P read from HBM exactly once
 // TI (MODE 2 only): 16-row tiles of H, nr <= 16 TI: a compile-time count keeps the MFMA loops free of
 // branches (a uniform branch per tile made hipcc wait for each LDS operand right before its MFMA).
-template <int MODE, int TI>
+// AUTO: the half_auto form of the speculative loop over long records (its own kernel: the other instantiations keep their registers)
+template <int MODE, int TI, bool AUTO = false>
 __device__ __forceinline__ void ekf_update_body(const UpdateArgs &a, const int b_in /* filter: blockIdx.x, or an entry of a compaction list */)
 {
     // (a list entry is a per-lane load: on the scalar unit the filter's base addresses are uniform and its gathers become scalar base +
@@ -475,9 +482,19 @@ __device__ __forceinline__ void ekf_update_body(const UpdateArgs &a, const int b
         const int j = blockIdx.y;
         if (j < a.cursor[b] || a.success_counter[b] >= a.max_successful) return;
         e = j * (int)gridDim.x + b;
+    } else if (AUTO && a.spec == 2 && a.half == 2) {
+        // second block of the long record the half-1 launch chose for this filter (if any)
+        sel = a.sel_io[b];
+        if (sel < 0) return;
+        e = sel * (int)gridDim.x + b;
+        if (a.gate_in[e] != 0) {                           // block 1 met a non-positive pivot (status CHI2 now): nothing applied, the track is final
+            if (threadIdx.x == 0) a.cursor[b] = sel + 1;
+            return;
+        }
     } else if (a.spec == 2) {
         // every thread runs the same short scan (uniform): the first pending track that passed its gate
         const int c0 = a.cursor[b];
+        if (AUTO && threadIdx.x == 0) a.sel_io[b] = -1;      // (thread 0 also writes the choice below: program order)
         if (c0 >= a.n_tracks || a.success_counter[b] >= a.max_successful) return;
         for (int j = c0; j < a.n_tracks && sel < 0; ++j) {
             const int ee = j * (int)gridDim.x + b;
@@ -520,15 +537,23 @@ __device__ __forceinline__ void ekf_update_body(const UpdateArgs &a, const int b
     const int n = a.n, l = a.l;
     int nr = a.nr, R = a.Rs, Rfull = a.R;                   // R is the column STRIDE of T below; Rfull rows are used
     int roff = 0, ld = a.nr;                               // first row of this launch's block inside the record; leading dimension of H
+    int half = a.half;                                     // (half_auto: this record's own split, see UpdateArgs)
     if (a.nr_rec || a.half) {                              // ragged batch / block update: this record's own shape (uniform per workgroup)
         int nr_full = __builtin_amdgcn_readfirstlane(nr_rec_v);
         if (nr_full < 1 || nr_full > a.v_stride) return;    // no track (the prepare launch also cleared `active`)
         nr = nr_full; ld = nr_full;
-        if (a.half) {
+        if constexpr (AUTO) {
+            if (nr_full <= 48) {
+                if (half == 2) return;
+                half = 0;
+            }
+            if (half == 1 && t == 0) a.sel_io[b] = sel;
+        }
+        if (half) {
             if (MODE != 2) return;                         // (the host only asks the LDS-resident kernels for block updates)
             const int h1 = 2 * ((nr_full + 3) >> 2);
-            roff = a.half == 2 ? h1 : 0;
-            nr = a.half == 2 ? nr_full - h1 : h1;
+            roff = half == 2 ? h1 : 0;
+            nr = half == 2 ? nr_full - h1 : h1;
         }
         if (nr < 1 || nr > a.nr) return;
         Rfull = nr + n + 1; R = Rfull;
@@ -894,6 +919,7 @@ __device__ __forceinline__ void ekf_update_body(const UpdateArgs &a, const int b
             }
             *s_stop = (a.mode == 0) || broken || ((a.mode == 2 || (two_r && pass == 0)) && outlier);
             if (broken && a.gate_rw) a.gate_rw[e] = 3 /*CHI2*/;
+            if (AUTO && broken && a.spec == 2 && half != 1) a.cursor[b] = sel + 1;     // (whole short record or block 2: not applied, the track is final)
             if (a.spec == 3 && pass == 0) {
                 const int j = blockIdx.y;
                 spec_publish(a, e, outlier ? 1 : 2);
@@ -929,7 +955,7 @@ __device__ __forceinline__ void ekf_update_body(const UpdateArgs &a, const int b
         double s = 0;
         for (int c = 0; c < nr; c++) s += T[(size_t)c * R + ry + j] * T[(size_t)c * R + rv];
         m[j] += s;
-        if (a.dm_out) a.dm_out[(size_t)b * n + j] = s;
+        if (a.dm_out && !(AUTO && half == 0)) a.dm_out[(size_t)b * n + j] = s;
     }
     // ---- F: P -= Y' Y ----
     if constexpr (MODE == 2) {
@@ -1004,10 +1030,11 @@ __device__ __forceinline__ void ekf_update_body(const UpdateArgs &a, const int b
     __syncthreads();
     PHASE_STAMP(5);
     // ---- G: quaternion normalisation (updateCommon ekf.cpp:29-31 / normalizeQuaternions 1024-1032) ----
-    const int nq = a.normalize_all < 0 ? 0 : a.normalize_all ? 1 + (n - a.map_dim - CAM) / POSE : 1;     // map points behind the trail are not poses (< 0: first block of a long track)
+    const bool first_block = AUTO ? half == 1 : a.normalize_all < 0;                              // of a long track: no normalisation yet
+    const int nq = first_block ? 0 : (a.normalize_all != 0) ? 1 + (n - a.map_dim - CAM) / POSE : 1;      // map points behind the trail are not poses
     if (t < nq) normalize4(m + (t == 0 ? ORI : CAM + POSE * (t - 1) + 3));
-    if (a.success_counter && t == 0) a.success_counter[b] += 1;
-    if (a.spec == 2 && t == 0) a.cursor[b] = sel + 1;      // the tracks up to the applied one are final, the rest is re-examined
+    if (a.success_counter && t == 0 && !(AUTO && half == 1)) a.success_counter[b] += 1;
+    if (a.spec == 2 && t == 0 && !(AUTO && half == 1)) a.cursor[b] = sel + 1;      // the tracks up to the applied one are final, the rest is re-examined
     if (a.spec == 3 && t == 0) a.cursor_out[b] = (int)blockIdx.y + 1;
 }
 
@@ -1020,6 +1047,12 @@ __global__ __launch_bounds__(UPD_THREADS) void ekf_update_kernel(UpdateArgs a)
     int b = blockIdx.x;
     if (a.rec_list) { if ((int)blockIdx.x >= *a.rec_count) return; b = a.rec_list[blockIdx.x]; }
     ekf_update_body<MODE, TI>(a, b);
+}
+
+// the update launches of the speculative loop over long records (UpdateArgs::half_auto), MODE 2, three row tiles
+__global__ __launch_bounds__(UPD_THREADS) void ekf_update_spec_long_kernel(UpdateArgs a)
+{
+    ekf_update_body<2, 3, true>(a, blockIdx.x);
 }
 
 // Two masked update launches in ONE grid (ragged visits: the inliers of the short class and the first block of the long class's
@@ -1701,7 +1734,8 @@ struct Ekf {
 
 // compact-H description handed to ekf_launch_update (null acol: dense H of l columns); half / nr_full / dm: block update of a long
 // track (UpdateArgs::half)
-struct CompactH { const int *acol = nullptr; int na_max = 0, ncam = 1; int half = 0, nr_full = 0; double *dm = nullptr; const int *rec_count = nullptr, *rec_list = nullptr; int *gate_rw = nullptr; };
+struct CompactH { const int *acol = nullptr; int na_max = 0, ncam = 1; int half = 0, nr_full = 0; double *dm = nullptr; const int *rec_count = nullptr, *rec_list = nullptr; int *gate_rw = nullptr;
+                  int half_auto = 0; int *sel_io = nullptr; };
 
 // an update launch prepared but not issued (ekf_launch_update's `defer`): two of them can share one grid (ekf_launch_update_dual)
 struct UpdateLaunch { UpdateArgs a; size_t base_bytes = 0; int kmode = -1, ti = 0, lbk = 0; };
@@ -1742,6 +1776,8 @@ static int ekf_launch_update(Ekf *e, int nr, int l, const double *H_dev, const d
         if (a.half == 1) { a.dm_out = compact->dm; a.gate_rw = compact->gate_rw; }
         if (a.half == 2) a.dm_in = compact->dm;
         a.rec_count = compact->rec_count; a.rec_list = compact->rec_list;
+        a.half_auto = compact->half_auto; a.sel_io = compact->sel_io;
+        if (a.half_auto && (spec != 2 || !a.half || !a.sel_io || !a.dm_out == !a.dm_in)) return HV_ERR_INVALID;
     }
     size_t tall = (((size_t)a.Rs * nr + 1) & ~(size_t)1) * sizeof(double);
     const size_t small = (size_t)(256 + 544 + UPD_THREADS / 64 + 2) * sizeof(double);           // W + col (incl. dump area) + red + flag
@@ -1768,13 +1804,14 @@ static int ekf_launch_update(Ekf *e, int nr, int l, const double *H_dev, const d
         return HV_OK;
     }
     using Kern = void (*)(UpdateArgs);
-    const Kern kern = kmode == 0 ? (Kern)ekf_update_kernel<0, 0> : kmode == 1 ? (Kern)ekf_update_kernel<1, 0>
+    if (a.half_auto && (kmode != 2 || ti != 3)) return HV_ERR_INVALID;
+    const Kern kern = a.half_auto ? (Kern)ekf_update_spec_long_kernel : kmode == 0 ? (Kern)ekf_update_kernel<0, 0> : kmode == 1 ? (Kern)ekf_update_kernel<1, 0>
                     : ti == 1 ? (Kern)ekf_update_kernel<2, 1> : ti == 2 ? (Kern)ekf_update_kernel<2, 2> : (Kern)ekf_update_kernel<2, 3>;
     // the attribute is per device: one flag per device ordinal (several contexts / devices may live in one process)
     static bool attr_set_dev[64] = {};
     bool &attr_set = attr_set_dev[c->p.device & 63];
     if (!attr_set) {
-        for (Kern k : { (Kern)ekf_update_kernel<1, 0>, (Kern)ekf_update_kernel<2, 1>, (Kern)ekf_update_kernel<2, 2>, (Kern)ekf_update_kernel<2, 3> })
+        for (Kern k : { (Kern)ekf_update_kernel<1, 0>, (Kern)ekf_update_kernel<2, 1>, (Kern)ekf_update_kernel<2, 2>, (Kern)ekf_update_kernel<2, 3>, (Kern)ekf_update_spec_long_kernel })
             HV_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set = true;
     }
@@ -2368,6 +2405,67 @@ static int visual_frame_dev_impl(hv_ekf *h, const hv_vu_params *p, int n_tracks,
     // tracks behind it are re-examined: <= min(max_successful, n_tracks) + 1 passes, the same statuses and the same filter as the
     // sequential loop (tracks in front of the first inlier saw the state they would have seen anyway).
     const int rows = 2 * (int)nt;
+    // Long tracks (49 .. 84 rows; ragged frames whose longest track is that long: the reference's default stereo configuration, SURVEY
+    // app. B) -- r04, VERDICT r03 item 6: the same speculative loop with the long build of the fused prepare + gate launch serving EVERY
+    // pending record of whatever length (grid (filters, tracks), one 158 KB workgroup per CU while the chip is idle), and the first
+    // pending inlier applied by the two block-update launches of the long class: a record of at most 48 rows whole by the first of them,
+    // a longer one block by block (UpdateArgs::half_auto; sel_io hands the chosen track from the first launch to the second).
+    // <= quota + 1 passes of three launches instead of n_tracks visits of four.
+    if (!c->knob.ekf_no_speculation && !adaptive && n_tracks >= 2 && B * (size_t)n_tracks <= (size_t)c->num_cus && rows > 48 && p && idx && feat && vel && y &&
+        c->knob.ekf_spec_split == 0 && c->knob.ekf_spec_mode != 3 && c->knob.ekf_long_fused != 0 && visit_shape(e, np, p->useStereo != 0).long_ok) {
+        const size_t rec = B * (size_t)n_tracks;
+        if (e->sp_records < rec || e->sp_rows < rows) {
+            HV_HIP(c, hipStreamSynchronize(c->stream));
+            void *old[] = {e->spH, e->spv, e->sppf, e->spactive, e->spcursor, e->spepoch, e->spcursor2, e->sppub, e->spacol, e->sprows};
+            for (void *q : old) if (q) (void)hipFree(q);
+            e->spH = e->spv = e->sppf = nullptr; e->spactive = nullptr; e->spcursor = e->spepoch = e->spcursor2 = e->sppub = e->spacol = e->sprows = nullptr; e->sp_records = 0;
+            HV_HIP(c, hipMalloc(reinterpret_cast<void **>(&e->spH), sizeof(double) * rec * rows * e->n));
+            HV_HIP(c, hipMalloc(reinterpret_cast<void **>(&e->spv), sizeof(double) * rec * rows));
+            HV_HIP(c, hipMalloc(reinterpret_cast<void **>(&e->sppf), sizeof(double) * rec * 3));
+            HV_HIP(c, hipMalloc(reinterpret_cast<void **>(&e->spactive), rec));
+            HV_HIP(c, hipMalloc(reinterpret_cast<void **>(&e->spcursor), sizeof(int) * B));
+            HV_HIP(c, hipMalloc(reinterpret_cast<void **>(&e->spepoch), sizeof(int) * rec));
+            HV_HIP(c, hipMalloc(reinterpret_cast<void **>(&e->spcursor2), sizeof(int) * B));
+            HV_HIP(c, hipMalloc(reinterpret_cast<void **>(&e->sppub), sizeof(int) * rec));
+            HV_HIP(c, hipMalloc(reinterpret_cast<void **>(&e->spacol), sizeof(int) * rec * e->n));
+            HV_HIP(c, hipMalloc(reinterpret_cast<void **>(&e->sprows), sizeof(int) * rec));
+            e->sp_records = rec; e->sp_rows = rows;
+        }
+        if (!e->side_dm) {
+            HV_HIP(c, hipMalloc(reinterpret_cast<void **>(&e->side_dm), sizeof(double) * (size_t)e->n * B));
+            HV_HIP(c, hipMemsetAsync(e->side_dm, 0, sizeof(double) * (size_t)e->n * B, c->stream));
+        }
+        HV_HIP(c, hipMemsetAsync(e->spcursor, 0, sizeof(int) * B, c->stream));
+        HV_HIP(c, hipMemsetAsync(e->spcursor2, 0xFF, sizeof(int) * B, c->stream));                // sel_io: -1
+        HV_HIP(c, hipMemsetAsync(e->spepoch, 0xFF, sizeof(int) * rec, c->stream));               // -1: nothing prepared yet
+        hv::VuPrepareArgs a;
+        int rc = vu_fill_args(e, p, np, idx, feat, vel, y, a);
+        if (rc != HV_OK) return rc;
+        const double ns = e->noise_scale;
+        const int ncam = a.stereo ? 2 : 1;
+        a.H = nullptr; a.v = e->spv; a.f = nullptr; a.pf = pf_dev ? pf_dev : e->sppf; a.status = status_dev; a.active = e->spactive;
+        a.gate_status = gate_status_dev; a.success_counter = success_counter_dev; a.max_successful = max_successful;
+        a.spec_tracks = n_tracks; a.cursor = e->spcursor; a.epoch = e->spepoch;
+        const int *nr_rec = nullptr;
+        if (np_rec_dev) { a.np_rec = np_rec_dev; a.rows_out = e->sprows; nr_rec = e->sprows; }
+        a.fused = 3; a.Hc = e->spH; a.acol = e->spacol; a.na_max = 7 * np + 1; a.P = e->P;
+        a.rd_gate = r_gate * r_gate * ns; a.noise_scale = ns; a.chi2 = chi2_dev;
+        hv::CompactH h1{e->spacol, a.na_max, ncam, 1, rows, e->side_dm, nullptr, nullptr, gate_status_dev}, h2{e->spacol, a.na_max, ncam, 2, rows, e->side_dm};
+        h1.half_auto = h2.half_auto = 1; h1.sel_io = h2.sel_io = e->spcursor2;
+        const int n_pass = (max_successful < n_tracks ? max_successful : n_tracks) + 1;
+        for (int pass = 0; pass < n_pass; ++pass) {
+            rc = hv::launch_vu_prepare(c, a);
+            if (rc != HV_OK) return rc;
+            for (const hv::CompactH *hh : {&h1, &h2}) {
+                // (48 rows per launch: a whole short record, or the longer block of an 84-row one)
+                rc = hv::ekf_launch_update(e, 48, e->n, e->spH, e->spv, nullptr, r_update * r_update * ns, 1, 0, hh == &h1 ? -1 : 1, nullptr,
+                                           nullptr, e->spactive, nullptr, success_counter_dev, 0.0, nullptr, 2, n_tracks, e->spcursor, max_successful,
+                                           gate_status_dev, nullptr, nullptr, 0, nr_rec, hh, rows);
+                if (rc != HV_OK) return rc;
+            }
+        }
+        return HV_OK;
+    }
     // (a growth factor != 1 makes the threshold of a track depend on the verdicts of the tracks in front of it: no parallel gating)
     if (!c->knob.ekf_no_speculation && !adaptive && n_tracks >= 2 && B * (size_t)n_tracks <= 256 && e->n <= 160 && rows <= 48 && p && idx && feat && vel && y) {
         const size_t rec = B * (size_t)n_tracks;

@@ -1124,7 +1124,8 @@ int launch_vu_prepare(Ctx *c, const VuPrepareArgs &a, hipStream_t stream)
     if (a.fused && (!a.Hc || !a.acol || a.na_max < 7 * a.np + 1)) return HV_ERR_INVALID;
     if (a.fused == 3) {                                      // long class: 12 .. 21 stereo poses (49 .. 84 rows; 48 rows ride along), n <= 160
         const int rows = 2 * nt;
-        if (!a.P || a.spec_tracks > 0 || a.n > 160 || rows > HV_GATE_TIGHT_ROWS || rows >= HV_CHI2INV95_N) return HV_ERR_UNSUPPORTED;
+        // (speculative frame loop, r04: grid (filters, tracks), never listed -- every pending record of whatever length on this build)
+        if (!a.P || (a.spec_tracks > 0 && a.rec_list) || a.n > 160 || rows > HV_GATE_TIGHT_ROWS || rows >= HV_CHI2INV95_N) return HV_ERR_UNSUPPORTED;
     }
     static bool attr_set_dev[64] = {};                       // per device: the kernels need more than the default 64 KB of dynamic LDS
     bool &attr_set = attr_set_dev[c->p.device & 63];
