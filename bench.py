@@ -467,7 +467,8 @@ class VisualEkfBench:
         if cam == 1:
             self.feat.copy_(self.c_feat_pad[:, :, :2 * NP])
 
-    def step(self):
+    def visual(self):
+        """trackerVisualUpdate of the frame (backend.cpp:1012-1252): the visit loop, on the device mean."""
         mv, Pv = self._views()
         if self.chained:
             self._regenerate_tracks(mv)                     # no state restore: the filters evolve, their tracks follow the device mean
@@ -481,6 +482,11 @@ class VisualEkfBench:
             e.visual_frame_dev(self.vp, VISITS, NPOSE, self.idx.data_ptr(), self.feat.data_ptr(), self.vel.data_ptr(), self.y.data_ptr(),
                                R_GATE, R_UPDATE, self.st.data_ptr(), self.gs.data_ptr(), self.counter.data_ptr(), QUOTA)
         self.applied += self.counter.sum()
+
+    def propagate(self):
+        """What the filter does between two camera frames and needs no image for: maintainPositiveSemiDefinite + pose augmentation,
+        then the IMU predicts up to the next frame (backend.cpp:1267, 804-805, 716-760)."""
+        e = self.ekf
         self.last_drop = HANOI[self.k % len(HANOI)]
         if FUSED_SYM_AUGMENT:
             e.symmetrize_augment_dev(self.drop[self.k % len(HANOI)].data_ptr())   # maintainPositiveSemiDefinite + augmentation, one pass
@@ -490,6 +496,9 @@ class VisualEkfBench:
         e.predict_n_dev(EKF_PREDICTS, self.dtn.data_ptr(), self.gyro.data_ptr(), self.acc.data_ptr())
         self.k += 1
 
+    def step(self):
+        self.visual()
+        self.propagate()
 
 def verify_c3(tb, eb, n_check, seed=0, frame=None):
     """Parity of the benchmarked configuration itself, OUTSIDE the timed region: n_check of the B
@@ -1704,10 +1713,10 @@ def main():
         lat3 = (time.perf_counter() - t0) / n_lat
         out["latency_mode"] = {"sequences": 1, "ms_per_frame": lat3 * 1e3, "frames_per_s": 1.0 / lat3, "launch": "eager",
                                # pyramid 4 (L0, L1, L2, L3 + border as one: per-level launches below 64 images) + 2 LK + RANSAC + detector,
-                               # visual update 2 x (quota + 1), symmetrise + augmentation + predicts
-                               "launches_per_frame": 5 + 2 + 1 + 1 + 2 * (QUOTA + 1) + 3,
-                               "visual_update_loop": "sequential, two length classes per visit (the headline's ragged tracks reach 84 rows; the speculative "
-                                                     "loop serves <= 48 rows: latency_mode_uniform)"}
+                               # visual update 3 x (quota + 1), symmetrise-augmentation + predicts
+                               "launches_per_frame": 5 + 2 + 1 + 1 + 3 * (QUOTA + 1) + 2,
+                               "visual_update_loop": "speculative (r04: also for the headline's ragged tracks of up to 84 rows): <= quota + 1 passes of (fused prepare + "
+                                                     "gate of every pending track, one launch) + (apply the first inlier: two block-update launches)"}
         # the same with r02's uniform 10-pose tracks (40 rows: the speculative visit loop applies), for round-over-round comparison
         try:
             e1u = VisualEkfBench(t1.ctx, 1, local_rank, seed=12345, realistic=False)
@@ -1755,6 +1764,10 @@ def main():
             del graphs
         except Exception as ex:                               # pragma: no cover
             out["latency_mode_graph"] = {"error": repr(ex)[:300]}
+        # (r04 also measured the frame as the DAG it is -- fork { maintainPSD + augmentation + predicts | pyramids + LK + RANSAC } -> visual
+        #  updates -> join on two lanes of one hv_lanes set, captured into the frame's graph: 2.10 ms per frame replayed, 1.26 ms eager, against
+        #  0.94 / 0.97 on one stream on the same box (scripts/r04_run17.sh). Every cross-stream edge costs more than the 75 us of filter
+        #  work the fork can hide at ONE sequence; the leg was removed again, VisualEkfBench keeps visual() / propagate() apart.)
         e1.ekf.close()
         del e1
         t1.chain = False
