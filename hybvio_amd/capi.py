@@ -154,6 +154,8 @@ def lib():
     global _LIB
     if _LIB is None:
         path = _build.build_hip()
+        # HV_LIB_OVERRIDE (developer A/B runs only): another build of the same library, e.g. the previous commit's, in the same process setup
+        path = os.environ.get("HV_LIB_OVERRIDE", path)
         if not os.path.exists(path):
             raise HvError(f"{path} missing: the HIP extension is required, there is no fallback")
         L = C.CDLL(path)

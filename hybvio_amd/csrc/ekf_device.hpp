@@ -142,6 +142,275 @@ __device__ __forceinline__ void factor_diag_block(double *T, double *W, double *
 }
 
 
+// Workgroup barrier that orders LDS traffic only: __syncthreads() also drains every outstanding GLOBAL access of the wave (s_waitcnt
+// vmcnt(0) in front of the s_barrier), i.e. exposes the HBM latency of stores nobody in the kernel reads back. For phases that talk
+// through LDS alone (global loads are waited for where their registers are used, as always).
+__device__ __forceinline__ void lds_barrier()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
+// Second half of a chi2 gate, by one workgroup of NT threads: T holds the lower triangle of H P H' (column-major, stride Rs) and v' in row
+// nr; adds R = rd I, runs the blocked Cholesky of [S; v'] and returns chi2 = noise_scale z'z in every thread (a non-positive pivot leaves
+// inf / NaN in it). work: >= 816 + NT / 64 doubles of LDS scratch. The caller has synchronised the workgroup behind its last write of T.
+template <int NT>
+__device__ __forceinline__ double gate_factor_chi2(double *T, int Rs, int nr, double rd, double noise_scale, double *work, long long *stamps = nullptr)
+{
+#ifdef HV_EKF_PHASE_STAMPS
+#define GATE_STAMP(i) do { if (stamps && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) stamps[i] = (long long)__builtin_readcyclecounter(); } while (0)
+#else
+#define GATE_STAMP(i) do { (void)stamps; } while (0)
+#endif
+    const int t = threadIdx.x, lane = t & 63, kq = lane >> 4, cl = lane & 15;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    constexpr int nwaves = NT / 64;
+    for (int i = t; i < nr; i += NT) T[(size_t)i * Rs + i] += rd;
+    double *W = work, *col = work + 256, *red = work + 256 + 544;
+    lds_barrier();
+    // blocked Cholesky of [S; v'] (ekf_update_kernel phase C restricted to the measurement rows). The diagonal blocks are factored by ONE
+    // wave (a ~340-cycle dependent chain per pivot that keeps its SIMD's issue port about half busy): the workgroups that share a CU use
+    // different waves for it (wave w sits on SIMD w % 4; workgroups 256 apart in the grid land on the same CU in the first rounds), or
+    // their chains queue up on SIMD 0 while the other three idle.
+    const int chol_wave = __builtin_amdgcn_readfirstlane((int)((blockIdx.x >> 8) & 3u));
+    const int Rlim = nr + 1;
+    for (int j0 = 0; j0 < nr; j0 += 16) {
+        const int w = min(16, nr - j0);
+        const int ntile = (Rlim - j0 + 15) / 16;
+        if (j0 > 0) {
+            for (int tile = wave; tile < ntile; tile += nwaves) {
+                const int i0 = j0 + 16 * tile, mi = Rlim - i0;
+                const double4v acc = mfma_tile(T + i0, 1, Rs, mi, T + j0, Rs, 1, w, j0);
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const int i = kq + 4 * q;
+                    if (i < mi && cl < w) T[(size_t)(j0 + cl) * Rs + i0 + i] -= acc[q];
+                }
+            }
+            lds_barrier();
+        }
+        if (wave == chol_wave) { if (w <= 8) factor_diag_block<8>(T, W, col, Rs, j0, w, lane); else factor_diag_block<16>(T, W, col, Rs, j0, w, lane); }
+        lds_barrier();
+        for (int i0 = j0 + w + 16 * wave; i0 < Rlim; i0 += 16 * nwaves) {
+            const int mi = Rlim - i0;
+            const double4v acc = mfma_tile(T + (size_t)j0 * Rs + i0, 1, Rs, mi, W, 16, 1, 16, w);
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const int i = kq + 4 * q;
+                if (i < mi && cl < w) T[(size_t)(j0 + cl) * Rs + i0 + i] = acc[q];
+            }
+        }
+        lds_barrier();
+    }
+    GATE_STAMP(1);
+    double sz = 0;
+    for (int c = t; c < nr; c += NT) { const double z = T[(size_t)c * Rs + nr]; sz += z * z; }
+    for (int o = 32; o > 0; o >>= 1) sz += __shfl_down(sz, o);
+    if (lane == 0) red[wave] = sz;
+    lds_barrier();
+    double tot = 0;
+#pragma unroll
+    for (int w2 = 0; w2 < nwaves; w2++) tot += red[w2];
+    GATE_STAMP(2);
+    return tot * noise_scale;
+#undef GATE_STAMP
+}
+
+// ---------------------------------------------------------------------------------------------
+// S = Hc P(a, a) Hc' of ONE track from the FACTORS of its Jacobian (r04), by one workgroup of NT threads on the vector unit.
+// On gfx950 v_mfma_f64_16x16x4 issues every 64 cycles per SIMD -- the f64 matrix peak IS the f64 vector peak (scripts/f64_ubench.hip) --
+// so the dense products of sparse_gate buy nothing per flop, and prepareVisualUpdate's Jacobian (triangulation.cpp:940-980) has structure
+// they cannot use. On its active columns
+//     Hc = Dp + O4 F4
+//   Dp (nr x na): rows 2i, 2i+1 (observation i) hold 7 values, in the columns of the observation's OWN pose k_i (-dip R | dip dRpt)
+//   O4 (nr x 4):  dip R -- the projection's derivative w.r.t. the triangulated point -- and the negated feature velocity
+//   F4 (4 x na):  the point's derivative w.r.t. every active column (dpf, and dpfi's time-shift column); the unit row of that column
+// and with W = P(a, a), W(u', u) = P[a_u N + a_u'] (read as stored, no symmetry assumed), A = W Dp' (na x nr), WF = W F4' (na x 4):
+//     S = Dp A + (Dp WF) O4' + O4 (F4 A + (F4 WF) O4')
+// ONE pass over W: lane u' loads the 7 values W(u', columns of pose k) and forms the 2 ncam entries of A(u', rows of pose k) and its
+// share of WF(u', :) from them; S1 = Dp A (7 multiply-adds per entry) and FA = F4 A follow per group of poses while A is in LDS, the
+// rank-4 terms at the end: 0.25 M multiply-adds for a 21-pose stereo track where the dense form spends 3.1 M (2220 + 840 MFMAs: 79 k
+// of the long gate's 208 k cycles; 16 poses 35 k of 130 k; 12 poses 25 k of 102 k -- profiles/r04/phase_stamps_one_track_visit.txt).
+// Same S up to the summation order. A does not fit beside the factors for the longest tracks: the poses are then served in two groups.
+// Deterministic: no atomics, partial sums meet in a fixed order.
+// LDS: O4 [nr][4], DV [nr][7] (Dp's values), F4 [4][f4s], WF [na][4], WFp [slots][na][3], FA [4][nr], DWF [nr][4], FWF [16] and G (g_cap
+// doubles) -- all disjoint from T; acol [na]. The caller has written O4 / DV / F4 and synchronised; T is zeroed, v' in row nr. Ends synchronised.
+// ---------------------------------------------------------------------------------------------
+// PREFETCH: the next pose's 7 values are requested before this pose's sums (14 more VGPRs: not in the 128-register two-per-CU build,
+// where the other workgroup of the CU covers the round trip)
+template <int NT, bool PREFETCH>
+__device__ __forceinline__ void structured_S(const double *P, int N, const int *acol, int na, int n, int ncam, int nr,
+                                             const double *O4, const double *DV, const double *F4, int f4s, double *WF, double *WFp, double *FA,
+                                             double *DWF, double *FWF, double *G, int g_cap, double *T, int Rs, long long *stamps = nullptr)
+{
+#ifdef HV_EKF_PHASE_STAMPS
+#define SS_STAMP(i) do { if (stamps && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) stamps[i] = (long long)__builtin_readcyclecounter(); } while (0)
+#else
+#define SS_STAMP(i) do { (void)stamps; } while (0)
+#endif
+    const int t = threadIdx.x;
+    SS_STAMP(0);
+    N = __builtin_amdgcn_readfirstlane(N); na = __builtin_amdgcn_readfirstlane(na); n = __builtin_amdgcn_readfirstlane(n);
+    ncam = __builtin_amdgcn_readfirstlane(ncam); nr = __builtin_amdgcn_readfirstlane(nr); Rs = __builtin_amdgcn_readfirstlane(Rs);
+    // lanes <-> rows u' of W (coalesced: a_u' runs through the 7 consecutive columns of a pose); slots of nap threads share the poses
+    const int nap = (na + 63) & ~63, nslots = NT / nap;
+    const int slot = t / nap, up = t - slot * nap;
+    const bool lane_on = slot < nslots && up < na;
+    const unsigned row_b = 8u * (unsigned)acol[lane_on ? up : 0];                  // byte offset of row a_u' inside a column of P
+    auto load7 = [&](double (&w)[7], int k) {                                      // W(u', 7 k + j): scalar base + 32-bit lane offset
+#pragma unroll
+        for (int j = 0; j < 7; j++)
+            w[j] = *reinterpret_cast<const double *>(reinterpret_cast<const char *>(P) + ((unsigned)(acol[7 * k + j] * N) * 8u + row_b));
+    };
+    // pose groups: all at once where A (na x nr, odd stride) fits g_cap, else two
+    const int ng = na * ((2 * ncam * n) | 1) <= g_cap ? 1 : 2;
+    const int per = (n + ng - 1) / ng, gs = (2 * ncam * per) | 1;
+    double wf0 = 0.0, wf1 = 0.0, wf2 = 0.0;
+    if (lane_on && slot == 0)                                                       // WF(:, 3) = W's time-shift column (F4's unit row)
+        WF[4 * up + 3] = *reinterpret_cast<const double *>(reinterpret_cast<const char *>(P) + ((unsigned)(acol[7 * n] * N) * 8u + row_b));
+    // the sums of one pose's values: WF's partial sums and the 2 ncam entries of A(u', rows of pose k)
+    auto consume = [&](const double (&w)[7], int k, int k0, int npg) {
+#pragma unroll
+        for (int j = 0; j < 7; j++) {
+            wf0 += w[j] * F4[7 * k + j]; wf1 += w[j] * F4[f4s + 7 * k + j]; wf2 += w[j] * F4[2 * f4s + 7 * k + j];
+        }
+        for (int cam = 0; cam < ncam; cam++) {
+            const double *d0 = DV + 14 * (cam * n + k);
+            double a0 = 0.0, a1 = 0.0;
+#pragma unroll
+            for (int j = 0; j < 7; j++) { a0 += w[j] * d0[j]; a1 += w[j] * d0[7 + j]; }
+            double *o = G + (size_t)up * gs + 2 * (cam * npg + k - k0);
+            o[0] = a0; o[1] = a1;
+        }
+    };
+    for (int g = 0; g < ng; g++) {
+        const int k0 = g * per, k1 = min(n, k0 + per), npg = k1 - k0, rows_g = 2 * ncam * npg;
+        // group-local row rl = 2 (cam npg + k - k0) + s  <->  global row r = 2 (cam n + k) + s
+        auto row_of = [&](int rl) -> int { const int il = rl >> 1, cam = il >= npg ? 1 : 0; return 2 * (cam * n + k0 + il - cam * npg) + (rl & 1); };
+        // ---- A = W Dp' for the poses of the group (into G), WF's partial sums ----
+        // (requesting all of a lane's poses at once -- up to 3 x 7 values -- was measured SLOWER: 14.4 k against 10.0 k cycles for the first
+        //  group of a 21-pose track, 26 spilled VGPRs; the gather is paced by the L1's line rate, not by exposed round trips)
+        if (lane_on && k0 + slot < k1) {
+            double wc[7], wn[7];
+            load7(wc, k0 + slot);
+            for (int k = k0 + slot; k < k1; k += nslots) {
+                const bool more = PREFETCH && k + nslots < k1;
+                if (more) load7(wn, k + nslots);                                   // (the next pose's values are in flight under this one's sums)
+                consume(wc, k, k0, npg);
+                if (more) {
+#pragma unroll
+                    for (int j = 0; j < 7; j++) wc[j] = wn[j];
+                } else if (!PREFETCH && k + nslots < k1) load7(wc, k + nslots);
+            }
+        }
+        if (g == ng - 1 && lane_on) { double *o = WFp + (size_t)(slot * na + up) * 3; o[0] = wf0; o[1] = wf1; o[2] = wf2; }
+        lds_barrier();
+        SS_STAMP(1 + 3 * g);
+        // ---- FA = F4 A: (c, row) outputs, each a dot product over u' split over `parts` adjacent lanes ----
+        {
+            int parts = 1;
+            while (parts < 8 && 2 * parts * 4 * rows_g <= NT) parts *= 2;
+            const int part = t & (parts - 1);
+            for (int q0 = 0; q0 < 4 * rows_g; q0 += NT / parts) {                  // (one round wherever 4 rows <= NT: every build there is)
+                const int q = q0 + t / parts;
+                const bool on = q < 4 * rows_g;
+                const int c = on ? q / rows_g : 0, rl = on ? q - c * rows_g : 0;
+                double sum = 0.0, sum2 = 0.0;                                       // (two chains: the LDS round trips overlap)
+                int u = part;
+                for (; u + parts < na; u += 2 * parts) {
+                    sum += F4[c * f4s + u] * G[(size_t)u * gs + rl];
+                    sum2 += F4[c * f4s + u + parts] * G[(size_t)(u + parts) * gs + rl];
+                }
+                if (u < na) sum += F4[c * f4s + u] * G[(size_t)u * gs + rl];
+                sum += sum2;
+                for (int o = 1; o < parts; o <<= 1) sum += __shfl_xor(sum, o);
+                if (on && part == 0) FA[c * nr + row_of(rl)] = sum;
+            }
+        }
+        SS_STAMP(2 + 3 * g);
+        // ---- S1(r', r) = sum_j Dp(r', 7 k' + j) A(7 k' + j, r), r in the group, r' >= r (A is only read here: no barrier in between).
+        // One group = the whole matrix: its lower triangle is walked as PAIRS of columns (r, nr - 1 - r: nr + 1 cells together, nr is even)
+        // -- walked as a rectangle, half the lanes of every round sat idle. Two groups keep the rectangle (group column, row).
+        {
+            auto cell = [&](int rl, int r, int rp) {
+                const int ip = rp >> 1, kp = ip >= n ? ip - n : ip;
+                const double *d = DV + 7 * rp, *gc = G + (size_t)(7 * kp) * gs + rl;
+                double sum = 0.0;
+#pragma unroll
+                for (int j = 0; j < 7; j++) sum += d[j] * gc[(size_t)j * gs];
+                T[(size_t)r * Rs + rp] = sum;
+            };
+            if (ng == 1) {
+                const unsigned inv = (unsigned)((0x100000000ull + (unsigned)nr) / (unsigned)(nr + 1));
+                for (int e = t; e < (nr >> 1) * (nr + 1); e += NT) {
+                    const int c2 = (int)__umulhi((unsigned)e, inv), off = e - c2 * (nr + 1);
+                    const bool first = off < nr - c2;
+                    const int r = first ? c2 : nr - 1 - c2, rp = first ? c2 + off : r + (off - (nr - c2));
+                    cell(r, r, rp);                                                 // (one group: local row = global row)
+                }
+            } else {
+                const unsigned inv = (unsigned)((0x100000000ull + (unsigned)nr - 1) / (unsigned)nr);
+                for (int e = t; e < rows_g * nr; e += NT) {
+                    const int rl = (int)__umulhi((unsigned)e, inv), rp = e - rl * nr, r = row_of(rl);
+                    if (rp >= r) cell(rl, r, rp);
+                }
+            }
+        }
+        lds_barrier();
+        SS_STAMP(3 + 3 * g);
+    }
+    // ---- the rank-4 terms: WF = sum of the slots' partial sums, DWF = Dp WF, FWF = F4 WF, FA += FWF O4', S += DWF O4' + O4 FA ----
+    for (int e = t; e < 3 * na; e += NT) {                                         // (WFp: written in front of the last group's first barrier)                                         // (e = 3 u' + c)
+        double sum = 0.0;
+        for (int sl = 0; sl < nslots; sl++) sum += WFp[(size_t)sl * na * 3 + e];
+        WF[4 * (e / 3) + e % 3] = sum;
+    }
+    lds_barrier();
+    SS_STAMP(7);
+    for (int e = t; e < 4 * nr; e += NT) {                                         // DWF(r', c), e = 4 r' + c
+        const int rp = e >> 2, c = e & 3, ip = rp >> 1, kp = ip >= n ? ip - n : ip;
+        const double *d = DV + 7 * rp;
+        double sum = 0.0;
+#pragma unroll
+        for (int j = 0; j < 7; j++) sum += d[j] * WF[4 * (7 * kp + j) + c];
+        DWF[e] = sum;
+    }
+    {                                                                              // FWF(c', c): 16 dot products over u', 16 lanes each
+        const int q = t >> 4, part = t & 15;
+        double sum = 0.0;
+        if (q < 16) for (int u = part; u < na; u += 16) sum += F4[(q >> 2) * f4s + u] * WF[4 * u + (q & 3)];
+        for (int o = 1; o < 16; o <<= 1) sum += __shfl_xor(sum, o);
+        if (q < 16 && part == 0) FWF[q] = sum;
+    }
+    lds_barrier();
+    SS_STAMP(8);
+    for (int e = t; e < 4 * nr; e += NT) {                                         // FA(c', r) += sum_c FWF(c', c) O4(r, c), e = c' nr + r
+        const int cp = e / nr, r = e - cp * nr;
+        const double *o = O4 + 4 * r, *f = FWF + 4 * cp;
+        FA[e] += f[0] * o[0] + f[1] * o[1] + f[2] * o[2] + f[3] * o[3];
+    }
+    lds_barrier();
+    SS_STAMP(9);
+    {
+        // the lower triangle only: the cells of column c2 (nr - c2 of them) and of column nr - 1 - c2 (c2 + 1) are nr + 1 together (nr is even)
+        const unsigned inv = (unsigned)((0x100000000ull + (unsigned)nr) / (unsigned)(nr + 1));
+        for (int e = t; e < (nr >> 1) * (nr + 1); e += NT) {
+            const int c2 = (int)__umulhi((unsigned)e, inv), off = e - c2 * (nr + 1);
+            const bool first = off < nr - c2;
+            const int r = first ? c2 : nr - 1 - c2, rp = first ? c2 + off : r + (off - (nr - c2));
+            const double *dw = DWF + 4 * rp, *o = O4 + 4 * r, *op = O4 + 4 * rp;
+            double sum = T[(size_t)r * Rs + rp];
+#pragma unroll
+            for (int c = 0; c < 4; c++) sum += dw[c] * o[c] + op[c] * FA[c * nr + r];
+            T[(size_t)r * Rs + rp] = sum;
+        }
+    }
+    lds_barrier();
+    SS_STAMP(10);
+#undef SS_STAMP
+}
+
 // ---------------------------------------------------------------------------------------------
 // Column-sparse chi2 gate of ONE track by one workgroup of NT threads: visualTrackOutlierCheck (ekf.cpp:787-819) on the active
 // columns only. prepareVisualUpdate fills H in the 7 columns of every pose of the track and in the time-shift column and nowhere
@@ -379,54 +648,7 @@ __device__ __forceinline__ double sparse_gate(const double *P, int n, const int 
     }
     __syncthreads();
     GATE_STAMP(0);
-    for (int i = t; i < nr; i += NT) T[(size_t)i * Rs + i] += rd;
-    double *W = work, *col = work + 256, *red = work + 256 + 544;
-    __syncthreads();
-    // blocked Cholesky of [S; v'] (ekf_update_kernel phase C restricted to the measurement rows). The diagonal blocks are factored by ONE
-    // wave (a ~340-cycle dependent chain per pivot that keeps its SIMD's issue port about half busy): the workgroups that share a CU use
-    // different waves for it (wave w sits on SIMD w % 4; workgroups 256 apart in the grid land on the same CU in the first rounds), or
-    // their chains queue up on SIMD 0 while the other three idle.
-    const int chol_wave = __builtin_amdgcn_readfirstlane((int)((blockIdx.x >> 8) & 3u));
-    const int Rlim = nr + 1;
-    for (int j0 = 0; j0 < nr; j0 += 16) {
-        const int w = min(16, nr - j0);
-        const int ntile = (Rlim - j0 + 15) / 16;
-        if (j0 > 0) {
-            for (int tile = wave; tile < ntile; tile += nwaves) {
-                const int i0 = j0 + 16 * tile, mi = Rlim - i0;
-                const double4v acc = mfma_tile(T + i0, 1, Rs, mi, T + j0, Rs, 1, w, j0);
-#pragma unroll
-                for (int q = 0; q < 4; q++) {
-                    const int i = kq + 4 * q;
-                    if (i < mi && cl < w) T[(size_t)(j0 + cl) * Rs + i0 + i] -= acc[q];
-                }
-            }
-            __syncthreads();
-        }
-        if (wave == chol_wave) { if (w <= 8) factor_diag_block<8>(T, W, col, Rs, j0, w, lane); else factor_diag_block<16>(T, W, col, Rs, j0, w, lane); }
-        __syncthreads();
-        for (int i0 = j0 + w + 16 * wave; i0 < Rlim; i0 += 16 * nwaves) {
-            const int mi = Rlim - i0;
-            const double4v acc = mfma_tile(T + (size_t)j0 * Rs + i0, 1, Rs, mi, W, 16, 1, 16, w);
-#pragma unroll
-            for (int q = 0; q < 4; q++) {
-                const int i = kq + 4 * q;
-                if (i < mi && cl < w) T[(size_t)(j0 + cl) * Rs + i0 + i] = acc[q];
-            }
-        }
-        __syncthreads();
-    }
-    GATE_STAMP(1);
-    double sz = 0;
-    for (int c = t; c < nr; c += NT) { const double z = T[(size_t)c * Rs + nr]; sz += z * z; }
-    for (int o = 32; o > 0; o >>= 1) sz += __shfl_down(sz, o);
-    if (lane == 0) red[wave] = sz;
-    __syncthreads();
-    double tot = 0;
-#pragma unroll
-    for (int w2 = 0; w2 < nwaves; w2++) tot += red[w2];
-    GATE_STAMP(2);
-    return tot * noise_scale;
+    return gate_factor_chi2<NT>(T, Rs, nr, rd, noise_scale, work, stamps);
 #undef GATE_STAMP
 }
 }  // namespace

@@ -822,19 +822,25 @@ __device__ __forceinline__ void vu_prepare_body(const VuPrepareArgs &a, const in
 #pragma unroll
             for (int k = 0; k < 3; ++k) a.pf[3 * rec + k] = pf_out[k];
         }
-        constexpr bool STAGED = FUSED == 1 || FUSED == 3;         // the compact Jacobian is also staged in LDS for the gate of this launch
-        const int na = 7 * n + 1, na4 = (na + 3) & ~3, ti = FUSED == 3 ? max((rows + 15) >> 4, 4) : (rows + 15) >> 4;
+        // FUSED 3 (the long build, which also serves every record of a speculative pass over long tracks): the gate works from the FACTORS
+        // of the Jacobian (ekf_device.hpp structured_S, r04), copied out of the Gauss-Newton arrays below before [S; v'] overwrites them;
+        // the compact Jacobian itself only goes to HBM, for the update of an inlier. FUSED 1 (<= 48 rows) keeps r03's form -- the compact
+        // Jacobian staged in LDS for sparse_gate's two dense MFMA products: measured on one box (scripts/r04_run21.sh, 1024 tracks per
+        // launch) the factor form takes 321 against 372 us at 21 stereo poses and 231 against 240 at 16, but 152 against 148 at 10.
+        constexpr bool STRUCT = FUSED == 3;
+        constexpr bool STAGED = FUSED == 1;                       // the compact Jacobian is also staged in LDS for the gate of this launch
+        const int na = 7 * n + 1, na4 = (na + 3) & ~3, ti = (rows + 15) >> 4;
         int Rs = rows + 1;                                        // column stride of [S; v']: 15 or 17 mod 32 doubles (bank spread)
         while ((Rs & 31) != 15 && (Rs & 31) != 17) Rs++;
-        // long build: the padded layout (16 ti rows per staged column) where it fits the carve, else sparse_gate's TIGHT one (84 rows per
-        // column, odd stride of [S; v']) -- 21 stereo poses
-        bool tight = false;
-        if constexpr (FUSED == 3) {
-            tight = na4 * 16 * ti > Lay::LONG_HS || Rs * rows > Lay::LONG_T;
-            if (tight) Rs = rows + 1 + (((rows + 1) & 1) ? 0 : 1);
-        }
-        const int nrp = tight ? HV_GATE_TIGHT_ROWS : 16 * ti;
+        constexpr int T_CAP = FUSED == 3 ? Lay::LONG_T : Lay::T_DOUBLES, REGION = FUSED == 3 ? Lay::LONG_HS : Lay::HS_DOUBLES;
+        if (STRUCT && Rs * rows > T_CAP) Rs = rows + 1 + (((rows + 1) & 1) ? 0 : 1);      // the longest tracks: any odd stride that fits (84 rows: 85)
+        const int nrp = 16 * ti;                                  // (STAGED: rows per staged column)
+        // region behind [S; v'] (the dead motion / linear-map arrays): the staged Jacobian, or the factors, their products and G
         double *Hs = vu_lds + (FUSED == 3 ? Lay::LONG_T : Lay::P0);
+        const int f4s = na, nslots_g = VT / ((na + 63) & ~63);
+        double *f_O4 = Hs, *f_DV = f_O4 + 4 * rows, *f_F4 = f_DV + 7 * rows, *f_WF = f_F4 + 4 * f4s, *f_FA = f_WF + 4 * na,
+               *f_DWF = f_FA + 4 * rows, *f_FWF = f_DWF + 4 * rows, *f_WFp = f_FWF + 16, *f_G = f_WFp + 3 * na * nslots_g;
+        const int g_cap = REGION - (int)(f_G - Hs);
         int *s_acol = s_flag + 4;
         if (tid < na) {                                           // compact column u -> state column: pose q's position / orientation, then SFT
             int col = SFT;
@@ -847,10 +853,38 @@ __device__ __forceinline__ void vu_prepare_body(const VuPrepareArgs &a, const in
             s_acol[tid] = col;                                    // (read by the gate, after the barriers below)
             a.acol[rec * a.na_max + tid] = col;
         }
+        if constexpr (STRUCT) {
+            // Hc = Dp + O4 F4 (see structured_S): observation tid's two rows of O4 and of Dp's 7 own-pose values, column tid of F4
+            if (tid < nt) {
+                const double *o = s_it + tid * ITER_WORDS;
+                double *o4 = f_O4 + 8 * tid, *dv = f_DV + 14 * tid;
+#pragma unroll
+                for (int c = 0; c < 3; ++c) { o4[c] = o[c]; o4[4 + c] = o[3 + c]; }
+                o4[3] = a.est_shift ? -s_feat[4 * tid + 2] : 0.0; o4[7] = a.est_shift ? -s_feat[4 * tid + 3] : 0.0;
+#pragma unroll
+                for (int comp = 0; comp < 7; ++comp) {
+                    dv[comp] = comp < 3 ? -o[comp] : o[6 + comp - 3];
+                    dv[7 + comp] = comp < 3 ? -o[3 + comp] : o[10 + comp - 3];
+                }
+            }
+            if (tid < na) {
+                const bool sft = tid == 7 * n;
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    double v = 0.0;
+                    if (!sft) { const int k = tid / 7, comp = tid - 7 * k; v = s_dpf[21 * k + comp + 7 * c]; }
+                    else if (a.est_shift) v = s_dpfi[c * ncol + dDim];
+                    f_F4[c * f4s + tid] = v;
+                }
+                f_F4[3 * f4s + tid] = sft ? 1.0 : 0.0;
+            }
+        }
         double *Hc = a.Hc + rec * (size_t)rows_max * a.na_max;    // record stride: the longest track; leading dimension: this track's rows
-        // work item = (compact column u < na4, row pair i < nrp / 2), i fastest: every element of the staged Hs is written exactly once
-        // (zero padding in rows >= 2 nt and columns >= na), the real ones also go to HBM for the update of an inlier
-        // (compact-only builds have no LDS copy to pad: their items are the real (column, pose) pairs)
+        // (the measurement is requested in front of the Jacobian's stores: behind them its round trip would queue up with theirs)
+        double yv[2] = {0.0, 0.0};
+        if (tid < nt && a.y) { yv[0] = a.y[rec * rows_max + 2 * tid]; yv[1] = a.y[rec * rows_max + 2 * tid + 1]; }
+        // work item = (compact column u, observation i), i fastest: the two rows of an observation are one 16-byte store. STAGED: u < na4,
+        // i < nrp / 2 -- every element of the staged Hs is written exactly once, zero padding in rows >= 2 nt and columns >= na included
         const int wi = STAGED ? nrp >> 1 : nt, n_items = (STAGED ? na4 : na) * wi;
         const unsigned inv_wi = (unsigned)((0x100000000ull + (unsigned)wi - 1) / (unsigned)wi);   // w / wi = umulhi(w, ceil(2^32 / wi))
         for (int w = tid; w < n_items; w += VT) {
@@ -883,7 +917,7 @@ __device__ __forceinline__ void vu_prepare_body(const VuPrepareArgs &a, const in
             for (int r = 0; r < 2; ++r) {
                 const size_t e = rec * rows_max + 2 * tid + r;
                 if (a.f) a.f[e] = o[14 + r];
-                vres[r] = (a.y ? a.y[e] : 0.0) - o[14 + r];
+                vres[r] = yv[r] - o[14 + r];
                 a.v[e] = vres[r];
             }
         }
@@ -894,17 +928,15 @@ __device__ __forceinline__ void vu_prepare_body(const VuPrepareArgs &a, const in
             }
             return;
         }
-        __syncthreads();                                          // everything but Hs / s_acol is dead from here on
+        lds_barrier();                                            // everything but the factor copies / s_acol is dead from here on (the stores above stay in flight)
         VU_STAMP(31);
         double *T = vu_lds;
-        if constexpr (FUSED == 3) {
-            if (tight && (ti != 6 || rows > HV_GATE_TIGHT_ROWS)) {     // (cannot happen: the launcher admits <= 21 stereo poses) not gated, never applied
-                if (tid == 0 && a.gate_status) a.gate_status[rec] = 1;
-                return;
-            }
+        if (STRUCT && (Rs * rows > T_CAP || g_cap < 832 + VT / 64)) {         // (cannot happen: the launcher admits what the carve holds) not gated, never applied
+            if (tid == 0 && a.gate_status) a.gate_status[rec] = 1;
+            return;
         }
         for (int i = tid; i < Rs * rows; i += VT) T[i] = 0.0;
-        __syncthreads();
+        lds_barrier();
         if (tid < nt) { T[(size_t)(2 * tid) * Rs + rows] = vres[0]; T[(size_t)(2 * tid + 1) * Rs + rows] = vres[1]; }
         VU_STAMP(32);
         const double *Pb = a.P + (size_t)b * N * N;
@@ -912,7 +944,7 @@ __device__ __forceinline__ void vu_prepare_body(const VuPrepareArgs &a, const in
         const double gscale = a.gate_scale ? a.gate_scale[b] : 1.0;
         const double rd_eff = a.rd_gate * gscale * gscale;
         if (a.rmse_thr >= 0.0) {                                  // (uniform) visualTrackOutlierCheck's early RMSE test, ekf.cpp:797-801
-            __syncthreads();                                      // v is in row `rows` of T
+            lds_barrier();                                        // v is in row `rows` of T
             double s2 = 0.0;
             for (int c = 0; c < rows; ++c) { const double vc = T[(size_t)c * Rs + rows]; s2 += vc * vc; }    // every thread: same order, same value
             if (sqrt(s2 / rows) > a.rmse_thr * gscale) {
@@ -926,10 +958,11 @@ __device__ __forceinline__ void vu_prepare_body(const VuPrepareArgs &a, const in
             }
         }
         double chi;
-        if constexpr (FUSED == 3) {
-            if (ti <= 4)      chi = sparse_gate<4, VT, false>(Pb, N, s_acol, na, Hs, T, Rs, rows, rd_eff, a.noise_scale, Hs, g_vu_stamp + 33);
-            else if (ti == 5) chi = sparse_gate<5, VT, false>(Pb, N, s_acol, na, Hs, T, Rs, rows, rd_eff, a.noise_scale, Hs, g_vu_stamp + 33);
-            else              chi = sparse_gate<6, VT, false, true>(Pb, N, s_acol, na, Hs, T, Rs, rows, rd_eff, a.noise_scale, Hs, g_vu_stamp + 33);
+        if constexpr (STRUCT) {
+            lds_barrier();                                        // (v' is in row `rows` of the zeroed T)
+            structured_S<VT, (VT > VT_THROUGHPUT)>(Pb, N, s_acol, na, n, ncam, rows, f_O4, f_DV, f_F4, f4s, f_WF, f_WFp, f_FA, f_DWF, f_FWF, f_G, g_cap, T, Rs, g_vu_stamp + 1);
+            VU_STAMP(33);
+            chi = gate_factor_chi2<VT>(T, Rs, rows, rd_eff, a.noise_scale, f_G, g_vu_stamp + 33);
         } else {
             if (ti == 1)      chi = sparse_gate<1, VT, false>(Pb, N, s_acol, na, Hs, T, Rs, rows, rd_eff, a.noise_scale, Hs, g_vu_stamp + 33);
             else if (ti == 2) chi = sparse_gate<2, VT, false>(Pb, N, s_acol, na, Hs, T, Rs, rows, rd_eff, a.noise_scale, Hs, g_vu_stamp + 33);

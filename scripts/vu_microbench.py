@@ -102,6 +102,8 @@ def main():
                 capi.lib().hv_debug_vu_phase_stamps.argtypes = [C.c_void_p, C.POINTER(C.c_longlong)]
                 capi.lib().hv_debug_vu_phase_stamps(ctx._h, st40)
                 s_ = list(st40)
+                if os.environ.get("HV_RAW_STAMPS") == "1":
+                    print("structured_S stamps (deltas of g_vu_stamp[1..11]):", [s_[k + 1] - s_[k] for k in range(1, 11)])
                 print("fused kernel phase cycles: up to prepare-pose", s_[29] - s_[0], "compact H + v", s_[31] - s_[29], "zero T", s_[32] - s_[31],
                       "gather + products", s_[33] - s_[32], "Cholesky", s_[34] - s_[33], "chi2", s_[35] - s_[34], "total", s_[35] - s_[0])
         g.close()
