@@ -205,10 +205,10 @@ __device__ __forceinline__ void pose_motion(const double *trail, const double *R
 
 // LDS layout of the kernel in doubles, for MAXP camera poses
 // LONG (the fused prepare + gate of the long class, FUSED = 3): the gate of a 49 .. 84-row track needs more room than the Gauss-Newton
-// arrays leave in the FUSED = 1 carve -- [S; v'] up to 86 x 84 and the staged compact Jacobian up to 148 x 84 doubles (21 stereo poses,
-// the TIGHT layout of sparse_gate). Everything the Jacobian is built FROM (pose records, dpf, dpfi, features, indices) lies below P0,
-// so the staged Hc goes to [LONG_T, LONG_T + LONG_HS) -- over the dead motion / linear-map arrays -- while it is built, [S; v'] to
-// [0, LONG_T) once the build is done, and the index arrays move behind both: 158.6 KB of the CU's 160.
+// arrays leave in the FUSED = 1 carve -- [S; v'] up to 86 x 84 doubles in [0, LONG_T) and, behind it, LONG_HS doubles for the factors of
+// the Jacobian, their products and A = P(a, a) Dp' (structured_S; until late r04 the staged compact Jacobian of up to 148 x 84 doubles,
+// which sized the region). Everything the factors are copied FROM (pose records, dpf, dpfi, features, indices) lies below P0, the
+// region lies over the dead motion / linear-map arrays, and the index arrays move behind both: 158.6 KB of the CU's 160.
 template <int MAXP, bool LONG = false>
 struct VuLds {
     static constexpr int MAXC = MAXP * 7 + 1, MOT_STRIDE = 13;
@@ -219,7 +219,7 @@ struct VuLds {
                          OWN = MOT + MAXPAIRS * MOT_STRIDE, LIN = OWN + MAXC * 9, LIN_END = LIN + 3 * MAXP * 9 + 32,
                          INTS = (LONG && LONG_T + LONG_HS > LIN_END) ? LONG_T + LONG_HS : LIN_END,
                          TOTAL = INTS + (MAXNP + 3 + 4 + MAXC + 1) / 2 + 1;       // s_idx, s_flag, s_acol (fused gate)
-    static_assert(!LONG || P0 <= LONG_T, "the sources of the compact Jacobian must lie below the staged copy");
+    static_assert(!LONG || P0 <= LONG_T, "the sources of the Jacobian's factors must lie below the region they are copied to");
     // fused gate (FUSED = 1 builds): once H exists the Gauss-Newton work arrays are dead -- the compact Jacobian is staged in [P0, INTS),
     // the (rows + 1) x rows matrix [S; v'] in [0, P0)
     static constexpr int HS_DOUBLES = INTS - P0, T_DOUBLES = P0;
@@ -234,9 +234,9 @@ static_assert(VuLds<42, true>::BYTES <= 160 * 1024, "the long build must fit one
 // FUSED (VuPrepareArgs::fused): 0 = the dense H of the public prepare entry point; 1 = compact Jacobian + the chi2 gate in this kernel
 // (ekf_device.hpp sparse_gate; few filters: one launch per visit / speculative pass); 2 = compact Jacobian only, the gate follows as
 // ekf_sparse_gate_kernel (many filters: three small workgroups per CU hide its Cholesky chain, which two of these cannot); 3 = like 1
-// for the LONG class (49 .. 84 rows, VuLds<.., true>, the 4- to 6-tile instantiations of sparse_gate; r04 -- r03 ran 2 + the big gate
-// kernel: two launches and a round trip of Hc through HBM on the critical path of every visit). In 1 .. 3 the dense H is never
-// written, only Hc / acol / v.
+// for the LONG class (49 .. 84 rows, VuLds<.., true>; r04 -- r03 ran 2 + the big gate kernel: two launches and a round trip of Hc
+// through HBM on the critical path of every visit), with S formed from the FACTORS of the Jacobian on the vector unit (ekf_device.hpp
+// structured_S) instead of sparse_gate's dense MFMA products. In 1 .. 3 the dense H is never written, only Hc / acol / v.
 template <int VT, int MAXP, int FUSED>
 __device__ __forceinline__ void vu_prepare_body(const VuPrepareArgs &a, const int bx /* filter: blockIdx.x, or the loop variable of a persistent launch */)
 {
@@ -1085,7 +1085,8 @@ __global__ __launch_bounds__(1024) void visit_order_kernel(const int *np_rec, in
         if (long_list && kl > 0) long_list[atomicAdd(&start[1][kl], 1)] = i;
     }
 }
-// the long class of a ragged visit: compact Jacobian + the 4- to 6-tile column-sparse gate in one launch (FUSED = 3), listed like vu_compact_kernel
+// the long class of a ragged visit: compact Jacobian + the chi2 gate (on the Jacobian's factors) in one launch (FUSED = 3), listed like
+// vu_compact_kernel; unlisted over a (filters, tracks) grid it serves EVERY record of a speculative pass over long tracks
 __global__ __launch_bounds__(VT_LATENCY, 3) void vu_gate_long_kernel(VuPrepareArgs a)
 {
     int b = blockIdx.x;

@@ -107,7 +107,7 @@ out = {
         "valu_busy_frac": frac(g("vu_gate_long_kernel", "SQ_ACTIVE_INST_VALU"), (g("vu_gate_long_kernel", "SQ_BUSY_CYCLES") or 0) * 32.0, 4.0),
         "mfma_busy_frac": frac(g("vu_gate_long_kernel", "SQ_VALU_MFMA_BUSY_CYCLES"), 32.0 * (g("vu_gate_long_kernel", "SQ_BUSY_CYCLES") or 0)),
         "wave_parked_frac": frac(g("vu_gate_long_kernel", "SQ_WAIT_ANY"), g("vu_gate_long_kernel", "SQ_WAVE_CYCLES")),
-        "how": "r04: triangulation + prepareVisualUpdate + the 4- to 6-tile column-sparse gate of the long-track class (12 .. 21 stereo poses) in one launch per visit; ~21 % of the records of a launch are live",
+        "how": "r04: triangulation + prepareVisualUpdate + the chi2 gate on the factors of the Jacobian (structured_S) of the long-track class (12 .. 21 stereo poses) in one launch per visit; ~21 % of the records of a launch are live",
     },
     "pyr_tail_kernel": {
         "fetch_kb_raw": g("pyr_tail_kernel", "FETCH_SIZE"), "write_kb": g("pyr_tail_kernel", "WRITE_SIZE"),
