@@ -127,6 +127,7 @@ PROTOTYPES = {
     "hv_ekf_visual_frame": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int] + [C.c_void_p] * 4 + [C.c_double, C.c_double] + [C.c_void_p] * 5 + [C.c_int]),
     "hv_ekf_visual_frame_ragged": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int] + [C.c_void_p] * 5 + [C.c_double, C.c_double] + [C.c_void_p] * 5 + [C.c_int]),
     "hv_ekf_visual_frame_ragged_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int] + [C.c_void_p] * 5 + [C.c_double, C.c_double] + [C.c_void_p] * 5 + [C.c_int]),
+    "hv_ekf_visual_frame_batch_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int] + [C.c_void_p] * 5 + [C.c_double, C.c_double] + [C.c_void_p] * 5 + [C.c_int, C.c_int]),
     "hv_ekf_augment_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "hv_ekf_symmetrize_augment_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "hv_ekf_visual_dev": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_double, C.c_int,
@@ -699,6 +700,14 @@ class EkfBatch:
         b = [C.c_void_p(x) for x in (status_dev, gate_status_dev, chi2_dev, pf_dev, success_counter_dev)]
         self._chk(lib().hv_ekf_visual_frame_ragged_dev(self._h, C.byref(params), int(n_tracks), int(n_poses_max), *a, float(r_gate),
                                                        float(r_update), *b, int(max_successful)), "hv_ekf_visual_frame_ragged_dev")
+
+    def visual_frame_batch_dev(self, params: VuParams, n_tracks, n_poses_max, n_poses_dev, pose_index_dev, features_dev, velocities_dev, y_dev,
+                               r_gate, r_update, status_dev, gate_status_dev, success_counter_dev, max_successful, max_update_rows=0, chi2_dev=0, pf_dev=0):
+        """hv_ekf_visual_frame_batch_dev: the frame loop with batchVisualUpdate (inlier blocks applied as one update per batch)."""
+        a = [C.c_void_p(x) for x in (n_poses_dev, pose_index_dev, features_dev, velocities_dev, y_dev)]
+        b = [C.c_void_p(x) for x in (status_dev, gate_status_dev, chi2_dev, pf_dev, success_counter_dev)]
+        self._chk(lib().hv_ekf_visual_frame_batch_dev(self._h, C.byref(params), int(n_tracks), int(n_poses_max), *a, float(r_gate),
+                                                      float(r_update), *b, int(max_successful), int(max_update_rows)), "hv_ekf_visual_frame_batch_dev")
 
     def visual_frame(self, params: VuParams, pose_index, features, velocities, y, r_gate, r_update, max_successful):
         """hv_ekf_visual_frame with numpy arrays [n_tracks][batch][...]: returns (status [K][B][2], gate_status [K][B], chi2, pf, applied [B])."""

@@ -1720,6 +1720,7 @@ struct Ekf {
     int side_rows = 0;
     int *side_acol = nullptr; double *side_dm = nullptr;
     int *err_dev = nullptr;                               // device error word (UpdateArgs::err)
+    double *bH = nullptr, *bv = nullptr; int *brows = nullptr; unsigned char *bany = nullptr; int b_rows = 0;   // batchVisualUpdate: stacked [H; v], rows, flags
     double *gate_scale = nullptr;                         // [batch] per-filter multiplier of the outlier thresholds inside a frame loop (backend.cpp:1192-1193)
     bool gate_scale_on = false;                           // set by the frame loop while its visits run with a growth factor != 1
     int *visit_counts = nullptr, *visit_lists = nullptr;  // compaction lists of a visit: counts {inliers short, long records, inliers long}, lists 3 x [batch]
@@ -1882,6 +1883,71 @@ static int ekf_launch_gate_stream(Ekf *e, int nr, int l, const double *H_dev, co
     return HV_OK;
 }
 
+// ---------------------------------------------------------------------------------------------
+// batchVisualUpdate (backend.cpp:1001-1010, 1169-1183, 1255-1262): inside a batch every track is gated against the SAME (m, P) -- the
+// updates are deferred --, so one speculative pass (every pending track prepared and gated in one launch) IS the reference's loop up to
+// the next flush. This kernel is the bookkeeping of that loop for one filter: it walks the pending tracks in visit order, appends the
+// inliers' blocks [H; v] to the filter's batch while they fit max_rows and the quota lasts, and leaves the stacked dense H (column-major,
+// leading dimension = the batch's row count) and v for ONE updateVisualTrack launch (ragged dense update: rows_out). A block that does
+// not fit ends the pass: the batch is flushed by that update, the block opens the NEXT batch unchanged (carry), and the next pass gates
+// the tracks behind it against the updated state -- the reference's flush-then-append.
+// ---------------------------------------------------------------------------------------------
+struct BatchAssembleArgs {
+    int n, n_tracks, batch, max_rows, max_successful, rows_stride, na_max, ncam;
+    const double *Hc, *v;             // compact records of the gate launch: [n_tracks][batch] x (rows_stride x na_max), x rows_stride
+    const int *acol, *nr_rec;         // [records][na_max]; rows of every record (null: rows_stride)
+    const unsigned char *active; const int *gate;
+    int *cursor, *success_counter, *carry;   // carry [batch]: the track whose block opens the next batch (-1: none)
+    double *Hd, *vd;                  // [batch][max_rows x n], [batch][max_rows]
+    int *rows_out; unsigned char *any_out;
+};
+constexpr int BATCH_THREADS = 256;
+__global__ __launch_bounds__(BATCH_THREADS) void ekf_batch_assemble_kernel(BatchAssembleArgs a)
+{
+    __shared__ int s_list[64], s_off[64], s_cnt, s_rows;
+    const int b = blockIdx.x, t = threadIdx.x;
+    if (t == 0) {
+        int succ = a.success_counter[b], rows = 0, cnt = 0, j = a.cursor[b];
+        // the track whose block did not fit the previous batch opens this one AS IT WAS prepared and gated -- against the state before
+        // the flush: the reference has its H, f, y in hand when it flushes and appends them afterwards (backend.cpp:1171-1182)
+        const int cj = a.carry[b];
+        if (cj >= 0) {
+            const int rec = cj * a.batch + b;
+            s_list[0] = cj; s_off[0] = 0; rows = a.nr_rec ? a.nr_rec[rec] : a.rows_stride; cnt = 1; ++succ;
+            a.carry[b] = -1;
+        }
+        for (; j < a.n_tracks; ++j) {
+            if (succ >= a.max_successful) break;                                   // quota (backend.cpp:1233): the next pass marks the rest NOT_VISITED
+            const int rec = j * a.batch + b;
+            if (!a.active[rec] || a.gate[rec] != 0) continue;                     // failed triangulation / outlier: final, nothing to apply
+            const int nr = a.nr_rec ? a.nr_rec[rec] : a.rows_stride;
+            if (rows + nr > a.max_rows || cnt == 64) { a.carry[b] = j; ++j; break; }      // flush first; the block waits for the next batch
+            s_list[cnt] = j; s_off[cnt] = rows; rows += nr; ++cnt; ++succ;
+        }
+        a.cursor[b] = j;                                                           // (n_tracks when every pending track is final)
+        a.success_counter[b] = succ;
+        a.rows_out[b] = rows; a.any_out[b] = rows > 0 ? 1 : 0;
+        s_cnt = cnt; s_rows = rows;
+    }
+    __syncthreads();
+    const int cnt = s_cnt, rows = s_rows;
+    if (rows == 0) return;
+    double *Hd = a.Hd + (size_t)b * a.max_rows * a.n, *vd = a.vd + (size_t)b * a.max_rows;
+    for (int i = t; i < rows * a.n; i += BATCH_THREADS) Hd[i] = 0.0;
+    __syncthreads();
+    for (int q = 0; q < cnt; ++q) {
+        const int rec = s_list[q] * a.batch + b, off = s_off[q];
+        const int nr = a.nr_rec ? a.nr_rec[rec] : a.rows_stride, na = 7 * (nr / (2 * a.ncam)) + 1;
+        const double *Hc = a.Hc + (size_t)rec * a.rows_stride * a.na_max, *v = a.v + (size_t)rec * a.rows_stride;
+        const int *acol = a.acol + (size_t)rec * a.na_max;
+        for (int i = t; i < na * nr; i += BATCH_THREADS) {
+            const int u = i / nr, r = i - u * nr;
+            Hd[(size_t)acol[u] * rows + off + r] = Hc[i];                          // (compact column u of the record, leading dimension nr)
+        }
+        for (int r = t; r < nr; r += BATCH_THREADS) vd[off + r] = v[r];
+    }
+}
+
 // ekf_sparse_gate_kernel over the compact records of a prepare launch (np = poses of the longest record)
 static int ekf_launch_sparse_gate(Ekf *e, int np, int ncam, const double *Hc_dev, const double *v_dev, const int *acol_dev, const int *nr_rec_dev,
                                   const unsigned char *active_dev, double rd, double *chi2_dev, int *status_dev,
@@ -1955,7 +2021,7 @@ void hv_ekf_destroy(hv_ekf *h)
     void *ptrs[] = { e->m, e->P, e->P1, e->m1, e->Q, e->dydx, e->ws, e->sH, e->sv, e->sr, e->schi2, e->simu,
                      e->sstatus, e->sdrop, e->sactive, e->vuH, e->vuv, e->vupf, e->vuactive, e->vustage,
                      e->spH, e->spv, e->sppf, e->spactive, e->spcursor, e->spepoch, e->spcursor2, e->sppub, e->vurows, e->sprows,
-                     e->vuacol, e->spacol, e->err_dev, e->gate_scale, e->sideH, e->sidev, e->side_active, e->side_acol, e->side_dm, e->visit_counts, e->visit_lists, e->visit_order, e->visit_long, e->visit_long_count };
+                     e->vuacol, e->spacol, e->err_dev, e->gate_scale, e->bH, e->bv, e->brows, e->bany, e->sideH, e->sidev, e->side_active, e->side_acol, e->side_dm, e->visit_counts, e->visit_lists, e->visit_order, e->visit_long, e->visit_long_count };
     for (void *p : ptrs) if (p) (void)hipFree(p);
     if (e->c && e->c->aux_stream) (void)hipStreamSynchronize(e->c->aux_stream);
     if (e->ev_fork) (void)hipEventDestroy(e->ev_fork);
@@ -2594,6 +2660,88 @@ int hv_ekf_visual_frame_ragged_dev(hv_ekf *h, const hv_vu_params *p, int n_track
     if (!n_poses_dev) return HV_ERR_INVALID;
     return visual_frame_dev_impl(h, p, n_tracks, np_max, n_poses_dev, idx, feat, vel, y, r_gate, r_update, status_dev, gate_status_dev,
                                  chi2_dev, pf_dev, success_counter_dev, max_successful);
+}
+
+// Session::trackerVisualUpdate with batchVisualUpdate (or a frame that is not a "full visual update": backend.cpp:1005): see
+// ekf_batch_assemble_kernel. <= min(quota, n_tracks) + 1 passes of (prepare + gate of every pending track | assemble | one dense update).
+int hv_ekf_visual_frame_batch_dev(hv_ekf *h, const hv_vu_params *p, int n_tracks, int np, const int *np_rec_dev, const int *idx,
+                                  const double *feat, const double *vel, const double *y, double r_gate, double r_update,
+                                  int *status_dev, int *gate_status_dev, double *chi2_dev, double *pf_dev, int *success_counter_dev,
+                                  int max_successful, int max_update_rows)
+{
+    if (!h || !p || n_tracks < 1 || !success_counter_dev || !status_dev || !gate_status_dev || !idx || !feat || !vel || !y) return HV_ERR_INVALID;
+    Ekf *e = &h->e; Ctx *c = e->c;
+    const int ncam = p->useStereo ? 2 : 1, rows = 2 * np * ncam;
+    if (max_update_rows <= 0) max_update_rows = e->n;                        // batchVisualUpdateMaxSizeMultiplier 1 (parameter_definitions.c:17)
+    if (max_successful <= 0 || max_successful > n_tracks) max_successful = n_tracks;
+    // a batch holds at least one whole track (the reference would write past its batch matrix otherwise) and at most stateDim rows (the
+    // dense update kernels' limit); the per-filter multiplier of the outlier thresholds would need the tracks of a pass in sequence
+    if (max_update_rows < rows || max_update_rows > e->max_rows || n_tracks > 64) return HV_ERR_INVALID;
+    if (p->trackOutlierThresholdGrowthFactor != 1.0) return HV_ERR_UNSUPPORTED;
+    const size_t B = (size_t)e->batch, rec = B * (size_t)n_tracks;
+    if (rec > 8192) return HV_ERR_UNSUPPORTED;                               // (every record's compact Jacobian is resident during a pass)
+    const VisitShape shape = visit_shape(e, np, p->useStereo != 0);
+    const bool long_build = rows > 48;
+    if (long_build ? !(shape.long_ok && c->knob.ekf_long_fused != 0) : !hv::vu_fused_supported(c, e->n, np, p->useStereo != 0, (int)rec)) return HV_ERR_UNSUPPORTED;
+    if (e->sp_records < rec || e->sp_rows < rows) {
+        HV_HIP(c, hipStreamSynchronize(c->stream));
+        void *old[] = {e->spH, e->spv, e->sppf, e->spactive, e->spcursor, e->spepoch, e->spcursor2, e->sppub, e->spacol, e->sprows};
+        for (void *q : old) if (q) (void)hipFree(q);
+        e->spH = e->spv = e->sppf = nullptr; e->spactive = nullptr; e->spcursor = e->spepoch = e->spcursor2 = e->sppub = e->spacol = e->sprows = nullptr; e->sp_records = 0;
+        HV_HIP(c, hipMalloc(reinterpret_cast<void **>(&e->spH), sizeof(double) * rec * rows * e->n));
+        HV_HIP(c, hipMalloc(reinterpret_cast<void **>(&e->spv), sizeof(double) * rec * rows));
+        HV_HIP(c, hipMalloc(reinterpret_cast<void **>(&e->sppf), sizeof(double) * rec * 3));
+        HV_HIP(c, hipMalloc(reinterpret_cast<void **>(&e->spactive), rec));
+        HV_HIP(c, hipMalloc(reinterpret_cast<void **>(&e->spcursor), sizeof(int) * B));
+        HV_HIP(c, hipMalloc(reinterpret_cast<void **>(&e->spepoch), sizeof(int) * rec));
+        HV_HIP(c, hipMalloc(reinterpret_cast<void **>(&e->spcursor2), sizeof(int) * B));
+        HV_HIP(c, hipMalloc(reinterpret_cast<void **>(&e->sppub), sizeof(int) * rec));
+        HV_HIP(c, hipMalloc(reinterpret_cast<void **>(&e->spacol), sizeof(int) * rec * e->n));
+        HV_HIP(c, hipMalloc(reinterpret_cast<void **>(&e->sprows), sizeof(int) * rec));
+        e->sp_records = rec; e->sp_rows = rows;
+    }
+    if (e->b_rows < max_update_rows) {
+        HV_HIP(c, hipStreamSynchronize(c->stream));
+        void *old[] = {e->bH, e->bv, e->brows, e->bany};
+        for (void *q : old) if (q) (void)hipFree(q);
+        e->bH = e->bv = nullptr; e->brows = nullptr; e->bany = nullptr; e->b_rows = 0;
+        HV_HIP(c, hipMalloc(reinterpret_cast<void **>(&e->bH), sizeof(double) * B * max_update_rows * e->n));
+        HV_HIP(c, hipMalloc(reinterpret_cast<void **>(&e->bv), sizeof(double) * B * max_update_rows));
+        HV_HIP(c, hipMalloc(reinterpret_cast<void **>(&e->brows), sizeof(int) * B));
+        HV_HIP(c, hipMalloc(reinterpret_cast<void **>(&e->bany), B));
+        e->b_rows = max_update_rows;
+    }
+    HV_HIP(c, hipMemsetAsync(success_counter_dev, 0, sizeof(int) * B, c->stream));
+    HV_HIP(c, hipMemsetAsync(e->spcursor, 0, sizeof(int) * B, c->stream));
+    HV_HIP(c, hipMemsetAsync(e->spepoch, 0xFF, sizeof(int) * rec, c->stream));
+    HV_HIP(c, hipMemsetAsync(e->spcursor2, 0xFF, sizeof(int) * B, c->stream));               // carry: -1
+    hv::VuPrepareArgs a;
+    int rc = vu_fill_args(e, p, np, idx, feat, vel, y, a);
+    if (rc != HV_OK) return rc;
+    const double ns = e->noise_scale;
+    a.H = nullptr; a.v = e->spv; a.f = nullptr; a.pf = pf_dev ? pf_dev : e->sppf; a.status = status_dev; a.active = e->spactive;
+    a.gate_status = gate_status_dev; a.success_counter = success_counter_dev; a.max_successful = max_successful;
+    a.spec_tracks = n_tracks; a.cursor = e->spcursor; a.epoch = e->spepoch;
+    const int *nr_rec = nullptr;
+    if (np_rec_dev) { a.np_rec = np_rec_dev; a.rows_out = e->sprows; nr_rec = e->sprows; }
+    a.fused = long_build ? 3 : 1; a.Hc = e->spH; a.acol = e->spacol; a.na_max = 7 * np + 1; a.P = e->P;
+    a.rd_gate = r_gate * r_gate * ns; a.noise_scale = ns; a.chi2 = chi2_dev;
+    hv::BatchAssembleArgs g{};
+    g.n = e->n; g.n_tracks = n_tracks; g.batch = e->batch; g.max_rows = max_update_rows; g.max_successful = max_successful;
+    g.rows_stride = rows; g.na_max = a.na_max; g.ncam = ncam; g.Hc = e->spH; g.v = e->spv; g.acol = e->spacol; g.nr_rec = nr_rec;
+    g.active = e->spactive; g.gate = gate_status_dev; g.cursor = e->spcursor; g.success_counter = success_counter_dev; g.carry = e->spcursor2;
+    g.Hd = e->bH; g.vd = e->bv; g.rows_out = e->brows; g.any_out = e->bany;
+    const int n_pass = max_successful + 1;
+    for (int pass = 0; pass < n_pass; ++pass) {
+        rc = hv::launch_vu_prepare(c, a);
+        if (rc != HV_OK) return rc;
+        hipLaunchKernelGGL(hv::ekf_batch_assemble_kernel, dim3(e->batch), dim3(hv::BATCH_THREADS), 0, c->stream, g);
+        HV_HIP(c, hipGetLastError());
+        rc = hv::ekf_launch_update(e, max_update_rows, e->n, e->bH, e->bv, nullptr, r_update * r_update * ns, 1, 0, 1, nullptr, nullptr, e->bany,
+                                   nullptr, nullptr, 0.0, nullptr, 0, 0, nullptr, 0, nullptr, nullptr, nullptr, 0, e->brows);
+        if (rc != HV_OK) return rc;
+    }
+    return HV_OK;
 }
 
 int hv_ekf_visual_track(hv_ekf *h, const hv_vu_params *p, int np, const int *idx, const double *feat, const double *vel,

@@ -312,6 +312,17 @@ int hv_ekf_visual_frame_ragged_dev(hv_ekf *ekf, const hv_vu_params *p, int n_tra
                                    const int *pose_index_dev, const double *features_dev, const double *velocities_dev,
                                    const double *y_dev, double r_gate, double r_update, int *status_dev, int *gate_status_dev,
                                    double *chi2_dev, double *pf_dev, int *success_counter_dev, int max_successful);
+/* Session::trackerVisualUpdate with batchVisualUpdate -- or on a frame that is not a "full visual update" -- (backend.cpp:1001-1010,
+ * 1169-1183, 1255-1262; ABI 3, r04): the inliers' blocks [H; f; y] are collected and applied as ONE updateVisualTrack per batch; a block
+ * that would take the batch beyond max_update_rows flushes it first and opens the next one. Every track between two flushes is prepared
+ * and gated against the same state, which the device does in one launch per batch (<= quota + 1 passes per frame). Arguments as
+ * hv_ekf_visual_frame_ragged_dev (n_poses_dev may be NULL: every track has n_poses_max poses); max_update_rows = int(stateDim *
+ * batchVisualUpdateMaxSizeMultiplier + 0.5), <= 0: stateDim. Valid for trackOutlierThresholdGrowthFactor 1 (HV_ERR_UNSUPPORTED
+ * otherwise), n_tracks <= 64, n_tracks * batch <= 8192, max_update_rows >= the rows of the longest track and <= stateDim. */
+int hv_ekf_visual_frame_batch_dev(hv_ekf *ekf, const hv_vu_params *p, int n_tracks, int n_poses_max, const int *n_poses_dev,
+                                  const int *pose_index_dev, const double *features_dev, const double *velocities_dev, const double *y_dev,
+                                  double r_gate, double r_update, int *status_dev, int *gate_status_dev, double *chi2_dev, double *pf_dev,
+                                  int *success_counter_dev, int max_successful, int max_update_rows);
 /* Reads (and clears) the error word of the filter batch: non-zero when a device-side wait of an asynchronous frame call gave up
  * (only the experimental hand-shake form of the speculative pass, knob ekf_spec_mode = 3, can raise it); the host-pointer entry
  * points check it themselves and return HV_ERR_TIMEOUT. Synchronous. */

@@ -622,6 +622,102 @@ def test_whole_frame_loop_with_ragged_track_lengths(oracle, B, speculative, ster
             assert max(lengths_applied) > 12 and min(lengths_applied) < 12, lengths_applied
         g.close()
 
+
+@pytest.mark.parametrize("B,np_max,K,quota,max_rows,stereo", [
+    (6, 8, 10, 6, 64, True),          # short tracks (<= 32 rows), batches of 64 rows: several flushes per frame, carried blocks
+    (5, 16, 9, 5, 0, True),           # long tracks (<= 64 rows, the long build), the reference's default batch of stateDim rows
+    (7, 10, 8, 8, 40, False),         # mono, quota = every inlier, small batches
+    (3, 21, 8, 4, 160, True)])        # 84-row tracks
+def test_frame_loop_with_batch_visual_update(oracle, B, np_max, K, quota, max_rows, stereo):
+    """hv_ekf_visual_frame_batch_dev = Session::trackerVisualUpdate with batchVisualUpdate (backend.cpp:1001-1010,1169-1183,1255-1262):
+    the inliers' blocks are stacked and applied as one update per batch; every track between two flushes is prepared and gated against the
+    state the last flush left; a block that does not fit flushes the batch and opens the next one as it was prepared."""
+    import torch
+    rng = np.random.default_rng(500 + B + np_max)
+    trail_len = 20
+    T1, T2, means, _, _, _ = _random_tracks(oracle, rng, B, trail_len, 6, stereo, bad_fraction=0.0)
+    ncam = 2 if stereo else 1
+    lens = rng.integers(2, np_max + 1, (K, B)).astype(np.int32)
+    lens[rng.uniform(size=(K, B)) < 0.1] = 0
+    lens[0, 0] = np_max
+    idx = np.zeros((K, B, np_max), np.int32); feat = np.zeros((K, B, ncam * np_max, 2)); vel = np.zeros_like(feat)
+    ys = np.zeros((K, B, 2 * ncam * np_max))
+    per = {}
+    for k in range(K):
+        for n in sorted(set(lens[k].tolist()) - {0}):
+            sel = np.nonzero(lens[k] == n)[0]
+            _, _, _, i_, f_, v_ = _random_tracks(oracle, rng, len(sel), trail_len, n, stereo, bad_fraction=0.15, given_means=means[sel])
+            for j, b in enumerate(sel):
+                yy = f_[j].reshape(-1) + 2e-3 * rng.normal(size=f_[j].size) + (3.0 if (k + b) % 4 == 0 else 0.0)
+                idx[k, b, :n] = i_[j]; feat[k, b, :ncam * n] = f_[j]; vel[k, b, :ncam * n] = v_[j]; ys[k, b, :2 * ncam * n] = yy
+                per[(k, b)] = (i_[j], f_[j], v_[j], yy)
+    vp = capi.vu_default_params(imu_to_camera=T1, second_imu_to_camera=T2) if stereo else capi.vu_default_params(imu_to_camera=T1)
+    par = oracle.tri_default_params()
+    r_gate, r_update = 1.5, 0.05
+    with capi.Context(width=64, height=64) as ctx:
+        g = capi.EkfBatch(ctx, capi.ekf_default_params(cameraTrailLength=trail_len), B)
+        cap = max_rows if max_rows > 0 else g.n
+        filters = []
+        for b in range(B):
+            o = oracle.Ekf(oracle.ekf_default_params(cameraTrailLength=trail_len))
+            P = o.P.copy() * 1e-6 + np.eye(o.n) * 1e-4
+            o.set_state(means[b]); o.set_cov(P)
+            g.set_state(b, means[b], P)
+            filters.append(o)
+        dev = lambda a, dt: torch.from_numpy(np.array(a, dt, order="C")).cuda()
+        d = [dev(lens, np.int32), dev(idx, np.int32), dev(feat, np.float64), dev(vel, np.float64), dev(ys, np.float64)]
+        st = torch.full((K, B, 2), -9, dtype=torch.int32, device="cuda"); gs = torch.full((K, B), -9, dtype=torch.int32, device="cuda")
+        counter = torch.full((B,), 77, dtype=torch.int32, device="cuda")
+        ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+        g.visual_frame_batch_dev(vp, K, np_max, d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(), d[3].data_ptr(), d[4].data_ptr(),
+                                 r_gate, r_update, st.data_ptr(), gs.data_ptr(), counter.data_ptr(), quota, max_rows)
+        torch.cuda.synchronize()
+        st, gs, counts = st.cpu().numpy(), gs.cpu().numpy(), counter.cpu().numpy()
+        flushes, applied, rejected, ties = 0, 0, 0, 0
+        for b, o in enumerate(filters):
+            Hb, fb, yb, rows, done = [], [], [], 0, 0
+
+            def flush():
+                o.update_visual_track(np.vstack(Hb), np.concatenate(fb), np.concatenate(yb), r_update)
+                Hb.clear(); fb.clear(); yb.clear()
+
+            for k in range(K):
+                if done >= quota or lens[k, b] == 0:
+                    assert st[k, b].tolist() == [-1, -1] and gs[k, b] == 1, (b, k)
+                    continue
+                i_, f_, v_, yy = per[(k, b)]
+                ost, ops, opf, oH, of = oracle.visual_track_prepare(par, o.m.copy(), i_, T1, T2 if stereo else None, f_, v_)
+                if st[k, b].tolist() != [ost, ops]:
+                    assert not _well_conditioned(oracle.tri_last_diag()) and ost != 0 and st[k, b, 0] != 0, (b, k, st[k, b].tolist(), [ost, ops])
+                    ties += 1
+                if (ost, ops) != (0, 0):
+                    assert gs[k, b] == 1
+                    continue
+                status, _ = o.visual_track_outlier_check(oH, of, yy, r_gate)
+                assert gs[k, b] == status, (b, k, lens[k, b])
+                if status != 0:
+                    rejected += 1
+                    continue
+                nr = oH.shape[0]
+                if rows + nr > cap:
+                    flush(); rows = 0; flushes += 1
+                Hb.append(oH); fb.append(of); yb.append(yy); rows += nr; done += 1
+            if rows:
+                flush()
+            assert counts[b] == done, (b, counts[b], done)
+            applied += done
+            mg, Pg = g.get_state(b)
+            assert _rel(mg, o.m) < 1e-8 and _rel(Pg, o.P) < 1e-7, (b, _rel(mg, o.m), _rel(Pg, o.P))
+        assert applied >= B and rejected > 0 and ties <= 1, (applied, rejected, ties)
+        if 0 < max_rows <= 64:
+            assert flushes > 0, "no batch overflowed: the carried-block path was not exercised"
+        # arguments the entry refuses: a batch smaller than the longest track, a growth factor != 1
+        with pytest.raises(capi.HvError):
+            g.visual_frame_batch_dev(vp, K, np_max, d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(), d[3].data_ptr(), d[4].data_ptr(),
+                                     r_gate, r_update, torch.zeros_like(torch.from_numpy(st)).cuda().data_ptr(), torch.zeros_like(torch.from_numpy(gs)).cuda().data_ptr(),
+                                     counter.data_ptr(), quota, 2 * ncam * np_max - 2)
+        g.close()
+
 @pytest.mark.parametrize("B,np_max,growth,rmse_thr,variant", [
     (48, 21, 1.5, 2.5, "sorted_small_batch"),      # two sorted length classes: vu_gate_kernel + vu_gate_long_kernel keep the per-filter multiplier
     (300, 21, 1.3, 2.5, "default"),                # ... more filters than CUs (two-per-CU build, second stream)
