@@ -121,6 +121,7 @@ PROTOTYPES = {
     "hv_vu_default_params": (None, [C.c_void_p]),
     "hv_ekf_visual_prepare_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int] + [C.c_void_p] * 10),
     "hv_ekf_visual_track_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int] + [C.c_void_p] * 4 + [C.c_double, C.c_double] + [C.c_void_p] * 4),
+    "hv_ekf_visual_track_hybrid_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int] + [C.c_void_p] * 6 + [C.c_double, C.c_double] + [C.c_void_p] * 4),
     "hv_ekf_visual_track_limited_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int] + [C.c_void_p] * 4 + [C.c_double, C.c_double] + [C.c_void_p] * 5 + [C.c_int]),
     "hv_ekf_visual_track": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int] + [C.c_void_p] * 4 + [C.c_double, C.c_double] + [C.c_void_p] * 4),
     "hv_ekf_visual_frame_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int] + [C.c_void_p] * 4 + [C.c_double, C.c_double] + [C.c_void_p] * 5 + [C.c_int]),
@@ -648,6 +649,14 @@ class EkfBatch:
         b = [C.c_void_p(x) for x in (status_dev, gate_status_dev, chi2_dev, pf_dev)]
         self._chk(lib().hv_ekf_visual_track_dev(self._h, C.byref(params), n_poses, *a, float(r_gate), float(r_update), *b),
                   "hv_ekf_visual_track_dev")
+
+    def visual_track_hybrid_dev(self, params: VuParams, n_poses, pose_index_dev, features_dev, velocities_dev, y_dev, map_update_dev, map_offer_dev,
+                                r_gate, r_update, status_dev, gate_status_dev, chi2_dev=0, pf_dev=0):
+        """hv_ekf_visual_track_hybrid_dev: a track visit with hybrid-map tracks (map_update_dev) and map-point offers (map_offer_dev)."""
+        a = [C.c_void_p(x) for x in (pose_index_dev, features_dev, velocities_dev, y_dev, map_update_dev, map_offer_dev)]
+        b = [C.c_void_p(x) for x in (status_dev, gate_status_dev, chi2_dev, pf_dev)]
+        self._chk(lib().hv_ekf_visual_track_hybrid_dev(self._h, C.byref(params), n_poses, *a, float(r_gate), float(r_update), *b),
+                  "hv_ekf_visual_track_hybrid_dev")
 
     def visual_track_limited_dev(self, params: VuParams, n_poses, pose_index_dev, features_dev, velocities_dev, y_dev, r_gate, r_update,
                                  status_dev, gate_status_dev, success_counter_dev, max_successful, chi2_dev=0, pf_dev=0):

@@ -1884,6 +1884,31 @@ static int ekf_launch_gate_stream(Ekf *e, int nr, int l, const double *H_dev, co
 }
 
 // ---------------------------------------------------------------------------------------------
+// Hybrid map (backend.cpp:1160-1168): an inlier pose-trail track that is OFFERED a map slot becomes a map point -- insertMapPoint
+// (ekf.cpp:911-921: the slot's rows and columns of P zeroed, 1e6 on its diagonal, the triangulated point in the mean) -- INSTEAD of
+// being applied. One workgroup per filter; active_out = the filters whose track still takes updateVisualTrack.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void ekf_hybrid_insert_kernel(int n, int map_base, double *m_all, double *P_all, const unsigned char *active,
+                                                                const int *gate, const int *map_index, const int *offer, const double *pf,
+                                                                unsigned char *active_out)
+{
+    const int b = blockIdx.x, t = threadIdx.x;
+    const bool act = active[b] != 0, inlier = act && gate[b] == 0;
+    const int slot = (inlier && (!map_index || map_index[b] < 0) && offer) ? offer[b] : -1;
+    if (t == 0) active_out[b] = (act && slot < 0) ? 1 : 0;
+    if (slot < 0) return;
+    const int off = map_base + 3 * slot;
+    double *m = m_all + (size_t)b * n, *P = P_all + (size_t)b * n * n;
+    for (int i = t; i < 3 * n; i += 256) {
+        const int k = i / n, j = i - k * n;
+        P[(size_t)(off + k) * n + j] = 0.0;
+        P[(size_t)j * n + off + k] = 0.0;
+    }
+    __syncthreads();
+    if (t < 3) { P[(size_t)(off + t) * n + off + t] = 1e6; m[off + t] = pf[3 * b + t]; }
+}
+
+// ---------------------------------------------------------------------------------------------
 // batchVisualUpdate (backend.cpp:1001-1010, 1169-1183, 1255-1262): inside a batch every track is gated against the SAME (m, P) -- the
 // updates are deferred --, so one speculative pass (every pending track prepared and gated in one launch) IS the reference's loop up to
 // the next flush. This kernel is the bookkeeping of that loop for one filter: it walks the pending tracks in visit order, appends the
@@ -2178,6 +2203,53 @@ int hv_ekf_visual_track_limited_dev(hv_ekf *h, const hv_vu_params *p, int np, co
     if (max_successful <= 0) max_successful = INT_MAX;
     return visual_track_dev_impl(h, p, np, idx, feat, vel, y, r_gate, r_update, status_dev, gate_status_dev, chi2_dev, pf_dev,
                                  success_counter_dev, max_successful);
+}
+
+// One track visit of a session with a hybrid map (odometry.hybridMapSize > 0; backend.cpp:1016, 1075-1082, 1146, 1160-1168):
+//   map_update_dev [batch]: the map point a mapPointUpdate track belongs to (>= 0) -- the point is read from the state, status
+//                           HV_TRI_HYBRID, H carries dip R in the point's columns -- or -1 for a pose-trail track;
+//   map_offer_dev [batch]:  the slot ekfStateIndex.offerMapPoint would hand to this track if the gate accepts it (-1: none; the offer
+//                           does not depend on the filter, so the adapter evaluates it up front): such an inlier is INSERTED as a map
+//                           point instead of being applied.
+// Dense kernels (the state is wider than 160 columns). Either array may be NULL.
+int hv_ekf_visual_track_hybrid_dev(hv_ekf *h, const hv_vu_params *p, int np, const int *idx, const double *feat, const double *vel,
+                                   const double *y, const int *map_update_dev, const int *map_offer_dev, double r_gate, double r_update,
+                                   int *status_dev, int *gate_status_dev, double *chi2_dev, double *pf_dev)
+{
+    if (!h || !status_dev || !gate_status_dev || !y) return HV_ERR_INVALID;
+    Ekf *e = &h->e; Ctx *c = e->c;
+    if (e->map_dim <= 0 && (map_update_dev || map_offer_dev)) return HV_ERR_INVALID;
+    hv::VuPrepareArgs a;
+    int rc = vu_fill_args(e, p, np, idx, feat, vel, y, a);
+    if (rc != HV_OK) return rc;
+    if (a.rmse_thr >= 0.0) return HV_ERR_UNSUPPORTED;                  // (the dense gate has no RMSE test)
+    const int rows = 2 * np * (a.stereo ? 2 : 1);
+    if (rows > e->max_rows || rows >= HV_CHI2INV95_N) return HV_ERR_INVALID;
+    if (e->vu_rows < rows) {
+        HV_HIP(c, hipStreamSynchronize(c->stream));
+        void *old[] = {e->vuH, e->vuv};
+        for (void *q : old) if (q) (void)hipFree(q);
+        e->vuH = e->vuv = nullptr; e->vu_rows = 0;
+        HV_HIP(c, hipMalloc(reinterpret_cast<void **>(&e->vuH), sizeof(double) * (size_t)rows * e->n * e->batch));
+        HV_HIP(c, hipMalloc(reinterpret_cast<void **>(&e->vuv), sizeof(double) * (size_t)rows * e->batch));
+        if (!e->vupf) HV_HIP(c, hipMalloc(reinterpret_cast<void **>(&e->vupf), sizeof(double) * 3 * e->batch));
+        if (!e->vuactive) HV_HIP(c, hipMalloc(reinterpret_cast<void **>(&e->vuactive), e->batch));
+        if (!e->vuacol) HV_HIP(c, hipMalloc(reinterpret_cast<void **>(&e->vuacol), sizeof(int) * (size_t)e->n * e->batch));
+        e->vu_rows = rows;
+    }
+    const double ns = e->noise_scale;
+    double *pf = pf_dev ? pf_dev : e->vupf;
+    a.H = e->vuH; a.v = e->vuv; a.f = nullptr; a.pf = pf; a.status = status_dev; a.active = e->vuactive; a.gate_status = gate_status_dev;
+    a.map_index = map_update_dev; a.map_base = e->n - e->map_dim;
+    rc = hv::launch_vu_prepare(c, a);
+    if (rc != HV_OK) return rc;
+    // visualTrackOutlierCheck, then -- per filter -- insertMapPoint or updateVisualTrack where it passed
+    rc = hv::ekf_launch_update(e, rows, e->n, e->vuH, e->vuv, nullptr, r_gate * r_gate * ns, 0, 0, 0, chi2_dev, gate_status_dev, e->vuactive);
+    if (rc != HV_OK) return rc;
+    hipLaunchKernelGGL(hv::ekf_hybrid_insert_kernel, dim3(e->batch), dim3(256), 0, c->stream, e->n, e->n - e->map_dim, e->m, e->P, e->vuactive,
+                       gate_status_dev, map_update_dev, map_offer_dev, pf, e->sactive);
+    HV_HIP(c, hipGetLastError());
+    return hv::ekf_launch_update(e, rows, e->n, e->vuH, e->vuv, nullptr, r_update * r_update * ns, 1, 0, 1, nullptr, nullptr, e->sactive, gate_status_dev);
 }
 
 static int visual_track_dev_impl(hv_ekf *h, const hv_vu_params *p, int np, const int *idx, const double *feat, const double *vel,

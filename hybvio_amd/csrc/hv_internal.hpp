@@ -152,6 +152,10 @@ struct VuPrepareArgs {
     // record) and, as an output for the gate / update launch, the per-record row counts 2 * cameras * poses (0: none)
     const int *np_rec;
     int *rows_out;
+    // hybrid-map tracks (mapPointUpdate, backend.cpp:1016,1075-1082; r04): map_index [records] = the map point of the track (>= 0) or -1
+    // for a pose-trail track; the point is then the state m[map_base + 3 idx ..] instead of a triangulation (status HV_TRI_HYBRID), H gets
+    // dip R in its three columns and no point-derivative terms (triangulation.cpp:968-985). Dense H only (fused = 0).
+    const int *map_index; int map_base;
     // length classes of a ragged launch (r03): only records with np_lo <= poses <= np_hi are processed (0, 0: all of them); the others
     // return at once and leave every output alone -- except `active`, cleared when class_inactive is set (a second launch sequence with
     // other kernels serves them in the same visit: short tracks on the two-per-CU fused kernels, long ones on the dense kernels)

@@ -237,7 +237,8 @@ static_assert(VuLds<42, true>::BYTES <= 160 * 1024, "the long build must fit one
 // for the LONG class (49 .. 84 rows, VuLds<.., true>; r04 -- r03 ran 2 + the big gate kernel: two launches and a round trip of Hc
 // through HBM on the critical path of every visit), with S formed from the FACTORS of the Jacobian on the vector unit (ekf_device.hpp
 // structured_S) instead of sparse_gate's dense MFMA products. In 1 .. 3 the dense H is never written, only Hc / acol / v.
-template <int VT, int MAXP, int FUSED>
+// MAP: the launch may hold hybrid-map tracks (VuPrepareArgs::map_index) -- its own instantiation, the others compile as before
+template <int VT, int MAXP, int FUSED, bool MAP = false>
 __device__ __forceinline__ void vu_prepare_body(const VuPrepareArgs &a, const int bx /* filter: blockIdx.x, or the loop variable of a persistent launch */)
 {
     // All LDS comes from the dynamic region (carved below): with static arrays the compiler derives the occupancy from their size
@@ -350,6 +351,16 @@ __device__ __forceinline__ void vu_prepare_body(const VuPrepareArgs &a, const in
     __syncthreads();
     VU_STAMP(1);
     const double *p0 = s_trail;
+    bool map_track = false; int map_off = 0;
+    if constexpr (MAP) {
+        const int mi = a.map_index ? a.map_index[rec] : -1;
+        map_track = mi >= 0; map_off = a.map_base + 3 * mi;
+    }
+    if (MAP && map_track) {
+        // mapPointUpdate (backend.cpp:1075-1082): the point IS a state, nothing to triangulate, no derivative of it w.r.t. the poses
+        if (tid < 3) pfw[tid] = m[map_off + tid];
+        if (tid == 0) { s_flag[1] = HV_TRI_HYBRID; s_flag[2] = 0; }
+    } else
     if (a.linear) {
         // ---- useLinearTriangulation (triangulation.cpp:146-152, triangulateLinear :820-895): the point closest to every camera
         // ray in closed form, pf = S0^-1 S1 with S0 = sum_i A_i, S1 = sum_i A_i p_i, A_i = I - vn_i vn_i', vn_i the normalised
@@ -717,7 +728,7 @@ __device__ __forceinline__ void vu_prepare_body(const VuPrepareArgs &a, const in
     // ---- status, back to world coordinates (:345-392) ----
     int *st_out = a.status + 2 * rec;
     double *M = s_small + 40, *pf0 = s_small + 49;           // R0T * dpf0_dpfi, the point in the frame of pose 0
-    if (tid == 0) {
+    if (tid == 0 && !(MAP && map_track)) {
         int status = HV_TRI_OK;
         if (a.linear) { /* pfw and the world-frame derivative columns are in place */ }
         else if (!s_flag[0]) status = HV_TRI_NO_CONVERGENCE;
@@ -756,7 +767,7 @@ __device__ __forceinline__ void vu_prepare_body(const VuPrepareArgs &a, const in
         __syncthreads();
         if (s_flag[2]) status = HV_TRI_BEHIND;
     }
-    {   // backend.cpp:1098-1102: depth window on whatever point the triangulation left behind
+    if (!(MAP && map_track)) {   // backend.cpp:1098-1102: depth window on whatever point the triangulation left behind
         const double dx = pfw[0] - p0[0], dy = pfw[1] - p0[1], dz = pfw[2] - p0[2], depth = sqrt(dx * dx + dy * dy + dz * dz);
         if (depth < a.min_dist || depth > a.max_dist) status = HV_TRI_BAD_DEPTH;
     }
@@ -1017,6 +1028,7 @@ __device__ __forceinline__ void vu_prepare_body(const VuPrepareArgs &a, const in
             h0 = o[0] * t0 + o[1] * t1 + o[2] * t2 - s_feat[4 * i + 2];
             h1 = o[3] * t0 + o[4] * t1 + o[5] * t2 - s_feat[4 * i + 3];
         }
+        if (MAP && map_track && c >= map_off && c < map_off + 3) { h0 += o[c - map_off]; h1 += o[3 + c - map_off]; }   // :982-984: dip R
         *reinterpret_cast<double2 *>(H + (size_t)c * rows + 2 * i) = double2{h0, h1};
     }
     if (tid < nt) {
@@ -1033,7 +1045,7 @@ __device__ __forceinline__ void vu_prepare_body(const VuPrepareArgs &a, const in
         int prep = 0;
         for (int i = 0; i < nt && prep == 0; ++i) prep = (int)s_it[i * ITER_WORDS + 16];   // first failing pose decides (:920-927)
         st_out[0] = status; st_out[1] = prep;
-        if (a.active) a.active[rec] = (status == HV_TRI_OK && prep == 0) ? 1 : 0;
+        if (a.active) a.active[rec] = ((status == HV_TRI_OK || (MAP && map_track)) && prep == 0) ? 1 : 0;      // backend.cpp:1151-1152
         if (a.gate_status) a.gate_status[rec] = 1;                                     // VuOutlierStatus::NOT_COMPUTED
         if (a.spec_tracks > 0) a.epoch[rec] = a.success_counter[b];                    // (written last: every thread has read it by now)
 #pragma unroll
@@ -1048,6 +1060,7 @@ __global__ __launch_bounds__(VT_THROUGHPUT, 4) void vu_prepare_kernel_2percu(VuP
     vu_prepare_body<VT_THROUGHPUT, MAXP_SMALL, 0>(a, blockIdx.x);
 }
 // the same two builds with the column-sparse chi2 gate fused in (VuPrepareArgs::fused)
+__global__ __launch_bounds__(VT_LATENCY, 3) void vu_prepare_map_kernel(VuPrepareArgs a) { vu_prepare_body<VT_LATENCY, MAXP_ALL, 0, true>(a, blockIdx.x); }
 __global__ __launch_bounds__(VT_LATENCY, 3) void vu_gate_kernel(VuPrepareArgs a) { vu_prepare_body<VT_LATENCY, MAXP_ALL, 1>(a, blockIdx.x); }
 __global__ __launch_bounds__(VT_THROUGHPUT, 4) void vu_gate_kernel_2percu(VuPrepareArgs a)
 {
@@ -1175,6 +1188,16 @@ int launch_vu_prepare(Ctx *c, const VuPrepareArgs &a, hipStream_t stream)
         attr_set = true;
     }
     const dim3 grid((unsigned)a.batch, (unsigned)(a.spec_tracks > 0 ? a.spec_tracks : 1));
+    if (a.map_index) {                                       // hybrid-map tracks: the dense-H build with the map branch
+        if (a.fused || a.map_base < 0) return HV_ERR_INVALID;
+        static bool map_attr_dev[64] = {};
+        bool &map_attr = map_attr_dev[c->p.device & 63];
+        if (!map_attr) {
+            HV_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void *>(vu_prepare_map_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)VuLds<MAXP_ALL>::BYTES));
+            map_attr = true;
+        }
+        hipLaunchKernelGGL(vu_prepare_map_kernel, grid, dim3(VT_LATENCY), VuLds<MAXP_ALL>::BYTES, stream, a);
+    } else
     if (a.fused == 3) {
         constexpr size_t long_bytes = VuLds<MAXP_ALL, true>::BYTES;
         hipLaunchKernelGGL(vu_gate_long_kernel, grid, dim3(VT_LATENCY), long_bytes, stream, a);

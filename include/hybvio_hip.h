@@ -280,6 +280,17 @@ int hv_ekf_visual_track_limited_dev(hv_ekf *ekf, const hv_vu_params *p, int n_po
                                     const double *features_dev, const double *velocities_dev, const double *y_dev,
                                     double r_gate, double r_update, int *status_dev, int *gate_status_dev, double *chi2_dev,
                                     double *pf_dev, int *success_counter_dev, int max_successful);
+/* One track visit of a session with a HYBRID MAP (odometry.hybridMapSize > 0: backend.cpp:1016, 1075-1082, 1146, 1160-1168; ABI 3, r04).
+ * map_update_dev [batch]: the map point a mapPointUpdate track belongs to (>= 0), -1 for a pose-trail track. Such a track is not
+ *   triangulated: the point is the state m[stateDim - 3 hybridMapSize + 3 idx ..], status {HV_TRI_HYBRID, prepare status}, H carries
+ *   dip R in the point's three columns and no point-derivative terms (triangulation.cpp:968-985); gate and update as usual.
+ * map_offer_dev [batch]: the slot ekfStateIndex.offerMapPoint hands to this (pose-trail) track if the gate accepts it, -1: none --
+ *   the offer depends on the track and the index, not on the filter, so the adapter evaluates it before the call. Such an inlier is
+ *   inserted as a map point (insertMapPoint, ekf.cpp:911-921) INSTEAD of being applied; its gate status reads INLIER.
+ * Either array may be NULL. Dense kernels (state wider than 160 columns); trackRmseThreshold < 0 only. Asynchronous. */
+int hv_ekf_visual_track_hybrid_dev(hv_ekf *ekf, const hv_vu_params *p, int n_poses, const int *pose_index_dev, const double *features_dev,
+                                   const double *velocities_dev, const double *y_dev, const int *map_update_dev, const int *map_offer_dev,
+                                   double r_gate, double r_update, int *status_dev, int *gate_status_dev, double *chi2_dev, double *pf_dev);
 /* The whole visual-update loop of one frame (Session::trackerVisualUpdate, backend.cpp:1012-1252, with batchVisualUpdate false)
  * in ONE call: n_tracks track visits in the caller's order (the reference's score order), each seeing the mean the previous one
  * left, a filter leaving the loop after max_successful applied updates. Arrays are TRACK-major so that a visit is one contiguous

@@ -718,6 +718,88 @@ def test_frame_loop_with_batch_visual_update(oracle, B, np_max, K, quota, max_ro
                                      counter.data_ptr(), quota, 2 * ncam * np_max - 2)
         g.close()
 
+
+@pytest.mark.parametrize("stereo,npose", [(True, 6), (False, 9), (True, 14)])
+def test_hybrid_map_track_visit(oracle, stereo, npose):
+    """hv_ekf_visual_track_hybrid_dev (backend.cpp:1016,1075-1082,1146,1160-1168) with odometry.hybridMapSize 3 (state 169 wide): pose-trail
+    tracks applied or -- when offered a slot -- inserted as map points, mapPointUpdate tracks prepared from the point in the state
+    (status HYBRID, dip R in the point's columns), gate rejections of both kinds; every filter against the oracle's sequence."""
+    import torch
+    rng = np.random.default_rng(900 + npose)
+    B, trail_len, M = 12, 20, 3
+    T1, T2, means, idx, feat, vel = _random_tracks(oracle, rng, B, trail_len, npose, stereo, bad_fraction=0.0)
+    n = 20 + 7 * trail_len + 3 * M
+    base = n - 3 * M
+    vp = capi.vu_default_params(imu_to_camera=T1, second_imu_to_camera=T2) if stereo else capi.vu_default_params(imu_to_camera=T1)
+    par = oracle.tri_default_params()
+    r_gate, r_update = 1.5, 0.05
+    kind = np.arange(B) % 4                  # 0 pose-trail track applied, 1 offered a slot, 2 map-point track, 3 map-point track with a gross error
+    map_update = np.where(kind >= 2, np.arange(B) % M, -1).astype(np.int32)
+    map_offer = np.where(kind == 1, (np.arange(B) + 1) % M, -1).astype(np.int32)
+    map_offer[5] = 2                                   # ... and one offered slot whose track the gate rejects (see ys below)
+    ys = feat.reshape(B, -1) + 2e-3 * rng.normal(size=(B, feat.shape[1] * 2))
+    ys[kind == 3] += 3.0
+    ys[5] += 3.0
+    with capi.Context(width=64, height=64) as ctx:
+        g = capi.EkfBatch(ctx, capi.ekf_default_params(cameraTrailLength=trail_len, hybridMapSize=M), B)
+        assert g.n == n
+        filters = []
+        for b in range(B):
+            o = oracle.Ekf(oracle.ekf_default_params(cameraTrailLength=trail_len, hybridMapSize=M))
+            m = np.concatenate([means[b], rng.normal(size=3 * M)])
+            if map_update[b] >= 0:                     # the map point of the track = the point its features were projected from (+ 1 mm)
+                _, _, pf_true, _, _ = oracle.visual_track_prepare(par, means[b], idx[b], T1, T2 if stereo else None, feat[b], vel[b])
+                m[base + 3 * map_update[b]: base + 3 * map_update[b] + 3] = pf_true + 1e-3 * rng.normal(size=3)
+            A = rng.normal(size=(n, n)) * 1e-3
+            P = np.eye(n) * 1e-4 + A @ A.T
+            o.set_state(m); o.set_cov(P)
+            g.set_state(b, m, P)
+            filters.append(o)
+        dev = lambda a, dt: torch.from_numpy(np.array(a, dt, order="C")).cuda()
+        d = [dev(idx, np.int32), dev(feat, np.float64), dev(vel, np.float64), dev(ys, np.float64), dev(map_update, np.int32), dev(map_offer, np.int32)]
+        st = torch.full((B, 2), -9, dtype=torch.int32, device="cuda"); gs = torch.full((B,), -9, dtype=torch.int32, device="cuda")
+        chi = torch.zeros(B, dtype=torch.float64, device="cuda"); pf = torch.zeros((B, 3), dtype=torch.float64, device="cuda")
+        ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+        g.visual_track_hybrid_dev(vp, npose, d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(), d[3].data_ptr(), d[4].data_ptr(), d[5].data_ptr(),
+                                  r_gate, r_update, st.data_ptr(), gs.data_ptr(), chi.data_ptr(), pf.data_ptr())
+        torch.cuda.synchronize()
+        st, gs, chi, pf = st.cpu().numpy(), gs.cpu().numpy(), chi.cpu().numpy(), pf.cpu().numpy()
+        seen = {"applied": 0, "inserted": 0, "map_applied": 0, "map_rejected": 0, "offer_rejected": 0}
+        for b, o in enumerate(filters):
+            m0 = o.m.copy()
+            if map_update[b] >= 0:
+                off = base + 3 * map_update[b]
+                trail = oracle.extract_camera_pose_trail(m0, idx[b], T1, T2 if stereo else None)
+                ops, oH, of = oracle.prepare_visual_update(m0[off:off + 3], None, None, np.zeros(3), vel[b], trail, idx[b], n, truncated=False,
+                                                           map_point_offset=off)
+                assert st[b].tolist() == [1, ops], (b, st[b].tolist(), ops)          # HV_TRI_HYBRID
+                assert np.allclose(pf[b], m0[off:off + 3], rtol=0, atol=0)
+                ok = ops == 0
+            else:
+                ost, ops, opf, oH, of = oracle.visual_track_prepare(par, m0, idx[b], T1, T2 if stereo else None, feat[b], vel[b])
+                assert st[b].tolist() == [ost, ops], (b, st[b].tolist(), [ost, ops])
+                ok = (ost, ops) == (0, 0)
+                if ok:
+                    assert _rel(pf[b], opf) < 1e-9
+            if not ok:
+                assert gs[b] == 1
+            else:
+                status, c2 = o.visual_track_outlier_check(oH, of, ys[b], r_gate)
+                assert gs[b] == status and abs(chi[b] - c2) <= 1e-7 * max(1.0, abs(c2)), (b, gs[b], status, chi[b], c2)
+                if status == 0:
+                    if map_update[b] < 0 and map_offer[b] >= 0:
+                        o.insert_map_point(int(map_offer[b]), opf); seen["inserted"] += 1
+                    else:
+                        o.update_visual_track(oH, of, ys[b], r_update); seen["map_applied" if map_update[b] >= 0 else "applied"] += 1
+                elif map_update[b] >= 0:
+                    seen["map_rejected"] += 1
+                elif map_offer[b] >= 0:
+                    seen["offer_rejected"] += 1
+            mg, Pg = g.get_state(b)
+            assert _rel(mg, o.m) < 1e-8 and _rel(Pg, o.P) < 1e-7, (b, kind[b], _rel(mg, o.m), _rel(Pg, o.P))
+        assert all(v > 0 for v in seen.values()), seen
+        g.close()
+
 @pytest.mark.parametrize("B,np_max,growth,rmse_thr,variant", [
     (48, 21, 1.5, 2.5, "sorted_small_batch"),      # two sorted length classes: vu_gate_kernel + vu_gate_long_kernel keep the per-filter multiplier
     (300, 21, 1.3, 2.5, "default"),                # ... more filters than CUs (two-per-CU build, second stream)
