@@ -942,7 +942,9 @@ __device__ __forceinline__ void vu_prepare_body(const VuPrepareArgs &a, const in
         lds_barrier();                                            // everything but the factor copies / s_acol is dead from here on (the stores above stay in flight)
         VU_STAMP(31);
         double *T = vu_lds;
-        if (STRUCT && (Rs * rows > T_CAP || g_cap < 832 + VT / 64)) {         // (cannot happen: the launcher admits what the carve holds) not gated, never applied
+        // (structured_S serves the poses in one group where A = na x rows fits g_cap, else in two: the half must fit)
+        const int g_half = na * ((2 * ncam * ((n + 1) >> 1)) | 1), g_all = na * (rows | 1);
+        if (STRUCT && (Rs * rows > T_CAP || g_cap < 832 + VT / 64 || (g_all > g_cap && g_half > g_cap))) {   // (cannot happen: the launcher admits what the carve holds) not gated, never applied
             if (tid == 0 && a.gate_status) a.gate_status[rec] = 1;
             return;
         }
