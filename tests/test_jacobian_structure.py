@@ -55,3 +55,56 @@ def test_prepare_visual_update_jacobian_is_block_diagonal_plus_rank_four(npose, 
         assert np.abs(resid).max() < 1e-9 * max(1.0, np.abs(col).max()), (npose, b, np.abs(resid).max())
         checked += 1
     assert checked >= 3
+
+
+@pytest.mark.parametrize("npose,stereo", [(7, True), (21, True), (12, False)])
+def test_structured_s_formula_equals_the_dense_product(npose, stereo):
+    """The arithmetic of structured_S restated in numpy on the oracle's Jacobian: recover O4 and F4 from H (O from the off-pose blocks,
+    F = the point's derivatives), check that what is left (Dp) lives in the own-pose blocks only, then form
+        A = W Dp', WF = W F4', S = Dp A + (Dp WF) O4' + O4 (F4 A + (F4 WF) O4')
+    with an UNSYMMETRIC W (P is read as stored) and compare with Hc W Hc'."""
+    rng = np.random.default_rng(70 + npose)
+    T1, T2, means, idx, feat = synth.visual_tracks(rng, 3, 20, npose, stereo)
+    vel = rng.normal(size=feat.shape) * 0.1
+    par = oracle.tri_default_params()
+    done = 0
+    for b in range(3):
+        st, ps, pf, H, f = oracle.visual_track_prepare(par, means[b], idx[b], T1, T2 if stereo else None, feat[b], vel[b])
+        if (st, ps) != (0, 0):
+            continue
+        nt = npose * (2 if stereo else 1)
+        acol = [c for k in range(npose) for c in _pose_cols(int(idx[b][k]))] + [SFT]      # the device's column order: 7 per pose, then SFT
+        Hc = H[:, acol]
+        nr, na = Hc.shape
+        pose_of_row = np.array([(r // 2) % npose for r in range(nr)])
+        own = np.zeros((nr, na), bool)
+        for r in range(nr):
+            own[r, 7 * pose_of_row[r]: 7 * pose_of_row[r] + 7] = True
+        # F (3 x 7 n) = the triangulated point's derivatives w.r.t. the poses (the two cameras of a pose summed: backend.cpp:1108-1119),
+        # straight from the oracle's triangulator; O (nr x 3) then follows from the off-pose entries of H by linear least squares
+        trail = oracle.extract_camera_pose_trail(means[b], idx[b], T1, T2 if stereo else None)
+        tst, tpf, dp, dq, dt = oracle.triangulate(par, trail, feat[b], vel[b], stereo=stereo, calc_derivatives=True)
+        assert tst == 0
+        F = np.zeros((3, 7 * npose))
+        for k in range(npose):
+            F[:, 7 * k: 7 * k + 3] = dp[k] + (dp[k + npose] if stereo else 0.0)
+            F[:, 7 * k + 3: 7 * k + 7] = dq[k] + (dq[k + npose] if stereo else 0.0)
+        M = ~own[:, :7 * npose]
+        O = np.zeros((nr, 3))
+        for r in range(nr):
+            O[r] = np.linalg.lstsq(F[:, M[r]].T, Hc[r, :7 * npose][M[r]], rcond=None)[0]
+        assert np.abs((O @ F - Hc[:, :7 * npose])[M]).max() < 1e-9 * np.abs(Hc).max()
+        ft = np.linalg.lstsq(O, Hc[:, -1] + vel[b].reshape(-1), rcond=None)[0]            # time-shift column = O f_t - velocity
+        O4 = np.hstack([O, -vel[b].reshape(-1, 1)])
+        F4 = np.zeros((4, na)); F4[:3, :7 * npose] = F; F4[:3, -1] = ft; F4[3, -1] = 1.0
+        Dp = Hc - O4 @ F4
+        assert np.abs(Dp[~own]).max() < 1e-8 * np.abs(Hc).max()                            # nothing of Dp outside the own-pose blocks
+        Dp = np.where(own, Dp, 0.0)
+        W = rng.normal(size=(na, na))                                                      # not symmetric on purpose
+        A, WF = W @ Dp.T, W @ F4.T
+        S = Dp @ A + (Dp @ WF) @ O4.T + O4 @ (F4 @ A + (F4 @ WF) @ O4.T)
+        ref = (Dp + O4 @ F4) @ W @ (Dp + O4 @ F4).T
+        assert np.abs(S - ref).max() < 1e-10 * np.abs(ref).max()
+        assert np.abs(ref - Hc @ W @ Hc.T).max() < 1e-6 * np.abs(ref).max()
+        done += 1
+    assert done >= 1
