@@ -303,7 +303,7 @@ int hv_ekf_visual_track_hybrid_dev(hv_ekf *ekf, const hv_vu_params *p, int n_pos
  * trackOutlierThresholdGrowthFactor != 1, trackRmseThreshold >= 0; gate status 2 = RMSE) are kept per filter on the device; with a
  * growth factor != 1 the loop always runs sequentially (a rejection changes the threshold of the NEXT track).
  * max_successful <= 0 means "no limit" (the reference's maxSuccessfulVisualUpdates <= 0, backend.cpp:1233).
- * With few sequences (batch * n_tracks <= 256, n_rows <= 48) the loop runs speculatively: each pass prepares and gates every
+ * With few sequences (batch * n_tracks <= 256; since r04 for tracks of up to 84 rows, i.e. 21 stereo poses) the loop runs speculatively: each pass prepares and gates every
  * pending track of a filter in parallel against the current (m, P), applies the first inlier in visit order and re-examines only
  * the tracks behind it -- at most min(max_successful, n_tracks) + 1 passes, the same statuses and the same filter as the sequential
  * loop. chi2_dev / pf_dev entries of tracks the loop never visits (status HV_TRI_NOT_VISITED) are 0.
