@@ -77,6 +77,16 @@ def test_vu_params_defaults_keep_the_adaptive_thresholds_off():
     assert vp.triangulationGaussNewtonIterations == 10 and vp.useLinearTriangulation == 0
 
 
+def test_r04_ekf_entries_reject_a_null_filter_before_any_device_work():
+    """hv_ekf_symmetrize_augment_dev, hv_ekf_visual_frame_batch_dev, hv_ekf_visual_track_hybrid_dev (ABI 3, r04): a null filter handle is
+    HV_ERR_INVALID, decided on the host."""
+    L = capi.lib()
+    vp = capi.vu_default_params()
+    assert L.hv_ekf_symmetrize_augment_dev(None, None, None) == -1
+    assert L.hv_ekf_visual_frame_batch_dev(None, C.byref(vp), 4, 6, None, None, None, None, None, 1.5, 0.05, None, None, None, None, None, 5, 0) == -1
+    assert L.hv_ekf_visual_track_hybrid_dev(None, C.byref(vp), 6, None, None, None, None, None, None, 1.5, 0.05, None, None, None, None) == -1
+
+
 def test_no_silent_cpu_fallback():
     """Without a GPU the product path must fail loudly (HV_ERR_NO_DEVICE), never compute on the CPU."""
     import torch
