@@ -2515,6 +2515,31 @@ static int visual_track_dev_impl(hv_ekf *h, const hv_vu_params *p, int np, const
 }
 
 
+// work buffers of the speculative frame loops and the batch loop: one record per (track, filter) -- compact or dense Jacobian, residual,
+// point, flags, column list, rows -- plus the per-filter cursors; grown (never shrunk below a later request) on first use of a shape
+static int ensure_spec_buffers(Ekf *e, size_t rec, int rows)
+{
+    Ctx *c = e->c;
+    if (e->sp_records >= rec && e->sp_rows >= rows) return HV_OK;
+    const size_t B = (size_t)e->batch;
+    HV_HIP(c, hipStreamSynchronize(c->stream));
+    void *old[] = {e->spH, e->spv, e->sppf, e->spactive, e->spcursor, e->spepoch, e->spcursor2, e->sppub, e->spacol, e->sprows};
+    for (void *q : old) if (q) (void)hipFree(q);
+    e->spH = e->spv = e->sppf = nullptr; e->spactive = nullptr; e->spcursor = e->spepoch = e->spcursor2 = e->sppub = e->spacol = e->sprows = nullptr; e->sp_records = 0;
+    HV_HIP(c, hipMalloc(reinterpret_cast<void **>(&e->spH), sizeof(double) * rec * rows * e->n));
+    HV_HIP(c, hipMalloc(reinterpret_cast<void **>(&e->spv), sizeof(double) * rec * rows));
+    HV_HIP(c, hipMalloc(reinterpret_cast<void **>(&e->sppf), sizeof(double) * rec * 3));
+    HV_HIP(c, hipMalloc(reinterpret_cast<void **>(&e->spactive), rec));
+    HV_HIP(c, hipMalloc(reinterpret_cast<void **>(&e->spcursor), sizeof(int) * B));
+    HV_HIP(c, hipMalloc(reinterpret_cast<void **>(&e->spepoch), sizeof(int) * rec));
+    HV_HIP(c, hipMalloc(reinterpret_cast<void **>(&e->spcursor2), sizeof(int) * B));
+    HV_HIP(c, hipMalloc(reinterpret_cast<void **>(&e->sppub), sizeof(int) * rec));
+    HV_HIP(c, hipMalloc(reinterpret_cast<void **>(&e->spacol), sizeof(int) * rec * e->n));
+    HV_HIP(c, hipMalloc(reinterpret_cast<void **>(&e->sprows), sizeof(int) * rec));
+    e->sp_records = rec; e->sp_rows = rows;
+    return HV_OK;
+}
+
 static int visual_frame_dev_impl(hv_ekf *h, const hv_vu_params *p, int n_tracks, int np, const int *np_rec_dev, const int *idx,
                                  const double *feat, const double *vel,
                             const double *y, double r_gate, double r_update, int *status_dev, int *gate_status_dev, double *chi2_dev,
@@ -2552,23 +2577,7 @@ static int visual_frame_dev_impl(hv_ekf *h, const hv_vu_params *p, int n_tracks,
     if (!c->knob.ekf_no_speculation && !adaptive && n_tracks >= 2 && B * (size_t)n_tracks <= (size_t)c->num_cus && rows > 48 && p && idx && feat && vel && y &&
         c->knob.ekf_spec_split == 0 && c->knob.ekf_spec_mode != 3 && c->knob.ekf_long_fused != 0 && visit_shape(e, np, p->useStereo != 0).long_ok) {
         const size_t rec = B * (size_t)n_tracks;
-        if (e->sp_records < rec || e->sp_rows < rows) {
-            HV_HIP(c, hipStreamSynchronize(c->stream));
-            void *old[] = {e->spH, e->spv, e->sppf, e->spactive, e->spcursor, e->spepoch, e->spcursor2, e->sppub, e->spacol, e->sprows};
-            for (void *q : old) if (q) (void)hipFree(q);
-            e->spH = e->spv = e->sppf = nullptr; e->spactive = nullptr; e->spcursor = e->spepoch = e->spcursor2 = e->sppub = e->spacol = e->sprows = nullptr; e->sp_records = 0;
-            HV_HIP(c, hipMalloc(reinterpret_cast<void **>(&e->spH), sizeof(double) * rec * rows * e->n));
-            HV_HIP(c, hipMalloc(reinterpret_cast<void **>(&e->spv), sizeof(double) * rec * rows));
-            HV_HIP(c, hipMalloc(reinterpret_cast<void **>(&e->sppf), sizeof(double) * rec * 3));
-            HV_HIP(c, hipMalloc(reinterpret_cast<void **>(&e->spactive), rec));
-            HV_HIP(c, hipMalloc(reinterpret_cast<void **>(&e->spcursor), sizeof(int) * B));
-            HV_HIP(c, hipMalloc(reinterpret_cast<void **>(&e->spepoch), sizeof(int) * rec));
-            HV_HIP(c, hipMalloc(reinterpret_cast<void **>(&e->spcursor2), sizeof(int) * B));
-            HV_HIP(c, hipMalloc(reinterpret_cast<void **>(&e->sppub), sizeof(int) * rec));
-            HV_HIP(c, hipMalloc(reinterpret_cast<void **>(&e->spacol), sizeof(int) * rec * e->n));
-            HV_HIP(c, hipMalloc(reinterpret_cast<void **>(&e->sprows), sizeof(int) * rec));
-            e->sp_records = rec; e->sp_rows = rows;
-        }
+        { const int rc_sp = ensure_spec_buffers(e, rec, rows); if (rc_sp != HV_OK) return rc_sp; }
         if (!e->side_dm) {
             HV_HIP(c, hipMalloc(reinterpret_cast<void **>(&e->side_dm), sizeof(double) * (size_t)e->n * B));
             HV_HIP(c, hipMemsetAsync(e->side_dm, 0, sizeof(double) * (size_t)e->n * B, c->stream));
@@ -2607,24 +2616,7 @@ static int visual_frame_dev_impl(hv_ekf *h, const hv_vu_params *p, int n_tracks,
     // (a growth factor != 1 makes the threshold of a track depend on the verdicts of the tracks in front of it: no parallel gating)
     if (!c->knob.ekf_no_speculation && !adaptive && n_tracks >= 2 && B * (size_t)n_tracks <= 256 && e->n <= 160 && rows <= 48 && p && idx && feat && vel && y) {
         const size_t rec = B * (size_t)n_tracks;
-        if (e->sp_records < rec || e->sp_rows < rows) {
-            HV_HIP(c, hipStreamSynchronize(c->stream));
-            void *old[] = {e->spH, e->spv, e->sppf, e->spactive, e->spcursor, e->spepoch, e->spcursor2, e->sppub, e->spacol};
-            for (void *q : old) if (q) (void)hipFree(q);
-            e->spH = e->spv = e->sppf = nullptr; e->spactive = nullptr; e->spcursor = e->spepoch = e->spcursor2 = e->sppub = e->spacol = nullptr; e->sp_records = 0;
-            HV_HIP(c, hipMalloc(reinterpret_cast<void **>(&e->spH), sizeof(double) * rec * rows * e->n));
-            HV_HIP(c, hipMalloc(reinterpret_cast<void **>(&e->spv), sizeof(double) * rec * rows));
-            HV_HIP(c, hipMalloc(reinterpret_cast<void **>(&e->sppf), sizeof(double) * rec * 3));
-            HV_HIP(c, hipMalloc(reinterpret_cast<void **>(&e->spactive), rec));
-            HV_HIP(c, hipMalloc(reinterpret_cast<void **>(&e->spcursor), sizeof(int) * B));
-            HV_HIP(c, hipMalloc(reinterpret_cast<void **>(&e->spepoch), sizeof(int) * rec));
-            HV_HIP(c, hipMalloc(reinterpret_cast<void **>(&e->spcursor2), sizeof(int) * B));
-            HV_HIP(c, hipMalloc(reinterpret_cast<void **>(&e->sppub), sizeof(int) * rec));
-            HV_HIP(c, hipMalloc(reinterpret_cast<void **>(&e->spacol), sizeof(int) * rec * e->n));
-            if (e->sprows) { (void)hipFree(e->sprows); e->sprows = nullptr; }
-            HV_HIP(c, hipMalloc(reinterpret_cast<void **>(&e->sprows), sizeof(int) * rec));
-            e->sp_records = rec; e->sp_rows = rows;
-        }
+        { const int rc_sp = ensure_spec_buffers(e, rec, rows); if (rc_sp != HV_OK) return rc_sp; }
         HV_HIP(c, hipMemsetAsync(e->spcursor, 0, sizeof(int) * B, c->stream));
         HV_HIP(c, hipMemsetAsync(e->spcursor2, 0, sizeof(int) * B, c->stream));                   // (ping-pong partner: never read uninitialised)
         HV_HIP(c, hipMemsetAsync(e->spepoch, 0xFF, sizeof(int) * rec, c->stream));               // -1: nothing prepared yet
@@ -2755,23 +2747,7 @@ int hv_ekf_visual_frame_batch_dev(hv_ekf *h, const hv_vu_params *p, int n_tracks
     const VisitShape shape = visit_shape(e, np, p->useStereo != 0);
     const bool long_build = rows > 48;
     if (long_build ? !(shape.long_ok && c->knob.ekf_long_fused != 0) : !hv::vu_fused_supported(c, e->n, np, p->useStereo != 0, (int)rec)) return HV_ERR_UNSUPPORTED;
-    if (e->sp_records < rec || e->sp_rows < rows) {
-        HV_HIP(c, hipStreamSynchronize(c->stream));
-        void *old[] = {e->spH, e->spv, e->sppf, e->spactive, e->spcursor, e->spepoch, e->spcursor2, e->sppub, e->spacol, e->sprows};
-        for (void *q : old) if (q) (void)hipFree(q);
-        e->spH = e->spv = e->sppf = nullptr; e->spactive = nullptr; e->spcursor = e->spepoch = e->spcursor2 = e->sppub = e->spacol = e->sprows = nullptr; e->sp_records = 0;
-        HV_HIP(c, hipMalloc(reinterpret_cast<void **>(&e->spH), sizeof(double) * rec * rows * e->n));
-        HV_HIP(c, hipMalloc(reinterpret_cast<void **>(&e->spv), sizeof(double) * rec * rows));
-        HV_HIP(c, hipMalloc(reinterpret_cast<void **>(&e->sppf), sizeof(double) * rec * 3));
-        HV_HIP(c, hipMalloc(reinterpret_cast<void **>(&e->spactive), rec));
-        HV_HIP(c, hipMalloc(reinterpret_cast<void **>(&e->spcursor), sizeof(int) * B));
-        HV_HIP(c, hipMalloc(reinterpret_cast<void **>(&e->spepoch), sizeof(int) * rec));
-        HV_HIP(c, hipMalloc(reinterpret_cast<void **>(&e->spcursor2), sizeof(int) * B));
-        HV_HIP(c, hipMalloc(reinterpret_cast<void **>(&e->sppub), sizeof(int) * rec));
-        HV_HIP(c, hipMalloc(reinterpret_cast<void **>(&e->spacol), sizeof(int) * rec * e->n));
-        HV_HIP(c, hipMalloc(reinterpret_cast<void **>(&e->sprows), sizeof(int) * rec));
-        e->sp_records = rec; e->sp_rows = rows;
-    }
+    { const int rc_sp = ensure_spec_buffers(e, rec, rows); if (rc_sp != HV_OK) return rc_sp; }
     if (e->b_rows < max_update_rows) {
         HV_HIP(c, hipStreamSynchronize(c->stream));
         void *old[] = {e->bH, e->bv, e->brows, e->bany};
