@@ -15,6 +15,7 @@ Prints ONE JSON line (rank 0). See DESIGN.md section "Measurement" for the byte 
 from __future__ import annotations
 
 import argparse
+import functools
 import json
 import os
 import sys
@@ -1142,6 +1143,67 @@ def tracker_leg(env, args, B, local_rank, rank, label):
     return tb, res
 
 
+# ---- what rank 0 prints ----------------------------------------------------------------------------------------------------------
+# The driver reads the LAST stdout line as the record and keeps only a few KB of stdout; r04's single 22.6 KB line did not survive
+# that (BENCH_r04.json: parsed null). So: the full object goes to a file (and, prefixed so that it is not mistaken for the record, to
+# an earlier stdout line); the last line is a compact object of scalars only, bounded by COMPACT_LIMIT bytes.
+COMPACT_LIMIT = 4096
+COMPACT_TOP = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data")
+COMPACT_CONFIG = ("workload", "sequences_per_gpu", "engines_per_gpu", "frames_per_step", "parallelism", "parity_ok", "parity_checked_sequences",
+                  "stage_frac_agreed", "stage_frac_actual", "one_engine_value", "lanes_2_value", "c3_uniform_value", "c3_chained_value",
+                  "c4_value", "c4_stage_frac_agreed", "latency_ms_eager", "latency_ms_graph")
+COMPACT_ROOFLINE = ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "algorithmic_bytes_per_launch", "avg_launch_ms",
+                    "frac_pmc_bytes", "frac_valu_issue", "valu_cycles_per_wave64_inst", "traffic_source")
+COMPACT_CPU = ("value", "unit", "cores", "kind", "single_thread_value", "ekf_threads", "compiler_flags", "sample")
+
+
+def _short(v, n):
+    if isinstance(v, float):
+        return float(f"{v:.6g}")
+    if isinstance(v, str) and len(v) > n:
+        return v[:n - 1] + "~"
+    return v
+
+
+def compact_record(out, limit=COMPACT_LIMIT):
+    """The record line: exactly the contract's keys + `config`, `roofline`, `cpu_baseline` of scalars, <= `limit` bytes."""
+    pick = lambda src, keys, n: {k: _short(src[k], n) for k in keys if k in src and not isinstance(src[k], (dict, list))}
+    for n in (400, 200, 120, 60):                                       # shorten the free-text fields until the line fits
+        rec = pick(out, COMPACT_TOP, n)
+        cfg = dict(out.get("config", {}))
+        get = lambda *path: functools.reduce(lambda o, k: o.get(k, {}) if isinstance(o, dict) else {}, path, out)
+        for k, v in (("c3_uniform_value", get("c3_uniform", "value")), ("c3_chained_value", get("c3_chained", "value")),
+                     ("c4_value", get("c4", "value")), ("c4_stage_frac_agreed", get("c4", "stage_pyramid_klt", "frac_of_8TBs")),
+                     ("latency_ms_eager", get("latency_mode", "ms_per_frame")), ("latency_ms_graph", get("latency_mode_graph", "ms_per_frame"))):
+            if not isinstance(v, dict):
+                cfg[k] = v
+        rec["config"] = pick(cfg, COMPACT_CONFIG, n)
+        rec["roofline"] = pick(out.get("roofline", {}), COMPACT_ROOFLINE, n)
+        if "cpu_baseline" in out:
+            rec["cpu_baseline"] = pick(out["cpu_baseline"], COMPACT_CPU, n)
+        rec["full_record"] = "bench_full.json (also the stdout line starting with FULL_RECORD)"
+        line = json.dumps(rec, separators=(",", ":"))
+        if len(line) <= limit:
+            return line
+    raise RuntimeError(f"compact bench record is {len(line)} bytes > {limit}")
+
+
+def emit_record(out):
+    full = json.dumps(out)
+    for path in ("bench_full.json", os.path.join("gpurun_out", "bench_full.json")):
+        try:
+            if os.path.dirname(path):
+                os.makedirs(os.path.dirname(path), exist_ok=True)
+            with open(path, "w") as f:
+                f.write(full + "\n")
+        except OSError:                                                  # read-only checkout: the stdout copy remains
+            pass
+    print("FULL_RECORD " + full)
+    sys.stdout.flush()
+    print(compact_record(out))
+    sys.stdout.flush()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -1826,7 +1888,7 @@ def main():
                                 if "error" not in nat else nat)}
     if rank == 0:
         out["max_barrier_wait_s"] = env.max_barrier_wait_s
-        print(json.dumps(out))
+        emit_record(out)
     env.close()
 
 

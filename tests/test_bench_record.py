@@ -1,0 +1,71 @@
+"""The record bench.py prints: the driver keeps a few KB of stdout and reads the LAST line (BENCH_r04.json: a 22.6 KB single line
+came back `parsed: null`). The last line must therefore stay a compact JSON object with the contract's keys, whatever the legs add
+to the full object."""
+import io
+import json
+import os
+from contextlib import redirect_stdout
+
+import bench
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+FULL = os.path.join(HERE, "..", "profiles", "r04", "bench_default.json")            # a full object as a real run produced it
+
+TOP = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data")
+
+
+def _full():
+    with open(FULL) as f:
+        return json.load(f)
+
+
+def test_compact_record_fits_and_carries_the_contract():
+    out = _full()
+    line = bench.compact_record(out)
+    assert "\n" not in line and len(line) <= bench.COMPACT_LIMIT < 6000
+    d = json.loads(line)
+    for k in TOP:
+        assert k in d, k
+    assert d["value"] == float(f"{out['value']:.6g}") and d["unit"] == "frames/s" and d["higher_is_better"] is True
+    assert abs(d["ms_per_step"] - out["ms_per_step"]) < 1e-3 * out["ms_per_step"]
+    cfg, roof, cpu = d["config"], d["roofline"], d["cpu_baseline"]
+    for k in ("workload", "sequences_per_gpu", "engines_per_gpu", "frames_per_step", "parity_ok", "parity_checked_sequences",
+              "stage_frac_agreed", "stage_frac_actual", "one_engine_value", "lanes_2_value"):
+        assert k in cfg, k
+    assert "model" not in cfg
+    for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "algorithmic_bytes_per_launch", "avg_launch_ms"):
+        assert k in roof, k
+    assert abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-4
+    for k in ("value", "unit", "cores", "kind", "sample"):
+        assert k in cpu, k
+    # nothing nested below the three objects: the record is scalars only
+    assert all(not isinstance(v, (dict, list)) for o in (cfg, roof, cpu) for v in o.values())
+
+
+def test_compact_record_stays_bounded_when_the_full_object_grows():
+    out = _full()
+    out["config"]["workload"] = "w" * 20000
+    out["cpu_baseline"]["sample"] = "s" * 20000
+    out["roofline"]["traffic_source"] = "t" * 20000
+    out["some_new_leg"] = {"blob": ["x" * 100] * 1000}
+    line = bench.compact_record(out)
+    assert len(line) <= bench.COMPACT_LIMIT
+    assert json.loads(line)["value"] == float(f"{out['value']:.6g}")
+
+
+def test_emit_record_prints_the_compact_object_last(tmp_path, monkeypatch):
+    monkeypatch.chdir(tmp_path)
+    out = _full()
+    buf = io.StringIO()
+    with redirect_stdout(buf):
+        bench.emit_record(out)
+    lines = buf.getvalue().splitlines()
+    assert len(lines) == 2 and lines[0].startswith("FULL_RECORD {") and lines[1].startswith("{")
+    assert len(lines[1]) <= bench.COMPACT_LIMIT
+    assert json.loads(lines[1])["metric"] == out["metric"]
+    assert json.loads(lines[0][len("FULL_RECORD "):]) == out
+    with open(tmp_path / "bench_full.json") as f:
+        assert json.load(f) == out
+    # what a tail of 8 KB of stdout still holds: the whole record line
+    tail = buf.getvalue()[-8192:]
+    assert json.loads(tail.splitlines()[-1])["value"] == float(f"{out['value']:.6g}")
