@@ -364,7 +364,10 @@ __device__ __forceinline__ void structured_S(const double *P, int N, const int *
     for (int e = t; e < 3 * na; e += NT) {                                         // (WFp: written in front of the last group's first barrier)                                         // (e = 3 u' + c)
         double sum = 0.0;
         for (int sl = 0; sl < nslots; sl++) sum += WFp[(size_t)sl * na * 3 + e];
-        WF[4 * (e / 3) + e % 3] = sum;
+        // the slots summed the pose columns u < 7 n; F4's last column (the point's derivative w.r.t. the time shift, non-zero with
+        // estimateImuCameraTimeShift) meets W's time-shift column, which is WF(:, 3) (r04 advisor: this term was missing)
+        const int up = e / 3, c = e - 3 * up;
+        WF[4 * up + c] = sum + WF[4 * up + 3] * F4[c * f4s + 7 * n];
     }
     lds_barrier();
     SS_STAMP(7);

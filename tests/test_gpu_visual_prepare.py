@@ -321,6 +321,62 @@ def test_visual_track_dev_prepare_gate_update_equals_the_reference_sequence(orac
         g.close()
 
 
+@pytest.mark.parametrize("variant,npose", [("default", 13), ("default", 17), ("default", 21), ("long_two_launches", 21), ("default", 9)])
+def test_long_gate_chi2_with_time_shift_cross_covariance(oracle, variant, npose):
+    """r04 advisor: structured_S (the factor form of the long class's gate, ekf_device.hpp) left W(:, sft) * dpf/dt out of WF = W F4'.
+    The term only shows when P couples the IMU-camera time shift (state 19) with the poses -- here strongly -- and the track has a
+    feature velocity, i.e. on every real sequence once the filter has run. chi2 and S must agree with the oracle as tightly as the
+    MFMA gates do: 1e-10 relative (the missing term was 1e-7 .. 2e-6)."""
+    import torch
+    rng = np.random.default_rng(500 + npose)
+    B, trail_len = 16, 20
+    T1, T2, means, idx, feat, vel = _random_tracks(oracle, rng, B, trail_len, npose, True, bad_fraction=0.0)
+    vel *= 5.0                                                                           # px/s-scale feature velocities: a large d pf / d t
+    y = feat.reshape(B, -1) + 2e-3 * rng.normal(size=(B, feat.shape[1] * 2))
+    vp = capi.vu_default_params(imu_to_camera=T1, second_imu_to_camera=T2)
+    assert vp.estimateImuCameraTimeShift
+    par = oracle.tri_default_params()
+    with capi.Context(width=64, height=64) as ctx:
+        _apply(ctx, variant)
+        g = capi.EkfBatch(ctx, capi.ekf_default_params(cameraTrailLength=trail_len), B)
+        filters = []
+        for b in range(B):
+            o = oracle.Ekf(oracle.ekf_default_params(cameraTrailLength=trail_len))
+            A = rng.normal(size=(o.n, o.n)) * 0.02
+            A[SFT, :] *= 30.0                                                            # the time shift is the most uncertain, most coupled state
+            P = A @ A.T * 1e-3 + np.eye(o.n) * 1e-5
+            o.set_state(means[b]); o.set_cov(P)
+            g.set_state(b, means[b], P)
+            filters.append(o)
+        dev = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a, dt)).cuda()
+        d_idx, d_feat, d_vel, d_y = dev(idx, np.int32), dev(feat, np.float64), dev(vel, np.float64), dev(y, np.float64)
+        st = torch.full((B, 2), -1, dtype=torch.int32, device="cuda")
+        gs = torch.full((B,), -1, dtype=torch.int32, device="cuda")
+        chi = torch.zeros((B,), dtype=torch.float64, device="cuda")
+        pf = torch.zeros((B, 3), dtype=torch.float64, device="cuda")
+        ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+        g.visual_track_dev(vp, npose, d_idx.data_ptr(), d_feat.data_ptr(), d_vel.data_ptr(), d_y.data_ptr(), 1.5, 0.05,
+                           st.data_ptr(), gs.data_ptr(), chi.data_ptr(), pf.data_ptr())
+        torch.cuda.synchronize()
+        st, gs, chi = st.cpu().numpy(), gs.cpu().numpy(), chi.cpu().numpy()
+        compared, coupled = 0, 0
+        for b, o in enumerate(filters):
+            ost, ops, opf, oH, of = oracle.visual_track_prepare(par, means[b], idx[b], T1, T2, feat[b], vel[b])
+            assert st[b].tolist() == [ost, ops]
+            if (ost, ops) != (0, 0):
+                continue
+            status, chi2 = o.visual_track_outlier_check(oH, of, y[b], 1.5)
+            assert gs[b] == status
+            assert abs(chi[b] - chi2) <= 1e-10 * max(1.0, abs(chi2)), (b, chi[b], chi2)
+            # the input exercises the term: dropping the time-shift column's coupling moves chi2 by far more than the tolerance
+            P2 = o.P.copy(); P2[SFT, :] = 0.0; P2[:, SFT] = 0.0
+            o2 = oracle.Ekf(oracle.ekf_default_params(cameraTrailLength=trail_len)); o2.set_state(means[b]); o2.set_cov(P2)
+            coupled += abs(o2.visual_track_outlier_check(oH, of, y[b], 1.5)[1] - chi2) > 1e-8 * abs(chi2)   # 100x the tolerance above
+            compared += 1
+        assert compared >= B // 2 and coupled >= compared // 2, (compared, coupled)
+        g.close()
+
+
 @pytest.mark.parametrize("variant", ["default", "vu384", "dense", "gate_own_launch_vu384"])
 def test_frame_loop_with_the_successful_update_quota(oracle, variant):
     """A frame's visual-update loop for a batch (backend.cpp:1012-1240): K tracks per filter, visited in order, each seeing the

@@ -101,7 +101,16 @@ def test_structured_s_formula_equals_the_dense_product(npose, stereo):
         assert np.abs(Dp[~own]).max() < 1e-8 * np.abs(Hc).max()                            # nothing of Dp outside the own-pose blocks
         Dp = np.where(own, Dp, 0.0)
         W = rng.normal(size=(na, na))                                                      # not symmetric on purpose
-        A, WF = W @ Dp.T, W @ F4.T
+        A = W @ Dp.T
+        # WF = W F4' summed as the device sums it (ekf_device.hpp structured_S): the pose columns u < 7 n in the gather loop, column 3 =
+        # W's time-shift column (F4's unit row), then the time-shift column's share of columns 0..2 -- leaving that last term out (r04)
+        # is an error of 1e-7 .. 1e-6 of S with a dense W, far above the 1e-10 asserted below
+        WF = np.zeros((na, 4))
+        WF[:, :3] = W[:, :7 * npose] @ F4[:3, :7 * npose].T
+        WF[:, 3] = W[:, -1]
+        assert np.abs(ft).max() > 0 and np.abs(WF - W @ F4.T).max() > 1e-9                 # the term matters on this input
+        WF[:, :3] += np.outer(WF[:, 3], F4[:3, -1])
+        assert np.abs(WF - W @ F4.T).max() < 1e-12 * np.abs(WF).max()
         S = Dp @ A + (Dp @ WF) @ O4.T + O4 @ (F4 @ A + (F4 @ WF) @ O4.T)
         ref = (Dp + O4 @ F4) @ W @ (Dp + O4 @ F4).T
         assert np.abs(S - ref).max() < 1e-10 * np.abs(ref).max()
