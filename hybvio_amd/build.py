@@ -26,13 +26,37 @@ def _stale() -> bool:
 
 
 def build_hip(force: bool = False, verbose: bool = False) -> str:
+    """One object per source (compiled in parallel, rebuilt only when the source or a header changed), then one link."""
     if not force and not _stale():
         return LIB
+    from concurrent.futures import ThreadPoolExecutor
     os.makedirs(LIBDIR, exist_ok=True)
+    objdir = os.path.join(LIBDIR, "obj")
+    os.makedirs(objdir, exist_ok=True)
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     extra = ["-DHV_EKF_PHASE_STAMPS"] if os.environ.get("HV_EKF_PHASE_STAMPS") == "1" else []
     extra += ["-D" + d for d in os.environ.get("HV_EXTRA_DEFINES", "").split() if d]        # developer experiments
-    cmd = [hipcc] + HIPCC_FLAGS + extra + ["-o", LIB] + sources()
+    flags = [f for f in HIPCC_FLAGS if f != "-shared"] + extra
+    tag = os.path.join(objdir, "flags.txt")                                                  # other flags: every object is stale
+    same_flags = os.path.exists(tag) and open(tag).read() == " ".join(flags)
+    headers = glob.glob(os.path.join(CSRC, "*.hpp")) + glob.glob(os.path.join(CSRC, "*.h")) + [os.path.join(PKG, "..", "include", "hybvio_hip.h")]
+    newest_header = max(os.path.getmtime(h) for h in headers)
+
+    def compile_one(src: str) -> str:
+        obj = os.path.join(objdir, os.path.splitext(os.path.basename(src))[0] + ".o")
+        fresh = same_flags and os.path.exists(obj) and os.path.getmtime(obj) >= max(os.path.getmtime(src), newest_header)
+        if not fresh or (force and os.environ.get("HV_BUILD_REUSE_OBJECTS") != "1"):
+            cmd = [hipcc] + flags + ["-c", "-o", obj, src]
+            if verbose:
+                print(" ".join(cmd))
+            subprocess.check_call(cmd, cwd=CSRC)
+        return obj
+
+    with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1)) as pool:
+        objs = list(pool.map(compile_one, sources()))
+    with open(tag, "w") as f:
+        f.write(" ".join(flags))
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd, cwd=CSRC)

@@ -14,7 +14,7 @@ namespace {
 struct KnobEntry { const char *name; int Knobs::*field; };
 const KnobEntry KNOB_TABLE[] = {
     {"pyr_tail", &Knobs::pyr_tail}, {"pyr_l0_tiled", &Knobs::pyr_l0_tiled}, {"gftt_tiled", &Knobs::gftt_tiled},
-    {"klt_tile", &Knobs::klt_tile}, {"vu_threads", &Knobs::vu_threads}, {"ekf_spec_split", &Knobs::ekf_spec_split},
+    {"klt_tile", &Knobs::klt_tile}, {"ekf_defer_jacobian", &Knobs::ekf_defer_jacobian}, {"vu_threads", &Knobs::vu_threads}, {"ekf_spec_split", &Knobs::ekf_spec_split},
     {"ekf_no_speculation", &Knobs::ekf_no_speculation}, {"ekf_stream_gate", &Knobs::ekf_stream_gate},
     {"ekf_gate_kmode", &Knobs::ekf_gate_kmode}, {"ingest_gather", &Knobs::ingest_gather},
     {"ekf_fused_gate", &Knobs::ekf_fused_gate}, {"ekf_spec_mode", &Knobs::ekf_spec_mode},

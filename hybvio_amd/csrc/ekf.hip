@@ -430,6 +430,10 @@ struct UpdateArgs {
     // and sel_io [batch] carries the chosen track of a long record (-1: none) from the half-1 launch to the half-2 launch, which
     // must not scan again: the first launch may have moved the cursor or turned the record's gate status into CHI2
     int half_auto; int *sel_io;
+    // half_auto: the epochs of the frame's records, [n_tracks][batch] (VuPrepareArgs::epoch). A long record whose block 1 was applied and
+    // whose block 2 then meets a non-positive pivot leaves (m, P) changed without a counted success: the filter's pending records are
+    // marked "never prepared" (-1) so that the next pass prepares them against the state as it is now (r04 advisor)
+    int *epoch;
     int batch;
     const int *rec_count, *rec_list;  // compaction list (VuPrepareArgs): workgroup i updates filter rec_list[i], i < *rec_count; the others exit
 };
@@ -920,6 +924,8 @@ __device__ __forceinline__ void ekf_update_body(const UpdateArgs &a, const int b
             *s_stop = (a.mode == 0) || broken || ((a.mode == 2 || (two_r && pass == 0)) && outlier);
             if (broken && a.gate_rw) a.gate_rw[e] = 3 /*CHI2*/;
             if (AUTO && broken && a.spec == 2 && half != 1) a.cursor[b] = sel + 1;     // (whole short record or block 2: not applied, the track is final)
+            if (AUTO && broken && a.spec == 2 && half == 2 && a.epoch)                 // block 1 of this record HAS been applied
+                for (int jj = sel + 1; jj < a.n_tracks; ++jj) a.epoch[jj * (int)gridDim.x + b] = -1;
             if (a.spec == 3 && pass == 0) {
                 const int j = blockIdx.y;
                 spec_publish(a, e, outlier ? 1 : 2);
@@ -1736,7 +1742,7 @@ struct Ekf {
 // compact-H description handed to ekf_launch_update (null acol: dense H of l columns); half / nr_full / dm: block update of a long
 // track (UpdateArgs::half)
 struct CompactH { const int *acol = nullptr; int na_max = 0, ncam = 1; int half = 0, nr_full = 0; double *dm = nullptr; const int *rec_count = nullptr, *rec_list = nullptr; int *gate_rw = nullptr;
-                  int half_auto = 0; int *sel_io = nullptr; };
+                  int half_auto = 0; int *sel_io = nullptr; int *epoch = nullptr; };
 
 // an update launch prepared but not issued (ekf_launch_update's `defer`): two of them can share one grid (ekf_launch_update_dual)
 struct UpdateLaunch { UpdateArgs a; size_t base_bytes = 0; int kmode = -1, ti = 0, lbk = 0; };
@@ -1777,7 +1783,7 @@ static int ekf_launch_update(Ekf *e, int nr, int l, const double *H_dev, const d
         if (a.half == 1) { a.dm_out = compact->dm; a.gate_rw = compact->gate_rw; }
         if (a.half == 2) a.dm_in = compact->dm;
         a.rec_count = compact->rec_count; a.rec_list = compact->rec_list;
-        a.half_auto = compact->half_auto; a.sel_io = compact->sel_io;
+        a.half_auto = compact->half_auto; a.sel_io = compact->sel_io; a.epoch = compact->epoch;
         if (a.half_auto && (spec != 2 || !a.half || !a.sel_io || !a.dm_out == !a.dm_in)) return HV_ERR_INVALID;
     }
     size_t tall = (((size_t)a.Rs * nr + 1) & ~(size_t)1) * sizeof(double);
@@ -2148,6 +2154,7 @@ static int vu_fill_args(Ekf *e, const hv_vu_params *p, int np, const int *idx, c
     a.conv_threshold = p->triangulationConvergenceThreshold; a.conv_r = p->triangulationConvergenceR;
     a.rcond_threshold = p->triangulationRcondThreshold; a.min_dist = p->triangulationMinDist; a.max_dist = p->triangulationMaxDist;
     a.gn_iters = (int)p->triangulationGaussNewtonIterations; a.est_shift = p->estimateImuCameraTimeShift ? 1 : 0;
+    a.defer_h = e->c->knob.ekf_defer_jacobian != 0;
     a.linear = p->useLinearTriangulation ? 1 : 0;
     // adaptive outlier thresholds (ABI 3): the RMSE test applies everywhere the fused gate runs; the per-filter growth only inside a
     // frame loop (visual_frame_dev_impl hands the multiplier array over through Ekf::gate_scale_on)
@@ -2516,11 +2523,14 @@ static int visual_track_dev_impl(hv_ekf *h, const hv_vu_params *p, int np, const
 
 
 // work buffers of the speculative frame loops and the batch loop: one record per (track, filter) -- compact or dense Jacobian, residual,
-// point, flags, column list, rows -- plus the per-filter cursors; grown (never shrunk below a later request) on first use of a shape
+// point, flags, column list, rows -- plus the per-filter cursors; grown on first use of a shape and never shrunk in either dimension
+// (r04 advisor: reallocating to exactly (rec, rows) let alternating shapes -- a short and a long frame, the speculative and the batch
+// loop -- free and allocate on every call, which a stream capture cannot hold)
 static int ensure_spec_buffers(Ekf *e, size_t rec, int rows)
 {
     Ctx *c = e->c;
     if (e->sp_records >= rec && e->sp_rows >= rows) return HV_OK;
+    rec = std::max(rec, e->sp_records); rows = std::max(rows, e->sp_rows);
     const size_t B = (size_t)e->batch;
     HV_HIP(c, hipStreamSynchronize(c->stream));
     void *old[] = {e->spH, e->spv, e->sppf, e->spactive, e->spcursor, e->spepoch, e->spcursor2, e->sppub, e->spacol, e->sprows};
@@ -2598,14 +2608,15 @@ static int visual_frame_dev_impl(hv_ekf *h, const hv_vu_params *p, int n_tracks,
         a.fused = 3; a.Hc = e->spH; a.acol = e->spacol; a.na_max = 7 * np + 1; a.P = e->P;
         a.rd_gate = r_gate * r_gate * ns; a.noise_scale = ns; a.chi2 = chi2_dev;
         hv::CompactH h1{e->spacol, a.na_max, ncam, 1, rows, e->side_dm, nullptr, nullptr, gate_status_dev}, h2{e->spacol, a.na_max, ncam, 2, rows, e->side_dm};
-        h1.half_auto = h2.half_auto = 1; h1.sel_io = h2.sel_io = e->spcursor2;
+        h1.half_auto = h2.half_auto = 1; h1.sel_io = h2.sel_io = e->spcursor2; h2.epoch = e->spepoch;
         const int n_pass = (max_successful < n_tracks ? max_successful : n_tracks) + 1;
         for (int pass = 0; pass < n_pass; ++pass) {
             rc = hv::launch_vu_prepare(c, a);
             if (rc != HV_OK) return rc;
             for (const hv::CompactH *hh : {&h1, &h2}) {
-                // (48 rows per launch: a whole short record, or the longer block of an 84-row one)
-                rc = hv::ekf_launch_update(e, 48, e->n, e->spH, e->spv, nullptr, r_update * r_update * ns, 1, 0, hh == &h1 ? -1 : 1, nullptr,
+                // (rows per launch: a whole short record of up to 48 rows, or the longer block -- 2 ceil(rows / 4) rows, the first camera's --
+                //  of a long one; 48 for everything visit_shape admits today, rows <= 96)
+                rc = hv::ekf_launch_update(e, std::max(48, 2 * ((rows + 3) / 4)), e->n, e->spH, e->spv, nullptr, r_update * r_update * ns, 1, 0, hh == &h1 ? -1 : 1, nullptr,
                                            nullptr, e->spactive, nullptr, success_counter_dev, 0.0, nullptr, 2, n_tracks, e->spcursor, max_successful,
                                            gate_status_dev, nullptr, nullptr, 0, nr_rec, hh, rows);
                 if (rc != HV_OK) return rc;

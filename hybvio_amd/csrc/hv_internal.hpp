@@ -71,6 +71,7 @@ struct Knobs {
     int ekf_long_first = 1;       // HV_EKF_LONG_FIRST: sorted ragged visits enqueue the long class's prepare + gate launch in front of (1) / behind (0) the short class's fused launch
     int ekf_dual_update = 1;      // HV_EKF_DUAL_UPDATE: 1 = ragged visits issue the short class's update and the long class's first block update as one grid (ekf_update_dual_kernel); 0 = one after the other
     int ekf_visit_order = 1;      // HV_EKF_VISIT_ORDER: 1 = ragged frame loops over more filters than the GPU has CUs hand the fused kernel its records longest track first (one sort launch per frame; the presorted long-class lists also enable ekf_side_stream 2 .. 4); 2 = at every batch size (tests); 0 = in filter order
+    int ekf_defer_jacobian = 1;   // HV_EKF_DEFER_JACOBIAN: 1 (r05) = the long class's one-launch build (vu_gate_long_kernel) forms and stores the compact Jacobian Hc = Dp + O4 F4 BEHIND its gate, for inliers only (the update is its only reader); 0 = for every prepared track, in front of the gate (r04)
     int rot_ransac_threads = 0;   // HV_ROT_RANSAC_THREADS: 0 auto (1024 threads up to 64 sets), 256 / 1024 force
 };
 int knob_set(Knobs &k, const char *name, int value);   // HV_ERR_INVALID for an unknown name
@@ -147,6 +148,7 @@ struct VuPrepareArgs {
     double imu_to_cam[2][12];          // per camera the top 3 x 4 of imuToCamera, row-major
     double conv_threshold, conv_r, rcond_threshold, min_dist, max_dist;
     int gn_iters, est_shift;
+    int defer_h;                  // Knobs::ekf_defer_jacobian (STRUCT builds only)
     int linear;                        // useLinearTriangulation: the closed-form branch instead of two-camera + Gauss-Newton
     // ragged batches: per-record pose counts (np above is then the record stride = the longest track; < 2: no track for this
     // record) and, as an output for the gate / update launch, the per-record row counts 2 * cameras * poses (0: none)

@@ -49,7 +49,7 @@ constexpr int GRAY_SHIFT = 7;          // gray samples are pre-scaled by 128 (<=
 // dot2 chain starts from 0. Gradients are stored as 4*d + 2 for the same reason (pyramid.hip).
 constexpr uint32_t ROUND_PAIR = 0x00020002u;
 constexpr int W_BITS = 14;
-constexpr int KLT_TILE_DEFAULT = 5;   // 40 x 36 tile at 5 waves per SIMD (96 VGPRs, 7 dwords of loop-invariant lane constants in scratch, reloaded once per level): -4 % against the 4-wave build of the same tile (bench r02, C2 and C3 legs)
+// default build (Knobs::klt_tile = 5): 40 x 36 tile at 5 waves per SIMD (96 VGPRs, 7 dwords of loop-invariant lane constants in scratch, reloaded once per level): -4 % against the 4-wave build of the same tile (bench r02, C2 and C3 legs)
 
 struct KltArgs {
     PyrLayout L;
@@ -85,7 +85,6 @@ __device__ __forceinline__ int dot2(uint32_t a, uint32_t b, int c)
 {
     return __builtin_amdgcn_sdot2(__builtin_bit_cast(short2v, a), __builtin_bit_cast(short2v, b), c, true);
 }
-__device__ __forceinline__ uint32_t pack16(int lo, int hi) { return ((uint32_t)hi << 16) | ((uint32_t)lo & 0xFFFFu); }
 __device__ __forceinline__ uint32_t lo16_pair(uint32_t a, uint32_t b) { return __builtin_amdgcn_perm(b, a, 0x05040100u); }
 __device__ __forceinline__ uint32_t hi16_pair(uint32_t a, uint32_t b) { return __builtin_amdgcn_perm(b, a, 0x07060302u); }
 __device__ __forceinline__ uint32_t pk_sub16(uint32_t a, uint32_t b)
@@ -616,14 +615,17 @@ __global__ __launch_bounds__(64, WPS) void klt_kernel(KltArgs a)
                 if (level == 0) st = 0;
                 break;
             }
-            ensure_tile(inx, iny);
+            int sb1 = 0, sb2 = 0;
             uint32_t wA, wB;
+            // (r05, measured and dropped: requesting the 17 tile dwords of a lane's rows together in front of the arithmetic and keeping them
+            //  while the integer window origin stays -- 128 VGPRs, 4 waves per SIMD -- ran 1.351 ms per launch against 1.324 for this loop at 4
+            //  waves and 1.256 at 5: the loop is not waiting for LDS, profiles/r05/klt_rows_in_registers_ab.txt)
+            ensure_tile(inx, iny);
             bilinear_weights(cxn - (float)inx, cyn - (float)iny, wA, wB);
 
             // (rows < 64: the 24-bit multiply is full rate, the v_mul_lo_u32 hipcc picks for a 32-bit product a quarter)
             const uint32_t *jrow = jt + __umul24((unsigned)(iny - toy + half * HALF_ROWS), (unsigned)TSX) + (unsigned)(inx - tox + cx);
             uint32_t jp = jrow[0];
-            int sb1 = 0, sb2 = 0;
 #pragma unroll
             for (int m = 0; m < HALF_ROWS / 2; ++m) {
                 const uint32_t r1 = jrow[(2 * m + 1) * TSX], r2 = jrow[(2 * m + 2) * TSX];
@@ -741,14 +743,14 @@ int launch_klt(Ctx *c, int n_pairs, const int *prev_slots_dev, const int *next_s
     a.eig_bound = a.min_eig * (float)(2 * WIN * WIN);
     a.eig_margin = 1e-5f * a.eig_bound;
     ScopedKernelTime tm(c, HV_K_KLT);
-    // knob klt_tile (HV_KLT_TILE at hv_create; experiments only): tile columns x rows / slack on the low side: 0 = 44 x 40 / 6, 4 (8 staging
-    // passes of 5 rows), 1 = 40 x 36 / 2, 1 (6 passes of 6 rows), 2 = 40 x 42 / 2, 4 (7 passes), 5 = shape 1 compiled for 5 waves per SIMD (96 VGPRs; its 7.6 KB of LDS allow 20 waves per CU)
-    const int tile_variant = c->knob.klt_tile == 7 ? 1 : 5;
+    // knob klt_tile (HV_KLT_TILE at hv_create; experiments only): 1 = the 40 x 36 tile (slack 2, 1 on the low side; 6 staging passes of 6 rows) compiled
+    // for 4 waves per SIMD, 5 (default, and every other value) = the same for 5 waves per SIMD (96 VGPRs; its 7.6 KB of LDS allow 20 waves per CU).
+    // r01 .. r03's other tile shapes (44 x 40, 40 x 42) measured slower and are gone
+    const int tile_variant = c->knob.klt_tile;
     if (pts_in_pair_dev)        hipLaunchKernelGGL((klt_kernel<40, 36, 2, 1, 5, true>), dim3((unsigned)n_points), dim3(64), 0, c->stream, a);
     else if (tile_variant == 1) hipLaunchKernelGGL((klt_kernel<40, 36, 2, 1, 4>), dim3((unsigned)n_points), dim3(64), 0, c->stream, a);
-    else if (tile_variant == 2) hipLaunchKernelGGL((klt_kernel<40, 42, 2, 4, 4>), dim3((unsigned)n_points), dim3(64), 0, c->stream, a);
     else if (tile_variant == 5) hipLaunchKernelGGL((klt_kernel<40, 36, 2, 1, 5>), dim3((unsigned)n_points), dim3(64), 0, c->stream, a);
-    else                        hipLaunchKernelGGL((klt_kernel<44, 40, 6, 4, 4>), dim3((unsigned)n_points), dim3(64), 0, c->stream, a);
+    else                        hipLaunchKernelGGL((klt_kernel<40, 36, 2, 1, 5>), dim3((unsigned)n_points), dim3(64), 0, c->stream, a);
     HV_HIP(c, hipGetLastError());
     return HV_OK;
 }

@@ -896,7 +896,9 @@ __device__ __forceinline__ void vu_prepare_body(const VuPrepareArgs &a, const in
         if (tid < nt && a.y) { yv[0] = a.y[rec * rows_max + 2 * tid]; yv[1] = a.y[rec * rows_max + 2 * tid + 1]; }
         // work item = (compact column u, observation i), i fastest: the two rows of an observation are one 16-byte store. STAGED: u < na4,
         // i < nrp / 2 -- every element of the staged Hs is written exactly once, zero padding in rows >= 2 nt and columns >= na included
-        const int wi = STAGED ? nrp >> 1 : nt, n_items = (STAGED ? na4 : na) * wi;
+        // (STRUCT: the compact Jacobian is only needed by the update of an INLIER -- a quarter of the gates at the reference's inlier rate --
+        //  and the factors it is made of survive the gate in LDS: it is built behind the gate, for inliers only; 24 k of a 21-pose gate's 176 k cycles)
+        const int wi = STAGED ? nrp >> 1 : nt, n_items = (STRUCT && a.defer_h) ? 0 : (STAGED ? na4 : na) * wi;
         const unsigned inv_wi = (unsigned)((0x100000000ull + (unsigned)wi - 1) / (unsigned)wi);   // w / wi = umulhi(w, ceil(2^32 / wi))
         for (int w = tid; w < n_items; w += VT) {
             const int u = (int)__umulhi((unsigned)w, inv_wi), i = w - u * wi;
@@ -976,6 +978,21 @@ __device__ __forceinline__ void vu_prepare_body(const VuPrepareArgs &a, const in
             structured_S<VT, (VT > VT_THROUGHPUT)>(Pb, N, s_acol, na, n, ncam, rows, f_O4, f_DV, f_F4, f4s, f_WF, f_WFp, f_FA, f_DWF, f_FWF, f_G, g_cap, T, Rs, g_vu_stamp + 1);
             VU_STAMP(33);
             chi = gate_factor_chi2<VT>(T, Rs, rows, rd_eff, a.noise_scale, f_G, g_vu_stamp + 33);
+            // every thread holds the same chi2: the inlier's compact Jacobian Hc = Dp + O4 F4, from the factor copies (intact: the gate's
+            // scratch lies behind them)
+            if (a.defer_h && chi < 1e300 && !((rows < HV_CHI2INV95_N) && chi > d_chi2inv95[rows])) {
+                const unsigned inv_nt = (unsigned)((0x100000000ull + (unsigned)nt - 1) / (unsigned)nt);
+                for (int w = tid; w < na * nt; w += VT) {
+                    const int u = (int)__umulhi((unsigned)w, inv_nt), i = w - u * nt;
+                    const int k = u / 7, comp = u - 7 * k;
+                    const bool own = u < 7 * n && k == (i >= n ? i - n : i);
+                    const double *o4 = f_O4 + 8 * i, *dv = f_DV + 14 * i;
+                    double h0 = o4[0] * f_F4[u] + o4[1] * f_F4[f4s + u] + o4[2] * f_F4[2 * f4s + u] + o4[3] * f_F4[3 * f4s + u];
+                    double h1 = o4[4] * f_F4[u] + o4[5] * f_F4[f4s + u] + o4[6] * f_F4[2 * f4s + u] + o4[7] * f_F4[3 * f4s + u];
+                    if (own) { h0 += dv[comp]; h1 += dv[7 + comp]; }
+                    *reinterpret_cast<double2 *>(Hc + (size_t)u * rows + 2 * i) = double2{h0, h1};
+                }
+            }
         } else {
             if (ti == 1)      chi = sparse_gate<1, VT, false>(Pb, N, s_acol, na, Hs, T, Rs, rows, rd_eff, a.noise_scale, Hs, g_vu_stamp + 33);
             else if (ti == 2) chi = sparse_gate<2, VT, false>(Pb, N, s_acol, na, Hs, T, Rs, rows, rd_eff, a.noise_scale, Hs, g_vu_stamp + 33);

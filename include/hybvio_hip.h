@@ -303,10 +303,15 @@ int hv_ekf_visual_track_hybrid_dev(hv_ekf *ekf, const hv_vu_params *p, int n_pos
  * trackOutlierThresholdGrowthFactor != 1, trackRmseThreshold >= 0; gate status 2 = RMSE) are kept per filter on the device; with a
  * growth factor != 1 the loop always runs sequentially (a rejection changes the threshold of the NEXT track).
  * max_successful <= 0 means "no limit" (the reference's maxSuccessfulVisualUpdates <= 0, backend.cpp:1233).
- * With few sequences (batch * n_tracks <= 256; since r04 for tracks of up to 84 rows, i.e. 21 stereo poses) the loop runs speculatively: each pass prepares and gates every
- * pending track of a filter in parallel against the current (m, P), applies the first inlier in visit order and re-examines only
- * the tracks behind it -- at most min(max_successful, n_tracks) + 1 passes, the same statuses and the same filter as the sequential
- * loop. chi2_dev / pf_dev entries of tracks the loop never visits (status HV_TRI_NOT_VISITED) are 0.
+ * With few sequences the loop runs speculatively: each pass prepares and gates every pending track of a filter in parallel against the
+ * current (m, P), applies the first inlier in visit order and re-examines only the tracks behind it -- at most min(max_successful,
+ * n_tracks) + 1 passes, the same statuses and the same filter as the sequential loop. Which frames take that form:
+ *   - longest track <= 48 rows (12 stereo poses): batch * n_tracks <= 256, n_tracks >= 2, trackOutlierThresholdGrowthFactor == 1;
+ *   - longest track 49 .. 84 rows (21 stereo poses, the reference's default stereo configuration; r04): batch * n_tracks <= the device's
+ *     CU count (256 on MI355X), the same conditions, and the library's default kernel selection (knobs ekf_long_fused != 0,
+ *     ekf_spec_split == 0, ekf_spec_mode != 3, ekf_no_speculation == 0);
+ *   - every other frame (more filters, adaptive thresholds) runs the sequential visit loop, with the same results.
+ * chi2_dev / pf_dev entries of tracks the loop never visits (status HV_TRI_NOT_VISITED) are 0.
  * hv_vu_params: always start from hv_vu_default_params() -- fields added in later ABI versions then hold their defaults. */
 int hv_ekf_visual_frame_dev(hv_ekf *ekf, const hv_vu_params *p, int n_tracks, int n_poses, const int *pose_index_dev,
                             const double *features_dev, const double *velocities_dev, const double *y_dev, double r_gate,

@@ -30,6 +30,10 @@ constexpr int REPS = 256, UNR = 32;            // 8192 instructions per wave and
     asm volatile(R4(OP " %0, %8, %9, %0" SFX "\n" OP " %1, %8, %9, %1" SFX "\n" OP " %2, %8, %9, %2" SFX "\n" OP " %3, %8, %9, %3" SFX "\n" \
                     OP " %4, %8, %9, %4" SFX "\n" OP " %5, %8, %9, %5" SFX "\n" OP " %6, %8, %9, %6" SFX "\n" OP " %7, %8, %9, %7" SFX "\n") \
                  : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3), "+v"(v4), "+v"(v5), "+v"(v6), "+v"(v7) : "v"(a), "v"(b))
+#define IND8_1(OP, SFX) \
+    asm volatile(R4(OP " %0, %8" SFX "\n" OP " %1, %8" SFX "\n" OP " %2, %8" SFX "\n" OP " %3, %8" SFX "\n" \
+                    OP " %4, %8" SFX "\n" OP " %5, %8" SFX "\n" OP " %6, %8" SFX "\n" OP " %7, %8" SFX "\n") \
+                 : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3), "+v"(v4), "+v"(v5), "+v"(v6), "+v"(v7) : "v"(a), "v"(b))
 #define DEP32(OP, SFX) asm volatile(R32(OP " %0, %0, %1" SFX "\n") : "+v"(v0) : "v"(a))
 #define DEP32_3(OP, SFX) asm volatile(R32(OP " %0, %1, %2, %0" SFX "\n") : "+v"(v0) : "v"(a), "v"(b))
 
@@ -69,6 +73,40 @@ KERNEL_HEAD(k_mullo_ind)  IND8("v_mul_lo_u32", "");                    KERNEL_TA
 KERNEL_HEAD(k_mul24_ind)  IND8("v_mul_u32_u24", "");                   KERNEL_TAIL
 KERNEL_HEAD(k_dpp_ind)    IND8("v_add_u32_dpp", " quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf"); KERNEL_TAIL
 KERNEL_HEAD(k_dpp_dep)    DEP32("v_add_u32_dpp", " quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf"); KERNEL_TAIL
+KERNEL_HEAD(k_and_ind)    IND8("v_and_b32", "");                       KERNEL_TAIL
+KERNEL_HEAD(k_or_ind)     IND8("v_or_b32", "");                        KERNEL_TAIL
+KERNEL_HEAD(k_lshl_ind)   IND8("v_lshlrev_b32", "");                   KERNEL_TAIL
+KERNEL_HEAD(k_sub_ind)    IND8("v_sub_u32", "");                       KERNEL_TAIL
+KERNEL_HEAD(k_max_ind)    IND8("v_max_i32", "");                       KERNEL_TAIL
+KERNEL_HEAD(k_mov_ind)    IND8_1("v_mov_b32", "");                     KERNEL_TAIL
+KERNEL_HEAD(k_mulf_ind)   IND8("v_mul_f32", "");                       KERNEL_TAIL
+KERNEL_HEAD(k_addf_ind)   IND8("v_add_f32", "");                       KERNEL_TAIL
+KERNEL_HEAD(k_cvt_ind)    IND8_1("v_cvt_f32_i32", "");                 KERNEL_TAIL
+KERNEL_HEAD(k_mad24_ind)  IND8_3("v_mad_u32_u24", "");                 KERNEL_TAIL
+KERNEL_HEAD(k_bfe_ind)    IND8_3("v_bfe_u32", "");                     KERNEL_TAIL
+KERNEL_HEAD(k_align_ind)  IND8_3("v_alignbit_b32", "");                KERNEL_TAIL
+KERNEL_HEAD(k_add3_ind)   IND8_3("v_add3_u32", "");                    KERNEL_TAIL
+KERNEL_HEAD(k_lshladd_ind) IND8_3("v_lshl_add_u32", "");               KERNEL_TAIL
+KERNEL_HEAD(k_or3_ind)    IND8_3("v_or3_b32", "");                     KERNEL_TAIL
+KERNEL_HEAD(k_pkadd_ind)  IND8("v_pk_add_u16", "");                    KERNEL_TAIL
+KERNEL_HEAD(k_pkmad_ind)  IND8_3("v_pk_mad_u16", "");                  KERNEL_TAIL
+KERNEL_HEAD(k_cnd64_ind)  IND8("v_cndmask_b32_e64", ", s[4:5]");       KERNEL_TAIL
+KERNEL_HEAD(k_movdpp_ind) IND8_1("v_mov_b32_dpp", " quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf"); KERNEL_TAIL
+KERNEL_HEAD(k_sdwa_ind)   IND8("v_add_u32_sdwa", " dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD"); KERNEL_TAIL
+KERNEL_HEAD(k_dot4_ind)   IND8_3("v_dot4_i32_i8", "");                 KERNEL_TAIL
+KERNEL_HEAD(k_dot2c_ind)  IND8("v_dot2c_i32_i16", "");                 KERNEL_TAIL
+KERNEL_HEAD(k_sad_ind)    IND8_3("v_sad_u16", "");                     KERNEL_TAIL
+// 4 VALU + 4 SALU per 8: does scalar work ride along for free? (s_mul_i32: an SALU instruction that leaves SCC alone -- the loop's
+// compare sits in front of the asm block, its branch behind)
+KERNEL_HEAD(k_valu_salu)  { asm volatile(R8("v_add_u32 %0, %8, %9\n s_mul_i32 s6, s6, s7\n v_add_u32 %1, %8, %9\n s_mul_i32 s7, s7, s6\n"
+                                            "v_add_u32 %2, %8, %9\n s_mul_i32 s6, s6, s7\n v_add_u32 %3, %8, %9\n s_mul_i32 s7, s7, s6\n")
+                                         : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3), "+v"(v4), "+v"(v5), "+v"(v6), "+v"(v7) : "v"(a), "v"(b) : "s6", "s7"); } KERNEL_TAIL
+KERNEL_HEAD(k_dot2_salu)  { asm volatile(R8("v_dot2_i32_i16 %0, %8, %9, %0 clamp\n s_mul_i32 s6, s6, s7\n v_dot2_i32_i16 %1, %8, %9, %1 clamp\n s_mul_i32 s7, s7, s6\n"
+                                            "v_dot2_i32_i16 %2, %8, %9, %2 clamp\n s_mul_i32 s6, s6, s7\n v_dot2_i32_i16 %3, %8, %9, %3 clamp\n s_mul_i32 s7, s7, s6\n")
+                                         : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3), "+v"(v4), "+v"(v5), "+v"(v6), "+v"(v7) : "v"(a), "v"(b) : "s6", "s7"); } KERNEL_TAIL
+// alternating 2-cycle and 4-cycle class instructions
+KERNEL_HEAD(k_add_dot2)   { asm volatile(R8("v_dot2_i32_i16 %0, %8, %9, %0 clamp\n v_add_u32 %4, %8, %9\n v_dot2_i32_i16 %1, %8, %9, %1 clamp\n v_add_u32 %5, %8, %9\n")
+                                         : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3), "+v"(v4), "+v"(v5), "+v"(v6), "+v"(v7) : "v"(a), "v"(b)); } KERNEL_TAIL
 // ds_read_b32 (independent destinations, waits once per 32)
 KERNEL_HEAD(k_dsread_ind) { asm volatile(R4("ds_read_b32 %0, %8\n ds_read_b32 %1, %8 offset:256\n ds_read_b32 %2, %8 offset:512\n ds_read_b32 %3, %8 offset:768\n"
                                             "ds_read_b32 %4, %8 offset:1024\n ds_read_b32 %5, %8 offset:1280\n ds_read_b32 %6, %8 offset:1536\n ds_read_b32 %7, %8 offset:1792\n")
@@ -113,6 +151,15 @@ int main()
         {"v_pk_mul_lo_u16 ind", k_pkmul_ind, 32}, {"v_lshl_or_b32 ind", k_lshlor_ind, 32},
         {"v_cndmask_b32 ind", k_cnd_ind, 32}, {"v_mul_lo_u32 ind", k_mullo_ind, 32}, {"v_mul_u32_u24 ind", k_mul24_ind, 32},
         {"v_add_u32_dpp ind", k_dpp_ind, 32}, {"v_add_u32_dpp dep", k_dpp_dep, 32},
+        {"v_and_b32 ind", k_and_ind, 32}, {"v_or_b32 ind", k_or_ind, 32}, {"v_lshlrev_b32 ind", k_lshl_ind, 32}, {"v_sub_u32 ind", k_sub_ind, 32},
+        {"v_max_i32 ind", k_max_ind, 32}, {"v_mov_b32 ind", k_mov_ind, 32}, {"v_mul_f32 ind", k_mulf_ind, 32}, {"v_add_f32 ind", k_addf_ind, 32},
+        {"v_cvt_f32_i32 ind", k_cvt_ind, 32}, {"v_mad_u32_u24 ind", k_mad24_ind, 32}, {"v_bfe_u32 ind", k_bfe_ind, 32},
+        {"v_alignbit_b32 ind", k_align_ind, 32}, {"v_add3_u32 ind", k_add3_ind, 32}, {"v_lshl_add_u32 ind", k_lshladd_ind, 32},
+        {"v_or3_b32 ind", k_or3_ind, 32}, {"v_pk_add_u16 ind", k_pkadd_ind, 32}, {"v_pk_mad_u16 ind", k_pkmad_ind, 32},
+        {"v_cndmask_b32_e64 (sgpr pair) ind", k_cnd64_ind, 32}, {"v_mov_b32_dpp ind", k_movdpp_ind, 32}, {"v_add_u32_sdwa ind", k_sdwa_ind, 32},
+        {"v_dot4_i32_i8 ind", k_dot4_ind, 32}, {"v_dot2c_i32_i16 (VOP2) ind", k_dot2c_ind, 32}, {"v_sad_u16 ind", k_sad_ind, 32},
+        {"v_add_u32 + s_mul_i32 alternating (per VALU)", k_valu_salu, 32}, {"v_dot2 + s_mul_i32 alternating (per VALU)", k_dot2_salu, 32},
+        {"v_dot2 + v_add_u32 alternating (per VALU)", k_add_dot2, 32},
         {"ds_read_b32 ind (per LDS read)", k_dsread_ind, 32},
         {"klt row-pair mix (8 VALU + 2 ds_read, wait per pair)", k_klt_mix, 36},
         {"klt row-pair mix, LDS reads one pair ahead", k_klt_mix_pipe, 44},
@@ -122,7 +169,7 @@ int main()
     for (int w : wps_list) printf(" %7d", w);
     printf("   (shader cycles per wave-instruction per SIMD; chip-wide G wave-inst/s at 8 waves)\n");
     for (const Case &c : cases) {
-        printf("%-58s", c.name);
+        printf("%-58s", c.name); fflush(stdout);
         double last_rate = 0, mhz = 0;
         for (int wps : wps_list) {
             const int blocks = cus * 4 * wps;
