@@ -25,20 +25,23 @@ def _stale() -> bool:
     return any(os.path.getmtime(d) > os.path.getmtime(LIB) for d in deps)
 
 
-def build_hip(force: bool = False, verbose: bool = False) -> str:
-    """One object per source (compiled in parallel, rebuilt only when the source or a header changed), then one link."""
-    if not force and not _stale():
+def build_hip(force: bool = False, verbose: bool = False, lib: str | None = None) -> str:
+    """One object per source (compiled in parallel, rebuilt only when the source or a header changed), then one link.
+    lib: a second build beside the default one (A/B runs through HV_LIB_OVERRIDE): its objects live in their own directory."""
+    lib = lib or LIB
+    if not force and lib == LIB and not _stale():
         return LIB
     from concurrent.futures import ThreadPoolExecutor
     os.makedirs(LIBDIR, exist_ok=True)
-    objdir = os.path.join(LIBDIR, "obj")
+    objdir = os.path.join(LIBDIR, "obj" if lib == LIB else "obj_" + os.path.splitext(os.path.basename(lib))[0])
     os.makedirs(objdir, exist_ok=True)
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     extra = ["-DHV_EKF_PHASE_STAMPS"] if os.environ.get("HV_EKF_PHASE_STAMPS") == "1" else []
     extra += ["-D" + d for d in os.environ.get("HV_EXTRA_DEFINES", "").split() if d]        # developer experiments
     flags = [f for f in HIPCC_FLAGS if f != "-shared"] + extra
     tag = os.path.join(objdir, "flags.txt")                                                  # other flags: every object is stale
-    same_flags = os.path.exists(tag) and open(tag).read() == " ".join(flags)
+    tag_text = " ".join(flags)
+    same_flags = os.path.exists(tag) and open(tag).read() == tag_text
     headers = glob.glob(os.path.join(CSRC, "*.hpp")) + glob.glob(os.path.join(CSRC, "*.h")) + [os.path.join(PKG, "..", "include", "hybvio_hip.h")]
     newest_header = max(os.path.getmtime(h) for h in headers)
 
@@ -55,12 +58,12 @@ def build_hip(force: bool = False, verbose: bool = False) -> str:
     with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1)) as pool:
         objs = list(pool.map(compile_one, sources()))
     with open(tag, "w") as f:
-        f.write(" ".join(flags))
-    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+        f.write(tag_text)
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + objs
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd, cwd=CSRC)
-    return LIB
+    return lib
 
 
 HOST = os.path.join(PKG, "host")

@@ -253,6 +253,9 @@ __global__ __launch_bounds__(64, WPS) void klt_kernel(KltArgs a)
             continue;
         }
 
+        // (r05, measured and dropped: touching the lines the NEXT finer level will ask for -- template rows at their exact position, the
+        //  J tile around twice this level's estimate -- with global_load_lds into a dump area while this level runs: 1.397 against
+        //  1.251 ms per launch, profiles/r05/klt_prefetch_ab.txt. The per-level round trip is not what the kernel waits for.)
         gptr_u8 Ig, Jg;
         int Igs, Jgs;
         if (level == 0) {

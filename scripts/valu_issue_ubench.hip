@@ -91,6 +91,20 @@ KERNEL_HEAD(k_or3_ind)    IND8_3("v_or3_b32", "");                     KERNEL_TA
 KERNEL_HEAD(k_pkadd_ind)  IND8("v_pk_add_u16", "");                    KERNEL_TAIL
 KERNEL_HEAD(k_pkmad_ind)  IND8_3("v_pk_mad_u16", "");                  KERNEL_TAIL
 KERNEL_HEAD(k_cnd64_ind)  IND8("v_cndmask_b32_e64", ", s[4:5]");       KERNEL_TAIL
+// the VOP2 form reads VCC implicitly: once with VCC written by a v_cmp in front of every 32, once in the VOP3 encoding naming vcc
+KERNEL_HEAD(k_cndvcc_cmp) { asm volatile("v_cmp_gt_u32 vcc, %0, %1" :: "v"(a), "v"(b) : "vcc"); IND8("v_cndmask_b32", ", vcc"); } KERNEL_TAIL
+KERNEL_HEAD(k_cnd64_vcc)  IND8("v_cndmask_b32_e64", ", vcc");          KERNEL_TAIL
+KERNEL_HEAD(k_addc32)     { asm volatile(R4("v_addc_co_u32_e32 %0, vcc, %8, %9, vcc\n v_addc_co_u32_e32 %1, vcc, %8, %9, vcc\n v_addc_co_u32_e32 %2, vcc, %8, %9, vcc\n v_addc_co_u32_e32 %3, vcc, %8, %9, vcc\n"
+                                            "v_addc_co_u32_e32 %4, vcc, %8, %9, vcc\n v_addc_co_u32_e32 %5, vcc, %8, %9, vcc\n v_addc_co_u32_e32 %6, vcc, %8, %9, vcc\n v_addc_co_u32_e32 %7, vcc, %8, %9, vcc\n")
+                                         : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3), "+v"(v4), "+v"(v5), "+v"(v6), "+v"(v7) : "v"(a), "v"(b) : "vcc"); } KERNEL_TAIL
+KERNEL_HEAD(k_addc64)     { asm volatile(R4("v_addc_co_u32_e64 %0, vcc, %8, %9, vcc\n v_addc_co_u32_e64 %1, vcc, %8, %9, vcc\n v_addc_co_u32_e64 %2, vcc, %8, %9, vcc\n v_addc_co_u32_e64 %3, vcc, %8, %9, vcc\n"
+                                            "v_addc_co_u32_e64 %4, vcc, %8, %9, vcc\n v_addc_co_u32_e64 %5, vcc, %8, %9, vcc\n v_addc_co_u32_e64 %6, vcc, %8, %9, vcc\n v_addc_co_u32_e64 %7, vcc, %8, %9, vcc\n")
+                                         : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3), "+v"(v4), "+v"(v5), "+v"(v6), "+v"(v7) : "v"(a), "v"(b) : "vcc"); } KERNEL_TAIL
+KERNEL_HEAD(k_addco32)    { asm volatile(R4("v_add_co_u32_e32 %0, vcc, %8, %9\n v_add_co_u32_e32 %1, vcc, %8, %9\n v_add_co_u32_e32 %2, vcc, %8, %9\n v_add_co_u32_e32 %3, vcc, %8, %9\n"
+                                            "v_add_co_u32_e32 %4, vcc, %8, %9\n v_add_co_u32_e32 %5, vcc, %8, %9\n v_add_co_u32_e32 %6, vcc, %8, %9\n v_add_co_u32_e32 %7, vcc, %8, %9\n")
+                                         : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3), "+v"(v4), "+v"(v5), "+v"(v6), "+v"(v7) : "v"(a), "v"(b) : "vcc"); } KERNEL_TAIL
+KERNEL_HEAD(k_cmp32)      { asm volatile(R32("v_cmp_gt_u32_e32 vcc, %0, %1\n") :: "v"(a), "v"(b) : "vcc"); } KERNEL_TAIL
+KERNEL_HEAD(k_cmp64)      { asm volatile(R32("v_cmp_gt_u32_e64 s[6:7], %0, %1\n") :: "v"(a), "v"(b) : "s6", "s7"); } KERNEL_TAIL
 KERNEL_HEAD(k_movdpp_ind) IND8_1("v_mov_b32_dpp", " quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf"); KERNEL_TAIL
 KERNEL_HEAD(k_sdwa_ind)   IND8("v_add_u32_sdwa", " dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD"); KERNEL_TAIL
 KERNEL_HEAD(k_dot4_ind)   IND8_3("v_dot4_i32_i8", "");                 KERNEL_TAIL
@@ -156,7 +170,10 @@ int main()
         {"v_cvt_f32_i32 ind", k_cvt_ind, 32}, {"v_mad_u32_u24 ind", k_mad24_ind, 32}, {"v_bfe_u32 ind", k_bfe_ind, 32},
         {"v_alignbit_b32 ind", k_align_ind, 32}, {"v_add3_u32 ind", k_add3_ind, 32}, {"v_lshl_add_u32 ind", k_lshladd_ind, 32},
         {"v_or3_b32 ind", k_or3_ind, 32}, {"v_pk_add_u16 ind", k_pkadd_ind, 32}, {"v_pk_mad_u16 ind", k_pkmad_ind, 32},
-        {"v_cndmask_b32_e64 (sgpr pair) ind", k_cnd64_ind, 32}, {"v_mov_b32_dpp ind", k_movdpp_ind, 32}, {"v_add_u32_sdwa ind", k_sdwa_ind, 32},
+        {"v_cndmask_b32_e64 (sgpr pair) ind", k_cnd64_ind, 32}, {"v_cndmask_b32 vcc, v_cmp in front of every 32", k_cndvcc_cmp, 33},
+        {"v_cndmask_b32_e64 naming vcc ind", k_cnd64_vcc, 32},
+        {"v_addc_co_u32_e32 (carry in and out through VCC)", k_addc32, 32}, {"v_addc_co_u32_e64 naming vcc", k_addc64, 32},
+        {"v_add_co_u32_e32 (carry out to VCC)", k_addco32, 32}, {"v_cmp_gt_u32_e32 (writes VCC)", k_cmp32, 32}, {"v_cmp_gt_u32_e64 (writes an SGPR pair)", k_cmp64, 32}, {"v_mov_b32_dpp ind", k_movdpp_ind, 32}, {"v_add_u32_sdwa ind", k_sdwa_ind, 32},
         {"v_dot4_i32_i8 ind", k_dot4_ind, 32}, {"v_dot2c_i32_i16 (VOP2) ind", k_dot2c_ind, 32}, {"v_sad_u16 ind", k_sad_ind, 32},
         {"v_add_u32 + s_mul_i32 alternating (per VALU)", k_valu_salu, 32}, {"v_dot2 + s_mul_i32 alternating (per VALU)", k_dot2_salu, 32},
         {"v_dot2 + v_add_u32 alternating (per VALU)", k_add_dot2, 32},

@@ -38,6 +38,8 @@ VARIANTS = {
     "long_two_launches_one_stream": {"ekf_long_fused": 0, "ekf_side_stream": 0, "ekf_visit_order": 2},
     "sorted_one_stream": {"ekf_side_stream": 0, "ekf_visit_order": 2},
     "fork_r03_arrangement": {"ekf_side_stream": 3, "ekf_visit_order": 2},   # long class on the second stream (r04 default: on the context stream)
+    # r05: the long build stores the compact Jacobian behind its gate, for inliers only; 0 = for every prepared track, in front of the gate (r04)
+    "jacobian_in_front_of_the_gate": {"ekf_defer_jacobian": 0},
 }
 
 
@@ -260,7 +262,8 @@ def test_parameters_reach_the_kernel(oracle):
                                            # every tile count 4 / 5 / 6-tight and the 48-row edge) + two block updates; `long_two_launches`: r03's
                                            # vu_compact_kernel + ekf_sparse_gate_big_kernel; `dense`: r02's H-from-L2 / global-workspace kernels
                                            ("default", 13), ("default", 16), ("default", 17), ("default", 20), ("default", 21), ("dense", 21), ("default", 12),
-                                           ("long_two_launches", 13), ("long_two_launches", 20), ("long_two_launches", 21)])
+                                           ("long_two_launches", 13), ("long_two_launches", 20), ("long_two_launches", 21),
+                                           ("jacobian_in_front_of_the_gate", 13), ("jacobian_in_front_of_the_gate", 21)])
 def test_visual_track_dev_prepare_gate_update_equals_the_reference_sequence(oracle, variant, npose):
     """hv_ekf_visual_track_dev = backend.cpp:1063-1185 for one track per filter: prepare from the device mean, gate with
     trackChiTestOutlierR, update with visualR only where triangulation, prepare and gate pass. Filters that fail stay
