@@ -131,6 +131,12 @@ PROTOTYPES = {
     "hv_ekf_visual_frame_batch_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int] + [C.c_void_p] * 5 + [C.c_double, C.c_double] + [C.c_void_p] * 5 + [C.c_int, C.c_int]),
     "hv_ekf_augment_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "hv_ekf_symmetrize_augment_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    # ABI 4: host-pointer forms of the r04 frame entries + map points on the resident state
+    "hv_ekf_symmetrize_augment": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "hv_ekf_visual_frame_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int] + [C.c_void_p] * 5 + [C.c_double, C.c_double] + [C.c_void_p] * 5 + [C.c_int, C.c_int]),
+    "hv_ekf_visual_track_hybrid": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int] + [C.c_void_p] * 6 + [C.c_double, C.c_double] + [C.c_void_p] * 4),
+    "hv_ekf_insert_map_point": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    "hv_ekf_get_map_point": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "hv_ekf_visual_dev": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_double, C.c_int,
                                     C.c_void_p, C.c_void_p]),
     "hv_ekf_augment": (C.c_int, [C.c_void_p, i32p, u8p]),

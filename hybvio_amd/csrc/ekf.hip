@@ -2840,10 +2840,12 @@ int hv_ekf_visual_track(hv_ekf *h, const hv_vu_params *p, int np, const int *idx
     return HV_OK;
 }
 
+// batch_rows: 0 = the sequential visit loop (visual_frame_dev_impl); != 0 = the batchVisualUpdate loop with this max_update_rows (< 0: the
+// library's default, stateDim)
 static int visual_frame_host_impl(hv_ekf *h, const hv_vu_params *p, int n_tracks, int np, const int *n_poses, const int *idx,
                                   const double *feat, const double *vel,
                         const double *y, double r_gate, double r_update, int *status, int *gate_status, double *chi2, double *pf,
-                        int *success_count, int max_successful)
+                        int *success_count, int max_successful, int batch_rows = 0)
 {
     if (!h || !p || !idx || !feat || !vel || !y || !status || !gate_status || np < 2 || n_tracks < 1) return HV_ERR_INVALID;
     Ekf *e = &h->e; Ctx *c = e->c;
@@ -2867,11 +2869,18 @@ static int visual_frame_host_impl(hv_ekf *h, const hv_vu_params *p, int n_tracks
     HV_HIP(c, hipMemcpyAsync(d + o_vel, vel, B * nt * 2 * sizeof(double), hipMemcpyHostToDevice, c->stream));
     HV_HIP(c, hipMemcpyAsync(d + o_y, y, B * nt * 2 * sizeof(double), hipMemcpyHostToDevice, c->stream));
     if (n_poses) HV_HIP(c, hipMemcpyAsync(d + o_np, n_poses, B * sizeof(int), hipMemcpyHostToDevice, c->stream));
-    const int rc = visual_frame_dev_impl(h, p, n_tracks, np, n_poses ? reinterpret_cast<const int *>(d + o_np) : nullptr,
+    const int *d_np = n_poses ? reinterpret_cast<const int *>(d + o_np) : nullptr;
+    const int rc = batch_rows == 0
+        ? visual_frame_dev_impl(h, p, n_tracks, np, d_np,
                                            reinterpret_cast<const int *>(d + o_idx), reinterpret_cast<const double *>(d + o_feat),
                                            reinterpret_cast<const double *>(d + o_vel), reinterpret_cast<const double *>(d + o_y), r_gate, r_update,
                                            reinterpret_cast<int *>(d + o_st), reinterpret_cast<int *>(d + o_gs), reinterpret_cast<double *>(d + o_chi),
-                                           reinterpret_cast<double *>(d + o_pf), reinterpret_cast<int *>(d + o_cnt), max_successful);
+                                           reinterpret_cast<double *>(d + o_pf), reinterpret_cast<int *>(d + o_cnt), max_successful)
+        : hv_ekf_visual_frame_batch_dev(h, p, n_tracks, np, d_np, reinterpret_cast<const int *>(d + o_idx), reinterpret_cast<const double *>(d + o_feat),
+                                        reinterpret_cast<const double *>(d + o_vel), reinterpret_cast<const double *>(d + o_y), r_gate, r_update,
+                                        reinterpret_cast<int *>(d + o_st), reinterpret_cast<int *>(d + o_gs), reinterpret_cast<double *>(d + o_chi),
+                                        reinterpret_cast<double *>(d + o_pf), reinterpret_cast<int *>(d + o_cnt), max_successful,
+                                        batch_rows < 0 ? 0 : batch_rows);
     if (rc != HV_OK) return rc;
     HV_HIP(c, hipMemcpyAsync(status, d + o_st, B * 2 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
     HV_HIP(c, hipMemcpyAsync(gate_status, d + o_gs, B * sizeof(int), hipMemcpyDeviceToHost, c->stream));
@@ -2900,6 +2909,93 @@ int hv_ekf_visual_frame_ragged(hv_ekf *h, const hv_vu_params *p, int n_tracks, i
     if (!n_poses) return HV_ERR_INVALID;
     return visual_frame_host_impl(h, p, n_tracks, np_max, n_poses, idx, feat, vel, y, r_gate, r_update, status, gate_status, chi2, pf,
                                   success_count, max_successful);
+}
+
+int hv_ekf_visual_frame_batch(hv_ekf *h, const hv_vu_params *p, int n_tracks, int np_max, const int *n_poses, const int *idx,
+                              const double *feat, const double *vel, const double *y, double r_gate, double r_update, int *status,
+                              int *gate_status, double *chi2, double *pf, int *success_count, int max_successful, int max_update_rows)
+{
+    return visual_frame_host_impl(h, p, n_tracks, np_max, n_poses, idx, feat, vel, y, r_gate, r_update, status, gate_status, chi2, pf,
+                                  success_count, max_successful, max_update_rows > 0 ? max_update_rows : -1);
+}
+
+// host-pointer form of hv_ekf_visual_track_hybrid_dev: one track per filter, arrays [batch]...
+int hv_ekf_visual_track_hybrid(hv_ekf *h, const hv_vu_params *p, int np, const int *idx, const double *feat, const double *vel, const double *y,
+                               const int *map_update, const int *map_offer, double r_gate, double r_update, int *status, int *gate_status,
+                               double *chi2, double *pf)
+{
+    if (!h || !p || !idx || !feat || !vel || !y || !status || !gate_status || np < 2) return HV_ERR_INVALID;
+    Ekf *e = &h->e; Ctx *c = e->c;
+    const size_t B = (size_t)e->batch, nt = (size_t)np * (p->useStereo ? 2 : 1);
+    auto up = [](size_t v) { return (v + 15) & ~(size_t)15; };
+    const size_t o_idx = 0, o_feat = up(o_idx + B * np * sizeof(int)), o_vel = up(o_feat + B * nt * 2 * sizeof(double));
+    const size_t o_y = up(o_vel + B * nt * 2 * sizeof(double)), o_st = up(o_y + B * nt * 2 * sizeof(double));
+    const size_t o_gs = up(o_st + B * 2 * sizeof(int)), o_chi = up(o_gs + B * sizeof(int)), o_pf = up(o_chi + B * sizeof(double));
+    const size_t o_mu = up(o_pf + B * 3 * sizeof(double)), o_mo = up(o_mu + B * sizeof(int)), total = up(o_mo + B * sizeof(int));
+    if (e->vustage_bytes < total) {
+        HV_HIP(c, hipStreamSynchronize(c->stream));
+        if (e->vustage) (void)hipFree(e->vustage);
+        e->vustage = nullptr; e->vustage_bytes = 0;
+        HV_HIP(c, hipMalloc(reinterpret_cast<void **>(&e->vustage), total));
+        e->vustage_bytes = total;
+    }
+    unsigned char *d = e->vustage;
+    HV_HIP(c, hipMemcpyAsync(d + o_idx, idx, B * np * sizeof(int), hipMemcpyHostToDevice, c->stream));
+    HV_HIP(c, hipMemcpyAsync(d + o_feat, feat, B * nt * 2 * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    HV_HIP(c, hipMemcpyAsync(d + o_vel, vel, B * nt * 2 * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    HV_HIP(c, hipMemcpyAsync(d + o_y, y, B * nt * 2 * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    if (map_update) HV_HIP(c, hipMemcpyAsync(d + o_mu, map_update, B * sizeof(int), hipMemcpyHostToDevice, c->stream));
+    if (map_offer) HV_HIP(c, hipMemcpyAsync(d + o_mo, map_offer, B * sizeof(int), hipMemcpyHostToDevice, c->stream));
+    const int rc = hv_ekf_visual_track_hybrid_dev(h, p, np, reinterpret_cast<const int *>(d + o_idx), reinterpret_cast<const double *>(d + o_feat),
+                                                  reinterpret_cast<const double *>(d + o_vel), reinterpret_cast<const double *>(d + o_y),
+                                                  map_update ? reinterpret_cast<const int *>(d + o_mu) : nullptr,
+                                                  map_offer ? reinterpret_cast<const int *>(d + o_mo) : nullptr, r_gate, r_update,
+                                                  reinterpret_cast<int *>(d + o_st), reinterpret_cast<int *>(d + o_gs),
+                                                  reinterpret_cast<double *>(d + o_chi), reinterpret_cast<double *>(d + o_pf));
+    if (rc != HV_OK) return rc;
+    HV_HIP(c, hipMemcpyAsync(status, d + o_st, B * 2 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HV_HIP(c, hipMemcpyAsync(gate_status, d + o_gs, B * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    if (chi2) HV_HIP(c, hipMemcpyAsync(chi2, d + o_chi, B * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    if (pf) HV_HIP(c, hipMemcpyAsync(pf, d + o_pf, B * 3 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HV_HIP(c, hipStreamSynchronize(c->stream));
+    return HV_OK;
+}
+
+// insertMapPoint (ekf.cpp:911-921) on the resident state of one filter: nothing but the three coordinates crosses the bus
+namespace hv { namespace {
+__global__ __launch_bounds__(256) void ekf_insert_map_point_kernel(int n, int off, double *m, double *P, double x, double y, double z)
+{
+    const int t = threadIdx.x;
+    for (int i = t; i < 3 * n; i += 256) {
+        const int k = i / n, j = i - k * n;
+        P[(size_t)(off + k) * n + j] = 0.0;
+        P[(size_t)j * n + off + k] = 0.0;
+    }
+    __syncthreads();
+    if (t < 3) { P[(size_t)(off + t) * n + off + t] = 1e6; m[off + t] = t == 0 ? x : t == 1 ? y : z; }
+}
+} }
+
+int hv_ekf_insert_map_point(hv_ekf *h, int b, int map_index, const double *pf)
+{
+    if (!h || !pf || b < 0 || b >= h->e.batch) return HV_ERR_INVALID;
+    Ekf *e = &h->e; Ctx *c = e->c;
+    if (map_index < 0 || 3 * (map_index + 1) > e->map_dim) return HV_ERR_INVALID;
+    const int off = e->n - e->map_dim + 3 * map_index;
+    hipLaunchKernelGGL(hv::ekf_insert_map_point_kernel, dim3(1), dim3(256), 0, c->stream, e->n, off, e->m + (size_t)b * e->n,
+                       e->P + (size_t)b * e->n * e->n, pf[0], pf[1], pf[2]);
+    HV_HIP(c, hipGetLastError());
+    return HV_OK;
+}
+
+int hv_ekf_get_map_point(hv_ekf *h, int b, int map_index, double *pf)
+{
+    if (!h || !pf || b < 0 || b >= h->e.batch) return HV_ERR_INVALID;
+    Ekf *e = &h->e; Ctx *c = e->c;
+    if (map_index < 0 || 3 * (map_index + 1) > e->map_dim) return HV_ERR_INVALID;
+    HV_HIP(c, hipMemcpyAsync(pf, e->m + (size_t)b * e->n + e->n - e->map_dim + 3 * map_index, 3 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HV_HIP(c, hipStreamSynchronize(c->stream));
+    return HV_OK;
 }
 
 int hv_ekf_frame_error(hv_ekf *h, int *flags)
@@ -3159,6 +3255,21 @@ static int augment_dev_impl(hv_ekf *h, const int *discarded_dev, const unsigned 
     HV_HIP(c, hipGetLastError());
     std::swap(e->P, e->P1);
     return HV_OK;
+}
+
+// host-pointer form of hv_ekf_symmetrize_augment_dev (ABI 4)
+int hv_ekf_symmetrize_augment(hv_ekf *h, const int *discarded, const unsigned char *active)
+{
+    if (!h) return HV_ERR_INVALID;
+    Ekf *e = &h->e; Ctx *c = e->c;
+    const int *d_drop = nullptr; const unsigned char *d_act = nullptr;
+    if (discarded) { HV_HIP(c, hipMemcpyAsync(e->sdrop, discarded, sizeof(int) * e->batch, hipMemcpyHostToDevice, c->stream)); d_drop = e->sdrop; }
+    if (active) { HV_HIP(c, hipMemcpyAsync(e->sactive, active, e->batch, hipMemcpyHostToDevice, c->stream)); d_act = e->sactive; }
+    const int rc = augment_dev_impl(h, d_drop, d_act, true);
+    if (rc != HV_ERR_UNSUPPORTED) return rc;
+    // (map-point states: the folded kernel's LDS limit; the two calls it stands for)
+    const int rc2 = hv_ekf_symmetrize(h);
+    return rc2 != HV_OK ? rc2 : hv_ekf_augment(h, discarded, active);
 }
 
 int hv_ekf_augment_dev(hv_ekf *h, const int *discarded_dev, const unsigned char *active_dev) { return augment_dev_impl(h, discarded_dev, active_dev, false); }

@@ -284,12 +284,12 @@ struct HipEKF : public EKF {
         return res;
     }
 
-    std::vector<VisualTrackResult> visualFrame(const hv_vu_params &parameters, const std::vector<VisualFrameTrack> &tracks,
-                                               double chiOutlierR, double visualR, int maxSuccessfulVisualUpdates,
-                                               int *updateSuccessCount) final {
+    // the frame's tracks as the C ABI takes them: records padded to the longest track, the device gets every track's own pose count
+    std::vector<VisualTrackResult> frameLoop(const hv_vu_params &parameters, const std::vector<VisualFrameTrack> &tracks, double chiOutlierR,
+                                             double visualR, int maxSuccessfulVisualUpdates, int *updateSuccessCount, bool batched,
+                                             int maxUpdateRows) {
         std::vector<VisualTrackResult> out(tracks.size());
         if (tracks.empty()) return out;
-        // tracks of a frame differ in length: records are padded to the longest one, the device gets every track's own pose count
         const size_t K = tracks.size(), ncam = parameters.useStereo ? 2 : 1;
         size_t n = 0;
         for (const VisualFrameTrack &t : tracks) n = std::max(n, t.poseTrailIndex.size());
@@ -307,17 +307,61 @@ struct HipEKF : public EKF {
             std::copy(t.y.begin(), t.y.end(), y.begin() + k * 2 * nt);
         }
         int applied = 0;
-        check(hv_ekf_visual_frame_ragged(dev(), &parameters, (int)K, (int)n, lens.data(), idx.data(), feat.data(), vel.data(), y.data(),
-                                         chiOutlierR, visualR, status.data(), gate.data(), nullptr, pf.data(), &applied,
-                                         maxSuccessfulVisualUpdates));
+        if (batched)
+            check(hv_ekf_visual_frame_batch(dev(), &parameters, (int)K, (int)n, lens.data(), idx.data(), feat.data(), vel.data(), y.data(),
+                                            chiOutlierR, visualR, status.data(), gate.data(), nullptr, pf.data(), &applied,
+                                            maxSuccessfulVisualUpdates, maxUpdateRows));
+        else
+            check(hv_ekf_visual_frame_ragged(dev(), &parameters, (int)K, (int)n, lens.data(), idx.data(), feat.data(), vel.data(), y.data(),
+                                             chiOutlierR, visualR, status.data(), gate.data(), nullptr, pf.data(), &applied,
+                                             maxSuccessfulVisualUpdates));
         for (size_t k = 0; k < K; ++k) {
             out[k].triangulateStatus = status[2 * k]; out[k].prepareVuStatus = status[2 * k + 1];
-            out[k].outlierStatus = gate[k] == 0 ? VuOutlierStatus::INLIER : gate[k] == 3 ? VuOutlierStatus::CHI2 : VuOutlierStatus::NOT_COMPUTED;
+            out[k].outlierStatus = gate[k] == 0 ? VuOutlierStatus::INLIER : gate[k] == 3 ? VuOutlierStatus::CHI2
+                                 : gate[k] == 2 ? VuOutlierStatus::RMSE : VuOutlierStatus::NOT_COMPUTED;
             for (int q = 0; q < 3; ++q) out[k].pf[q] = pf[3 * k + q];
         }
         if (updateSuccessCount) *updateSuccessCount = applied;
         if (applied > 0) dirty();
         return out;
+    }
+    std::vector<VisualTrackResult> visualFrame(const hv_vu_params &parameters, const std::vector<VisualFrameTrack> &tracks,
+                                               double chiOutlierR, double visualR, int maxSuccessfulVisualUpdates,
+                                               int *updateSuccessCount) final {
+        return frameLoop(parameters, tracks, chiOutlierR, visualR, maxSuccessfulVisualUpdates, updateSuccessCount, false, 0);
+    }
+    std::vector<VisualTrackResult> visualFrameBatch(const hv_vu_params &parameters, const std::vector<VisualFrameTrack> &tracks,
+                                                    double chiOutlierR, double visualR, int maxSuccessfulVisualUpdates, int maxUpdateRows,
+                                                    int *updateSuccessCount) final {
+        return frameLoop(parameters, tracks, chiOutlierR, visualR, maxSuccessfulVisualUpdates, updateSuccessCount, true, maxUpdateRows);
+    }
+
+    VisualTrackResult visualTrackHybrid(const hv_vu_params &parameters, const std::vector<int> &poseTrailIndex,
+                                        const std::vector<double> &imageFeatures, const std::vector<double> &featureVelocities,
+                                        const VectorXd &y, int mapPointIndex, int offeredMapPointIndex, double chiOutlierR,
+                                        double visualR) final {
+        const size_t n = poseTrailIndex.size(), nt = n * (parameters.useStereo ? 2 : 1);
+        assert(imageFeatures.size() == 2 * nt && featureVelocities.size() == 2 * nt && y.size() == 2 * nt);
+        assert(mapPointIndex < par.hybridMapSize && offeredMapPointIndex < par.hybridMapSize);
+        int status[2] = {0, 0}, gate = 1;
+        VisualTrackResult res{};
+        check(hv_ekf_visual_track_hybrid(dev(), &parameters, (int)n, poseTrailIndex.data(), imageFeatures.data(), featureVelocities.data(),
+                                         y.data(), par.hybridMapSize > 0 ? &mapPointIndex : nullptr,
+                                         par.hybridMapSize > 0 ? &offeredMapPointIndex : nullptr, chiOutlierR, visualR, status, &gate,
+                                         nullptr, res.pf.data()));
+        res.triangulateStatus = status[0]; res.prepareVuStatus = status[1];
+        res.outlierStatus = gate == 0 ? VuOutlierStatus::INLIER : gate == 3 ? VuOutlierStatus::CHI2 : VuOutlierStatus::NOT_COMPUTED;
+        if (gate == 0) dirty();                       // applied, or inserted as a map point
+        return res;
+    }
+
+    void symmetrizeAugment(int discardedPoseIndex) final {
+        check(hv_ekf_symmetrize_augment(dev(), &discardedPoseIndex, nullptr));
+        dirty();
+        augmentTimes.push_back(getPlatformTime());
+        if (augmentCount < camPoseCount) augmentCount++;
+        else augmentTimes.erase(augmentTimes.begin());
+        assert(static_cast<int>(augmentTimes.size()) == augmentCount);
     }
 
     void updateVisualPoseAugmentation(int discardedPoseIndex) final {
@@ -336,18 +380,16 @@ struct HipEKF : public EKF {
         augmentCount--;
     }
 
-    Vector3d getMapPoint(int idx) const final {
-        const int off = getMapPointStateIndex(idx);
-        assert(idx >= 0 && off + MAP_POINT_DIM <= stateDim);
-        return seg3(off);
+    Vector3d getMapPoint(int idx) const final {               // ekf.cpp:905-909: read from the resident mean
+        assert(idx >= 0 && getMapPointStateIndex(idx) + MAP_POINT_DIM <= stateDim);
+        Vector3d pf{};
+        check(hv_ekf_get_map_point(dev(), 0, idx, pf.data()));
+        return pf;
     }
-    void insertMapPoint(int idx, const Vector3d &pf) final {   // ekf.cpp:911-921
-        const int off = getMapPointStateIndex(idx);
-        assert(idx >= 0 && off + MAP_POINT_DIM <= stateDim);
-        syncAll();
-        for (int k = 0; k < MAP_POINT_DIM; k++) for (int i = 0; i < stateDim; i++) { P(off + k, i) = 0; P(i, off + k) = 0; }
-        for (int k = 0; k < MAP_POINT_DIM; k++) { P(off + k, off + k) = 1e6; m[off + k] = pf[k]; }
-        pushAll();
+    void insertMapPoint(int idx, const Vector3d &pf) final {   // ekf.cpp:911-921, on the resident state (ABI 4)
+        assert(idx >= 0 && getMapPointStateIndex(idx) + MAP_POINT_DIM <= stateDim);
+        check(hv_ekf_insert_map_point(dev(), 0, idx, pf.data()));
+        dirty();
     }
     int getMapPointStateIndex(int idx) const final {
         if (idx == -1) return -1;

@@ -324,6 +324,24 @@ public:
     virtual std::vector<VisualTrackResult> visualFrame(const hv_vu_params &parameters, const std::vector<VisualFrameTrack> &tracks,
                                                        double chiOutlierR, double visualR, int maxSuccessfulVisualUpdates,
                                                        int *updateSuccessCount = nullptr) = 0;
+    // The same loop with parameters.batchVisualUpdate -- or on a frame that is not a "full visual update" -- (backend.cpp:1001-1010,
+    // 1169-1183, 1255-1262): inliers' blocks are collected and applied as ONE updateVisualTrack per batch of at most maxUpdateRows rows
+    // (= int(stateDim * batchVisualUpdateMaxSizeMultiplier + 0.5); <= 0: stateDim); every track between two flushes is gated against the
+    // same state. hv_ekf_visual_frame_batch (ABI 4).
+    virtual std::vector<VisualTrackResult> visualFrameBatch(const hv_vu_params &parameters, const std::vector<VisualFrameTrack> &tracks,
+                                                            double chiOutlierR, double visualR, int maxSuccessfulVisualUpdates,
+                                                            int maxUpdateRows, int *updateSuccessCount = nullptr) = 0;
+    // One track visit with the hybrid-map branches of the loop (backend.cpp:1075-1082, 1146-1168): mapPointIndex >= 0 = the track's
+    // point is map point mapPointIndex of the state (no triangulation: triangulateStatus HV_TRI_HYBRID); offeredMapPointIndex >= 0 = the
+    // slot ekfStateIndex.offerMapPoint hands to this pose-trail track -- if the gate accepts it the point is INSERTED as that map point
+    // (insertMapPoint) instead of being applied. Both -1: visualTrack. hv_ekf_visual_track_hybrid (ABI 4).
+    virtual VisualTrackResult visualTrackHybrid(const hv_vu_params &parameters, const std::vector<int> &poseTrailIndex,
+                                                const std::vector<double> &imageFeatures, const std::vector<double> &featureVelocities,
+                                                const VectorXd &y, int mapPointIndex, int offeredMapPointIndex, double chiOutlierR,
+                                                double visualR) = 0;
+    // maintainPositiveSemiDefinite() followed by updateVisualPoseAugmentation(discardedPoseIndex), the end of every frame
+    // (backend.cpp:1267, 804-805), as one pass over the covariance (hv_ekf_symmetrize_augment, ABI 4); bit-identical to the two calls.
+    virtual void symmetrizeAugment(int discardedPoseIndex = -1) = 0;
 };
 
 }  // namespace odometry

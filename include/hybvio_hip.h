@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define HV_ABI_VERSION 3   /* 3 (r04): hv_lanes_*, hv_get_stream; 2 (r03): hv_debug_*_knob, hv_ekf_frame_error, HV_ERR_TIMEOUT; maxSuccessfulVisualUpdates <= 0 = no limit */
+#define HV_ABI_VERSION 4   /* 4 (r05): host-pointer forms of the r04 frame entries (hv_ekf_visual_frame_batch, hv_ekf_visual_track_hybrid, hv_ekf_symmetrize_augment), hv_ekf_insert_map_point / hv_ekf_get_map_point; 3 (r04): hv_lanes_*, hv_get_stream; 2 (r03): hv_debug_*_knob, hv_ekf_frame_error, HV_ERR_TIMEOUT; maxSuccessfulVisualUpdates <= 0 = no limit */
 #define HV_MAX_LEVELS 6
 
 typedef enum hv_status {
@@ -350,6 +350,23 @@ int hv_ekf_visual_frame(hv_ekf *ekf, const hv_vu_params *p, int n_tracks, int n_
 int hv_ekf_visual_frame_ragged(hv_ekf *ekf, const hv_vu_params *p, int n_tracks, int n_poses_max, const int *n_poses, const int *pose_index,
                                const double *features, const double *velocities, const double *y, double r_gate, double r_update,
                                int *status, int *gate_status, double *chi2, double *pf, int *success_count, int max_successful);
+/* host-pointer form of hv_ekf_visual_frame_batch_dev (ABI 4): what a single session with batchVisualUpdate calls once per frame
+ * (backend.cpp:1001-1010,1169-1183,1255-1262). n_poses may be NULL (every track has n_poses_max poses). Synchronous. */
+int hv_ekf_visual_frame_batch(hv_ekf *ekf, const hv_vu_params *p, int n_tracks, int n_poses_max, const int *n_poses, const int *pose_index,
+                              const double *features, const double *velocities, const double *y, double r_gate, double r_update,
+                              int *status, int *gate_status, double *chi2, double *pf, int *success_count, int max_successful,
+                              int max_update_rows);
+/* host-pointer form of hv_ekf_visual_track_hybrid_dev (ABI 4): one track visit per filter with the hybrid-map branches
+ * (backend.cpp:1075-1082 mapPointUpdate tracks, :1146-1168 insertMapPoint for an offered slot). map_update / map_offer [batch] or NULL.
+ * chi2 / pf may be NULL. Synchronous. */
+int hv_ekf_visual_track_hybrid(hv_ekf *ekf, const hv_vu_params *p, int n_poses, const int *pose_index, const double *features,
+                               const double *velocities, const double *y, const int *map_update, const int *map_offer, double r_gate,
+                               double r_update, int *status, int *gate_status, double *chi2, double *pf);
+/* EKF::insertMapPoint / getMapPoint (ekf.hpp:129-131, ekf.cpp:905-921) on the resident state of filter `filter` (ABI 4): the slot's rows
+ * and columns of P are zeroed, 1e6 goes on its diagonal, pf into the mean -- 24 bytes cross the bus instead of the covariance twice.
+ * insert is asynchronous (pf is read before the call returns), get synchronous. map_index in [0, hybridMapSize). */
+int hv_ekf_insert_map_point(hv_ekf *ekf, int filter, int map_index, const double *pf);
+int hv_ekf_get_map_point(hv_ekf *ekf, int filter, int map_index, double *pf);
 /* Host-pointer form of hv_ekf_visual_track_dev (arrays [batch][...] as above): about 1 KB per track goes to the device
  * and 40 bytes come back, instead of the mean coming back and a (2 * ncam * n_poses) x stateDim Jacobian going up.
  * chi2 / pf may be NULL. Synchronous. */
@@ -366,6 +383,9 @@ int hv_ekf_augment_dev(hv_ekf *ekf, const int *discarded_dev, const unsigned cha
  * every covariance element together with its mirror, so (P + P') / 2 is formed on the fly; results are bit-identical to the
  * two calls in sequence (tests/test_gpu_ekf.py), inactive filters come out symmetrised and otherwise untouched. */
 int hv_ekf_symmetrize_augment_dev(hv_ekf *ekf, const int *discarded_dev, const unsigned char *active_dev);
+/* host-array form (ABI 4): maintainPositiveSemiDefinite + updateVisualPoseAugmentation as the backend issues them at the end of a frame
+ * (backend.cpp:1267, 804-805). States with map points fall back to the two separate calls (same results). */
+int hv_ekf_symmetrize_augment(hv_ekf *ekf, const int *discarded /* [batch] or NULL */, const unsigned char *active);
 int hv_ekf_undo_augment(hv_ekf *ekf, const unsigned char *active);
 int hv_ekf_symmetrize(hv_ekf *ekf);                                 /* maintainPositiveSemiDefinite */
 int hv_ekf_normalize_quaternions(hv_ekf *ekf, int only_current);    /* ekf.cpp:1024-1032            */

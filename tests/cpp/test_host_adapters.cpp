@@ -368,6 +368,139 @@ static void test_visual_frame(Session &s, const std::string &dir)
     REQUIRE(applied_all == done_all && done_all >= 1);
 }
 
+// ABI 4 (r05): the r04 frame entries behind the C++ interface. Each is checked against the sequence of interface calls it stands for
+// (the numbers themselves are pinned against the oracle in tests/test_gpu_visual_prepare.py / test_gpu_ekf.py).
+static void test_abi4_entries(Session &s, const std::string &dir)
+{
+    hv_ekf_params par; hv_ekf_default_params(&par);
+    par.cameraTrailLength = 20; par.noiseScale = 1000.0;
+    const std::vector<double> poses = load(dir + "/visual_poses.txt"), uv = load(dir + "/visual_uv.txt");
+    auto seed_state = [&](odometry::EKF &e) {
+        VectorXd m = e.getState();
+        for (int k = 0; k < 3; k++) m[odometry::POS + k] = poses[k];
+        for (int k = 0; k < 4; k++) m[odometry::ORI + k] = poses[3 + k];
+        for (int i = 0; i < 9; i++) for (int k = 0; k < 7; k++) m[odometry::CAM + 7 * i + k] = poses[7 * (i + 1) + k];
+        e.setState(m);
+    };
+    hv_vu_params vp; hv_vu_default_params(&vp);
+    // ---- symmetrizeAugment == maintainPositiveSemiDefinite + updateVisualPoseAugmentation, to the bit (backend.cpp:1267, 804-805) ----
+    {
+        auto a = odometry::EKF::buildHip(s, par);
+        seed_state(*a);
+        MatrixXd P = a->getStateCovariance();
+        const int n = a->getStateDim();
+        unsigned lcg = 12345u;
+        for (int j = 0; j < n; j++) for (int i = 0; i < n; i++) {          // an asymmetric perturbation: the symmetrisation has work to do
+            lcg = lcg * 1664525u + 1013904223u;
+            P(i, j) += 1e-9 * (double)(lcg >> 8) / (double)(1u << 24);
+        }
+        a->setStateCovariance(P);
+        auto b = a->clone();
+        for (int round = 0; round < 3; round++) {
+            const int drop = round == 1 ? 2 : -1;
+            a->symmetrizeAugment(drop);
+            b->maintainPositiveSemiDefinite(); b->updateVisualPoseAugmentation(drop);
+            REQUIRE(a->getPoseCount() == b->getPoseCount());
+            const MatrixXd Pa = a->getStateCovariance(), Pb = b->getStateCovariance();
+            REQUIRE(Pa.data == Pb.data);
+            REQUIRE(a->getState() == b->getState());
+        }
+    }
+    // ---- visualFrameBatch (backend.cpp:1001-1010,1169-1183,1255-1262) ----
+    {
+        auto a = odometry::EKF::buildHip(s, par);
+        seed_state(*a);
+        std::vector<odometry::EKF::VisualFrameTrack> tracks(5);
+        for (size_t k = 0; k < tracks.size(); k++) {
+            auto &t = tracks[k];
+            t.poseTrailIndex.resize(10);
+            for (int i = 0; i < 10; i++) t.poseTrailIndex[i] = i;
+            t.imageFeatures = uv; t.featureVelocities.assign(20, 0.1);
+            t.y = VectorXd(uv.begin(), uv.end());
+            if (k == 1) for (auto &x : t.imageFeatures) x = -x;              // never reaches the gate
+            if (k >= 2) for (size_t i = 0; i < t.y.size(); i++) t.y[i] += 1e-4 * ((i + k) % 3);
+        }
+        // (i) a batch that holds exactly one track's block = the sequential loop: every inlier is flushed before the next one is gated
+        auto seq = a->clone(), one = a->clone();
+        int applied_seq = -1, applied_one = -1;
+        const auto rs = seq->visualFrame(vp, tracks, 1.5, 0.05, 0, &applied_seq);
+        const auto ro = one->visualFrameBatch(vp, tracks, 1.5, 0.05, 0, 20, &applied_one);
+        REQUIRE(applied_one == applied_seq && applied_seq >= 2);
+        for (size_t k = 0; k < tracks.size(); k++) {
+            REQUIRE(ro[k].triangulateStatus == rs[k].triangulateStatus && ro[k].prepareVuStatus == rs[k].prepareVuStatus);
+            REQUIRE(ro[k].outlierStatus == rs[k].outlierStatus);
+        }
+        {
+            const VectorXd &ma = one->getState(), &mb = seq->getState();
+            double diff = 0, norm = 0;
+            for (size_t i = 0; i < ma.size(); i++) { diff += std::fabs(ma[i] - mb[i]); norm += std::fabs(mb[i]); }
+            REQUIRE(diff <= 1e-9 * norm);
+        }
+        // (ii) one batch for the whole frame (max_update_rows = stateDim): every track is gated against the state the frame started
+        // with -- the verdict each track gets alone on a clone of that state -- and the inliers are applied together
+        auto all = a->clone();
+        int applied_all = -1;
+        const auto ra = all->visualFrameBatch(vp, tracks, 1.5, 0.05, 0, 0, &applied_all);
+        int inliers = 0;
+        for (size_t k = 0; k < tracks.size(); k++) {
+            auto c = a->clone();
+            const auto r1 = c->visualTrack(vp, tracks[k].poseTrailIndex, tracks[k].imageFeatures, tracks[k].featureVelocities, tracks[k].y, 1.5, 0.05);
+            REQUIRE(ra[k].triangulateStatus == r1.triangulateStatus && ra[k].outlierStatus == r1.outlierStatus);
+            inliers += r1.outlierStatus == odometry::VuOutlierStatus::INLIER;
+        }
+        REQUIRE(applied_all == inliers && inliers >= 2);
+        const VectorXd &m0 = a->getState(), &m1 = all->getState();
+        double moved = 0; for (size_t i = 0; i < m0.size(); i++) moved += std::fabs(m1[i] - m0[i]);
+        REQUIRE(moved > 0.0 && moved < 1.0);
+    }
+    // ---- hybrid map: insertMapPoint / getMapPoint on the resident state, visualTrackHybrid (backend.cpp:1075-1082,1146-1168) ----
+    {
+        hv_ekf_params ph = par; ph.hybridMapSize = 2;
+        auto a = odometry::EKF::buildHip(s, ph);
+        seed_state(*a);
+        const int n = a->getStateDim();
+        REQUIRE(n == 20 + 7 * 20 + 6 && a->getMapPointStateIndex(1) == n - 3);
+        std::vector<int> idx(10);
+        for (int i = 0; i < 10; i++) idx[i] = i;
+        std::vector<double> vel(20, 0.1);
+        VectorXd y(uv.begin(), uv.end());
+        // neither a map-point track nor an offer: visualTrack
+        auto b = a->clone(), c = a->clone();
+        const auto r0 = b->visualTrackHybrid(vp, idx, uv, vel, y, -1, -1, 1.5, 0.05);
+        const auto r1 = c->visualTrack(vp, idx, uv, vel, y, 1.5, 0.05);
+        REQUIRE(r0.triangulateStatus == r1.triangulateStatus && r0.outlierStatus == r1.outlierStatus && r0.outlierStatus == odometry::VuOutlierStatus::INLIER);
+        {
+            const VectorXd &mb = b->getState(), &mc = c->getState();
+            double diff = 0, norm = 0;
+            for (size_t i = 0; i < mb.size(); i++) { diff += std::fabs(mb[i] - mc[i]); norm += std::fabs(mc[i]); }
+            REQUIRE(diff <= 1e-9 * norm);
+        }
+        // an accepted track that was offered slot 1: inserted as a map point INSTEAD of being applied == insertMapPoint(1, pf)
+        auto d = a->clone(), e = a->clone();
+        const auto r2 = d->visualTrackHybrid(vp, idx, uv, vel, y, -1, 1, 1.5, 0.05);
+        REQUIRE(r2.outlierStatus == odometry::VuOutlierStatus::INLIER && r2.triangulateStatus == HV_TRI_OK);
+        e->insertMapPoint(1, r2.pf);
+        REQUIRE(d->getState() == e->getState());
+        REQUIRE(d->getStateCovariance().data == e->getStateCovariance().data);
+        const Vector3d got = d->getMapPoint(1);
+        REQUIRE(got[0] == r2.pf[0] && got[1] == r2.pf[1] && got[2] == r2.pf[2]);
+        const MatrixXd Pd = d->getStateCovariance();
+        const int off = d->getMapPointStateIndex(1);
+        bool rows_zero = true;
+        for (int k = 0; k < 3; k++) for (int i = 0; i < n; i++) if (i != off + k) rows_zero = rows_zero && Pd(off + k, i) == 0.0 && Pd(i, off + k) == 0.0;
+        REQUIRE(rows_zero && Pd(off, off) == 1e6 && Pd(off + 2, off + 2) == 1e6);
+        for (int i = 0; i < off; i++) REQUIRE(d->getState()[i] == a->getState()[i]);    // nothing else moved
+        // the track of that map point one frame later: no triangulation (HV_TRI_HYBRID), the point is read from the state, gate + update
+        const auto r3 = d->visualTrackHybrid(vp, idx, uv, vel, y, 1, -1, 1.5, 0.05);
+        REQUIRE(r3.triangulateStatus == HV_TRI_HYBRID && r3.prepareVuStatus == HV_PREPARE_VU_OK);
+        REQUIRE(r3.pf[0] == got[0] && r3.pf[1] == got[1] && r3.pf[2] == got[2]);
+        REQUIRE(r3.outlierStatus == odometry::VuOutlierStatus::INLIER);
+        const Vector3d after = d->getMapPoint(1);
+        REQUIRE(std::fabs(after[0] - got[0]) + std::fabs(after[1] - got[1]) + std::fabs(after[2] - got[2]) < 1e-2);
+        REQUIRE(d->getStateCovariance()(off, off) < 1e6);                               // the update tightened the point
+    }
+}
+
 // RotRansac::fit as doRansac2 calls it (ransac_pipeline.cpp:197-216): two consecutive frames share ONE std::mt19937, so
 // the second call only agrees with the oracle if the first consumed exactly what the reference loop would have
 static void test_rot_ransac(Session &s, const std::string &dir)
@@ -413,6 +546,7 @@ int main(int argc, char **argv)
     test_ingest(session, dir);
     test_visual_track(session, dir);
     test_visual_frame(session, dir);
+    test_abi4_entries(session, dir);
     test_rot_ransac(session, dir);
     {   // the same EKF / tracker / visual-update tests through the lanes of an hv_lanes set (library-owned high-priority streams)
         Lanes lanes(p, 2);
@@ -421,6 +555,7 @@ int main(int argc, char **argv)
         test_der_predict(lanes.session(1), dir);
         test_tracker(lanes.session(1), dir);
         test_visual_frame(lanes.session(0), dir);
+        test_abi4_entries(lanes.session(1), dir);
     }
     std::printf("%s (%d failure%s)\n", failures ? "FAILED" : "all host adapter tests passed", failures, failures == 1 ? "" : "s");
     return failures ? 1 : 0;

@@ -30,7 +30,7 @@ def test_header_symbols_exported_and_bound():
 
 def test_defaults_and_status_strings():
     L = capi.lib()
-    assert L.hv_abi_version() == 3
+    assert L.hv_abi_version() == 4
     p = capi.Params()
     L.hv_default_params(C.byref(p))
     # codegen/parameter_definitions.c:262,336-344
