@@ -266,3 +266,94 @@ def test_lanes_driven_from_their_own_host_threads(problems4):
             l.check(f"threaded lane {i}")
         for l in L:
             l.g.close()
+
+
+def test_two_lanes_run_the_batch_loop_and_the_hybrid_visit_beside_each_other(oracle):
+    """r05: the r04 entries under lanes. Lane 0 runs hv_ekf_visual_frame_batch_dev over 130 distinct filters
+    (84-row tracks: the long build + dense batched updates) while lane 1 runs it over 300 filters of short tracks with carried blocks,
+    both enqueued before either is waited for; every filter of both lanes against the oracle's batchVisualUpdate loop. Then both lanes
+    run a hybrid-map visit (hv_ekf_visual_track_hybrid_dev) concurrently and must leave what each leaves alone."""
+    import torch
+    from test_gpu_visual_prepare import _batch_loop_case, _run_batch_loop
+    cases = [_batch_loop_case(oracle, 7101, 130, 21, 6, 3, 160, True), _batch_loop_case(oracle, 7102, 300, 10, 6, 4, 64, True)]
+    with capi.Lanes(2, width=64, height=64) as lanes:
+        gs_, outs = [], []
+        for ctx, case in zip(lanes.ctx, cases):
+            g = capi.EkfBatch(ctx, capi.ekf_default_params(cameraTrailLength=case["trail_len"]), case["B"])
+            gs_.append(g); outs.append(_run_batch_loop(case, ctx, g))
+        for rep in range(2):                                    # the second round runs with every work buffer allocated
+            for g, case, (d, st, gsx, counter) in zip(gs_, cases, outs):
+                for b in range(case["B"]):
+                    g.set_state(b, case["means"][b], case["P0"][b])
+                st.fill_(-9); gsx.fill_(-9); counter.fill_(77)
+            torch.cuda.synchronize()
+            for g, case, (d, st, gsx, counter) in zip(gs_, cases, outs):     # asynchronous on the lane's own stream
+                g.visual_frame_batch_dev(case["vp"], case["K"], case["np_max"], d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(), d[3].data_ptr(),
+                                         d[4].data_ptr(), case["r_gate"], case["r_update"], st.data_ptr(), gsx.data_ptr(), counter.data_ptr(),
+                                         case["quota"], case["max_rows"])
+            torch.cuda.synchronize()
+        for g, case, (d, st, gsx, counter) in zip(gs_, cases, outs):
+            case["verify"](g, st.cpu().numpy(), gsx.cpu().numpy(), counter.cpu().numpy())
+            g.close()
+
+
+def test_hybrid_visit_on_two_lanes_equals_the_visit_alone(oracle):
+    import torch
+    from test_gpu_visual_prepare import _random_tracks
+    trail_len, M, npose, B = 20, 3, 8, 48
+    n = 20 + 7 * trail_len + 3 * M
+    inputs = []
+    for seed in (8101, 8102):
+        rng = np.random.default_rng(seed)
+        T1, T2, means, idx, feat, vel = _random_tracks(oracle, rng, B, trail_len, npose, True, bad_fraction=0.1)
+        m = np.concatenate([means, rng.normal(size=(B, 3 * M))], axis=1)
+        P = np.zeros((B, n, n))
+        for b in range(B):
+            A = rng.normal(size=(n, n)) * 1e-3
+            P[b] = np.eye(n) * 1e-4 + A @ A.T
+        ys = feat.reshape(B, -1) + 2e-3 * rng.normal(size=(B, feat.shape[1] * 2))
+        ys[::5] += 3.0
+        offer = np.where(np.arange(B) % 3 == 1, np.arange(B) % M, -1).astype(np.int32)
+        inputs.append(dict(T1=T1, T2=T2, m=m, P=P, idx=idx, feat=feat, vel=vel, ys=ys, offer=offer))
+
+    def visit(ctx, inp, sync):
+        g = capi.EkfBatch(ctx, capi.ekf_default_params(cameraTrailLength=trail_len, hybridMapSize=M), B)
+        for b in range(B):
+            g.set_state(b, inp["m"][b], inp["P"][b])
+        dev = lambda a, dt: torch.from_numpy(np.array(a, dt, order="C")).cuda()
+        d = [dev(inp["idx"], np.int32), dev(inp["feat"], np.float64), dev(inp["vel"], np.float64), dev(inp["ys"], np.float64),
+             dev(np.full(B, -1, np.int32), np.int32), dev(inp["offer"], np.int32)]
+        st = torch.full((B, 2), -9, dtype=torch.int32, device="cuda"); gs = torch.full((B,), -9, dtype=torch.int32, device="cuda")
+        chi = torch.zeros(B, dtype=torch.float64, device="cuda"); pf = torch.zeros((B, 3), dtype=torch.float64, device="cuda")
+        vp = capi.vu_default_params(imu_to_camera=inp["T1"], second_imu_to_camera=inp["T2"])
+        torch.cuda.synchronize()
+
+        def launch():
+            g.visual_track_hybrid_dev(vp, npose, d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(), d[3].data_ptr(), d[4].data_ptr(), d[5].data_ptr(),
+                                      1.5, 0.05, st.data_ptr(), gs.data_ptr(), chi.data_ptr(), pf.data_ptr())
+
+        def result():
+            out = (st.cpu().numpy().copy(), gs.cpu().numpy().copy(), [g.get_state(b) for b in range(B)])
+            g.close()
+            return out
+        if sync:
+            launch(); torch.cuda.synchronize()
+            return result()
+        return launch, result, (d, st, gs, chi, pf)
+
+    alone = []
+    for inp in inputs:
+        with capi.Context(width=64, height=64) as ctx:
+            ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+            alone.append(visit(ctx, inp, True))
+    with capi.Lanes(2, width=64, height=64) as lanes:
+        pend = [visit(ctx, inp, False) for ctx, inp in zip(lanes.ctx, inputs)]
+        for launch, _, _ in pend:
+            launch()                                            # both visits in flight on the two lanes' streams
+        torch.cuda.synchronize()
+        for (launch, result, keep), ref in zip(pend, alone):
+            st, gs, states = result()
+            assert np.array_equal(st, ref[0]) and np.array_equal(gs, ref[1])
+            assert (gs == 0).sum() >= 8 and (gs == 3).sum() >= 3
+            for (mg, Pg), (mr, Pr) in zip(states, ref[2]):
+                assert np.array_equal(mg, mr) and np.array_equal(Pg, Pr)
