@@ -1152,8 +1152,8 @@ COMPACT_TOP = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_s
 COMPACT_CONFIG = ("workload", "sequences_per_gpu", "engines_per_gpu", "frames_per_step", "parallelism", "parity_ok", "parity_checked_sequences",
                   "stage_frac_agreed", "stage_frac_actual", "one_engine_value", "lanes_2_value", "c3_uniform_value", "c3_chained_value",
                   "c4_value", "c4_stage_frac_agreed", "latency_ms_eager", "latency_ms_graph")
-COMPACT_ROOFLINE = ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "algorithmic_bytes_per_launch", "avg_launch_ms",
-                    "frac_pmc_bytes", "frac_valu_issue", "valu_cycles_per_wave64_inst", "traffic_source")
+COMPACT_ROOFLINE = ("kernel", "bound", "limited_by", "achieved", "peak", "unit", "frac", "traffic", "algorithmic_bytes_per_launch", "avg_launch_ms",
+                    "frac_pmc_bytes", "frac_valu_issue", "valu_cycles_per_wave64_inst", "valu_peak_G_wave_insts_per_s", "traffic_source")
 COMPACT_CPU = ("value", "unit", "cores", "kind", "single_thread_value", "ekf_threads", "compiler_flags", "sample")
 
 
@@ -1229,7 +1229,7 @@ def main():
                     help="lanes of the hv_lanes set of the realistic headline leg: each a batched context on library-owned streams with its own HIP "
                          "graphs and --sequences resident sequences; their launch chains run beside each other (2 = r03's headline configuration, "
                          "reported as `lanes_2` whenever more lanes run; 1 = one context on a torch stream)")
-    ap.add_argument("--verify-per-engine", type=int, default=2, help="sequences checked per lane when more than two lanes run (--verify applies up to two)")
+    ap.add_argument("--verify-per-engine", type=int, default=4, help="sequences checked per lane when more than two lanes run (--verify applies up to two)")
     ap.add_argument("--one-sequence-leg", action="store_true", help="add the literal north-star configuration (ONE sequence per GPU) at N > 1 too")
     ap.add_argument("--cpu-baseline-child", type=float, default=None, help=argparse.SUPPRESS)
     args = ap.parse_args()
@@ -1550,16 +1550,23 @@ def main():
              "frac_of_measured_copy_ceiling": stage_gbs / HBM_COPY_CEILING_GBS, "algorithmic_bytes_per_stereo_frame": ab["stereo_frame"],
              "stage_actual_bytes_per_step": stage_actual,
              "frac_actual": (stage_actual / (stage_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if stage_actual else None,
-             "bound": "valu", "valu_busy_frac_klt": pmc("klt", "valu_busy_frac"),
+             "bound": "hbm", "limiter": "valu-issue (klt_kernel)",
              "note": "frac_of_8TBs prices the AGREED bytes of SURVEY 8(d) (gradient planes of every level written, windows read once); the kernels "
                      "move stage_actual_bytes (levels 0-1 keep no gradient plane, LK windows are cache hits): frac_actual is the real HBM "
                      "utilisation; the limiter of the stage is klt_kernel's integer VALU issue rate"}
     # limiter of the dominant kernel class, stated for what it is (item 5 iii): the EKF kernels are f64 matrix / latency structured
     f64_peak_tflops = 78.6                                        # MI355X f64 vector = matrix peak (MI355X_MICROARCH.md)
-    VALU_PEAK_WAVE_INSTS = 1024 * 2.4e9 / 4.0                     # wave64 instructions per second the chip can issue
+    # wave64 VALU instructions per second the chip issues, MEASURED for the instruction classes klt_kernel is made of (r05,
+    # scripts/valu_issue_ubench.hip -> profiles/r05/valu_issue_ubench.txt, all CUs busy, 8 waves per SIMD): v_dot2_i32_i16 / v_perm_b32 /
+    # v_pk_* / v_lshl_or / DPP 541 .. 577 G/s (4 cycles per SIMD at the ~2.3 GHz the chip holds under this load); only v_add / v_sub /
+    # v_and / v_or / v_mov / f32 add / mul / fma issue every 2 cycles, and only in runs of their own kind (alternating with a dot2:
+    # 570 G/s per instruction). r04 assumed 1024 x 2.4 GHz / 4 = 614 G/s; the guide's "2 cycles" holds for that second class only.
+    VALU_PEAK_WAVE_INSTS = 565e9
+    VALU_CYCLES_PER_INST = 4.0
     valu_pf = pmc("klt", "valu_insts_per_feature")
     flops_vu = B * (1.1e6 * lens_mean / 10.0 + 2 * rows_mean * na_mean * na_mean + 2 * rows_mean * rows_mean * na_mean + rows_mean ** 3 / 3)
-    limiter = {"klt": "VALU issue (integer): klt_kernel issues VALU instructions > 90 % of the time; HBM traffic is a quarter of the agreed bytes",
+    limiter = {"klt": "VALU issue: klt_kernel's packed-integer instructions (dot2 / perm / pk / DPP) issue every 4 cycles per SIMD on gfx950; it runs at "
+                      "~0.85 of that measured ceiling, HBM traffic is a quarter of the agreed bytes (profiles/r05/valu_issue_ubench.txt)",
                "vu_prepare": "per-workgroup latency: the fused triangulation + prepareVisualUpdate + column-sparse chi2 gate kernel is a chain of ~50 "
                              "barrier-separated f64 phases (two 80 KB workgroups per CU, waves parked 70 % of the time, VALU busy ~25 %, MFMA busy ~10 %); "
                              "neither HBM nor the matrix pipe bounds it",
@@ -1599,10 +1606,11 @@ def main():
                        "timing_process_group": args.dist_backend if world > 1 else None, "host_cores_per_rank": env.cores},
             # the dominant kernel, labelled for what bounds it: klt_kernel issues integer VALU instructions > 90 % of the time. achieved /
             # peak / frac stay in the contract's units on the AGREED bytes of SURVEY 8(d) (windows read once, every gradient plane counted);
-            # frac_pmc_bytes prices the bytes the kernel really moves (PMC); frac_valu_issue = instructions issued per second / the chip's
-            # 614 G wave-instructions/s (1024 SIMDs x 2.4 GHz / 4 cycles per wave64 instruction), from the PMC instruction count per
-            # feature and the launch time measured HERE
-            "roofline": {"bound": "valu", "kernel": "klt_kernel", "kernel_class": dom, "chosen_by": "largest single-kernel share of the step's GPU time (rocprofv3 kernel trace)",
+            # frac_pmc_bytes prices the bytes the kernel really moves (PMC); frac_valu_issue = instructions issued per second / the MEASURED
+            # issue ceiling of its instruction classes (VALU_PEAK_WAVE_INSTS above), from the PMC instruction count per feature and the
+            # launch time measured HERE. `bound` stays in the contract's vocabulary: achieved / peak / frac are HBM figures on the agreed
+            # bytes; `limited_by` says what really sets the kernel's time
+            "roofline": {"bound": "hbm", "limited_by": "valu-issue", "kernel": "klt_kernel", "kernel_class": dom, "chosen_by": "largest single-kernel share of the step's GPU time (rocprofv3 kernel trace)",
                          "achieved": k3[dom]["achieved_GBs"], "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": k3[dom]["achieved_GBs"] / HBM_PEAK_GBS, "traffic": traffic,
                          "algorithmic_bytes_per_launch": alg[dom], "avg_launch_ms": k3[dom]["avg_ms"], "traffic_source": traffic_note,
@@ -1610,7 +1618,8 @@ def main():
                          "frac_pmc_bytes": (traffic / (k3[dom]["avg_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
                          "valu_insts_per_feature": valu_pf,
                          "frac_valu_issue": (valu_pf * B * NPTS / (k3[dom]["avg_ms"] * 1e-3) / VALU_PEAK_WAVE_INSTS) if valu_pf else None,
-                         "valu_busy_frac": pmc(dom, "valu_busy_frac"),
+                         "valu_cycles_per_wave64_inst": VALU_CYCLES_PER_INST, "valu_peak_G_wave_insts_per_s": VALU_PEAK_WAVE_INSTS / 1e9,
+                         "valu_peak_source": "scripts/valu_issue_ubench.hip, profiles/r05/valu_issue_ubench.txt (measured, instruction classes of the kernel)",
                          "limiter": limiter,
                          "stage_frac_agreed": stage["frac_of_8TBs"], "stage_frac_actual": stage["frac_actual"], "stage_ms_per_step": stage["ms_per_step"],
                          "parity_ok": verify["ok"] if verify else None,
@@ -1622,7 +1631,7 @@ def main():
                              "achieved": k3.get("vu_prepare", {}).get("achieved_GBs"), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                              "frac": (k3["vu_prepare"]["achieved_GBs"] / HBM_PEAK_GBS) if "vu_prepare" in k3 else None,
                              "f64_flop_frac": (flops_vu / (k3["vu_prepare"]["avg_ms"] * 1e-3) / 1e12 / f64_peak_tflops) if "vu_prepare" in k3 else None,
-                             "mfma_busy_frac": pmc("vu_prepare", "mfma_busy_frac"), "valu_busy_frac": pmc("vu_prepare", "valu_busy_frac"),
+                             "mfma_busy_frac": pmc("vu_prepare", "mfma_busy_frac"),
                              "wave_parked_frac": pmc("vu_prepare", "wave_parked_frac"),
                              "update_avg_launch_ms": k3.get("ekf_update_gate", {}).get("avg_ms"),
                              "update_achieved_GBs": k3.get("ekf_update_gate", {}).get("achieved_GBs"),
