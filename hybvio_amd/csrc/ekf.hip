@@ -1186,21 +1186,23 @@ __global__ __launch_bounds__(GATE_THREADS, 2) void ekf_gate_stream_kernel(GateAr
             }
         }
     }
-    // ---- the waves' partial S meet in LDS (ds_add_f64 on the zeroed block: the sums of 4 addends per entry are added in a fixed
-    // order per wave, but the order in which the waves arrive is not fixed -- f64 addition of 4 values differs by < 1 ulp of S) ----
-    {
-        int u = 0;
+    // ---- the waves' partial S meet in LDS in WAVE ORDER (r05: one wave per round, a barrier between the rounds -- with ds_add_f64 in
+    // arrival order, r01 .. r04, two runs could differ by ~1 ulp of S) ----
+    for (int w_turn = 0; w_turn < nwaves; ++w_turn) {
+        if (wave == w_turn) {
+            int u = 0;
 #pragma unroll
-        for (int ct = 0; ct < TI; ct++)
+            for (int ct = 0; ct < TI; ct++)
 #pragma unroll
-            for (int rt = ct; rt < TI; rt++, u++)
+                for (int rt = ct; rt < TI; rt++, u++)
 #pragma unroll
-                for (int q = 0; q < 4; q++) {
-                    const int i = 16 * rt + kq + 4 * q, c = 16 * ct + cl;
-                    if (i < nr && c < nr && i >= c) unsafeAtomicAdd(&T[(size_t)c * R + i], accS[u][q]);
-                }
+                    for (int q = 0; q < 4; q++) {
+                        const int i = 16 * rt + kq + 4 * q, c = 16 * ct + cl;
+                        if (i < nr && c < nr && i >= c) T[(size_t)c * R + i] += accS[u][q];
+                    }
+        }
+        __syncthreads();
     }
-    __syncthreads();
     for (int i = t; i < nr; i += GATE_THREADS) { T[(size_t)i * R + i] += a.rd; T[(size_t)i * R + nr] = a.v[(size_t)b * nr + i]; }
     double *W = Hs, *col = Hs + 256, *red = Hs + 256 + 544;    // H is dead from here on
     __syncthreads();
@@ -1998,7 +2000,9 @@ static int ekf_launch_sparse_gate(Ekf *e, int np, int ncam, const double *Hc_dev
     // LDS: Hc staged [na4][nrp] + [S; v'] (Rs x nr) + the column list. The launch is sized for its longest record; in the big build a
     // record whose padded layout does not fit (84 rows) uses the tight one (nrp = 84, odd Rs) inside the same carve.
     size_t hs = (size_t)na4 * nrp, tt = (size_t)Rs * nr;
-    const size_t cap = (size_t)(big ? 160 : 96) * 1024, ints = sizeof(int) * (size_t)(na_max + 2);
+    // (the gate's turn counters are 32 bytes of STATIC LDS: the dynamic part of the big build ends 64 bytes below the CU's 160 KB)
+    constexpr size_t BIG_CAP = 160 * 1024 - 64;
+    const size_t cap = big ? BIG_CAP : (size_t)96 * 1024, ints = sizeof(int) * (size_t)(na_max + 2);
     if (big && sizeof(double) * (hs + tt) + ints > cap) {
         if (nr > HV_GATE_TIGHT_ROWS) return HV_ERR_UNSUPPORTED;
         hs = (size_t)na4 * HV_GATE_TIGHT_ROWS; tt = (size_t)(nr + 2) * nr;
@@ -2011,7 +2015,7 @@ static int ekf_launch_sparse_gate(Ekf *e, int np, int ncam, const double *Hc_dev
     bool &attr_set = attr_set_dev[c->p.device & 63];
     if (!attr_set) {
         HV_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void *>(ekf_sparse_gate_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
-        HV_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void *>(ekf_sparse_gate_big_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        HV_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void *>(ekf_sparse_gate_big_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)BIG_CAP));
         attr_set = true;
     }
     ScopedKernelTime tm(c, HV_K_EKF_GATE, stream);

@@ -433,6 +433,8 @@ __device__ __forceinline__ void structured_S(const double *P, int N, const int *
 // kernel, ~110 VGPRs); !PIPE: chunks of 10 k-steps, double buffered (the fused prepare + gate kernel, which lives on 128 VGPRs).
 // TIGHT: the staged Hc has nrp = 84 rows per column instead of 16 TI = 96 (the 84-row track of 21 stereo poses: Hc alone is 100 KB; rows
 // nr .. 83 zero); the last row tile reads on into the next column instead of meeting zero padding.
+// (ONE static array for every instantiation of sparse_gate: the two-per-CU build of the fused kernel has 192 bytes of LDS to spare)
+__device__ __forceinline__ int *gate_turn_lds() { __shared__ int turn[8]; return turn; }
 constexpr int HV_GATE_TIGHT_ROWS = 84;     // rows per staged column of the TIGHT layout: 21 stereo poses, the longest track there is
 template <int TI, int NT, bool PIPE, bool TIGHT = false>
 __device__ __forceinline__ double sparse_gate(const double *P, int n, const int *acol, int na, const double *Hs, double *T, int Rs, int nr,
@@ -468,6 +470,9 @@ __device__ __forceinline__ double sparse_gate(const double *P, int n, const int 
     // round-robin over the waves would give those SIMDs twice the matrix work. Slots for 6 waves: 0 1 2 3 4 5 2 3 (SIMDs 0 1 2 3 0 1 2 3),
     // i.e. waves 2 and 3 take every 4th item, the others every 8th.
     constexpr int NCG = TI > 3 ? 2 : 1, CGS = (TI + NCG - 1) / NCG;
+    int *gate_turn = gate_turn_lds();                               // per column tile: the next block J whose partial sums may enter S
+    if (t < 8) gate_turn[t] = 0;
+    lds_barrier();
     const int n_items = nJ * NCG, stride = nwaves == 6 ? ((wave == 2 || wave == 3) ? 4 : 8) : nwaves;
     // second product + LDS accumulation of one item, given G = P(a_J, a) Hc(tile ct)' in the accumulator layout. CT is a compile-time
     // copy of ct: with `if (rt >= ct)` around every MFMA each tile was its own basic block -- LDS read, full wait, MFMA, branch --
@@ -497,15 +502,21 @@ __device__ __forceinline__ double sparse_gate(const double *P, int n, const int 
 #pragma unroll
             for (int r = 0; r < NR; r++) accS[r] = __builtin_amdgcn_mfma_f64_16x16x4f64(ha[v & 1][r], accG[v], accS[r], 0, 0, 0);
         }
-        // the items' partial S meet in LDS (ds_add_f64 on the zeroed matrix; the order in which the waves arrive is not fixed: < 1 ulp of S)
+        // The items' partial S meet in LDS IN THE ORDER OF J (r05): column tile CT receives one contribution per 16-row block J of
+        // P(a, a), from whichever wave that item was dealt to; a turn counter per column tile lets block J in only after block J - 1, so the
+        // sums are formed in one order whatever the waves' timing -- chi2 and the gate status are reproducible to the bit, run to run.
+        // (r03 / r04 added them with ds_add_f64 as the waves arrived: up to ~1 ulp of S between two runs.) Deadlock-free: every wave
+        // takes its items in rising order, an item only ever waits for a lower one. The matrix work is done before the wait.
+        while (__hip_atomic_load(&gate_turn[CT], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != J) __builtin_amdgcn_s_sleep(1);
 #pragma unroll
         for (int r = 0; r < NR; r++) {
 #pragma unroll
             for (int q = 0; q < 4; q++) {
                 const int i = 16 * (CT + r) + kq + 4 * q, c = 16 * CT + cl;
-                if (i < nr && c < nr && i >= c) unsafeAtomicAdd(&T[(size_t)c * Rs + i], accS[r][q]);
+                if (i < nr && c < nr && i >= c) T[(size_t)c * Rs + i] += accS[r][q];
             }
         }
+        if (lane == 0) __hip_atomic_store(&gate_turn[CT], J + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);   // (a wave's LDS writes complete in order)
     };
     // the second products of an item's column tiles CT0 .. CT0 + NCT - 1
     auto finish_group = [&](auto ct0c, auto nctc, int J, const double4v *accG) {

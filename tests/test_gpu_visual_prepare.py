@@ -380,6 +380,52 @@ def test_long_gate_chi2_with_time_shift_cross_covariance(oracle, variant, npose)
         g.close()
 
 
+@pytest.mark.parametrize("variant,npose,B", [("default", 10, 64), ("vu384", 11, 300), ("gate_own_launch", 9, 64), ("default", 21, 64),
+                                             ("long_two_launches", 17, 64)])
+def test_gate_is_reproducible_to_the_bit(oracle, variant, npose, B):
+    """r05: the partial sums of S = Hc P(a, a) Hc' meet in LDS in a fixed order (ekf_device.hpp sparse_gate: a turn counter per column
+    tile; the long build's factor form never used atomics), so chi2 -- and with it the gate status -- is the same bit pattern every time
+    the same track is gated against the same state. r03 / r04 added the waves' contributions as they arrived (ds_add_f64): two runs
+    could differ in the last place. Six repetitions with other work in flight in between."""
+    import torch
+    rng = np.random.default_rng(900 + npose)
+    trail_len = 20
+    T1, T2, means, idx, feat, vel = _random_tracks(oracle, rng, B, trail_len, npose, True, bad_fraction=0.0)
+    y = feat.reshape(B, -1) + 2e-3 * rng.normal(size=(B, feat.shape[1] * 2))
+    vp = capi.vu_default_params(imu_to_camera=T1, second_imu_to_camera=T2)
+    n = 20 + 7 * trail_len
+    with capi.Context(width=64, height=64) as ctx:
+        _apply(ctx, variant)
+        g = capi.EkfBatch(ctx, capi.ekf_default_params(cameraTrailLength=trail_len), B)
+        Ps = []
+        for b in range(B):
+            A = rng.normal(size=(n, n)) * 0.02
+            Ps.append(A @ A.T * 1e-3 + np.eye(n) * 1e-4)
+        dev = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a, dt)).cuda()
+        d_idx, d_feat, d_vel, d_y = dev(idx, np.int32), dev(feat, np.float64), dev(vel, np.float64), dev(y, np.float64)
+        ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+        runs = []
+        busy = torch.zeros(1 << 22, device="cuda")
+        for rep in range(6):
+            for b in range(B):
+                g.set_state(b, means[b], Ps[b])
+            st = torch.full((B, 2), -1, dtype=torch.int32, device="cuda")
+            gs = torch.full((B,), -1, dtype=torch.int32, device="cuda")
+            chi = torch.zeros((B,), dtype=torch.float64, device="cuda")
+            pf = torch.zeros((B, 3), dtype=torch.float64, device="cuda")
+            if rep % 2:
+                busy.add_(1.0)                                   # other work in front: the waves of the gate start on a busier chip
+            # r_gate large: nothing is applied by this call's update half, the state stays what the next repetition needs anyway
+            g.visual_track_dev(vp, npose, d_idx.data_ptr(), d_feat.data_ptr(), d_vel.data_ptr(), d_y.data_ptr(), 1.5, 0.05,
+                               st.data_ptr(), gs.data_ptr(), chi.data_ptr(), pf.data_ptr())
+            torch.cuda.synchronize()
+            runs.append((chi.cpu().numpy().view(np.uint64).copy(), gs.cpu().numpy().copy()))
+        assert (runs[0][1] == 0).sum() + (runs[0][1] == 3).sum() >= B // 2           # gated tracks
+        for chi_bits, gs_ in runs[1:]:
+            assert np.array_equal(chi_bits, runs[0][0]) and np.array_equal(gs_, runs[0][1])
+        g.close()
+
+
 @pytest.mark.parametrize("variant", ["default", "vu384", "dense", "gate_own_launch_vu384"])
 def test_frame_loop_with_the_successful_update_quota(oracle, variant):
     """A frame's visual-update loop for a batch (backend.cpp:1012-1240): K tracks per filter, visited in order, each seeing the
