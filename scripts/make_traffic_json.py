@@ -7,8 +7,8 @@ import json
 import os
 import sys
 
-src = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/prof_r04"
-dst = sys.argv[2] if len(sys.argv) > 2 else "profiles/r04/traffic.json"
+src = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/prof_r05"
+dst = sys.argv[2] if len(sys.argv) > 2 else "profiles/r05/traffic.json"
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench  # noqa: E402
 
@@ -72,8 +72,6 @@ out = {
     "klt_kernel": {
         "fetch_kb_raw": g("klt_kernel", "FETCH_SIZE"), "write_kb": g("klt_kernel", "WRITE_SIZE"),
         "hbm_bytes_per_launch": hbm("klt_kernel"), "algorithmic_bytes_per_launch": alg["klt_call"] * B,
-        # SQ_ACTIVE_INST_VALU counts quad-cycles summed over the 32 SQ instances SQ_BUSY_CYCLES is reported for
-        "valu_busy_frac": frac(g("klt_kernel", "SQ_ACTIVE_INST_VALU"), (g("klt_kernel", "SQ_BUSY_CYCLES") or 0) * 32.0, 4.0),
         "valu_insts_per_feature": frac(g("klt_kernel", "SQ_INSTS_VALU"), B * NPTS),
         "salu_insts_per_feature": frac(g("klt_kernel", "SQ_INSTS_SALU"), B * NPTS),
         "lds_insts_per_feature": frac(g("klt_kernel", "SQ_INSTS_LDS"), B * NPTS),
@@ -95,7 +93,6 @@ out = {
     },
     "vu_gate_kernel_2percu": {
         "hbm_bytes_per_launch": hbm("vu_gate_kernel_2percu"),
-        "valu_busy_frac": frac(g("vu_gate_kernel_2percu", "SQ_ACTIVE_INST_VALU"), (g("vu_gate_kernel_2percu", "SQ_BUSY_CYCLES") or 0) * 32.0, 4.0),
         "mfma_busy_frac": frac(g("vu_gate_kernel_2percu", "SQ_VALU_MFMA_BUSY_CYCLES"), 32.0 * (g("vu_gate_kernel_2percu", "SQ_BUSY_CYCLES") or 0)),
         "wave_parked_frac": frac(g("vu_gate_kernel_2percu", "SQ_WAIT_ANY"), g("vu_gate_kernel_2percu", "SQ_WAVE_CYCLES")),
         "valu_insts_per_track": frac(g("vu_gate_kernel_2percu", "SQ_INSTS_VALU"), B),
@@ -104,7 +101,6 @@ out = {
     },
     "vu_gate_long_kernel": {
         "hbm_bytes_per_launch": hbm("vu_gate_long_kernel"),
-        "valu_busy_frac": frac(g("vu_gate_long_kernel", "SQ_ACTIVE_INST_VALU"), (g("vu_gate_long_kernel", "SQ_BUSY_CYCLES") or 0) * 32.0, 4.0),
         "mfma_busy_frac": frac(g("vu_gate_long_kernel", "SQ_VALU_MFMA_BUSY_CYCLES"), 32.0 * (g("vu_gate_long_kernel", "SQ_BUSY_CYCLES") or 0)),
         "wave_parked_frac": frac(g("vu_gate_long_kernel", "SQ_WAIT_ANY"), g("vu_gate_long_kernel", "SQ_WAVE_CYCLES")),
         "how": "r04: triangulation + prepareVisualUpdate + the chi2 gate on the factors of the Jacobian (structured_S) of the long-track class (12 .. 21 stereo poses) in one launch per visit; ~21 % of the records of a launch are live",
