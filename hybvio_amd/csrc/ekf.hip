@@ -1085,6 +1085,11 @@ __global__ __launch_bounds__(UPD_THREADS) void ekf_update_dual_kernel(UpdatePair
     ekf_update_body<MODE, TI>(a, a.rec_list[j]);
 }
 
+// (r05, measured and dropped: the same grid with a long record's workgroup running block 2 right behind block 1 -- P through L2 in
+// between -- and a second launch that only serves the short records that found no CU: one lane 10.04 / 10.00 -> 10.13 / 10.10 ms per
+// step, four lanes 29.44 / 29.27 -> 29.40 / 29.23: the visit's length is the long records' block-1 -> block-2 chain either way, and two
+// instances of the body cost 12 more spilled VGPRs. profiles/r05/long_blocks_one_launch_ab.txt)
+
 // ---------------------------------------------------------------------------------------------
 // chi2 gate for MANY filters at once (throughput launches): S = H P H' + R without ever holding H P.
 //
