@@ -376,6 +376,7 @@ void hv_destroy(hv_ctx *h)
     if (c->d_gftt_kp) (void)hipFree(c->d_gftt_kp);
     if (c->d_ingest_stage) (void)hipFree(c->d_ingest_stage);
     if (c->d_ransac_stage) (void)hipFree(c->d_ransac_stage);
+    if (c->d_ransac_split) (void)hipFree(c->d_ransac_split);
     for (int k = 0; k < HV_INGEST_CAMERAS; ++k)
         if (c->d_tile_box[k]) (void)hipFree(c->d_tile_box[k]);
     for (int k = 0; k < HV_INGEST_CAMERAS; ++k)

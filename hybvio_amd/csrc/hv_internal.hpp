@@ -72,7 +72,7 @@ struct Knobs {
     int ekf_dual_update = 1;      // HV_EKF_DUAL_UPDATE: 1 = ragged visits issue the short class's update and the long class's first block update as one grid (ekf_update_dual_kernel); 0 = one after the other
     int ekf_visit_order = 1;      // HV_EKF_VISIT_ORDER: 1 = ragged frame loops over more filters than the GPU has CUs hand the fused kernel its records longest track first (one sort launch per frame; the presorted long-class lists also enable ekf_side_stream 2 .. 4); 2 = at every batch size (tests); 0 = in filter order
     int ekf_defer_jacobian = 1;   // HV_EKF_DEFER_JACOBIAN: 1 (r05) = the long class's one-launch build (vu_gate_long_kernel) forms and stores the compact Jacobian Hc = Dp + O4 F4 BEHIND its gate, for inliers only (the update is its only reader); 0 = for every prepared track, in front of the gate (r04)
-    int rot_ransac_threads = 0;   // HV_ROT_RANSAC_THREADS: 0 auto (1024 threads up to 64 sets), 256 / 1024 force
+    int rot_ransac_threads = 0;   // HV_ROT_RANSAC_THREADS: 0 auto (25 workgroups per set while they all get a CU, 1024 threads up to 64 sets, 256 beyond), 25 / 256 / 1024 force
 };
 int knob_set(Knobs &k, const char *name, int value);   // HV_ERR_INVALID for an unknown name
 int knob_get(const Knobs &k, const char *name, int *value);
@@ -112,6 +112,8 @@ struct Ctx {
     size_t ingest_stage_bytes = 0;
     unsigned char *d_ransac_stage = nullptr;   // staging of the host-pointer rotation-RANSAC entry (f4)
     size_t ransac_stage_bytes = 0;
+    unsigned char *d_ransac_split = nullptr;   // records of the split rotation-RANSAC launches (rot_ransac.hip), ransac_split_sets of them
+    int ransac_split_sets = 0;
     std::string last_error;
     bool profiling = false;
     KernelTimer timers[HV_K_COUNT];

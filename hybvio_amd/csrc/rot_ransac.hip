@@ -23,6 +23,14 @@ constexpr int RT_MANY = 256;           // workgroup size with many frames in fli
 constexpr int RT_FEW = 1024;           // a handful of frames: the 20 000 (point, hypothesis) tests of ONE frame spread 4x wider (91 -> ~30 us)
 constexpr int MAX_PTS = 1024;
 constexpr int HYP = 100;              // ROT_RANSAC_MAX_ITERS (rot_ransac.cpp:6)
+// r05, a single sequence's frame (<= num_cus / RT_SPLIT_GROUPS sets in flight): the hypotheses of ONE set spread over RT_SPLIT_GROUPS
+// workgroups -- each forms the rays of every point (cheap) and counts the inliers of its own HYP / RT_SPLIT_GROUPS hypotheses (the 20 000
+// point x hypothesis tests are what a lone workgroup spends its time on); counts, validity and rotations meet in a small global record
+// and the workgroup that arrives last (a ticket) runs the reference loop's bookkeeping, the refit and the final classification.
+// Integer counts and the same rotations: the results are the lone workgroup's, bit for bit.
+constexpr int RT_SPLIT_GROUPS = 25, RT_SPLIT = 256;
+static_assert(HYP % RT_SPLIT_GROUPS == 0, "whole groups of hypotheses");
+constexpr size_t SPLIT_REC_BYTES = sizeof(int) * (2 * HYP + 4) + sizeof(float) * 9 * HYP;   // per set: counts, valid, ticket (+pad), rotations
 
 struct RansacArgs {
     int max_points;
@@ -36,6 +44,7 @@ struct RansacArgs {
     int *status;                      // [sets][max_points]: 0 TRACKED / 3 RANSAC_OUTLIER
     float *R;                         // [sets][9]
     int *summary;                     // [sets][2]: bestInlierCount, hypotheses visited by the reference loop
+    unsigned char *split;             // split launches: [sets] records of SPLIT_REC_BYTES (tickets zero between launches)
     hv_camera_model cam1, cam2;
 };
 
@@ -256,9 +265,10 @@ __device__ bool inlier(const float *R, const float *p1, float c2x, float c2y, co
     return dx * dx + dy * dy <= thr;
 }
 
-template <int RT>
+template <int RT, int NG = 1>
 __global__ __launch_bounds__(RT) void rot_ransac_kernel(RansacArgs a)
 {
+    constexpr int HPG = HYP / NG;                 // hypotheses of this workgroup: k_lo .. k_lo + HPG - 1
     __shared__ float s_p1[MAX_PTS * 3], s_p2[MAX_PTS * 3], s_c2[MAX_PTS * 2];
     __shared__ float s_R[HYP * 9];
     __shared__ int s_count[HYP], s_valid[HYP];
@@ -267,7 +277,8 @@ __global__ __launch_bounds__(RT) void rot_ransac_kernel(RansacArgs a)
     __shared__ int s_best[4];
     __shared__ unsigned short s_map[MAX_PTS];     // compacted index -> original feature number
     __shared__ int s_chunk[MAX_PTS / 64 + 1];
-    const int set = blockIdx.x, tid = threadIdx.x;
+    const int set = NG > 1 ? blockIdx.y : blockIdx.x, tid = threadIdx.x;
+    const int k_lo = NG > 1 ? (int)blockIdx.x * HPG : 0;
     const int n_all = min(max(a.n_points[set], 0), a.max_points);      // a device-supplied count never indexes past the set's arrays
     const float *c1 = a.c1 + (size_t)set * a.max_points * 2, *c2 = a.c2 + (size_t)set * a.max_points * 2;
     int *status = a.status + (size_t)set * a.max_points;
@@ -301,7 +312,7 @@ __global__ __launch_bounds__(RT) void rot_ransac_kernel(RansacArgs a)
     }
     __syncthreads();
     if (n < 2) {                                                             // ransac_pipeline.cpp:209: nothing to fit
-        if (tid == 0) { a.summary[2 * set] = 0; a.summary[2 * set + 1] = 0; }
+        if (tid == 0 && k_lo == 0) { a.summary[2 * set] = 0; a.summary[2 * set + 1] = 0; }
         return;
     }
     const double thr = (double)a.threshold_pow2;
@@ -318,17 +329,18 @@ __global__ __launch_bounds__(RT) void rot_ransac_kernel(RansacArgs a)
     if (tid < HYP) s_count[tid] = 0;
     __syncthreads();
     // ---- hypothesis k: the rotation of its two pairs (:80-87) ----
-    if (tid < HYP) {
+    if (tid < HPG) {
+        const int hk = k_lo + tid;
         int i1, i2;
         if (a.draws) {                                                       // rng() % n (rot_ransac.cpp:82-83), n known only here
-            i1 = (int)(a.draws[((size_t)set * HYP + tid) * 2] % (uint32_t)n);
-            i2 = (int)(a.draws[((size_t)set * HYP + tid) * 2 + 1] % (uint32_t)n);
+            i1 = (int)(a.draws[((size_t)set * HYP + hk) * 2] % (uint32_t)n);
+            i2 = (int)(a.draws[((size_t)set * HYP + hk) * 2 + 1] % (uint32_t)n);
         } else {
-            i1 = a.pairs[((size_t)set * HYP + tid) * 2]; i2 = a.pairs[((size_t)set * HYP + tid) * 2 + 1];
+            i1 = a.pairs[((size_t)set * HYP + hk) * 2]; i2 = a.pairs[((size_t)set * HYP + hk) * 2 + 1];
         }
         // caller-supplied index pairs outside [0, n) make the hypothesis invalid instead of reading outside the set
         const int ok = i1 != i2 && (unsigned)i1 < (unsigned)n && (unsigned)i2 < (unsigned)n;
-        s_valid[tid] = ok;
+        s_valid[hk] = ok;
         if (ok) {
             float H[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, R[9];
 #pragma unroll
@@ -341,16 +353,39 @@ __global__ __launch_bounds__(RT) void rot_ransac_kernel(RansacArgs a)
             }
             kabsch_rotation(H, R);
 #pragma unroll
-            for (int k = 0; k < 9; ++k) s_R[9 * tid + k] = R[k];
+            for (int k = 0; k < 9; ++k) s_R[9 * hk + k] = R[k];
         }
     }
     __syncthreads();
     // ---- inlier counts of every hypothesis (:90-97): (point, hypothesis) pairs over the threads ----
-    for (int w = tid; w < n * HYP; w += RT) {
-        const int k = w / n, i = w - k * n;                                   // consecutive lanes: consecutive points of one hypothesis
+    for (int w = tid; w < n * HPG; w += RT) {
+        const int kk = w / n, i = w - kk * n, k = k_lo + kk;                  // consecutive lanes: consecutive points of one hypothesis
         if (s_valid[k] && inlier(s_R + 9 * k, s_p1 + 3 * i, s_c2[2 * i], s_c2[2 * i + 1], a.cam2, thr)) atomicAdd(&s_count[k], 1);
     }
     __syncthreads();
+    if constexpr (NG > 1) {
+        // this workgroup's hypotheses go to the set's record; the last workgroup to arrive collects all of them and carries on alone
+        int *rec_i = reinterpret_cast<int *>(a.split + (size_t)set * SPLIT_REC_BYTES);
+        float *rec_R = reinterpret_cast<float *>(rec_i + 2 * HYP + 4);
+        if (tid < HPG) {
+            rec_i[k_lo + tid] = s_count[k_lo + tid];
+            rec_i[HYP + k_lo + tid] = s_valid[k_lo + tid];
+        }
+        for (int i = tid; i < 9 * HPG; i += RT) rec_R[9 * k_lo + i] = s_valid[k_lo + i / 9] ? s_R[9 * k_lo + i] : 0.0f;
+        __threadfence();                                                      // (every writer: its stores are visible device-wide before the ticket)
+        __syncthreads();
+        if (tid == 0) s_best[3] = atomicAdd(&rec_i[2 * HYP], 1);
+        __syncthreads();
+        if (s_best[3] != NG - 1) return;
+        __threadfence();
+        if (tid < HYP) {
+            s_count[tid] = __hip_atomic_load(&rec_i[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            s_valid[tid] = __hip_atomic_load(&rec_i[HYP + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        for (int i = tid; i < 9 * HYP; i += RT) s_R[i] = __hip_atomic_load(&rec_R[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (tid == 0) rec_i[2 * HYP] = 0;                                     // the ticket counter is ready for the next launch
+        __syncthreads();
+    }
     // ---- the loop's bookkeeping (:99-104): first maximum, stop after the first hypothesis with every point an inlier ----
     if (tid == 0) {
         int best = 0, bk = -1, visited = HYP;
@@ -466,6 +501,35 @@ int hv_camera_model_init(hv_camera_model *m)
     return HV_OK;
 }
 
+namespace hv { namespace {
+// knob rot_ransac_threads (tests only): 256 / 1024 force the many-frames / the few-frames instantiation at any batch size, 25 the
+// split form (RT_SPLIT_GROUPS workgroups per set); auto: split while every workgroup of the launch gets a CU of its own, 1024 threads
+// up to 64 sets, 256 beyond
+int launch_rot_ransac(Ctx *c, int n_sets, RansacArgs &a)
+{
+    const int rt_forced = c->knob.rot_ransac_threads;
+    const bool split = rt_forced == RT_SPLIT_GROUPS || (rt_forced == 0 && n_sets * RT_SPLIT_GROUPS <= c->num_cus);
+    if (split) {
+        if (c->ransac_split_sets < n_sets) {                     // (first use of a batch size: not inside a stream capture)
+            HV_HIP(c, hipStreamSynchronize(c->stream));
+            if (c->d_ransac_split) (void)hipFree(c->d_ransac_split);
+            c->d_ransac_split = nullptr; c->ransac_split_sets = 0;
+            const int sets = n_sets < 16 ? 16 : n_sets;
+            HV_HIP(c, hipMalloc(reinterpret_cast<void **>(&c->d_ransac_split), SPLIT_REC_BYTES * (size_t)sets));
+            HV_HIP(c, hipMemsetAsync(c->d_ransac_split, 0, SPLIT_REC_BYTES * (size_t)sets, c->stream));
+            c->ransac_split_sets = sets;
+        }
+        a.split = c->d_ransac_split;
+        hipLaunchKernelGGL((rot_ransac_kernel<RT_SPLIT, RT_SPLIT_GROUPS>), dim3(RT_SPLIT_GROUPS, (unsigned)n_sets), dim3(RT_SPLIT), 0, c->stream, a);
+    } else if (rt_forced == RT_FEW || (rt_forced != RT_MANY && n_sets <= 64))
+        hipLaunchKernelGGL((rot_ransac_kernel<RT_FEW>), dim3((unsigned)n_sets), dim3(RT_FEW), 0, c->stream, a);
+    else
+        hipLaunchKernelGGL((rot_ransac_kernel<RT_MANY>), dim3((unsigned)n_sets), dim3(RT_MANY), 0, c->stream, a);
+    HV_HIP(c, hipGetLastError());
+    return HV_OK;
+}
+} }
+
 int hv_rot_ransac_batch_dev(hv_ctx *h, int n_sets, int max_points, const int *n_points_dev, const float *c1_dev, const float *c2_dev,
                             const hv_camera_model *cam1, const hv_camera_model *cam2, const int *pairs_dev, float threshold_pow2,
                             int *status_dev, float *R_dev, int *summary_dev)
@@ -479,13 +543,7 @@ int hv_rot_ransac_batch_dev(hv_ctx *h, int n_sets, int max_points, const int *n_
     a.threshold_pow2 = threshold_pow2; a.status = status_dev; a.R = R_dev; a.summary = summary_dev;
     a.cam1 = *cam1; a.cam2 = *cam2;
     hv::ScopedKernelTime tm(c, HV_K_ROT_RANSAC);
-    // knob rot_ransac_threads (tests only): 256 / 1024 force the many-frames / the few-frames instantiation at any batch size
-    const int rt_forced = c->knob.rot_ransac_threads;
-    if (rt_forced == hv::RT_FEW || (rt_forced != hv::RT_MANY && n_sets <= 64))
-        hipLaunchKernelGGL(hv::rot_ransac_kernel<hv::RT_FEW>, dim3((unsigned)n_sets), dim3(hv::RT_FEW), 0, c->stream, a);
-    else              hipLaunchKernelGGL(hv::rot_ransac_kernel<hv::RT_MANY>, dim3((unsigned)n_sets), dim3(hv::RT_MANY), 0, c->stream, a);
-    HV_HIP(c, hipGetLastError());
-    return HV_OK;
+    return hv::launch_rot_ransac(c, n_sets, a);
 }
 
 int hv_rot_ransac_lk_batch_dev(hv_ctx *h, int n_sets, int max_points, const int *n_points_dev, const float *c1_dev, const float *c2_dev,
@@ -504,13 +562,7 @@ int hv_rot_ransac_lk_batch_dev(hv_ctx *h, int n_sets, int max_points, const int 
     a.threshold_pow2 = threshold_pow2; a.status = status_dev; a.R = R_dev; a.summary = summary_dev;
     a.cam1 = *cam1; a.cam2 = *cam2;
     hv::ScopedKernelTime tm(c, HV_K_ROT_RANSAC);
-    // knob rot_ransac_threads (tests only): 256 / 1024 force the many-frames / the few-frames instantiation at any batch size
-    const int rt_forced = c->knob.rot_ransac_threads;
-    if (rt_forced == hv::RT_FEW || (rt_forced != hv::RT_MANY && n_sets <= 64))
-        hipLaunchKernelGGL(hv::rot_ransac_kernel<hv::RT_FEW>, dim3((unsigned)n_sets), dim3(hv::RT_FEW), 0, c->stream, a);
-    else              hipLaunchKernelGGL(hv::rot_ransac_kernel<hv::RT_MANY>, dim3((unsigned)n_sets), dim3(hv::RT_MANY), 0, c->stream, a);
-    HV_HIP(c, hipGetLastError());
-    return HV_OK;
+    return hv::launch_rot_ransac(c, n_sets, a);
 }
 
 int hv_rot_ransac(hv_ctx *h, int n, const float *c1, const float *c2, const hv_camera_model *cam1, const hv_camera_model *cam2,

@@ -70,7 +70,7 @@ def test_pyramids_and_lk_over_640_slots_and_320_pairs(oracle):
         assert 0 < lost < D * NPTS // 4
 
 
-@pytest.mark.parametrize("n_sets,threads", [(80, 0), (80, 1024), (7, 256), (300, 0)])
+@pytest.mark.parametrize("n_sets,threads", [(80, 0), (80, 1024), (7, 256), (300, 0), (80, 25)])       # 25: the split form, 2000 workgroups
 def test_rot_ransac_both_instantiations(oracle, n_sets, threads):
     """rot_ransac_kernel<256> (what more than 64 sets -- the benchmark's 1024 -- run) and <1024>, each forced at both batch sizes."""
     import torch

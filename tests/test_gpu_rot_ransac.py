@@ -64,16 +64,22 @@ def test_camera_model_init_matches_the_oracle_models(oracle):
         capi.camera_model("pinhole", 400.0, 400.0, 300.0, 200.0, coeffs=[0.1, 0.2])          # camera.cpp:163: 3 coefficients or none
 
 
+# knob rot_ransac_threads: 0 = auto (a single set: the split form, 25 workgroups per set, r05), 1024 / 256 = one workgroup per set
+@pytest.mark.parametrize("threads", [0, 1024, 256])
 @pytest.mark.parametrize("kind", ["pinhole", "plain", "rotated"])
 @pytest.mark.parametrize("n,outliers", [(200, 40), (400, 150), (37, 5), (2, 0), (3, 1), (1000, 300)])
-def test_fit_bit_exact_pinhole(oracle, kind, n, outliers):
+def test_fit_bit_exact_pinhole(oracle, kind, n, outliers, threads):
     ocam, gcam = _cams(oracle, kind)
     rng = np.random.default_rng(n + outliers)
     c1, c2 = _scene(ocam, rng, n, outliers)
     draws = oracle.mt19937_draws(4649, 200, skip=7 * n)
     st_o, R_o, best_o, used_o = oracle.rot_ransac_fit(c1, c2, ocam, ocam, draws, THR)
     with capi.Context(width=752, height=480) as ctx:
+        ctx.set_knob("rot_ransac_threads", threads)
         st, R, best, visited = ctx.rot_ransac(c1, c2, gcam, gcam, _pairs(draws, n), THR)
+        if threads == 0:                                     # the split form's ticket counters are back at zero: a second call gives the same
+            st2, R2, best2, visited2 = ctx.rot_ransac(c1, c2, gcam, gcam, _pairs(draws, n), THR)
+            assert np.array_equal(st2, st) and np.array_equal(R2.view(np.uint32), R.view(np.uint32)) and (best2, visited2) == (best, visited)
     assert np.array_equal(st, st_o) and best == best_o and 2 * visited == used_o
     assert np.array_equal(R.view(np.uint32), R_o.view(np.uint32))
     if n > 10:
@@ -116,7 +122,8 @@ def test_control_flow_early_exit_repeated_indices_and_different_cameras(oracle):
         assert np.array_equal(st, st_o) and best == best_o and np.array_equal(R.view(np.uint32), R_o.view(np.uint32))
 
 
-def test_batch_dev_ragged_sets(oracle):
+@pytest.mark.parametrize("threads", [0, 25, 1024])          # 7 sets: auto = the split form (175 workgroups on 256 CUs)
+def test_batch_dev_ragged_sets(oracle, threads):
     import torch
     ocam, gcam = _cams(oracle, "pinhole")
     rng = np.random.default_rng(21)
@@ -139,9 +146,12 @@ def test_batch_dev_ragged_sets(oracle):
         st = torch.full((S, M), -5, dtype=torch.int32, device="cuda")
         R = torch.zeros((S, 9), dtype=torch.float32, device="cuda"); summ = torch.full((S, 2), -1, dtype=torch.int32, device="cuda")
         ctx.set_stream(torch.cuda.current_stream().cuda_stream)
-        ctx.rot_ransac_batch_dev(S, M, d_n.data_ptr(), d_c1.data_ptr(), d_c2.data_ptr(), gcam, gcam, d_pairs.data_ptr(), THR,
-                                 st.data_ptr(), R.data_ptr(), summ.data_ptr())
-        torch.cuda.synchronize()
+        ctx.set_knob("rot_ransac_threads", threads)
+        for rep in range(2):                                    # (twice: the split form leaves its ticket counters at zero)
+            st.fill_(-5)
+            ctx.rot_ransac_batch_dev(S, M, d_n.data_ptr(), d_c1.data_ptr(), d_c2.data_ptr(), gcam, gcam, d_pairs.data_ptr(), THR,
+                                     st.data_ptr(), R.data_ptr(), summ.data_ptr())
+            torch.cuda.synchronize()
         st, R, summ = st.cpu().numpy(), R.cpu().numpy(), summ.cpu().numpy()
     for s, n in enumerate(sizes):
         if ref[s] is None:
