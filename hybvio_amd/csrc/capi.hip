@@ -19,6 +19,7 @@ const KnobEntry KNOB_TABLE[] = {
     {"ekf_gate_kmode", &Knobs::ekf_gate_kmode}, {"ingest_gather", &Knobs::ingest_gather},
     {"ekf_fused_gate", &Knobs::ekf_fused_gate}, {"ekf_spec_mode", &Knobs::ekf_spec_mode},
     {"rot_ransac_threads", &Knobs::rot_ransac_threads}, {"ekf_side_stream", &Knobs::ekf_side_stream}, {"ekf_dual_update", &Knobs::ekf_dual_update}, {"ekf_long_fused", &Knobs::ekf_long_fused}, {"ekf_long_first", &Knobs::ekf_long_first}, {"ekf_visit_order", &Knobs::ekf_visit_order},
+    {"ekf_split_tri", &Knobs::ekf_split_tri},
 };
 }  // namespace
 
@@ -317,6 +318,7 @@ static int create_ctx(const hv_params *params, int high_priority, hv_ctx **out)
         for (int s = p.pool_size - 1; s >= 0; --s) c->free_slots.push_back(s);
         rc = hv::ensure_point_staging(c, p.max_tracks);
         if (rc == HV_OK) rc = hv::fill_gradient_borders(c, 0, p.pool_size);
+        if (rc == HV_OK) rc = hv::rot_ransac_alloc_split(c);     // (r05 advisor: once, here -- never inside a launch that may be under capture)
     } while (0);
     if (rc != HV_OK) { hv_destroy(h); return rc; }
     *out = h;

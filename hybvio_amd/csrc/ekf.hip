@@ -1732,6 +1732,7 @@ struct Ekf {
     unsigned char *side_active = nullptr;
     int side_rows = 0;
     int *side_acol = nullptr; double *side_dm = nullptr;
+    double *tri_rec = nullptr; int tri_stride = 0;        // factor records of vu_tri_kernel (split form of a visit, r06): [batch][tri_stride]
     int *err_dev = nullptr;                               // device error word (UpdateArgs::err)
     double *bH = nullptr, *bv = nullptr; int *brows = nullptr; unsigned char *bany = nullptr; int b_rows = 0;   // batchVisualUpdate: stacked [H; v], rows, flags
     double *gate_scale = nullptr;                         // [batch] per-filter multiplier of the outlier thresholds inside a frame loop (backend.cpp:1192-1193)
@@ -2061,7 +2062,7 @@ void hv_ekf_destroy(hv_ekf *h)
     void *ptrs[] = { e->m, e->P, e->P1, e->m1, e->Q, e->dydx, e->ws, e->sH, e->sv, e->sr, e->schi2, e->simu,
                      e->sstatus, e->sdrop, e->sactive, e->vuH, e->vuv, e->vupf, e->vuactive, e->vustage,
                      e->spH, e->spv, e->sppf, e->spactive, e->spcursor, e->spepoch, e->spcursor2, e->sppub, e->vurows, e->sprows,
-                     e->vuacol, e->spacol, e->err_dev, e->gate_scale, e->bH, e->bv, e->brows, e->bany, e->sideH, e->sidev, e->side_active, e->side_acol, e->side_dm, e->visit_counts, e->visit_lists, e->visit_order, e->visit_long, e->visit_long_count };
+                     e->vuacol, e->spacol, e->err_dev, e->gate_scale, e->bH, e->bv, e->brows, e->bany, e->sideH, e->sidev, e->side_active, e->side_acol, e->side_dm, e->tri_rec, e->visit_counts, e->visit_lists, e->visit_order, e->visit_long, e->visit_long_count };
     for (void *p : ptrs) if (p) (void)hipFree(p);
     if (e->c && e->c->aux_stream) (void)hipStreamSynchronize(e->c->aux_stream);
     if (e->ev_fork) (void)hipEventDestroy(e->ev_fork);
@@ -2349,6 +2350,31 @@ static int visual_track_dev_impl(hv_ekf *h, const hv_vu_params *p, int np, const
         }
         return HV_OK;
     };
+    // factor records of the split form (knob ekf_split_tri, r06): vu_tri_kernel -> record -> record-fed gate
+    auto ensure_tri = [&]() -> int {
+        const int stride = hv::vu_tri_rec_stride(np, ncam);
+        if (e->tri_stride >= stride) return HV_OK;
+        HV_HIP(c, hipStreamSynchronize(main_stream));
+        if (c->aux_stream) HV_HIP(c, hipStreamSynchronize(c->aux_stream));
+        if (e->tri_rec) (void)hipFree(e->tri_rec);
+        e->tri_rec = nullptr; e->tri_stride = 0;
+        HV_HIP(c, hipMalloc(reinterpret_cast<void **>(&e->tri_rec), sizeof(double) * (size_t)stride * e->batch));
+        e->tri_stride = stride;
+        return HV_OK;
+    };
+    // the gate launch `g` of one length class in split form: the triangulation front first, on the same stream; false = not a shape
+    // the split form serves (the caller issues the fused launch)
+    auto split_launch = [&](hv::VuPrepareArgs &g, hipStream_t stream, int *rc_out) -> bool {
+        if (!hv::vu_split_supported(c, g, g.fused)) return false;
+        int rc2 = ensure_tri();
+        if (rc2 == HV_OK) {
+            g.tri_rec = e->tri_rec; g.tri_stride = e->tri_stride;
+            rc2 = hv::launch_vu_tri(c, g, stream);
+        }
+        if (rc2 == HV_OK) { g.from_rec = 1; rc2 = hv::launch_vu_prepare(c, g, stream); }
+        *rc_out = rc2;
+        return true;
+    };
     // prepare + gate of the long class on `stream` (nothing else touches c->stream: r03 swapped the context's stream for these calls)
     auto long_prepare_gate = [&](hv::VuPrepareArgs l_, double *Hc, double *vv, int *acol, unsigned char *act, bool listed, hipStream_t stream) -> int {
         l_.H = nullptr; l_.Hc = Hc; l_.v = vv; l_.acol = acol; l_.na_max = 7 * np + 1; l_.active = act; l_.chi2 = chi2_dev;
@@ -2358,6 +2384,8 @@ static int visual_track_dev_impl(hv_ekf *h, const hv_vu_params *p, int np, const
         if (c->knob.ekf_long_fused != 0) {
             l_.fused = 3; l_.P = e->P; l_.rd_gate = r_gate * r_gate * ns; l_.noise_scale = ns;
             l_.inl_count = cnt_inl_long; l_.inl_list = list_inl_long;
+            int rc_s = HV_OK;
+            if (split_launch(l_, stream, &rc_s)) return rc_s;
             return hv::launch_vu_prepare(c, l_, stream);
         }
         l_.fused = 2;
@@ -2447,7 +2475,7 @@ static int visual_track_dev_impl(hv_ekf *h, const hv_vu_params *p, int np, const
         hipStream_t long_stream = forked && !swap ? c->aux_stream : main_stream, short_stream = swap ? c->aux_stream : main_stream;
         const bool long_first = presorted && (forked || c->knob.ekf_long_first != 0);
         if (long_first) rc = long_prepare_gate(l_, e->sideH, e->sidev, e->side_acol, e->side_active, true, long_stream);
-        if (rc == HV_OK) rc = hv::launch_vu_prepare(c, s_, short_stream);
+        if (rc == HV_OK) { int rc_s = HV_OK; rc = split_launch(s_, short_stream, &rc_s) ? rc_s : hv::launch_vu_prepare(c, s_, short_stream); }
         if (rc == HV_OK && !long_first) rc = long_prepare_gate(l_, e->sideH, e->sidev, e->side_acol, e->side_active, true, main_stream);
         if (forked) {
             hipError_t he = hipEventRecord(e->ev_join, c->aux_stream);

@@ -72,6 +72,7 @@ struct Knobs {
     int ekf_dual_update = 1;      // HV_EKF_DUAL_UPDATE: 1 = ragged visits issue the short class's update and the long class's first block update as one grid (ekf_update_dual_kernel); 0 = one after the other
     int ekf_visit_order = 1;      // HV_EKF_VISIT_ORDER: 1 = ragged frame loops over more filters than the GPU has CUs hand the fused kernel its records longest track first (one sort launch per frame; the presorted long-class lists also enable ekf_side_stream 2 .. 4); 2 = at every batch size (tests); 0 = in filter order
     int ekf_defer_jacobian = 1;   // HV_EKF_DEFER_JACOBIAN: 1 (r05) = the long class's one-launch build (vu_gate_long_kernel) forms and stores the compact Jacobian Hc = Dp + O4 F4 BEHIND its gate, for inliers only (the update is its only reader); 0 = for every prepared track, in front of the gate (r04)
+    int ekf_split_tri = 1;        // HV_EKF_SPLIT_TRI: 1 (r06) = ragged two-class visits run the triangulation front as its own launch (vu_tri_kernel: a wavefront per short track, four per long track) and the gates from its factor records (three short-class gates per CU instead of two fused workgroups); 0 = r03 .. r05's fused prepare + gate kernels
     int rot_ransac_threads = 0;   // HV_ROT_RANSAC_THREADS: 0 auto (25 workgroups per set while they all get a CU, 1024 threads up to 64 sets, 256 beyond), 25 / 256 / 1024 force
 };
 int knob_set(Knobs &k, const char *name, int value);   // HV_ERR_INVALID for an unknown name
@@ -197,7 +198,17 @@ struct VuPrepareArgs {
     // by `growth`. rmse_thr < 0: no RMSE test (ekf.cpp:797-801)
     double *gate_scale; double growth, rmse_thr;
     double *chi2;                      // optional [records]
+    // split form (r06, knob ekf_split_tri): vu_tri_kernel -- one wavefront (short class) or four (long class) per track -- runs the
+    // triangulation and the per-pose part of prepareVisualUpdate and leaves a FACTOR RECORD per track in HBM / L2 (tri_rec, tri_stride
+    // doubles per record: [nt_max][17] per-pose values, [np][21] summed point derivatives, the time-shift column, prep status); the
+    // gate kernels launched with from_rec = 1 start from that record instead of running the front themselves, in a third of the LDS
+    double *tri_rec; int tri_stride; int from_rec;
 };
+// doubles per factor record of vu_tri_kernel for tracks of up to np poses on ncam cameras
+inline int vu_tri_rec_stride(int np, int ncam) { return 17 * np * ncam + 21 * np + 4; }
+int rot_ransac_alloc_split(Ctx *c);     // rot_ransac.hip: the split form's record buffer, allocated and zeroed once per context
+int launch_vu_tri(Ctx *c, const VuPrepareArgs &a, hipStream_t stream = nullptr);       // the triangulation front of the split form
+bool vu_split_supported(const Ctx *c, const VuPrepareArgs &a, int fused);              // shapes the record-fed gate builds serve
 int launch_vu_prepare(Ctx *c, const VuPrepareArgs &a, hipStream_t stream = nullptr);   // stream: null = the context's
 // order[v][0 .. batch): the filters of visit v sorted by descending pose count among those with np_lo <= np_rec <= np_hi (the others last);
 // long_list[v][0 .. long_count[v]) (optional): those with np_hi < np_rec <= np_max, longest first

@@ -14,6 +14,7 @@
 // model; the fisheye model calls sin / cos / acos, whose last bit may differ from the host's libm.
 #include "hv_internal.hpp"
 
+#include <algorithm>
 #include <cmath>
 
 namespace hv {
@@ -445,6 +446,18 @@ __global__ __launch_bounds__(RT) void rot_ransac_kernel(RansacArgs a)
 
 using hv::Ctx;
 
+namespace hv {
+int rot_ransac_alloc_split(Ctx *c)
+{
+    if (c->d_ransac_split) return HV_OK;
+    const int sets = std::max(16, c->num_cus / RT_SPLIT_GROUPS);       // every set count the auto rule sends to the split form
+    if (hipMalloc(reinterpret_cast<void **>(&c->d_ransac_split), SPLIT_REC_BYTES * (size_t)sets) != hipSuccess) return HV_ERR_NOMEM;
+    HV_HIP(c, hipMemsetAsync(c->d_ransac_split, 0, SPLIT_REC_BYTES * (size_t)sets, c->stream));
+    c->ransac_split_sets = sets;
+    return HV_OK;
+}
+}  // namespace hv
+
 extern "C" {
 
 // CameraBase / PinholeCamera / FisheyeCamera constructors (camera.cpp:24-36,152-167,318-351): the derived fields
@@ -508,17 +521,11 @@ namespace hv { namespace {
 int launch_rot_ransac(Ctx *c, int n_sets, RansacArgs &a)
 {
     const int rt_forced = c->knob.rot_ransac_threads;
-    const bool split = rt_forced == RT_SPLIT_GROUPS || (rt_forced == 0 && n_sets * RT_SPLIT_GROUPS <= c->num_cus);
+    // the split form's records exist once per context (rot_ransac_alloc_split, hv_create): a launch with more sets than they hold --
+    // only the forced knob can ask for that -- takes the 1024-thread form instead of allocating in the launch path (r05 advisor: a
+    // synchronise / free / malloc here would invalidate a stream capture)
+    const bool split = (rt_forced == RT_SPLIT_GROUPS || (rt_forced == 0 && n_sets * RT_SPLIT_GROUPS <= c->num_cus)) && n_sets <= c->ransac_split_sets;
     if (split) {
-        if (c->ransac_split_sets < n_sets) {                     // (first use of a batch size: not inside a stream capture)
-            HV_HIP(c, hipStreamSynchronize(c->stream));
-            if (c->d_ransac_split) (void)hipFree(c->d_ransac_split);
-            c->d_ransac_split = nullptr; c->ransac_split_sets = 0;
-            const int sets = n_sets < 16 ? 16 : n_sets;
-            HV_HIP(c, hipMalloc(reinterpret_cast<void **>(&c->d_ransac_split), SPLIT_REC_BYTES * (size_t)sets));
-            HV_HIP(c, hipMemsetAsync(c->d_ransac_split, 0, SPLIT_REC_BYTES * (size_t)sets, c->stream));
-            c->ransac_split_sets = sets;
-        }
         a.split = c->d_ransac_split;
         hipLaunchKernelGGL((rot_ransac_kernel<RT_SPLIT, RT_SPLIT_GROUPS>), dim3(RT_SPLIT_GROUPS, (unsigned)n_sets), dim3(RT_SPLIT), 0, c->stream, a);
     } else if (rt_forced == RT_FEW || (rt_forced != RT_MANY && n_sets <= 64))

@@ -141,7 +141,9 @@ __device__ __forceinline__ double norm1_3(const double *M)
 // One (pose, column) pair of the derivative sums (triangulation.cpp:264-311): given dh (the change of h), dC and dt
 // (the change of C and t; zero unless HEAVY) it adds dEblock' * error + Eblock' * dErrorBlock to dEe and
 // dEblock' * Eblock + Eblock' * dEblock to dM. o = the pose record of this iteration (C t h E err d).
-template <bool HEAVY>
+// MODE 0: dC = dt = 0 (the plain part); 1: both given (false / true of r01 .. r05's bool parameter); 2 (r06): dt only -- a position
+// component moves t of the pose and leaves C alone
+template <int MODE>
 __device__ __forceinline__ void pair_sums(const double *o, const double *dh, const double *dC, const double *dt, double vel0,
                                           double vel1, double *dEe, double *dM)
 {
@@ -156,10 +158,10 @@ __device__ __forceinline__ void pair_sums(const double *o, const double *dh, con
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
             dE[3 * r + c] = -dih2 * C[3 * r + c] + g * C[6 + c];
-            if (HEAVY) dE[3 * r + c] += -ih2 * dC[3 * r + c] + h[r] * ih2sq * dC[6 + c];
+            if (MODE == 1) dE[3 * r + c] += -ih2 * dC[3 * r + c] + h[r] * ih2sq * dC[6 + c];
         }
         dE[3 * r + 2] = -t[r] * dih2 + g * t[2];
-        if (HEAVY) dE[3 * r + 2] += -dt[r] * ih2 + h[r] * ih2sq * dt[2];
+        if (MODE != 0) dE[3 * r + 2] += -dt[r] * ih2 + h[r] * ih2sq * dt[2];
     }
 #pragma unroll
     for (int r = 0; r < 3; ++r) {
@@ -227,6 +229,26 @@ struct VuLds {
 };
 static_assert(VuLds<42, true>::BYTES <= 160 * 1024, "the long build must fit one CU's LDS");
 
+// LDS layout of the RECORD-FED gate builds (r06, VuPrepareArgs::from_rec): the front has run in vu_tri_kernel, so only the gate's own
+// areas are left -- [S; v'] in [0, P0), the staged Jacobian / the factors and their products behind it -- and the record's copies (the
+// per-pose values, features, dpf, the time-shift column) alias the front of [S; v']: they are dead before T is zeroed. Short class:
+// 48 KB instead of 80, THREE workgroups per CU.
+template <int MAXP, bool LONG = false>
+struct VuRecLds {
+    static constexpr int MAXC = MAXP * 7 + 1, MOT_STRIDE = 13;
+    static constexpr int LONG_T = 7224, LONG_HS = 12432;
+    static constexpr int TRAIL = 0, IT = 0, FEAT = IT + MAXP * ITER_WORDS, DPF = FEAT + MAXP * 4, DPFI = DPF + MAXP * 21, SMALL = DPFI + 4,
+                         SMALL_END = SMALL + 64;
+    static constexpr int P0 = LONG ? LONG_T : 2068;                      // short class: [S; v'] of up to 44 rows at stride 47
+    static constexpr int MOT = P0, OWN = P0, LIN = P0;                   // (no Gauss-Newton arrays)
+    static constexpr int INTS = LONG ? LONG_T + LONG_HS : P0 + 3840;     // short class: the staged Jacobian, 80 columns x 48 rows
+    static constexpr int TOTAL = INTS + (MAXNP + 3 + 4 + MAXC + 1) / 2 + 1;
+    static constexpr int HS_DOUBLES = INTS - P0, T_DOUBLES = P0;
+    static_assert(SMALL_END <= P0, "the record's copies must fit in front of the staged Jacobian");
+    static constexpr size_t BYTES = sizeof(double) * TOTAL;
+};
+static_assert(3 * VuRecLds<22>::BYTES <= 160 * 1024, "three record-fed short-class gates per CU");
+
 // MAXP (camera poses the LDS arrays are sized for) is a template parameter next to VT: <768, 42> holds every track (151 KB of LDS,
 // one workgroup per CU); <384, 22> holds the common sizes in 75 KB and 6 waves of 138 VGPRs, so TWO filters share a CU and one's
 // serial sections (pose records, 3 x 3 solves, barriers: most of the kernel since r02 took the column work off the critical path)
@@ -238,12 +260,14 @@ static_assert(VuLds<42, true>::BYTES <= 160 * 1024, "the long build must fit one
 // through HBM on the critical path of every visit), with S formed from the FACTORS of the Jacobian on the vector unit (ekf_device.hpp
 // structured_S) instead of sparse_gate's dense MFMA products. In 1 .. 3 the dense H is never written, only Hc / acol / v.
 // MAP: the launch may hold hybrid-map tracks (VuPrepareArgs::map_index) -- its own instantiation, the others compile as before
-template <int VT, int MAXP, int FUSED, bool MAP = false>
+// REC (r06): the gate half only -- the front has run as vu_tri_kernel and left a factor record per track (VuPrepareArgs::tri_rec)
+template <int VT, int MAXP, int FUSED, bool MAP = false, bool REC = false>
 __device__ __forceinline__ void vu_prepare_body(const VuPrepareArgs &a, const int bx /* filter: blockIdx.x, or the loop variable of a persistent launch */)
 {
     // All LDS comes from the dynamic region (carved below): with static arrays the compiler derives the occupancy from their size
     // and stops honouring the register cap that lets two of the small workgroups share a CU.
-    using Lay = VuLds<MAXP, FUSED == 3>;
+    static_assert(!REC || (FUSED == 1 || FUSED == 3), "record-fed builds are gate builds");
+    using Lay = std::conditional_t<REC, VuRecLds<MAXP, FUSED == 3>, VuLds<MAXP, FUSED == 3>>;
     constexpr int MOT_STRIDE = Lay::MOT_STRIDE;
     extern __shared__ __attribute__((aligned(16))) double vu_lds[];
     double *s_trail = vu_lds + Lay::TRAIL;       // [MAXP][POSE_WORDS]
@@ -321,6 +345,24 @@ __device__ __forceinline__ void vu_prepare_body(const VuPrepareArgs &a, const in
             s_feat[4 * tid + 2 + k] = a.velocities[(rec * nt_max + tid) * 2 + k];
         }
     }
+    int status = HV_TRI_OK;
+    int *st_out = a.status + 2 * rec;
+    bool with_derivatives = false;
+    const double *p0 = s_trail;
+    bool map_track = false; int map_off = 0;
+    if constexpr (REC) {
+        // the record vu_tri_kernel left for this track: [nt_max][17] per-pose values, [np][21] dpf, the time-shift column, prep
+        const double *recp = a.tri_rec + rec * (size_t)a.tri_stride;
+        const int R_DPF = 17 * nt_max, R_SFT = R_DPF + 21 * a.np;
+        status = a.status[2 * rec];
+        for (int w = tid; w < 17 * nt; w += VT) { const int i = w / 17, k = w - 17 * i; s_it[i * ITER_WORDS + k] = recp[w]; }
+        if (status == HV_TRI_OK) {
+            for (int w = tid; w < 21 * n; w += VT) s_dpf[w] = recp[R_DPF + w];
+            if (tid < 3) s_dpfi[tid] = recp[R_SFT + tid];
+        }
+        if (tid < 3) pfw[tid] = a.pf[3 * rec + tid];
+        __syncthreads();
+    } else {
     __syncthreads();
     // ---- extractCameraPoseTrail (triangulation.cpp:65-103): pose k of camera c from the mean ----
     if (tid < nt) {
@@ -350,8 +392,6 @@ __device__ __forceinline__ void vu_prepare_body(const VuPrepareArgs &a, const in
     for (int i = tid; i < 3 * ncol; i += VT) s_dpfi[i] = 0.0;
     __syncthreads();
     VU_STAMP(1);
-    const double *p0 = s_trail;
-    bool map_track = false; int map_off = 0;
     if constexpr (MAP) {
         const int mi = a.map_index ? a.map_index[rec] : -1;
         map_track = mi >= 0; map_off = a.map_base + 3 * mi;
@@ -638,7 +678,7 @@ __device__ __forceinline__ void vu_prepare_body(const VuPrepareArgs &a, const in
             const double *o = s_it + i * ITER_WORDS;
             const double dh[3] = {u < 2 ? o[u] : o[9], u < 2 ? o[3 + u] : o[10], u < 2 ? o[6 + u] : o[11]};
             double e3[3] = {0, 0, 0}, m9[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-            pair_sums<false>(o, dh, nullptr, nullptr, 0.0, 0.0, e3, m9);
+            pair_sums<0>(o, dh, nullptr, nullptr, 0.0, 0.0, e3, m9);
             double *dst = s_lin + task * 9;
             dst[0] = e3[0]; dst[1] = e3[1]; dst[2] = e3[2];
             dst[3] = m9[0]; dst[4] = m9[1]; dst[5] = m9[2]; dst[6] = m9[4]; dst[7] = m9[5]; dst[8] = m9[8];
@@ -653,7 +693,7 @@ __device__ __forceinline__ void vu_prepare_body(const VuPrepareArgs &a, const in
             for (int k = 0; k < 3; ++k) dt[k] = mot[9 + k];
 #pragma unroll
             for (int r = 0; r < 3; ++r) dh[r] = (dC[3 * r] * pfi[0] + dC[3 * r + 1] * pfi[1] + dC[3 * r + 2]) + pfi[2] * dt[r];
-            pair_sums<true>(o, dh, dC, dt, 0.0, 0.0, e3, m9);
+            pair_sums<1>(o, dh, dC, dt, 0.0, 0.0, e3, m9);
             double *dst = m_p0pair ? s_p0 + (m_comp * MAXP + m_i) * 9 : s_own + m_col * 9;
             dst[0] = e3[0]; dst[1] = e3[1]; dst[2] = e3[2];
             dst[3] = m9[0]; dst[4] = m9[1]; dst[5] = m9[2]; dst[6] = m9[4]; dst[7] = m9[5]; dst[8] = m9[8];
@@ -726,7 +766,6 @@ __device__ __forceinline__ void vu_prepare_body(const VuPrepareArgs &a, const in
     }   // iterative branch
     VU_STAMP(27);
     // ---- status, back to world coordinates (:345-392) ----
-    int *st_out = a.status + 2 * rec;
     double *M = s_small + 40, *pf0 = s_small + 49;           // R0T * dpf0_dpfi, the point in the frame of pose 0
     if (tid == 0 && !(MAP && map_track)) {
         int status = HV_TRI_OK;
@@ -748,7 +787,7 @@ __device__ __forceinline__ void vu_prepare_body(const VuPrepareArgs &a, const in
         s_flag[2] = 0;                                        // behind any camera
     }
     __syncthreads();
-    int status = s_flag[1];
+    status = s_flag[1];
     if (status == HV_TRI_OK) {
         if (tid < ncol && !a.linear) {
             const int j = tid;
@@ -771,7 +810,7 @@ __device__ __forceinline__ void vu_prepare_body(const VuPrepareArgs &a, const in
         const double dx = pfw[0] - p0[0], dy = pfw[1] - p0[1], dz = pfw[2] - p0[2], depth = sqrt(dx * dx + dy * dy + dz * dz);
         if (depth < a.min_dist || depth > a.max_dist) status = HV_TRI_BAD_DEPTH;
     }
-    const bool with_derivatives = status == HV_TRI_OK;
+    with_derivatives = status == HV_TRI_OK;
     // backend.cpp:1108-1119: per-pose derivative blocks, the two cameras of a pose summed
     if (with_derivatives)
         for (int i = tid; i < n * 21; i += VT) {
@@ -809,6 +848,9 @@ __device__ __forceinline__ void vu_prepare_body(const VuPrepareArgs &a, const in
     }
     __syncthreads();
     VU_STAMP(29);
+    }   // !REC: the front
+    // the point's derivative w.r.t. the time shift: the last column of dpfi (record-fed builds keep just that column)
+    auto sft_col = [&](int c) -> double { return REC ? s_dpfi[c] : s_dpfi[c * ncol + dDim]; };
     const int rows = 2 * nt;
     if constexpr (FUSED != 0) {
         // ---- prepareVisualUpdate in compact form + visualTrackOutlierCheck on the active columns (see VuPrepareArgs::fused) ----
@@ -884,7 +926,7 @@ __device__ __forceinline__ void vu_prepare_body(const VuPrepareArgs &a, const in
                 for (int c = 0; c < 3; ++c) {
                     double v = 0.0;
                     if (!sft) { const int k = tid / 7, comp = tid - 7 * k; v = s_dpf[21 * k + comp + 7 * c]; }
-                    else if (a.est_shift) v = s_dpfi[c * ncol + dDim];
+                    else if (a.est_shift) v = sft_col(c);
                     f_F4[c * f4s + tid] = v;
                 }
                 f_F4[3 * f4s + tid] = sft ? 1.0 : 0.0;
@@ -915,7 +957,7 @@ __device__ __forceinline__ void vu_prepare_body(const VuPrepareArgs &a, const in
                     h0 += o[0] * dp[0] + o[1] * dp[7] + o[2] * dp[14];
                     h1 += o[3] * dp[0] + o[4] * dp[7] + o[5] * dp[14];
                 } else if (a.est_shift) {                                                  // :965-967
-                    const double sft_t0 = s_dpfi[dDim], sft_t1 = s_dpfi[ncol + dDim], sft_t2 = s_dpfi[2 * ncol + dDim];
+                    const double sft_t0 = sft_col(0), sft_t1 = sft_col(1), sft_t2 = sft_col(2);
                     h0 = o[0] * sft_t0 + o[1] * sft_t1 + o[2] * sft_t2 - s_feat[4 * i + 2];
                     h1 = o[3] * sft_t0 + o[4] * sft_t1 + o[5] * sft_t2 - s_feat[4 * i + 3];
                 }
@@ -1072,6 +1114,485 @@ __device__ __forceinline__ void vu_prepare_body(const VuPrepareArgs &a, const in
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Split form (r06): the triangulation front as its OWN kernel. r03 .. r05's fused kernels run pose trail ->
+// two-camera start -> Gauss-Newton -> prepareVisualUpdate -> gate as ~50 barrier-separated phases of one 384- / 768-thread workgroup
+// that holds 80 / 158 KB of LDS throughout (waves parked 70 %; for the typical 6-pose track 39 k of 74 k cycles pass before
+// prepareVisualUpdate starts, profiles/r04/phase_stamps_one_track_visit.txt). Here NT = 64 threads -- ONE wavefront, whose LDS traffic
+// is ordered by the hardware: the barriers below cost a wave nothing -- or NT = 256 (the long class: four wavefronts cut the longest
+// track's chain) run everything up to the per-pose part of prepareVisualUpdate in 19 .. 49 KB of LDS, 3 .. 5 tracks per CU, and leave a
+// FACTOR RECORD per track (VuPrepareArgs::tri_rec): the 17 per-pose values of prepareVisualUpdate, the summed point derivatives, the
+// time-shift column. The gate kernels (from_rec builds of vu_prepare_body) start from it.
+//
+// The derivative sums are the same as vu_prepare_body's with the motion pairs taken by TYPE, each type a loop of its own (a wave's
+// lanes run one code path) and each evaluated from what it really needs instead of through pose_motion's 0 / 1 weights:
+//   P  own position column (pose i >= 1, component c):  dC = 0, dt = -R_i(:, c). The pose-0 column c has dt = +R_i(:, c) for the same
+//      pose, and pair_sums is linear in (dh, dC, dt): ONE evaluation r serves both -- +r into the pose-0 total, -r for the own column
+//      (exact: every operation of pair_sums is odd in its inputs) -- 11 nt - 7 pair evaluations per iteration instead of 14 nt - 7;
+//   C  pose-0 quaternion column (pose i, q):  dC = R_i dR0_q' (+ dR0_q R0' for i = 0), dt = -R_i (dR0_q' base_0) (0 for i = 0);
+//   Q  own quaternion column (pose i >= 1, q):  dC = dR_iq R0', dt = dR_iq (p_0 - p_i) + R_i (dR_iq' base_i);
+// nothing is parked in LDS across the iterations (s_mot of the fused kernels: 13 doubles per pair). A lane that evaluates an own pair
+// updates that column of dpfi right away (X, the step and the linear maps L of the plain part are in place by then), so the own sums
+// never meet LDS either; the pose-0 sums and the plain part's maps go through one scratch area in a fixed order (deterministic).
+// Reference: triangulation.cpp:65-103,120-407,612-716,897-947; backend.cpp:1098-1119.
+// ---------------------------------------------------------------------------------------------
+struct TriLds {                       // run-time carve of the dynamic LDS (doubles) for tracks of up to ntm camera poses / nm poses
+    int trail, it, dpfi, feat, small, dpf, scr, lsum, tot, ints, total;
+    __host__ __device__ TriLds(int ntm, int nm)
+    {
+        trail = 0; it = trail + ntm * POSE_WORDS; dpfi = it + ntm * ITER_WORDS; feat = dpfi + 3 * (7 * ntm + 1);
+        (void)nm;
+        small = feat + 4 * ntm; dpf = small + 72; scr = dpf; lsum = scr + 4 * ntm * 9; tot = lsum + 32; ints = tot + 64;
+        total = ints + (MAXNP + 3 + 4 + 1) / 2 + 1;
+    }
+};
+
+template <int NT>
+__device__ __forceinline__ void vu_tri_body(const VuPrepareArgs &a, const int b)
+{
+    extern __shared__ __attribute__((aligned(16))) double vu_lds[];
+    const int tid = threadIdx.x;
+    const size_t rec = (size_t)b;
+    // the records the gate launch of this class will look at (its early exits restated, without their side effects)
+    const int np_rec = __builtin_amdgcn_readfirstlane(a.np_rec ? a.np_rec[rec] : a.np);
+    if (np_rec < 2 || np_rec > a.np) return;
+    if (a.np_hi > 0 && (np_rec < a.np_lo || np_rec > a.np_hi)) return;
+    if (a.success_counter && a.success_counter[b] >= a.max_successful) return;
+    const int n = np_rec, ncam = a.stereo ? 2 : 1, nt = n * ncam, N = a.n;
+    const int nt_max = a.np * ncam;
+    const int dDim = nt * 7, ncol = dDim + 1;
+    const int np_carve = a.np_hi > 0 && a.np_hi < a.np ? a.np_hi : a.np;      // the longest track of THIS launch (launch_vu_tri sizes the LDS by it)
+    const TriLds L(np_carve * ncam, np_carve);
+    double *s_trail = vu_lds + L.trail, *s_it = vu_lds + L.it, *s_dpfi = vu_lds + L.dpfi, *s_feat = vu_lds + L.feat;
+    double *s_small = vu_lds + L.small, *s_scr = vu_lds + L.scr, *s_L = vu_lds + L.lsum, *s_tot = vu_lds + L.tot;
+    int *s_idx = reinterpret_cast<int *>(vu_lds + L.ints), *s_flag = s_idx + MAXNP + 3;
+    const double *m = a.m + (size_t)b * N;
+    double *pfi = s_small, *pfw = s_small + 3, *R0T = s_small + 18, *scal = s_small + 36, *sums13 = s_small + 52;
+    auto sync = [] { lds_barrier(); };
+    if (tid < n) s_idx[tid] = a.pose_index[rec * a.np + tid];
+    if (tid < nt) {
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            s_feat[4 * tid + k] = a.features[(rec * nt_max + tid) * 2 + k];
+            s_feat[4 * tid + 2 + k] = a.velocities[(rec * nt_max + tid) * 2 + k];
+        }
+    }
+    sync();
+    // ---- extractCameraPoseTrail (triangulation.cpp:65-103) ----
+    if (tid < nt) {
+        const int cam = tid / n, k = tid - cam * n;
+        const double *T = a.imu_to_cam[cam];
+        const double Ric[9] = {T[0], T[1], T[2], T[4], T[5], T[6], T[8], T[9], T[10]}, base[3] = {T[3], T[7], T[11]};
+        int ip, io;
+        pos_ori(s_idx[k], ip, io);
+        const double q[4] = {m[io], m[io + 1], m[io + 2], m[io + 3]};
+        double Rw[9], dRw[36], R[9], t[3];
+        quat2rmat_d(q, Rw, dRw);
+        mm3(Ric, Rw, R);
+        mTv3(R, base, t);
+        double *o = s_trail + tid * POSE_WORDS;
+#pragma unroll
+        for (int k2 = 0; k2 < 3; ++k2) { o[k2] = m[ip + k2] - t[k2]; o[48 + k2] = base[k2]; }
+#pragma unroll
+        for (int k2 = 0; k2 < 9; ++k2) o[3 + k2] = R[k2];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            double d[9];
+            mm3(Ric, dRw + 9 * j, d);
+#pragma unroll
+            for (int k2 = 0; k2 < 9; ++k2) o[12 + 9 * j + k2] = d[k2];
+        }
+    }
+    for (int i = tid; i < 3 * ncol; i += NT) s_dpfi[i] = 0.0;
+    sync();
+    const double *p0 = s_trail;
+    // ---- triangulateWithTwoCameras between pose 0 and pose ind1 (:154-173, 612-716): lane j < 15 owns derivative column j ----
+    const int ind1 = a.stereo ? nt / 2 - 1 : nt - 1;
+    if (tid < 15) {
+        const double *P0 = s_trail, *P1 = s_trail + ind1 * POSE_WORDS;
+        const double *R0 = P0 + 3, *R1 = P1 + 3;
+        double C[9], d01[3], bb[3];
+        mmT3(R0, R1, C);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) d01[k] = P1[k] - P0[k];
+        mv3(R0, d01, bb);
+        const double v0[3] = {s_feat[0], s_feat[1], 1.0}, v1[3] = {s_feat[4 * ind1], s_feat[4 * ind1 + 1], 1.0};
+        const double n0 = sqrt(v0[0] * v0[0] + v0[1] * v0[1] + 1.0), n1 = sqrt(v1[0] * v1[0] + v1[1] * v1[1] + 1.0);
+        const double vn0[3] = {v0[0] / n0, v0[1] / n0, v0[2] / n0}, vn1[3] = {v1[0] / n1, v1[1] / n1, v1[2] / n1};
+        double Cvn1[3], A[6], iA[6];
+        mv3(C, vn1, Cvn1);
+#pragma unroll
+        for (int r = 0; r < 3; ++r) { A[2 * r] = vn0[r]; A[2 * r + 1] = -Cvn1[r]; }
+        pinv32(A, iA);
+        const double s0 = iA[0] * bb[0] + iA[1] * bb[1] + iA[2] * bb[2];
+        double pf[3] = {s0 * vn0[0], s0 * vn0[1], s0 * vn0[2]};
+        double ip3[3], dd[9];
+        inverse_depth(pf, ip3, dd);
+        double dA[6] = {0, 0, 0, 0, 0, 0}, db[3] = {0, 0, 0}, col[3];
+        const int j = tid;
+        if (j < 14) {
+            const int second = j >= 7, comp = second ? j - 7 : j;
+            if (comp < 3) {
+#pragma unroll
+                for (int r = 0; r < 3; ++r) db[r] = (second ? 1.0 : -1.0) * R0[3 * r + comp];
+            } else {
+                const int qi = comp - 3;
+                double dC[9], t[3];
+                if (!second) { mmT3(P0 + 12 + 9 * qi, R1, dC); mv3(P0 + 12 + 9 * qi, d01, db); }
+                else mmT3(R0, P1 + 12 + 9 * qi, dC);
+                mv3(dC, vn1, t);
+#pragma unroll
+                for (int r = 0; r < 3; ++r) dA[2 * r + 1] = -t[r];
+            }
+            double diA[6];
+            dpinv(A, iA, dA, diA);
+            const double ds = (iA[0] * db[0] + iA[1] * db[1] + iA[2] * db[2]) + (diA[0] * bb[0] + diA[1] * bb[1] + diA[2] * bb[2]);
+#pragma unroll
+            for (int r = 0; r < 3; ++r) col[r] = ds * vn0[r];
+        } else if (a.est_shift) {
+            double w0[3], w1[3], cw1[3], diA[6];
+#pragma unroll
+            for (int r = 0; r < 3; ++r) {
+                w0[r] = 0; w1[r] = 0;
+#pragma unroll
+                for (int c = 0; c < 2; ++c) {
+                    w0[r] += ((r == c ? 1.0 : 0.0) - vn0[r] * vn0[c]) / n0 * s_feat[2 + c];
+                    w1[r] += ((r == c ? 1.0 : 0.0) - vn1[r] * vn1[c]) / n1 * s_feat[4 * ind1 + 2 + c];
+                }
+            }
+            mv3(C, w1, cw1);
+#pragma unroll
+            for (int r = 0; r < 3; ++r) { dA[2 * r] = w0[r]; dA[2 * r + 1] = -cw1[r]; }
+            dpinv(A, iA, dA, diA);
+            const double ds0dt = diA[0] * bb[0] + diA[1] * bb[1] + diA[2] * bb[2];
+#pragma unroll
+            for (int r = 0; r < 3; ++r) col[r] = s0 * w0[r] + vn0[r] * ds0dt;
+        } else { col[0] = col[1] = col[2] = 0.0; }
+        double mapped[3];
+        mv3(dd, col, mapped);
+        const int dst = j < 7 ? j : j < 14 ? 7 * ind1 + (j - 7) : dDim;
+        if (!(j < 7 && ind1 == 0)) {
+#pragma unroll
+            for (int r = 0; r < 3; ++r) s_dpfi[r * ncol + dst] = mapped[r];
+        }
+        if (tid == 0) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) { pfi[k] = ip3[k]; pfw[k] = pf[k]; }
+#pragma unroll
+            for (int r = 0; r < 3; ++r)
+#pragma unroll
+                for (int c = 0; c < 3; ++c) R0T[3 * r + c] = R0[3 * c + r];
+            scal[1] = 0.0; scal[2] = 1e10;
+            s_flag[0] = 0;
+        }
+    }
+    sync();
+    // ---- Gauss-Newton with derivatives (:206-343) ----
+    const double *Lm = s_L;
+    // column j of dpfi takes its step: (dEe_j, dM_j) = L' d_j + the motion sums `own` (dEe[3], upper dM[6]) -- or, for the time-shift
+    // column, the velocity term c_t -- then d(A^-1 b) = X (dM step) - X dEe (:324-328)
+    auto update_col = [&](int j, const double *own, bool is_sft, const double (&X)[9], const double (&step)[3]) {
+        const double d0 = s_dpfi[j], d1 = s_dpfi[ncol + j], d2 = s_dpfi[2 * ncol + j];
+        double v[9];
+#pragma unroll
+        for (int e = 0; e < 9; ++e) v[e] = (Lm[e] * d0 + Lm[9 + e] * d1) + Lm[18 + e] * d2;
+        double dEe[3] = {v[0], v[1], v[2]}, dM[9] = {v[3], v[4], v[5], v[4], v[6], v[7], v[5], v[7], v[8]};
+        if (!is_sft) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) dEe[k] += own[k];
+            dM[0] += own[3]; dM[1] += own[4]; dM[2] += own[5]; dM[4] += own[6]; dM[5] += own[7]; dM[8] += own[8];
+            dM[3] = dM[1]; dM[6] = dM[2]; dM[7] = dM[5];
+        } else {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) dEe[k] += Lm[27 + k];
+        }
+        double t1[3], t2[3], t3[3];
+        mv3(dM, step, t1);
+        mv3(X, t1, t2);
+        mv3(X, dEe, t3);
+#pragma unroll
+        for (int r = 0; r < 3; ++r) s_dpfi[r * ncol + j] += t2[r] - t3[r];
+    };
+    for (int it = 0; it < a.gn_iters; ++it) {
+        if (tid < nt) {                                       // per-pose quantities of this iteration
+            const double *cur = s_trail + tid * POSE_WORDS;
+            double *o = s_it + tid * ITER_WORDS;
+            double C[9], t[3], d[3], h[3];
+            mm3(cur + 3, R0T, C);
+#pragma unroll
+            for (int k = 0; k < 3; ++k) d[k] = p0[k] - cur[k];
+            mv3(cur + 3, d, t);
+            const double pfiab[3] = {pfi[0], pfi[1], 1.0};
+            mv3(C, pfiab, h);
+#pragma unroll
+            for (int k = 0; k < 3; ++k) h[k] += pfi[2] * t[k];
+            const double ih2 = 1.0 / h[2], ih2sq = ih2 * ih2;
+#pragma unroll
+            for (int k = 0; k < 9; ++k) o[k] = C[k];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) { o[9 + k] = t[k]; o[12 + k] = h[k]; o[23 + k] = d[k]; }
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+#pragma unroll
+                for (int c = 0; c < 2; ++c) o[15 + 3 * r + c] = -ih2 * C[3 * r + c] + h[r] * ih2sq * C[6 + c];
+                o[15 + 3 * r + 2] = -t[r] * ih2 + h[r] * ih2sq * t[2];
+                o[21 + r] = s_feat[4 * tid + r] - h[r] * ih2;
+            }
+        }
+        sync();
+        // ETE (9), Eerror (3), error2: entry k = sum over the poses of o[x0] o[y0] + o[x0 + dx] o[y0 + dy], four adjacent lanes each
+        if (tid < 52) {
+            const int k = tid >> 2, part = tid & 3;
+            const int r = k / 3, c = k - 3 * r;
+            const int x0 = k < 9 ? 15 + r : k < 12 ? 15 + (k - 9) : 21, y0 = k < 9 ? 15 + c : 21;
+            const int dx = k < 12 ? 3 : 1, dy = k < 9 ? 3 : 1;
+            double acc = 0.0;
+            for (int i = part; i < nt; i += 4) {
+                const double *o = s_it + i * ITER_WORDS;
+                acc += o[x0] * o[y0] + o[x0 + dx] * o[y0 + dy];
+            }
+            acc += __shfl_xor(acc, 1);
+            acc += __shfl_xor(acc, 2);
+            if (part == 0) sums13[k] = acc;
+        }
+        // PLAIN part: task (pose i, unit vector u) -> the 3 + 6 numbers pair_sums gives for dh = column u of [C_i(:, 0:2) | t_i]
+        {
+            const int t0 = NT > 64 ? tid - 64 : tid, tstep = NT > 64 ? NT - 64 : NT;
+            if (t0 >= 0)
+                for (int task = t0; task < 3 * nt; task += tstep) {
+                    const int i = task / 3, u = task - 3 * i;
+                    const double *o = s_it + i * ITER_WORDS;
+                    const double dh[3] = {u < 2 ? o[u] : o[9], u < 2 ? o[3 + u] : o[10], u < 2 ? o[6 + u] : o[11]};
+                    double e3[3] = {0, 0, 0}, m9[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+                    pair_sums<0>(o, dh, nullptr, nullptr, 0.0, 0.0, e3, m9);
+                    double *dst = s_scr + task * 9;
+                    dst[0] = e3[0]; dst[1] = e3[1]; dst[2] = e3[2];
+                    dst[3] = m9[0]; dst[4] = m9[1]; dst[5] = m9[2]; dst[6] = m9[4]; dst[7] = m9[5]; dst[8] = m9[8];
+                }
+        }
+        sync();
+        // every lane: X = (E'E)^-1 and the step, in registers (the column updates below use them)
+        double X[9], step[3];
+        {
+            double ETE[9], Ee[3];
+#pragma unroll
+            for (int q = 0; q < 9; ++q) ETE[q] = sums13[q];
+#pragma unroll
+            for (int q = 0; q < 3; ++q) Ee[q] = sums13[9 + q];
+            inv3sym(ETE, X);
+            mv3(X, Ee, step);
+            if (tid == 0) { scal[0] = sums13[12]; scal[1] = 1.0 / (norm1_3(ETE) * norm1_3(X)); }
+        }
+        // L[u][e] = sum over the poses of the plain part's maps (27), c_t = sum_i E_i' vel_i (3): two adjacent lanes each
+        if (tid < 60) {
+            const int sigma = tid >> 1, part = tid & 1;
+            double acc = 0.0;
+            if (sigma < 27) {
+                const int u = sigma / 9, e = sigma - 9 * u;
+                for (int q = part; q < nt; q += 2) acc += s_scr[(3 * q + u) * 9 + e];
+            } else {
+                const int r = sigma - 27;
+                for (int q = part; q < nt; q += 2)
+                    acc += s_it[q * ITER_WORDS + 15 + r] * s_feat[4 * q + 2] + s_it[q * ITER_WORDS + 18 + r] * s_feat[4 * q + 3];
+            }
+            acc += __shfl_xor(acc, 1);
+            if (part == 0) s_L[sigma] = acc;
+        }
+        sync();
+        // ---- type C: pose-0 quaternion columns, pair (pose i, q) -> scratch [q][i][9] ----
+        for (int e = tid; e < 4 * nt; e += NT) {
+            const int q = e / nt, i = e - q * nt;
+            const double *cur = s_trail + i * POSE_WORDS, *dR0 = s_trail + 12 + 9 * q, *o = s_it + i * ITER_WORDS;
+            double dC[9], dt[3], dp0[3], dh[3], e3[3] = {0, 0, 0}, m9[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+            mmT3(cur + 3, dR0, dC);
+            mTv3(dR0, s_trail + 48, dp0);
+            const double dd[3] = {-dp0[0], -dp0[1], -dp0[2]};
+            mv3(cur + 3, dd, dt);
+            if (i == 0) {                                     // pose 0 itself: both rotations move, the positions cancel
+                double a1[9];
+                mm3(dR0, R0T, a1);
+#pragma unroll
+                for (int k = 0; k < 9; ++k) dC[k] += a1[k];
+                dt[0] = 0.0; dt[1] = 0.0; dt[2] = 0.0;
+            }
+#pragma unroll
+            for (int r = 0; r < 3; ++r) dh[r] = (dC[3 * r] * pfi[0] + dC[3 * r + 1] * pfi[1] + dC[3 * r + 2]) + pfi[2] * dt[r];
+            pair_sums<1>(o, dh, dC, dt, 0.0, 0.0, e3, m9);
+            double *dst = s_scr + e * 9;
+            dst[0] = e3[0]; dst[1] = e3[1]; dst[2] = e3[2];
+            dst[3] = m9[0]; dst[4] = m9[1]; dst[5] = m9[2]; dst[6] = m9[4]; dst[7] = m9[5]; dst[8] = m9[8];
+        }
+        sync();
+        if (tid < 36) {                                       // totals of the pose-0 quaternion columns (q, entry), poses in order
+            const int q = tid / 9, en = tid - 9 * q;
+            double acc = 0.0;
+            for (int i = 0; i < nt; ++i) acc += s_scr[(q * nt + i) * 9 + en];
+            s_tot[(3 + q) * 9 + en] = acc;
+        }
+        sync();
+        // ---- type P: own position columns (pose i >= 1, component c); +r to the pose-0 position totals through scratch [c][i - 1][9] ----
+        for (int e = tid; e < 3 * (nt - 1); e += NT) {
+            const int c = e / (nt - 1), i = 1 + e - c * (nt - 1);
+            const double *cur = s_trail + i * POSE_WORDS, *o = s_it + i * ITER_WORDS;
+            const double dt[3] = {cur[3 + c], cur[6 + c], cur[9 + c]};          // R_i(:, c)
+            const double dh[3] = {pfi[2] * dt[0], pfi[2] * dt[1], pfi[2] * dt[2]};
+            double e3[3] = {0, 0, 0}, m9[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+            pair_sums<2>(o, dh, nullptr, dt, 0.0, 0.0, e3, m9);
+            const double r9[9] = {e3[0], e3[1], e3[2], m9[0], m9[1], m9[2], m9[4], m9[5], m9[8]};
+            double *dst = s_scr + e * 9;
+            double own[9];
+#pragma unroll
+            for (int k = 0; k < 9; ++k) { dst[k] = r9[k]; own[k] = -r9[k]; }
+            update_col(7 * i + c, own, false, X, step);
+        }
+        // ---- type Q: own quaternion columns (pose i >= 1, q) ----
+        for (int e = tid; e < 4 * (nt - 1); e += NT) {
+            const int q = e / (nt - 1), i = 1 + e - q * (nt - 1);
+            const double *cur = s_trail + i * POSE_WORDS, *dR = cur + 12 + 9 * q, *o = s_it + i * ITER_WORDS;
+            double dC[9], dt[3], dpi[3], t1[3], t2[3], dh[3], e3[3] = {0, 0, 0}, m9[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+            mm3(dR, R0T, dC);
+            mTv3(dR, cur + 48, dpi);
+            mv3(dR, o + 23, t1);
+            mv3(cur + 3, dpi, t2);
+#pragma unroll
+            for (int k = 0; k < 3; ++k) dt[k] = t1[k] + t2[k];
+#pragma unroll
+            for (int r = 0; r < 3; ++r) dh[r] = (dC[3 * r] * pfi[0] + dC[3 * r + 1] * pfi[1] + dC[3 * r + 2]) + pfi[2] * dt[r];
+            pair_sums<1>(o, dh, dC, dt, 0.0, 0.0, e3, m9);
+            const double own[9] = {e3[0], e3[1], e3[2], m9[0], m9[1], m9[2], m9[4], m9[5], m9[8]};
+            update_col(7 * i + 3 + q, own, false, X, step);
+        }
+        sync();
+        if (tid < 27) {                                       // totals of the pose-0 position columns (c, entry), poses in order
+            const int c = tid / 9, en = tid - 9 * c;
+            double acc = 0.0;
+            for (int i = 0; i < nt - 1; ++i) acc += s_scr[(c * (nt - 1) + i) * 9 + en];
+            s_tot[c * 9 + en] = acc;
+        }
+        sync();
+        if (tid < 7) update_col(tid, s_tot + 9 * tid, false, X, step);
+        else if (tid == 7 && a.est_shift) update_col(dDim, nullptr, true, X, step);
+        sync();                                               // everybody is done with the old pfi
+        if (tid == 0) {                                       // :316-342
+#pragma unroll
+            for (int k = 0; k < 3; ++k) pfi[k] -= step[k];
+            const double J = 0.5 * scal[0] / (a.conv_r * a.conv_r), Jd = fabs((J - scal[2]) / J);
+            scal[2] = J;
+            if (Jd < a.conv_threshold) s_flag[0] = 1;
+        }
+        sync();
+        if (s_flag[0]) break;
+    }
+    // ---- status, back to world coordinates (:345-392) ----
+    double *M = s_small + 40, *pf0 = s_small + 49;
+    if (tid == 0) {
+        int status = HV_TRI_OK;
+        if (!s_flag[0]) status = HV_TRI_NO_CONVERGENCE;
+        else if (scal[1] < a.rcond_threshold) status = HV_TRI_BAD_COND;
+        if (status == HV_TRI_OK) {
+            double d[9], q[3], w[3], Ml[9];
+            inverse_depth(pfi, q, d);
+            mv3(R0T, q, w);
+#pragma unroll
+            for (int k = 0; k < 3; ++k) { pfw[k] = w[k] + p0[k]; pf0[k] = q[k]; }
+            if (pfw[0] == p0[0] && pfw[1] == p0[1] && pfw[2] == p0[2]) status = HV_TRI_UNKNOWN_PROBLEM;
+            mm3(R0T, d, Ml);
+#pragma unroll
+            for (int k = 0; k < 9; ++k) M[k] = Ml[k];
+        }
+        s_flag[1] = status;
+        s_flag[2] = 0;
+    }
+    sync();
+    int status = s_flag[1];
+    if (status == HV_TRI_OK) {
+        for (int j = tid; j < ncol; j += NT) {
+            double u[3] = {0, 0, 0}, v[3];
+            if (j >= 3 && j < 7) mTv3(s_trail + 12 + 9 * (j - 3), pf0, u);
+            const double cur[3] = {s_dpfi[j], s_dpfi[ncol + j], s_dpfi[2 * ncol + j]};
+            mv3(M, cur, v);
+#pragma unroll
+            for (int r = 0; r < 3; ++r) s_dpfi[r * ncol + j] = u[r] + v[r] + (j == r ? 1.0 : 0.0);
+        }
+        if (tid < nt) {                                       // isBehind (:54-60)
+            const double *cur = s_trail + tid * POSE_WORDS;
+            const double d[3] = {pfw[0] - cur[0], pfw[1] - cur[1], pfw[2] - cur[2]};
+            if (cur[9] * d[0] + cur[10] * d[1] + cur[11] * d[2] < 0) atomicOr(&s_flag[2], 1);
+        }
+        sync();
+        if (s_flag[2]) status = HV_TRI_BEHIND;
+    }
+    {   // backend.cpp:1098-1102: depth window on whatever point the triangulation left behind
+        const double dx = pfw[0] - p0[0], dy = pfw[1] - p0[1], dz = pfw[2] - p0[2], depth = sqrt(dx * dx + dy * dy + dz * dz);
+        if (depth < a.min_dist || depth > a.max_dist) status = HV_TRI_BAD_DEPTH;
+    }
+    double *recp = a.tri_rec + rec * (size_t)a.tri_stride;
+    const int R_DPF = 17 * nt_max, R_SFT = R_DPF + 21 * a.np;
+    // backend.cpp:1108-1119: per-pose derivative blocks, the two cameras of a pose summed -- straight into the record
+    if (status == HV_TRI_OK) {
+        for (int i = tid; i < n * 21; i += NT) {
+            const int k = i / 21, e = i - 21 * k, r = e / 7, c = e - 7 * r;
+            double v = s_dpfi[r * ncol + 7 * k + c];
+            if (a.stereo) v += s_dpfi[r * ncol + 7 * (k + n) + c];
+            recp[R_DPF + i] = v;
+        }
+        if (tid < 3) recp[R_SFT + tid] = a.est_shift ? s_dpfi[tid * ncol + dDim] : 0.0;
+    }
+    // ---- prepareVisualUpdate, per-pose part (triangulation.cpp:897-947): dip R (2x3), dip dRpt (2x4), f, depth class ----
+    if (tid < nt) {
+        const double *pose = s_trail + tid * POSE_WORDS;
+        double *o = recp + 17 * tid;
+        const double pt[3] = {pfw[0] - pose[0], pfw[1] - pose[1], pfw[2] - pose[2]};
+        double pfc[3], ipH[3], dip[9];
+        mv3(pose + 3, pt, pfc);
+        inverse_depth(pfc, ipH, dip);
+        const double cls = pfc[2] == 0 ? 1.0 : pfc[2] < 0 ? 2.0 : 0.0;
+        o[16] = cls;
+        s_it[tid * ITER_WORDS + 16] = cls;
+        o[14] = ipH[0]; o[15] = ipH[1];
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) o[3 * r + c] = dip[3 * r] * pose[3 + c] + dip[3 * r + 1] * pose[6 + c] + dip[3 * r + 2] * pose[9 + c];
+#pragma unroll
+        for (int jq = 0; jq < 4; ++jq) {
+            const double *dR = pose + 12 + 9 * jq;
+            double a1[3], b1[3], b2[3];
+            mv3(dR, pt, a1);
+            mTv3(dR, pose + 48, b1);
+            mv3(pose + 3, b1, b2);
+#pragma unroll
+            for (int r = 0; r < 2; ++r) o[6 + 4 * r + jq] = dip[3 * r] * (a1[0] + b2[0]) + dip[3 * r + 1] * (a1[1] + b2[1]) + dip[3 * r + 2] * (a1[2] + b2[2]);
+        }
+    }
+    sync();
+    if (tid == 0) {
+        int prep = 0;
+        for (int i = 0; i < nt && prep == 0; ++i) prep = (int)s_it[i * ITER_WORDS + 16];   // first failing pose decides (:920-927)
+        recp[R_SFT + 3] = (double)prep;
+        a.status[2 * rec] = status;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) a.pf[3 * rec + k] = pfw[k];
+    }
+}
+
+// one wavefront per track: the short class (and every class of a small launch); listed / ordered like the gate launch it feeds
+__global__ __launch_bounds__(64) void vu_tri_kernel(VuPrepareArgs a)
+{
+    int b = blockIdx.x;
+    if (a.rec_list) { if (b >= *a.rec_count) return; b = a.rec_list[b]; }
+    else if (a.order) b = __builtin_amdgcn_readfirstlane(a.order[blockIdx.x]);
+    vu_tri_body<64>(a, b);
+}
+// four wavefronts per track: the long class, whose chain sets the visit's length
+__global__ __launch_bounds__(256) void vu_tri_kernel_x4(VuPrepareArgs a)
+{
+    int b = blockIdx.x;
+    if (a.rec_list) { if (b >= *a.rec_count) return; b = a.rec_list[b]; }
+    else if (a.order) b = __builtin_amdgcn_readfirstlane(a.order[blockIdx.x]);
+    vu_tri_body<256>(a, b);
+}
+
 __global__ __launch_bounds__(VT_LATENCY, 3) void vu_prepare_kernel(VuPrepareArgs a) { vu_prepare_body<VT_LATENCY, MAXP_ALL, 0>(a, blockIdx.x); }
 // 4 waves per SIMD = 128 VGPRs: two workgroups of 6 waves may put 4 waves on one SIMD (512 VGPRs per lane there)
 __global__ __launch_bounds__(VT_THROUGHPUT, 4) void vu_prepare_kernel_2percu(VuPrepareArgs a)
@@ -1087,6 +1608,20 @@ __global__ __launch_bounds__(VT_THROUGHPUT, 4) void vu_gate_kernel_2percu(VuPrep
     // launch is ~1.6 waves of workgroups on the chip's 512 slots: in filter order a long track that starts late sets the launch time
     const int b = a.order ? __builtin_amdgcn_readfirstlane(a.order[blockIdx.x]) : (int)blockIdx.x;
     vu_prepare_body<VT_THROUGHPUT, MAXP_SMALL, 1>(a, b);
+}
+
+// record-fed gate builds (r06): the front has run as vu_tri_kernel; three of the short class's workgroups share a CU (48 KB each)
+constexpr int VT_REC = 256;
+__global__ __launch_bounds__(VT_REC, 3) void vu_gate_rec_kernel(VuPrepareArgs a)
+{
+    const int b = a.order ? __builtin_amdgcn_readfirstlane(a.order[blockIdx.x]) : (int)blockIdx.x;
+    vu_prepare_body<VT_REC, MAXP_SMALL, 1, false, true>(a, b);
+}
+__global__ __launch_bounds__(VT_LATENCY, 3) void vu_gate_long_rec_kernel(VuPrepareArgs a)
+{
+    int b = blockIdx.x;
+    if (a.rec_list) { if (b >= *a.rec_count) return; b = a.rec_list[b]; }
+    vu_prepare_body<VT_LATENCY, MAXP_ALL, 3, false, true>(a, b);
 }
 
 // launch_visit_order: counting sort of one visit's filters per workgroup (keys 0 .. 63: the pose count inside the class, else 0)
@@ -1174,6 +1709,35 @@ bool vu_fused_supported(const Ctx *c, int n_state, int np, int stereo, int batch
     return na4 * nrp <= hs_cap && 816 + VT_LATENCY / 64 <= hs_cap && Rs * rows <= t_cap;
 }
 
+// shapes the split form serves: iterative triangulation of pose-trail tracks, no speculation; the record-fed short-class gate holds
+// stereo tracks of up to 11 poses (its staged Jacobian is 80 x 48 doubles), the long-class gate everything vu_gate_long_kernel does
+bool vu_split_supported(const Ctx *c, const VuPrepareArgs &a, int fused)
+{
+    if (c->knob.ekf_split_tri == 0 || a.linear || a.map_index || a.spec_tracks > 0 || !a.P || a.n > 160) return false;
+    const int ncam = a.stereo ? 2 : 1, np_sel = a.np_hi > 0 && a.np_hi < a.np ? a.np_hi : a.np;
+    if (a.np > MAXNP || a.np * ncam > MAXP_ALL) return false;
+    // (knob value 2: at every batch size -- tests; 1: where the two-per-CU fused build would run)
+    if (fused == 1) return a.stereo && np_sel * ncam <= MAXP_SMALL && (a.batch > 256 || c->knob.ekf_split_tri == 2) && vu_fused_supported(c, a.n, np_sel, a.stereo, a.batch);
+    return fused == 3;
+}
+
+int launch_vu_tri(Ctx *c, const VuPrepareArgs &a, hipStream_t stream)
+{
+    if (!stream) stream = c->stream;
+    const int ncam = a.stereo ? 2 : 1;
+    if (a.np < 2 || a.batch < 1 || a.np > MAXNP || a.np * ncam > MAXP_ALL) return HV_ERR_INVALID;
+    if (!a.tri_rec || a.tri_stride < vu_tri_rec_stride(a.np, ncam) || a.spec_tracks > 0 || a.linear || a.map_index) return HV_ERR_INVALID;
+    ScopedKernelTime tm(c, HV_K_VU_PREPARE, stream);
+    const int np_sel = a.np_hi > 0 && a.np_hi < a.np ? a.np_hi : a.np;
+    const TriLds L(np_sel * ncam, np_sel);
+    const size_t bytes = sizeof(double) * (size_t)L.total;
+    // four wavefronts per track where the launch may hold long tracks (their chain sets the length of the visit), one otherwise
+    if (np_sel * ncam > MAXP_SMALL) hipLaunchKernelGGL(vu_tri_kernel_x4, dim3((unsigned)a.batch), dim3(256), bytes, stream, a);
+    else                            hipLaunchKernelGGL(vu_tri_kernel, dim3((unsigned)a.batch), dim3(64), bytes, stream, a);
+    HV_HIP(c, hipGetLastError());
+    return HV_OK;
+}
+
 int launch_vu_prepare(Ctx *c, const VuPrepareArgs &a, hipStream_t stream)
 {
     if (!stream) stream = c->stream;
@@ -1207,6 +1771,21 @@ int launch_vu_prepare(Ctx *c, const VuPrepareArgs &a, hipStream_t stream)
         attr_set = true;
     }
     const dim3 grid((unsigned)a.batch, (unsigned)(a.spec_tracks > 0 ? a.spec_tracks : 1));
+    if (a.from_rec) {                                        // the gate half of the split form (the caller has launched vu_tri_kernel)
+        if (!a.tri_rec || !vu_split_supported(c, a, a.fused)) return HV_ERR_INVALID;
+        static bool rec_attr_dev[64] = {};
+        bool &rec_attr = rec_attr_dev[c->p.device & 63];
+        if (!rec_attr) {
+            constexpr int rec_long_attr = (int)VuRecLds<MAXP_ALL, true>::BYTES;
+            HV_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void *>(vu_gate_long_rec_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, rec_long_attr));
+            rec_attr = true;
+        }
+        constexpr size_t rec_long_bytes = VuRecLds<MAXP_ALL, true>::BYTES, rec_short_bytes = VuRecLds<MAXP_SMALL>::BYTES;
+        if (a.fused == 3) hipLaunchKernelGGL(vu_gate_long_rec_kernel, grid, dim3(VT_LATENCY), rec_long_bytes, stream, a);
+        else              hipLaunchKernelGGL(vu_gate_rec_kernel, grid, dim3(VT_REC), rec_short_bytes, stream, a);
+        HV_HIP(c, hipGetLastError());
+        return HV_OK;
+    }
     if (a.map_index) {                                       // hybrid-map tracks: the dense-H build with the map branch
         if (a.fused || a.map_base < 0) return HV_ERR_INVALID;
         static bool map_attr_dev[64] = {};

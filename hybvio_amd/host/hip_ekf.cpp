@@ -244,6 +244,12 @@ struct HipEKF : public EKF {
         dirty();
     }
 
+    // gate status of the device entries (include/hybvio_hip.h: 0 inlier, 1 not computed, 2 RMSE, 3 chi2) -> the reference's enum; ONE
+    // mapping for visualTrack, visualTrackHybrid and frameLoop (r05 advisor: two of the three reported an RMSE rejection as NOT_COMPUTED)
+    static VuOutlierStatus outlierStatusOfGate(int gate) {
+        return gate == 0 ? VuOutlierStatus::INLIER : gate == 3 ? VuOutlierStatus::CHI2 : gate == 2 ? VuOutlierStatus::RMSE : VuOutlierStatus::NOT_COMPUTED;
+    }
+
     VuOutlierStatus visualTrackOutlierCheck(const MatrixXd &visH, const VectorXd &f, const VectorXd &y, double r,
                                             double trackRmseThreshold) final {
         const int n = visH.rows;
@@ -279,7 +285,7 @@ struct HipEKF : public EKF {
         check(hv_ekf_visual_track(dev(), &parameters, (int)n, poseTrailIndex.data(), imageFeatures.data(), featureVelocities.data(),
                                   y.data(), chiOutlierR, visualR, status, &gate, nullptr, res.pf.data()));
         res.triangulateStatus = status[0]; res.prepareVuStatus = status[1];
-        res.outlierStatus = gate == 0 ? VuOutlierStatus::INLIER : gate == 3 ? VuOutlierStatus::CHI2 : VuOutlierStatus::NOT_COMPUTED;
+        res.outlierStatus = outlierStatusOfGate(gate);
         if (gate == 0) dirty();                       // the filter was updated
         return res;
     }
@@ -317,8 +323,7 @@ struct HipEKF : public EKF {
                                              maxSuccessfulVisualUpdates));
         for (size_t k = 0; k < K; ++k) {
             out[k].triangulateStatus = status[2 * k]; out[k].prepareVuStatus = status[2 * k + 1];
-            out[k].outlierStatus = gate[k] == 0 ? VuOutlierStatus::INLIER : gate[k] == 3 ? VuOutlierStatus::CHI2
-                                 : gate[k] == 2 ? VuOutlierStatus::RMSE : VuOutlierStatus::NOT_COMPUTED;
+            out[k].outlierStatus = outlierStatusOfGate(gate[k]);
             for (int q = 0; q < 3; ++q) out[k].pf[q] = pf[3 * k + q];
         }
         if (updateSuccessCount) *updateSuccessCount = applied;
@@ -350,7 +355,7 @@ struct HipEKF : public EKF {
                                          par.hybridMapSize > 0 ? &offeredMapPointIndex : nullptr, chiOutlierR, visualR, status, &gate,
                                          nullptr, res.pf.data()));
         res.triangulateStatus = status[0]; res.prepareVuStatus = status[1];
-        res.outlierStatus = gate == 0 ? VuOutlierStatus::INLIER : gate == 3 ? VuOutlierStatus::CHI2 : VuOutlierStatus::NOT_COMPUTED;
+        res.outlierStatus = outlierStatusOfGate(gate);
         if (gate == 0) dirty();                       // applied, or inserted as a map point
         return res;
     }

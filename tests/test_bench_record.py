@@ -9,7 +9,7 @@ from contextlib import redirect_stdout
 import bench
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-FULL = os.path.join(HERE, "..", "profiles", "r04", "bench_default.json")            # a full object as a real run produced it
+FULL = os.path.join(HERE, "..", "profiles", "r05", "bench_default.json")            # a full object as a real run produced it
 
 TOP = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data")
 
@@ -30,8 +30,11 @@ def test_compact_record_fits_and_carries_the_contract():
     assert abs(d["ms_per_step"] - out["ms_per_step"]) < 1e-3 * out["ms_per_step"]
     cfg, roof, cpu = d["config"], d["roofline"], d["cpu_baseline"]
     for k in ("workload", "sequences_per_gpu", "engines_per_gpu", "frames_per_step", "parity_ok", "parity_checked_sequences",
-              "stage_frac_agreed", "stage_frac_actual", "one_engine_value", "lanes_2_value"):
+              "stage_frac_agreed", "stage_frac_actual", "one_engine_value", "lanes_2_value",
+              # r06 (VERDICT r05 missing #3): the north star's stage metric is quoted on configs[1] -- the C2 leg -- and must be in the line
+              "c2_value", "c2_stage_frac_agreed", "klt_ms_c2", "klt_ms_c3"):
         assert k in cfg, k
+    assert cfg["c2_stage_frac_agreed"] == float(f"{out['c2']['stage_pyramid_klt']['frac_of_8TBs']:.6g}")
     assert "model" not in cfg
     for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "algorithmic_bytes_per_launch", "avg_launch_ms"):
         assert k in roof, k

@@ -40,6 +40,12 @@ VARIANTS = {
     "fork_r03_arrangement": {"ekf_side_stream": 3, "ekf_visit_order": 2},   # long class on the second stream (r04 default: on the context stream)
     # r05: the long build stores the compact Jacobian behind its gate, for inliers only; 0 = for every prepared track, in front of the gate (r04)
     "jacobian_in_front_of_the_gate": {"ekf_defer_jacobian": 0},
+    # r06: the triangulation front as its own launch (vu_tri_kernel: a wavefront per short track, four per long track) + record-fed gates;
+    # 2 = at every batch size (default 1: where the two-per-CU build would run, i.e. above one filter per CU); 0 = r05's fused kernels
+    "split_tri": {"ekf_split_tri": 2, "ekf_visit_order": 2},
+    "split_tri_one_stream": {"ekf_split_tri": 2, "ekf_visit_order": 2, "ekf_side_stream": 0},
+    "split_tri_unsorted": {"ekf_split_tri": 2, "ekf_visit_order": 0},
+    "fused_front": {"ekf_split_tri": 0},
 }
 
 
@@ -638,7 +644,10 @@ def test_speculative_frame_loop_under_contention(variant, npose):
     (48, False, True, "long_two_launches", 21), (48, False, True, "long_two_launches_sorted", 21), (48, False, True, "long_two_launches_one_stream", 21),
     (48, False, True, "sorted_small_batch", 21), (48, False, True, "sorted_one_stream", 21), (48, False, True, "fork_r03_arrangement", 21),
     (300, False, True, "fork_r03_arrangement", 21),
-    (300, False, True, "default", 21), (300, False, True, "one_stream", 21), (300, False, True, "long_two_launches", 21)])
+    (300, False, True, "default", 21), (300, False, True, "one_stream", 21), (300, False, True, "long_two_launches", 21),
+    # r06: the split form (default above one filter per CU) at small batches, on one stream, in filter order; r05's fused kernels behind the knob
+    (48, False, True, "split_tri", 21), (48, False, True, "split_tri_one_stream", 21), (48, False, True, "split_tri_unsorted", 21),
+    (48, False, True, "split_tri", 10), (300, False, True, "fused_front", 21), (300, False, True, "split_tri_one_stream", 21)])
 def test_whole_frame_loop_with_ragged_track_lengths(oracle, B, speculative, stereo, variant, np_max):
     """hv_ekf_visual_frame_ragged_dev: the sequences of a batch do not share track lengths -- every (visit, filter) record has its own
     pose count (2 .. n_poses_max, 0 = this filter has no candidate at this visit), padded to the longest. Result = the reference's
