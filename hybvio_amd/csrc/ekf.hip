@@ -2514,7 +2514,7 @@ static int visual_track_dev_impl(hv_ekf *h, const hv_vu_params *p, int np, const
         a.fused = split_gate ? 2 : 1; a.H = nullptr; a.Hc = e->vuH; a.acol = e->vuacol; a.na_max = 7 * np + 1; a.P = e->P;
         a.rd_gate = r_gate * r_gate * ns; a.noise_scale = ns; a.chi2 = chi2_dev;
         if (!split_gate) { a.inl_count = cnt_inl; a.inl_list = list_inl; }
-        rc = hv::launch_vu_prepare(c, a);
+        { int rc_s = HV_OK; rc = (!split_gate && split_launch(a, main_stream, &rc_s)) ? rc_s : hv::launch_vu_prepare(c, a); }
         if (rc != HV_OK) return rc;
         if (split_gate) {
             rc = hv::ekf_launch_sparse_gate(e, np, a.stereo ? 2 : 1, e->vuH, e->vuv, e->vuacol, nr_rec, e->vuactive, a.rd_gate, chi2_dev, gate_status_dev,

@@ -507,7 +507,13 @@ __device__ __forceinline__ double sparse_gate(const double *P, int n, const int 
         // sums are formed in one order whatever the waves' timing -- chi2 and the gate status are reproducible to the bit, run to run.
         // (r03 / r04 added them with ds_add_f64 as the waves arrived: up to ~1 ulp of S between two runs.) Deadlock-free: every wave
         // takes its items in rising order, an item only ever waits for a lower one. The matrix work is done before the wait.
-        while (__hip_atomic_load(&gate_turn[CT], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != J) __builtin_amdgcn_s_sleep(1);
+        // (r05 advisor: the wait is only sound while the dealing above hands every wave its items in RISING order and all waves of the
+        //  workgroup are resident -- both true by construction here; a change of the slot table that breaks it must fail loudly, not hang
+        //  the GPU: the spin is bounded at ~30 ms, far beyond any gate, and traps)
+        for (int spin = 0; __hip_atomic_load(&gate_turn[CT], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != J; ++spin) {
+            if (spin > (1 << 19)) __builtin_trap();
+            __builtin_amdgcn_s_sleep(1);
+        }
 #pragma unroll
         for (int r = 0; r < NR; r++) {
 #pragma unroll

@@ -77,6 +77,22 @@ typedef short short2v __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ gptr_u8 as_global(const uint8_t *p) { return (gptr_u8)(uintptr_t)p; }
 
+// Row loads of the border-free paths go through RAW BUFFER instructions (r06): address = descriptor base (4 SGPRs, wave-uniform) +
+// soffset (an SGPR: the row's byte offset, one s_add per row) + voffset (the lane's byte offset, formed once per level). The global_load
+// forms of r01 .. r05 cost a 64-bit VALU add per load wherever hipcc hoisted base + lane offset into a VGPR pair (v_lshl_add_u64: 68 per
+// feature on the stored-gradient levels, profiles/r06/klt_static_census_r05.txt) and 4 scalar instructions per row for the 64-bit row base.
+// Every offset is >= 0: the descriptor base is the SLOT (levels >= 1: the level's offset rides in soffset, padded rows lie behind the
+// slot base) or the caller's level-0 image (inside paths only).
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const uint8_t *p)
+{
+    // the pointer is wave-uniform by construction (one feature per wave) but comes out of per-lane loads: v_readfirstlane pins the
+    // descriptor to SGPRs once per level (left alone, every buffer_load re-reads its four dwords from VGPRs)
+    const uint64_t v = reinterpret_cast<uint64_t>(p);
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+    return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<uint8_t *>(((uint64_t)hi << 32) | lo), 0, -1 /* no range limit */, 0x00020000);
+}
+
 // v_dot2_i32_i16: a.lo*b.lo + a.hi*b.hi + c on packed int16 pairs (a 32-bit v_mul_lo_u32 is
 // quarter-rate on CDNA and every operand here fits 16 bits). clamp=true selects the 3-operand
 // VOP3P encoding, which takes an inline 0 / a separate accumulator; without it hipcc emits the
@@ -222,8 +238,6 @@ __global__ __launch_bounds__(64, WPS) void klt_kernel(KltArgs a)
     // fast tile staging: lane (st_lr, st_c) = row-in-pass, 4-pixel group; lanes beyond RPI * G repeat the last item
     constexpr int G = TSX / 4, RPI = 64 / G, NIT = TSY / RPI;
     static_assert(TSY % RPI == 0, "whole passes: no row clamp in the staging loop");
-    const int st_ln = min(lane, RPI * G - 1), st_lr = st_ln / G, st_c = st_ln - st_lr * G;
-    const int st_loff = st_lr * TSX + 4 * st_c;
     const float half_win = (float)(WIN - 1) * 0.5f;
     const float FLT_SCALE = 1.f / (float)(1 << 20);
     // uniform: pinned to SGPRs (the f64 -> f32 conversions are VALU instructions; left alone their results occupy two VGPRs for the
@@ -268,6 +282,10 @@ __global__ __launch_bounds__(64, WPS) void klt_kernel(KltArgs a)
         Igs = __builtin_amdgcn_readfirstlane(Igs); Jgs = __builtin_amdgcn_readfirstlane(Jgs);   // wave-uniform: keep them in SGPRs
         const gptr_u32 Id = (gptr_u32)as_global(prev_base + L.doff[level]);
         const int Ids = __builtin_amdgcn_readfirstlane(L.dstride[level]);
+        // buffer descriptors of the level's planes and the byte offset of the plane's origin inside them (see make_rsrc)
+        const __amdgpu_buffer_rsrc_t rI = make_rsrc(level == 0 ? a.l0_ptr[sp] : prev_base), rJ = make_rsrc(level == 0 ? a.l0_ptr[sn] : next_base),
+                                     rD = make_rsrc(prev_base);
+        const int g0 = level == 0 ? 0 : (int)L.goff[level], d0 = (int)L.doff[level], j0 = g0;
         // levels with a physical 32-px border (REFLECT_101 gray, zero gradients in memory, see PyrLayout): every window the
         // range test above lets through lies inside the padded rectangle, so the border-free paths serve all of them
         const bool padded = L.pad[level] != 0;                                             // wave-uniform
@@ -278,6 +296,12 @@ __global__ __launch_bounds__(64, WPS) void klt_kernel(KltArgs a)
         // together with the template rows, one memory round trip per level instead of three) ----
         float cxn = nx - half_win, cyn = ny - half_win;
         int tox = -(1 << 28), toy = -(1 << 28);
+        // (r06) the staging lane constants are re-derived per level from an opaque copy of the lane id: hoisted to the kernel prologue
+        // they were the three VGPRs the 5-wave build kept in scratch (12 VALU per level against 206 MB of scratch write-back per launch)
+        int st_lane = lane;
+        asm volatile("" : "+v"(st_lane));
+        const int st_ln = min(st_lane, RPI * G - 1), st_lr = (int)(__umul24((unsigned)st_ln, (unsigned)((65536 + G - 1) / G)) >> 16), st_c = st_ln - st_lr * G;
+        const int st_loff = st_lr * TSX + 4 * st_c;
         const unsigned st_goff = __umul24((unsigned)st_lr, (unsigned)Jgs) + 4u * (unsigned)st_c;   // lane part of the staging loads
         const bool j_aligned = ((reinterpret_cast<uintptr_t>(Jg) | (uintptr_t)Jgs) & 3u) == 0;
         // origin of the tile that holds window (ix, iy); true when the plain coalesced staging loop can load it
@@ -299,10 +323,12 @@ __global__ __launch_bounds__(64, WPS) void klt_kernel(KltArgs a)
         // (LDS offset); the per-lane part (st_goff, st_loff) is formed once per level. r01 stepped a flat item index
         // through the tile instead: ~9 VALU of index arithmetic per item, 163 per staging against ~9 per pass here.
         auto tile_request = [&](uint2 (&raw)[NIT]) {
+            int tb = j0 + toy * Jgs + tox, tstep = RPI * Jgs;
+            asm volatile("" : "+s"(tb), "+s"(tstep));
 #pragma unroll
             for (int i = 0; i < NIT; ++i) {
-                const long long rowbase = (long long)((toy + i * RPI) * Jgs + tox);                          // scalar, signed
-                __builtin_memcpy(&raw[i], (const void *)(uintptr_t)(Jg + rowbase + st_goff), 8);
+                const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(rJ, st_goff, tb + i * tstep, 0);   // (scalar row offset: one s_add per pass)
+                raw[i] = make_uint2(v.x, v.y);
             }
         };
         auto tile_commit = [&](const uint2 (&raw)[NIT]) {
@@ -333,6 +359,7 @@ __global__ __launch_bounds__(64, WPS) void klt_kernel(KltArgs a)
             // -- an unsigned VGPR offset of the saddr addressing mode -- stays >= 0)
             const unsigned vg = __umul24((unsigned)(half * HALF_ROWS), (unsigned)Igs) + (unsigned)cx;      // rows and strides < 2^24:
             const unsigned vd = __umul24((unsigned)(half * HALF_ROWS), (unsigned)Ids) + (unsigned)cx;      // full-rate v_mul_u32_u24
+            const unsigned vd4 = 4u * vd;                                                                  // ... as the byte offset of the buffer loads
 
             // DESCALE(s, 9) == (128 s + 32768) >> 16 and DESCALE(s, 14) == (4 s + 32768) >> 16: the
             // inputs are pre-scaled by 128 / 4 and carry the +2 that sums to 32768, so each sample is
@@ -375,11 +402,10 @@ __global__ __launch_bounds__(64, WPS) void klt_kernel(KltArgs a)
                 uint2 raw[NIT];
                 uint32_t q[NQ];
                 tile_request(raw);
+                int qb = g0 + (ipy - 1) * Igs + ipx - 1, qstep = Igs;                          // scalar: one s_add per row below
+                asm volatile("" : "+s"(qb), "+s"(qstep));                                        // (opaque: see the gradient rows below)
 #pragma unroll
-                for (int r = 0; r < NQ; ++r) {
-                    const gptr_u8 grow = Ig + (long long)((ipy - 1 + r) * Igs + ipx - 1);         // scalar, signed
-                    __builtin_memcpy(&q[r], (const void *)(uintptr_t)(grow + vg), 4);
-                }
+                for (int r = 0; r < NQ; ++r) q[r] = __builtin_amdgcn_raw_buffer_load_b32(rI, vg, qb + r * qstep, 0);
                 __builtin_amdgcn_sched_barrier(0);       // everything in flight before the first use
                 tile_commit(raw);
                 ScharrRow ra = scharr_row(q[0]), rb = scharr_row(q[1]), rc = scharr_row(q[2]);
@@ -397,12 +423,14 @@ __global__ __launch_bounds__(64, WPS) void klt_kernel(KltArgs a)
                 uint16_t graw[NR];
                 uint2 draw[NR];
                 tile_request(raw);
+                int gb = g0 + ipy * Igs + ipx, gstep = Igs;
+                int db = d0 + 4 * (ipy * Ids + ipx), dstep = 4 * Ids;                            // scalar: one s_add per load below
+                asm volatile("" : "+s"(gb), "+s"(gstep), "+s"(db), "+s"(dstep));                 // (opaque: hipcc re-derives 4 * ((ipy + r) * Ids + ipx) per row otherwise: 3 scalar instructions per load)
 #pragma unroll
                 for (int r = 0; r < NR; ++r) {
-                    const gptr_u8 grow = Ig + (long long)((ipy + r) * Igs + ipx);                 // scalar, signed
-                    const gptr_u32 drow = Id + (long long)((ipy + r) * Ids + ipx);
-                    __builtin_memcpy(&graw[r], (const void *)(uintptr_t)(grow + vg), 2);
-                    __builtin_memcpy(&draw[r], (const void *)(uintptr_t)(drow + vd), 8);
+                    graw[r] = __builtin_amdgcn_raw_buffer_load_b16(rI, vg, gb + r * gstep, 0);
+                    const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(rD, vd4, db + r * dstep, 0);
+                    draw[r] = make_uint2(v.x, v.y);
                 }
                 __builtin_amdgcn_sched_barrier(0);       // everything in flight before the first use
                 tile_commit(raw);
@@ -430,10 +458,7 @@ __global__ __launch_bounds__(64, WPS) void klt_kernel(KltArgs a)
                     uint32_t q[NB + 2];
                     if (inside) {
 #pragma unroll
-                        for (int r = 0; r < NB + 2; ++r) {
-                            const gptr_u8 grow = Ig + (long long)((ipy + r0 - 1 + r) * Igs + ipx - 1);   // scalar, signed
-                            __builtin_memcpy(&q[r], (const void *)(uintptr_t)(grow + vg), 4);
-                        }
+                        for (int r = 0; r < NB + 2; ++r) q[r] = __builtin_amdgcn_raw_buffer_load_b32(rI, vg, g0 + (ipy + r0 - 1) * Igs + ipx - 1 + r * Igs, 0);
                     } else {
                         // virtual border: BORDER_REFLECT_101 gray for the samples AND for the stencils of the pixels inside the
                         // image (what cv::calcSharrDeriv sees on the padded level); gradients outside the image are 0
@@ -473,10 +498,9 @@ __global__ __launch_bounds__(64, WPS) void klt_kernel(KltArgs a)
                     uint2 draw[NB];
 #pragma unroll
                     for (int r = 0; r < NB; ++r) {
-                        const gptr_u8 grow = Ig + (long long)((ipy + r0 + r) * Igs + ipx);        // scalar, signed
-                        const gptr_u32 drow = Id + (long long)((ipy + r0 + r) * Ids + ipx);
-                        __builtin_memcpy(&graw[r], (const void *)(uintptr_t)(grow + vg), 2);
-                        __builtin_memcpy(&draw[r], (const void *)(uintptr_t)(drow + vd), 8);
+                        graw[r] = __builtin_amdgcn_raw_buffer_load_b16(rI, vg, g0 + (ipy + r0) * Igs + ipx + r * Igs, 0);
+                        const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(rD, vd4, d0 + 4 * ((ipy + r0) * Ids + ipx) + r * (4 * Ids), 0);
+                        draw[r] = make_uint2(v.x, v.y);
                     }
 #pragma unroll
                     for (int r = 0; r < NB; ++r) {

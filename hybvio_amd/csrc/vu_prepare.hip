@@ -19,10 +19,13 @@
 namespace hv {
 // developer aid: s_memtime stamps of workgroup 0 at the phase boundaries (only with -DHV_EKF_PHASE_STAMPS)
 __device__ long long g_vu_stamp[40];
+__device__ long long g_tri_stamp[64];
 #ifdef HV_EKF_PHASE_STAMPS
 #define VU_STAMP(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_vu_stamp[i] = (long long)__builtin_readcyclecounter(); } while (0)
+#define TRI_STAMP(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_tri_stamp[i] = (long long)__builtin_readcyclecounter(); } while (0)
 #else
 #define VU_STAMP(i) do { } while (0)
+#define TRI_STAMP(i) do { } while (0)
 #endif
 namespace {
 
@@ -143,12 +146,13 @@ __device__ __forceinline__ double norm1_3(const double *M)
 // dEblock' * Eblock + Eblock' * dEblock to dM. o = the pose record of this iteration (C t h E err d).
 // MODE 0: dC = dt = 0 (the plain part); 1: both given (false / true of r01 .. r05's bool parameter); 2 (r06): dt only -- a position
 // component moves t of the pose and leaves C alone
+// ih2_given (r06): 1 / h_z of the pose record as the per-pose phase computed it (the same value: one f64 division sequence per pair less)
 template <int MODE>
 __device__ __forceinline__ void pair_sums(const double *o, const double *dh, const double *dC, const double *dt, double vel0,
-                                          double vel1, double *dEe, double *dM)
+                                          double vel1, double *dEe, double *dM, const double *ih2_given = nullptr)
 {
     const double *C = o, *t = o + 9, *h = o + 12, *E = o + 15, *er = o + 21;
-    const double ih2 = 1.0 / h[2], ih2sq = ih2 * ih2;
+    const double ih2 = ih2_given ? *ih2_given : 1.0 / h[2], ih2sq = ih2 * ih2;
     const double dih2 = -dh[2] * ih2sq, dih2sq = -2 * dh[2] * ih2sq * ih2;
     double dErr[2], dE[6];
 #pragma unroll
@@ -1136,16 +1140,30 @@ __device__ __forceinline__ void vu_prepare_body(const VuPrepareArgs &a, const in
 // never meet LDS either; the pose-0 sums and the plain part's maps go through one scratch area in a fixed order (deterministic).
 // Reference: triangulation.cpp:65-103,120-407,612-716,897-947; backend.cpp:1098-1119.
 // ---------------------------------------------------------------------------------------------
-struct TriLds {                       // run-time carve of the dynamic LDS (doubles) for tracks of up to ntm camera poses / nm poses
-    int trail, it, dpfi, feat, small, dpf, scr, lsum, tot, ints, total;
-    __host__ __device__ TriLds(int ntm, int nm)
+constexpr int TRI_ITW = 28;         // pose record of an iteration: ITER_WORDS + 1 / h_z (+ pad)
+struct TriLds {                       // run-time carve of the dynamic LDS (doubles) for tracks of up to ntm camera poses
+    int trail, it, dpfi, feat, small, scr, lsum, tot, ints, total;
+    __host__ __device__ TriLds(int ntm)
     {
-        trail = 0; it = trail + ntm * POSE_WORDS; dpfi = it + ntm * ITER_WORDS; feat = dpfi + 3 * (7 * ntm + 1);
-        (void)nm;
-        small = feat + 4 * ntm; dpf = small + 72; scr = dpf; lsum = scr + 4 * ntm * 9; tot = lsum + 32; ints = tot + 64;
+        trail = 0; it = trail + ntm * POSE_WORDS; dpfi = it + ntm * TRI_ITW; feat = dpfi + 3 * (7 * ntm + 1);
+        small = feat + 4 * ntm; scr = small + 72; lsum = scr + 7 * ntm * 9; tot = lsum + 32; ints = tot + 64;
         total = ints + (MAXNP + 3 + 4 + 1) / 2 + 1;
     }
 };
+
+// sum of n terms base[(first + k) * stride], k = part, part + parts, ... -- four loads in flight per step (a lane per sum walking
+// dependent LDS reads is a chain of ~130-cycle round trips: 5.6 k cycles for the 42 terms of a 21-pose track, profiles/r06/tri_stamps.txt)
+__device__ __forceinline__ double strided_sum(const double *base, int stride, int n, int part, int parts)
+{
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+    int k = part;
+    for (; k + 3 * parts < n; k += 4 * parts) {
+        a0 += base[(size_t)k * stride]; a1 += base[(size_t)(k + parts) * stride];
+        a2 += base[(size_t)(k + 2 * parts) * stride]; a3 += base[(size_t)(k + 3 * parts) * stride];
+    }
+    for (; k < n; k += parts) a0 += base[(size_t)k * stride];
+    return (a0 + a1) + (a2 + a3);
+}
 
 template <int NT>
 __device__ __forceinline__ void vu_tri_body(const VuPrepareArgs &a, const int b)
@@ -1162,13 +1180,14 @@ __device__ __forceinline__ void vu_tri_body(const VuPrepareArgs &a, const int b)
     const int nt_max = a.np * ncam;
     const int dDim = nt * 7, ncol = dDim + 1;
     const int np_carve = a.np_hi > 0 && a.np_hi < a.np ? a.np_hi : a.np;      // the longest track of THIS launch (launch_vu_tri sizes the LDS by it)
-    const TriLds L(np_carve * ncam, np_carve);
+    const TriLds L(np_carve * ncam);
     double *s_trail = vu_lds + L.trail, *s_it = vu_lds + L.it, *s_dpfi = vu_lds + L.dpfi, *s_feat = vu_lds + L.feat;
     double *s_small = vu_lds + L.small, *s_scr = vu_lds + L.scr, *s_L = vu_lds + L.lsum, *s_tot = vu_lds + L.tot;
     int *s_idx = reinterpret_cast<int *>(vu_lds + L.ints), *s_flag = s_idx + MAXNP + 3;
     const double *m = a.m + (size_t)b * N;
     double *pfi = s_small, *pfw = s_small + 3, *R0T = s_small + 18, *scal = s_small + 36, *sums13 = s_small + 52;
     auto sync = [] { lds_barrier(); };
+    TRI_STAMP(0);
     if (tid < n) s_idx[tid] = a.pose_index[rec * a.np + tid];
     if (tid < nt) {
 #pragma unroll
@@ -1178,6 +1197,7 @@ __device__ __forceinline__ void vu_tri_body(const VuPrepareArgs &a, const int b)
         }
     }
     sync();
+    TRI_STAMP(1);
     // ---- extractCameraPoseTrail (triangulation.cpp:65-103) ----
     if (tid < nt) {
         const int cam = tid / n, k = tid - cam * n;
@@ -1205,6 +1225,7 @@ __device__ __forceinline__ void vu_tri_body(const VuPrepareArgs &a, const int b)
     }
     for (int i = tid; i < 3 * ncol; i += NT) s_dpfi[i] = 0.0;
     sync();
+    TRI_STAMP(2);
     const double *p0 = s_trail;
     // ---- triangulateWithTwoCameras between pose 0 and pose ind1 (:154-173, 612-716): lane j < 15 owns derivative column j ----
     const int ind1 = a.stereo ? nt / 2 - 1 : nt - 1;
@@ -1287,6 +1308,7 @@ __device__ __forceinline__ void vu_tri_body(const VuPrepareArgs &a, const int b)
         }
     }
     sync();
+    TRI_STAMP(3);
     // ---- Gauss-Newton with derivatives (:206-343) ----
     const double *Lm = s_L;
     // column j of dpfi takes its step: (dEe_j, dM_j) = L' d_j + the motion sums `own` (dEe[3], upper dM[6]) -- or, for the time-shift
@@ -1313,10 +1335,16 @@ __device__ __forceinline__ void vu_tri_body(const VuPrepareArgs &a, const int b)
 #pragma unroll
         for (int r = 0; r < 3; ++r) s_dpfi[r * ncol + j] += t2[r] - t3[r];
     };
+    // lanes per sum of the reductions below
+    constexpr int PARTS_L = NT >= 240 ? 8 : NT >= 120 ? 4 : 2;          // 30 sums: L[u][e] and c_t
+    constexpr int PARTS_T = NT >= 252 ? 4 : NT >= 126 ? 2 : 1;          // 63 sums: the pose-0 totals
+    const int NC = 4 * nt, NPp = 3 * (nt - 1), NQ = 4 * (nt - 1);       // pair tasks by type
     for (int it = 0; it < a.gn_iters; ++it) {
+#define TRI_IT_STAMP(k) do { if (it < 5) TRI_STAMP(4 + 10 * it + (k)); } while (0)
+        TRI_IT_STAMP(0);
         if (tid < nt) {                                       // per-pose quantities of this iteration
             const double *cur = s_trail + tid * POSE_WORDS;
-            double *o = s_it + tid * ITER_WORDS;
+            double *o = s_it + tid * TRI_ITW;
             double C[9], t[3], d[3], h[3];
             mm3(cur + 3, R0T, C);
 #pragma unroll
@@ -1331,6 +1359,7 @@ __device__ __forceinline__ void vu_tri_body(const VuPrepareArgs &a, const int b)
             for (int k = 0; k < 9; ++k) o[k] = C[k];
 #pragma unroll
             for (int k = 0; k < 3; ++k) { o[9 + k] = t[k]; o[12 + k] = h[k]; o[23 + k] = d[k]; }
+            o[26] = ih2;
 #pragma unroll
             for (int r = 0; r < 2; ++r) {
 #pragma unroll
@@ -1340,17 +1369,22 @@ __device__ __forceinline__ void vu_tri_body(const VuPrepareArgs &a, const int b)
             }
         }
         sync();
+        TRI_IT_STAMP(1);
         // ETE (9), Eerror (3), error2: entry k = sum over the poses of o[x0] o[y0] + o[x0 + dx] o[y0 + dy], four adjacent lanes each
         if (tid < 52) {
             const int k = tid >> 2, part = tid & 3;
             const int r = k / 3, c = k - 3 * r;
             const int x0 = k < 9 ? 15 + r : k < 12 ? 15 + (k - 9) : 21, y0 = k < 9 ? 15 + c : 21;
             const int dx = k < 12 ? 3 : 1, dy = k < 9 ? 3 : 1;
-            double acc = 0.0;
-            for (int i = part; i < nt; i += 4) {
-                const double *o = s_it + i * ITER_WORDS;
+            double acc = 0.0, acc2 = 0.0;
+            int i = part;
+            for (; i + 4 < nt; i += 8) {
+                const double *o = s_it + i * TRI_ITW, *o2 = o + 4 * TRI_ITW;
                 acc += o[x0] * o[y0] + o[x0 + dx] * o[y0 + dy];
+                acc2 += o2[x0] * o2[y0] + o2[x0 + dx] * o2[y0 + dy];
             }
+            if (i < nt) { const double *o = s_it + i * TRI_ITW; acc += o[x0] * o[y0] + o[x0 + dx] * o[y0 + dy]; }
+            acc += acc2;
             acc += __shfl_xor(acc, 1);
             acc += __shfl_xor(acc, 2);
             if (part == 0) sums13[k] = acc;
@@ -1361,16 +1395,34 @@ __device__ __forceinline__ void vu_tri_body(const VuPrepareArgs &a, const int b)
             if (t0 >= 0)
                 for (int task = t0; task < 3 * nt; task += tstep) {
                     const int i = task / 3, u = task - 3 * i;
-                    const double *o = s_it + i * ITER_WORDS;
+                    const double *o = s_it + i * TRI_ITW;
                     const double dh[3] = {u < 2 ? o[u] : o[9], u < 2 ? o[3 + u] : o[10], u < 2 ? o[6 + u] : o[11]};
                     double e3[3] = {0, 0, 0}, m9[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-                    pair_sums<0>(o, dh, nullptr, nullptr, 0.0, 0.0, e3, m9);
+                    pair_sums<0>(o, dh, nullptr, nullptr, 0.0, 0.0, e3, m9, o + 26);
                     double *dst = s_scr + task * 9;
                     dst[0] = e3[0]; dst[1] = e3[1]; dst[2] = e3[2];
                     dst[3] = m9[0]; dst[4] = m9[1]; dst[5] = m9[2]; dst[6] = m9[4]; dst[7] = m9[5]; dst[8] = m9[8];
                 }
         }
         sync();
+        TRI_IT_STAMP(2);
+        // L[u][e] = sum over the poses of the plain part's maps (27), c_t = sum_i E_i' vel_i (3): PARTS_L adjacent lanes each
+        if (tid < 30 * PARTS_L) {
+            const int sigma = tid / PARTS_L, part = tid - sigma * PARTS_L;
+            double acc;
+            if (sigma < 27) {
+                const int u = sigma / 9, e = sigma - 9 * u;
+                acc = strided_sum(s_scr + u * 9 + e, 27, nt, part, PARTS_L);
+            } else {
+                const int r = sigma - 27;
+                acc = 0.0;
+                for (int q = part; q < nt; q += PARTS_L)
+                    acc += s_it[q * TRI_ITW + 15 + r] * s_feat[4 * q + 2] + s_it[q * TRI_ITW + 18 + r] * s_feat[4 * q + 3];
+            }
+#pragma unroll
+            for (int o = 1; o < PARTS_L; o <<= 1) acc += __shfl_xor(acc, o);
+            if (part == 0) s_L[sigma] = acc;
+        }
         // every lane: X = (E'E)^-1 and the step, in registers (the column updates below use them)
         double X[9], step[3];
         {
@@ -1381,112 +1433,103 @@ __device__ __forceinline__ void vu_tri_body(const VuPrepareArgs &a, const int b)
             for (int q = 0; q < 3; ++q) Ee[q] = sums13[9 + q];
             inv3sym(ETE, X);
             mv3(X, Ee, step);
-            if (tid == 0) { scal[0] = sums13[12]; scal[1] = 1.0 / (norm1_3(ETE) * norm1_3(X)); }
         }
-        // L[u][e] = sum over the poses of the plain part's maps (27), c_t = sum_i E_i' vel_i (3): two adjacent lanes each
-        if (tid < 60) {
-            const int sigma = tid >> 1, part = tid & 1;
-            double acc = 0.0;
-            if (sigma < 27) {
-                const int u = sigma / 9, e = sigma - 9 * u;
-                for (int q = part; q < nt; q += 2) acc += s_scr[(3 * q + u) * 9 + e];
+        sync();
+        TRI_IT_STAMP(3);
+        // ---- the motion pairs, one task per lane, by type (header): C -> scratch [3 + q][i][9]; P -> scratch [c][i][9] and the own
+        // column's update with -r; Q -> the own column's update. (the plain part's maps in the scratch are dead: L is in s_L) ----
+        for (int e = tid; e < NC + NPp + NQ; e += NT) {
+            if (e < NC) {
+                const int q = e / nt, i = e - q * nt;
+                const double *cur = s_trail + i * POSE_WORDS, *dR0 = s_trail + 12 + 9 * q, *o = s_it + i * TRI_ITW;
+                double dC[9], dt[3], dp0[3], dh[3], e3[3] = {0, 0, 0}, m9[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+                mmT3(cur + 3, dR0, dC);
+                mTv3(dR0, s_trail + 48, dp0);
+                const double dd[3] = {-dp0[0], -dp0[1], -dp0[2]};
+                mv3(cur + 3, dd, dt);
+                if (i == 0) {                                     // pose 0 itself: both rotations move, the positions cancel
+                    double a1[9];
+                    mm3(dR0, R0T, a1);
+#pragma unroll
+                    for (int k = 0; k < 9; ++k) dC[k] += a1[k];
+                    dt[0] = 0.0; dt[1] = 0.0; dt[2] = 0.0;
+                }
+#pragma unroll
+                for (int r = 0; r < 3; ++r) dh[r] = (dC[3 * r] * pfi[0] + dC[3 * r + 1] * pfi[1] + dC[3 * r + 2]) + pfi[2] * dt[r];
+                pair_sums<1>(o, dh, dC, dt, 0.0, 0.0, e3, m9, o + 26);
+                double *dst = s_scr + ((3 + q) * nt + i) * 9;
+                dst[0] = e3[0]; dst[1] = e3[1]; dst[2] = e3[2];
+                dst[3] = m9[0]; dst[4] = m9[1]; dst[5] = m9[2]; dst[6] = m9[4]; dst[7] = m9[5]; dst[8] = m9[8];
+            } else if (e < NC + NPp) {
+                const int e2 = e - NC, c = e2 / (nt - 1), i = 1 + e2 - c * (nt - 1);
+                const double *cur = s_trail + i * POSE_WORDS, *o = s_it + i * TRI_ITW;
+                const double dt[3] = {cur[3 + c], cur[6 + c], cur[9 + c]};          // R_i(:, c)
+                const double dh[3] = {pfi[2] * dt[0], pfi[2] * dt[1], pfi[2] * dt[2]};
+                double e3[3] = {0, 0, 0}, m9[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+                pair_sums<2>(o, dh, nullptr, dt, 0.0, 0.0, e3, m9, o + 26);
+                const double r9[9] = {e3[0], e3[1], e3[2], m9[0], m9[1], m9[2], m9[4], m9[5], m9[8]};
+                double *dst = s_scr + (c * nt + i) * 9;
+                double own[9];
+#pragma unroll
+                for (int k = 0; k < 9; ++k) { dst[k] = r9[k]; own[k] = -r9[k]; }
+                update_col(7 * i + c, own, false, X, step);
             } else {
-                const int r = sigma - 27;
-                for (int q = part; q < nt; q += 2)
-                    acc += s_it[q * ITER_WORDS + 15 + r] * s_feat[4 * q + 2] + s_it[q * ITER_WORDS + 18 + r] * s_feat[4 * q + 3];
+                const int e2 = e - NC - NPp, q = e2 / (nt - 1), i = 1 + e2 - q * (nt - 1);
+                const double *cur = s_trail + i * POSE_WORDS, *dR = cur + 12 + 9 * q, *o = s_it + i * TRI_ITW;
+                double dC[9], dt[3], dpi[3], t1[3], t2[3], dh[3], e3[3] = {0, 0, 0}, m9[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+                mm3(dR, R0T, dC);
+                mTv3(dR, cur + 48, dpi);
+                mv3(dR, o + 23, t1);
+                mv3(cur + 3, dpi, t2);
+#pragma unroll
+                for (int k = 0; k < 3; ++k) dt[k] = t1[k] + t2[k];
+#pragma unroll
+                for (int r = 0; r < 3; ++r) dh[r] = (dC[3 * r] * pfi[0] + dC[3 * r + 1] * pfi[1] + dC[3 * r + 2]) + pfi[2] * dt[r];
+                pair_sums<1>(o, dh, dC, dt, 0.0, 0.0, e3, m9, o + 26);
+                const double own[9] = {e3[0], e3[1], e3[2], m9[0], m9[1], m9[2], m9[4], m9[5], m9[8]};
+                update_col(7 * i + 3 + q, own, false, X, step);
             }
-            acc += __shfl_xor(acc, 1);
-            if (part == 0) s_L[sigma] = acc;
         }
         sync();
-        // ---- type C: pose-0 quaternion columns, pair (pose i, q) -> scratch [q][i][9] ----
-        for (int e = tid; e < 4 * nt; e += NT) {
-            const int q = e / nt, i = e - q * nt;
-            const double *cur = s_trail + i * POSE_WORDS, *dR0 = s_trail + 12 + 9 * q, *o = s_it + i * ITER_WORDS;
-            double dC[9], dt[3], dp0[3], dh[3], e3[3] = {0, 0, 0}, m9[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-            mmT3(cur + 3, dR0, dC);
-            mTv3(dR0, s_trail + 48, dp0);
-            const double dd[3] = {-dp0[0], -dp0[1], -dp0[2]};
-            mv3(cur + 3, dd, dt);
-            if (i == 0) {                                     // pose 0 itself: both rotations move, the positions cancel
-                double a1[9];
-                mm3(dR0, R0T, a1);
+        TRI_IT_STAMP(4);
+        // totals of the pose-0 columns (component, entry) over the poses, in a fixed order (position components: poses 1 ..)
+        if (tid < 63 * PARTS_T) {
+            const int sigma = tid / PARTS_T, part = tid - sigma * PARTS_T;
+            const int comp = sigma / 9, en = sigma - 9 * comp, first = comp < 3 ? 1 : 0;
+            double acc = strided_sum(s_scr + ((size_t)comp * nt + first) * 9 + en, 9, nt - first, part, PARTS_T);
 #pragma unroll
-                for (int k = 0; k < 9; ++k) dC[k] += a1[k];
-                dt[0] = 0.0; dt[1] = 0.0; dt[2] = 0.0;
-            }
-#pragma unroll
-            for (int r = 0; r < 3; ++r) dh[r] = (dC[3 * r] * pfi[0] + dC[3 * r + 1] * pfi[1] + dC[3 * r + 2]) + pfi[2] * dt[r];
-            pair_sums<1>(o, dh, dC, dt, 0.0, 0.0, e3, m9);
-            double *dst = s_scr + e * 9;
-            dst[0] = e3[0]; dst[1] = e3[1]; dst[2] = e3[2];
-            dst[3] = m9[0]; dst[4] = m9[1]; dst[5] = m9[2]; dst[6] = m9[4]; dst[7] = m9[5]; dst[8] = m9[8];
+            for (int o = 1; o < PARTS_T; o <<= 1) acc += __shfl_xor(acc, o);
+            if (part == 0) s_tot[sigma] = acc;
         }
         sync();
-        if (tid < 36) {                                       // totals of the pose-0 quaternion columns (q, entry), poses in order
-            const int q = tid / 9, en = tid - 9 * q;
-            double acc = 0.0;
-            for (int i = 0; i < nt; ++i) acc += s_scr[(q * nt + i) * 9 + en];
-            s_tot[(3 + q) * 9 + en] = acc;
-        }
-        sync();
-        // ---- type P: own position columns (pose i >= 1, component c); +r to the pose-0 position totals through scratch [c][i - 1][9] ----
-        for (int e = tid; e < 3 * (nt - 1); e += NT) {
-            const int c = e / (nt - 1), i = 1 + e - c * (nt - 1);
-            const double *cur = s_trail + i * POSE_WORDS, *o = s_it + i * ITER_WORDS;
-            const double dt[3] = {cur[3 + c], cur[6 + c], cur[9 + c]};          // R_i(:, c)
-            const double dh[3] = {pfi[2] * dt[0], pfi[2] * dt[1], pfi[2] * dt[2]};
-            double e3[3] = {0, 0, 0}, m9[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-            pair_sums<2>(o, dh, nullptr, dt, 0.0, 0.0, e3, m9);
-            const double r9[9] = {e3[0], e3[1], e3[2], m9[0], m9[1], m9[2], m9[4], m9[5], m9[8]};
-            double *dst = s_scr + e * 9;
-            double own[9];
-#pragma unroll
-            for (int k = 0; k < 9; ++k) { dst[k] = r9[k]; own[k] = -r9[k]; }
-            update_col(7 * i + c, own, false, X, step);
-        }
-        // ---- type Q: own quaternion columns (pose i >= 1, q) ----
-        for (int e = tid; e < 4 * (nt - 1); e += NT) {
-            const int q = e / (nt - 1), i = 1 + e - q * (nt - 1);
-            const double *cur = s_trail + i * POSE_WORDS, *dR = cur + 12 + 9 * q, *o = s_it + i * ITER_WORDS;
-            double dC[9], dt[3], dpi[3], t1[3], t2[3], dh[3], e3[3] = {0, 0, 0}, m9[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-            mm3(dR, R0T, dC);
-            mTv3(dR, cur + 48, dpi);
-            mv3(dR, o + 23, t1);
-            mv3(cur + 3, dpi, t2);
-#pragma unroll
-            for (int k = 0; k < 3; ++k) dt[k] = t1[k] + t2[k];
-#pragma unroll
-            for (int r = 0; r < 3; ++r) dh[r] = (dC[3 * r] * pfi[0] + dC[3 * r + 1] * pfi[1] + dC[3 * r + 2]) + pfi[2] * dt[r];
-            pair_sums<1>(o, dh, dC, dt, 0.0, 0.0, e3, m9);
-            const double own[9] = {e3[0], e3[1], e3[2], m9[0], m9[1], m9[2], m9[4], m9[5], m9[8]};
-            update_col(7 * i + 3 + q, own, false, X, step);
-        }
-        sync();
-        if (tid < 27) {                                       // totals of the pose-0 position columns (c, entry), poses in order
-            const int c = tid / 9, en = tid - 9 * c;
-            double acc = 0.0;
-            for (int i = 0; i < nt - 1; ++i) acc += s_scr[(c * (nt - 1) + i) * 9 + en];
-            s_tot[c * 9 + en] = acc;
-        }
-        sync();
-        if (tid < 7) update_col(tid, s_tot + 9 * tid, false, X, step);
-        else if (tid == 7 && a.est_shift) update_col(dDim, nullptr, true, X, step);
-        sync();                                               // everybody is done with the old pfi
-        if (tid == 0) {                                       // :316-342
+        TRI_IT_STAMP(5);
+        if (tid < 8) {                                        // the 7 columns of pose 0 and the time-shift column: one code path
+            const bool sft = tid == 7;
+            if (!sft || a.est_shift) update_col(sft ? dDim : tid, s_tot + 9 * (sft ? 0 : tid), sft, X, step);
+        } else if (tid == NT - 1) {                             // :316-342 (everybody is done with the old pfi: the barrier above)
 #pragma unroll
             for (int k = 0; k < 3; ++k) pfi[k] -= step[k];
-            const double J = 0.5 * scal[0] / (a.conv_r * a.conv_r), Jd = fabs((J - scal[2]) / J);
+            const double J = 0.5 * sums13[12] / (a.conv_r * a.conv_r), Jd = fabs((J - scal[2]) / J);
             scal[2] = J;
             if (Jd < a.conv_threshold) s_flag[0] = 1;
         }
         sync();
+        TRI_IT_STAMP(6);
+#undef TRI_IT_STAMP
         if (s_flag[0]) break;
     }
+    TRI_STAMP(54);
     // ---- status, back to world coordinates (:345-392) ----
     double *M = s_small + 40, *pf0 = s_small + 49;
     if (tid == 0) {
         int status = HV_TRI_OK;
+        if (a.gn_iters > 0) {                                 // reciprocal condition number of the last iteration's E'E (:313-315)
+            double ETE[9], Xl[9];
+#pragma unroll
+            for (int q = 0; q < 9; ++q) ETE[q] = sums13[q];
+            inv3sym(ETE, Xl);
+            scal[1] = 1.0 / (norm1_3(ETE) * norm1_3(Xl));
+        }
         if (!s_flag[0]) status = HV_TRI_NO_CONVERGENCE;
         else if (scal[1] < a.rcond_threshold) status = HV_TRI_BAD_COND;
         if (status == HV_TRI_OK) {
@@ -1504,76 +1547,77 @@ __device__ __forceinline__ void vu_tri_body(const VuPrepareArgs &a, const int b)
         s_flag[2] = 0;
     }
     sync();
+    TRI_STAMP(55);
     int status = s_flag[1];
-    if (status == HV_TRI_OK) {
-        for (int j = tid; j < ncol; j += NT) {
-            double u[3] = {0, 0, 0}, v[3];
-            if (j >= 3 && j < 7) mTv3(s_trail + 12 + 9 * (j - 3), pf0, u);
-            const double cur[3] = {s_dpfi[j], s_dpfi[ncol + j], s_dpfi[2 * ncol + j]};
-            mv3(M, cur, v);
-#pragma unroll
-            for (int r = 0; r < 3; ++r) s_dpfi[r * ncol + j] = u[r] + v[r] + (j == r ? 1.0 : 0.0);
-        }
-        if (tid < nt) {                                       // isBehind (:54-60)
-            const double *cur = s_trail + tid * POSE_WORDS;
-            const double d[3] = {pfw[0] - cur[0], pfw[1] - cur[1], pfw[2] - cur[2]};
-            if (cur[9] * d[0] + cur[10] * d[1] + cur[11] * d[2] < 0) atomicOr(&s_flag[2], 1);
-        }
-        sync();
-        if (s_flag[2]) status = HV_TRI_BEHIND;
-    }
-    {   // backend.cpp:1098-1102: depth window on whatever point the triangulation left behind
-        const double dx = pfw[0] - p0[0], dy = pfw[1] - p0[1], dz = pfw[2] - p0[2], depth = sqrt(dx * dx + dy * dy + dz * dz);
-        if (depth < a.min_dist || depth > a.max_dist) status = HV_TRI_BAD_DEPTH;
-    }
     double *recp = a.tri_rec + rec * (size_t)a.tri_stride;
     const int R_DPF = 17 * nt_max, R_SFT = R_DPF + 21 * a.np;
-    // backend.cpp:1108-1119: per-pose derivative blocks, the two cameras of a pose summed -- straight into the record
-    if (status == HV_TRI_OK) {
-        for (int i = tid; i < n * 21; i += NT) {
-            const int k = i / 21, e = i - 21 * k, r = e / 7, c = e - 7 * r;
-            double v = s_dpfi[r * ncol + 7 * k + c];
-            if (a.stereo) v += s_dpfi[r * ncol + 7 * (k + n) + c];
-            recp[R_DPF + i] = v;
+    // ---- prepareVisualUpdate, per-pose part (triangulation.cpp:897-947): dip R (2x3), dip dRpt (2x4), f, depth class; isBehind (:54-60).
+    // The last wave takes the poses, the others the columns' way back to world coordinates ----
+    {
+        const int t0 = NT > 64 ? tid - (NT - 64) : tid;
+        if (t0 >= 0 && t0 < nt) {
+            const double *pose = s_trail + t0 * POSE_WORDS;
+            double *o = recp + 17 * t0;
+            const double pt[3] = {pfw[0] - pose[0], pfw[1] - pose[1], pfw[2] - pose[2]};
+            if (status == HV_TRI_OK && pose[9] * pt[0] + pose[10] * pt[1] + pose[11] * pt[2] < 0) atomicOr(&s_flag[2], 1);
+            double pfc[3], ipH[3], dip[9];
+            mv3(pose + 3, pt, pfc);
+            inverse_depth(pfc, ipH, dip);
+            const double cls = pfc[2] == 0 ? 1.0 : pfc[2] < 0 ? 2.0 : 0.0;
+            o[16] = cls;
+            s_it[t0 * TRI_ITW + 16] = cls;
+            o[14] = ipH[0]; o[15] = ipH[1];
+#pragma unroll
+            for (int r = 0; r < 2; ++r)
+#pragma unroll
+                for (int c = 0; c < 3; ++c) o[3 * r + c] = dip[3 * r] * pose[3 + c] + dip[3 * r + 1] * pose[6 + c] + dip[3 * r + 2] * pose[9 + c];
+#pragma unroll
+            for (int jq = 0; jq < 4; ++jq) {
+                const double *dR = pose + 12 + 9 * jq;
+                double a1[3], b1[3], b2[3];
+                mv3(dR, pt, a1);
+                mTv3(dR, pose + 48, b1);
+                mv3(pose + 3, b1, b2);
+#pragma unroll
+                for (int r = 0; r < 2; ++r) o[6 + 4 * r + jq] = dip[3 * r] * (a1[0] + b2[0]) + dip[3 * r + 1] * (a1[1] + b2[1]) + dip[3 * r + 2] * (a1[2] + b2[2]);
+            }
         }
-        if (tid < 3) recp[R_SFT + tid] = a.est_shift ? s_dpfi[tid * ncol + dDim] : 0.0;
     }
-    // ---- prepareVisualUpdate, per-pose part (triangulation.cpp:897-947): dip R (2x3), dip dRpt (2x4), f, depth class ----
-    if (tid < nt) {
-        const double *pose = s_trail + tid * POSE_WORDS;
-        double *o = recp + 17 * tid;
-        const double pt[3] = {pfw[0] - pose[0], pfw[1] - pose[1], pfw[2] - pose[2]};
-        double pfc[3], ipH[3], dip[9];
-        mv3(pose + 3, pt, pfc);
-        inverse_depth(pfc, ipH, dip);
-        const double cls = pfc[2] == 0 ? 1.0 : pfc[2] < 0 ? 2.0 : 0.0;
-        o[16] = cls;
-        s_it[tid * ITER_WORDS + 16] = cls;
-        o[14] = ipH[0]; o[15] = ipH[1];
-#pragma unroll
-        for (int r = 0; r < 2; ++r)
-#pragma unroll
-            for (int c = 0; c < 3; ++c) o[3 * r + c] = dip[3 * r] * pose[3 + c] + dip[3 * r + 1] * pose[6 + c] + dip[3 * r + 2] * pose[9 + c];
-#pragma unroll
-        for (int jq = 0; jq < 4; ++jq) {
-            const double *dR = pose + 12 + 9 * jq;
-            double a1[3], b1[3], b2[3];
-            mv3(dR, pt, a1);
-            mTv3(dR, pose + 48, b1);
-            mv3(pose + 3, b1, b2);
-#pragma unroll
-            for (int r = 0; r < 2; ++r) o[6 + 4 * r + jq] = dip[3 * r] * (a1[0] + b2[0]) + dip[3 * r + 1] * (a1[1] + b2[1]) + dip[3 * r + 2] * (a1[2] + b2[2]);
-        }
+    if (status == HV_TRI_OK) {
+        // backend.cpp:1108-1119: per-pose derivative blocks in world coordinates (:345-392), the two cameras of a pose summed -- straight
+        // into the record: entry (k, r, c) = world(column 7 k + c)[r] + world(column 7 (k + n) + c)[r]
+        auto world = [&](int j, int r) -> double {
+            double u = 0.0;
+            if (j >= 3 && j < 7) { const double *dR = s_trail + 12 + 9 * (j - 3); u = dR[r] * pf0[0] + dR[3 + r] * pf0[1] + dR[6 + r] * pf0[2]; }   // (dR0' pf0)[r]
+            const double v = M[3 * r] * s_dpfi[j] + M[3 * r + 1] * s_dpfi[ncol + j] + M[3 * r + 2] * s_dpfi[2 * ncol + j];
+            return u + v + (j == r ? 1.0 : 0.0);
+        };
+        const int nlan = NT > 64 ? NT - 64 : NT;
+        if (tid < nlan)
+            for (int i = tid; i < n * 21; i += nlan) {
+                const int k = i / 21, e = i - 21 * k, r = e / 7, c = e - 7 * r;
+                double v = world(7 * k + c, r);
+                if (a.stereo) v += world(7 * (k + n) + c, r);
+                recp[R_DPF + i] = v;
+            }
+        if (tid < 3) recp[R_SFT + tid] = a.est_shift ? world(dDim, tid) : 0.0;
     }
     sync();
+    TRI_STAMP(56);
     if (tid == 0) {
+        if (status == HV_TRI_OK && s_flag[2]) status = HV_TRI_BEHIND;
+        {   // backend.cpp:1098-1102: depth window on whatever point the triangulation left behind
+            const double dx = pfw[0] - p0[0], dy = pfw[1] - p0[1], dz = pfw[2] - p0[2], depth = sqrt(dx * dx + dy * dy + dz * dz);
+            if (depth < a.min_dist || depth > a.max_dist) status = HV_TRI_BAD_DEPTH;
+        }
         int prep = 0;
-        for (int i = 0; i < nt && prep == 0; ++i) prep = (int)s_it[i * ITER_WORDS + 16];   // first failing pose decides (:920-927)
+        for (int i = 0; i < nt && prep == 0; ++i) prep = (int)s_it[i * TRI_ITW + 16];   // first failing pose decides (:920-927)
         recp[R_SFT + 3] = (double)prep;
         a.status[2 * rec] = status;
 #pragma unroll
         for (int k = 0; k < 3; ++k) a.pf[3 * rec + k] = pfw[k];
     }
+    TRI_STAMP(57);
 }
 
 // one wavefront per track: the short class (and every class of a small launch); listed / ordered like the gate launch it feeds
@@ -1586,6 +1630,22 @@ __global__ __launch_bounds__(64) void vu_tri_kernel(VuPrepareArgs a)
 }
 // four wavefronts per track: the long class, whose chain sets the visit's length
 __global__ __launch_bounds__(256) void vu_tri_kernel_x4(VuPrepareArgs a)
+{
+    int b = blockIdx.x;
+    if (a.rec_list) { if (b >= *a.rec_count) return; b = a.rec_list[b]; }
+    else if (a.order) b = __builtin_amdgcn_readfirstlane(a.order[blockIdx.x]);
+    vu_tri_body<256>(a, b);
+}
+// ... and two (knob vu_tri_threads)
+__global__ __launch_bounds__(128) void vu_tri_kernel_x2(VuPrepareArgs a)
+{
+    int b = blockIdx.x;
+    if (a.rec_list) { if (b >= *a.rec_count) return; b = a.rec_list[b]; }
+    else if (a.order) b = __builtin_amdgcn_readfirstlane(a.order[blockIdx.x]);
+    vu_tri_body<128>(a, b);
+}
+// four wavefronts at 128 VGPRs: four workgroups per CU (the short class's ~810 records of a 1024-filter visit resident at once)
+__global__ __launch_bounds__(256, 4) void vu_tri_kernel_x4s(VuPrepareArgs a)
 {
     int b = blockIdx.x;
     if (a.rec_list) { if (b >= *a.rec_count) return; b = a.rec_list[b]; }
@@ -1611,11 +1671,17 @@ __global__ __launch_bounds__(VT_THROUGHPUT, 4) void vu_gate_kernel_2percu(VuPrep
 }
 
 // record-fed gate builds (r06): the front has run as vu_tri_kernel; three of the short class's workgroups share a CU (48 KB each)
-constexpr int VT_REC = 256;
+constexpr int VT_REC = 256, VT_REC5 = 320;
 __global__ __launch_bounds__(VT_REC, 3) void vu_gate_rec_kernel(VuPrepareArgs a)
 {
     const int b = a.order ? __builtin_amdgcn_readfirstlane(a.order[blockIdx.x]) : (int)blockIdx.x;
     vu_prepare_body<VT_REC, MAXP_SMALL, 1, false, true>(a, b);
+}
+// five wavefronts: one per 16-row block of P(a, a) of the longest short track (78 active columns: 5 items of sparse_gate)
+__global__ __launch_bounds__(VT_REC5, 4) void vu_gate_rec5_kernel(VuPrepareArgs a)
+{
+    const int b = a.order ? __builtin_amdgcn_readfirstlane(a.order[blockIdx.x]) : (int)blockIdx.x;
+    vu_prepare_body<VT_REC5, MAXP_SMALL, 1, false, true>(a, b);
 }
 __global__ __launch_bounds__(VT_LATENCY, 3) void vu_gate_long_rec_kernel(VuPrepareArgs a)
 {
@@ -1729,11 +1795,18 @@ int launch_vu_tri(Ctx *c, const VuPrepareArgs &a, hipStream_t stream)
     if (!a.tri_rec || a.tri_stride < vu_tri_rec_stride(a.np, ncam) || a.spec_tracks > 0 || a.linear || a.map_index) return HV_ERR_INVALID;
     ScopedKernelTime tm(c, HV_K_VU_PREPARE, stream);
     const int np_sel = a.np_hi > 0 && a.np_hi < a.np ? a.np_hi : a.np;
-    const TriLds L(np_sel * ncam, np_sel);
+    const TriLds L(np_sel * ncam);
     const size_t bytes = sizeof(double) * (size_t)L.total;
     // four wavefronts per track where the launch may hold long tracks (their chain sets the length of the visit), one otherwise
-    if (np_sel * ncam > MAXP_SMALL) hipLaunchKernelGGL(vu_tri_kernel_x4, dim3((unsigned)a.batch), dim3(256), bytes, stream, a);
-    else                            hipLaunchKernelGGL(vu_tri_kernel, dim3((unsigned)a.batch), dim3(64), bytes, stream, a);
+    // knob vu_tri_threads (experiments / tests): 64 / 128 / 256 force a build; 257 = 256 threads at 128 VGPRs
+    const int forced = c->knob.vu_tri_threads;
+    // auto: four wavefronts per track where the launch may hold long tracks (their chain sets the length of the visit), two for the short
+    // class (profiles/r06/split_tri_ab_v2.txt: 4 lanes 27.90 ms per step with 128 threads, 28.12 with 64, 28.2 with 256)
+    const int nthr = forced == 64 || forced == 128 || forced == 256 || forced == 257 ? forced : (np_sel * ncam > MAXP_SMALL ? 256 : 128);
+    if (nthr == 256)      hipLaunchKernelGGL(vu_tri_kernel_x4, dim3((unsigned)a.batch), dim3(256), bytes, stream, a);
+    else if (nthr == 257) hipLaunchKernelGGL(vu_tri_kernel_x4s, dim3((unsigned)a.batch), dim3(256), bytes, stream, a);
+    else if (nthr == 128) hipLaunchKernelGGL(vu_tri_kernel_x2, dim3((unsigned)a.batch), dim3(128), bytes, stream, a);
+    else                  hipLaunchKernelGGL(vu_tri_kernel, dim3((unsigned)a.batch), dim3(64), bytes, stream, a);
     HV_HIP(c, hipGetLastError());
     return HV_OK;
 }
@@ -1782,6 +1855,7 @@ int launch_vu_prepare(Ctx *c, const VuPrepareArgs &a, hipStream_t stream)
         }
         constexpr size_t rec_long_bytes = VuRecLds<MAXP_ALL, true>::BYTES, rec_short_bytes = VuRecLds<MAXP_SMALL>::BYTES;
         if (a.fused == 3) hipLaunchKernelGGL(vu_gate_long_rec_kernel, grid, dim3(VT_LATENCY), rec_long_bytes, stream, a);
+        else if (c->knob.vu_rec_threads == VT_REC5) hipLaunchKernelGGL(vu_gate_rec5_kernel, grid, dim3(VT_REC5), rec_short_bytes, stream, a);
         else              hipLaunchKernelGGL(vu_gate_rec_kernel, grid, dim3(VT_REC), rec_short_bytes, stream, a);
         HV_HIP(c, hipGetLastError());
         return HV_OK;
@@ -1814,6 +1888,15 @@ int launch_vu_prepare(Ctx *c, const VuPrepareArgs &a, hipStream_t stream)
 }
 
 }  // namespace hv
+
+extern "C" int hv_debug_tri_phase_stamps(hv_ctx *ctx, long long *out64 /* [64] */)
+{
+    hv::Ctx *c = hv::ctx_of(ctx);
+    if (!c || !out64) return HV_ERR_INVALID;
+    HV_HIP(c, hipStreamSynchronize(c->stream));
+    HV_HIP(c, hipMemcpyFromSymbol(out64, HIP_SYMBOL(hv::g_tri_stamp), sizeof(long long) * 64));
+    return HV_OK;
+}
 
 extern "C" int hv_debug_vu_phase_stamps(hv_ctx *ctx, long long *out32 /* [40] */)
 {

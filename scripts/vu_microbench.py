@@ -102,6 +102,15 @@ def main():
                 capi.lib().hv_debug_vu_phase_stamps.argtypes = [C.c_void_p, C.POINTER(C.c_longlong)]
                 capi.lib().hv_debug_vu_phase_stamps(ctx._h, st40)
                 s_ = list(st40)
+                t64 = (C.c_longlong * 64)()
+                capi.lib().hv_debug_tri_phase_stamps.argtypes = [C.c_void_p, C.POINTER(C.c_longlong)]
+                capi.lib().hv_debug_tri_phase_stamps(ctx._h, t64)
+                t_ = list(t64)
+                if t_[57] > t_[0] > 0:
+                    its = [[t_[4 + 10 * k + j + 1] - t_[4 + 10 * k + j] for j in range(6)] for k in range(5) if t_[4 + 10 * k + 6] > t_[4 + 10 * k] > t_[0]]
+                    print("vu_tri_kernel phase cycles (workgroup 0): load", t_[1] - t_[0], "trail", t_[2] - t_[1], "two-cam", t_[3] - t_[2],
+                          "iterations [pose, ETE+plain, L+X, pairs C/P/Q, pose-0 totals, pose-0 columns + step]:", its,
+                          "status", t_[55] - t_[54], "prepare-pose + world + record", t_[56] - t_[55], "final", t_[57] - t_[56], "total", t_[57] - t_[0])
                 if os.environ.get("HV_RAW_STAMPS") == "1":
                     print("structured_S stamps (deltas of g_vu_stamp[1..11]):", [s_[k + 1] - s_[k] for k in range(1, 11)])
                 print("fused kernel phase cycles: up to prepare-pose", s_[29] - s_[0], "compact H + v", s_[31] - s_[29], "zero T", s_[32] - s_[31],

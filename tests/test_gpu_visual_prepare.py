@@ -857,6 +857,32 @@ def test_frame_loop_with_batch_visual_update(oracle, B, np_max, K, quota, max_ro
         g.close()
 
 
+def test_batch_visual_update_refuses_what_it_cannot_serve(oracle):
+    """hv_ekf_visual_frame_batch_dev: a batch smaller than the longest track's block, and a threshold growth factor != 1 (the batch
+    loop has no per-track rejection to grow on), are errors -- not silent truncation (r05 advisor: the only negative test of the entry
+    went away with r05's refactor; EKF::visualFrameBatch forwards maxUpdateRows straight into this check)."""
+    import torch
+    B, np_max, K, quota = 6, 6, 3, 2
+    case = _batch_loop_case(oracle, 4242, B, np_max, K, quota, 96, True)
+    with capi.Context(width=64, height=64) as ctx:
+        g = capi.EkfBatch(ctx, capi.ekf_default_params(cameraTrailLength=case["trail_len"]), B)
+        d, st, gs, counter = _run_batch_loop(case, ctx, g)
+        ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+        call = lambda vp, max_rows: g.visual_frame_batch_dev(vp, K, np_max, d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(), d[3].data_ptr(),
+                                                             d[4].data_ptr(), case["r_gate"], case["r_update"], st.data_ptr(), gs.data_ptr(),
+                                                             counter.data_ptr(), quota, max_rows)
+        with pytest.raises(capi.HvError):
+            call(case["vp"], 2 * 2 * np_max - 2)                  # the longest track's block (24 rows) does not fit the batch
+        vp_growth = capi.vu_default_params(imu_to_camera=list(case["vp"].imuToCamera), second_imu_to_camera=list(case["vp"].secondImuToCamera))
+        vp_growth.trackOutlierThresholdGrowthFactor = 1.5
+        with pytest.raises(capi.HvError):
+            call(vp_growth, 96)
+        call(case["vp"], 96)                                      # ... and the context still serves a valid call afterwards
+        torch.cuda.synchronize()
+        case["verify"](g, st.cpu().numpy(), gs.cpu().numpy(), counter.cpu().numpy())
+        g.close()
+
+
 @pytest.mark.parametrize("stereo,npose", [(True, 6), (False, 9), (True, 14)])
 def test_hybrid_map_track_visit(oracle, stereo, npose):
     """hv_ekf_visual_track_hybrid_dev (backend.cpp:1016,1075-1082,1146,1160-1168) with odometry.hybridMapSize 3 (state 169 wide): pose-trail
