@@ -1226,14 +1226,14 @@ def main():
     ap.add_argument("--no-ransac", action="store_true", help="skip the f4 (2-point rotation RANSAC kernel) measurement")
     ap.add_argument("--no-pcie", action="store_true", help="skip the PCIe-inclusive measurement (frames handed over as host buffers)")
     ap.add_argument("--only-headline", action="store_true", help="C2 + C3 legs only (what the rocprofv3 collection runs)")
-    ap.add_argument("--verify", type=int, default=4, help="sequences of the C3 batch re-computed by the CPU oracle after the timed region (0 = off)")
+    ap.add_argument("--verify", type=int, default=16, help="sequences of the C3 batch re-computed by the CPU oracle after the timed region (0 = off)")
     ap.add_argument("--repeats", type=int, default=5, help="repeats of the K-step timed region of the headline; `value` is the median repeat")
     ap.add_argument("--no-graph", action="store_true", help="time the headline with eager launches instead of HIP-graph replay of the captured steps")
     ap.add_argument("--engines", type=int, default=4,
                     help="lanes of the hv_lanes set of the realistic headline leg: each a batched context on library-owned streams with its own HIP "
                          "graphs and --sequences resident sequences; their launch chains run beside each other (2 = r03's headline configuration, "
                          "reported as `lanes_2` whenever more lanes run; 1 = one context on a torch stream)")
-    ap.add_argument("--verify-per-engine", type=int, default=4, help="sequences checked per lane when more than two lanes run (--verify applies up to two)")
+    ap.add_argument("--verify-per-engine", type=int, default=16, help="sequences checked per lane when more than two lanes run (--verify applies up to two); r06: 16 (64 of the 4096 resident sequences)")
     ap.add_argument("--one-sequence-leg", action="store_true", help="add the literal north-star configuration (ONE sequence per GPU) at N > 1 too")
     ap.add_argument("--cpu-baseline-child", type=float, default=None, help=argparse.SUPPRESS)
     args = ap.parse_args()

@@ -263,18 +263,33 @@ const char *hv_status_string(int s)
 // of one queue run one after the other) depended on the process history (r03: 15.8 / 17.3 / 18.6 ms per step for the same two engines
 // after different warm-ups). hv_lanes_create therefore takes its streams from the HIGH-priority pool, which nothing else uses
 // unless asked to: up to four streams (two lanes) get a hardware queue each, independent of what ran before.
-static int create_streams(Ctx *c, int high_priority)
+// which: 1 = the context stream, 2 = the second stream, 3 = both. A stream is bound to a hardware queue of its priority's pool (four
+// queues) when it first runs a command -- to the queue with the fewest users: hv_lanes_create therefore creates AND uses the context
+// streams of all its lanes before any second stream (r06: created pairwise, lanes 0 and 2 -- and 1 and 3 -- shared a queue with each
+// other while the second streams, idle under graph replay, held the other two: never more than two lanes' kernels in flight,
+// profiles/r06/concurrency_probe.txt)
+static int create_streams(Ctx *c, int high_priority, int which)
 {
     int least = 0, greatest = 0;
     if (high_priority && hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) high_priority = 0;
     if (high_priority && greatest == least) high_priority = 0;                 // the device has one priority level only
     c->stream_priority = high_priority ? 1 : 0;
-    for (hipStream_t *s : { &c->stream, &c->aux_stream }) {
-        const hipError_t e = high_priority ? hipStreamCreateWithPriority(s, hipStreamNonBlocking, greatest)
-                                           : hipStreamCreateWithFlags(s, hipStreamNonBlocking);
+    hipStream_t *both[2] = { &c->stream, &c->aux_stream };
+    for (int i = 0; i < 2; ++i) {
+        if (!(which & (1 << i))) continue;
+        const hipError_t e = high_priority ? hipStreamCreateWithPriority(both[i], hipStreamNonBlocking, greatest)
+                                           : hipStreamCreateWithFlags(both[i], hipStreamNonBlocking);
         if (e != hipSuccess) return hip_fail(c, e, "hipStreamCreate");
     }
     c->own_stream = true;
+    return HV_OK;
+}
+
+// the second stream's first command (binds its hardware queue now, not inside the first frame)
+static int prime_aux_stream(Ctx *c)
+{
+    if (hipMemsetAsync(c->d_slots, 0, sizeof(int) * 4, c->aux_stream) != hipSuccess) return HV_ERR_HIP;
+    if (hipStreamSynchronize(c->aux_stream) != hipSuccess) return HV_ERR_HIP;
     return HV_OK;
 }
 
@@ -303,7 +318,7 @@ static int create_ctx(const hv_params *params, int high_priority, hv_ctx **out)
     do {
         if (hipSetDevice(p.device) != hipSuccess) { rc = HV_ERR_NO_DEVICE; break; }
         { hipDeviceProp_t prop; if (hipGetDeviceProperties(&prop, p.device) == hipSuccess && prop.multiProcessorCount > 0) c->num_cus = prop.multiProcessorCount; }
-        rc = create_streams(c, high_priority);
+        rc = create_streams(c, high_priority, high_priority ? 1 : 3);       // (lanes: the second streams follow once every lane's context stream is bound)
         if (rc != HV_OK) break;
         const size_t slab_bytes = (size_t)c->L.slot_bytes * p.pool_size + hv::SLAB_SLACK;
         if (hipMalloc(&c->slab, slab_bytes) != hipSuccess) { rc = HV_ERR_NOMEM; break; }
@@ -312,8 +327,8 @@ static int create_ctx(const hv_params *params, int high_priority, hv_ctx **out)
         if (hipMalloc(&c->d_slots, sizeof(int) * 4) != hipSuccess) { rc = HV_ERR_NOMEM; break; }
         if (hipMemsetAsync(c->d_l0_ptr, 0, sizeof(void *) * p.pool_size, c->stream) != hipSuccess) { rc = HV_ERR_HIP; break; }
         // (the second stream runs its first command here, not inside the first frame: a stream's hardware queue is bound when it is used)
-        if (hipMemsetAsync(c->d_slots, 0, sizeof(int) * 4, c->aux_stream) != hipSuccess) { rc = HV_ERR_HIP; break; }
-        if (hipStreamSynchronize(c->aux_stream) != hipSuccess) { rc = HV_ERR_HIP; break; }
+        if (c->aux_stream && prime_aux_stream(c) != HV_OK) { rc = HV_ERR_HIP; break; }
+        if (hipStreamSynchronize(c->stream) != hipSuccess) { rc = HV_ERR_HIP; break; }      // the context stream has run its first command
         c->slot_used.assign(p.pool_size, 0);
         for (int s = p.pool_size - 1; s >= 0; --s) c->free_slots.push_back(s);
         rc = hv::ensure_point_staging(c, p.max_tracks);
@@ -341,6 +356,11 @@ int hv_lanes_create(const hv_params *params, int n_lanes, hv_lanes **out)
         const int rc = create_ctx(params, 1, &h);
         if (rc != HV_OK) { hv_lanes_destroy(g); return rc; }
         g->ctx.push_back(h);
+    }
+    for (hv_ctx *h : g->ctx) {                               // second streams: behind every context stream (create_streams)
+        int rc = create_streams(&h->c, 1, 2);
+        if (rc == HV_OK) rc = prime_aux_stream(&h->c);
+        if (rc != HV_OK) { hv_lanes_destroy(g); return rc; }
     }
     *out = g;
     return HV_OK;
