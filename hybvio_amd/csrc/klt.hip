@@ -236,7 +236,11 @@ __global__ __launch_bounds__(64, WPS) void klt_kernel(KltArgs a)
     if (a.use_init) guess = a.next_xy[pt];
 
     // fast tile staging: lane (st_lr, st_c) = row-in-pass, 4-pixel group; lanes beyond RPI * G repeat the last item
-    constexpr int G = TSX / 4, RPI = 64 / G, NIT = TSY / RPI;
+    // (r06: 8-pixel groups, 16-byte loads -- G = 5 lanes per tile row, 12 rows per pass, 3 passes: half the vector-memory instructions
+    //  of r01 .. r05's 4-pixel groups / 8-byte loads / 6 passes. The kernel is co-limited by the rate at which a CU's 20 waves get
+    //  their VMEM instructions through address processing, profiles/r06/klt_planar_levels_ab.txt)
+    constexpr int G = TSX / 8, RPI = 64 / G, NIT = TSY / RPI;
+    static_assert(TSX % 8 == 0 && TSX + 8 <= RW, "8-pixel staging groups: the load footprint is TSX + 8 columns");
     static_assert(TSY % RPI == 0, "whole passes: no row clamp in the staging loop");
     const float half_win = (float)(WIN - 1) * 0.5f;
     const float FLT_SCALE = 1.f / (float)(1 << 20);
@@ -301,8 +305,8 @@ __global__ __launch_bounds__(64, WPS) void klt_kernel(KltArgs a)
         int st_lane = lane;
         asm volatile("" : "+v"(st_lane));
         const int st_ln = min(st_lane, RPI * G - 1), st_lr = (int)(__umul24((unsigned)st_ln, (unsigned)((65536 + G - 1) / G)) >> 16), st_c = st_ln - st_lr * G;
-        const int st_loff = st_lr * TSX + 4 * st_c;
-        const unsigned st_goff = __umul24((unsigned)st_lr, (unsigned)Jgs) + 4u * (unsigned)st_c;   // lane part of the staging loads
+        const int st_loff = st_lr * TSX + 8 * st_c;
+        const unsigned st_goff = __umul24((unsigned)st_lr, (unsigned)Jgs) + 8u * (unsigned)st_c;   // lane part of the staging loads
         const bool j_aligned = ((reinterpret_cast<uintptr_t>(Jg) | (uintptr_t)Jgs) & 3u) == 0;
         // origin of the tile that holds window (ix, iy); true when the plain coalesced staging loop can load it
         auto plan_tile = [&](int ix, int iy, int &ox, int &oy) -> bool {
@@ -310,33 +314,37 @@ __global__ __launch_bounds__(64, WPS) void klt_kernel(KltArgs a)
             // keep the (TSX+4) x TSY load footprint inside the image whenever the window allows it, so
             // only windows that really cross the border take the reflecting path
             const int bp = padded ? PYR_PAD : 0;                 // the rectangle that exists in memory: [-bp, w + bp) x [-bp, h + bp)
-            const int cx0 = min(max(ox, -bp), (w + bp - TSX - 4) & ~3), cy0 = min(max(oy, -bp), h + bp - TSY);
-            if (w + 2 * bp >= TSX + 4 && h + 2 * bp >= TSY && ix >= cx0 && ix + 32 <= cx0 + TSX && iy >= cy0 && iy + 32 <= cy0 + TSY) {
+            const int cx0 = min(max(ox, -bp), (w + bp - TSX - 8) & ~3), cy0 = min(max(oy, -bp), h + bp - TSY);
+            if (w + 2 * bp >= TSX + 8 && h + 2 * bp >= TSY && ix >= cx0 && ix + 32 <= cx0 + TSX && iy >= cy0 && iy + 32 <= cy0 + TSY) {
                 ox = cx0; oy = cy0;
             }
             // padded level: where the clamp above cannot hold the window (right edge, ix > w + bp - 36) the load footprint runs a
             // few bytes past the row into the next row / the slab slack; those tile cells are never read by a window lane
-            return j_aligned && (padded || (ox >= 0 && ox + TSX + 4 <= w && oy >= 0 && oy + TSY <= h));
+            return j_aligned && (padded || (ox >= 0 && ox + TSX + 8 <= w && oy >= 0 && oy + TSY <= h));
         };
         // G = TSX / 4 lanes cover a tile row (8 source bytes -> 4 pixel pairs each), RPI = 64 / G rows per pass: pass i of
         // lane (lr, c) is row i * RPI + lr. The per-pass part of both addresses is scalar (row base) resp. an immediate
         // (LDS offset); the per-lane part (st_goff, st_loff) is formed once per level. r01 stepped a flat item index
         // through the tile instead: ~9 VALU of index arithmetic per item, 163 per staging against ~9 per pass here.
-        auto tile_request = [&](uint2 (&raw)[NIT]) {
+        auto tile_request = [&](uint4 (&raw)[NIT]) {
             int tb = j0 + toy * Jgs + tox, tstep = RPI * Jgs;
             asm volatile("" : "+s"(tb), "+s"(tstep));
 #pragma unroll
             for (int i = 0; i < NIT; ++i) {
-                const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(rJ, st_goff, tb + i * tstep, 0);   // (scalar row offset: one s_add per pass)
-                raw[i] = make_uint2(v.x, v.y);
+                typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+                const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rJ, st_goff, tb + i * tstep, 0);   // (scalar row offset: one s_add per pass)
+                raw[i] = make_uint4(v.x, v.y, v.z, v.w);
             }
         };
-        auto tile_commit = [&](const uint2 (&raw)[NIT]) {
+        auto tile_commit = [&](const uint4 (&raw)[NIT]) {
 #pragma unroll
-            for (int i = 0; i < NIT; ++i)
-                *reinterpret_cast<uint4 *>(&jt[st_loff + i * RPI * TSX]) =
-                    make_uint4(scaled_pair<0>(raw[i].x, raw[i].y), scaled_pair<1>(raw[i].x, raw[i].y),
-                               scaled_pair<2>(raw[i].x, raw[i].y), scaled_pair<3>(raw[i].x, raw[i].y));
+            for (int i = 0; i < NIT; ++i) {
+                uint4 *dst = reinterpret_cast<uint4 *>(&jt[st_loff + i * RPI * TSX]);
+                dst[0] = make_uint4(scaled_pair<0>(raw[i].x, raw[i].y), scaled_pair<1>(raw[i].x, raw[i].y),
+                                    scaled_pair<2>(raw[i].x, raw[i].y), scaled_pair<3>(raw[i].x, raw[i].y));
+                dst[1] = make_uint4(scaled_pair<0>(raw[i].y, raw[i].z), scaled_pair<1>(raw[i].y, raw[i].z),
+                                    scaled_pair<2>(raw[i].y, raw[i].z), scaled_pair<3>(raw[i].y, raw[i].z));
+            }
         };
 
         // ---- template patch: bilinear samples of I and dI into registers, A = sum(dI dI^T) ----
@@ -399,7 +407,7 @@ __global__ __launch_bounds__(64, WPS) void klt_kernel(KltArgs a)
             }
             if (early && fly) {
                 constexpr int NQ = HALF_ROWS + 3;        // source rows -1 .. 17 of this half
-                uint2 raw[NIT];
+                uint4 raw[NIT];
                 uint32_t q[NQ];
                 tile_request(raw);
                 int qb = g0 + (ipy - 1) * Igs + ipx - 1, qstep = Igs;                          // scalar: one s_add per row below
@@ -419,7 +427,7 @@ __global__ __launch_bounds__(64, WPS) void klt_kernel(KltArgs a)
                 }
             } else if (early) {
                 constexpr int NR = HALF_ROWS + 1;
-                uint2 raw[NIT];
+                uint4 raw[NIT];
                 uint16_t graw[NR];
                 uint2 draw[NR];
                 tile_request(raw);
@@ -583,7 +591,7 @@ __global__ __launch_bounds__(64, WPS) void klt_kernel(KltArgs a)
             if (ix >= tox && ix + 32 <= tox + TSX && iy >= toy && iy + 32 <= toy + TSY) return;
             const bool fast = plan_tile(ix, iy, tox, toy);
             if (fast) {
-                uint2 raw[NIT];
+                uint4 raw[NIT];
                 tile_request(raw);
                 tile_commit(raw);
             } else if (w >= RW && h >= TSY) {
