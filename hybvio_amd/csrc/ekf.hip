@@ -2364,19 +2364,19 @@ static int visual_track_dev_impl(hv_ekf *h, const hv_vu_params *p, int np, const
     };
     // the gate launch `g` of one length class in split form: the triangulation front first, on the same stream; false = not a shape
     // the split form serves (the caller issues the fused launch)
-    auto split_launch = [&](hv::VuPrepareArgs &g, hipStream_t stream, int *rc_out) -> bool {
+    // phase: 0 = both launches, 1 = the triangulation only, 2 = the gate only (one-stream visits interleave the two classes' launches:
+    // knob ekf_long_first)
+    auto split_launch = [&](hv::VuPrepareArgs &g, hipStream_t stream, int *rc_out, int phase = 0) -> bool {
         if (!hv::vu_split_supported(c, g, g.fused)) return false;
         int rc2 = ensure_tri();
-        if (rc2 == HV_OK) {
-            g.tri_rec = e->tri_rec; g.tri_stride = e->tri_stride;
-            rc2 = hv::launch_vu_tri(c, g, stream);
-        }
-        if (rc2 == HV_OK) { g.from_rec = 1; rc2 = hv::launch_vu_prepare(c, g, stream); }
+        g.tri_rec = e->tri_rec; g.tri_stride = e->tri_stride;
+        if (rc2 == HV_OK && phase != 2) rc2 = hv::launch_vu_tri(c, g, stream);
+        if (rc2 == HV_OK && phase != 1) { g.from_rec = 1; rc2 = hv::launch_vu_prepare(c, g, stream); }
         *rc_out = rc2;
         return true;
     };
     // prepare + gate of the long class on `stream` (nothing else touches c->stream: r03 swapped the context's stream for these calls)
-    auto long_prepare_gate = [&](hv::VuPrepareArgs l_, double *Hc, double *vv, int *acol, unsigned char *act, bool listed, hipStream_t stream) -> int {
+    auto long_prepare_gate = [&](hv::VuPrepareArgs l_, double *Hc, double *vv, int *acol, unsigned char *act, bool listed, hipStream_t stream, int phase = 0) -> int {
         l_.H = nullptr; l_.Hc = Hc; l_.v = vv; l_.acol = acol; l_.na_max = 7 * np + 1; l_.active = act; l_.chi2 = chi2_dev;
         if (listed) { l_.rec_count = cnt_long; l_.rec_list = list_long; }
         const bool adaptive_gate = l_.rmse_thr >= 0.0 || l_.gate_scale;     // (served by the fused gates only)
@@ -2385,7 +2385,8 @@ static int visual_track_dev_impl(hv_ekf *h, const hv_vu_params *p, int np, const
             l_.fused = 3; l_.P = e->P; l_.rd_gate = r_gate * r_gate * ns; l_.noise_scale = ns;
             l_.inl_count = cnt_inl_long; l_.inl_list = list_inl_long;
             int rc_s = HV_OK;
-            if (split_launch(l_, stream, &rc_s)) return rc_s;
+            if (split_launch(l_, stream, &rc_s, phase)) return rc_s;
+            if (phase == 1) return HV_OK;                      // (not a split shape: the fused launch is the gate phase)
             return hv::launch_vu_prepare(c, l_, stream);
         }
         l_.fused = 2;
@@ -2473,10 +2474,30 @@ static int visual_track_dev_impl(hv_ekf *h, const hv_vu_params *p, int np, const
         // replay 9.67 -> 9.63 (profiles/r04/lanes_probe.txt, session 9).
         const bool swap = forked && c->knob.ekf_side_stream != 3;
         hipStream_t long_stream = forked && !swap ? c->aux_stream : main_stream, short_stream = swap ? c->aux_stream : main_stream;
-        const bool long_first = presorted && (forked || c->knob.ekf_long_first != 0);
+        const bool long_first = presorted && (forked || c->knob.ekf_long_first == 1);
+        auto short_phase = [&](int phase) -> int {
+            int rc_s = HV_OK;
+            if (split_launch(s_, short_stream, &rc_s, phase)) return rc_s;
+            return phase == 1 ? HV_OK : hv::launch_vu_prepare(c, s_, short_stream);
+        };
+        // one-stream sorted visits, knob ekf_long_first: 0 = short class (triangulation, gate) then long class; 1 = long class first;
+        // 2 .. 4 (split form, r06) = both triangulations in front of both gates: T long, T short, G long, G short / T short, T long,
+        // G short, G long / T long, T short, G short, G long (profiles/r06/visit_launch_order_sweep.txt)
+        const int order = presorted && !forked ? c->knob.ekf_long_first : -1;
+        if (order >= 2 && order <= 4) {
+            const bool lf = order != 3;
+            if (lf) rc = long_prepare_gate(l_, e->sideH, e->sidev, e->side_acol, e->side_active, true, main_stream, 1);
+            if (rc == HV_OK) rc = short_phase(1);
+            if (rc == HV_OK && !lf) rc = long_prepare_gate(l_, e->sideH, e->sidev, e->side_acol, e->side_active, true, main_stream, 1);
+            const bool gl_first = order == 2;
+            if (rc == HV_OK && gl_first) rc = long_prepare_gate(l_, e->sideH, e->sidev, e->side_acol, e->side_active, true, main_stream, 2);
+            if (rc == HV_OK) rc = short_phase(2);
+            if (rc == HV_OK && !gl_first) rc = long_prepare_gate(l_, e->sideH, e->sidev, e->side_acol, e->side_active, true, main_stream, 2);
+        } else {
         if (long_first) rc = long_prepare_gate(l_, e->sideH, e->sidev, e->side_acol, e->side_active, true, long_stream);
-        if (rc == HV_OK) { int rc_s = HV_OK; rc = split_launch(s_, short_stream, &rc_s) ? rc_s : hv::launch_vu_prepare(c, s_, short_stream); }
+        if (rc == HV_OK) rc = short_phase(0);
         if (rc == HV_OK && !long_first) rc = long_prepare_gate(l_, e->sideH, e->sidev, e->side_acol, e->side_active, true, main_stream);
+        }
         if (forked) {
             hipError_t he = hipEventRecord(e->ev_join, c->aux_stream);
             if (he == hipSuccess) he = hipStreamWaitEvent(main_stream, e->ev_join, 0);
