@@ -1147,6 +1147,7 @@ def tracker_leg(env, args, B, local_rank, rank, label):
 # The driver reads the LAST stdout line as the record and keeps only a few KB of stdout; r04's single 22.6 KB line did not survive
 # that (BENCH_r04.json: parsed null). So: the full object goes to a file (and, prefixed so that it is not mistaken for the record, to
 # an earlier stdout line); the last line is a compact object of scalars only, bounded by COMPACT_LIMIT bytes.
+GFTT_VALU_PER_LAUNCH_1024 = 436e6   # SQ_INSTS_VALU of gftt_march_kernel<32> per launch of 1024 images 752x480 (profiles/r05/pmc3.csv)
 COMPACT_LIMIT = 4096
 COMPACT_TOP = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data")
 COMPACT_CONFIG = ("workload", "sequences_per_gpu", "engines_per_gpu", "frames_per_step", "parallelism", "parity_ok", "parity_checked_sequences",
@@ -1449,9 +1450,13 @@ def main():
             "frac_of_8TBs": gbytes / (ms / n * 1e-3) / 1e9 / HBM_PEAK_GBS,
             "blocks_with_a_corner": found,
             "note": "a thread marches a 4-column strip of one arg-max block through sliding register windows (gftt_march_kernel; the "
-                    "LDS-tiled kernel serves < 128 images): ~70 binary32 instructions per pixel on 1 byte of HBM traffic, VALU-issue bound "
-                    "by construction (the chip issues 614 G wave-instructions/s: 0.6 ms floor for 1024 images; the reference materialises "
-                    "6 float images = 24 B per pixel instead)"}
+                    "LDS-tiled kernel serves < 128 images): ~75 binary32 instructions per pixel on 1 byte of HBM traffic, VALU-issue bound "
+                    "by construction. Classified ceiling (r06, ISA census of the marching loop: 123 of its 199 VALU instructions per 4-pixel "
+                    "row step are of the 4-cycle class -- v_pk_mul / v_pk_add_f32, v_cndmask, v_cmp, v_cvt, v_sqrt -- and 76 of the 2-cycle "
+                    "class, which only issue at 2 cycles in runs of their own kind, scripts/valu_issue_ubench.hip): 565 .. 727 G "
+                    "wave-instructions/s; the kernel issues ~490 G/s (PMC: 436 M per launch of 1024 images), i.e. 0.67 .. 0.87 of it; the "
+                    "reference materialises 6 float images = 24 B per pixel instead",
+            "frac_valu_issue_range": [GFTT_VALU_PER_LAUNCH_1024 * (B / 1024.0) / (ms / n * 1e-3) / 727e9, GFTT_VALU_PER_LAUNCH_1024 * (B / 1024.0) / (ms / n * 1e-3) / 565e9]}
         if not args.no_cpu_baseline:
             from oracle import orc
             img = tb.frames[0, 0, 0].cpu().numpy()
@@ -1528,7 +1533,9 @@ def main():
     # the `vu_prepare` class run BESIDE each other on two streams, so that sum double-counted wall time.
     dom = "klt" if "klt" in k3 else max(k3, key=lambda k: k3[k]["total_ms"])
     prof_t = profiled_traffic() if rank == 0 else None
-    pmc_key = {"klt": "klt_kernel", "pyr_l0": "pyr_down_l0_kernel", "ekf_update_gate": "ekf_update_kernel", "vu_prepare": "vu_gate_kernel_2percu",
+    # (vu_prepare class, r06: the split form's short-class gate; the fused kernel of r03 .. r05 where the profile predates the split)
+    vu_key = "vu_gate_rec_kernel" if isinstance((prof_t or {}).get("vu_gate_rec_kernel"), dict) and (prof_t or {})["vu_gate_rec_kernel"].get("hbm_bytes_per_launch") else "vu_gate_kernel_2percu"
+    pmc_key = {"klt": "klt_kernel", "pyr_l0": "pyr_down_l0_kernel", "ekf_update_gate": "ekf_update_kernel", "vu_prepare": vu_key,
                "pyr_ln": "pyr_tail_kernel", "ekf_gate": "ekf_sparse_gate_kernel"}
 
     def pmc(kname, field):
@@ -1623,14 +1630,14 @@ def main():
                          "valu_insts_per_feature": valu_pf,
                          "frac_valu_issue": (valu_pf * B * NPTS / (k3[dom]["avg_ms"] * 1e-3) / VALU_PEAK_WAVE_INSTS) if valu_pf else None,
                          "valu_cycles_per_wave64_inst": VALU_CYCLES_PER_INST, "valu_peak_G_wave_insts_per_s": VALU_PEAK_WAVE_INSTS / 1e9,
-                         "valu_peak_source": "scripts/valu_issue_ubench.hip, profiles/r05/valu_issue_ubench.txt (measured, instruction classes of the kernel)",
+                         "valu_peak_source": "scripts/valu_issue_ubench.hip, profiles/r05/valu_issue_ubench.txt (measured in r05, instruction classes of the kernel)",
                          "limiter": limiter,
                          "stage_frac_agreed": stage["frac_of_8TBs"], "stage_frac_actual": stage["frac_actual"], "stage_ms_per_step": stage["ms_per_step"],
                          "parity_ok": verify["ok"] if verify else None,
                          "stage_pyramid_klt": stage},
             # the EKF half reported separately, per kernel class of the visit loop (hipEvents of the one-engine eager region; the long class's
             # launch runs beside the short class's on a second stream: these per-class times are NOT additive wall time)
-            "roofline_ekf": {"bound": "f64-valu+mfma/latency", "kernel": "vu_gate_kernel_2percu (+ vu_gate_long_kernel on the second stream)",
+            "roofline_ekf": {"bound": "f64-valu+mfma/latency", "kernel": "r06 split form: vu_tri_kernel_x2 -> vu_gate_rec_kernel (short class), vu_tri_kernel_x4 -> vu_gate_long_rec_kernel (long class); the class's hipEvent time covers all four launches",
                              "avg_launch_ms": k3.get("vu_prepare", {}).get("avg_ms"), "algorithmic_bytes_per_launch": alg["vu_prepare"],
                              "achieved": k3.get("vu_prepare", {}).get("achieved_GBs"), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                              "frac": (k3["vu_prepare"]["achieved_GBs"] / HBM_PEAK_GBS) if "vu_prepare" in k3 else None,
@@ -1639,7 +1646,7 @@ def main():
                              "wave_parked_frac": pmc("vu_prepare", "wave_parked_frac"),
                              "update_avg_launch_ms": k3.get("ekf_update_gate", {}).get("avg_ms"),
                              "update_achieved_GBs": k3.get("ekf_update_gate", {}).get("achieved_GBs"),
-                             "limiter": "per-workgroup latency: ~50 barrier-separated f64 phases per track at two 80 KB workgroups per CU; neither HBM nor the matrix pipe bounds it"},
+                             "limiter": "per-workgroup latency and LDS slots: the triangulation is a chain of f64 phases (a lone wavefront issues an f64 instruction every ~6.5 cycles), the gates a 16-wide Cholesky chain; neither HBM nor the matrix pipe bounds them (profiles/r06)"},
             "measured_ceilings_GBs": (prof_t or {}).get("measured_hbm_ceilings_GBs"),
             "kernels": k3,
             # the reference's own `-timer` keys -> device ms per step of B frames

@@ -1438,8 +1438,16 @@ __device__ __forceinline__ void vu_tri_body(const VuPrepareArgs &a, const int b)
         TRI_IT_STAMP(3);
         // ---- the motion pairs, one task per lane, by type (header): C -> scratch [3 + q][i][9]; P -> scratch [c][i][9] and the own
         // column's update with -r; Q -> the own column's update. (the plain part's maps in the scratch are dead: L is in s_L) ----
-        for (int e = tid; e < NC + NPp + NQ; e += NT) {
-            if (e < NC) {
+        // Tasks are dealt in GROUPS of 64 of ONE type (C groups, then P, then Q), a group per wavefront and round: every lane of a
+        // wavefront runs the same code path (dealt flat, the waves that straddled a type boundary ran two paths: +15 % VALU work)
+        const int gC = (NC + 63) >> 6, gP = (NPp + 63) >> 6, gQ = (NQ + 63) >> 6;
+        for (int grp = tid >> 6; grp < gC + gP + gQ; grp += NT / 64) {
+            const int lane_ = tid & 63;
+            const int ty = grp < gC ? 0 : grp < gC + gP ? 1 : 2;                       // (wave-uniform)
+            const int e_in = (grp - (ty == 0 ? 0 : ty == 1 ? gC : gC + gP)) * 64 + lane_;
+            if (e_in >= (ty == 0 ? NC : ty == 1 ? NPp : NQ)) continue;
+            const int e = e_in + (ty == 0 ? 0 : ty == 1 ? NC : NC + NPp);
+            if (ty == 0) {
                 const int q = e / nt, i = e - q * nt;
                 const double *cur = s_trail + i * POSE_WORDS, *dR0 = s_trail + 12 + 9 * q, *o = s_it + i * TRI_ITW;
                 double dC[9], dt[3], dp0[3], dh[3], e3[3] = {0, 0, 0}, m9[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -1460,7 +1468,7 @@ __device__ __forceinline__ void vu_tri_body(const VuPrepareArgs &a, const int b)
                 double *dst = s_scr + ((3 + q) * nt + i) * 9;
                 dst[0] = e3[0]; dst[1] = e3[1]; dst[2] = e3[2];
                 dst[3] = m9[0]; dst[4] = m9[1]; dst[5] = m9[2]; dst[6] = m9[4]; dst[7] = m9[5]; dst[8] = m9[8];
-            } else if (e < NC + NPp) {
+            } else if (ty == 1) {
                 const int e2 = e - NC, c = e2 / (nt - 1), i = 1 + e2 - c * (nt - 1);
                 const double *cur = s_trail + i * POSE_WORDS, *o = s_it + i * TRI_ITW;
                 const double dt[3] = {cur[3 + c], cur[6 + c], cur[9 + c]};          // R_i(:, c)

@@ -1,10 +1,10 @@
 #!/bin/bash
 # Runs on the GPU box (via gpurun): rocprofv3 kernel-trace stats of the headline legs of the bench command (C2 + C3 at the
 # default B) plus the PMC passes needed for HBM traffic and VALU / MFMA utilisation. PMC passes are separate runs with --pmc
-# only (never combined with trace domains). Writes small summaries to gpurun_out/prof_r05/ (copy what is judged to profiles/).
+# only (never combined with trace domains). Writes small summaries to gpurun_out/prof_r06/ (copy what is judged to profiles/).
 set -u
 R=${GRAFT_REPO_ROOT:-$(pwd)}
-OUT=$R/gpurun_out/${PROF_DIR:-prof_r05}
+OUT=$R/gpurun_out/${PROF_DIR:-prof_r06}
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 ulimit -c 0

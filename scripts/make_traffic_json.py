@@ -7,8 +7,8 @@ import json
 import os
 import sys
 
-src = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/prof_r05"
-dst = sys.argv[2] if len(sys.argv) > 2 else "profiles/r05/traffic.json"
+src = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/prof_r06"
+dst = sys.argv[2] if len(sys.argv) > 2 else "profiles/r06/traffic.json"
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench  # noqa: E402
 
@@ -46,7 +46,11 @@ W2, H2 = (W1 + 1) // 2, (H1 + 1) // 2
 wgs_l1 = (((W2 + 3) // 4) * ((H2 + 1) // 2) + 255) // 256          # the level-1 launch of the same kernel
 GRID = {"klt_kernel": B * NPTS * 64, L0K: L0GRID, "ekf_update_kernel": B * 512, "pyr_tail_kernel": 2 * B * 512,
         "vu_gate_kernel_2percu": B * 384, "ekf_sparse_gate_kernel": B * 256, "vu_compact_kernel_2percu": B * 384,
-        "vu_gate_long_kernel": B * 768}
+        "vu_gate_long_kernel": B * 768,
+        # r06, the split form of a visit: vu_tri_kernel_x2 (short class, 128 threads per track) / _x4 (long class, 256) share the summary
+        # name "vu_tri_kernel" (scripts/pmc_summary.py) and differ by grid; the record-fed gates
+        "vu_tri_kernel": B * 128, "vu_gate_rec_kernel": B * 256, "vu_gate_long_rec_kernel": B * 768}
+GRID_TRI_LONG = B * 256
 GRID_L1 = 2 * B * wgs_l1 * 256
 
 
@@ -104,6 +108,22 @@ out = {
         "mfma_busy_frac": frac(g("vu_gate_long_kernel", "SQ_VALU_MFMA_BUSY_CYCLES"), 32.0 * (g("vu_gate_long_kernel", "SQ_BUSY_CYCLES") or 0)),
         "wave_parked_frac": frac(g("vu_gate_long_kernel", "SQ_WAIT_ANY"), g("vu_gate_long_kernel", "SQ_WAVE_CYCLES")),
         "how": "r04: triangulation + prepareVisualUpdate + the chi2 gate on the factors of the Jacobian (structured_S) of the long-track class (12 .. 21 stereo poses) in one launch per visit; ~21 % of the records of a launch are live",
+    },
+    # r06: the split form's kernels (short class: triangulation then record-fed gate; long class likewise)
+    **{k: {"hbm_bytes_per_launch": hbm(k),
+           "mfma_busy_frac": frac(g(k, "SQ_VALU_MFMA_BUSY_CYCLES"), 32.0 * (g(k, "SQ_BUSY_CYCLES") or 0)),
+           "wave_parked_frac": frac(g(k, "SQ_WAIT_ANY"), g(k, "SQ_WAVE_CYCLES")),
+           "valu_insts_per_track": frac(g(k, "SQ_INSTS_VALU"), B), "mfma_insts_per_track": frac(g(k, "SQ_INSTS_MFMA"), B),
+           "lds_bank_conflict_frac": frac(g(k, "SQ_LDS_BANK_CONFLICT"), g(k, "SQ_LDS_IDX_ACTIVE")), "how": how}
+       for k, how in (("vu_tri_kernel", "short class: pose trail + two-camera start + Gauss-Newton with derivatives + per-pose part of prepareVisualUpdate -> factor record (128 threads per track)"),
+                      ("vu_gate_rec_kernel", "short class: compact Jacobian from the factor record + column-sparse chi2 gate, three workgroups per CU"),
+                      ("vu_gate_long_rec_kernel", "long class: the gate on the Jacobian's factors (structured_S) from the factor record"))},
+    "vu_tri_kernel_long": {
+        "hbm_bytes_per_launch": (lambda f, w: None if f is None or w is None else (2 * f + w) * 1024.0)(
+            val.get(("vu_tri_kernel", GRID_TRI_LONG, "FETCH_SIZE")), val.get(("vu_tri_kernel", GRID_TRI_LONG, "WRITE_SIZE"))),
+        "wave_parked_frac": frac(val.get(("vu_tri_kernel", GRID_TRI_LONG, "SQ_WAIT_ANY")), val.get(("vu_tri_kernel", GRID_TRI_LONG, "SQ_WAVE_CYCLES"))),
+        "valu_insts_per_track": frac(val.get(("vu_tri_kernel", GRID_TRI_LONG, "SQ_INSTS_VALU")), B),
+        "how": f"long class (12 .. 21 stereo poses): the same front with 256 threads per track, grid {GRID_TRI_LONG} threads",
     },
     "pyr_tail_kernel": {
         "fetch_kb_raw": g("pyr_tail_kernel", "FETCH_SIZE"), "write_kb": g("pyr_tail_kernel", "WRITE_SIZE"),
