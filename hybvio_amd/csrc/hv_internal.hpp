@@ -73,8 +73,7 @@ struct Knobs {
     int ekf_visit_order = 1;      // HV_EKF_VISIT_ORDER: 1 = ragged frame loops over more filters than the GPU has CUs hand the fused kernel its records longest track first (one sort launch per frame; the presorted long-class lists also enable ekf_side_stream 2 .. 4); 2 = at every batch size (tests); 0 = in filter order
     int ekf_defer_jacobian = 1;   // HV_EKF_DEFER_JACOBIAN: 1 (r05) = the long class's one-launch build (vu_gate_long_kernel) forms and stores the compact Jacobian Hc = Dp + O4 F4 BEHIND its gate, for inliers only (the update is its only reader); 0 = for every prepared track, in front of the gate (r04)
     int ekf_split_tri = 1;        // HV_EKF_SPLIT_TRI: 1 (r06) = ragged two-class visits run the triangulation front as its own launch (vu_tri_kernel: a wavefront per short track, four per long track) and the gates from its factor records (three short-class gates per CU instead of two fused workgroups); 0 = r03 .. r05's fused prepare + gate kernels
-    int vu_tri_threads = 0;       // HV_VU_TRI_THREADS: threads per track of vu_tri_kernel: 0 auto (64 for the short class, 256 for the long class), 64 / 128 / 256 force, 257 = 256 threads at 128 VGPRs (four workgroups per CU)
-    int vu_rec_threads = 0;       // HV_VU_REC_THREADS: threads of the record-fed short-class gate: 0 = 256 (four wavefronts), 320 = five
+    int vu_tri_threads = 0;       // HV_VU_TRI_THREADS: threads per track of vu_tri_kernel: 0 auto (128 for the short class, 256 for the long class), 64 / 128 / 256 force
     int rot_ransac_threads = 0;   // HV_ROT_RANSAC_THREADS: 0 auto (25 workgroups per set while they all get a CU, 1024 threads up to 64 sets, 256 beyond), 25 / 256 / 1024 force
 };
 int knob_set(Knobs &k, const char *name, int value);   // HV_ERR_INVALID for an unknown name

@@ -1652,14 +1652,6 @@ __global__ __launch_bounds__(128) void vu_tri_kernel_x2(VuPrepareArgs a)
     else if (a.order) b = __builtin_amdgcn_readfirstlane(a.order[blockIdx.x]);
     vu_tri_body<128>(a, b);
 }
-// four wavefronts at 128 VGPRs: four workgroups per CU (the short class's ~810 records of a 1024-filter visit resident at once)
-__global__ __launch_bounds__(256, 4) void vu_tri_kernel_x4s(VuPrepareArgs a)
-{
-    int b = blockIdx.x;
-    if (a.rec_list) { if (b >= *a.rec_count) return; b = a.rec_list[b]; }
-    else if (a.order) b = __builtin_amdgcn_readfirstlane(a.order[blockIdx.x]);
-    vu_tri_body<256>(a, b);
-}
 
 __global__ __launch_bounds__(VT_LATENCY, 3) void vu_prepare_kernel(VuPrepareArgs a) { vu_prepare_body<VT_LATENCY, MAXP_ALL, 0>(a, blockIdx.x); }
 // 4 waves per SIMD = 128 VGPRs: two workgroups of 6 waves may put 4 waves on one SIMD (512 VGPRs per lane there)
@@ -1679,17 +1671,11 @@ __global__ __launch_bounds__(VT_THROUGHPUT, 4) void vu_gate_kernel_2percu(VuPrep
 }
 
 // record-fed gate builds (r06): the front has run as vu_tri_kernel; three of the short class's workgroups share a CU (48 KB each)
-constexpr int VT_REC = 256, VT_REC5 = 320;
+constexpr int VT_REC = 256;     // (five wavefronts -- one per 16-row block of P(a, a) of an 11-pose track -- measured slower on four lanes: profiles/r06/split_tri_ab_v2.txt)
 __global__ __launch_bounds__(VT_REC, 3) void vu_gate_rec_kernel(VuPrepareArgs a)
 {
     const int b = a.order ? __builtin_amdgcn_readfirstlane(a.order[blockIdx.x]) : (int)blockIdx.x;
     vu_prepare_body<VT_REC, MAXP_SMALL, 1, false, true>(a, b);
-}
-// five wavefronts: one per 16-row block of P(a, a) of the longest short track (78 active columns: 5 items of sparse_gate)
-__global__ __launch_bounds__(VT_REC5, 4) void vu_gate_rec5_kernel(VuPrepareArgs a)
-{
-    const int b = a.order ? __builtin_amdgcn_readfirstlane(a.order[blockIdx.x]) : (int)blockIdx.x;
-    vu_prepare_body<VT_REC5, MAXP_SMALL, 1, false, true>(a, b);
 }
 __global__ __launch_bounds__(VT_LATENCY, 3) void vu_gate_long_rec_kernel(VuPrepareArgs a)
 {
@@ -1806,13 +1792,12 @@ int launch_vu_tri(Ctx *c, const VuPrepareArgs &a, hipStream_t stream)
     const TriLds L(np_sel * ncam);
     const size_t bytes = sizeof(double) * (size_t)L.total;
     // four wavefronts per track where the launch may hold long tracks (their chain sets the length of the visit), one otherwise
-    // knob vu_tri_threads (experiments / tests): 64 / 128 / 256 force a build; 257 = 256 threads at 128 VGPRs
+    // knob vu_tri_threads (experiments / tests): 64 / 128 / 256 force a build
     const int forced = c->knob.vu_tri_threads;
     // auto: four wavefronts per track where the launch may hold long tracks (their chain sets the length of the visit), two for the short
     // class (profiles/r06/split_tri_ab_v2.txt: 4 lanes 27.90 ms per step with 128 threads, 28.12 with 64, 28.2 with 256)
-    const int nthr = forced == 64 || forced == 128 || forced == 256 || forced == 257 ? forced : (np_sel * ncam > MAXP_SMALL ? 256 : 128);
+    const int nthr = forced == 64 || forced == 128 || forced == 256 ? forced : (np_sel * ncam > MAXP_SMALL ? 256 : 128);
     if (nthr == 256)      hipLaunchKernelGGL(vu_tri_kernel_x4, dim3((unsigned)a.batch), dim3(256), bytes, stream, a);
-    else if (nthr == 257) hipLaunchKernelGGL(vu_tri_kernel_x4s, dim3((unsigned)a.batch), dim3(256), bytes, stream, a);
     else if (nthr == 128) hipLaunchKernelGGL(vu_tri_kernel_x2, dim3((unsigned)a.batch), dim3(128), bytes, stream, a);
     else                  hipLaunchKernelGGL(vu_tri_kernel, dim3((unsigned)a.batch), dim3(64), bytes, stream, a);
     HV_HIP(c, hipGetLastError());
@@ -1863,7 +1848,6 @@ int launch_vu_prepare(Ctx *c, const VuPrepareArgs &a, hipStream_t stream)
         }
         constexpr size_t rec_long_bytes = VuRecLds<MAXP_ALL, true>::BYTES, rec_short_bytes = VuRecLds<MAXP_SMALL>::BYTES;
         if (a.fused == 3) hipLaunchKernelGGL(vu_gate_long_rec_kernel, grid, dim3(VT_LATENCY), rec_long_bytes, stream, a);
-        else if (c->knob.vu_rec_threads == VT_REC5) hipLaunchKernelGGL(vu_gate_rec5_kernel, grid, dim3(VT_REC5), rec_short_bytes, stream, a);
         else              hipLaunchKernelGGL(vu_gate_rec_kernel, grid, dim3(VT_REC), rec_short_bytes, stream, a);
         HV_HIP(c, hipGetLastError());
         return HV_OK;
