@@ -209,6 +209,120 @@ __device__ __forceinline__ void pose_motion(const double *trail, const double *R
     for (int k = 0; k < 3; ++k) dt[k] = t1[k] + t2[k];
 }
 
+// ---- shared by the fused body (vu_prepare_body) and the split form's front (vu_tri_body) ----
+// extractCameraPoseTrail (triangulation.cpp:65-103): the record of trail pose t (pose k = t % n of camera t / n) from the mean:
+// p[3] R[9] dR[4][9] baseline[3] (POSE_WORDS doubles at o)
+__device__ __forceinline__ void trail_pose_record(const VuPrepareArgs &a, const double *m, const int *s_idx, int t, int n, double *o)
+{
+    const int cam = t / n, k = t - cam * n;
+    const double *T = a.imu_to_cam[cam];                 // 3x4 row-major [R | baseline]
+    const double Ric[9] = {T[0], T[1], T[2], T[4], T[5], T[6], T[8], T[9], T[10]}, base[3] = {T[3], T[7], T[11]};
+    int ip, io;
+    pos_ori(s_idx[k], ip, io);
+    const double q[4] = {m[io], m[io + 1], m[io + 2], m[io + 3]};
+    double Rw[9], dRw[36], R[9], t3[3];
+    quat2rmat_d(q, Rw, dRw);
+    mm3(Ric, Rw, R);
+    mTv3(R, base, t3);
+#pragma unroll
+    for (int k2 = 0; k2 < 3; ++k2) { o[k2] = m[ip + k2] - t3[k2]; o[48 + k2] = base[k2]; }
+#pragma unroll
+    for (int k2 = 0; k2 < 9; ++k2) o[3 + k2] = R[k2];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        double d[9];
+        mm3(Ric, dRw + 9 * j, d);
+#pragma unroll
+        for (int k2 = 0; k2 < 9; ++k2) o[12 + 9 * j + k2] = d[k2];
+    }
+}
+
+// triangulateWithTwoCameras between pose 0 and pose ind1 (triangulation.cpp:154-173, 612-716), by lanes j = tid < 15: lane j owns
+// derivative column j (p0 q0 p1 q1 t) of dpfTwoCameras, every one of them recomputes the small shared part; the columns land in
+// s_dpfi (mapped through dpfi_dpf, :181-199), lane 0 publishes pfi, pfw, R0', the convergence scalars and the flag
+__device__ __forceinline__ void two_camera_start(const VuPrepareArgs &a, int tid, int ind1, int ncol, int dDim, const double *s_trail,
+                                                 const double *s_feat, double *s_dpfi, double *pfi, double *pfw, double *R0T, double *scal, int *s_flag)
+{
+    const double *P0 = s_trail, *P1 = s_trail + ind1 * POSE_WORDS;
+    const double *R0 = P0 + 3, *R1 = P1 + 3;
+    double C[9], d01[3], bb[3];
+    mmT3(R0, R1, C);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) d01[k] = P1[k] - P0[k];
+    mv3(R0, d01, bb);
+    const double v0[3] = {s_feat[0], s_feat[1], 1.0}, v1[3] = {s_feat[4 * ind1], s_feat[4 * ind1 + 1], 1.0};
+    const double n0 = sqrt(v0[0] * v0[0] + v0[1] * v0[1] + 1.0), n1 = sqrt(v1[0] * v1[0] + v1[1] * v1[1] + 1.0);
+    const double vn0[3] = {v0[0] / n0, v0[1] / n0, v0[2] / n0}, vn1[3] = {v1[0] / n1, v1[1] / n1, v1[2] / n1};
+    double Cvn1[3], A[6], iA[6];
+    mv3(C, vn1, Cvn1);
+#pragma unroll
+    for (int r = 0; r < 3; ++r) { A[2 * r] = vn0[r]; A[2 * r + 1] = -Cvn1[r]; }
+    pinv32(A, iA);
+    const double s0 = iA[0] * bb[0] + iA[1] * bb[1] + iA[2] * bb[2];
+    double pf[3] = {s0 * vn0[0], s0 * vn0[1], s0 * vn0[2]};
+    double ip3[3], dd[9];
+    inverse_depth(pf, ip3, dd);
+    // column tid of dpfTwoCameras
+    double dA[6] = {0, 0, 0, 0, 0, 0}, db[3] = {0, 0, 0}, col[3];
+    const int j = tid;
+    if (j < 14) {
+        const int second = j >= 7, comp = second ? j - 7 : j;
+        if (comp < 3) {
+#pragma unroll
+            for (int r = 0; r < 3; ++r) db[r] = (second ? 1.0 : -1.0) * R0[3 * r + comp];
+        } else {
+            const int qi = comp - 3;
+            double dC[9], t[3];
+            if (!second) { mmT3(P0 + 12 + 9 * qi, R1, dC); mv3(P0 + 12 + 9 * qi, d01, db); }
+            else mmT3(R0, P1 + 12 + 9 * qi, dC);
+            mv3(dC, vn1, t);
+#pragma unroll
+            for (int r = 0; r < 3; ++r) dA[2 * r + 1] = -t[r];
+        }
+        double diA[6];
+        dpinv(A, iA, dA, diA);
+        const double ds = (iA[0] * db[0] + iA[1] * db[1] + iA[2] * db[2]) + (diA[0] * bb[0] + diA[1] * bb[1] + diA[2] * bb[2]);
+#pragma unroll
+        for (int r = 0; r < 3; ++r) col[r] = ds * vn0[r];
+    } else if (a.est_shift) {
+        double w0[3], w1[3], cw1[3], diA[6];
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            w0[r] = 0; w1[r] = 0;
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                w0[r] += ((r == c ? 1.0 : 0.0) - vn0[r] * vn0[c]) / n0 * s_feat[2 + c];
+                w1[r] += ((r == c ? 1.0 : 0.0) - vn1[r] * vn1[c]) / n1 * s_feat[4 * ind1 + 2 + c];
+            }
+        }
+        mv3(C, w1, cw1);
+#pragma unroll
+        for (int r = 0; r < 3; ++r) { dA[2 * r] = w0[r]; dA[2 * r + 1] = -cw1[r]; }
+        dpinv(A, iA, dA, diA);
+        const double ds0dt = diA[0] * bb[0] + diA[1] * bb[1] + diA[2] * bb[2];
+#pragma unroll
+        for (int r = 0; r < 3; ++r) col[r] = s0 * w0[r] + vn0[r] * ds0dt;
+    } else { col[0] = col[1] = col[2] = 0.0; }
+    // :181-199: place the two pose blocks and the time-shift column, all mapped through dpfi_dpf
+    double mapped[3];
+    mv3(dd, col, mapped);
+    const int dst = j < 7 ? j : j < 14 ? 7 * ind1 + (j - 7) : dDim;
+    if (!(j < 7 && ind1 == 0)) {                         // (a one-pose trail cannot occur: poseCount >= 2)
+#pragma unroll
+        for (int r = 0; r < 3; ++r) s_dpfi[r * ncol + dst] = mapped[r];
+    }
+    if (tid == 0) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { pfi[k] = ip3[k]; pfw[k] = pf[k]; }
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) R0T[3 * r + c] = R0[3 * c + r];
+        scal[1] = 0.0; scal[2] = 1e10;
+        s_flag[0] = 0;                                   // converged
+    }
+}
+
 // LDS layout of the kernel in doubles, for MAXP camera poses
 // LONG (the fused prepare + gate of the long class, FUSED = 3): the gate of a 49 .. 84-row track needs more room than the Gauss-Newton
 // arrays leave in the FUSED = 1 carve -- [S; v'] up to 86 x 84 doubles in [0, LONG_T) and, behind it, LONG_HS doubles for the factors of
@@ -369,30 +483,7 @@ __device__ __forceinline__ void vu_prepare_body(const VuPrepareArgs &a, const in
     } else {
     __syncthreads();
     // ---- extractCameraPoseTrail (triangulation.cpp:65-103): pose k of camera c from the mean ----
-    if (tid < nt) {
-        const int cam = tid / n, k = tid - cam * n;
-        const double *T = a.imu_to_cam[cam];                 // 3x4 row-major [R | baseline]
-        const double Ric[9] = {T[0], T[1], T[2], T[4], T[5], T[6], T[8], T[9], T[10]}, base[3] = {T[3], T[7], T[11]};
-        int ip, io;
-        pos_ori(s_idx[k], ip, io);
-        const double q[4] = {m[io], m[io + 1], m[io + 2], m[io + 3]};
-        double Rw[9], dRw[36], R[9], t[3];
-        quat2rmat_d(q, Rw, dRw);
-        mm3(Ric, Rw, R);
-        mTv3(R, base, t);
-        double *o = s_trail + tid * POSE_WORDS;
-#pragma unroll
-        for (int k2 = 0; k2 < 3; ++k2) { o[k2] = m[ip + k2] - t[k2]; o[48 + k2] = base[k2]; }
-#pragma unroll
-        for (int k2 = 0; k2 < 9; ++k2) o[3 + k2] = R[k2];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            double d[9];
-            mm3(Ric, dRw + 9 * j, d);
-#pragma unroll
-            for (int k2 = 0; k2 < 9; ++k2) o[12 + 9 * j + k2] = d[k2];
-        }
-    }
+    if (tid < nt) trail_pose_record(a, m, s_idx, tid, n, s_trail + tid * POSE_WORDS);
     for (int i = tid; i < 3 * ncol; i += VT) s_dpfi[i] = 0.0;
     __syncthreads();
     VU_STAMP(1);
@@ -498,86 +589,7 @@ __device__ __forceinline__ void vu_prepare_body(const VuPrepareArgs &a, const in
     // ---- triangulateWithTwoCameras between pose 0 and pose ind1 (triangulation.cpp:154-173, 612-716): thread j < 15
     // owns derivative column j (p0 q0 p1 q1 t); every one of them recomputes the small shared part ----
     const int ind1 = a.stereo ? nt / 2 - 1 : nt - 1;
-    const double *P0 = s_trail, *P1 = s_trail + ind1 * POSE_WORDS;
-    if (tid < 15) {
-        const double *R0 = P0 + 3, *R1 = P1 + 3;
-        double C[9], d01[3], bb[3];
-        mmT3(R0, R1, C);
-#pragma unroll
-        for (int k = 0; k < 3; ++k) d01[k] = P1[k] - P0[k];
-        mv3(R0, d01, bb);
-        const double v0[3] = {s_feat[0], s_feat[1], 1.0}, v1[3] = {s_feat[4 * ind1], s_feat[4 * ind1 + 1], 1.0};
-        const double n0 = sqrt(v0[0] * v0[0] + v0[1] * v0[1] + 1.0), n1 = sqrt(v1[0] * v1[0] + v1[1] * v1[1] + 1.0);
-        const double vn0[3] = {v0[0] / n0, v0[1] / n0, v0[2] / n0}, vn1[3] = {v1[0] / n1, v1[1] / n1, v1[2] / n1};
-        double Cvn1[3], A[6], iA[6];
-        mv3(C, vn1, Cvn1);
-#pragma unroll
-        for (int r = 0; r < 3; ++r) { A[2 * r] = vn0[r]; A[2 * r + 1] = -Cvn1[r]; }
-        pinv32(A, iA);
-        const double s0 = iA[0] * bb[0] + iA[1] * bb[1] + iA[2] * bb[2];
-        double pf[3] = {s0 * vn0[0], s0 * vn0[1], s0 * vn0[2]};
-        double ip3[3], dd[9];
-        inverse_depth(pf, ip3, dd);
-        // column tid of dpfTwoCameras
-        double dA[6] = {0, 0, 0, 0, 0, 0}, db[3] = {0, 0, 0}, col[3];
-        const int j = tid;
-        if (j < 14) {
-            const int second = j >= 7, comp = second ? j - 7 : j;
-            if (comp < 3) {
-#pragma unroll
-                for (int r = 0; r < 3; ++r) db[r] = (second ? 1.0 : -1.0) * R0[3 * r + comp];
-            } else {
-                const int qi = comp - 3;
-                double dC[9], t[3];
-                if (!second) { mmT3(P0 + 12 + 9 * qi, R1, dC); mv3(P0 + 12 + 9 * qi, d01, db); }
-                else mmT3(R0, P1 + 12 + 9 * qi, dC);
-                mv3(dC, vn1, t);
-#pragma unroll
-                for (int r = 0; r < 3; ++r) dA[2 * r + 1] = -t[r];
-            }
-            double diA[6];
-            dpinv(A, iA, dA, diA);
-            const double ds = (iA[0] * db[0] + iA[1] * db[1] + iA[2] * db[2]) + (diA[0] * bb[0] + diA[1] * bb[1] + diA[2] * bb[2]);
-#pragma unroll
-            for (int r = 0; r < 3; ++r) col[r] = ds * vn0[r];
-        } else if (a.est_shift) {
-            double w0[3], w1[3], cw1[3], diA[6];
-#pragma unroll
-            for (int r = 0; r < 3; ++r) {
-                w0[r] = 0; w1[r] = 0;
-#pragma unroll
-                for (int c = 0; c < 2; ++c) {
-                    w0[r] += ((r == c ? 1.0 : 0.0) - vn0[r] * vn0[c]) / n0 * s_feat[2 + c];
-                    w1[r] += ((r == c ? 1.0 : 0.0) - vn1[r] * vn1[c]) / n1 * s_feat[4 * ind1 + 2 + c];
-                }
-            }
-            mv3(C, w1, cw1);
-#pragma unroll
-            for (int r = 0; r < 3; ++r) { dA[2 * r] = w0[r]; dA[2 * r + 1] = -cw1[r]; }
-            dpinv(A, iA, dA, diA);
-            const double ds0dt = diA[0] * bb[0] + diA[1] * bb[1] + diA[2] * bb[2];
-#pragma unroll
-            for (int r = 0; r < 3; ++r) col[r] = s0 * w0[r] + vn0[r] * ds0dt;
-        } else { col[0] = col[1] = col[2] = 0.0; }
-        // :181-199: place the two pose blocks and the time-shift column, all mapped through dpfi_dpf
-        double mapped[3];
-        mv3(dd, col, mapped);
-        const int dst = j < 7 ? j : j < 14 ? 7 * ind1 + (j - 7) : dDim;
-        if (!(j < 7 && ind1 == 0)) {                         // (a one-pose trail cannot occur: poseCount >= 2)
-#pragma unroll
-            for (int r = 0; r < 3; ++r) s_dpfi[r * ncol + dst] = mapped[r];
-        }
-        if (tid == 0) {
-#pragma unroll
-            for (int k = 0; k < 3; ++k) { pfi[k] = ip3[k]; pfw[k] = pf[k]; }
-#pragma unroll
-            for (int r = 0; r < 3; ++r)
-#pragma unroll
-                for (int c = 0; c < 3; ++c) R0T[3 * r + c] = R0[3 * c + r];
-            scal[1] = 0.0; scal[2] = 1e10;
-            s_flag[0] = 0;                                   // converged
-        }
-    }
+    if (tid < 15) two_camera_start(a, tid, ind1, ncol, dDim, s_trail, s_feat, s_dpfi, pfi, pfw, R0T, scal, s_flag);
     __syncthreads();
     // ---- Gauss-Newton with derivatives (triangulation.cpp:206-343) ----
     // Lanes of the derivative-column phase. Every (pose i, column j) pair contributes through d(pfi)/dx_j (the plain
@@ -1199,114 +1211,14 @@ __device__ __forceinline__ void vu_tri_body(const VuPrepareArgs &a, const int b)
     sync();
     TRI_STAMP(1);
     // ---- extractCameraPoseTrail (triangulation.cpp:65-103) ----
-    if (tid < nt) {
-        const int cam = tid / n, k = tid - cam * n;
-        const double *T = a.imu_to_cam[cam];
-        const double Ric[9] = {T[0], T[1], T[2], T[4], T[5], T[6], T[8], T[9], T[10]}, base[3] = {T[3], T[7], T[11]};
-        int ip, io;
-        pos_ori(s_idx[k], ip, io);
-        const double q[4] = {m[io], m[io + 1], m[io + 2], m[io + 3]};
-        double Rw[9], dRw[36], R[9], t[3];
-        quat2rmat_d(q, Rw, dRw);
-        mm3(Ric, Rw, R);
-        mTv3(R, base, t);
-        double *o = s_trail + tid * POSE_WORDS;
-#pragma unroll
-        for (int k2 = 0; k2 < 3; ++k2) { o[k2] = m[ip + k2] - t[k2]; o[48 + k2] = base[k2]; }
-#pragma unroll
-        for (int k2 = 0; k2 < 9; ++k2) o[3 + k2] = R[k2];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            double d[9];
-            mm3(Ric, dRw + 9 * j, d);
-#pragma unroll
-            for (int k2 = 0; k2 < 9; ++k2) o[12 + 9 * j + k2] = d[k2];
-        }
-    }
+    if (tid < nt) trail_pose_record(a, m, s_idx, tid, n, s_trail + tid * POSE_WORDS);
     for (int i = tid; i < 3 * ncol; i += NT) s_dpfi[i] = 0.0;
     sync();
     TRI_STAMP(2);
     const double *p0 = s_trail;
     // ---- triangulateWithTwoCameras between pose 0 and pose ind1 (:154-173, 612-716): lane j < 15 owns derivative column j ----
     const int ind1 = a.stereo ? nt / 2 - 1 : nt - 1;
-    if (tid < 15) {
-        const double *P0 = s_trail, *P1 = s_trail + ind1 * POSE_WORDS;
-        const double *R0 = P0 + 3, *R1 = P1 + 3;
-        double C[9], d01[3], bb[3];
-        mmT3(R0, R1, C);
-#pragma unroll
-        for (int k = 0; k < 3; ++k) d01[k] = P1[k] - P0[k];
-        mv3(R0, d01, bb);
-        const double v0[3] = {s_feat[0], s_feat[1], 1.0}, v1[3] = {s_feat[4 * ind1], s_feat[4 * ind1 + 1], 1.0};
-        const double n0 = sqrt(v0[0] * v0[0] + v0[1] * v0[1] + 1.0), n1 = sqrt(v1[0] * v1[0] + v1[1] * v1[1] + 1.0);
-        const double vn0[3] = {v0[0] / n0, v0[1] / n0, v0[2] / n0}, vn1[3] = {v1[0] / n1, v1[1] / n1, v1[2] / n1};
-        double Cvn1[3], A[6], iA[6];
-        mv3(C, vn1, Cvn1);
-#pragma unroll
-        for (int r = 0; r < 3; ++r) { A[2 * r] = vn0[r]; A[2 * r + 1] = -Cvn1[r]; }
-        pinv32(A, iA);
-        const double s0 = iA[0] * bb[0] + iA[1] * bb[1] + iA[2] * bb[2];
-        double pf[3] = {s0 * vn0[0], s0 * vn0[1], s0 * vn0[2]};
-        double ip3[3], dd[9];
-        inverse_depth(pf, ip3, dd);
-        double dA[6] = {0, 0, 0, 0, 0, 0}, db[3] = {0, 0, 0}, col[3];
-        const int j = tid;
-        if (j < 14) {
-            const int second = j >= 7, comp = second ? j - 7 : j;
-            if (comp < 3) {
-#pragma unroll
-                for (int r = 0; r < 3; ++r) db[r] = (second ? 1.0 : -1.0) * R0[3 * r + comp];
-            } else {
-                const int qi = comp - 3;
-                double dC[9], t[3];
-                if (!second) { mmT3(P0 + 12 + 9 * qi, R1, dC); mv3(P0 + 12 + 9 * qi, d01, db); }
-                else mmT3(R0, P1 + 12 + 9 * qi, dC);
-                mv3(dC, vn1, t);
-#pragma unroll
-                for (int r = 0; r < 3; ++r) dA[2 * r + 1] = -t[r];
-            }
-            double diA[6];
-            dpinv(A, iA, dA, diA);
-            const double ds = (iA[0] * db[0] + iA[1] * db[1] + iA[2] * db[2]) + (diA[0] * bb[0] + diA[1] * bb[1] + diA[2] * bb[2]);
-#pragma unroll
-            for (int r = 0; r < 3; ++r) col[r] = ds * vn0[r];
-        } else if (a.est_shift) {
-            double w0[3], w1[3], cw1[3], diA[6];
-#pragma unroll
-            for (int r = 0; r < 3; ++r) {
-                w0[r] = 0; w1[r] = 0;
-#pragma unroll
-                for (int c = 0; c < 2; ++c) {
-                    w0[r] += ((r == c ? 1.0 : 0.0) - vn0[r] * vn0[c]) / n0 * s_feat[2 + c];
-                    w1[r] += ((r == c ? 1.0 : 0.0) - vn1[r] * vn1[c]) / n1 * s_feat[4 * ind1 + 2 + c];
-                }
-            }
-            mv3(C, w1, cw1);
-#pragma unroll
-            for (int r = 0; r < 3; ++r) { dA[2 * r] = w0[r]; dA[2 * r + 1] = -cw1[r]; }
-            dpinv(A, iA, dA, diA);
-            const double ds0dt = diA[0] * bb[0] + diA[1] * bb[1] + diA[2] * bb[2];
-#pragma unroll
-            for (int r = 0; r < 3; ++r) col[r] = s0 * w0[r] + vn0[r] * ds0dt;
-        } else { col[0] = col[1] = col[2] = 0.0; }
-        double mapped[3];
-        mv3(dd, col, mapped);
-        const int dst = j < 7 ? j : j < 14 ? 7 * ind1 + (j - 7) : dDim;
-        if (!(j < 7 && ind1 == 0)) {
-#pragma unroll
-            for (int r = 0; r < 3; ++r) s_dpfi[r * ncol + dst] = mapped[r];
-        }
-        if (tid == 0) {
-#pragma unroll
-            for (int k = 0; k < 3; ++k) { pfi[k] = ip3[k]; pfw[k] = pf[k]; }
-#pragma unroll
-            for (int r = 0; r < 3; ++r)
-#pragma unroll
-                for (int c = 0; c < 3; ++c) R0T[3 * r + c] = R0[3 * c + r];
-            scal[1] = 0.0; scal[2] = 1e10;
-            s_flag[0] = 0;
-        }
-    }
+    if (tid < 15) two_camera_start(a, tid, ind1, ncol, dDim, s_trail, s_feat, s_dpfi, pfi, pfw, R0T, scal, s_flag);
     sync();
     TRI_STAMP(3);
     // ---- Gauss-Newton with derivatives (:206-343) ----
