@@ -1235,7 +1235,7 @@ class BenchRun:
         # independent inlier patterns, quota 5, symmetrise, augmentation, 10 predicts ----
         self.names = (("pyr_l0", capi.K_PYR_L0), ("pyr_ln", capi.K_PYR_LN), ("klt", capi.K_KLT), ("rot_ransac", capi.K_ROT_RANSAC), ("gftt", capi.K_GFTT),
                  ("ekf_predict", capi.K_EKF_PREDICT), ("vu_prepare", capi.K_VU_PREPARE), ("ekf_update_gate", capi.K_EKF_UPDATE),
-                 ("ekf_gate", capi.K_EKF_GATE), ("ekf_augment", capi.K_EKF_AUGMENT))
+                 ("ekf_gate", capi.K_EKF_GATE), ("ekf_augment", capi.K_EKF_AUGMENT), ("vu_tri", capi.K_VU_TRI))
         self.keep_graphs = []
         self.out = {}
 
@@ -1503,7 +1503,9 @@ class BenchRun:
         alg = {"klt": self.B * ab["klt_call"], "pyr_l0": 2 * self.B * ab["pyr_l0"], "pyr_ln": 2 * self.B * ab["pyr_ln"] * self.nprof3 / max(1, self.k3.get("pyr_ln", {}).get("launches", 1)),
                "vu_prepare": self.B * (n_state * 8 + 12 * 8 * 2 * self.lens_mean + na_mean * na_mean * 8 + hc_bytes),
                "ekf_update_gate": self.B * (QUOTA / VISITS) * (2 * p_bytes + hc_bytes), "ekf_gate": self.B * (na_mean * na_mean * 8 + hc_bytes),
-               "ekf_augment": self.B * p_bytes * 2, "ekf_predict": self.B * p_bytes * 2, "rot_ransac": self.B * NPTS * 20, "gftt": self.B * W * H}
+               "ekf_augment": self.B * p_bytes * 2, "ekf_predict": self.B * p_bytes * 2, "rot_ransac": self.B * NPTS * 20, "gftt": self.B * W * H,
+               # r06, the split form's front: mean in, track in, factor record out (17 values per camera pose, 21 per pose, 4)
+               "vu_tri": self.B * (n_state * 8 + 12 * 8 * 2 * self.lens_mean + (17 * 2 + 21) * 8 * self.lens_mean + 32)}
         for k in self.k3:
             self.k3[k]["algorithmic_bytes_per_launch"] = alg[k]
             self.k3[k]["achieved_GBs"] = alg[k] / (self.k3[k]["avg_ms"] * 1e-3) / 1e9
@@ -1553,7 +1555,11 @@ class BenchRun:
         VALU_PEAK_WAVE_INSTS = 565e9
         VALU_CYCLES_PER_INST = 4.0
         valu_pf = pmc("klt", "valu_insts_per_feature")
-        flops_vu = self.B * (1.1e6 * self.lens_mean / 10.0 + 2 * rows_mean * na_mean * na_mean + 2 * rows_mean * rows_mean * na_mean + rows_mean ** 3 / 3)
+        # f64 flops of a visit: the front (triangulation with derivatives: ~1.1 Mflop per 10-pose track in r01 .. r05's count; r06 evaluates
+        # 11 nt - 7 motion pairs instead of 14 nt - 7) and the gate (two products on the active columns + the Cholesky of S)
+        flops_front = self.B * 1.1e6 * self.lens_mean / 10.0 * (11.0 / 14.0)
+        flops_gate = self.B * (2 * rows_mean * na_mean * na_mean + 2 * rows_mean * rows_mean * na_mean + rows_mean ** 3 / 3)
+        flops_vu = flops_front + flops_gate
         limiter = {"klt": "VALU issue: klt_kernel's packed-integer instructions (dot2 / perm / pk / DPP) issue every 4 cycles per SIMD on gfx950; it runs at "
                           "~0.85 of that measured ceiling, HBM traffic is a quarter of the agreed bytes (profiles/r05/valu_issue_ubench.txt)",
                    "vu_prepare": "per-workgroup latency: the fused triangulation + prepareVisualUpdate + column-sparse chi2 gate kernel is a chain of ~50 "
@@ -1615,13 +1621,17 @@ class BenchRun:
                              "stage_pyramid_klt": stage},
                 # the EKF half reported separately, per kernel class of the visit loop (hipEvents of the one-engine eager region; the long class's
                 # launch runs beside the short class's on a second stream: these per-class times are NOT additive wall time)
-                "roofline_ekf": {"bound": "f64-valu+mfma/latency", "kernel": "r06 split form: vu_tri_kernel_x2 -> vu_gate_rec_kernel (short class), vu_tri_kernel_x4 -> vu_gate_long_rec_kernel (long class); the class's hipEvent time covers all four launches",
+                "roofline_ekf": {"bound": "f64-valu+mfma/latency", "kernel": "r06 split form: vu_tri_kernel_x2 -> vu_gate_rec_kernel (short class), vu_tri_kernel_x4 -> vu_gate_long_rec_kernel (long class); avg_launch_ms = the two record-fed gate launches of a visit (timer class vu_prepare), front_avg_launch_ms = the two fronts (timer class vu_tri)",
                                  "avg_launch_ms": self.k3.get("vu_prepare", {}).get("avg_ms"), "algorithmic_bytes_per_launch": alg["vu_prepare"],
                                  "achieved": self.k3.get("vu_prepare", {}).get("achieved_GBs"), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                  "frac": (self.k3["vu_prepare"]["achieved_GBs"] / HBM_PEAK_GBS) if "vu_prepare" in self.k3 else None,
-                                 "f64_flop_frac": (flops_vu / (self.k3["vu_prepare"]["avg_ms"] * 1e-3) / 1e12 / f64_peak_tflops) if "vu_prepare" in self.k3 else None,
+                                 # (r03 .. r05's convention: a visit's flops over the AVERAGE launch time of the class -- the short and the long class's launches
+                                 #  run beside each other in this eager forked region)
+                                 "f64_flop_frac": ((flops_gate if "vu_tri" in self.k3 else flops_vu) / (self.k3["vu_prepare"]["avg_ms"] * 1e-3) / 1e12 / f64_peak_tflops) if "vu_prepare" in self.k3 else None,
+                                 "front_f64_flop_frac": (flops_front / (self.k3["vu_tri"]["avg_ms"] * 1e-3) / 1e12 / f64_peak_tflops) if "vu_tri" in self.k3 else None,
                                  "mfma_busy_frac": pmc("vu_prepare", "mfma_busy_frac"),
                                  "wave_parked_frac": pmc("vu_prepare", "wave_parked_frac"),
+                                 "front_avg_launch_ms": self.k3.get("vu_tri", {}).get("avg_ms"),
                                  "update_avg_launch_ms": self.k3.get("ekf_update_gate", {}).get("avg_ms"),
                                  "update_achieved_GBs": self.k3.get("ekf_update_gate", {}).get("achieved_GBs"),
                                  "limiter": "per-workgroup latency and LDS slots: the triangulation is a chain of f64 phases (a lone wavefront issues an f64 instruction every ~6.5 cycles), the gates a 16-wide Cholesky chain; neither HBM nor the matrix pipe bounds them (profiles/r06)"},
@@ -1631,7 +1641,7 @@ class BenchRun:
                 "timers_ms_per_step": {"pyramid": sum(self.k3[k]["ms_per_step"] for k in ("pyr_l0", "pyr_ln") if k in self.k3),
                                        "computeOpticalFlow": self.k3.get("klt", {}).get("ms_per_step"),
                                        "KF predict": self.k3.get("ekf_predict", {}).get("ms_per_step"),
-                                       "trackerVisualUpdate": sum(self.k3[k]["ms_per_step"] for k in ("vu_prepare", "ekf_update_gate", "ekf_gate") if k in self.k3),
+                                       "trackerVisualUpdate": sum(self.k3[k]["ms_per_step"] for k in ("vu_tri", "vu_prepare", "ekf_update_gate", "ekf_gate") if k in self.k3),
                                        "augmentation": self.k3.get("ekf_augment", {}).get("ms_per_step"),
                                        "note": "per-class hipEvent sums over the eager profiling steps; in the realistic leg the long class's prepare + "
                                                "gate launches run on a second stream BESIDE the short class's fused launch (DESIGN 3.3 o), so the "

@@ -29,7 +29,7 @@ f32p = C.POINTER(C.c_float)
 f64p = C.POINTER(C.c_double)
 
 HV_MAX_LEVELS = 6
-K_PYR_L0, K_PYR_LN, K_KLT, K_EKF_PREDICT, K_EKF_UPDATE, K_EKF_AUGMENT, K_GFTT, K_INGEST, K_VU_PREPARE, K_ROT_RANSAC, K_EKF_GATE = range(11)
+K_PYR_L0, K_PYR_LN, K_KLT, K_EKF_PREDICT, K_EKF_UPDATE, K_EKF_AUGMENT, K_GFTT, K_INGEST, K_VU_PREPARE, K_ROT_RANSAC, K_EKF_GATE, K_VU_TRI = range(12)
 
 # tracker::Feature::Status (src/tracker/track.hpp:9-21)
 ST_TRACKED, ST_NEW, ST_FAILED_FLOW, ST_RANSAC_OUTLIER, ST_FLOW_OUT_OF_RANGE = 0, 1, 2, 3, 4

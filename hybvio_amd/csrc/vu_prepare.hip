@@ -1699,7 +1699,7 @@ int launch_vu_tri(Ctx *c, const VuPrepareArgs &a, hipStream_t stream)
     const int ncam = a.stereo ? 2 : 1;
     if (a.np < 2 || a.batch < 1 || a.np > MAXNP || a.np * ncam > MAXP_ALL) return HV_ERR_INVALID;
     if (!a.tri_rec || a.tri_stride < vu_tri_rec_stride(a.np, ncam) || a.spec_tracks > 0 || a.linear || a.map_index) return HV_ERR_INVALID;
-    ScopedKernelTime tm(c, HV_K_VU_PREPARE, stream);
+    ScopedKernelTime tm(c, HV_K_VU_TRI, stream);
     const int np_sel = a.np_hi > 0 && a.np_hi < a.np ? a.np_hi : a.np;
     const TriLds L(np_sel * ncam);
     const size_t bytes = sizeof(double) * (size_t)L.total;

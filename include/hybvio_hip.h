@@ -493,7 +493,9 @@ int hv_rot_ransac_lk_batch_dev(hv_ctx *ctx, int n_sets, int max_points, const in
 
 /* ---- per-kernel timing (hipEvents on the context stream) ---------------------------------- */
 enum { HV_K_PYR_L0 = 0, HV_K_PYR_LN = 1, HV_K_KLT = 2, HV_K_EKF_PREDICT = 3, HV_K_EKF_UPDATE = 4,
-       HV_K_EKF_AUGMENT = 5, HV_K_GFTT = 6, HV_K_INGEST = 7, HV_K_VU_PREPARE = 8, HV_K_ROT_RANSAC = 9, HV_K_EKF_GATE = 10, HV_K_COUNT = 11 };
+       HV_K_EKF_AUGMENT = 5, HV_K_GFTT = 6, HV_K_INGEST = 7, HV_K_VU_PREPARE = 8, HV_K_ROT_RANSAC = 9, HV_K_EKF_GATE = 10,
+       HV_K_VU_TRI = 11 /* r06: the triangulation front of the split form (vu_tri_kernel); HV_K_VU_PREPARE then times the record-fed gates */,
+       HV_K_COUNT = 12 };
 int hv_profile_enable(hv_ctx *ctx, int on);
 int hv_profile_reset(hv_ctx *ctx);
 /* Synchronizes, then returns accumulated device milliseconds and launch count of a kernel class. */
