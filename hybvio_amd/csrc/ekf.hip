@@ -536,6 +536,11 @@ __device__ __forceinline__ void ekf_update_body(const UpdateArgs &a, const int b
     const int nr_rec_v = shape_pin;
     if (!act_v) return;
     if (req_v != 0) return;
+#ifdef HV_DEBUG_SKIP_UPDATE
+    // experiment only (scripts/lanes_probe.py, never in the shipped library): what do the update workgroups cost a step? An applied
+    // update counts as a success and leaves (m, P) as they are
+    if (a.mode == 1 && a.spec == 0) { if (a.success_counter && t == 0) a.success_counter[b] += 1; return; }
+#endif
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);     // wave-uniform: tile indices and their addresses stay on the scalar unit
     constexpr int nwaves = UPD_THREADS / 64;
     const int n = a.n, l = a.l;
@@ -2195,10 +2200,14 @@ static int visual_track_dev_impl(hv_ekf *h, const hv_vu_params *p, int np, const
 // shapes of a track visit: the longest track the short class's fused two-per-CU kernels serve, whether tracks of np poses take the
 // long-class launches (49 .. 96 rows), and whether a ragged visit of up to np poses runs as TWO length classes
 struct VisitShape { int ncam, np_short, rows; bool long_ok, two_class; };
-static VisitShape visit_shape(const Ekf *e, int np, bool stereo)
+// (r06: where the split form serves the visit -- stereo, iterative triangulation, more filters than CUs -- the short class ends at
+//  12 poses = 48 rows, what the record-fed gate stages three to a CU, instead of 11: 4 % of a ragged visit's records leave the long
+//  class, its 158 KB gate and its two block updates)
+static VisitShape visit_shape(const Ekf *e, int np, bool stereo, bool linear)
 {
     VisitShape v{};
     v.ncam = stereo ? 2 : 1; v.np_short = 22 / v.ncam; v.rows = 2 * np * v.ncam;
+    if (hv::vu_split_short_ok(e->c, e->n, stereo, e->batch, linear)) v.np_short = hv::vu_split_short_np(e->c);
     v.long_ok = e->c->knob.ekf_fused_gate != 0 && e->n <= 160 && v.rows > 48 && v.rows <= 96 && v.rows < HV_CHI2INV95_N && (v.rows + 3) / 4 * 2 <= 48;
     v.two_class = np > v.np_short && v.long_ok && hv::vu_fused_supported(e->c, e->n, v.np_short, stereo, e->batch);
     return v;
@@ -2311,7 +2320,7 @@ static int visual_track_dev_impl(hv_ekf *h, const hv_vu_params *p, int np, const
     // Long tracks (more than 48 rows / 22 camera poses: 12 .. 21 stereo poses): prepare + column-sparse gate of up to 96 rows in ONE
     // launch (r04: vu_gate_long_kernel; r03: vu_compact_kernel + ekf_sparse_gate_big_kernel, kept behind knob ekf_long_fused = 0) and the
     // update as TWO block updates of at most 48 rows each on the P-resident kernel (UpdateArgs::half).
-    const VisitShape shape = visit_shape(e, np, a.stereo != 0);
+    const VisitShape shape = visit_shape(e, np, a.stereo != 0, a.linear != 0);
     const int ncam = shape.ncam, np_short = shape.np_short;
     const bool long_ok = shape.long_ok;
     // compaction lists of this visit (VuPrepareArgs): zeroed here, filled by the kernels, consumed by the launches behind them
@@ -2643,7 +2652,7 @@ static int visual_frame_dev_impl(hv_ekf *h, const hv_vu_params *p, int n_tracks,
     // a longer one block by block (UpdateArgs::half_auto; sel_io hands the chosen track from the first launch to the second).
     // <= quota + 1 passes of three launches instead of n_tracks visits of four.
     if (!c->knob.ekf_no_speculation && !adaptive && n_tracks >= 2 && B * (size_t)n_tracks <= (size_t)c->num_cus && rows > 48 && p && idx && feat && vel && y &&
-        c->knob.ekf_spec_split == 0 && c->knob.ekf_spec_mode != 3 && c->knob.ekf_long_fused != 0 && visit_shape(e, np, p->useStereo != 0).long_ok) {
+        c->knob.ekf_spec_split == 0 && c->knob.ekf_spec_mode != 3 && c->knob.ekf_long_fused != 0 && visit_shape(e, np, p->useStereo != 0, p->useLinearTriangulation != 0).long_ok) {
         const size_t rec = B * (size_t)n_tracks;
         { const int rc_sp = ensure_spec_buffers(e, rec, rows); if (rc_sp != HV_OK) return rc_sp; }
         if (!e->side_dm) {
@@ -2756,7 +2765,7 @@ static int visual_frame_dev_impl(hv_ekf *h, const hv_vu_params *p, int n_tracks,
     //  a single sequence went from 1.14 to 1.51 ms per frame with them)
     if (p && np_rec_dev && c->knob.ekf_visit_order != 0 && n_tracks >= 1 && n_tracks <= Ekf::VISIT_SLOTS && (B > (size_t)c->num_cus || c->knob.ekf_visit_order == 2)) {
         // (only where the visits really run as two length classes: 12 stereo poses = 48 rows still ride the short class -- r03 advisor)
-        const VisitShape shape = visit_shape(e, np, p->useStereo != 0);
+        const VisitShape shape = visit_shape(e, np, p->useStereo != 0, p->useLinearTriangulation != 0);
         if (shape.two_class) {
             const int rc = hv::launch_visit_order(c, n_tracks, B, np_rec_dev, 2, shape.np_short, np, e->visit_order, e->visit_long, e->visit_long_count);
             if (rc != HV_OK) return rc;
@@ -2813,7 +2822,7 @@ int hv_ekf_visual_frame_batch_dev(hv_ekf *h, const hv_vu_params *p, int n_tracks
     if (p->trackOutlierThresholdGrowthFactor != 1.0) return HV_ERR_UNSUPPORTED;
     const size_t B = (size_t)e->batch, rec = B * (size_t)n_tracks;
     if (rec > 8192) return HV_ERR_UNSUPPORTED;                               // (every record's compact Jacobian is resident during a pass)
-    const VisitShape shape = visit_shape(e, np, p->useStereo != 0);
+    const VisitShape shape = visit_shape(e, np, p->useStereo != 0, p->useLinearTriangulation != 0);
     const bool long_build = rows > 48;
     if (long_build ? !(shape.long_ok && c->knob.ekf_long_fused != 0) : !hv::vu_fused_supported(c, e->n, np, p->useStereo != 0, (int)rec)) return HV_ERR_UNSUPPORTED;
     { const int rc_sp = ensure_spec_buffers(e, rec, rows); if (rc_sp != HV_OK) return rc_sp; }

@@ -35,6 +35,7 @@ namespace {
 constexpr int VT_LATENCY = 768, VT_THROUGHPUT = 384;
 constexpr int MAXP_ALL = 42;            // 2 cameras x (cameraTrailLength + 1 <= 21) poses: the largest track
 constexpr int MAXP_SMALL = 22;          // the 384-thread build: up to 22 camera poses (10 or 11 stereo poses, 21 mono poses)
+constexpr int MAXP_REC = 24;            // the record-fed short-class gate (r06): up to 12 stereo poses = 48 rows, everything sparse_gate's 3 row tiles hold
 constexpr int MAXNP = 21;              // poses per camera: s_dpf is [MAXNP][21], s_idx holds MAXNP (+3 spare) indices
 constexpr int POSE_WORDS = 51;          // p[3] R[9] dR[4][9] baseline[3]
 constexpr int ITER_WORDS = 26;          // C[9] t[3] h[3] E[6] err[2] d[3]
@@ -357,15 +358,16 @@ struct VuRecLds {
     static constexpr int LONG_T = 7224, LONG_HS = 12432;
     static constexpr int TRAIL = 0, IT = 0, FEAT = IT + MAXP * ITER_WORDS, DPF = FEAT + MAXP * 4, DPFI = DPF + MAXP * 21, SMALL = DPFI + 4,
                          SMALL_END = SMALL + 64;
-    static constexpr int P0 = LONG ? LONG_T : 2068;                      // short class: [S; v'] of up to 44 rows at stride 47
+    static constexpr int P0 = LONG ? LONG_T : 2352;                      // short class: [S; v'] of up to 48 rows at stride 49 (44 rows: 47)
     static constexpr int MOT = P0, OWN = P0, LIN = P0;                   // (no Gauss-Newton arrays)
-    static constexpr int INTS = LONG ? LONG_T + LONG_HS : P0 + 3840;     // short class: the staged Jacobian, 80 columns x 48 rows
+    static constexpr int INTS = LONG ? LONG_T + LONG_HS : P0 + 4224;     // short class: the staged Jacobian, 88 columns x 48 rows
     static constexpr int TOTAL = INTS + (MAXNP + 3 + 4 + MAXC + 1) / 2 + 1;
     static constexpr int HS_DOUBLES = INTS - P0, T_DOUBLES = P0;
     static_assert(SMALL_END <= P0, "the record's copies must fit in front of the staged Jacobian");
     static constexpr size_t BYTES = sizeof(double) * TOTAL;
 };
-static_assert(3 * VuRecLds<22>::BYTES <= 160 * 1024, "three record-fed short-class gates per CU");
+// (LDS is handed out in granules of 1280 bytes, 128 per CU: three workgroups get 42 each; 32 bytes of static LDS ride along -- gate_turn_lds)
+static_assert(VuRecLds<MAXP_REC>::BYTES + 32 <= 42 * 1280, "three record-fed short-class gates per CU");
 
 // MAXP (camera poses the LDS arrays are sized for) is a template parameter next to VT: <768, 42> holds every track (151 KB of LDS,
 // one workgroup per CU); <384, 22> holds the common sizes in 75 KB and 6 waves of 138 VGPRs, so TWO filters share a CU and one's
@@ -1587,7 +1589,7 @@ constexpr int VT_REC = 256;     // (five wavefronts -- one per 16-row block of P
 __global__ __launch_bounds__(VT_REC, 3) void vu_gate_rec_kernel(VuPrepareArgs a)
 {
     const int b = a.order ? __builtin_amdgcn_readfirstlane(a.order[blockIdx.x]) : (int)blockIdx.x;
-    vu_prepare_body<VT_REC, MAXP_SMALL, 1, false, true>(a, b);
+    vu_prepare_body<VT_REC, MAXP_REC, 1, false, true>(a, b);
 }
 __global__ __launch_bounds__(VT_LATENCY, 3) void vu_gate_long_rec_kernel(VuPrepareArgs a)
 {
@@ -1682,15 +1684,29 @@ bool vu_fused_supported(const Ctx *c, int n_state, int np, int stereo, int batch
 }
 
 // shapes the split form serves: iterative triangulation of pose-trail tracks, no speculation; the record-fed short-class gate holds
-// stereo tracks of up to 11 poses (its staged Jacobian is 80 x 48 doubles), the long-class gate everything vu_gate_long_kernel does
+// stereo tracks of up to 12 poses (its staged Jacobian is 88 x 48 doubles), the long-class gate everything vu_gate_long_kernel does
+// vu_split_short_ok: what a caller knows before the arguments of a launch exist (ekf.hip visit_shape: where the short class ends)
+bool vu_split_short_ok(const Ctx *c, int n_state, bool stereo, int batch, bool linear)
+{
+    // (knob value 2: at every batch size -- tests; 1: where the two-per-CU fused build would run)
+    return c->knob.ekf_split_tri != 0 && stereo && !linear && n_state <= 160 && (batch > 256 || c->knob.ekf_split_tri == 2);
+}
+int vu_split_short_np(const Ctx *c) { return c->knob.ekf_short_np == 11 ? 11 : MAXP_REC / 2; }
+
 bool vu_split_supported(const Ctx *c, const VuPrepareArgs &a, int fused)
 {
     if (c->knob.ekf_split_tri == 0 || a.linear || a.map_index || a.spec_tracks > 0 || !a.P || a.n > 160) return false;
     const int ncam = a.stereo ? 2 : 1, np_sel = a.np_hi > 0 && a.np_hi < a.np ? a.np_hi : a.np;
     if (a.np > MAXNP || a.np * ncam > MAXP_ALL) return false;
-    // (knob value 2: at every batch size -- tests; 1: where the two-per-CU fused build would run)
-    if (fused == 1) return a.stereo && np_sel * ncam <= MAXP_SMALL && (a.batch > 256 || c->knob.ekf_split_tri == 2) && vu_fused_supported(c, a.n, np_sel, a.stereo, a.batch);
-    return fused == 3;
+    if (fused == 1) {
+        if (!vu_split_short_ok(c, a.n, a.stereo != 0, a.batch, a.linear != 0) || np_sel * ncam > MAXP_REC) return false;
+        const int rows = 2 * np_sel * ncam, na4 = (7 * np_sel + 1 + 3) & ~3, nrp = 16 * ((rows + 15) / 16);
+        int Rs = rows + 1;
+        while ((Rs & 31) != 15 && (Rs & 31) != 17) Rs++;
+        return rows < HV_CHI2INV95_N && na4 * nrp <= VuRecLds<MAXP_REC>::HS_DOUBLES && Rs * rows <= VuRecLds<MAXP_REC>::T_DOUBLES &&
+               c->knob.ekf_fused_gate != 0 && np_sel >= 2;
+    }
+    return fused == 3 && c->knob.ekf_split_tri != 3;        // (3: experiments -- the short class only, the long class keeps r05's fused launch)
 }
 
 int launch_vu_tri(Ctx *c, const VuPrepareArgs &a, hipStream_t stream)
@@ -1708,7 +1724,7 @@ int launch_vu_tri(Ctx *c, const VuPrepareArgs &a, hipStream_t stream)
     const int forced = c->knob.vu_tri_threads;
     // auto: four wavefronts per track where the launch may hold long tracks (their chain sets the length of the visit), two for the short
     // class (profiles/r06/split_tri_ab_v2.txt: 4 lanes 27.90 ms per step with 128 threads, 28.12 with 64, 28.2 with 256)
-    const int nthr = forced == 64 || forced == 128 || forced == 256 ? forced : (np_sel * ncam > MAXP_SMALL ? 256 : 128);
+    const int nthr = forced == 64 || forced == 128 || forced == 256 ? forced : (np_sel * ncam > MAXP_REC ? 256 : 128);
     if (nthr == 256)      hipLaunchKernelGGL(vu_tri_kernel_x4, dim3((unsigned)a.batch), dim3(256), bytes, stream, a);
     else if (nthr == 128) hipLaunchKernelGGL(vu_tri_kernel_x2, dim3((unsigned)a.batch), dim3(128), bytes, stream, a);
     else                  hipLaunchKernelGGL(vu_tri_kernel, dim3((unsigned)a.batch), dim3(64), bytes, stream, a);
@@ -1758,7 +1774,7 @@ int launch_vu_prepare(Ctx *c, const VuPrepareArgs &a, hipStream_t stream)
             HV_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void *>(vu_gate_long_rec_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, rec_long_attr));
             rec_attr = true;
         }
-        constexpr size_t rec_long_bytes = VuRecLds<MAXP_ALL, true>::BYTES, rec_short_bytes = VuRecLds<MAXP_SMALL>::BYTES;
+        constexpr size_t rec_long_bytes = VuRecLds<MAXP_ALL, true>::BYTES, rec_short_bytes = VuRecLds<MAXP_REC>::BYTES;
         if (a.fused == 3) hipLaunchKernelGGL(vu_gate_long_rec_kernel, grid, dim3(VT_LATENCY), rec_long_bytes, stream, a);
         else              hipLaunchKernelGGL(vu_gate_rec_kernel, grid, dim3(VT_REC), rec_short_bytes, stream, a);
         HV_HIP(c, hipGetLastError());

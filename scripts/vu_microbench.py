@@ -77,8 +77,9 @@ def main():
             torch.cuda.synchronize()
             wall = (time.perf_counter() - t0) / 20 * 1e6
             ms1, c1 = ctx.profile_read(capi.K_VU_PREPARE); ms2, c2 = ctx.profile_read(capi.K_EKF_UPDATE); ms3, c3 = ctx.profile_read(capi.K_EKF_GATE)
+            ms4, c4 = ctx.profile_read(capi.K_VU_TRI)
             ctx.profile_enable(False)
-            print(f"visual_track_dev ({name}): {wall:.1f} us per call; prepare(+gate) kernel {ms1 / c1 * 1e3:.1f} us, sparse gate kernel {ms3 / max(c3, 1) * 1e3:.1f} us, update launch {ms2 / c2 * 1e3:.1f} us; "
+            print(f"visual_track_dev ({name}): {wall:.1f} us per call; triangulation front {ms4 / max(c4, 1) * 1e3:.1f} us, prepare(+gate) kernel {ms1 / c1 * 1e3:.1f} us, sparse gate kernel {ms3 / max(c3, 1) * 1e3:.1f} us, update launch {ms2 / c2 * 1e3:.1f} us; "
                   f"gate inliers {int((gs.cpu().numpy() == 0).sum())}/{B}")
             if os.environ.get("HV_EKF_PHASE_STAMPS") == "1" and name == "all rejected" and ms3 > 0:
                 import ctypes as C

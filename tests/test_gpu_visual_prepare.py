@@ -46,6 +46,8 @@ VARIANTS = {
     "split_tri_one_stream": {"ekf_split_tri": 2, "ekf_visit_order": 2, "ekf_side_stream": 0},
     "split_tri_unsorted": {"ekf_split_tri": 2, "ekf_visit_order": 0},
     "fused_front": {"ekf_split_tri": 0},
+    # (the split form's short class ends at 12 stereo poses = 48 rows; 11 = the fused builds' boundary)
+    "split_tri_short11": {"ekf_split_tri": 2, "ekf_visit_order": 2, "ekf_short_np": 11},
 }
 
 
@@ -676,6 +678,8 @@ def test_speculative_frame_loop_under_contention(oracle, variant, npose):
     # r06: the split form (default above one filter per CU) at small batches, on one stream, in filter order; r05's fused kernels behind the knob
     (48, False, True, "split_tri", 21), (48, False, True, "split_tri_one_stream", 21), (48, False, True, "split_tri_unsorted", 21),
     (48, False, True, "split_tri", 10), (300, False, True, "fused_front", 21), (300, False, True, "split_tri_one_stream", 21),
+    # ... the class boundary: 12 poses (48 rows) are the record-fed short gate's longest track, 13 the long class's shortest
+    (48, False, True, "split_tri", 12), (48, False, True, "split_tri", 13), (300, False, True, "split_tri_short11", 21), (300, False, True, "default", 12),
     # r06: the headline's grid -- 1024 distinct ragged filters in one frame loop, every one against the oracle
     (1024, False, True, "default", 21)])
 def test_whole_frame_loop_with_ragged_track_lengths(oracle, B, speculative, stereo, variant, np_max):
