@@ -312,7 +312,7 @@ def sample_track_lengths(rng, size):
     backend.cpp:1194-1206) -- and ~20 fresh ones enter at age 0. Equilibrium: ~20 tracks per age up to the median age of 5, above it
     20 of ~100 eligible tracks are picked per frame, i.e. the cohorts shrink by 0.8 per frame: unused poses = 5 + Geometric(0.2),
     capped by the trail (cameraTrailLength + 1 = 21): mean 8.9 poses, 21 % of the visits see more than 11 poses (> 44 rows in
-    stereo), 3 % the full trail. TrackSampling::GAP adds the oldest pose that holds the track (ekf_state_index.cpp:98-115): the
+    stereo), 17 % more than 12 (the long class of the split form), 3 % the full trail. TrackSampling::GAP adds the oldest pose that holds the track (ekf_state_index.cpp:98-115): the
     returned count includes it."""
     return np.minimum(5 + rng.geometric(0.2, size) - 1, 21).astype(np.int32)
 
@@ -1485,7 +1485,7 @@ class BenchRun:
                                        f"{self.B} distinct filters per engine with per-filter covariances")
         self.tracked3 = self.tb.tracked_fraction()
         self.lens_mean = float(eb.lens_host.mean()); self.long_share = float((eb.lens_host > 11).mean())
-        self.lens_mean = float(eb.lens_host.mean()); self.long_share = float((eb.lens_host > 11).mean())
+        self.long_class_share = float((eb.lens_host > 12).mean())      # (split form, late r06: the short class ends at 12 poses = 48 rows)
         eb.ekf.close()
         del eb
 
@@ -1591,7 +1591,7 @@ class BenchRun:
                                       "from the device's high-priority queue pool; a step replays one captured graph of each, their launch chains fill each "
                                       "other's idle CUs; `one_engine` = the same leg with one context on a torch stream",
                            "parallelism": f"replicas x{self.world} (no collective)",
-                           "track_poses_mean": self.lens_mean, "tracks_longer_than_11_poses": self.long_share, "distinct_filters_per_engine": self.B,
+                           "track_poses_mean": self.lens_mean, "tracks_longer_than_11_poses": self.long_share, "tracks_in_the_long_class": self.long_class_share, "distinct_filters_per_engine": self.B,
                            "parity_ok": self.verify["ok"] if self.verify else None, "parity_checked_sequences": self.verify["parity_checked_sequences"] if self.verify else 0,
                            "parity_engines_checked": self.verify["engines_checked"] if self.verify else 0,
                            "stage_frac_agreed": stage["frac_of_8TBs"], "stage_frac_actual": stage["frac_actual"],
