@@ -18,7 +18,7 @@ const KnobEntry KNOB_TABLE[] = {
     {"ekf_no_speculation", &Knobs::ekf_no_speculation}, {"ekf_stream_gate", &Knobs::ekf_stream_gate},
     {"ekf_gate_kmode", &Knobs::ekf_gate_kmode}, {"ingest_gather", &Knobs::ingest_gather},
     {"ekf_fused_gate", &Knobs::ekf_fused_gate}, {"ekf_spec_mode", &Knobs::ekf_spec_mode},
-    {"rot_ransac_threads", &Knobs::rot_ransac_threads}, {"ekf_side_stream", &Knobs::ekf_side_stream}, {"ekf_dual_update", &Knobs::ekf_dual_update}, {"ekf_long_fused", &Knobs::ekf_long_fused}, {"ekf_long_first", &Knobs::ekf_long_first}, {"ekf_short_np", &Knobs::ekf_short_np}, {"ekf_visit_order", &Knobs::ekf_visit_order},
+    {"rot_ransac_threads", &Knobs::rot_ransac_threads}, {"ekf_side_stream", &Knobs::ekf_side_stream}, {"ekf_dual_update", &Knobs::ekf_dual_update}, {"ekf_long_fused", &Knobs::ekf_long_fused}, {"ekf_long_first", &Knobs::ekf_long_first}, {"ekf_short_np", &Knobs::ekf_short_np}, {"ekf_predict_chain", &Knobs::ekf_predict_chain}, {"ekf_visit_order", &Knobs::ekf_visit_order},
     {"ekf_split_tri", &Knobs::ekf_split_tri}, {"vu_tri_threads", &Knobs::vu_tri_threads},
 };
 }  // namespace

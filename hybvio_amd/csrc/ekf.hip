@@ -375,6 +375,339 @@ __global__ __launch_bounds__(256) void ekf_predict_kernel(PredictArgs a)
 
 
 // ---------------------------------------------------------------------------------------------
+// ekf_predict_chain_kernel (late r06): the same arithmetic as ekf_predict_kernel, element by element and in the same
+// order -- results are bit-identical --, with the sample-to-sample dependency reduced to what really depends: the MEAN. A sample's F and L
+// only read quantities of the mean recursion (A, the old and the new quaternion, R, T xa - ba, dt), so
+//   phase 1  ONE wavefront runs the mean recursion of up to PCH samples back to back -- five short stages per sample that talk through LDS
+//            inside the wave (DS operations of a wave execute in order: a wave-level fence, no workgroup barrier) -- and leaves every
+//            sample's stage values in its own slot;
+//   phase 2  all 256 threads form dR, F and L of ALL those samples at once (four workgroup barriers per chunk instead of nine per sample);
+//   phase 3  the 20 x 20 recursions P00 <- F P00 F' + L Q L', Phi <- F Phi sample by sample (two barriers each), as before.
+// ekf_predict_kernel spent ~5.3 us per sample on nine barrier-separated stages (profiles/r06/predict_pipe_ab.txt); knob ekf_predict_chain 0
+// keeps it.
+constexpr int PCH = 5;                  // samples per chunk (F and L of a chunk stay in LDS: 5 x (400 + 240) doubles)
+__device__ __forceinline__ void wave_sync_lds()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+__global__ __launch_bounds__(256) void ekf_predict_chain_kernel(PredictArgs a)
+{
+    constexpr int SHW = 112;                                  // stage values of one sample (the layout of ekf_predict_kernel's `sh`) ...
+    constexpr int X_DT = 107, X_LIVE = 108, X_VBAA = 109, X_VBGA = 110;   // ... + its dt, whether it runs, the drift variances of Q
+    __shared__ double Fs[PCH * INER * INER], Ls[PCH * INER * QD], Qs[QD * QD], LQ[INER * QD], P00[INER * INER], FP[INER * INER];
+    __shared__ double Phi[INER * INER], PhiN[INER * INER];
+    __shared__ double ms[INER], shs[PCH * SHW], imu[PCH * 8];    // imu: dt, gyro[3], acc[3] of the chunk's samples
+    const int b = blockIdx.x, t = threadIdx.x, n = a.n;
+    double *m = a.m + (size_t)b * n, *P = a.P + (size_t)b * n * n, *Q = a.Q + (size_t)b * QD * QD;
+    bool any = false;
+    for (int s = 0; s < a.nsteps; s++) { const double d = a.dt ? a.dt[(size_t)s * a.batch + b] : a.dt0; any = any || d > 0.0; }
+    if (!any) return;                              // ekf.cpp:365-368 (the host adapter keeps the clock)
+
+    PHASE_STAMP(12);
+    // off-diagonal items: the slabs of the first five items of every wave are requested here (see ekf_predict_kernel)
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6), lane = t & 63, kq = lane >> 4, cl = lane & 15;
+    const int tiles = (n - INER + 15) >> 4;
+    constexpr int NIT = 5;
+    auto slab_ptr = [&](int it, int sx) -> double * {
+        const int k = min(4 * sx + kq, INER - 1);
+        if (it < tiles) return P + (size_t)k * n + min(INER + 16 * it + cl, n - 1);          // P10(i, k): lanes along i
+        return P + (size_t)min(INER + 16 * (it - tiles) + cl, n - 1) * n + k;                // P01(k, c): lanes along c
+    };
+    double slab[NIT][5];
+#pragma unroll
+    for (int u = 0; u < NIT; u++) {
+        const int it = wave + 4 * u;
+        if (it < 2 * tiles) {
+#pragma unroll
+            for (int sx = 0; sx < 5; sx++) slab[u][sx] = *slab_ptr(it, sx);
+        }
+    }
+    for (int i = t; i < INER * INER; i += 256) { Phi[i] = (i % (INER + 1) == 0) ? 1.0 : 0.0; P00[i] = P[(size_t)(i / INER) * n + (i % INER)]; }
+    for (int i = t; i < QD * QD; i += 256) Qs[i] = Q[i];
+    if (t < INER) ms[t] = m[t];
+    __syncthreads();
+
+    double exp_dt = -1.0, e_baa2 = 1.0, e_bga2 = 1.0, e_baa1 = 1.0, e_bga1 = 1.0;     // lane 0 of wave 0 only
+    for (int s0 = 0; s0 < a.nsteps; s0 += PCH) {
+        const int ns = min(PCH, a.nsteps - s0);
+        // the chunk's IMU samples in ONE round trip (requested per sample, every sample's chain started with two dependent global loads)
+        if (t < ns * 8) {
+            const int sl = t >> 3, e = t & 7;
+            const size_t sb = (size_t)(s0 + sl) * a.batch + b;
+            double v = 0.0;
+            if (e == 0) v = a.dt ? a.dt[sb] : a.dt0;
+            else if (e < 4) v = a.gyro ? a.gyro[3 * sb + e - 1] : a.g0[e - 1];
+            else if (e < 7) v = a.acc ? a.acc[3 * sb + e - 4] : a.a0[e - 4];
+            imu[t] = v;
+        }
+        __syncthreads();
+        // ---- phase 1: the mean recursion of the chunk's samples (ekf.cpp:370-503, the entries of the mean), wave 0 ----
+        if (wave == 0) {
+            for (int sl = 0; sl < ns; sl++) {
+                double *const sh = shs + sl * SHW;
+                double *const sA = sh, *const sSrow = sh + 16, *const sqn = sh + 32, *const sprevQ = sh + 36, *const sR = sh + 40,
+                       *const sTxab = sh + 85, *const sxa = sh + 100, *const ssc = sh + 103;
+                const double dt = imu[8 * sl];
+                if (t == 0) { sh[X_DT] = dt; sh[X_LIVE] = dt > 0.0 ? 1.0 : 0.0; }
+                if (!(dt > 0.0)) continue;                     // uniform
+                if (t == 0) {
+                    double xg[3];
+                    for (int i = 0; i < 3; i++) { xg[i] = imu[8 * sl + 1 + i]; sxa[i] = imu[8 * sl + 4 + i]; }
+                    if (dt != exp_dt) {
+                        exp_dt = dt;
+                        e_baa2 = a.baa_rev > 0.0 ? (1 - exp(-2 * dt * a.baa_rev)) / (2 * a.baa_rev) : 1.0;
+                        e_bga2 = a.bga_rev > 0.0 ? (1 - exp(-2 * dt * a.bga_rev)) / (2 * a.bga_rev) : 1.0;
+                        e_baa1 = exp(-dt * a.baa_rev); e_bga1 = exp(-dt * a.bga_rev);
+                    }
+                    ssc[2] = e_baa1; ssc[3] = e_bga1;
+                    if (a.baa > 0.0) { double v = a.noise_scale * a.baa * a.baa; if (a.baa_rev > 0.0) v *= e_baa2; sh[X_VBAA] = v; }   // ekf.cpp:397-404
+                    if (a.bga > 0.0) { double v = a.noise_scale * a.bga * a.bga; if (a.bga_rev > 0.0) v *= e_bga2; sh[X_VBGA] = v; }   // ekf.cpp:405-412
+                    // A = exp(-dt/2 Omega(w)) = cos(th) I + sin(th)/th S, th = |w| dt/2   (ekf.cpp:415-425)
+                    const double w[3] = { xg[0] - ms[BGA], xg[1] - ms[BGA + 1], xg[2] - ms[BGA + 2] };
+                    const double Srow[16] = { 0, -w[0], -w[1], -w[2],  w[0], 0, -w[2], w[1],  w[1], w[2], 0, -w[0],  w[2], -w[1], w[0], 0 };
+#pragma unroll
+                    for (int i = 0; i < 16; i++) sSrow[i] = Srow[i];
+                    const double th = sqrt(w[0]*w[0] + w[1]*w[1] + w[2]*w[2]) * dt / 2;
+                    ssc[0] = cos(th); ssc[1] = th > 1e-8 ? sin(th) / th : 1.0 - th * th / 6.0;
+                }
+                wave_sync_lds();
+                {   // stage B: A (column-major 4x4), the previous quaternion, T xa - ba, the position
+                    const double c = ssc[0], sc = ssc[1];
+                    if (t < 16) { const int i = t & 3, j = t >> 2; sA[4 * j + i] = sc * sSrow[4 * i + j] * (-dt / 2) + (i == j ? c : 0.0); }
+                    else if (t < 20) sprevQ[t - 16] = ms[ORI + t - 16];
+                    else if (t >= 32 && t < 35) { const int i = t - 32; sTxab[i] = ms[BAT + i] * sxa[i] - ms[BAA + i]; }
+                    else if (t >= 40 && t < 43) { const int i = t - 40; ms[POS + i] += ms[VEL + i] * dt; }
+                }
+                wave_sync_lds();
+                if (t < 4) { double s_ = 0; for (int j = 0; j < 4; j++) s_ += sA[4 * j + t] * sprevQ[j]; sqn[t] = s_; }
+                wave_sync_lds();
+                if (t < 9) {   // stage D, the part the mean needs: R(q) (util.cpp:10-47, column-major)
+                    const double q0 = sqn[0], q1 = sqn[1], q2 = sqn[2], q3 = sqn[3];
+                    const int i = t / 3, j = t - 3 * i;                 // Rr[3 i + j] -> R[3 j + i]
+                    double v;
+                    switch (t) {
+                        case 0: v = q0*q0+q1*q1-q2*q2-q3*q3; break;
+                        case 1: v = 2*q1*q2 - 2*q0*q3; break;
+                        case 2: v = 2*q1*q3 + 2*q0*q2; break;
+                        case 3: v = 2*q1*q2 + 2*q0*q3; break;
+                        case 4: v = q0*q0-q1*q1+q2*q2-q3*q3; break;
+                        case 5: v = 2*q2*q3 - 2*q0*q1; break;
+                        case 6: v = 2*q1*q3 - 2*q0*q2; break;
+                        case 7: v = 2*q2*q3 + 2*q0*q1; break;
+                        default: v = q0*q0-q1*q1-q2*q2+q3*q3; break;
+                    }
+                    sR[3 * j + i] = v;
+                }
+                wave_sync_lds();
+                {   // stage E, the entries of the mean
+                    if (t < 3) {
+                        const int i = t;
+                        const double grav = i == 2 ? -a.gravity : 0.0;
+                        double s_ = 0; for (int j = 0; j < 3; j++) s_ += sR[3 * i + j] * sTxab[j];
+                        ms[VEL + i] += (s_ + grav) * dt;
+                    } else if (t >= 4 && t < 8) ms[ORI + t - 4] = sqn[t - 4];
+                    else if (t >= 8 && t < 11) { if (a.baa > 0.0) ms[BAA + t - 8] *= ssc[2]; }
+                    else if (t >= 12 && t < 15) { if (a.bga > 0.0) ms[BGA + t - 12] *= ssc[3]; }
+                }
+                wave_sync_lds();
+            }
+        }
+        __syncthreads();
+        PHASE_STAMP(13);
+        // ---- phase 2: dR, F and L of every live sample of the chunk, one element per lane and pass, the reference's expressions ----
+        for (int i = t; i < ns * INER * INER; i += 256) Fs[i] = ((i % (INER * INER)) % (INER + 1) == 0) ? 1.0 : 0.0;
+        for (int i = t; i < ns * INER * QD; i += 256) Ls[i] = 0.0;
+        for (int w = t; w < ns * 36; w += 256) {                        // stage D: dR / dq
+            const int sl = w / 36, e = w - 36 * sl;
+            double *const sh = shs + sl * SHW;
+            if (sh[X_LIVE] == 0.0) continue;
+            const double q0 = sh[32], q1 = sh[33], q2 = sh[34], q3 = sh[35];
+            const int k = e / 9, ij = e - 9 * k, i = ij / 3, j = ij - 3 * i;
+            constexpr unsigned char IDX[4][9] = { {0,3,2, 3,0,1, 2,1,0}, {1,2,3, 2,1,0, 3,0,1}, {2,1,0, 1,2,3, 0,3,2}, {3,0,1, 0,3,2, 1,2,3} };
+            constexpr signed char SGN[4][9] = { {1,-1,1, 1,1,-1, -1,1,1}, {1,1,1, 1,-1,-1, 1,1,-1}, {-1,1,1, 1,1,1, -1,1,-1}, {-1,-1,1, 1,-1,1, 1,1,1} };
+            const int id = IDX[k][ij];
+            const double qv = id == 0 ? q0 : id == 1 ? q1 : id == 2 ? q2 : q3;
+            sh[49 + 9 * k + 3 * j + i] = SGN[k][ij] > 0 ? 2 * qv : -2 * qv;
+        }
+        __syncthreads();
+        for (int w = t; w < ns * 64; w += 256) {                        // stage E: the entries of F and L that depend on R, dR, A only
+            const int sl = w >> 6, tt = w & 63;
+            double *const sh = shs + sl * SHW;
+            if (sh[X_LIVE] == 0.0) continue;
+            double *const F = Fs + sl * INER * INER, *const Lm = Ls + sl * INER * QD;
+            const double *const sA = sh, *const sprevQ = sh + 36, *const sR = sh + 40, *const sdR = sh + 49, *const sTxab = sh + 85, *const sxa = sh + 100;
+            double *const sT34 = sh + 88;
+            const double dt = sh[X_DT];
+            if (tt < 3) {
+                const int i = tt;
+                F_(POS + i, VEL + i) = dt;
+                L_(BGA + i, Q_BGA_DRIFT + i) = 1.0; L_(BAA + i, Q_BAA_DRIFT + i) = 1.0;
+            } else if (tt >= 4 && tt < 16) {
+                const int e = tt - 4, k = e / 3, i = e - 3 * k;
+                double s_ = 0; for (int j = 0; j < 3; j++) s_ += sdR[9 * k + 3 * i + j] * sTxab[j];
+                sT34[3 * k + i] = s_ * dt;
+            } else if (tt >= 16 && tt < 28) {
+                const int e = tt - 16, g = e >> 2, i = e & 3;
+                const double h = dt / 2;
+                const double dS[3][16] = {
+                    { 0, h, 0, 0,  -h, 0, 0, 0,  0, 0, 0, h,  0, 0, -h, 0 },
+                    { 0, 0, h, 0,  0, 0, 0, -h,  -h, 0, 0, 0,  0, h, 0, 0 },
+                    { 0, 0, 0, h,  0, 0, h, 0,  0, -h, 0, 0,  -h, 0, 0, 0 } };
+                double t1[4];
+#pragma unroll
+                for (int ii = 0; ii < 4; ii++) {
+                    double s_ = 0;
+#pragma unroll
+                    for (int j = 0; j < 4; j++) { const double d = g == 0 ? dS[0][4 * ii + j] : g == 1 ? dS[1][4 * ii + j] : dS[2][4 * ii + j]; s_ += d * sprevQ[j]; }
+                    t1[ii] = s_;
+                }
+                double s_ = 0;
+#pragma unroll
+                for (int j = 0; j < 4; j++) s_ += sA[4 * j + i] * t1[j];
+                L_(ORI + i, Q_GYRO + g) = s_;
+            } else if (tt >= 28 && tt < 37) {
+                const int e = tt - 28, i = e / 3, j = e - 3 * i;
+                L_(VEL + i, Q_ACC + j) = sR[3 * i + j] * dt;
+                F_(VEL + i, BAA + j) = -sR[3 * i + j] * dt; F_(VEL + i, BAT + j) = sR[3 * i + j] * sxa[j] * dt;
+            } else if (tt >= 40 && tt < 56) {
+                const int e = tt - 40, i = e & 3, j = e >> 2;
+                F_(ORI + i, ORI + j) = sA[4 * j + i];
+            }
+        }
+        __syncthreads();
+        for (int w = t; w < ns * 12; w += 256) {
+            const int sl = w / 12, tt = w - 12 * sl;
+            double *const sh = shs + sl * SHW;
+            if (sh[X_LIVE] == 0.0) continue;
+            double *const F = Fs + sl * INER * INER;
+            const double *const sA = sh, *const sT34 = sh + 88;
+            const int i = tt / 4, j = tt - 4 * i;
+            double s_ = 0; for (int k = 0; k < 4; k++) s_ += sT34[3 * k + i] * sA[4 * j + k];
+            F_(VEL + i, ORI + j) = s_;
+        }
+        __syncthreads();
+        for (int w = t; w < ns * 32; w += 256) {
+            const int sl = w >> 5, tt = w & 31;
+            double *const sh = shs + sl * SHW;
+            if (sh[X_LIVE] == 0.0) continue;
+            double *const F = Fs + sl * INER * INER, *const Lm = Ls + sl * INER * QD;
+            if (tt < 9) {
+                const int i = tt / 3, g = tt - 3 * i;
+                double s_ = 0; for (int k = 0; k < 4; k++) s_ += F_(VEL + i, ORI + k) * L_(ORI + k, Q_GYRO + g);
+                L_(VEL + i, Q_GYRO + g) = s_;
+                F_(VEL + i, BGA + g) = -s_;
+            } else if (tt >= 16 && tt < 28) {
+                const int e = tt - 16, i = e / 3, g = e - 3 * i;
+                F_(ORI + i, BGA + g) = -L_(ORI + i, Q_GYRO + g);
+            }
+        }
+        // ---- phase 3: P00 = F P00 F' + L Q L' (ekf.cpp:504-505), Phi <- F Phi, sample by sample (see ekf_predict_kernel) ----
+        int last_live = -1;
+        bool q_set = false;
+        // the drift variances of Q (ekf.cpp:397-412) of one sample: Qs is read by the first product phase of a sample only
+        auto set_q = [&](const double *sh_q) {
+            if (a.baa > 0.0 && t < 9) { const int i = t % 3, j = t / 3; Qs[(Q_BAA_DRIFT + j) * QD + Q_BAA_DRIFT + i] = (i == j) ? sh_q[X_VBAA] : 0.0; }
+            if (a.bga > 0.0 && t >= 16 && t < 25) { const int e = t - 16, i = e % 3, j = e / 3; Qs[(Q_BGA_DRIFT + j) * QD + Q_BGA_DRIFT + i] = (i == j) ? sh_q[X_VBGA] : 0.0; }
+        };
+        for (int sl = 0; sl < ns; sl++) {
+            double *const sh = shs + sl * SHW;
+            __syncthreads();                                     // (F, L of the chunk; the previous sample's P00 and Phi)
+            if (sh[X_LIVE] == 0.0) continue;                     // uniform
+            last_live = sl;
+            const double *const F = Fs + sl * INER * INER, *const Lm = Ls + sl * INER * QD;
+            if (!q_set) { set_q(sh); __syncthreads(); }           // (the chunk's first live sample; the others: behind the previous one's middle barrier)
+            q_set = false;
+            const int ti = wave & 1, tj = wave >> 1;                 // output rows 16 ti .., columns 16 tj ..
+            const int mi = ti ? INER - 16 : 16, nj = tj ? INER - 16 : 16;
+            const double4v fp = mfma_tile(F + 16 * ti, 1, INER, mi, P00 + 16 * tj * INER, 1, INER, nj, INER);
+            const double4v ph = mfma_tile(F + 16 * ti, 1, INER, mi, Phi + 16 * tj * INER, 1, INER, nj, INER);
+            double4v lq = {0.0, 0.0, 0.0, 0.0};
+            if (wave < 2) lq = mfma_tile(Lm + 16 * wave, 1, INER, wave ? INER - 16 : 16, Qs, 1, QD, QD, QD);
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const int r = kq + 4 * q;
+                if (r < mi && cl < nj) { FP[(16 * tj + cl) * INER + 16 * ti + r] = fp[q]; PhiN[(16 * tj + cl) * INER + 16 * ti + r] = ph[q]; }
+                if (wave < 2 && r < (wave ? INER - 16 : 16) && cl < QD) LQ[cl * INER + 16 * wave + r] = lq[q];
+            }
+            __syncthreads();
+            {   // the next live sample's Q entries (uniform search)
+                int nx = sl + 1;
+                while (nx < ns && shs[nx * SHW + X_LIVE] == 0.0) nx++;
+                if (nx < ns) { set_q(shs + nx * SHW); q_set = true; }
+            }
+            const double4v p1 = mfma_tile(FP + 16 * ti, 1, INER, mi, F + 16 * tj, INER, 1, nj, INER);
+            const double4v p2 = mfma_tile(LQ + 16 * ti, 1, INER, mi, Lm + 16 * tj, INER, 1, nj, QD);
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const int r = kq + 4 * q;
+                if (r < mi && cl < nj) P00[(16 * tj + cl) * INER + 16 * ti + r] = p1[q] + p2[q];
+            }
+            for (int e = t; e < INER * INER; e += 256) Phi[e] = PhiN[e];
+        }
+        __syncthreads();
+        if (last_live >= 0)                                       // der_predict reads the LAST sample's F (ekf_predict_kernel: F after its loop)
+            for (int i = t; i < INER * INER; i += 256) a.dydx[(size_t)b * INER * INER + i] = Fs[last_live * INER * INER + i];
+        __syncthreads();                                          // (the next chunk overwrites the stage values, F and L)
+    }
+    for (int i = t; i < INER * INER; i += 256) P[(size_t)(i / INER) * n + (i % INER)] = P00[i];
+    for (int i = t; i < QD * QD; i += 256) Q[i] = Qs[i];
+    if (t < INER) m[t] = ms[t];
+    PHASE_STAMP(14);
+    {
+        double f0[5], f1[5];
+#pragma unroll
+        for (int sx = 0; sx < 5; sx++) {
+            const int k = 4 * sx + kq;                                                        // < 20
+            f0[sx] = Phi[k * INER + cl];
+            f1[sx] = Phi[k * INER + min(16 + cl, INER - 1)];
+        }
+        for (int base = 0; base < 2 * tiles; base += 4 * NIT) {
+#pragma unroll
+            for (int u = 0; u < NIT; u++) {
+                const int it = base + wave + 4 * u;
+                if (it < 2 * tiles) {
+                    if (base > 0) {
+#pragma unroll
+                        for (int sx = 0; sx < 5; sx++) slab[u][sx] = *slab_ptr(it, sx);
+                    }
+                    double4v a0 = {0.0, 0.0, 0.0, 0.0}, a1 = a0;
+                    const bool p10 = it < tiles;
+#pragma unroll
+                    for (int sx = 0; sx < 5; sx++) {
+                        const double x0 = p10 ? f0[sx] : slab[u][sx], y0 = p10 ? slab[u][sx] : f0[sx];
+                        const double x1 = p10 ? f1[sx] : slab[u][sx], y1 = p10 ? slab[u][sx] : f1[sx];
+                        a0 = __builtin_amdgcn_mfma_f64_16x16x4f64(x0, y0, a0, 0, 0, 0);
+                        a1 = __builtin_amdgcn_mfma_f64_16x16x4f64(x1, y1, a1, 0, 0, 0);
+                    }
+#pragma unroll
+                    for (int q = 0; q < 4; q++) {
+                        const int rr = kq + 4 * q;                                            // output row within the tile
+                        if (p10) {
+                            const int i = INER + 16 * it + cl;                                // (c = rr [+16], i)
+                            if (i < n) {
+                                P[(size_t)rr * n + i] = a0[q];
+                                if (16 + rr < INER) P[(size_t)(16 + rr) * n + i] = a1[q];
+                            }
+                        } else {
+                            const int c = INER + 16 * (it - tiles) + rr;                      // (c, r = cl [+16])
+                            if (c < n) {
+                                P[(size_t)c * n + cl] = a0[q];
+                                if (16 + cl < INER) P[(size_t)c * n + 16 + cl] = a1[q];
+                            }
+                        }
+                    }
+                }
+            }
+        }
+    }
+    __syncthreads();
+    PHASE_STAMP(15);
+}
+
+// ---------------------------------------------------------------------------------------------
 // update / gate (ekf.cpp:57-82, 760-844)
 // ---------------------------------------------------------------------------------------------
 struct UpdateArgs {
@@ -3164,7 +3497,13 @@ static int predict_common(Ekf *e, const double *dt_dev, const double *gyro_dev, 
     a.baa = e->par.noiseProcessBAA; a.baa_rev = e->par.noiseProcessBAARev;
     a.bga = e->par.noiseProcessBGA; a.bga_rev = e->par.noiseProcessBGARev;
     hv::ScopedKernelTime tm(c, HV_K_EKF_PREDICT);
-    hipLaunchKernelGGL(hv::ekf_predict_kernel, dim3(e->batch), dim3(256), 0, c->stream, a);
+    // knob ekf_predict_chain: 1 (late r06) = launches of three or more samples run ekf_predict_chain_kernel (the mean recursion of the samples
+    // on one wavefront, F / L of a chunk of samples in one pass); 2 = every launch; 0 = never (ekf_predict_kernel: nine barrier-separated
+    // stages per sample). Bit-identical results. Measured (profiles/r06/predict_chain_ab.txt): 10 samples 53.2 -> 50.3 us for one filter,
+    // 139 -> 129 us at 1024 filters; ONE sample 13.4 -> 15.0 us, hence the rule
+    const int chain = c->knob.ekf_predict_chain;
+    if (chain == 2 || (chain == 1 && nsteps >= 3)) hipLaunchKernelGGL(hv::ekf_predict_chain_kernel, dim3(e->batch), dim3(256), 0, c->stream, a);
+    else                                hipLaunchKernelGGL(hv::ekf_predict_kernel, dim3(e->batch), dim3(256), 0, c->stream, a);
     HV_HIP(c, hipGetLastError());
     return HV_OK;
 }

@@ -68,6 +68,7 @@ struct Knobs {
     int ekf_spec_mode = -1;       // HV_EKF_SPEC_MODE: speculative pass form: -1 auto, 2 = gate launch + apply launch, 3 = one launch with hand-shake
     int ekf_side_stream = 6;      // HV_EKF_SIDE_STREAM, ragged visits with two length classes inside a frame loop over more filters than CUs (needs the per-frame sort of launch_visit_order): 0 = one stream; 6 (default of hv_create) = the visit forks: long class's prepare + gate launch on the context stream, short class's fused launch on the context's second stream, joined in front of the update launches (+6 % on the realistic C3 step against 0); 3 = r03's arrangement of the fork (long class on the second stream, enqueued first: 3 % slower than 6 with eager launches, equal under graph replay); 5 (default of the contexts of an hv_lanes set) = 6, but never inside a stream capture (a captured fork is replayed on a default-priority stream of the graph instance, not on the lane's own: ekf.hip). r03's other forms (1, 2, 4: whole long chain on the second stream / enqueued behind) measured slower and were removed in r04
     int ekf_long_fused = 1;       // HV_EKF_LONG_FUSED: 1 (r04 default) = prepare + column-sparse gate of the long class (49 .. 84 rows) in ONE launch (vu_gate_long_kernel); 0 = r03's vu_compact_kernel + ekf_sparse_gate_big_kernel
+    int ekf_predict_chain = 1;    // HV_EKF_PREDICT_CHAIN: 1 (late r06) = launches of >= 3 IMU samples run ekf_predict_chain_kernel (the samples' mean recursion on one wavefront without workgroup barriers, dR / F / L of up to five samples per pass, then the 20 x 20 recursions); 2 = every launch; 0 = ekf_predict_kernel (nine barrier-separated stages per sample). Bit-identical
     int ekf_short_np = 12;        // HV_EKF_SHORT_NP: longest stereo track of the short class where the split form serves the visit: 12 (48 rows, r06 default) or 11 (the fused builds' boundary, r03 .. r05)
     int ekf_long_first = 0;       // HV_EKF_LONG_FIRST: launch order of a ONE-STREAM sorted ragged visit (captured lanes): 0 (r06 default) = short class (triangulation, gate) then long class; 1 = long class first (r04 / r05 default: the fused long launch needed whole CUs); 2 .. 4 = both triangulations in front of both gates (T long, T short, G long, G short / T short, T long, G short, G long / T long, T short, G short, G long). Four lanes: 27.37 ms per step with 0 against 27.57 with 1, the others in between (profiles/r06/visit_launch_order_sweep.txt)
     int ekf_dual_update = 1;      // HV_EKF_DUAL_UPDATE: 1 = ragged visits issue the short class's update and the long class's first block update as one grid (ekf_update_dual_kernel); 0 = one after the other

@@ -120,6 +120,35 @@ def test_predict_n_samples_in_one_launch(oracle, ctx):
         np.testing.assert_allclose(g.get_dydx(0), os_[0].dydx, rtol=1e-12, atol=1e-14)
 
 
+@pytest.mark.parametrize("B,nS,trail", [(1, 10, 20), (3, 7, 20), (3, 12, 5), (300, 10, 20), (2, 1, 20)])
+def test_predict_kernel_forms_agree_to_the_bit(oracle, ctx, B, nS, trail):
+    """ekf_predict_chain_kernel (knob 2: every launch; default 1: launches of three or more samples -- the samples' mean recursion on one wavefront, F / L of up to five samples per pass) against
+    ekf_predict_kernel (knob ekf_predict_chain 0: nine barrier-separated stages per sample): the same expressions in the same order --
+    mean, covariance and dydx identical to the bit, with skipped samples (dt <= 0), a sample that changes dt, more samples than a chunk."""
+    import torch
+    rng = np.random.default_rng(1000 * B + nS)
+    os_, g = make_pair(oracle, ctx, rng, batch=B, trail=trail)
+    dt = np.full((nS, B), 0.005)
+    if nS > 4:
+        dt[4, B // 2] = 0.0; dt[nS - 2, :] = 0.0025; dt[nS - 1, 0] = 0.0
+    gy = rng.normal(0, 0.05, (nS, B, 3)); ac = rng.normal(0, 0.05, (nS, B, 3)) + [0.1, -0.2, 9.8]
+    d_dt, d_gy, d_ac = (torch.from_numpy(x).cuda() for x in (dt, gy, ac))
+    states = [g.get_state(b) for b in range(B)]
+    out = {}
+    for form in (2, 0):
+        for b in range(B):
+            g.set_state(b, *states[b])
+        ctx.set_knob("ekf_predict_chain", form)
+        assert ctx.get_knob("ekf_predict_chain") == form
+        g.predict_n_dev(nS, d_dt.data_ptr(), d_gy.data_ptr(), d_ac.data_ptr())
+        out[form] = ([g.get_state(b) for b in range(0, B, max(1, B // 7))], g.get_dydx(0).copy(), g.get_dydx(B - 1).copy())
+    ctx.set_knob("ekf_predict_chain", 1)
+    for (m1, P1), (m0, P0) in zip(out[2][0], out[0][0]):
+        assert np.array_equal(m1, m0) and np.array_equal(P1, P0)
+    assert np.array_equal(out[2][1], out[0][1]) and np.array_equal(out[2][2], out[0][2])
+    assert np.isfinite(out[2][0][0][1]).all() and not np.array_equal(out[2][0][0][1], states[0][1])
+
+
 def test_reference_der_predict_on_gpu(oracle, ctx):
     """test/ekf.cpp:73-117 run against the HIP predict: analytic dydx vs forward differences < 1e-3."""
     fx = np.load(GOLD)
