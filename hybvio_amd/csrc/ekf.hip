@@ -92,10 +92,58 @@ __device__ void quat2rmat_d(const double q[4], double R[9], double dR[36])   // 
     for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) R[3 * j + i] = Rr[3 * i + j];
 }
 
+// cos(th) and sin(th) / th of the half rotation angle th = |w| dt / 2 >= 0 of one IMU sample (ekf.cpp:415-425). Below 0.25 rad -- 100 rad/s at
+// dt = 5 ms; every sample a camera rig produces -- both are Taylor polynomials in th^2 up to th^16 / th^17 (remainder < 1e-26), two Horner
+// chains side by side on the one lane that owns the mean's serial section, instead of the device library's cos() and sin() with their
+// argument reduction and a division (~1.1 k of a sample's ~2.9 k cycles, late r06). Within an ulp of the library's values; the
+// reference's own branch for th <= 1e-8 is kept as it is.
+__device__ __forceinline__ void cos_sinc(double th, double &c, double &sc)
+{
+    if (th < 0.25) {
+        const double x = th * th;
+        double pc = 1.0 / 20922789888000.0, ps = -1.0 / 355687428096000.0;     // 1 / 16!, -1 / 17!
+        pc = pc * x - 1.0 / 87178291200.0;   ps = ps * x + 1.0 / 1307674368000.0;   // -1 / 14!, 1 / 15!
+        pc = pc * x + 1.0 / 479001600.0;     ps = ps * x - 1.0 / 6227020800.0;      //  1 / 12!, -1 / 13!
+        pc = pc * x - 1.0 / 3628800.0;       ps = ps * x + 1.0 / 39916800.0;        // -1 / 10!, 1 / 11!
+        pc = pc * x + 1.0 / 40320.0;         ps = ps * x - 1.0 / 362880.0;          //  1 / 8!, -1 / 9!
+        pc = pc * x - 1.0 / 720.0;           ps = ps * x + 1.0 / 5040.0;            // -1 / 6!, 1 / 7!
+        pc = pc * x + 1.0 / 24.0;            ps = ps * x - 1.0 / 120.0;             //  1 / 4!, -1 / 5!
+        pc = pc * x - 0.5;                   ps = ps * x + 1.0 / 6.0;               // -1 / 2!, 1 / 3!
+        c = pc * x + 1.0;
+        sc = th > 1e-8 ? 1.0 - ps * x : 1.0 - th * th / 6.0;
+    } else {
+        c = cos(th); sc = sin(th) / th;
+    }
+}
+
+// entry t = 3 i + j of Rr(q) (util.cpp:10-47), for the lane that owns it: two code paths -- the diagonal's four squares, the off-diagonal's
+// two products -- with the operands selected per lane (a `switch` over the nine entries ran its cases one after the other: ~890 cycles of a
+// sample's mean recursion, late r06). Shared by both predict kernels, so that they contract to the same FMAs.
+__device__ __forceinline__ double quat_rotation_entry(int t, const double *sqn)
+{
+    const double qq[4] = {sqn[0], sqn[1], sqn[2], sqn[3]};
+    const int i = t / 3, j = t - 3 * i;
+    if (i == j) {                                           // q0^2 + s1 q1^2 + s2 q2^2 + s3 q3^2, signs (+ - -), (- + -), (- - +)
+        const double a1 = qq[1] * qq[1], a2 = qq[2] * qq[2], a3 = qq[3] * qq[3];
+        double acc = qq[0] * qq[0];
+        acc = i == 0 ? acc + a1 : acc - a1;
+        acc = i == 1 ? acc + a2 : acc - a2;
+        acc = i == 2 ? acc + a3 : acc - a3;
+        return acc;
+    }
+    // Rr: (0,1) 2q1q2 - 2q0q3, (0,2) 2q1q3 + 2q0q2, (1,0) 2q1q2 + 2q0q3, (1,2) 2q2q3 - 2q0q1, (2,0) 2q1q3 - 2q0q2, (2,1) 2q2q3 + 2q0q1
+    const int ia = i + 1, ib = j + 1, ic = 6 - ia - ib;
+    const int lo = ia < ib ? ia : ib, hi = ia < ib ? ib : ia;
+    const double p = 2 * qq[lo] * qq[hi], r = 2 * qq[0] * qq[ic];
+    const bool plus = (i == 0 && j == 2) || (i == 1 && j == 0) || (i == 2 && j == 1);
+    return plus ? p + r : p - r;
+}
+
 #define F_(i, j) F[(j) * INER + (i)]
 #define L_(i, j) Lm[(j) * INER + (i)]
 
-__global__ __launch_bounds__(256) void ekf_predict_kernel(PredictArgs a)
+// (two workgroups per CU: 256 registers per lane)
+__global__ __launch_bounds__(256, 2) void ekf_predict_kernel(PredictArgs a)
 {
     __shared__ double F[INER * INER], Lm[INER * QD], Qs[QD * QD], LQ[INER * QD], P00[INER * INER], FP[INER * INER];
     __shared__ double Phi[INER * INER], PhiN[INER * INER];
@@ -180,7 +228,7 @@ __global__ __launch_bounds__(256) void ekf_predict_kernel(PredictArgs a)
 #pragma unroll
         for (int i = 0; i < 16; i++) sSrow[i] = Srow[i];
         const double th = sqrt(w[0]*w[0] + w[1]*w[1] + w[2]*w[2]) * dt / 2;
-        ssc[0] = cos(th); ssc[1] = th > 1e-8 ? sin(th) / th : 1.0 - th * th / 6.0;
+        cos_sinc(th, ssc[0], ssc[1]);
     }
     __syncthreads();
     {   // stage B: A (column-major 4x4), the previous quaternion, T xa - ba, the position
@@ -197,18 +245,7 @@ __global__ __launch_bounds__(256) void ekf_predict_kernel(PredictArgs a)
         const double q0 = sqn[0], q1 = sqn[1], q2 = sqn[2], q3 = sqn[3];
         if (t < 9) {
             const int i = t / 3, j = t - 3 * i;                 // Rr[3 i + j] -> R[3 j + i]
-            double v;
-            switch (t) {
-                case 0: v = q0*q0+q1*q1-q2*q2-q3*q3; break;
-                case 1: v = 2*q1*q2 - 2*q0*q3; break;
-                case 2: v = 2*q1*q3 + 2*q0*q2; break;
-                case 3: v = 2*q1*q2 + 2*q0*q3; break;
-                case 4: v = q0*q0-q1*q1+q2*q2-q3*q3; break;
-                case 5: v = 2*q2*q3 - 2*q0*q1; break;
-                case 6: v = 2*q1*q3 - 2*q0*q2; break;
-                case 7: v = 2*q2*q3 + 2*q0*q1; break;
-                default: v = q0*q0-q1*q1-q2*q2+q3*q3; break;
-            }
+            const double v = quat_rotation_entry(t, sqn);
             sR[3 * j + i] = v;
         } else if (t >= 64 && t < 100) {
             // rows[k][3 i + j] = sign * 2 q[idx]: two bits of index and one of sign per entry
@@ -393,7 +430,7 @@ __device__ __forceinline__ void wave_sync_lds()
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-__global__ __launch_bounds__(256) void ekf_predict_chain_kernel(PredictArgs a)
+__global__ __launch_bounds__(256, 2) void ekf_predict_chain_kernel(PredictArgs a)
 {
     constexpr int SHW = 112;                                  // stage values of one sample (the layout of ekf_predict_kernel's `sh`) ...
     constexpr int X_DT = 107, X_LIVE = 108, X_VBAA = 109, X_VBGA = 110;   // ... + its dt, whether it runs, the drift variances of Q
@@ -453,6 +490,7 @@ __global__ __launch_bounds__(256) void ekf_predict_chain_kernel(PredictArgs a)
                 const double dt = imu[8 * sl];
                 if (t == 0) { sh[X_DT] = dt; sh[X_LIVE] = dt > 0.0 ? 1.0 : 0.0; }
                 if (!(dt > 0.0)) continue;                     // uniform
+                if (s0 == 0 && sl == 0) PHASE_STAMP(0);
                 if (t == 0) {
                     double xg[3];
                     for (int i = 0; i < 3; i++) { xg[i] = imu[8 * sl + 1 + i]; sxa[i] = imu[8 * sl + 4 + i]; }
@@ -471,9 +509,10 @@ __global__ __launch_bounds__(256) void ekf_predict_chain_kernel(PredictArgs a)
 #pragma unroll
                     for (int i = 0; i < 16; i++) sSrow[i] = Srow[i];
                     const double th = sqrt(w[0]*w[0] + w[1]*w[1] + w[2]*w[2]) * dt / 2;
-                    ssc[0] = cos(th); ssc[1] = th > 1e-8 ? sin(th) / th : 1.0 - th * th / 6.0;
+                    cos_sinc(th, ssc[0], ssc[1]);
                 }
                 wave_sync_lds();
+                if (s0 == 0 && sl == 0) PHASE_STAMP(1);
                 {   // stage B: A (column-major 4x4), the previous quaternion, T xa - ba, the position
                     const double c = ssc[0], sc = ssc[1];
                     if (t < 16) { const int i = t & 3, j = t >> 2; sA[4 * j + i] = sc * sSrow[4 * i + j] * (-dt / 2) + (i == j ? c : 0.0); }
@@ -482,26 +521,16 @@ __global__ __launch_bounds__(256) void ekf_predict_chain_kernel(PredictArgs a)
                     else if (t >= 40 && t < 43) { const int i = t - 40; ms[POS + i] += ms[VEL + i] * dt; }
                 }
                 wave_sync_lds();
+                if (s0 == 0 && sl == 0) PHASE_STAMP(2);
                 if (t < 4) { double s_ = 0; for (int j = 0; j < 4; j++) s_ += sA[4 * j + t] * sprevQ[j]; sqn[t] = s_; }
                 wave_sync_lds();
+                if (s0 == 0 && sl == 0) PHASE_STAMP(3);
                 if (t < 9) {   // stage D, the part the mean needs: R(q) (util.cpp:10-47, column-major)
-                    const double q0 = sqn[0], q1 = sqn[1], q2 = sqn[2], q3 = sqn[3];
                     const int i = t / 3, j = t - 3 * i;                 // Rr[3 i + j] -> R[3 j + i]
-                    double v;
-                    switch (t) {
-                        case 0: v = q0*q0+q1*q1-q2*q2-q3*q3; break;
-                        case 1: v = 2*q1*q2 - 2*q0*q3; break;
-                        case 2: v = 2*q1*q3 + 2*q0*q2; break;
-                        case 3: v = 2*q1*q2 + 2*q0*q3; break;
-                        case 4: v = q0*q0-q1*q1+q2*q2-q3*q3; break;
-                        case 5: v = 2*q2*q3 - 2*q0*q1; break;
-                        case 6: v = 2*q1*q3 - 2*q0*q2; break;
-                        case 7: v = 2*q2*q3 + 2*q0*q1; break;
-                        default: v = q0*q0-q1*q1-q2*q2+q3*q3; break;
-                    }
-                    sR[3 * j + i] = v;
+                    sR[3 * j + i] = quat_rotation_entry(t, sqn);
                 }
                 wave_sync_lds();
+                if (s0 == 0 && sl == 0) PHASE_STAMP(4);
                 {   // stage E, the entries of the mean
                     if (t < 3) {
                         const int i = t;
@@ -513,6 +542,7 @@ __global__ __launch_bounds__(256) void ekf_predict_chain_kernel(PredictArgs a)
                     else if (t >= 12 && t < 15) { if (a.bga > 0.0) ms[BGA + t - 12] *= ssc[3]; }
                 }
                 wave_sync_lds();
+                if (s0 == 0 && sl == 0) PHASE_STAMP(5);
             }
         }
         __syncthreads();
@@ -604,6 +634,7 @@ __global__ __launch_bounds__(256) void ekf_predict_chain_kernel(PredictArgs a)
                 F_(ORI + i, BGA + g) = -L_(ORI + i, Q_GYRO + g);
             }
         }
+        if (s0 == 0) PHASE_STAMP(6);
         // ---- phase 3: P00 = F P00 F' + L Q L' (ekf.cpp:504-505), Phi <- F Phi, sample by sample (see ekf_predict_kernel) ----
         int last_live = -1;
         bool q_set = false;
@@ -620,34 +651,39 @@ __global__ __launch_bounds__(256) void ekf_predict_chain_kernel(PredictArgs a)
             const double *const F = Fs + sl * INER * INER, *const Lm = Ls + sl * INER * QD;
             if (!q_set) { set_q(sh); __syncthreads(); }           // (the chunk's first live sample; the others: behind the previous one's middle barrier)
             q_set = false;
+            if (s0 == 0 && sl == 1) PHASE_STAMP(7);
             const int ti = wave & 1, tj = wave >> 1;                 // output rows 16 ti .., columns 16 tj ..
             const int mi = ti ? INER - 16 : 16, nj = tj ? INER - 16 : 16;
-            const double4v fp = mfma_tile(F + 16 * ti, 1, INER, mi, P00 + 16 * tj * INER, 1, INER, nj, INER);
-            const double4v ph = mfma_tile(F + 16 * ti, 1, INER, mi, Phi + 16 * tj * INER, 1, INER, nj, INER);
+            const double4v fp = mfma_tile<5>(F + 16 * ti, 1, INER, mi, P00 + 16 * tj * INER, 1, INER, nj, INER);
+            const double4v ph = mfma_tile<5>(F + 16 * ti, 1, INER, mi, Phi + 16 * tj * INER, 1, INER, nj, INER);
             double4v lq = {0.0, 0.0, 0.0, 0.0};
-            if (wave < 2) lq = mfma_tile(Lm + 16 * wave, 1, INER, wave ? INER - 16 : 16, Qs, 1, QD, QD, QD);
+            if (wave < 2) lq = mfma_tile<3>(Lm + 16 * wave, 1, INER, wave ? INER - 16 : 16, Qs, 1, QD, QD, QD);
 #pragma unroll
             for (int q = 0; q < 4; q++) {
                 const int r = kq + 4 * q;
                 if (r < mi && cl < nj) { FP[(16 * tj + cl) * INER + 16 * ti + r] = fp[q]; PhiN[(16 * tj + cl) * INER + 16 * ti + r] = ph[q]; }
                 if (wave < 2 && r < (wave ? INER - 16 : 16) && cl < QD) LQ[cl * INER + 16 * wave + r] = lq[q];
             }
+            if (s0 == 0 && sl == 1) PHASE_STAMP(8);
             __syncthreads();
+            if (s0 == 0 && sl == 1) PHASE_STAMP(9);
             {   // the next live sample's Q entries (uniform search)
                 int nx = sl + 1;
                 while (nx < ns && shs[nx * SHW + X_LIVE] == 0.0) nx++;
                 if (nx < ns) { set_q(shs + nx * SHW); q_set = true; }
             }
-            const double4v p1 = mfma_tile(FP + 16 * ti, 1, INER, mi, F + 16 * tj, INER, 1, nj, INER);
-            const double4v p2 = mfma_tile(LQ + 16 * ti, 1, INER, mi, Lm + 16 * tj, INER, 1, nj, QD);
+            const double4v p1 = mfma_tile<5>(FP + 16 * ti, 1, INER, mi, F + 16 * tj, INER, 1, nj, INER);
+            const double4v p2 = mfma_tile<3>(LQ + 16 * ti, 1, INER, mi, Lm + 16 * tj, INER, 1, nj, QD);
 #pragma unroll
             for (int q = 0; q < 4; q++) {
                 const int r = kq + 4 * q;
                 if (r < mi && cl < nj) P00[(16 * tj + cl) * INER + 16 * ti + r] = p1[q] + p2[q];
             }
             for (int e = t; e < INER * INER; e += 256) Phi[e] = PhiN[e];
+            if (s0 == 0 && sl == 1) PHASE_STAMP(10);
         }
         __syncthreads();
+        if (s0 == 0) PHASE_STAMP(11);
         if (last_live >= 0)                                       // der_predict reads the LAST sample's F (ekf_predict_kernel: F after its loop)
             for (int i = t; i < INER * INER; i += 256) a.dydx[(size_t)b * INER * INER + i] = Fs[last_live * INER * INER + i];
         __syncthreads();                                          // (the next chunk overwrites the stage values, F and L)

@@ -50,6 +50,9 @@ acn = torch.tensor([[[0, 0, 9.8]] * B] * 10, dtype=torch.float64, device="cuda")
 print(f"predict x10 in one launch {bench(lambda: ekf.predict_n_dev(10, dtn.data_ptr(), gyn.data_ptr(), acn.data_ptr())):7.1f} us")
 sp = (C.c_longlong * 16)(); capi.lib().hv_debug_ekf_phase_stamps(ekf._h, sp)
 print("predict phases [serial mean/F/L, P00 block, trailing rows] ticks =", [sp[13]-sp[12], sp[14]-sp[13], sp[15]-sp[14]])
+if sp[5] > sp[0] > 0:
+    print("predict chain kernel, first sample / first chunk (cycles): S0", sp[1]-sp[0], "stage B", sp[2]-sp[1], "q", sp[3]-sp[2], "R", sp[4]-sp[3], "mean entries", sp[5]-sp[4],
+          "| start -> end of F / L", sp[6]-sp[12], "| sample 2: products 1", sp[8]-sp[7], "barrier", sp[9]-sp[8], "products 2 + stores", sp[10]-sp[9], "| chunk's five recursions", sp[11]-sp[6])
 print(f"augment  {bench(lambda: ekf._chk(capi.lib().hv_ekf_augment(ekf._h, None, None), 'aug')):7.1f} us")
 print(f"symmetr  {bench(lambda: ekf.symmetrize()):7.1f} us")
 ekf.close(); ctx.close()
